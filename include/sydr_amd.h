@@ -1,0 +1,245 @@
+/*
+ * sydr_amd.h -- C-ABI of the MI355X (gfx950) GNSS correlator engine.
+ *
+ * This is the drop-in boundary for the one hot path of aproposorg/sydr:
+ * PCPS acquisition, the E/P/L tracking correlators and PRN replica
+ * generation.  It supersedes the reference's legacy native layer
+ * (sydr/c_functions/tracking.c, acquisition.c, loaded through ctypes by
+ * sydr/old/tracking/tracking_epl_c.py:31 and
+ * sydr/old/acquisition/acquisition_pcps_c.py:32) and is what the live NumPy
+ * hot path (sydr/dsp/acquisition.py:9-115, sydr/dsp/tracking.py:92-116,
+ * sydr/signal/gnsssignal.py:9-58) is replaced with.
+ *
+ * Conventions (kept from the reference's ctypes layer):
+ *   - plain C linkage, plain pointers and sizes, caller allocates every output;
+ *   - complex numbers are interleaved (re, im);
+ *   - 2-D arrays are C-contiguous row-major;
+ *   - the library keeps no caller pointer after a call returns.
+ * Added over the reference (which returned void and had no error path):
+ *   - every call returns 0 or a negative sdr_status, text via sdr_last_error();
+ *   - one opaque engine per GPU; calls on one engine are serialised by the caller.
+ *
+ * All arithmetic that decides an INTEGER result (code-chip index, peak
+ * indices) is IEEE fp64 in the reference's operation order.
+ */
+#ifndef SYDR_AMD_H
+#define SYDR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDR_ABI_VERSION 1
+
+typedef struct sdr_engine sdr_engine;
+
+enum sdr_status {
+    SDR_OK = 0,
+    SDR_ERR_INVALID = -1,     /* bad argument                                   */
+    SDR_ERR_HIP = -2,         /* a HIP runtime call failed (text has the cause) */
+    SDR_ERR_NOMEM = -3,       /* host or device allocation failed               */
+    SDR_ERR_UNSUPPORTED = -4, /* size / format not supported by the kernels     */
+    SDR_ERR_RANGE = -5,       /* request reaches outside the IQ ring / code LUT */
+    SDR_ERR_STATE = -6        /* call made before the state it needs exists     */
+};
+
+/* IQ sample formats held in HBM.  ci8 is the reference's file format
+ * (sydr/signal/rfsignal.py:36-37,127-130: interleaved int8 I,Q). */
+enum sdr_iq_format {
+    SDR_FMT_CI8 = 0,  /* int8  I, int8  Q  (2 B / sample) */
+    SDR_FMT_CI16 = 1, /* int16 I, int16 Q  (4 B / sample) */
+    SDR_FMT_CF32 = 2, /* float I, float Q  (8 B / sample) */
+    SDR_FMT_CF64 = 3  /* double I, double Q (16 B / sample) = numpy complex128 */
+};
+
+#define SDR_MAX_TAPS 8
+#define SDR_GPS_L1CA_CHIPS 1023
+
+/* ---------------------------------------------------------------- library */
+const char* sdr_last_error(void);
+int sdr_abi_version(void);
+/* Number of visible GPUs (0 on a CPU-only host; never an error there). */
+int sdr_device_count(int* n);
+
+/* ----------------------------------------------------------------- engine */
+int sdr_engine_create(int device_id, sdr_engine** out);
+void sdr_engine_destroy(sdr_engine* e);
+/* Wait for everything queued on the engine's stream. */
+int sdr_engine_sync(sdr_engine* e);
+/* Per-kernel HIP-event timing.  enable=1 brackets every kernel launch with
+ * hipEvents on the launch stream; sdr_prof_read drains them (it syncs). */
+int sdr_prof_enable(sdr_engine* e, int enable);
+/* Sum/count of launch durations of kernels whose name starts with `prefix`
+ * ("" = all) since the last sdr_prof_reset. */
+int sdr_prof_read(sdr_engine* e, const char* prefix, double* total_ms, int64_t* launches);
+int sdr_prof_reset(sdr_engine* e);
+
+/* ---------------------------------------------------------------- IQ ring
+ * Replaces the host shm ring (sydr/channel/channelManager.py:57-61,
+ * sydr/utils/circularbuffer.py:21-137): capacity_samples slots in HBM,
+ * addressed modulo capacity.  capacity must be a multiple of 8 samples. */
+int sdr_iq_alloc(sdr_engine* e, int64_t capacity_samples, int fmt);
+/* Copy n_samples host samples (in the ring's format) to ring_offset.. ,
+ * wrapping at the end of the ring (CircularBuffer.shift, circularbuffer.py:54-82). */
+int sdr_iq_upload(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset);
+/* Copy ring samples back to the host in the ring's format (tests / oracle). */
+int sdr_iq_download(sdr_engine* e, void* iq, int64_t n_samples, int64_t ring_offset);
+
+/* Synthetic multi-satellite IQ written straight into the ring:
+ *   x[n] = sum_s amp * c_s(chip_s(n)) * d_s(n) * exp(j*2*pi*(doppler_s*n/fs + phase_s)) + CN(0, sigma^2)
+ * rounded and clipped to the ring's integer format.  chip_s(n) =
+ * code_phase_s + n * 1.023e6*(1+doppler_s/1575.42e6)/fs (chips, mod 1023); d_s is a
+ * seeded +-1 sequence changing every 20 code periods.  Deterministic in (seed, n). */
+typedef struct sdr_synth_sat {
+    int32_t prn;        /* GPS PRN 1..210                              */
+    int32_t reserved;
+    double doppler_hz;  /* carrier Doppler                             */
+    double code_phase;  /* chips into the code at ring sample 0        */
+    double carrier_phase; /* cycles at ring sample 0                   */
+    double amplitude;   /* per-axis amplitude in LSB                   */
+} sdr_synth_sat;
+int sdr_iq_synth(sdr_engine* e, const sdr_synth_sat* sats, int n_sats, double fs,
+                 double noise_sigma, uint64_t seed, int64_t first_sample, int64_t n_samples);
+
+/* ------------------------------------------------------------ PRN replicas
+ * Code slots are device-resident +-1 chip tables staged for the correlators.
+ * sdr_code_gps_l1ca generates the C/A Gold code ON DEVICE (G1/G2 LFSRs, G2
+ * delay table) and replaces GenerateGPSGoldCode (sydr/signal/gnsssignal.py:9-31
+ * -> sydr/signal/ca.py:70-112; chip mapping bit 1 -> +1, bit 0 -> -1). */
+int sdr_code_slots(sdr_engine* e, int n_slots, int max_chips);
+int sdr_code_gps_l1ca(sdr_engine* e, int slot, int prn);
+/* Stage an arbitrary +-1 code (e.g. a synthetic 4092-chip E1-like code). */
+int sdr_code_custom(sdr_engine* e, int slot, const int8_t* chips, int n_chips);
+/* Read a staged code back: out_chips[n_chips] in {-1,+1}. */
+int sdr_code_read(sdr_engine* e, int slot, int8_t* out_chips, int max_chips, int* n_chips);
+/* UpsampleCode (sydr/signal/gnsssignal.py:35-58): out[k] = code[trunc((ts*k)/tc)],
+ * k < n_samples = round(fs/1000) for GPS L1 C/A; computed on device. */
+int sdr_code_upsample(sdr_engine* e, int slot, double fs, int64_t n_samples, int8_t* out);
+
+/* ------------------------------------------------ E/P/L tracking correlators
+ * One item = one call of EPL (sydr/dsp/tracking.py:92-116) = one channel-epoch:
+ *   replica_i = exp(1j*(-(carrier_hz*2.0*pi*(i/fs)) + rem_carrier)),  i = 0..n-1
+ *   idx_i     = ceil(linspace(rem_code+spacing, code_step*n+rem_code+spacing, n, endpoint=False))
+ *   I_tap, Q_tap = sum code[idx_i]*Re/Im(replica_i*x_i)
+ * with code the padded table [c[L-1], c[0..L-1], c[0]] (channel_l1ca_kaplan.py:104-107),
+ * extended periodically here so that any tap spacing can be served. */
+typedef struct sdr_epl_item {
+    int32_t code_slot;    /* staged PRN replica                                   */
+    int32_t n_samples;    /* samples in this epoch (track_requiredSamples)        */
+    int64_t start_sample; /* ring index of the first sample (currentSample)       */
+    double carrier_hz;    /* carrierFrequency                                     */
+    double rem_carrier;   /* remainingCarrier [rad]                               */
+    double rem_code;      /* remainingCode [chips]                                */
+    double code_step;     /* codeStep [chips/sample]                              */
+} sdr_epl_item;
+
+/* Synchronous convenience call: out[n_items][2*n_taps] = I,Q per tap, in tap order
+ * (the reference's [IE,QE,IP,QP,IL,QL] for taps (-0.5,0,0.5)). */
+int sdr_epl_batch(sdr_engine* e, const sdr_epl_item* items, int n_items, const double* spacing,
+                  int n_taps, double fs, double* out);
+
+/* Resident plans: items and outputs stay in HBM so a timed region holds only
+ * kernel launches.  run is asynchronous on the engine stream. */
+typedef struct sdr_epl_plan sdr_epl_plan;
+int sdr_epl_plan_create(sdr_engine* e, const sdr_epl_item* items, int n_items,
+                        const double* spacing, int n_taps, double fs, sdr_epl_plan** out);
+int sdr_epl_plan_run(sdr_engine* e, sdr_epl_plan* p);
+/* Launch only items [first, first+count) of the plan (e.g. one second of a long stream). */
+int sdr_epl_plan_run_range(sdr_engine* e, sdr_epl_plan* p, int64_t first, int64_t count);
+int sdr_epl_plan_fetch(sdr_engine* e, sdr_epl_plan* p, double* out); /* syncs */
+void sdr_epl_plan_destroy(sdr_engine* e, sdr_epl_plan* p);
+
+/* --------------------------------------------------------- PCPS acquisition
+ * PCPS (sydr/dsp/acquisition.py:9-74) + TwoCorrelationPeakComparison (:78-115)
+ * for n_prn staged codes over the same ring slice:
+ *   bins = arange(-doppler_range, doppler_range+1, doppler_step)
+ *   map[prn][b][:] = sum_noncoh | sum_coh ifft( fft(x_ms * exp(-1j*(if_hz-bins[b])*k*2*pi/fs)) * conj(fft(code)) ) |
+ * peak_bin/peak_code: first global maximum in row-major order;
+ * peak_ratio: peak / second peak in the same row outside +-samplesPerChip,
+ * never looking at the last code sample (reference behaviour).
+ * corr_map may be NULL (indices and ratio only). n_bins_out (nullable) gets len(bins). */
+int sdr_pcps(sdr_engine* e, const int32_t* code_slots, int n_prn, int64_t start_sample, double fs,
+             double if_hz, double doppler_range, double doppler_step, int coh, int noncoh,
+             int64_t* peak_bin, int64_t* peak_code, double* peak_ratio, double* corr_map,
+             int* n_bins_out);
+/* len(np.arange(-range, range+1, step)) for float range/step. */
+int sdr_pcps_bins(double doppler_range, double doppler_step);
+/* TwoCorrelationPeakComparison alone on a caller-supplied map[n_bins][n_code] (row-major
+ * f64), as the legacy twoCorrelationPeakComparison symbol offered (acquisition.c:181-244);
+ * the search itself runs on the device. */
+int sdr_two_peak_compare(sdr_engine* e, const double* corr_map, int n_bins, int n_code,
+                         int samples_per_chip, int64_t* peak_bin, int64_t* peak_code,
+                         double* peak_ratio);
+
+/* ------------------------------------------------- closed-loop tracking
+ * On-device loop closure: one persistent workgroup per
+ * channel runs n_epochs of correlate -> discriminators -> loop filters -> NCO
+ * update without leaving the GPU.  loop_kind selects the reference plugin whose
+ * arithmetic is followed: 0 = Borre (channel_l1ca_borre.py:333-451),
+ * 1 = Kaplan (channel_l1ca_kaplan.py:342-619). */
+typedef struct sdr_track_state {
+    int32_t code_slot;
+    int32_t n_samples;        /* track_requiredSamples of the NEXT epoch            */
+    int64_t current_sample;   /* currentSample (ring index)                         */
+    double carrier_hz;        /* carrierFrequency                                   */
+    double code_hz;           /* codeFrequency                                      */
+    double rem_carrier;       /* remainingCarrier / NCO_remainingCarrier            */
+    double rem_code;          /* remainingCode / NCO_remainingCode                  */
+    double code_step;         /* codeStep                                           */
+    double dll_mem;           /* Borre: NCO_codeError; Kaplan: dllDiscrim           */
+    double pll_mem;           /* Borre: NCO_carrierError; Kaplan: fll_vel_memory    */
+    double i_prompt_prev;     /* Kaplan iPromptPrev                                 */
+    double q_prompt_prev;     /* Kaplan qPromptPrev                                 */
+    double fll_lock;          /* Kaplan fllLockIndicator                            */
+    double pll_lock;          /* Kaplan pllLockIndicator                            */
+    double cn0;               /* Kaplan cn0 (= dllLockIndicator)                    */
+    double cn0_ratio_acc;     /* Kaplan cn0_PdPnRatio                               */
+    double fll_bw;            /* Kaplan fllBandwidth                                */
+    double pll_bw;            /* Kaplan pllBandwidth                                */
+    int32_t code_counter;     /* codeCounter                                        */
+    int32_t accum_counter;    /* Kaplan correlatorsAccumCounter                     */
+    int32_t lock_state;       /* Kaplan LoopLockState (1 PULL_IN, 2 WIDE, 3 NARROW) */
+    int32_t track_flags;      /* TrackingFlags bit set                              */
+    int32_t time_in_state;    /* Kaplan timeSinceLastState                          */
+    int32_t spacing_sel;      /* Kaplan: 0 = wide taps, 1 = narrow taps             */
+} sdr_track_state;
+
+typedef struct sdr_loop_cfg {
+    int32_t loop_kind;        /* 0 Borre, 1 Kaplan                                  */
+    int32_t n_taps;           /* 3                                                  */
+    double fs;
+    double spacing_wide[SDR_MAX_TAPS];
+    double spacing_narrow[SDR_MAX_TAPS];
+    double dll_tau1, dll_tau2, dll_pdi;
+    double pll_tau1, pll_tau2, pll_pdi;       /* Borre                              */
+    double dll_threshold;                     /* Kaplan                             */
+    double fll_bw_pullin, fll_bw_wide, fll_bw_narrow, fll_thr_wide, fll_thr_narrow;
+    double pll_bw_wide, pll_bw_narrow, pll_thr_wide, pll_thr_narrow;
+} sdr_loop_cfg;
+
+/* Per-epoch record written when traj != NULL (what the reference's tracking
+ * packet carries, channel_l1ca_kaplan.py:653-676, plus the NCO inputs used). */
+typedef struct sdr_track_epoch {
+    int64_t start_sample;
+    int32_t n_samples;
+    int32_t lock_state;
+    double carrier_hz_in, rem_carrier_in, rem_code_in, code_step_in; /* inputs of the epoch */
+    double corr[2 * SDR_MAX_TAPS];
+    double dll, pll, fll;
+    double carrier_err, code_err;
+    double carrier_hz, code_hz;           /* after the update */
+    double cn0, pll_lock, fll_lock;
+    int32_t track_flags;
+    int32_t reserved;
+} sdr_track_epoch;
+
+int sdr_track_closed_loop(sdr_engine* e, int n_ch, sdr_track_state* st, const sdr_loop_cfg* cfg,
+                          int n_epochs, sdr_track_epoch* traj /* [n_ch][n_epochs], nullable */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYDR_AMD_H */

@@ -1,0 +1,248 @@
+// Engine lifetime, error text, IQ ring in HBM, per-kernel hipEvent timing.
+#include "engine_internal.h"
+
+#include <cstring>
+
+static thread_local std::string g_last_error = "";
+
+void sdr_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int sdr_fail(int status, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return status;
+}
+
+int sdr_set_device(sdr_engine* e) {
+    if (!e) return sdr_fail(SDR_ERR_INVALID, "engine is NULL");
+    SDR_HIP(hipSetDevice(e->device));
+    return SDR_OK;
+}
+
+int sdr_devbuf_reserve(sdr_engine* e, DevBuf* b, size_t bytes) {
+    if (bytes <= b->bytes && b->ptr) return SDR_OK;
+    if (b->ptr) {
+        SDR_HIP(hipStreamSynchronize(e->stream));
+        SDR_HIP(hipFree(b->ptr));
+        b->ptr = nullptr;
+        b->bytes = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t err = hipMalloc(&b->ptr, want);
+    if (err != hipSuccess) {
+        b->ptr = nullptr;
+        return sdr_fail(SDR_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(err));
+    }
+    b->bytes = want;
+    return SDR_OK;
+}
+
+ProfScope::ProfScope(sdr_engine* eng, const char* name) : e(eng), active(eng->prof) {
+    rec.name = name;
+    rec.start = rec.stop = nullptr;
+    if (!active) return;
+    for (int i = 0; i < 2; ++i) {
+        hipEvent_t ev = nullptr;
+        if (!e->prof_pool.empty()) {
+            ev = e->prof_pool.back();
+            e->prof_pool.pop_back();
+        } else if (hipEventCreate(&ev) != hipSuccess) {
+            active = false;
+            return;
+        }
+        (i == 0 ? rec.start : rec.stop) = ev;
+    }
+    (void)hipEventRecord(rec.start, e->stream);
+}
+
+ProfScope::~ProfScope() {
+    if (!active) return;
+    (void)hipEventRecord(rec.stop, e->stream);
+    e->prof_records.push_back(rec);
+}
+
+extern "C" {
+
+const char* sdr_last_error(void) { return g_last_error.c_str(); }
+
+int sdr_abi_version(void) { return SDR_ABI_VERSION; }
+
+int sdr_device_count(int* n) {
+    if (!n) return sdr_fail(SDR_ERR_INVALID, "n is NULL");
+    int c = 0;
+    hipError_t err = hipGetDeviceCount(&c);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;  // CPU-only host: not an error for this query
+    }
+    *n = c;
+    return SDR_OK;
+}
+
+int sdr_engine_create(int device_id, sdr_engine** out) {
+    if (!out) return sdr_fail(SDR_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int c = 0;
+    hipError_t err = hipGetDeviceCount(&c);
+    if (err != hipSuccess || c == 0) {
+        (void)hipGetLastError();
+        return sdr_fail(SDR_ERR_HIP, "no HIP device visible (%s): this engine has no CPU fallback",
+                        err == hipSuccess ? "count=0" : hipGetErrorString(err));
+    }
+    if (device_id < 0 || device_id >= c)
+        return sdr_fail(SDR_ERR_INVALID, "device_id %d outside [0,%d)", device_id, c);
+    SDR_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    SDR_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return sdr_fail(SDR_ERR_UNSUPPORTED, "device %d is %s; this library only carries gfx950 code",
+                        device_id, prop.gcnArchName);
+    sdr_engine* e = new (std::nothrow) sdr_engine();
+    if (!e) return sdr_fail(SDR_ERR_NOMEM, "host allocation failed");
+    e->device = device_id;
+    err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err != hipSuccess) {
+        delete e;
+        return sdr_fail(SDR_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(err));
+    }
+    *out = e;
+    return SDR_OK;
+}
+
+void sdr_engine_destroy(sdr_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (auto& r : e->prof_records) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    for (auto ev : e->prof_pool) (void)hipEventDestroy(ev);
+    DevBuf* bufs[] = {&e->ws_items,  &e->ws_out,   &e->ws_spacing, &e->pcps_fwd,   &e->pcps_a,
+                      &e->pcps_b,    &e->pcps_code, &e->pcps_tw,   &e->pcps_map,   &e->pcps_csum,
+                      &e->pcps_part, &e->pcps_res,  &e->track_state, &e->track_cfg, &e->track_traj};
+    for (DevBuf* b : bufs)
+        if (b->ptr) (void)hipFree(b->ptr);
+    if (e->iq) (void)hipFree(e->iq);
+    if (e->codes) (void)hipFree(e->codes);
+    if (e->code_len) (void)hipFree(e->code_len);
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int sdr_engine_sync(sdr_engine* e) {
+    if (int rc = sdr_set_device(e)) return rc;
+    SDR_HIP(hipStreamSynchronize(e->stream));
+    return SDR_OK;
+}
+
+int sdr_prof_enable(sdr_engine* e, int enable) {
+    if (!e) return sdr_fail(SDR_ERR_INVALID, "engine is NULL");
+    e->prof = enable != 0;
+    return SDR_OK;
+}
+
+int sdr_prof_reset(sdr_engine* e) {
+    if (int rc = sdr_set_device(e)) return rc;
+    SDR_HIP(hipStreamSynchronize(e->stream));
+    for (auto& r : e->prof_records) {
+        e->prof_pool.push_back(r.start);
+        e->prof_pool.push_back(r.stop);
+    }
+    e->prof_records.clear();
+    return SDR_OK;
+}
+
+int sdr_prof_read(sdr_engine* e, const char* prefix, double* total_ms, int64_t* launches) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!total_ms || !launches) return sdr_fail(SDR_ERR_INVALID, "NULL output");
+    SDR_HIP(hipStreamSynchronize(e->stream));
+    size_t plen = prefix ? strlen(prefix) : 0;
+    double tot = 0.0;
+    int64_t cnt = 0;
+    for (auto& r : e->prof_records) {
+        if (plen && strncmp(r.name, prefix, plen) != 0) continue;
+        float ms = 0.f;
+        SDR_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
+        tot += ms;
+        ++cnt;
+    }
+    *total_ms = tot;
+    *launches = cnt;
+    return SDR_OK;
+}
+
+/* ------------------------------------------------------------------ IQ ring */
+
+int sdr_iq_alloc(sdr_engine* e, int64_t capacity_samples, int fmt) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (fmt < SDR_FMT_CI8 || fmt > SDR_FMT_CF64) return sdr_fail(SDR_ERR_INVALID, "bad IQ format %d", fmt);
+    if (capacity_samples <= 0 || capacity_samples % 8 != 0)
+        return sdr_fail(SDR_ERR_INVALID, "ring capacity %lld must be a positive multiple of 8 samples",
+                        (long long)capacity_samples);
+    SDR_HIP(hipStreamSynchronize(e->stream));
+    if (e->iq) {
+        SDR_HIP(hipFree(e->iq));
+        e->iq = nullptr;
+        e->iq_capacity = 0;
+    }
+    size_t bytes = (size_t)capacity_samples * sdr_fmt_bytes(fmt);
+    hipError_t err = hipMalloc(&e->iq, bytes);
+    if (err != hipSuccess) {
+        e->iq = nullptr;
+        return sdr_fail(SDR_ERR_NOMEM, "hipMalloc(%zu) for the IQ ring failed: %s", bytes,
+                        hipGetErrorString(err));
+    }
+    SDR_HIP(hipMemsetAsync(e->iq, 0, bytes, e->stream));
+    e->iq_capacity = capacity_samples;
+    e->iq_fmt = fmt;
+    return SDR_OK;
+}
+
+static int iq_copy(sdr_engine* e, void* host, int64_t n, int64_t off, bool upload) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!e->iq) return sdr_fail(SDR_ERR_STATE, "IQ ring not allocated");
+    if (!host && n > 0) return sdr_fail(SDR_ERR_INVALID, "host pointer is NULL");
+    if (n < 0 || n > e->iq_capacity)
+        return sdr_fail(SDR_ERR_RANGE, "n_samples %lld exceeds ring capacity %lld", (long long)n,
+                        (long long)e->iq_capacity);
+    if (off < 0) return sdr_fail(SDR_ERR_RANGE, "negative ring offset");
+    off %= e->iq_capacity;
+    size_t sb = sdr_fmt_bytes(e->iq_fmt);
+    int64_t first = n < e->iq_capacity - off ? n : e->iq_capacity - off;
+    char* dev = (char*)e->iq;
+    char* h = (char*)host;
+    if (upload) {
+        if (first) SDR_HIP(hipMemcpyAsync(dev + off * sb, h, first * sb, hipMemcpyHostToDevice, e->stream));
+        if (n > first)
+            SDR_HIP(hipMemcpyAsync(dev, h + first * sb, (n - first) * sb, hipMemcpyHostToDevice, e->stream));
+    } else {
+        if (first) SDR_HIP(hipMemcpyAsync(h, dev + off * sb, first * sb, hipMemcpyDeviceToHost, e->stream));
+        if (n > first)
+            SDR_HIP(hipMemcpyAsync(h + first * sb, dev, (n - first) * sb, hipMemcpyDeviceToHost, e->stream));
+    }
+    // The caller owns `host`; do not keep it past return.
+    SDR_HIP(hipStreamSynchronize(e->stream));
+    return SDR_OK;
+}
+
+int sdr_iq_upload(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset) {
+    return iq_copy(e, const_cast<void*>(iq), n_samples, ring_offset, true);
+}
+
+int sdr_iq_download(sdr_engine* e, void* iq, int64_t n_samples, int64_t ring_offset) {
+    return iq_copy(e, iq, n_samples, ring_offset, false);
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+// Internal declarations shared by the HIP translation units of libsydr_amd.so.
+// gfx950 only; no other backend exists.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/sydr_amd.h"
+
+// Thread-local error text behind sdr_last_error().
+void sdr_set_error(const char* fmt, ...);
+int sdr_fail(int status, const char* fmt, ...);
+
+#define SDR_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t _err = (call);                                                              \
+        if (_err != hipSuccess)                                                                \
+            return sdr_fail(SDR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_err), \
+                            __FILE__, __LINE__);                                               \
+    } while (0)
+
+// Code LUT layout in HBM and LDS: lut[q + SDR_LUT_PAD] = chip[(q - 1) mod L] for
+// q in [-SDR_LUT_PAD, L + SDR_LUT_PAD], i.e. the reference's padded table
+// [c[L-1], c[0..L-1], c[0]] (channel_l1ca_kaplan.py:104-107) extended periodically.
+#define SDR_LUT_PAD 4
+
+struct ProfRecord {
+    const char* name;
+    hipEvent_t start, stop;
+};
+
+// Grow-only device buffer.
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct sdr_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+    // IQ ring
+    void* iq = nullptr;
+    int64_t iq_capacity = 0;  // samples
+    int iq_fmt = SDR_FMT_CI8;
+
+    // code slots: int8 chips, row stride = code_stride bytes, plus per-slot length
+    int8_t* codes = nullptr;  // [n_slots][code_stride] raw chips (+-1), no padding
+    int32_t* code_len = nullptr;  // device [n_slots]
+    std::vector<int32_t> code_len_host;
+    int n_slots = 0;
+    int code_stride = 0;
+
+    // workspaces
+    DevBuf ws_items, ws_out, ws_spacing;
+    DevBuf pcps_fwd, pcps_a, pcps_b, pcps_code, pcps_tw, pcps_map, pcps_csum, pcps_part, pcps_res;
+    DevBuf track_state, track_cfg, track_traj;
+    int64_t pcps_tw_n = 0;
+
+    // profiling
+    bool prof = false;
+    std::vector<ProfRecord> prof_records;
+    std::vector<hipEvent_t> prof_pool;
+};
+
+int sdr_devbuf_reserve(sdr_engine* e, DevBuf* b, size_t bytes);
+
+static inline size_t sdr_fmt_bytes(int fmt) {
+    switch (fmt) {
+        case SDR_FMT_CI8: return 2;
+        case SDR_FMT_CI16: return 4;
+        case SDR_FMT_CF32: return 8;
+        case SDR_FMT_CF64: return 16;
+    }
+    return 0;
+}
+
+// RAII bracket: records hipEvents around a launch when profiling is on.
+struct ProfScope {
+    sdr_engine* e;
+    ProfRecord rec;
+    bool active;
+    ProfScope(sdr_engine* eng, const char* name);
+    ~ProfScope();
+};
+
+int sdr_set_device(sdr_engine* e);

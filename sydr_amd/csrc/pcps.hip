@@ -1,0 +1,646 @@
+// K2-K6: Parallel Code Phase Search on device (sydr/dsp/acquisition.py:9-115).
+//
+//   for every Doppler bin b:   F_b = FFT_N( x[n] * exp(-1j*(IF - bin_b)*((2n)*pi/fs)) )      (PRN independent,
+//                                                                                             computed ONCE, not per PRN)
+//   for every (PRN p, bin b):  map[p][b][:] += | IFFT_N( F_b * conj(FFT_N(upsampled code_p)) ) |
+//   per PRN: first global argmax (row-major) + second peak in the winning row.
+//
+// N = samples per code = 4000 / 10000 / 25000 / 50000 are not powers of two, so
+// the transform is a hand-written mixed-radix (2,3,4,5,8 + small primes)
+// Stockham autosort FFT in fp64, batched over (PRN, bin); each pass streams the
+// batch through HBM/L2 with 16-byte complex loads.  The Doppler mix and the
+// int8->fp64 conversion are fused into the first forward pass, the code-spectrum
+// multiply into the first inverse pass, and 1/N scale + magnitude + (non-)coherent
+// accumulation into the last inverse pass.  fp64 throughout: the peak INDEX must
+// match NumPy's bit for bit, and a 1e-7 relative error could reorder near-ties.
+#include "engine_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kThreads = 256;
+
+enum LoadMode { LOAD_PLAIN = 0, LOAD_IQ_MIX = 1, LOAD_MUL_CODE = 2, LOAD_CODE_REAL = 3 };
+enum StoreMode { STORE_PLAIN = 0, STORE_CONJ = 1, STORE_MAG_ACC = 2, STORE_CPLX_ACC = 3 };
+
+struct PassArgs {
+    const double2* in;    // [batch][N]
+    double2* out;         // [batch][N]
+    const double2* tw;    // W[m] = exp(-2*pi*i*m/N)
+    int N, R, Ns, nbf;    // nbf = N / R butterflies per transform
+    int tw_stride;        // N / (Ns * R)
+    // LOAD_IQ_MIX
+    const void* ring;
+    int64_t capacity;
+    int64_t first_sample;  // ring index of sample 0 of this 1 ms block
+    int64_t carrier_offset;  // idx_coh * N (index into phasePoints)
+    double fs, if_hz, bin_start, bin_delta;
+    // LOAD_MUL_CODE: in = F[nbins][N]; code spectra [n_prn][N]
+    const double2* code_spec;
+    int nbins;
+    // LOAD_CODE_REAL
+    const int8_t* code_samples;  // [batch][N]
+    // STORE_*_ACC
+    double* map;        // [batch][N] magnitudes
+    double2* csum;      // [batch][N]
+    double scale;
+    int first_block;    // 1: overwrite, 0: accumulate
+};
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+// multiply by -i (forward) or +i (inverse)
+template <bool INV>
+__device__ __forceinline__ double2 mul_mi(double2 a) {
+    return INV ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+}
+
+template <int R, bool INV>
+struct Butterfly;
+
+template <bool INV>
+struct Butterfly<2, INV> {
+    static __device__ __forceinline__ void run(double2* v) {
+        double2 a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    }
+};
+
+template <bool INV>
+struct Butterfly<3, INV> {
+    static __device__ __forceinline__ void run(double2* v) {
+        const double c = -0.5, s = 0.86602540378443864676;  // cos, sin of 2*pi/3
+        double2 t1 = cadd(v[1], v[2]);
+        double2 t2 = csub(v[1], v[2]);
+        double2 m = make_double2(v[0].x + c * t1.x, v[0].y + c * t1.y);
+        double2 r = mul_mi<INV>(make_double2(s * t2.x, s * t2.y));
+        v[0] = cadd(v[0], t1);
+        v[1] = cadd(m, r);
+        v[2] = csub(m, r);
+    }
+};
+
+template <bool INV>
+struct Butterfly<4, INV> {
+    static __device__ __forceinline__ void run(double2* v) {
+        double2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+        double2 t2 = cadd(v[1], v[3]), t3 = mul_mi<INV>(csub(v[1], v[3]));
+        v[0] = cadd(t0, t2);
+        v[1] = cadd(t1, t3);
+        v[2] = csub(t0, t2);
+        v[3] = csub(t1, t3);
+    }
+};
+
+template <bool INV>
+struct Butterfly<5, INV> {
+    static __device__ __forceinline__ void run(double2* v) {
+        const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;  // cos(2pi/5), cos(4pi/5)
+        const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;   // sin(2pi/5), sin(4pi/5)
+        double2 a1 = cadd(v[1], v[4]), b1 = csub(v[1], v[4]);
+        double2 a2 = cadd(v[2], v[3]), b2 = csub(v[2], v[3]);
+        double2 m1 = make_double2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
+        double2 m2 = make_double2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+        double2 r1 = mul_mi<INV>(make_double2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y));
+        double2 r2 = mul_mi<INV>(make_double2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y));
+        v[0] = cadd(v[0], cadd(a1, a2));
+        v[1] = cadd(m1, r1);
+        v[4] = csub(m1, r1);
+        v[2] = cadd(m2, r2);
+        v[3] = csub(m2, r2);
+    }
+};
+
+template <bool INV>
+struct Butterfly<8, INV> {
+    static __device__ __forceinline__ void run(double2* v) {
+        const double h = 0.70710678118654752440;
+        // radix-2 split into evens / odds, two radix-4 butterflies, then combine.
+        double2 e[4] = {v[0], v[2], v[4], v[6]};
+        double2 o[4] = {v[1], v[3], v[5], v[7]};
+        Butterfly<4, INV>::run(e);
+        Butterfly<4, INV>::run(o);
+        // twiddles W8^k, k = 1..3: (h, -+h), (0, -+1), (-h, -+h)
+        double2 w1 = INV ? make_double2(h * (o[1].x - o[1].y), h * (o[1].x + o[1].y))
+                         : make_double2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));
+        double2 w2 = mul_mi<INV>(o[2]);
+        double2 w3 = INV ? make_double2(-h * (o[3].x + o[3].y), h * (o[3].x - o[3].y))
+                         : make_double2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));
+        v[0] = cadd(e[0], o[0]);
+        v[4] = csub(e[0], o[0]);
+        v[1] = cadd(e[1], w1);
+        v[5] = csub(e[1], w1);
+        v[2] = cadd(e[2], w2);
+        v[6] = csub(e[2], w2);
+        v[3] = cadd(e[3], w3);
+        v[7] = csub(e[3], w3);
+    }
+};
+
+template <int FMT>
+__device__ __forceinline__ double2 ring_sample(const void* ring, int64_t pos) {
+    if (FMT == SDR_FMT_CI8) {
+        const char2 v = static_cast<const char2*>(ring)[pos];
+        return make_double2((double)v.x, (double)v.y);
+    } else if (FMT == SDR_FMT_CI16) {
+        const short2 v = static_cast<const short2*>(ring)[pos];
+        return make_double2((double)v.x, (double)v.y);
+    } else if (FMT == SDR_FMT_CF32) {
+        const float2 v = static_cast<const float2*>(ring)[pos];
+        return make_double2((double)v.x, (double)v.y);
+    } else {
+        return static_cast<const double2*>(ring)[pos];
+    }
+}
+
+template <int LOAD, int FMT, bool INV>
+__device__ __forceinline__ double2 load_elem(const PassArgs& a, int batch, int idx) {
+    if (LOAD == LOAD_PLAIN) {
+        return a.in[(size_t)batch * a.N + idx];
+    } else if (LOAD == LOAD_IQ_MIX) {
+        // acquisition.py:33,42-45,53: carrier = exp(-1j*freq*phasePoints), phasePoints[m] = ((m*2)*pi)/fs
+        int64_t pos = (a.first_sample + idx) % a.capacity;
+        double2 x = ring_sample<FMT>(a.ring, pos);
+        double bin = a.bin_start + (double)batch * a.bin_delta;
+        double freq = a.if_hz - bin;
+        int64_t m = a.carrier_offset + idx;
+        double pp = (double)(m * 2) * M_PI;
+        pp = pp / a.fs;
+        double arg = freq * pp;
+        double s, c;
+        sincos(arg, &s, &c);
+        return cmul(make_double2(c, -s), x);
+    } else if (LOAD == LOAD_MUL_CODE) {
+        int prn = batch / a.nbins, bin = batch - prn * a.nbins;
+        double2 f = a.in[(size_t)bin * a.N + idx];
+        double2 c = a.code_spec[(size_t)prn * a.N + idx];
+        return cmul(f, c);
+    } else {
+        return make_double2((double)a.code_samples[(size_t)batch * a.N + idx], 0.0);
+    }
+}
+
+template <int STORE>
+__device__ __forceinline__ void store_elem(const PassArgs& a, int batch, int idx, double2 v) {
+    const size_t o = (size_t)batch * a.N + idx;
+    if (STORE == STORE_PLAIN) {
+        a.out[o] = v;
+    } else if (STORE == STORE_CONJ) {
+        a.out[o] = make_double2(v.x, -v.y);
+    } else if (STORE == STORE_MAG_ACC) {
+        double mag = hypot(v.x * a.scale, v.y * a.scale);
+        a.map[o] = a.first_block ? 0.0 + mag : a.map[o] + mag;
+    } else {
+        double2 s = make_double2(v.x * a.scale, v.y * a.scale);
+        a.csum[o] = a.first_block ? s : cadd(a.csum[o], s);
+    }
+}
+
+// One Stockham pass of radix R: thread j owns butterfly j of transform blockIdx.y.
+template <int R, bool INV, int LOAD, int STORE, int FMT>
+__global__ __launch_bounds__(kThreads) void fft_pass_kernel(const PassArgs a) {
+    const int j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= a.nbf) return;
+    const int batch = blockIdx.y;
+    const int k = j % a.Ns;
+    double2 v[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) v[t] = load_elem<LOAD, FMT, INV>(a, batch, j + t * a.nbf);
+    if (a.Ns > 1) {
+#pragma unroll
+        for (int t = 1; t < R; ++t) {
+            double2 w = a.tw[(size_t)t * k * a.tw_stride];
+            if (INV) w.y = -w.y;
+            v[t] = cmul(v[t], w);
+        }
+    }
+    Butterfly<R, INV>::run(v);
+    const int o = (j - k) * R + k;
+#pragma unroll
+    for (int t = 0; t < R; ++t) store_elem<STORE>(a, batch, o + t * a.Ns, v[t]);
+}
+
+// Any other prime radix (7, 11, 13, ...): O(R^2) DFT with roots from the twiddle table.
+constexpr int kMaxGenericRadix = 64;
+template <bool INV, int LOAD, int STORE, int FMT>
+__global__ __launch_bounds__(kThreads) void fft_pass_generic_kernel(const PassArgs a) {
+    const int j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= a.nbf) return;
+    const int batch = blockIdx.y;
+    const int R = a.R;
+    const int k = j % a.Ns;
+    const int root_stride = a.N / R;
+    const int o = (j - k) * R + k;
+    for (int q = 0; q < R; ++q) {
+        double2 acc = make_double2(0.0, 0.0);
+        for (int t = 0; t < R; ++t) {
+            double2 x = load_elem<LOAD, FMT, INV>(a, batch, j + t * a.nbf);
+            if (a.Ns > 1 && t > 0) {
+                double2 w = a.tw[(size_t)t * k * a.tw_stride];
+                if (INV) w.y = -w.y;
+                x = cmul(x, w);
+            }
+            double2 r = a.tw[(size_t)((t * q) % R) * root_stride];
+            if (INV) r.y = -r.y;
+            acc = cadd(acc, cmul(x, r));
+        }
+        store_elem<STORE>(a, batch, o + q * a.Ns, acc);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void twiddle_kernel(double2* tw, int N) {
+    int m = blockIdx.x * kThreads + threadIdx.x;
+    if (m >= N) return;
+    double s, c;
+    sincospi(2.0 * (double)m / (double)N, &s, &c);
+    tw[m] = make_double2(c, -s);
+}
+
+__global__ __launch_bounds__(kThreads) void upsample_batch_kernel(const int8_t* __restrict__ codes,
+                                                                  const int32_t* __restrict__ code_len,
+                                                                  int code_stride, const int32_t* __restrict__ slots,
+                                                                  double ts, double tc, int N,
+                                                                  int8_t* __restrict__ out) {
+    int k = blockIdx.x * kThreads + threadIdx.x;
+    if (k >= N) return;
+    const int slot = slots[blockIdx.y];
+    const int L = code_len[slot];
+    double v = (ts * (double)k) / tc;  // gnsssignal.py:53
+    int idx = (int)trunc(v);
+    if (idx >= L) idx = L - 1;
+    out[(size_t)blockIdx.y * N + k] = codes[(size_t)slot * code_stride + idx];
+}
+
+// map += |csum| (acquisition.py:68)
+__global__ __launch_bounds__(kThreads) void mag_acc_kernel(const double2* __restrict__ csum, double* __restrict__ map,
+                                                           size_t count, int first_block) {
+    size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= count) return;
+    double mag = hypot(csum[i].x, csum[i].y);
+    map[i] = first_block ? 0.0 + mag : map[i] + mag;
+}
+
+/* ------------------------------------------------------- peak search (K6) */
+
+struct Best {
+    double v;
+    long long i;
+};
+__device__ __forceinline__ Best better(Best a, Best b) {
+    // larger value wins; on ties the smaller flat index (first occurrence, np.argmax)
+    if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+__device__ __forceinline__ Best block_best(Best mine, Best* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.v = __shfl_down(mine.v, off, 64);
+        o.i = __shfl_down(mine.i, off, 64);
+        mine = better(mine, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = mine;
+    __syncthreads();
+    Best r = sh[0];
+    for (int w = 1; w < kThreads / 64; ++w) r = better(r, sh[w]);
+    __syncthreads();
+    return r;
+}
+
+constexpr int kPeakParts = 64;
+
+__global__ __launch_bounds__(kThreads) void argmax_part_kernel(const double* __restrict__ map, long long per_prn,
+                                                               Best* __restrict__ parts) {
+    __shared__ Best sh[kThreads / 64];
+    const int prn = blockIdx.y, part = blockIdx.x;
+    const double* m = map + (size_t)prn * per_prn;
+    long long chunk = (per_prn + kPeakParts - 1) / kPeakParts;
+    long long lo = (long long)part * chunk, hi = lo + chunk < per_prn ? lo + chunk : per_prn;
+    Best mine = {-1.0, 0x7fffffffffffffffLL};
+    for (long long i = lo + threadIdx.x; i < hi; i += kThreads) {
+        Best c = {m[i], i};
+        mine = better(mine, c);
+    }
+    Best r = block_best(mine, sh);
+    if (threadIdx.x == 0) parts[(size_t)prn * kPeakParts + part] = r;
+}
+
+// TwoCorrelationPeakComparison (acquisition.py:78-115), including its quirks.
+__global__ __launch_bounds__(kThreads) void peak_finish_kernel(const double* __restrict__ map, int nbins, int N,
+                                                               int spc, const Best* __restrict__ parts,
+                                                               long long* __restrict__ out_bin,
+                                                               long long* __restrict__ out_code,
+                                                               double* __restrict__ out_ratio) {
+    __shared__ Best sh[kThreads / 64];
+    const int prn = blockIdx.x;
+    Best mine = {-1.0, 0x7fffffffffffffffLL};
+    if (threadIdx.x < kPeakParts) mine = parts[(size_t)prn * kPeakParts + threadIdx.x];
+    Best top = block_best(mine, sh);
+    const long long bin = top.i / N;
+    const int code = (int)(top.i - bin * N);
+    const double* row = map + ((size_t)prn * nbins + bin) * N;
+    const int e0 = code - spc, e1 = code + spc;
+    // allowed = [a0,a1) U [b0,b1)
+    int a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    if (e0 < 1) {
+        b0 = e1;
+        b1 = N - 1;
+    } else if (e1 >= N) {
+        a1 = e0;
+    } else {
+        a1 = e0;
+        b0 = e1;
+        b1 = N - 1;
+    }
+    Best second = {-1.0, 0x7fffffffffffffffLL};
+    for (int i = threadIdx.x; i < N; i += kThreads) {
+        bool ok = (i >= a0 && i < a1) || (i >= b0 && i < b1);
+        if (ok) {
+            Best c = {row[i], i};
+            second = better(second, c);
+        }
+    }
+    Best p2 = block_best(second, sh);
+    if (threadIdx.x == 0) {
+        out_bin[prn] = bin;
+        out_code[prn] = code;
+        out_ratio[prn] = p2.v >= 0.0 ? top.v / p2.v : nan("");
+    }
+}
+
+/* ------------------------------------------------------------ host driver */
+
+std::vector<int> factor_radices(int64_t N) {
+    std::vector<int> r;
+    int64_t n = N;
+    while (n % 5 == 0) { r.push_back(5); n /= 5; }
+    while (n % 3 == 0) { r.push_back(3); n /= 3; }
+    while (n % 8 == 0) { r.push_back(8); n /= 8; }
+    while (n % 4 == 0) { r.push_back(4); n /= 4; }
+    while (n % 2 == 0) { r.push_back(2); n /= 2; }
+    for (int p = 7; (int64_t)p <= n && p <= kMaxGenericRadix; p += 2)
+        while (n % p == 0) { r.push_back(p); n /= p; }
+    if (n != 1) r.clear();
+    return r;
+}
+
+template <bool INV, int LOAD, int STORE, int FMT>
+void launch_pass(sdr_engine* e, const PassArgs& a, int batch) {
+    dim3 grid((a.nbf + kThreads - 1) / kThreads, batch);
+    switch (a.R) {
+        case 2: hipLaunchKernelGGL((fft_pass_kernel<2, INV, LOAD, STORE, FMT>), grid, dim3(kThreads), 0, e->stream, a); break;
+        case 3: hipLaunchKernelGGL((fft_pass_kernel<3, INV, LOAD, STORE, FMT>), grid, dim3(kThreads), 0, e->stream, a); break;
+        case 4: hipLaunchKernelGGL((fft_pass_kernel<4, INV, LOAD, STORE, FMT>), grid, dim3(kThreads), 0, e->stream, a); break;
+        case 5: hipLaunchKernelGGL((fft_pass_kernel<5, INV, LOAD, STORE, FMT>), grid, dim3(kThreads), 0, e->stream, a); break;
+        case 8: hipLaunchKernelGGL((fft_pass_kernel<8, INV, LOAD, STORE, FMT>), grid, dim3(kThreads), 0, e->stream, a); break;
+        default: hipLaunchKernelGGL((fft_pass_generic_kernel<INV, LOAD, STORE, FMT>), grid, dim3(kThreads), 0, e->stream, a); break;
+    }
+}
+
+// Runs all passes of one batched transform.  `first` carries the fused load of
+// pass 0, `last_store` the fused store of the final pass.  Ping-pongs bufA/bufB.
+template <bool INV, int LOAD0, int STORE_LAST, int FMT>
+void run_fft(sdr_engine* e, const std::vector<int>& radices, PassArgs a, int batch, double2* bufA, double2* bufB,
+             double2* final_out, const char* prof_name) {
+    ProfScope ps(e, prof_name);
+    const int np = (int)radices.size();
+    int Ns = 1;
+    const double2* src = a.in;
+    for (int p = 0; p < np; ++p) {
+        a.R = radices[p];
+        a.Ns = Ns;
+        a.nbf = a.N / a.R;
+        a.tw_stride = a.N / (Ns * a.R);
+        const bool first = p == 0, last = p == np - 1;
+        a.in = first ? a.in : src;
+        double2* dst = last ? final_out : ((p & 1) ? bufB : bufA);
+        a.out = dst;
+        if (first && last) launch_pass<INV, LOAD0, STORE_LAST, FMT>(e, a, batch);
+        else if (first) launch_pass<INV, LOAD0, STORE_PLAIN, FMT>(e, a, batch);
+        else if (last) launch_pass<INV, LOAD_PLAIN, STORE_LAST, FMT>(e, a, batch);
+        else launch_pass<INV, LOAD_PLAIN, STORE_PLAIN, FMT>(e, a, batch);
+        src = dst;
+        Ns *= a.R;
+    }
+}
+
+template <int FMT>
+int pcps_run(sdr_engine* e, const int32_t* d_slots, int n_prn, int64_t start, double fs, double if_hz,
+             double bin_start, double bin_delta, int nbins, int N, int spc, int coh, int noncoh,
+             const std::vector<int>& radices, int prn_chunk) {
+    double2* F = (double2*)e->pcps_fwd.ptr;
+    double2* A = (double2*)e->pcps_a.ptr;
+    double2* B = (double2*)e->pcps_b.ptr;
+    double2* C = (double2*)e->pcps_code.ptr;
+    double* map = (double*)e->pcps_map.ptr;
+    double2* csum = (double2*)e->pcps_csum.ptr;
+    const double2* tw = (const double2*)e->pcps_tw.ptr;
+
+    // K7/a3: upsample every code and take conj(fft(code)) (channel_l1ca_kaplan.py:184-185).
+    {
+        int8_t* up = (int8_t*)B;  // scratch: n_prn*N bytes fits easily in a work buffer
+        {
+            ProfScope ps(e, "pcps_upsample");
+            hipLaunchKernelGGL(upsample_batch_kernel, dim3((N + kThreads - 1) / kThreads, n_prn), dim3(kThreads), 0,
+                               e->stream, e->codes, e->code_len, e->code_stride, d_slots, 1.0 / fs, 1.0 / 1.023e6, N, up);
+        }
+        PassArgs a = {};
+        a.tw = tw;
+        a.N = N;
+        a.code_samples = up;
+        // ping-pong inside A (two halves are not needed: code batch is small) -> use A and F as scratch
+        run_fft<false, LOAD_CODE_REAL, STORE_CONJ, FMT>(e, radices, a, n_prn, A, F, C, "pcps_code_fft");
+    }
+
+    for (int inc = 0; inc < noncoh; ++inc) {
+        for (int ic = 0; ic < coh; ++ic) {
+            // Forward transforms of the Doppler-mixed millisecond, all bins at once.
+            PassArgs f = {};
+            f.tw = tw;
+            f.N = N;
+            f.ring = e->iq;
+            f.capacity = e->iq_capacity;
+            f.first_sample = start + ((int64_t)inc * coh + ic) * N;
+            f.carrier_offset = (int64_t)ic * N;
+            f.fs = fs;
+            f.if_hz = if_hz;
+            f.bin_start = bin_start;
+            f.bin_delta = bin_delta;
+            run_fft<false, LOAD_IQ_MIX, STORE_PLAIN, FMT>(e, radices, f, nbins, A, B, F, "pcps_fwd_fft");
+
+            for (int p0 = 0; p0 < n_prn; p0 += prn_chunk) {
+                const int pc = n_prn - p0 < prn_chunk ? n_prn - p0 : prn_chunk;
+                PassArgs g = {};
+                g.tw = tw;
+                g.N = N;
+                g.in = F;
+                g.code_spec = C + (size_t)p0 * N;
+                g.nbins = nbins;
+                g.scale = 1.0 / (double)N;
+                g.map = map + (size_t)p0 * nbins * N;
+                g.csum = csum ? csum + (size_t)p0 * nbins * N : nullptr;
+                if (coh == 1) {
+                    g.first_block = inc == 0;
+                    run_fft<true, LOAD_MUL_CODE, STORE_MAG_ACC, FMT>(e, radices, g, pc * nbins, A, B, nullptr, "pcps_inv_fft");
+                } else {
+                    g.first_block = ic == 0;
+                    run_fft<true, LOAD_MUL_CODE, STORE_CPLX_ACC, FMT>(e, radices, g, pc * nbins, A, B, nullptr, "pcps_inv_fft");
+                }
+            }
+        }
+        if (coh > 1) {
+            ProfScope ps(e, "pcps_mag_acc");
+            size_t count = (size_t)n_prn * nbins * N;
+            hipLaunchKernelGGL(mag_acc_kernel, dim3((unsigned)((count + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                               e->stream, csum, map, count, inc == 0 ? 1 : 0);
+        }
+    }
+
+    // K6
+    Best* parts = (Best*)e->pcps_part.ptr;
+    long long* res_bin = (long long*)e->pcps_res.ptr;
+    long long* res_code = res_bin + n_prn;
+    double* res_ratio = (double*)(res_code + n_prn);
+    {
+        ProfScope ps(e, "pcps_peak");
+        hipLaunchKernelGGL(argmax_part_kernel, dim3(kPeakParts, n_prn), dim3(kThreads), 0, e->stream, map,
+                           (long long)nbins * N, parts);
+        hipLaunchKernelGGL(peak_finish_kernel, dim3(n_prn), dim3(kThreads), 0, e->stream, map, nbins, N, spc, parts,
+                           res_bin, res_code, res_ratio);
+    }
+    SDR_HIP(hipGetLastError());
+    return SDR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdr_pcps_bins(double doppler_range, double doppler_step) {
+    if (!(doppler_step > 0.0) || !(doppler_range >= 0.0)) return 0;
+    // len(np.arange(-R, R+1, S)) = ceil((stop - start)/step)
+    double len = std::ceil(((doppler_range + 1.0) - (-doppler_range)) / doppler_step);
+    return len > 0 ? (int)len : 0;
+}
+
+int sdr_two_peak_compare(sdr_engine* e, const double* corr_map, int n_bins, int n_code, int samples_per_chip,
+                         int64_t* peak_bin, int64_t* peak_code, double* peak_ratio) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!corr_map || !peak_bin || !peak_code || !peak_ratio) return sdr_fail(SDR_ERR_INVALID, "NULL argument");
+    if (n_bins < 1 || n_code < 2 || samples_per_chip < 0) return sdr_fail(SDR_ERR_INVALID, "bad map geometry");
+    const size_t count = (size_t)n_bins * n_code;
+    int rc = sdr_devbuf_reserve(e, &e->pcps_map, count * sizeof(double));
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_part, kPeakParts * sizeof(Best));
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_res, 3 * sizeof(double) + sizeof(int32_t));
+    if (rc) return rc;
+    double* map = (double*)e->pcps_map.ptr;
+    long long* res = (long long*)e->pcps_res.ptr;
+    SDR_HIP(hipMemcpyAsync(map, corr_map, count * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    {
+        ProfScope ps(e, "pcps_peak");
+        hipLaunchKernelGGL(argmax_part_kernel, dim3(kPeakParts, 1), dim3(kThreads), 0, e->stream, map,
+                           (long long)count, (Best*)e->pcps_part.ptr);
+        hipLaunchKernelGGL(peak_finish_kernel, dim3(1), dim3(kThreads), 0, e->stream, map, n_bins, n_code,
+                           samples_per_chip, (const Best*)e->pcps_part.ptr, res, res + 1, (double*)(res + 2));
+    }
+    SDR_HIP(hipGetLastError());
+    long long host[3];
+    SDR_HIP(hipMemcpyAsync(host, res, sizeof(host), hipMemcpyDeviceToHost, e->stream));
+    SDR_HIP(hipStreamSynchronize(e->stream));
+    *peak_bin = host[0];
+    *peak_code = host[1];
+    memcpy(peak_ratio, &host[2], sizeof(double));
+    return SDR_OK;
+}
+
+int sdr_pcps(sdr_engine* e, const int32_t* code_slots, int n_prn, int64_t start_sample, double fs, double if_hz,
+             double doppler_range, double doppler_step, int coh, int noncoh, int64_t* peak_bin,
+             int64_t* peak_code, double* peak_ratio, double* corr_map, int* n_bins_out) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!e->iq) return sdr_fail(SDR_ERR_STATE, "IQ ring not allocated");
+    if (!e->codes) return sdr_fail(SDR_ERR_STATE, "code slots not allocated");
+    if (!code_slots || n_prn <= 0) return sdr_fail(SDR_ERR_INVALID, "no PRN to search");
+    if (!peak_bin || !peak_code || !peak_ratio) return sdr_fail(SDR_ERR_INVALID, "NULL peak outputs");
+    if (!(fs > 0.0) || coh < 1 || noncoh < 1) return sdr_fail(SDR_ERR_INVALID, "bad fs / integration counts");
+    const int nbins = sdr_pcps_bins(doppler_range, doppler_step);
+    if (nbins <= 0) return sdr_fail(SDR_ERR_INVALID, "empty Doppler grid");
+    if (n_bins_out) *n_bins_out = nbins;
+    // samplesPerCode / samplesPerCodeChip (channel_l1ca_kaplan.py:186,205-206), Python round = half-even
+    const int64_t N64 = (int64_t)std::nearbyint(fs * 1023.0 / 1.023e6);
+    const int spc = (int)std::nearbyint(fs / 1.023e6);
+    if (N64 < 2 || N64 > (1 << 24)) return sdr_fail(SDR_ERR_UNSUPPORTED, "samples per code %lld unsupported", (long long)N64);
+    const int N = (int)N64;
+    const std::vector<int> radices = factor_radices(N);
+    if (radices.empty())
+        return sdr_fail(SDR_ERR_UNSUPPORTED, "N=%d has a prime factor above %d", N, kMaxGenericRadix);
+    const int64_t need = (int64_t)N * coh * noncoh;
+    if (start_sample < 0 || need > e->iq_capacity)
+        return sdr_fail(SDR_ERR_RANGE, "acquisition needs %lld samples, ring holds %lld", (long long)need,
+                        (long long)e->iq_capacity);
+    for (int i = 0; i < n_prn; ++i)
+        if (code_slots[i] < 0 || code_slots[i] >= e->n_slots || e->code_len_host[code_slots[i]] <= 0)
+            return sdr_fail(SDR_ERR_INVALID, "PRN entry %d: code slot %d is not staged", i, code_slots[i]);
+
+    // Work-buffer sizing: transforms in flight per inverse sweep are capped at 8 GiB per buffer.
+    const size_t tbytes = (size_t)N * sizeof(double2);
+    int prn_chunk = (int)std::min<int64_t>(n_prn, std::max<int64_t>(1, (int64_t)((8ull << 30) / (tbytes * nbins))));
+    if ((int64_t)prn_chunk * nbins > 65535) prn_chunk = std::max(1, 65535 / nbins);
+    if (nbins > 65535 || n_prn > 65535) return sdr_fail(SDR_ERR_UNSUPPORTED, "grid too large");
+    const size_t work = tbytes * (size_t)std::max(prn_chunk * nbins, std::max(n_prn, nbins));
+    int rc = sdr_devbuf_reserve(e, &e->pcps_fwd, tbytes * (size_t)std::max(nbins, n_prn));
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_a, work);
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_b, work);
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_code, tbytes * n_prn);
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_map, (size_t)n_prn * nbins * N * sizeof(double));
+    if (!rc && coh > 1) rc = sdr_devbuf_reserve(e, &e->pcps_csum, (size_t)n_prn * nbins * tbytes);
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_part, (size_t)n_prn * kPeakParts * sizeof(Best));
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_res, (size_t)n_prn * 3 * sizeof(double) + n_prn * sizeof(int32_t));
+    if (rc) return rc;
+    if (e->pcps_tw_n != N) {
+        if ((rc = sdr_devbuf_reserve(e, &e->pcps_tw, tbytes))) return rc;
+        hipLaunchKernelGGL(twiddle_kernel, dim3((N + kThreads - 1) / kThreads), dim3(kThreads), 0, e->stream,
+                           (double2*)e->pcps_tw.ptr, N);
+        SDR_HIP(hipGetLastError());
+        e->pcps_tw_n = N;
+    }
+    int32_t* d_slots = (int32_t*)((char*)e->pcps_res.ptr + (size_t)n_prn * 3 * sizeof(double));
+    SDR_HIP(hipMemcpyAsync(d_slots, code_slots, n_prn * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+
+    // np.arange(-R, R+1, S): element k = start + k*delta with delta = (start+step) - start
+    const double bin_start = -doppler_range;
+    const double bin_delta = (bin_start + doppler_step) - bin_start;
+
+    switch (e->iq_fmt) {
+        case SDR_FMT_CI8: rc = pcps_run<SDR_FMT_CI8>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk); break;
+        case SDR_FMT_CI16: rc = pcps_run<SDR_FMT_CI16>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk); break;
+        case SDR_FMT_CF32: rc = pcps_run<SDR_FMT_CF32>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk); break;
+        default: rc = pcps_run<SDR_FMT_CF64>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk); break;
+    }
+    if (rc) return rc;
+
+    std::vector<long long> hb(2 * (size_t)n_prn);
+    SDR_HIP(hipMemcpyAsync(hb.data(), e->pcps_res.ptr, 2 * (size_t)n_prn * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
+    SDR_HIP(hipMemcpyAsync(peak_ratio, (char*)e->pcps_res.ptr + 2 * (size_t)n_prn * sizeof(long long),
+                           (size_t)n_prn * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (corr_map)
+        SDR_HIP(hipMemcpyAsync(corr_map, e->pcps_map.ptr, (size_t)n_prn * nbins * N * sizeof(double),
+                               hipMemcpyDeviceToHost, e->stream));
+    SDR_HIP(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < n_prn; ++i) {
+        peak_bin[i] = hb[i];
+        peak_code[i] = hb[n_prn + i];
+    }
+    return SDR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+"""Engine: one MI355X's correlator state (IQ ring, staged PRN replicas, work buffers)
+behind the C-ABI.  NumPy arrays in, NumPy arrays out; the arithmetic all runs in the HIP
+library (there is deliberately no host implementation to fall back to)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (EPL_ITEM_DTYPE, FMT_CF32, FMT_CF64, FMT_CI16, FMT_CI8, TRACK_EPOCH_DTYPE, LoopCfg, SynthSat,
+                   TrackState, check, ptr)
+
+__all__ = ["Engine", "EplPlan", "make_items", "FMT_CI8", "FMT_CI16", "FMT_CF32", "FMT_CF64"]
+
+
+def make_items(code_slot, n_samples, start_sample, carrier_hz, rem_carrier, rem_code, code_step) -> np.ndarray:
+    """Pack per-epoch NCO parameters (scalars or equal-length arrays) into sdr_epl_item records."""
+    arrs = np.broadcast_arrays(code_slot, n_samples, start_sample, carrier_hz, rem_carrier, rem_code, code_step)
+    items = np.zeros(arrs[0].shape, dtype=EPL_ITEM_DTYPE).reshape(-1)
+    for name, a in zip(EPL_ITEM_DTYPE.names, arrs):
+        items[name] = np.asarray(a).reshape(-1)
+    return items
+
+
+class EplPlan:
+    """Items + outputs resident in HBM; run() only launches kernels (asynchronous)."""
+
+    def __init__(self, engine: "Engine", items: np.ndarray, spacing, fs: float):
+        self._e = engine
+        self._lib = _lib.load()
+        items = np.ascontiguousarray(items, dtype=EPL_ITEM_DTYPE)
+        spacing = np.ascontiguousarray(spacing, dtype=np.float64)
+        self.n_items = len(items)
+        self.n_taps = len(spacing)
+        self._h = C.c_void_p()
+        check(self._lib.sdr_epl_plan_create(engine._h, ptr(items), self.n_items, ptr(spacing), self.n_taps,
+                                            float(fs), C.byref(self._h)))
+
+    def run(self, first=None, count=None):
+        if first is None:
+            check(self._lib.sdr_epl_plan_run(self._e._h, self._h))
+        else:
+            check(self._lib.sdr_epl_plan_run_range(self._e._h, self._h, int(first), int(count)))
+
+    def fetch(self) -> np.ndarray:
+        out = np.empty((self.n_items, 2 * self.n_taps), dtype=np.float64)
+        check(self._lib.sdr_epl_plan_fetch(self._e._h, self._h, ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.sdr_epl_plan_destroy(self._e._h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    def __init__(self, device_id: int = 0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        check(self._lib.sdr_engine_create(int(device_id), C.byref(self._h)))
+        self.device_id = device_id
+        self.iq_fmt = None
+        self.iq_capacity = 0
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if self._h:
+            self._lib.sdr_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self._lib.sdr_engine_sync(self._h))
+
+    def prof_enable(self, on=True):
+        check(self._lib.sdr_prof_enable(self._h, 1 if on else 0))
+
+    def prof_reset(self):
+        check(self._lib.sdr_prof_reset(self._h))
+
+    def prof_read(self, prefix=""):
+        tot, cnt = C.c_double(0), C.c_int64(0)
+        check(self._lib.sdr_prof_read(self._h, prefix.encode(), C.byref(tot), C.byref(cnt)))
+        return tot.value, cnt.value
+
+    # ------------------------------------------------------------------ IQ ring
+    def iq_alloc(self, capacity_samples: int, fmt: int = FMT_CI8):
+        check(self._lib.sdr_iq_alloc(self._h, int(capacity_samples), int(fmt)))
+        self.iq_fmt, self.iq_capacity = fmt, int(capacity_samples)
+
+    def iq_upload(self, raw: np.ndarray, ring_offset: int = 0):
+        """raw: interleaved I,Q in the ring's element type (complex128 accepted for FMT_CF64)."""
+        dt = _lib.fmt_dtype(self.iq_fmt)
+        if np.iscomplexobj(raw):
+            raw = np.ascontiguousarray(raw, dtype=np.complex128).view(np.float64)
+            if self.iq_fmt != FMT_CF64:
+                raw = raw.astype(dt)
+        raw = np.ascontiguousarray(raw, dtype=dt).reshape(-1)
+        if raw.size % 2:
+            raise ValueError("interleaved IQ needs an even number of elements")
+        check(self._lib.sdr_iq_upload(self._h, ptr(raw), raw.size // 2, int(ring_offset)))
+
+    def iq_download(self, n_samples: int, ring_offset: int = 0) -> np.ndarray:
+        out = np.empty(2 * int(n_samples), dtype=_lib.fmt_dtype(self.iq_fmt))
+        check(self._lib.sdr_iq_download(self._h, ptr(out), int(n_samples), int(ring_offset)))
+        return out
+
+    def iq_synth(self, sats, fs, noise_sigma, seed, first_sample, n_samples):
+        arr = (SynthSat * max(1, len(sats)))()
+        for i, s in enumerate(sats):
+            arr[i].prn = int(s["prn"])
+            arr[i].doppler_hz = float(s["doppler"])
+            arr[i].code_phase = float(s["code_phase"])
+            arr[i].carrier_phase = float(s.get("phase", 0.0))
+            arr[i].amplitude = float(s["amp"])
+        check(self._lib.sdr_iq_synth(self._h, arr, len(sats), float(fs), float(noise_sigma), int(seed),
+                                     int(first_sample), int(n_samples)))
+
+    # ------------------------------------------------------------------ PRN replicas
+    def code_slots(self, n_slots: int, max_chips: int = 1023):
+        check(self._lib.sdr_code_slots(self._h, int(n_slots), int(max_chips)))
+        self.n_slots = int(n_slots)
+
+    def load_gps_code(self, slot: int, prn: int):
+        check(self._lib.sdr_code_gps_l1ca(self._h, int(slot), int(prn)))
+
+    def set_code(self, slot: int, chips):
+        chips = np.ascontiguousarray(chips, dtype=np.int8)
+        check(self._lib.sdr_code_custom(self._h, int(slot), ptr(chips), chips.size))
+
+    def read_code(self, slot: int, max_chips: int = 65536) -> np.ndarray:
+        out = np.empty(max_chips, dtype=np.int8)
+        n = C.c_int(0)
+        check(self._lib.sdr_code_read(self._h, int(slot), ptr(out), max_chips, C.byref(n)))
+        return out[:n.value].copy()
+
+    def upsample(self, slot: int, fs: float, n_samples: int) -> np.ndarray:
+        out = np.empty(int(n_samples), dtype=np.int8)
+        check(self._lib.sdr_code_upsample(self._h, int(slot), float(fs), int(n_samples), ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ correlators
+    def epl_batch(self, items: np.ndarray, spacing, fs: float) -> np.ndarray:
+        items = np.ascontiguousarray(items, dtype=EPL_ITEM_DTYPE)
+        spacing = np.ascontiguousarray(spacing, dtype=np.float64)
+        out = np.empty((len(items), 2 * len(spacing)), dtype=np.float64)
+        check(self._lib.sdr_epl_batch(self._h, ptr(items), len(items), ptr(spacing), len(spacing), float(fs),
+                                      ptr(out)))
+        return out
+
+    def epl_plan(self, items, spacing, fs) -> EplPlan:
+        return EplPlan(self, items, spacing, fs)
+
+    # ------------------------------------------------------------------ acquisition
+    def pcps(self, code_slots, start_sample, fs, if_hz, doppler_range, doppler_step, coh=1, noncoh=1,
+             want_map=False):
+        slots = np.ascontiguousarray(code_slots, dtype=np.int32)
+        n = len(slots)
+        nbins = self._lib.sdr_pcps_bins(float(doppler_range), float(doppler_step))
+        n_code = int(round(fs * 1023 / 1.023e6))
+        pb = np.empty(n, dtype=np.int64)
+        pc = np.empty(n, dtype=np.int64)
+        pr = np.empty(n, dtype=np.float64)
+        cmap = np.empty((n, nbins, n_code), dtype=np.float64) if want_map else None
+        nb = C.c_int(0)
+        check(self._lib.sdr_pcps(self._h, ptr(slots), n, int(start_sample), float(fs), float(if_hz),
+                                 float(doppler_range), float(doppler_step), int(coh), int(noncoh), ptr(pb),
+                                 ptr(pc), ptr(pr), ptr(cmap) if want_map else None, C.byref(nb)))
+        return pb, pc, pr, cmap
+
+    def two_peak_compare(self, cmap: np.ndarray, samples_per_chip: int):
+        cmap = np.ascontiguousarray(cmap, dtype=np.float64)
+        pb, pc, pr = C.c_int64(0), C.c_int64(0), C.c_double(0)
+        check(self._lib.sdr_two_peak_compare(self._h, ptr(cmap), cmap.shape[0], cmap.shape[1],
+                                             int(samples_per_chip), C.byref(pb), C.byref(pc), C.byref(pr)))
+        return [pb.value, pc.value], pr.value
+
+    # ------------------------------------------------------------------ closed loop
+    def track_closed_loop(self, states, cfg: LoopCfg, n_epochs: int, want_traj=True):
+        n_ch = len(states)
+        arr = (TrackState * n_ch)(*states)
+        traj = np.zeros((n_ch, n_epochs), dtype=TRACK_EPOCH_DTYPE) if want_traj else None
+        check(self._lib.sdr_track_closed_loop(self._h, n_ch, arr, C.byref(cfg), int(n_epochs),
+                                              ptr(traj) if want_traj else None))
+        return list(arr), traj

@@ -1,0 +1,89 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol the
+header declares, struct layouts agree between C, ctypes and NumPy, and -- without a GPU --
+the engine refuses to start instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from sydr_amd import _lib
+
+HEADER = os.path.join(REPO, "include", "sydr_amd.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/sydr_amd.h but not exported"
+    # and the binding covers exactly the declared surface
+    assert sorted(_lib.exported_symbols()) == names
+
+
+def test_only_gfx950_code_objects():
+    out = subprocess.run(["strings", "-a", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    targets = set(re.findall(r"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", out))
+    assert targets == {"gfx950"}, targets
+
+
+def test_struct_layouts():
+    assert C.sizeof(_lib.EplItem) == 48 == _lib.EPL_ITEM_DTYPE.itemsize
+    for name, (_, off) in _lib.EPL_ITEM_DTYPE.fields.items():
+        assert getattr(_lib.EplItem, name).offset == off
+    assert C.sizeof(_lib.SynthSat) == 40
+    assert C.sizeof(_lib.TrackEpoch) == _lib.TRACK_EPOCH_DTYPE.itemsize
+    for name, (_, off) in _lib.TRACK_EPOCH_DTYPE.fields.items():
+        assert getattr(_lib.TrackEpoch, name).offset == off
+    assert C.sizeof(_lib.TrackState) == 8 + 8 + 15 * 8 + 6 * 4
+    assert C.sizeof(_lib.LoopCfg) == 8 + 8 + 2 * 8 * 8 + 16 * 8
+
+
+def test_struct_sizes_agree_with_the_c_compiler(tmp_path):
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "sydr_amd.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n",'
+                   "sizeof(sdr_epl_item),sizeof(sdr_synth_sat),sizeof(sdr_track_state),sizeof(sdr_loop_cfg),"
+                   "sizeof(sdr_track_epoch));return 0;}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
+    sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [C.sizeof(_lib.EplItem), C.sizeof(_lib.SynthSat), C.sizeof(_lib.TrackState),
+                     C.sizeof(_lib.LoopCfg), C.sizeof(_lib.TrackEpoch)]
+
+
+def test_doppler_grid_length_host_helper():
+    lib = _lib.load()
+    for rng, step in ((5000.0, 250.0), (5000.0, 100.0), (5000.0, 300.0), (7000.0, 125.0), (10.0, 3.0)):
+        assert lib.sdr_pcps_bins(rng, step) == len(np.arange(-rng, rng + 1, step))
+
+
+def test_no_cpu_fallback_without_gpu():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.sdr_engine_create(0, C.byref(h))
+    assert rc == -2 and not h.value
+    assert b"no CPU fallback" in lib.sdr_last_error()
+    from sydr_amd.engine import Engine
+    with pytest.raises(_lib.SdrError):
+        Engine(0)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "sydr_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert "sydr_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f

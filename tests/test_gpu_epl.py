@@ -1,0 +1,222 @@
+"""GPU parity: on-device PRN replicas and the E/P/L correlator kernel vs the golden vectors
+captured from the reference and vs the CPU oracle on the same seeded inputs.
+
+Bar: chip indices bit-exact (a single wrong chip moves an accumulator by >= 1e-5 relative,
+so the 1e-9 accumulator tolerance used here also proves the indices); complex accumulators
+within 1e-6 relative per BASELINE.json -- the kernel is held to 1e-9 of |I+jQ| scale."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import sydr_oracle as orc
+from sydr_amd.engine import FMT_CF32, FMT_CF64, FMT_CI16, FMT_CI8, make_items
+
+pytestmark = pytest.mark.gpu
+
+EPL_RTOL = 1e-9  # relative to the accumulator norm; north_star allows 1e-6
+
+
+def assert_corr_close(got, ref, rtol=EPL_RTOL):
+    got = np.asarray(got, dtype=np.float64).reshape(-1, 2)
+    ref = np.asarray(ref, dtype=np.float64).reshape(-1, 2)
+    scale = np.maximum(np.hypot(ref[:, 0], ref[:, 1]), 1.0)
+    err = np.hypot(got[:, 0] - ref[:, 0], got[:, 1] - ref[:, 1]) / scale
+    assert err.max() <= rtol, f"max relative accumulator error {err.max():.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ codes
+def test_gold_codes_on_device(engine):
+    g = load_golden("g1_codes.npz")
+    engine.code_slots(len(g["prns"]))
+    for slot, (prn, chips) in enumerate(zip(g["prns"], g["chips"])):
+        engine.load_gps_code(slot, int(prn))
+        assert np.array_equal(engine.read_code(slot), chips), f"PRN {prn}"
+
+
+@pytest.mark.parametrize("fs", [4e6, 10e6, 12e6, 25e6, 50e6])
+def test_upsample_on_device(engine, fs):
+    g = load_golden("g1_codes.npz")
+    idx = g[f"upsample_idx_{int(fs)}"]
+    engine.code_slots(2)
+    engine.load_gps_code(1, 19)
+    got = engine.upsample(1, fs, len(idx))
+    assert np.array_equal(got, orc.gold_code(19).astype(np.int8)[idx])
+
+
+def test_custom_code_roundtrip_and_validation(engine):
+    from sydr_amd import SdrError
+    engine.code_slots(1, max_chips=4092)
+    chips = np.where(np.random.default_rng(5).random(4092) < 0.5, -1, 1).astype(np.int8)
+    engine.set_code(0, chips)
+    assert np.array_equal(engine.read_code(0), chips)
+    bad = chips.copy()
+    bad[7] = 0
+    with pytest.raises(SdrError):
+        engine.set_code(0, bad)
+    with pytest.raises(SdrError):
+        engine.load_gps_code(0, 211)
+
+
+# ------------------------------------------------------------------------------------------------ EPL golden
+def _run_case(engine, raw, fmt, prn, fs, f, rc, rk, step, spacing, start=0, capacity=None):
+    n = raw.size // 2
+    cap = capacity or ((n + start + 15) // 8) * 8
+    engine.iq_alloc(cap, fmt)
+    engine.iq_upload(raw, start)
+    engine.code_slots(4)
+    engine.load_gps_code(2, int(prn))
+    items = make_items(2, n, start, f, rc, rk, step)
+    return engine.epl_batch(items, spacing, fs)[0]
+
+
+def test_epl_reference_fixture(engine):
+    g = load_golden("g5_epl.npz")
+    prn, fs, f, rc, rk, step = g["fixture_params"]
+    got = _run_case(engine, g["fixture_iq"], FMT_CI8, prn, fs, f, rc, rk, step, (-0.5, 0.0, 0.5))
+    assert_corr_close(got, g["fixture_out"])
+
+
+def test_epl_golden_cases(engine):
+    g = load_golden("g5_epl.npz")
+    for tag in g["cases"]:
+        prn, fs, f, rc, rk, step, n = g[f"{tag}_params"]
+        raw = g[f"{tag}_iq"]
+        fmt = FMT_CI16 if raw.dtype == np.int16 else FMT_CI8
+        got = _run_case(engine, raw, fmt, prn, fs, f, rc, rk, step, tuple(g[f"{tag}_spacing"]))
+        assert_corr_close(got, g[f"{tag}_out"])
+
+
+@pytest.mark.parametrize("fmt", [FMT_CI8, FMT_CI16, FMT_CF32, FMT_CF64])
+def test_epl_all_ring_formats(engine, fmt):
+    g = load_golden("g5_epl.npz")
+    prn, fs, f, rc, rk, step, n = g["r10_params"]
+    raw = g["r10_iq"]
+    got = _run_case(engine, raw.astype({FMT_CI8: np.int8, FMT_CI16: np.int16, FMT_CF32: np.float32,
+                                        FMT_CF64: np.float64}[fmt]), fmt, prn, fs, f, rc, rk, step,
+                    tuple(g["r10_spacing"]))
+    assert_corr_close(got, g["r10_out"])
+
+
+def test_epl_complex128_non_integer_samples(engine):
+    """Function-level drop-in takes complex128 rfData like the reference; values need not be integers."""
+    rng = np.random.default_rng(77)
+    n, fs = 4001, 4e6
+    rf = rng.normal(0, 11.3, n) + 1j * rng.normal(0, 11.3, n)
+    code = orc.pad_code(orc.gold_code(5))
+    ref = orc.epl(rf, code, fs, 812.5, 2.2, 0.11, 0.25574, (-0.5, 0.0, 0.5))
+    got = _run_case(engine, rf, FMT_CF64, 5, fs, 812.5, 2.2, 0.11, 0.25574, (-0.5, 0.0, 0.5))
+    assert_corr_close(got, ref)
+
+
+# ------------------------------------------------------------------------------------------------ EPL vs oracle
+def test_epl_batch_random_items_vs_oracle(engine):
+    """Many channel-epochs in one launch: misaligned starts, ring wrap, n = N-1/N/N+1, 32 PRNs."""
+    rng = np.random.default_rng(20261001)
+    fs, cap = 25e6, 8 * 40000
+    sats = [dict(prn=p, doppler=float(rng.uniform(-4500, 4500)), code_phase=float(rng.uniform(0, 1023)),
+                 phase=float(rng.random()), amp=6.0) for p in (3, 11, 27)]
+    raw = orc.synth_iq(fs, cap, sats, 20.0, 20261002)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(32)
+    for s in range(32):
+        engine.load_gps_code(s, s + 1)
+    rf = orc.iq_to_complex(raw)
+    n_items = 96
+    slot = rng.integers(0, 32, n_items)
+    step = (1.023e6 + rng.uniform(-4, 4, n_items)) / fs
+    rem_code = rng.uniform(0, step)
+    n = np.ceil((1023 - rem_code) / step).astype(np.int64) + rng.integers(-1, 2, n_items)
+    start = rng.integers(0, cap, n_items)
+    start[:8] = cap - rng.integers(1, 25000, 8)  # force ring wrap
+    start[8:16] = (start[8:16] // 8) * 8 + np.arange(8)  # every misalignment 0..7
+    f = rng.uniform(-5000, 5000, n_items)
+    rem_carrier = rng.uniform(0, 2 * np.pi, n_items)
+    items = make_items(slot, n, start, f, rem_carrier, rem_code, step)
+    got = engine.epl_batch(items, (-0.5, 0.0, 0.5), fs)
+    for k in range(n_items):
+        x = orc.ring_slice(rf, int(start[k]), int(n[k]))
+        ref = orc.epl(x, orc.pad_code(orc.gold_code(int(slot[k]) + 1)), fs, f[k], rem_carrier[k], rem_code[k],
+                      step[k], (-0.5, 0.0, 0.5))
+        assert_corr_close(got[k], ref)
+
+
+@pytest.mark.parametrize("spacing", [(0.0,), (-0.1, 0.1), (-0.5, 0.0, 0.5), (-1.0, -0.5, 0.0, 0.5),
+                                     (-1.0, -0.5, 0.0, 0.5, 1.0), (-1.0, -0.5, -0.1, 0.0, 0.1, 0.5, 1.0),
+                                     (-1.5, -1.0, -0.5, -0.1, 0.0, 0.1, 0.5, 1.0)])
+def test_epl_any_number_of_taps(engine, spacing):
+    """1..8 taps incl. the 5-tap VE/E/P/L/VL of BASELINE config 4 (oracle = generalised restatement)."""
+    g = load_golden("g5_epl.npz")
+    prn, fs, f, rc, rk, step, n = g["r11_params"]
+    raw = g["r11_iq"]
+    got = _run_case(engine, raw, FMT_CI8, prn, fs, f, rc, rk, step, spacing)
+    ref = orc.epl(orc.iq_to_complex(raw), orc.pad_code(orc.gold_code(int(prn))), fs, f, rc, rk, step, spacing)
+    assert_corr_close(got, ref)
+
+
+def test_epl_tiny_and_ragged_epochs(engine):
+    rng = np.random.default_rng(9)
+    fs, cap = 4e6, 8192
+    raw = rng.integers(-60, 60, 2 * cap).astype(np.int8)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(1)
+    engine.load_gps_code(0, 9)
+    rf = orc.iq_to_complex(raw)
+    ns = np.array([1, 2, 7, 8, 9, 63, 64, 65, 255, 2047, 2049, 4000])
+    starts = np.array([5, 0, 3, 8, 1, 17, 6, 2, 4095, 100, 6000, 4200])
+    items = make_items(0, ns, starts, 1000.0, 0.3, 0.01, 0.25575)
+    got = engine.epl_batch(items, (-0.5, 0.0, 0.5), fs)
+    for k in range(len(ns)):
+        x = orc.ring_slice(rf, int(starts[k]), int(ns[k]))
+        ref = orc.epl(x, orc.pad_code(orc.gold_code(9)), fs, 1000.0, 0.3, 0.01, 0.25575, (-0.5, 0.0, 0.5))
+        assert_corr_close(got[k], ref)
+
+
+def test_epl_linearity_and_sign(engine):
+    """Size-independent property: correlators are linear in the IQ (x -> -x flips every sign exactly)."""
+    rng = np.random.default_rng(10)
+    fs, n = 25e6, 25000
+    raw = rng.integers(-100, 100, 2 * n).astype(np.int8)
+    a = _run_case(engine, raw, FMT_CI8, 21, fs, -3333.0, 1.0, 0.02, 0.04092, (-0.5, 0.0, 0.5))
+    b = _run_case(engine, (-raw).astype(np.int8), FMT_CI8, 21, fs, -3333.0, 1.0, 0.02, 0.04092, (-0.5, 0.0, 0.5))
+    assert np.array_equal(a, -b)
+
+
+def test_epl_rejects_bad_items(engine):
+    from sydr_amd import SdrError
+    engine.iq_alloc(8192, FMT_CI8)
+    engine.code_slots(2)
+    engine.load_gps_code(0, 1)
+    ok = dict(code_slot=0, n_samples=4000, start_sample=0, carrier_hz=0.0, rem_carrier=0.0, rem_code=0.0,
+              code_step=0.25575)
+    for bad in (dict(code_slot=1), dict(code_slot=5), dict(n_samples=0), dict(n_samples=9000),
+                dict(start_sample=-1), dict(code_step=0.0), dict(rem_code=float("nan")), dict(rem_code=-30.0),
+                dict(code_step=0.3)):
+        with pytest.raises(SdrError):
+            engine.epl_batch(make_items(**{**ok, **bad}), (-0.5, 0.0, 0.5), 4e6)
+    with pytest.raises(SdrError):
+        engine.epl_batch(make_items(**ok), tuple(np.linspace(-1, 1, 9)), 4e6)
+
+
+def test_epl_plan_is_deterministic(engine):
+    """Same plan run twice -> bit-identical outputs (fixed reduction order; needed for N-GPU == 1-GPU)."""
+    rng = np.random.default_rng(12)
+    fs, cap = 25e6, 8 * 12500
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(rng.integers(-100, 100, 2 * cap).astype(np.int8), 0)
+    engine.code_slots(4)
+    for s in range(4):
+        engine.load_gps_code(s, 10 + s)
+    items = make_items(np.arange(64) % 4, 25000, rng.integers(0, cap, 64), 100.0, 0.0, 0.0, 0.04092)
+    plan = engine.epl_plan(items, (-0.5, 0.0, 0.5), fs)
+    plan.run()
+    a = plan.fetch()
+    plan.run()
+    b = plan.fetch()
+    plan.close()
+    assert np.array_equal(a, b)
+    # and a permutation of the items permutes the outputs bit for bit
+    perm = rng.permutation(64)
+    c = engine.epl_batch(items[perm], (-0.5, 0.0, 0.5), fs)
+    assert np.array_equal(c, a[perm])

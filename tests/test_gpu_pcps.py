@@ -1,0 +1,157 @@
+"""GPU parity: PCPS acquisition + two-peak comparison vs golden vectors captured from the
+reference (peak indices bit-exact, map values / ratio to 1e-9 relative) and vs the oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import sydr_oracle as orc
+from sydr_amd.engine import FMT_CF64, FMT_CI8
+
+pytestmark = pytest.mark.gpu
+
+MAP_RTOL = 1e-9
+
+
+def _stage(engine, raw, prns, fmt=FMT_CI8, start=0, capacity=None):
+    n = raw.size // 2
+    cap = capacity or ((n + start + 7) // 8) * 8
+    engine.iq_alloc(cap, fmt)
+    engine.iq_upload(raw, start)
+    engine.code_slots(len(prns))
+    for s, p in enumerate(prns):
+        engine.load_gps_code(s, int(p))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
+def test_pcps_golden(engine, tag):
+    g = load_golden("g3_pcps.npz")
+    fs, if_hz, rng_hz, step, coh, noncoh, n, spc = g[f"{tag}_params"]
+    prns = g[f"{tag}_prns"]
+    _stage(engine, g[f"{tag}_iq"], prns)
+    pb, pc, pr, cmap = engine.pcps(np.arange(len(prns)), 0, fs, if_hz, rng_hz, step, int(coh), int(noncoh),
+                                   want_map=True)
+    assert cmap.shape == (len(prns), len(orc.doppler_bins(rng_hz, step)), int(n))
+    for k in range(len(prns)):
+        assert [int(pb[k]), int(pc[k])] == list(g[f"{tag}_peak"][k]), f"case {tag} PRN {prns[k]}"
+        scale = g[f"{tag}_row"][k].max()
+        np.testing.assert_allclose(cmap[k, pb[k]], g[f"{tag}_row"][k], rtol=0, atol=MAP_RTOL * scale)
+        np.testing.assert_allclose(cmap[k, :, pc[k]], g[f"{tag}_col"][k], rtol=0, atol=MAP_RTOL * scale)
+        np.testing.assert_allclose(cmap[k].sum(axis=1), g[f"{tag}_binsum"][k], rtol=MAP_RTOL)
+        assert pr[k] == pytest.approx(float(g[f"{tag}_ratio"][k]), rel=1e-9)
+    # indices-only call (no map transfer) returns the same answer
+    pb2, pc2, pr2, none = engine.pcps(np.arange(len(prns)), 0, fs, if_hz, rng_hz, step, int(coh), int(noncoh))
+    assert none is None and np.array_equal(pb, pb2) and np.array_equal(pc, pc2) and np.array_equal(pr, pr2)
+
+
+def test_two_peak_compare_edge_cases(engine):
+    g = load_golden("g4_peaks.npz")
+    n, bins, spc = (int(v) for v in g["geometry"])
+    for m, idx, ratio in zip(g["maps"], g["idx"], g["ratio"]):
+        got_idx, got_ratio = engine.two_peak_compare(m, spc)
+        assert got_idx == list(idx)
+        assert got_ratio == ratio  # a single fp64 division of two map entries: exact
+
+
+def test_pcps_full_map_vs_oracle_with_ring_offset(engine):
+    """Whole map (every bin) against the oracle; slice starts mid-ring and wraps."""
+    fs, n = 4e6, 4000
+    sats = [dict(prn=14, doppler=-2250.0, code_phase=512.3, phase=0.2, amp=7.0)]
+    raw = orc.synth_iq(fs, 2 * n, sats, 20.0, 4242)
+    cap, start = 8000, 6104
+    ring = np.zeros(2 * cap, dtype=np.int8)
+    lin = np.arange(start, start + 2 * n) % cap
+    ring[2 * lin] = raw[0::2]
+    ring[2 * lin + 1] = raw[1::2]
+    _stage(engine, ring, [14, 2], capacity=cap)
+    pb, pc, pr, cmap = engine.pcps([0, 1], start, fs, 0.0, 5000.0, 250.0, 1, 2, want_map=True)
+    rf = orc.iq_to_complex(raw).reshape(1, -1)
+    for k, prn in enumerate((14, 2)):
+        ref = orc.pcps_map(rf, 0.0, fs, orc.code_spectrum(orc.gold_code(prn), fs), 5000.0, 250.0, n, 1, 2)
+        np.testing.assert_allclose(cmap[k], ref, rtol=0, atol=MAP_RTOL * ref.max())
+        peak, ratio = orc.two_peak_compare(ref, n, 4)
+        assert [int(pb[k]), int(pc[k])] == peak
+        assert pr[k] == pytest.approx(ratio, rel=1e-9)
+
+
+def test_pcps_complex128_ring(engine):
+    rng = np.random.default_rng(3)
+    fs, n = 4e6, 4000
+    rf = rng.normal(0, 9.0, n) + 1j * rng.normal(0, 9.0, n)
+    engine.iq_alloc(n, FMT_CF64)
+    engine.iq_upload(rf, 0)
+    engine.code_slots(1)
+    engine.load_gps_code(0, 8)
+    pb, pc, pr, cmap = engine.pcps([0], 0, fs, 2000.0, 3000.0, 500.0, 1, 1, want_map=True)
+    ref = orc.pcps_map(rf.reshape(1, -1), 2000.0, fs, orc.code_spectrum(orc.gold_code(8), fs), 3000.0, 500.0, n)
+    np.testing.assert_allclose(cmap[0], ref, rtol=0, atol=MAP_RTOL * ref.max())
+    peak, _ = orc.two_peak_compare(ref, n, 4)
+    assert [int(pb[0]), int(pc[0])] == peak
+
+
+@pytest.mark.parametrize("fs", [2.046e6, 3e6, 6e6, 7e6, 12e6])
+def test_pcps_other_transform_sizes(engine, fs):
+    """N = 2046 (2*3*11*31), 3000, 6000, 7000 (7 as a generic radix), 12000 (radix 3)."""
+    n = orc.samples_per_code(fs)
+    sats = [dict(prn=6, doppler=750.0, code_phase=100.5, phase=0.0, amp=9.0)]
+    raw = orc.synth_iq(fs, n, sats, 15.0, 99)
+    _stage(engine, raw, [6])
+    pb, pc, pr, cmap = engine.pcps([0], 0, fs, 0.0, 1000.0, 250.0, 1, 1, want_map=True)
+    ref = orc.pcps_map(orc.iq_to_complex(raw).reshape(1, -1), 0.0, fs, orc.code_spectrum(orc.gold_code(6), fs),
+                       1000.0, 250.0, n)
+    np.testing.assert_allclose(cmap[0], ref, rtol=0, atol=MAP_RTOL * ref.max())
+    peak, ratio = orc.two_peak_compare(ref, n, round(fs / orc.CODE_RATE))
+    assert [int(pb[0]), int(pc[0])] == peak
+
+
+def test_pcps_32_prns_25mhz_properties(engine):
+    """BASELINE config 2 size (32 PRNs, 25 MHz, 41 bins) through size-independent properties:
+    every present PRN is found at its true Doppler bin and code delay; the search is linear in
+    IQ scale (x -> 2x doubles the map, same indices, same ratio)."""
+    fs, n = 25e6, 25000
+    rng = np.random.default_rng(20260002)
+    prns = list(range(1, 33))
+    sats = [dict(prn=p, doppler=float(rng.integers(-18, 19) * 250.0), code_phase=float(rng.uniform(0, 1023)),
+                 phase=float(rng.random()), amp=3.0) for p in prns]
+    engine.iq_alloc(n, FMT_CI8)
+    engine.code_slots(32)
+    for s, p in enumerate(prns):
+        engine.load_gps_code(s, p)
+    engine.iq_synth(sats, fs, 12.0, 777, 0, n)
+    raw = engine.iq_download(n, 0)
+    pb, pc, pr, _ = engine.pcps(np.arange(32), 0, fs, 0.0, 5000.0, 250.0, 1, 1)
+    bins = orc.doppler_bins(5000.0, 250.0)
+    for k, s in enumerate(sats):
+        # estimated Doppler = -bin (acquisition.py:42; kaplan:222-224)
+        assert -bins[pb[k]] == s["doppler"], (k, pb[k])
+        expect = ((1023.0 - s["code_phase"]) / (1.023e6 / fs)) % n
+        assert min(abs(pc[k] - expect), n - abs(pc[k] - expect)) <= 1.5, (k, pc[k], expect)
+        assert pr[k] > 1.5
+    # three PRNs cross-checked in full against the oracle on the downloaded bytes
+    rf = orc.iq_to_complex(raw).reshape(1, -1)
+    for k in (0, 13, 31):
+        ref = orc.pcps_map(rf, 0.0, fs, orc.code_spectrum(orc.gold_code(prns[k]), fs), 5000.0, 250.0, n)
+        peak, ratio = orc.two_peak_compare(ref, n, 24)
+        assert [int(pb[k]), int(pc[k])] == peak
+        assert pr[k] == pytest.approx(ratio, rel=1e-9)
+    half = (raw // 2).astype(np.int8)
+    engine.iq_upload(half, 0)
+    b1, c1, r1, _ = engine.pcps(np.arange(32), 0, fs, 0.0, 5000.0, 250.0, 1, 1)
+    engine.iq_upload((2 * half).astype(np.int8), 0)
+    b2, c2, r2, _ = engine.pcps(np.arange(32), 0, fs, 0.0, 5000.0, 250.0, 1, 1)
+    assert np.array_equal(b1, b2) and np.array_equal(c1, c2)
+    np.testing.assert_allclose(r1, r2, rtol=1e-12)
+
+
+def test_pcps_rejects_bad_requests(engine):
+    from sydr_amd import SdrError
+    engine.iq_alloc(4000, FMT_CI8)
+    engine.code_slots(2)
+    engine.load_gps_code(0, 1)
+    with pytest.raises(SdrError):
+        engine.pcps([1], 0, 4e6, 0.0, 5000.0, 250.0)       # slot not staged
+    with pytest.raises(SdrError):
+        engine.pcps([0], 0, 4e6, 0.0, 5000.0, 250.0, 2, 1)  # needs 8000 samples
+    with pytest.raises(SdrError):
+        engine.pcps([0], 0, 4e6, 0.0, 5000.0, 0.0)          # empty grid
+    with pytest.raises(SdrError):
+        engine.pcps([0], 0, 4.079e6, 0.0, 5000.0, 250.0)    # N = 4079 is prime

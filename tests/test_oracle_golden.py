@@ -1,0 +1,195 @@
+"""Pins the CPU oracle (oracle/sydr_oracle.py) to golden vectors captured from the reference
+itself (tests/golden/make_golden.py).  CPU only; runs anywhere."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import sydr_oracle as orc
+
+
+# ------------------------------------------------------------------------------------------------ G1 / G2
+def test_gold_codes_match_reference():
+    g = load_golden("g1_codes.npz")
+    for prn, chips, octal in zip(g["prns"], g["chips"], g["first10"]):
+        code = orc.gold_code(int(prn))
+        assert code.dtype == np.float64
+        assert np.array_equal(code.astype(np.int8), chips), f"PRN {prn}"
+        assert orc.first_10_chips_octal(int(prn)) == int(octal)
+
+
+def test_first_ten_chips_icd_table():
+    # IS-GPS-200 table, PRN 1..10 (also printed by the reference's ca.py:137-149)
+    expect = [0o1440, 0o1620, 0o1710, 0o1744, 0o1133, 0o1455, 0o1131, 0o1454, 0o1626, 0o1504]
+    assert [orc.first_10_chips_octal(p) for p in range(1, 11)] == expect
+
+
+@pytest.mark.parametrize("fs", [4e6, 10e6, 12e6, 25e6, 50e6])
+def test_upsample_index_bit_exact(fs):
+    g = load_golden("g1_codes.npz")
+    ref = g[f"upsample_idx_{int(fs)}"]
+    assert np.array_equal(orc.upsample_index(fs), ref)
+    assert orc.samples_per_code(fs) == len(ref)
+
+
+# ------------------------------------------------------------------------------------------------ G3
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
+def test_pcps_matches_reference(tag):
+    g = load_golden("g3_pcps.npz")
+    fs, if_hz, rng_hz, step, coh, noncoh, n, spc = g[f"{tag}_params"]
+    coh, noncoh, n, spc = int(coh), int(noncoh), int(n), int(spc)
+    rf = orc.iq_to_complex(g[f"{tag}_iq"]).reshape(1, -1)
+    for k, prn in enumerate(g[f"{tag}_prns"]):
+        spec = orc.code_spectrum(orc.gold_code(int(prn)), fs)
+        cmap = orc.pcps_map(rf, if_hz, fs, spec, rng_hz, step, n, coh, noncoh)
+        peak, ratio = orc.two_peak_compare(cmap, n, spc)
+        assert peak == list(g[f"{tag}_peak"][k])
+        # same NumPy primitives in the same order: bit-identical on the build host
+        np.testing.assert_allclose(cmap[peak[0]], g[f"{tag}_row"][k], rtol=1e-13, atol=0)
+        np.testing.assert_allclose(cmap[:, peak[1]], g[f"{tag}_col"][k], rtol=1e-13, atol=0)
+        np.testing.assert_allclose(cmap.sum(axis=1), g[f"{tag}_binsum"][k], rtol=1e-13)
+        assert ratio == pytest.approx(float(g[f"{tag}_ratio"][k]), rel=1e-13)
+
+
+def test_doppler_grid_lengths():
+    # float range/step -> 41 bins @250, 101 @100, 34 @300 (asymmetric)
+    assert len(orc.doppler_bins(5000.0, 250.0)) == 41
+    assert len(orc.doppler_bins(5000.0, 100.0)) == 101
+    b = orc.doppler_bins(5000.0, 300.0)
+    assert len(b) == 34 and b[-1] == 4900.0
+
+
+# ------------------------------------------------------------------------------------------------ G4
+def test_two_peak_compare_edge_cases():
+    g = load_golden("g4_peaks.npz")
+    n, bins, spc = (int(v) for v in g["geometry"])
+    for m, idx, ratio in zip(g["maps"], g["idx"], g["ratio"]):
+        got_idx, got_ratio = orc.two_peak_compare(m.copy(), n, spc)
+        assert got_idx == list(idx)
+        assert got_ratio == ratio
+
+
+# ------------------------------------------------------------------------------------------------ G5 / G8
+def test_epl_reference_fixture():
+    """The reference's own unit-test input (sydr/unitTest/data/i_rfdata.txt: PRN 2, 3700 Hz, 10 MHz)."""
+    g = load_golden("g5_epl.npz")
+    prn, fs, f, rc, rk, step = g["fixture_params"]
+    rf = orc.iq_to_complex(g["fixture_iq"])
+    out = orc.epl(rf, orc.pad_code(orc.gold_code(int(prn))), fs, f, rc, rk, step, (-0.5, 0.0, 0.5))
+    assert np.array_equal(np.array(out), g["fixture_out"])
+    # values quoted in SURVEY.md 8c (probe of the reference)
+    np.testing.assert_allclose(out, [-209.48629766813846, -4378.819831485676, -2771.533819861607,
+                                     -2997.4691729749657, -924.5637349695502, -3715.3502647689807], rtol=1e-12)
+
+
+def test_epl_random_cases():
+    g = load_golden("g5_epl.npz")
+    for tag in g["cases"]:
+        prn, fs, f, rc, rk, step, n = g[f"{tag}_params"]
+        rf = orc.iq_to_complex(g[f"{tag}_iq"])
+        assert len(rf) == int(n)
+        sp = tuple(g[f"{tag}_spacing"])
+        out = orc.epl(rf, orc.pad_code(orc.gold_code(int(prn))), fs, f, rc, rk, step, sp)
+        assert np.array_equal(np.array(out), g[f"{tag}_out"]), tag
+        for t, s in enumerate(sp):
+            assert np.array_equal(orc.epl_indices(int(n), rk, step, s), g[f"{tag}_idx"][t]), tag
+
+
+def test_epl_periodic_extension_reduces_to_padded_table():
+    """The oracle's generalisation (taps beyond +-1 chip wrap periodically) must not change E/P/L."""
+    g = load_golden("g5_epl.npz")
+    prn, fs, f, rc, rk, step, n = g["r10_params"]
+    rf = orc.iq_to_complex(g["r10_iq"])
+    code = orc.pad_code(orc.gold_code(int(prn)))
+    five = orc.epl(rf, code, fs, f, rc, rk, step, (-1.0, -0.5, 0.0, 0.5, 1.0))
+    assert np.array_equal(np.array(five[2:8]), g["r10_out"])
+
+
+def test_replica_known_answers():
+    """sydr/c_functions/tracking.c:243-247: fs=1e7, f=-1500 Hz, 5 samples, eps 1e-8."""
+    g = load_golden("g5_epl.npz")
+    truth = np.array([1 + 0j, 0.9999995558678348 + 0.000942477656548699j, 0.9999982234717338 + 0.0018849544759281136j,
+                      0.9999960028128805 + 0.002827429620969703j, 0.9999928938932473 + 0.0037699022545064132j])
+    assert np.max(np.abs(g["replica_known"] - truth)) < 1e-8
+    # our EPL with a constant +1 "code" and unit samples reproduces the replica sum
+    ones = np.ones(5, dtype=complex)
+    out = orc.epl(ones, np.ones(1025), 1e7, -1500.0, 0.0, 0.0, 0.1, (0.0,))
+    assert complex(out[0], out[1]) == pytest.approx(truth.sum(), rel=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ G7
+def test_scalar_loop_math():
+    g = load_golden("g7_loopmath.npz")
+    c = g["inputs"]
+    with np.errstate(all="ignore"):
+        for k, r in enumerate(c):
+            assert orc.dll_nneml(r[0], r[1], r[4], r[5]) == g["dll"][k]
+            np.testing.assert_equal(orc.pll_costas(r[2], r[3]), g["pll"][k])
+            np.testing.assert_equal(orc.fll_atan(r[2], r[3], r[6], r[7], 1e-3), g["fll"][k])
+            np.testing.assert_equal(orc.fll_lock_borre(r[2], r[6], r[3], r[7], 0.3, alpha=0.005), g["fll_lock"][k])
+            np.testing.assert_equal(orc.pll_lock_borre(r[2], r[3], 0.4, alpha=0.005), g["pll_lock"][k])
+            assert orc.cn0_beaulieu(abs(r[0]) * 1e-3 + 1.0, 20, 20e-3, abs(r[1]) * 1e-3) == g["cn0"][k]
+            assert orc.borre_filter(r[0] * 1e-5, r[1] * 1e-5, g["coeff"][0, 0], g["coeff"][0, 1], 0.001) == \
+                g["borre_filter"][k]
+            assert list(orc.fll_assisted_pll_2nd(r[0] * 1e-6, r[1] * 1e-3, 100.0 / 0.25, 25.0 / 0.53, 1.414, 1e-3,
+                                                 r[2] * 1e-4)) == list(g["fll_pll"][k])
+    for k, (b, z, gain) in enumerate(((2.0, 0.7, 1.0), (1.0, 0.7, 1.0), (8.0, 0.7, 0.25), (15.0, 0.7, 1.5))):
+        assert list(orc.loop_coefficients(b, z, gain)) == list(g["coeff"][k])
+
+
+# ------------------------------------------------------------------------------------------------ G6
+BORRE_CFG = dict(correlator_early=-0.5, correlator_prompt=0.0, correlator_late=0.5, dll_damping_ratio=0.7,
+                 dll_noise_bandwidth=1.0, dll_loop_gain=1.0, dll_pdi=0.001, pll_damping_ratio=0.7,
+                 pll_noise_bandwidth=8.0, pll_loop_gain=0.25, pll_pdi=0.001)
+KAPLAN_CFG = dict(correlator_epl_wide=0.5, correlator_epl_narrow=0.5, dll_threshold=10.0, dll_damping_ratio=0.7,
+                  dll_noise_bandwidth=2.0, dll_loop_gain=1.0, dll_pdi=0.001, pll_bandwidth_wide=25.0,
+                  pll_bandwidth_narrow=15.0, pll_threshold_wide=0.5, pll_threshold_narrow=0.8,
+                  fll_bandwidth_pullin=100.0, fll_bandwidth_wide=50.0, fll_bandwidth_narrow=15.0,
+                  fll_threshold_wide=0.5, fll_threshold_narrow=0.8)
+
+
+def trajectory_iq():
+    g = load_golden("g6_trajectories.npz")
+    fs, n, prn, dop, cph, ph, amp, sigma, seed = g["synth"]
+    raw = orc.synth_iq(fs, int(n), [dict(prn=int(prn), doppler=dop, code_phase=cph, phase=ph, amp=amp)], sigma,
+                       int(seed))
+    digest = np.frombuffer(hashlib.sha256(raw.tobytes()).digest(), dtype=np.uint8)
+    assert np.array_equal(digest, g["iq_sha256"]), "seeded IQ differs from the one the golden run used"
+    return g, fs, raw
+
+
+@pytest.mark.parametrize("plugin", ["borre", "kaplan"])
+def test_closed_loop_trajectory(plugin):
+    """BASELINE config 1: 1 channel, 4 MHz, 1 ms PCPS + ~500 ms tracking, vs the reference plugin."""
+    g, fs, raw = trajectory_iq()
+    rf = orc.iq_to_complex(raw)
+    n_code, spc = orc.samples_per_code(fs), round(fs / orc.CODE_RATE)
+    code = orc.gold_code(7)
+    cmap = orc.pcps_map(rf[:n_code].reshape(1, -1), 0.0, fs, orc.code_spectrum(code, fs), 5000.0, 250.0, n_code)
+    peak, ratio = orc.two_peak_compare(cmap, n_code, spc)
+    acq = g[f"{plugin}_acq"]
+    assert peak == [int(acq[0]), int(acq[1])]
+    assert ratio == pytest.approx(acq[2], rel=1e-13)
+    track0 = orc.required_samples(0.0, orc.CODE_RATE / fs)
+    assert track0 == 4001
+    carrier, offset, cur = orc.post_acquisition(0.0, 5000.0, 250.0, peak, 0, n_code, track0)
+    assert (carrier, offset, cur, track0) == (acq[3], int(acq[4]), int(acq[5]), int(acq[6]))
+
+    loop = (orc.BorreLoop(fs, code, BORRE_CFG, carrier, cur) if plugin == "borre"
+            else orc.KaplanLoop(fs, code, KAPLAN_CFG, carrier, cur))
+    ref = g[f"{plugin}_epochs"]
+    ring = 100 * int(fs * 1e-3)
+    for k, row in enumerate(ref):
+        # the reference indexes a 100 ms ring; absolute position = ring index + wraps
+        assert loop.current_sample % ring == int(row[0]), k
+        assert loop.n == int(row[1]), k
+        assert (loop.carrier_hz, loop.rem_carrier, loop.rem_code, loop.code_step) == tuple(row[2:6]), k
+        rec = loop.step(rf[loop.current_sample:loop.current_sample + loop.n])
+        assert rec["corr"] == list(row[6:12]), k
+        assert rec["carrier_hz"] == row[15] and rec["code_hz"] == row[16], k
+        if plugin == "kaplan":
+            assert (rec["dll"], rec["pll"], rec["fll"]) == tuple(row[12:15]), k
+            np.testing.assert_equal([rec["cn0"], rec["pll_lock"], rec["fll_lock"]], row[19:22])
+            assert (rec["lock_state"], rec["flags"]) == (int(row[22]), int(row[23])), k
+    assert len(ref) >= 500
