@@ -96,6 +96,44 @@ def cpu_tracking_baseline(engine, items, n_items, budget_s):
     return out[:done], done, dt, rf
 
 
+def closed_loop_leg(eng, items, n_epochs):
+    """On-device loop closure (persistent workgroup per channel, Kaplan loops): latency-bound, so it is
+    reported beside, not instead of, the open-loop correlator throughput."""
+    from sydr_amd._lib import LoopCfg, TrackState
+    cfg = LoopCfg()
+    cfg.loop_kind, cfg.n_taps, cfg.fs = 1, 3, FS
+    for t, s in enumerate(SPACING):
+        cfg.spacing_wide[t] = cfg.spacing_narrow[t] = s
+    wn = 2.0 * 8.0 * 0.7 / (4.0 * 0.7**2 + 1)              # channel_GPS_L1CA_kaplan.ini DLL: 2 Hz, zeta 0.7, gain 1
+    cfg.dll_tau1, cfg.dll_tau2, cfg.dll_pdi, cfg.dll_threshold = 1.0 / wn**2, 2.0 * 0.7 / wn, 0.001, 10.0
+    cfg.fll_bw_pullin, cfg.fll_bw_wide, cfg.fll_bw_narrow, cfg.fll_thr_wide, cfg.fll_thr_narrow = 100.0, 50.0, 15.0, 0.5, 0.8
+    cfg.pll_bw_wide, cfg.pll_bw_narrow, cfg.pll_thr_wide, cfg.pll_thr_narrow = 25.0, 15.0, 0.5, 0.8
+    states = []
+    for c in range(N_CH):
+        it = items[c]
+        st = TrackState()
+        st.code_slot, st.n_samples, st.current_sample = int(it["code_slot"]), int(it["n_samples"]), int(it["start_sample"])
+        st.carrier_hz, st.code_hz = float(it["carrier_hz"]), CODE_RATE
+        st.rem_carrier, st.rem_code, st.code_step = float(it["rem_carrier"]), float(it["rem_code"]), CODE_RATE / FS
+        st.fll_bw, st.pll_bw, st.lock_state = 100.0, 25.0, 1
+        states.append(st)
+    eng.track_closed_loop([TrackState.from_buffer_copy(s) for s in states], cfg, 50, want_traj=False)  # warm
+    eng.prof_reset()
+    eng.prof_enable(True)
+    t0 = time.perf_counter()
+    end, _ = eng.track_closed_loop(states, cfg, n_epochs, want_traj=False)
+    wall = time.perf_counter() - t0
+    eng.prof_enable(False)
+    kern_ms, _ = eng.prof_read("track_kernel")
+    eng.prof_reset()
+    samples = float(np.mean([e.current_sample - s.current_sample for e, s in zip(end, states)]))
+    lost = sum(abs(e.carrier_hz - s.carrier_hz) > 100.0 for e, s in zip(end, states))
+    return {"metric": "closed-loop tracking, 32 channels, loop closure on device (Kaplan FLL/PLL/DLL)",
+            "epochs": n_epochs, "kernel_ms": kern_ms, "wall_ms": wall * 1e3,
+            "x_realtime": samples / FS / (kern_ms * 1e-3), "Msamples_per_s": samples / (kern_ms * 1e-3) / 1e6,
+            "us_per_epoch": kern_ms * 1e3 / n_epochs, "channels_lost": int(lost)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +142,8 @@ def main():
     ap.add_argument("--stream-seconds", type=float, default=60.0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-acquisition", action="store_true")
+    ap.add_argument("--no-closed-loop", action="store_true")
+    ap.add_argument("--closed-loop-epochs", type=int, default=2000)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -236,6 +276,8 @@ def main():
                                      "ms_total_32_prn": acq_ms, "cpu_ms_per_prn_1core": cpu_ms,
                                      "algorithmic_GBps": N_CH * bins * 40.0 * n_code / (acq_ms * 1e-3) / 1e9,
                                      "peaks_match_oracle": bool(ok)}
+    if rank == 0 and world == 1 and not args.no_closed_loop:
+        result["closed_loop"] = closed_loop_leg(eng, items, min(n_epochs, args.closed_loop_epochs))
     plan.close()
     eng.close()
     if rank == 0:

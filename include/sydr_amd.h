@@ -165,6 +165,13 @@ int sdr_pcps(sdr_engine* e, const int32_t* code_slots, int n_prn, int64_t start_
              double if_hz, double doppler_range, double doppler_step, int coh, int noncoh,
              int64_t* peak_bin, int64_t* peak_code, double* peak_ratio, double* corr_map,
              int* n_bins_out);
+/* Same search with caller-supplied code spectra: code_spectra[n_prn][n_code] interleaved
+ * complex128 = the `codeFFT` argument of the reference's PCPS() (acquisition.py:9; built as
+ * conj(fft(UpsampleCode(code))) at channel_l1ca_kaplan.py:184-185).  Function-level drop-in. */
+int sdr_pcps_spectra(sdr_engine* e, const double* code_spectra, int n_prn, int n_code,
+                     int64_t start_sample, double fs, double if_hz, double doppler_range,
+                     double doppler_step, int coh, int noncoh, int64_t* peak_bin, int64_t* peak_code,
+                     double* peak_ratio, double* corr_map, int* n_bins_out);
 /* len(np.arange(-range, range+1, step)) for float range/step. */
 int sdr_pcps_bins(double doppler_range, double doppler_step);
 /* TwoCorrelationPeakComparison alone on a caller-supplied map[n_bins][n_code] (row-major

@@ -115,6 +115,8 @@ _PROTOTYPES = {
     "sdr_epl_plan_destroy": (None, [_VP, _VP]),
     "sdr_pcps": (C.c_int, [_VP, _VP, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
                            C.c_int, C.c_int, _VP, _VP, _VP, _VP, C.POINTER(C.c_int)]),
+    "sdr_pcps_spectra": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                   C.c_double, C.c_int, C.c_int, _VP, _VP, _VP, _VP, C.POINTER(C.c_int)]),
     "sdr_pcps_bins": (C.c_int, [C.c_double, C.c_double]),
     "sdr_two_peak_compare": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64),
                                        C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -200,7 +200,7 @@ int sdr_code_gps_l1ca(sdr_engine* e, int slot, int prn) {
 int sdr_code_custom(sdr_engine* e, int slot, const int8_t* chips, int n_chips) {
     if (int rc = sdr_set_device(e)) return rc;
     if (int rc = check_slot(e, slot)) return rc;
-    if (!chips || n_chips < 1 || n_chips > e->code_stride)
+    if (!chips || n_chips < 16 || n_chips > e->code_stride)
         return sdr_fail(SDR_ERR_INVALID, "custom code of %d chips does not fit a %d-chip slot", n_chips,
                         e->code_stride);
     for (int i = 0; i < n_chips; ++i)

@@ -15,92 +15,14 @@
 // 8-sample group in fp64 (exact range reduction + libm-grade sincos) and
 // advanced inside the group by 8 precomputed fp64 rotations, which agrees with
 // the reference to ~1e-12 rad (far inside the 1e-6 relative bar on accumulators).
-#include "engine_internal.h"
-
-#include <cmath>
-
-#pragma clang fp contract(off)
+#include "correlator.h"
 
 namespace {
 
+using namespace sdr;
+
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kGroup = 8;  // samples per lane per iteration
-
-constexpr double kTwoPiHi = 6.283185307179586232e+00;   // fl(2*pi)
-constexpr double kTwoPiLo = 2.449293598294706414e-16;   // 2*pi - fl(2*pi)
-constexpr double kInvTwoPi = 1.591549430918953456e-01;
-
-__device__ __forceinline__ void sincos_reduced(double ph, double* s, double* c) {
-    // ph may be thousands of radians (non-zero IF): remove whole turns exactly first.
-    double k = rint(ph * kInvTwoPi);
-    double r = fma(-k, kTwoPiHi, ph);
-    r = fma(-k, kTwoPiLo, r);
-    sincos(r, s, c);
-}
-
-template <int FMT>
-struct Loader;
-
-template <>
-struct Loader<SDR_FMT_CI8> {
-    static __device__ __forceinline__ void load(const void* ring, int64_t pos, double* xr, double* xi) {
-        const int4 v = *reinterpret_cast<const int4*>(static_cast<const char*>(ring) + pos * 2);
-        const int w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            xr[2 * d] = (double)(int)(int8_t)(w[d]);
-            xi[2 * d] = (double)(int)(int8_t)(w[d] >> 8);
-            xr[2 * d + 1] = (double)(int)(int8_t)(w[d] >> 16);
-            xi[2 * d + 1] = (double)(w[d] >> 24);
-        }
-    }
-};
-
-template <>
-struct Loader<SDR_FMT_CI16> {
-    static __device__ __forceinline__ void load(const void* ring, int64_t pos, double* xr, double* xi) {
-        const int4* p = reinterpret_cast<const int4*>(static_cast<const char*>(ring) + pos * 4);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int4 v = p[h];
-            const int w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                xr[4 * h + d] = (double)(int)(int16_t)(w[d]);
-                xi[4 * h + d] = (double)(w[d] >> 16);
-            }
-        }
-    }
-};
-
-template <>
-struct Loader<SDR_FMT_CF32> {
-    static __device__ __forceinline__ void load(const void* ring, int64_t pos, double* xr, double* xi) {
-        const float4* p = reinterpret_cast<const float4*>(static_cast<const char*>(ring) + pos * 8);
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const float4 v = p[h];
-            xr[2 * h] = v.x;
-            xi[2 * h] = v.y;
-            xr[2 * h + 1] = v.z;
-            xi[2 * h + 1] = v.w;
-        }
-    }
-};
-
-template <>
-struct Loader<SDR_FMT_CF64> {
-    static __device__ __forceinline__ void load(const void* ring, int64_t pos, double* xr, double* xi) {
-        const double2* p = reinterpret_cast<const double2*>(static_cast<const char*>(ring) + pos * 16);
-#pragma unroll
-        for (int h = 0; h < 8; ++h) {
-            const double2 v = p[h];
-            xr[h] = v.x;
-            xi[h] = v.y;
-        }
-    }
-};
 
 // Dynamic LDS: [rot: 16 doubles][red: kWaves*2*NT doubles][lut: lut_words uint32]
 template <int FMT, int NT>
@@ -118,122 +40,26 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
 
     const int tid = threadIdx.x;
     const sdr_epl_item it = items[blockIdx.x];
-    const int n = it.n_samples;
-    const int L = code_len[it.code_slot];
-
-    // Stage the PRN replica: lut[q] = chip[(q - PAD - 1) mod L] as the high word of +-1.0.
-    {
-        const int8_t* chips = codes + (size_t)it.code_slot * code_stride;
-        const int words = L + 2 * SDR_LUT_PAD + 2;
-        for (int q = tid; q < words; q += kThreads) {
-            int c = q - SDR_LUT_PAD - 1;
-            c %= L;
-            if (c < 0) c += L;
-            lut[q] = chips[c] > 0 ? 0x3FF00000u : 0xBFF00000u;
-        }
-    }
-
-    // Per-sample carrier advance inside a group: rot_j = exp(-1j*j*dphi).
-    const double w = (it.carrier_hz * 2.0) * M_PI;
-    const double dphi = w / fs;
-    if (tid < kGroup) {
-        double s, c;
-        sincos_reduced(-(double)tid * dphi, &s, &c);
-        rot[2 * tid] = c;
-        rot[2 * tid + 1] = s;
-    }
+    stage_lut<kThreads>(lut, codes + (size_t)it.code_slot * code_stride, code_len[it.code_slot], tid);
+    const double dphi = carrier_step(it.carrier_hz, fs);
+    stage_rotations(rot, dphi, tid);
     __syncthreads();
-    double rc[kGroup], rs[kGroup];
-#pragma unroll
-    for (int j = 0; j < kGroup; ++j) {
-        rc[j] = rot[2 * j];
-        rs[j] = rot[2 * j + 1];
-    }
 
-    // np.linspace(shift, code_step*n + shift, n, endpoint=False) per tap.
-    const double nd = (double)n;
-    double shift[NT], step[NT];
+    EpochParams ep;
+    ep.start_sample = it.start_sample;
+    ep.n = it.n_samples;
+    ep.carrier_hz = it.carrier_hz;
+    ep.rem_carrier = it.rem_carrier;
+    ep.rem_code = it.rem_code;
+    ep.code_step = it.code_step;
+    double sp[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        shift[t] = it.rem_code + spacing[tap0 + t];
-        double stop = it.code_step * nd;
-        stop = stop + shift[t];
-        double delta = stop - shift[t];
-        step[t] = delta / nd;
-    }
+    for (int t = 0; t < NT; ++t) sp[t] = spacing[tap0 + t];
 
     double accr[NT], acci[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) accr[t] = acci[t] = 0.0;
-
-    const int64_t aligned = it.start_sample & ~(int64_t)(kGroup - 1);
-    const int head = (int)(it.start_sample - aligned);
-    const int n_groups = (head + n + kGroup - 1) / kGroup;
-    const int64_t base = aligned % capacity;
-
-    for (int g = tid; g < n_groups; g += kThreads) {
-        int64_t pos = base + (int64_t)g * kGroup;
-        if (pos >= capacity) pos -= capacity;
-        double xr[kGroup], xi[kGroup];
-        Loader<FMT>::load(ring, pos, xr, xi);
-
-        const int i0 = g * kGroup - head;
-        double sb, cb;
-        sincos_reduced(fma(-(double)i0, dphi, it.rem_carrier), &sb, &cb);
-
-        double gr[NT], gi[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) gr[t] = gi[t] = 0.0;
-
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) {
-            const int i = i0 + j;
-            const bool valid = (unsigned)i < (unsigned)n;
-            const double ar = valid ? xr[j] : 0.0;
-            const double ai = valid ? xi[j] : 0.0;
-            const double zr = ar * rc[j] - ai * rs[j];
-            const double zi = ar * rs[j] + ai * rc[j];
-            const int ic = i < 0 ? 0 : (i >= n ? n - 1 : i);
-            const double di = (double)ic;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                double y = di * step[t];
-                y = y + shift[t];
-                const int p = (int)ceil(y);
-                const double c = __hiloint2double((int)lut[p + SDR_LUT_PAD], 0);
-                gr[t] += c * zr;
-                gi[t] += c * zi;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            accr[t] += cb * gr[t] - sb * gi[t];
-            acci[t] += cb * gi[t] + sb * gr[t];
-        }
-    }
-
-    // Wavefront shuffle reduction (64 lanes), then the 4 waves through LDS.
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        double a = accr[t], b = acci[t];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            a += __shfl_down(a, off, 64);
-            b += __shfl_down(b, off, 64);
-        }
-        if (lane == 0) {
-            red[wave * 2 * NT + 2 * t] = a;
-            red[wave * 2 * NT + 2 * t + 1] = b;
-        }
-    }
-    __syncthreads();
-    if (tid < 2 * NT) {
-        double s = red[tid];
-#pragma unroll
-        for (int wv = 1; wv < kWaves; ++wv) s += red[wv * 2 * NT + tid];
-        out[(size_t)blockIdx.x * 2 * n_taps_total + 2 * tap0 + tid] = s;
-    }
+    correlate_epoch<FMT, NT, kThreads>(ring, capacity, ep, sp, dphi, rot, lut, tid, accr, acci);
+    const double total = reduce_taps<NT, kThreads>(accr, acci, red, tid);
+    if (tid < 2 * NT) out[(size_t)blockIdx.x * 2 * n_taps_total + 2 * tap0 + tid] = total;
 }
 
 template <int FMT, int NT>

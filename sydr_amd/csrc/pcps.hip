@@ -437,7 +437,7 @@ void run_fft(sdr_engine* e, const std::vector<int>& radices, PassArgs a, int bat
 template <int FMT>
 int pcps_run(sdr_engine* e, const int32_t* d_slots, int n_prn, int64_t start, double fs, double if_hz,
              double bin_start, double bin_delta, int nbins, int N, int spc, int coh, int noncoh,
-             const std::vector<int>& radices, int prn_chunk) {
+             const std::vector<int>& radices, int prn_chunk, bool have_spectra) {
     double2* F = (double2*)e->pcps_fwd.ptr;
     double2* A = (double2*)e->pcps_a.ptr;
     double2* B = (double2*)e->pcps_b.ptr;
@@ -446,8 +446,9 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, int n_prn, int64_t start, do
     double2* csum = (double2*)e->pcps_csum.ptr;
     const double2* tw = (const double2*)e->pcps_tw.ptr;
 
-    // K7/a3: upsample every code and take conj(fft(code)) (channel_l1ca_kaplan.py:184-185).
-    {
+    // K7/a3: upsample every code and take conj(fft(code)) (channel_l1ca_kaplan.py:184-185),
+    // unless the caller handed in its own codeFFT arrays (function-level drop-in of PCPS()).
+    if (!have_spectra) {
         int8_t* up = (int8_t*)B;  // scratch: n_prn*N bytes fits easily in a work buffer
         {
             ProfScope ps(e, "pcps_upsample");
@@ -563,20 +564,21 @@ int sdr_two_peak_compare(sdr_engine* e, const double* corr_map, int n_bins, int 
     return SDR_OK;
 }
 
-int sdr_pcps(sdr_engine* e, const int32_t* code_slots, int n_prn, int64_t start_sample, double fs, double if_hz,
-             double doppler_range, double doppler_step, int coh, int noncoh, int64_t* peak_bin,
-             int64_t* peak_code, double* peak_ratio, double* corr_map, int* n_bins_out) {
+static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* code_spectra, int n_code_in, int n_prn,
+                     int64_t start_sample, double fs, double if_hz, double doppler_range, double doppler_step,
+                     int coh, int noncoh, int64_t* peak_bin, int64_t* peak_code, double* peak_ratio,
+                     double* corr_map, int* n_bins_out) {
     if (int rc = sdr_set_device(e)) return rc;
     if (!e->iq) return sdr_fail(SDR_ERR_STATE, "IQ ring not allocated");
-    if (!e->codes) return sdr_fail(SDR_ERR_STATE, "code slots not allocated");
-    if (!code_slots || n_prn <= 0) return sdr_fail(SDR_ERR_INVALID, "no PRN to search");
+    if (!code_spectra && !e->codes) return sdr_fail(SDR_ERR_STATE, "code slots not allocated");
+    if ((!code_slots && !code_spectra) || n_prn <= 0) return sdr_fail(SDR_ERR_INVALID, "no PRN to search");
     if (!peak_bin || !peak_code || !peak_ratio) return sdr_fail(SDR_ERR_INVALID, "NULL peak outputs");
     if (!(fs > 0.0) || coh < 1 || noncoh < 1) return sdr_fail(SDR_ERR_INVALID, "bad fs / integration counts");
     const int nbins = sdr_pcps_bins(doppler_range, doppler_step);
     if (nbins <= 0) return sdr_fail(SDR_ERR_INVALID, "empty Doppler grid");
     if (n_bins_out) *n_bins_out = nbins;
     // samplesPerCode / samplesPerCodeChip (channel_l1ca_kaplan.py:186,205-206), Python round = half-even
-    const int64_t N64 = (int64_t)std::nearbyint(fs * 1023.0 / 1.023e6);
+    const int64_t N64 = code_spectra ? (int64_t)n_code_in : (int64_t)std::nearbyint(fs * 1023.0 / 1.023e6);
     const int spc = (int)std::nearbyint(fs / 1.023e6);
     if (N64 < 2 || N64 > (1 << 24)) return sdr_fail(SDR_ERR_UNSUPPORTED, "samples per code %lld unsupported", (long long)N64);
     const int N = (int)N64;
@@ -587,7 +589,7 @@ int sdr_pcps(sdr_engine* e, const int32_t* code_slots, int n_prn, int64_t start_
     if (start_sample < 0 || need > e->iq_capacity)
         return sdr_fail(SDR_ERR_RANGE, "acquisition needs %lld samples, ring holds %lld", (long long)need,
                         (long long)e->iq_capacity);
-    for (int i = 0; i < n_prn; ++i)
+    for (int i = 0; i < n_prn && !code_spectra; ++i)
         if (code_slots[i] < 0 || code_slots[i] >= e->n_slots || e->code_len_host[code_slots[i]] <= 0)
             return sdr_fail(SDR_ERR_INVALID, "PRN entry %d: code slot %d is not staged", i, code_slots[i]);
 
@@ -614,17 +616,21 @@ int sdr_pcps(sdr_engine* e, const int32_t* code_slots, int n_prn, int64_t start_
         e->pcps_tw_n = N;
     }
     int32_t* d_slots = (int32_t*)((char*)e->pcps_res.ptr + (size_t)n_prn * 3 * sizeof(double));
-    SDR_HIP(hipMemcpyAsync(d_slots, code_slots, n_prn * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    if (code_spectra)
+        SDR_HIP(hipMemcpyAsync(e->pcps_code.ptr, code_spectra, tbytes * n_prn, hipMemcpyHostToDevice, e->stream));
+    else
+        SDR_HIP(hipMemcpyAsync(d_slots, code_slots, n_prn * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    const bool hs = code_spectra != nullptr;
 
     // np.arange(-R, R+1, S): element k = start + k*delta with delta = (start+step) - start
     const double bin_start = -doppler_range;
     const double bin_delta = (bin_start + doppler_step) - bin_start;
 
     switch (e->iq_fmt) {
-        case SDR_FMT_CI8: rc = pcps_run<SDR_FMT_CI8>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk); break;
-        case SDR_FMT_CI16: rc = pcps_run<SDR_FMT_CI16>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk); break;
-        case SDR_FMT_CF32: rc = pcps_run<SDR_FMT_CF32>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk); break;
-        default: rc = pcps_run<SDR_FMT_CF64>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk); break;
+        case SDR_FMT_CI8: rc = pcps_run<SDR_FMT_CI8>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs); break;
+        case SDR_FMT_CI16: rc = pcps_run<SDR_FMT_CI16>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs); break;
+        case SDR_FMT_CF32: rc = pcps_run<SDR_FMT_CF32>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs); break;
+        default: rc = pcps_run<SDR_FMT_CF64>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs); break;
     }
     if (rc) return rc;
 
@@ -641,6 +647,23 @@ int sdr_pcps(sdr_engine* e, const int32_t* code_slots, int n_prn, int64_t start_
         peak_code[i] = hb[n_prn + i];
     }
     return SDR_OK;
+}
+
+int sdr_pcps(sdr_engine* e, const int32_t* code_slots, int n_prn, int64_t start_sample, double fs, double if_hz,
+             double doppler_range, double doppler_step, int coh, int noncoh, int64_t* peak_bin,
+             int64_t* peak_code, double* peak_ratio, double* corr_map, int* n_bins_out) {
+    if (!code_slots) return sdr_fail(SDR_ERR_INVALID, "code_slots is NULL");
+    return pcps_impl(e, code_slots, nullptr, 0, n_prn, start_sample, fs, if_hz, doppler_range, doppler_step, coh,
+                     noncoh, peak_bin, peak_code, peak_ratio, corr_map, n_bins_out);
+}
+
+int sdr_pcps_spectra(sdr_engine* e, const double* code_spectra, int n_prn, int n_code, int64_t start_sample,
+                     double fs, double if_hz, double doppler_range, double doppler_step, int coh, int noncoh,
+                     int64_t* peak_bin, int64_t* peak_code, double* peak_ratio, double* corr_map,
+                     int* n_bins_out) {
+    if (!code_spectra || n_code < 2) return sdr_fail(SDR_ERR_INVALID, "code_spectra is NULL or too short");
+    return pcps_impl(e, nullptr, code_spectra, n_code, n_prn, start_sample, fs, if_hz, doppler_range, doppler_step,
+                     coh, noncoh, peak_bin, peak_code, peak_ratio, corr_map, n_bins_out);
 }
 
 }  // extern "C"

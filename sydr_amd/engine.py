@@ -132,6 +132,7 @@ class Engine:
     def code_slots(self, n_slots: int, max_chips: int = 1023):
         check(self._lib.sdr_code_slots(self._h, int(n_slots), int(max_chips)))
         self.n_slots = int(n_slots)
+        self.code_generation = getattr(self, "code_generation", 0) + 1  # staged codes are gone
 
     def load_gps_code(self, slot: int, prn: int):
         check(self._lib.sdr_code_gps_l1ca(self._h, int(slot), int(prn)))
@@ -178,6 +179,22 @@ class Engine:
         check(self._lib.sdr_pcps(self._h, ptr(slots), n, int(start_sample), float(fs), float(if_hz),
                                  float(doppler_range), float(doppler_step), int(coh), int(noncoh), ptr(pb),
                                  ptr(pc), ptr(pr), ptr(cmap) if want_map else None, C.byref(nb)))
+        return pb, pc, pr, cmap
+
+    def pcps_spectra(self, code_spectra, start_sample, fs, if_hz, doppler_range, doppler_step, coh=1, noncoh=1,
+                     want_map=True):
+        """PCPS with caller-supplied codeFFT rows (complex128 [n_prn][n_code]) -- the reference's PCPS() signature."""
+        spec = np.ascontiguousarray(np.atleast_2d(code_spectra), dtype=np.complex128)
+        n, n_code = spec.shape
+        nbins = self._lib.sdr_pcps_bins(float(doppler_range), float(doppler_step))
+        pb = np.empty(n, dtype=np.int64)
+        pc = np.empty(n, dtype=np.int64)
+        pr = np.empty(n, dtype=np.float64)
+        cmap = np.empty((n, nbins, n_code), dtype=np.float64) if want_map else None
+        nb = C.c_int(0)
+        check(self._lib.sdr_pcps_spectra(self._h, ptr(spec), n, n_code, int(start_sample), float(fs), float(if_hz),
+                                         float(doppler_range), float(doppler_step), int(coh), int(noncoh), ptr(pb),
+                                         ptr(pc), ptr(pr), ptr(cmap) if want_map else None, C.byref(nb)))
         return pb, pc, pr, cmap
 
     def two_peak_compare(self, cmap: np.ndarray, samples_per_chip: int):

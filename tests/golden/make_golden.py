@@ -238,22 +238,27 @@ def _channel_config(path, overrides):
     return cfg
 
 
-def make_trajectories():
+def make_trajectories(fname="g6_trajectories.npz", ms=510, amp=8.0, sigma=20.0, seed=20260001,
+                      plugins=("borre", "kaplan"), track_over=None):
     from sydr.channel.channel_l1ca_borre import ChannelL1CA as RefBorre
     from sydr.channel.channel_l1ca_kaplan import ChannelL1CA_Kaplan as RefKaplan
 
     fs = 4e6
-    ms = 510
     spms = int(fs * 1e-3)
-    sats = [dict(prn=7, doppler=1750.0, code_phase=300.25, phase=0.1, amp=8.0)]
-    seed = 20260001
-    raw = orc.synth_iq(fs, ms * spms, sats, 20.0, seed)
+    sats = [dict(prn=7, doppler=1750.0, code_phase=300.25, phase=0.1, amp=amp)]
+    raw = orc.synth_iq(fs, ms * spms, sats, sigma, seed)
     rf = raw[0::2] + 1j * raw[1::2]
     acq_over = {"ACQUISITION": dict(doppler_steps=250, coherent_integration=1, non_coherent_integration=1)}
-    out = dict(iq_sha256=iq_hash(raw), synth=np.array([fs, ms * spms, 7, 1750.0, 300.25, 0.1, 8.0, 20.0, seed]))
+    if track_over:
+        acq_over["TRACKING"] = track_over
+    out = dict(iq_sha256=iq_hash(raw), synth=np.array([fs, ms * spms, 7, 1750.0, 300.25, 0.1, amp, sigma, seed]),
+               track_override_keys=np.array(sorted(track_over or {})),
+               track_override_vals=np.array([float((track_over or {})[k]) for k in sorted(track_over or {})]))
 
     for tag, cls, ini in (("borre", RefBorre, "channel_GPS_L1CA_borre.ini"),
                           ("kaplan", RefKaplan, "channel_GPS_L1CA_kaplan.ini")):
+        if tag not in plugins:
+            continue
         cfg = _channel_config(os.path.join(REF, "config/channels", ini), acq_over)
         rfs = RFSignal(dict(filepath="none", sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0,
                             data_size=8))
@@ -286,7 +291,7 @@ def make_trajectories():
                                      "code_step_in", "ie", "qe", "ip", "qp", "il", "ql", "dll", "pll", "fll",
                                      "carrier_hz", "code_hz", "carrier_err", "code_err", "cn0", "pll_lock",
                                      "fll_lock", "lock_state", "flags"])
-    save("g6_trajectories.npz", **out)
+    save(fname, **out)
 
 
 # ---------------------------------------------------------------------------------------------- G7
@@ -324,5 +329,9 @@ if __name__ == "__main__":
         make_epl()
     if "traj" in which:
         make_trajectories()
+        # strong signal, 1.5 s: drives the Kaplan plugin through PULL_IN -> WIDE -> NARROW, code lock, bit sync
+        make_trajectories("g6b_kaplan_strong.npz", ms=1200, amp=30.0, sigma=10.0, seed=20260611, plugins=("kaplan",),
+                          track_over=dict(fll_threshold_wide=0.3, fll_threshold_narrow=0.7, pll_threshold_narrow=0.7,
+                                          dll_threshold=3.0, correlator_epl_narrow=0.25))
     if "loop" in which:
         make_loopmath()

@@ -122,7 +122,8 @@ def test_pcps_32_prns_25mhz_properties(engine):
     bins = orc.doppler_bins(5000.0, 250.0)
     for k, s in enumerate(sats):
         # estimated Doppler = -bin (acquisition.py:42; kaplan:222-224)
-        assert -bins[pb[k]] == s["doppler"], (k, pb[k])
+        # (a neighbouring 250 Hz bin loses < 1 dB over 1 ms, so noise may pick it: allow one bin)
+        assert abs(-bins[pb[k]] - s["doppler"]) <= 250.0, (k, pb[k])
         expect = ((1023.0 - s["code_phase"]) / (1.023e6 / fs)) % n
         assert min(abs(pc[k] - expect), n - abs(pc[k] - expect)) <= 1.5, (k, pc[k], expect)
         assert pr[k] > 1.5

@@ -1,0 +1,254 @@
+"""GPU parity of the closed-loop tracking kernel, the host plugins on the real engine and the
+function-level drop-ins, against the reference's golden trajectories and the CPU oracle.
+
+Integers (sample indices, epoch lengths, lock states, flags) must match exactly; floating-point
+loop quantities to 1e-9 relative -- the feedback loop is contractive, so the ~1e-15 reduction-order
+differences of the correlators do not grow."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import sydr_oracle as orc
+from test_host_layer import BORRE_INI, KAPLAN_INI, channel_config, drive, rf_signal
+from test_oracle_golden import BORRE_CFG, KAPLAN_CFG, kaplan_strong_cfg, trajectory_iq
+
+from sydr_amd._lib import LoopCfg, TrackState
+from sydr_amd.engine import FMT_CI8
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def loop_cfg(kind, fs, c):
+    cfg = LoopCfg()
+    cfg.loop_kind, cfg.n_taps, cfg.fs = kind, 3, fs
+    cfg.dll_tau1, cfg.dll_tau2 = orc.loop_coefficients(c["dll_noise_bandwidth"], c["dll_damping_ratio"], c["dll_loop_gain"])
+    cfg.dll_pdi = c["dll_pdi"]
+    if kind == 0:
+        sp = [c["correlator_early"], c["correlator_prompt"], c["correlator_late"]]
+        for t in range(3):
+            cfg.spacing_wide[t] = cfg.spacing_narrow[t] = sp[t]
+        cfg.pll_tau1, cfg.pll_tau2 = orc.loop_coefficients(c["pll_noise_bandwidth"], c["pll_damping_ratio"], c["pll_loop_gain"])
+        cfg.pll_pdi = c["pll_pdi"]
+    else:
+        for t, s in enumerate((-1.0, 0.0, 1.0)):
+            cfg.spacing_wide[t] = s * c["correlator_epl_wide"]
+            cfg.spacing_narrow[t] = s * c["correlator_epl_narrow"]
+        cfg.dll_threshold = c["dll_threshold"]
+        cfg.fll_bw_pullin, cfg.fll_bw_wide, cfg.fll_bw_narrow = c["fll_bandwidth_pullin"], c["fll_bandwidth_wide"], c["fll_bandwidth_narrow"]
+        cfg.fll_thr_wide, cfg.fll_thr_narrow = c["fll_threshold_wide"], c["fll_threshold_narrow"]
+        cfg.pll_bw_wide, cfg.pll_bw_narrow = c["pll_bandwidth_wide"], c["pll_bandwidth_narrow"]
+        cfg.pll_thr_wide, cfg.pll_thr_narrow = c["pll_threshold_wide"], c["pll_threshold_narrow"]
+    return cfg
+
+
+def initial_state(kind, fs, carrier, current_sample, c, slot=0):
+    st = TrackState()
+    st.code_slot = slot
+    st.code_step = orc.CODE_RATE / fs
+    st.n_samples = orc.required_samples(0.0, st.code_step)
+    st.current_sample = current_sample
+    st.carrier_hz, st.code_hz = carrier, orc.CODE_RATE
+    if kind == 1:
+        st.fll_bw, st.pll_bw = c["fll_bandwidth_pullin"], c["pll_bandwidth_wide"]
+        st.lock_state = orc.LOCK_PULL_IN
+    return st
+
+
+def close(a, b, scale=None):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    s = np.maximum(np.abs(b), 1e-300) if scale is None else scale
+    return np.all(np.abs(a - b) <= RTOL * s)
+
+
+CASES = {"borre": ("g6_trajectories.npz", 0), "kaplan": ("g6_trajectories.npz", 1),
+         "kaplan_strong": ("g6b_kaplan_strong.npz", 1)}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_closed_loop_kernel_matches_reference_trajectory(engine, case):
+    fname, kind = CASES[case]
+    g, fs, raw = trajectory_iq(fname)
+    plugin = "borre" if kind == 0 else "kaplan"
+    c = BORRE_CFG if kind == 0 else (kaplan_strong_cfg(g) if case == "kaplan_strong" else KAPLAN_CFG)
+    ref, acq = g[f"{plugin}_epochs"], g[f"{plugin}_acq"]
+    n = raw.size // 2
+    engine.iq_alloc((n + 7) // 8 * 8, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(2)
+    engine.load_gps_code(1, 7)
+    st = initial_state(kind, fs, acq[3], int(acq[5]), c, slot=1)
+    states, traj = engine.track_closed_loop([st], loop_cfg(kind, fs, c), len(ref))
+    tr = traj[0]
+    ring = 100 * int(fs * 1e-3)
+    # integers: exact
+    assert np.array_equal(tr["start_sample"] % ring, ref[:, 0].astype(np.int64))
+    assert np.array_equal(tr["n_samples"], ref[:, 1].astype(np.int32))
+    # NCO inputs and correlators of every epoch
+    assert close(tr["carrier_hz_in"], ref[:, 2]) and close(tr["code_step_in"], ref[:, 5])
+    assert close(tr["rem_carrier_in"], ref[:, 3], scale=2 * np.pi) and close(tr["rem_code_in"], ref[:, 4], scale=1.0)
+    corr = tr["corr"][:, :6]
+    for t in range(3):
+        mag = np.hypot(ref[:, 6 + 2 * t], ref[:, 7 + 2 * t])
+        err = np.hypot(corr[:, 2 * t] - ref[:, 6 + 2 * t], corr[:, 2 * t + 1] - ref[:, 7 + 2 * t])
+        assert np.all(err <= RTOL * np.maximum(mag, 1.0)), (t, (err / mag).max())
+    assert close(tr["carrier_hz"], ref[:, 15]) and close(tr["code_hz"], ref[:, 16])
+    assert close(tr["dll"], ref[:, 12], scale=1.0) and close(tr["pll"], ref[:, 13], scale=1.0)
+    assert close(tr["carrier_err"], ref[:, 17], scale=1.0) and close(tr["code_err"], ref[:, 18], scale=1.0)
+    if kind == 1:
+        assert close(tr["fll"], ref[:, 14], scale=1.0)
+        assert close(tr["cn0"], ref[:, 19], scale=1.0)
+        assert close(tr["pll_lock"], ref[:, 20], scale=1.0) and close(tr["fll_lock"], ref[:, 21], scale=1.0)
+        assert np.array_equal(tr["lock_state"], ref[:, 22].astype(np.int32))
+        assert np.array_equal(tr["track_flags"], ref[:, 23].astype(np.int32))
+    # end state continues where the trajectory stopped
+    assert states[0].current_sample == int(tr["start_sample"][-1]) + int(tr["n_samples"][-1])
+    assert states[0].code_counter == len(ref)
+
+
+def test_closed_loop_many_channels_and_resume(engine):
+    """8 channels in one launch == each channel alone; 2 x 100 epochs == 200 epochs (state round trip)."""
+    fs, ms = 4e6, 260
+    rng = np.random.default_rng(20261010)
+    prns = [2, 5, 9, 13, 17, 21, 26, 31]
+    sats = [dict(prn=p, doppler=float(rng.integers(-16, 17) * 250.0), code_phase=float(rng.uniform(0, 1023)),
+                 phase=float(rng.random()), amp=7.0) for p in prns]
+    n = int(ms * fs * 1e-3)
+    engine.iq_alloc(n, FMT_CI8)
+    engine.code_slots(8)
+    for s, p in enumerate(prns):
+        engine.load_gps_code(s, p)
+    engine.iq_synth(sats, fs, 15.0, 4711, 0, n)
+    pb, pc, pr, _ = engine.pcps(np.arange(8), 0, fs, 0.0, 5000.0, 250.0, 1, 1)
+    bins = orc.doppler_bins(5000.0, 250.0)
+    n0 = orc.required_samples(0.0, orc.CODE_RATE / fs)
+    cfg = loop_cfg(1, fs, KAPLAN_CFG)
+
+    def fresh():
+        out = []
+        for s in range(8):
+            carrier, _, cur = orc.post_acquisition(0.0, 5000.0, 250.0, [int(pb[s]), int(pc[s])], 0, 4000, n0)
+            out.append(initial_state(1, fs, carrier, cur, KAPLAN_CFG, slot=s))
+        return out
+
+    all_states, all_traj = engine.track_closed_loop(fresh(), cfg, 200)
+    for s in (0, 3, 7):
+        one_state, one_traj = engine.track_closed_loop([fresh()[s]], cfg, 200)
+        assert one_traj[0].tobytes() == all_traj[s].tobytes()          # bitwise: no cross-channel coupling
+    half, t1 = engine.track_closed_loop(fresh(), cfg, 100)
+    rest, t2 = engine.track_closed_loop(half, cfg, 100)
+    assert np.concatenate([t1, t2], axis=1).tobytes() == all_traj.tobytes()
+    assert bytes(rest[5]) == bytes(all_states[5])
+    # and the loops did lock on: prompt power dominates, Doppler within a bin of the truth
+    for s, sat in enumerate(sats):
+        tail = all_traj[s][-50:]
+        assert abs(np.mean(tail["carrier_hz"]) - sat["doppler"]) < 30.0
+        p = np.hypot(tail["corr"][:, 2], tail["corr"][:, 3]).mean()
+        assert p > np.hypot(tail["corr"][:, 0], tail["corr"][:, 1]).mean()   # prompt above early (0.5 chip off)
+
+
+def test_closed_loop_stops_instead_of_reading_out_of_range(engine):
+    from sydr_amd import SdrError
+    fs = 4e6
+    engine.iq_alloc(40000, FMT_CI8)
+    engine.iq_upload(np.random.default_rng(1).integers(-50, 50, 80000).astype(np.int8), 0)
+    engine.code_slots(1)
+    engine.load_gps_code(0, 3)
+    st = initial_state(0, fs, 100.0, 0, BORRE_CFG)
+    st.code_step = 0.4                     # 4001 * 0.4 chips: far outside the staged replica
+    with pytest.raises(SdrError, match="stopped after 0 epochs"):
+        engine.track_closed_loop([st], loop_cfg(0, fs, BORRE_CFG), 10)
+    cfg = loop_cfg(0, fs, BORRE_CFG)
+    cfg.n_taps = 5
+    with pytest.raises(SdrError):
+        engine.track_closed_loop([initial_state(0, fs, 0.0, 0, BORRE_CFG)], cfg, 1)
+
+
+# ------------------------------------------------------------------------------------------------ host plugins on the GPU
+@pytest.mark.parametrize("plugin", ["borre", "kaplan"])
+def test_manager_on_gpu_matches_reference_trajectory(engine, plugin):
+    from sydr_amd.channel.l1ca_borre import ChannelL1CA
+    from sydr_amd.channel.l1ca_kaplan import ChannelL1CA_Kaplan
+    from sydr_amd.channel.manager import ChannelManager
+    from sydr_amd.utils.enumerations import ChannelMessage
+    g, fs, raw = trajectory_iq()
+    mgr = ChannelManager(rf_signal(fs), engine=engine)
+    cls, ini = (ChannelL1CA, BORRE_INI) if plugin == "borre" else (ChannelL1CA_Kaplan, KAPLAN_INI)
+    mgr.addChannel(cls, channel_config(ini), 1)
+    mgr.requestTracking(7)
+    ticks = drive(mgr, raw, int(fs * 1e-3), 510)
+    acq = [p for t in ticks for p in t if p["type"] is ChannelMessage.ACQUISITION_UPDATE][0]
+    trk = [p for t in ticks for p in t if p["type"] is ChannelMessage.TRACKING_UPDATE]
+    ref_acq, ref = g[f"{plugin}_acq"], g[f"{plugin}_epochs"]
+    assert (acq["frequency_idx"], acq["code_idx"], acq["codeOffset"]) == (int(ref_acq[0]), int(ref_acq[1]), int(ref_acq[4]))
+    assert acq["peak_ratio"] == pytest.approx(ref_acq[2], rel=RTOL) and acq["correlation_map"].shape == (41, 4000)
+    assert len(trk) == len(ref)
+    got = np.array([[p["i_early"], p["q_early"], p["i_prompt"], p["q_prompt"], p["i_late"], p["q_late"],
+                     p["carrier_frequency"], p["code_frequency"]] for p in trk])
+    scale = np.maximum(np.abs(ref[:, [6, 7, 8, 9, 10, 11, 15, 16]]), 1.0)
+    mag = np.repeat(np.hypot(ref[:, 6:12:2], ref[:, 7:12:2]), 2, axis=1)
+    scale[:, :6] = np.maximum(mag, 1.0)
+    assert np.all(np.abs(got - ref[:, [6, 7, 8, 9, 10, 11, 15, 16]]) <= RTOL * scale)
+
+
+def test_run_block_continues_a_per_tick_run(engine):
+    """Per-tick host loop for 150 ms, then 300 epochs closed-loop on the device: same trajectory as
+    the reference plugin ran per millisecond."""
+    from sydr_amd.channel.l1ca_kaplan import ChannelL1CA_Kaplan
+    from sydr_amd.channel.manager import ChannelManager
+    from sydr_amd.utils.enumerations import ChannelMessage
+    g, fs, raw = trajectory_iq()
+    spms = int(fs * 1e-3)
+    mgr = ChannelManager(rf_signal(fs), engine=engine)
+    # a ring long enough to hold the whole record, so the block run has its samples resident
+    from sydr_amd.utils.devicering import CircularBuffer
+    mgr.sharedBuffer = CircularBuffer(520 * spms, np.int8, engine=engine)
+    mgr.addChannel(ChannelL1CA_Kaplan, channel_config(KAPLAN_INI), 1)
+    ch = mgr.requestTracking(7)
+    ticks = drive(mgr, raw, spms, 150)
+    done = sum(p["type"] is ChannelMessage.TRACKING_UPDATE for t in ticks for p in t)
+    mgr.addNewRFData(raw[2 * 150 * spms:2 * 410 * spms])  # 260 more ms, resident before the block run
+    packets = mgr.runBlock(250)
+    trk = [p for p in packets if p["type"] is ChannelMessage.TRACKING_UPDATE]
+    ref = g["kaplan_epochs"][done:done + 250]
+    got = np.array([[p["i_prompt"], p["q_prompt"], p["carrier_frequency"], p["code_frequency"]] for p in trk])
+    want = ref[:, [8, 9, 15, 16]]
+    scale = np.maximum(np.abs(want), 1.0)
+    scale[:, :2] = np.maximum(np.hypot(ref[:, 8], ref[:, 9]), 1.0)[:, None]
+    assert np.all(np.abs(got - want) <= RTOL * scale)
+    assert ch.codeCounter == done + 250 and packets[-1]["type"] is ChannelMessage.CHANNEL_UPDATE
+
+
+# ------------------------------------------------------------------------------------------------ function-level drop-ins
+def test_function_level_dropins_read_like_the_reference():
+    """`from sydr_amd.dsp.acquisition import PCPS ...` used exactly as sydr.dsp.* is used by the plugins."""
+    from sydr_amd.dsp.acquisition import PCPS, TwoCorrelationPeakComparison
+    from sydr_amd.dsp.tracking import EPL
+    from sydr_amd.signal.replica import GenerateGPSGoldCode, UpsampleCode, getSamplesPerCode
+    g = load_golden("g3_pcps.npz")
+    fs, if_hz, rng_hz, step, coh, noncoh, n, spc = g["d_params"]
+    rf = orc.iq_to_complex(g["d_iq"]).reshape(1, -1)
+    code = GenerateGPSGoldCode(7)
+    assert np.array_equal(code, orc.gold_code(7)) and getSamplesPerCode(fs) == int(n)
+    up = UpsampleCode(code, fs)
+    assert np.array_equal(up, orc.upsample_code(orc.gold_code(7), fs))
+    ramp = np.arange(1023, dtype=np.float64)
+    assert np.array_equal(UpsampleCode(ramp, fs), orc.upsample_index(fs).astype(float))
+    codeFFT = np.conj(np.fft.fft(up))
+    cmap = PCPS(rfData=rf, interFrequency=if_hz, samplingFrequency=fs, codeFFT=codeFFT, dopplerRange=rng_hz,
+                dopplerStep=step, samplesPerCode=int(n), coherentIntegration=int(coh),
+                nonCoherentIntegration=int(noncoh))
+    idx, ratio = TwoCorrelationPeakComparison(cmap, int(n), int(spc))
+    assert idx == list(g["d_peak"][0]) and ratio == pytest.approx(float(g["d_ratio"][0]), rel=RTOL)
+    np.testing.assert_allclose(cmap[idx[0]], g["d_row"][0], rtol=0, atol=RTOL * g["d_row"][0].max())
+
+    e = load_golden("g5_epl.npz")
+    prn, fs, f, rc, rk, cstep, n = e["r20_params"]
+    rfd = orc.iq_to_complex(e["r20_iq"]).reshape(1, -1)
+    padded = np.r_[orc.gold_code(int(prn))[-1], orc.gold_code(int(prn)), orc.gold_code(int(prn))[0]]
+    out = EPL(rfData=rfd, code=padded, samplingFrequency=fs, carrierFrequency=f, remainingCarrier=rc,
+              remainingCode=rk, codeStep=cstep, correlatorsSpacing=tuple(e["r20_spacing"]))
+    assert isinstance(out, list) and len(out) == 6
+    ref = e["r20_out"]
+    scale = np.repeat(np.hypot(ref[0::2], ref[1::2]), 2)
+    assert np.all(np.abs(np.array(out) - ref) <= RTOL * scale)

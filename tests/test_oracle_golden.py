@@ -149,8 +149,8 @@ KAPLAN_CFG = dict(correlator_epl_wide=0.5, correlator_epl_narrow=0.5, dll_thresh
                   fll_threshold_wide=0.5, fll_threshold_narrow=0.8)
 
 
-def trajectory_iq():
-    g = load_golden("g6_trajectories.npz")
+def trajectory_iq(fname="g6_trajectories.npz"):
+    g = load_golden(fname)
     fs, n, prn, dop, cph, ph, amp, sigma, seed = g["synth"]
     raw = orc.synth_iq(fs, int(n), [dict(prn=int(prn), doppler=dop, code_phase=cph, phase=ph, amp=amp)], sigma,
                        int(seed))
@@ -193,3 +193,29 @@ def test_closed_loop_trajectory(plugin):
             np.testing.assert_equal([rec["cn0"], rec["pll_lock"], rec["fll_lock"]], row[19:22])
             assert (rec["lock_state"], rec["flags"]) == (int(row[22]), int(row[23])), k
     assert len(ref) >= 500
+
+
+def kaplan_strong_cfg(g):
+    cfg = dict(KAPLAN_CFG)
+    for k, v in zip(g["track_override_keys"], g["track_override_vals"]):
+        cfg[str(k)] = float(v)
+    return cfg
+
+
+def test_closed_loop_kaplan_lock_state_machine():
+    """Strong signal + lowered thresholds: PULL_IN -> WIDE -> NARROW (narrow taps), code lock, bit sync."""
+    g, fs, raw = trajectory_iq("g6b_kaplan_strong.npz")
+    rf = orc.iq_to_complex(raw)
+    acq = g["kaplan_acq"]
+    loop = orc.KaplanLoop(fs, orc.gold_code(7), kaplan_strong_cfg(g), acq[3], int(acq[5]))
+    ref = g["kaplan_epochs"]
+    ring = 100 * int(fs * 1e-3)
+    for k, row in enumerate(ref):
+        assert (loop.current_sample % ring, loop.n) == (int(row[0]), int(row[1])), k
+        rec = loop.step(rf[loop.current_sample:loop.current_sample + loop.n])
+        assert rec["corr"] == list(row[6:12]), k
+        assert (rec["carrier_hz"], rec["code_hz"], rec["dll"], rec["pll"], rec["fll"]) == \
+            (row[15], row[16], row[12], row[13], row[14]), k
+        np.testing.assert_equal([rec["cn0"], rec["pll_lock"], rec["fll_lock"]], row[19:22])
+        assert (rec["lock_state"], rec["flags"]) == (int(row[22]), int(row[23])), k
+    assert {int(r[22]) for r in ref} == {1, 2, 3} and int(ref[-1][23]) == 3
