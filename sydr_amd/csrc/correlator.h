@@ -61,6 +61,14 @@ __device__ __forceinline__ void sincos_reduced(double ph, double* s, double* c) 
     *c = ((q + 1) & 2) ? -b : b;
 }
 
+// Values that are the same in every lane (per-epoch constants) are pinned to SGPRs: it frees ~60
+// VGPRs per lane, which is what decides between 2 and 3-4 resident waves per SIMD here.
+__device__ __forceinline__ double uniform(double x) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
 // Load 8 consecutive ring samples starting at aligned position `pos` and widen to fp64.
 template <int FMT>
 struct Loader;
@@ -145,44 +153,64 @@ struct EpochParams {
     double carrier_hz, rem_carrier, rem_code, code_step;
 };
 
-// exp(-1j*j*dphi), j = 0..7, computed by lanes 0..7 into rot[16]; caller barriers afterwards.
 __device__ __forceinline__ double carrier_step(double carrier_hz, double fs) {
     const double w = (carrier_hz * 2.0) * M_PI;  // tracking.py:102 uses np.pi
     return w / fs;
 }
-__device__ __forceinline__ void stage_rotations(double* rot, double dphi, int tid) {
-    if (tid < kGroup) {
-        double s, c;
-        sincos_reduced(-(double)tid * dphi, &s, &c);
-        rot[2 * tid] = c;
-        rot[2 * tid + 1] = s;
+
+// Per-epoch constants, computed ONCE per workgroup by a few lanes of wave 0 (each lane a different
+// quantity, so the sincos / fp64-division sequences are issued once instead of once per quantity per
+// wave) and handed to every lane through LDS.  Layout in doubles:
+//   [2j],[2j+1]  j=0..7   cos,sin(-j*dphi)          per-sample rotations inside a group
+//   [16],[17]             cos,sin(-8*dphi)          first -> second half of a 16-sample group
+//   [18],[19]             cos,sin(-8*THREADS*dphi)  lane stride of the 8-sample loop
+//   [20],[21]             cos,sin(-16*THREADS*dphi) lane stride of the 16-sample loop
+//   [22+3t .. 24+3t]      shift_t, step_t, 1/step_t (np.linspace of tracking.py:111-112; 1/step only predicts)
+constexpr int kConstDoubles = 22 + 3 * SDR_MAX_TAPS;
+
+template <int NT, int THREADS>
+__device__ __forceinline__ void stage_constants(double* kc, const EpochParams& ep, const double* spacing,
+                                                double dphi, int tid) {
+    if (tid < 11) {
+        const double mult = tid < 8 ? (double)tid : (tid == 8 ? 8.0 : (tid == 9 ? (double)(kGroup * THREADS)
+                                                                                  : (double)(2 * kGroup * THREADS)));
+        double sn, cs;
+        sincos_reduced(-mult * dphi, &sn, &cs);
+        kc[2 * tid] = cs;
+        kc[2 * tid + 1] = sn;
+    } else if (tid >= 16 && tid < 16 + NT) {
+        const int t = tid - 16;
+        const double nd = (double)ep.n;
+        const double shift = ep.rem_code + spacing[t];  // reference arithmetic, operation for operation
+        double stop = ep.code_step * nd;
+        stop = stop + shift;
+        const double delta = stop - shift;
+        const double step = delta / nd;
+        kc[22 + 3 * t] = shift;
+        kc[23 + 3 * t] = step;
+        kc[24 + 3 * t] = 1.0 / step;
     }
 }
 
 // Correlate this thread's share (groups tid, tid+THREADS, ...) of one epoch.
-// accr/acci[NT] receive the thread-partial fp64 accumulators.
+// accr/acci[NT] receive the thread-partial fp64 accumulators.  kc = staged constants (after a barrier).
 template <int FMT, int NT, int THREADS>
 __device__ __forceinline__ void correlate_epoch(const void* __restrict__ ring, int64_t capacity,
-                                                const EpochParams& ep, const double* spacing, double dphi,
-                                                const double* rot, const uint32_t* lut, int tid, double* accr,
-                                                double* acci) {
+                                                const EpochParams& ep, double dphi, const double* kc,
+                                                const uint32_t* lut, int tid, double* accr, double* acci) {
     const int n = ep.n;
     double rc[kGroup], rs[kGroup];
 #pragma unroll
     for (int j = 0; j < kGroup; ++j) {
-        rc[j] = rot[2 * j];
-        rs[j] = rot[2 * j + 1];
+        rc[j] = uniform(kc[2 * j]);
+        rs[j] = uniform(kc[2 * j + 1]);
     }
-    // np.linspace(shift, code_step*n + shift, n, endpoint=False) per tap (tracking.py:111-112).
-    const double nd = (double)n;
+    const double c_it = uniform(kc[18]), s_it = uniform(kc[19]);
     double shift[NT], step[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        shift[t] = ep.rem_code + spacing[t];
-        double stop = ep.code_step * nd;
-        stop = stop + shift[t];
-        double delta = stop - shift[t];
-        step[t] = delta / nd;
+        shift[t] = uniform(kc[22 + 3 * t]);
+        step[t] = uniform(kc[23 + 3 * t]);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) accr[t] = acci[t] = 0.0;
@@ -194,7 +222,7 @@ __device__ __forceinline__ void correlate_epoch(const void* __restrict__ ring, i
 
     // One 8-sample group.  EDGE = the group straddles the start or the end of the epoch:
     // samples outside [0,n) are zeroed and their (unused) chip index is clamped into range.
-    auto group = [&](int g, auto edge_tag) {
+    auto group = [&](int g, double sb, double cb, auto edge_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
         int64_t pos = base + (int64_t)g * kGroup;
         if (pos >= capacity) pos -= capacity;
@@ -202,8 +230,6 @@ __device__ __forceinline__ void correlate_epoch(const void* __restrict__ ring, i
         Loader<FMT>::load(ring, pos, xr, xi);
 
         const int i0 = g * kGroup - head;
-        double sb, cb;
-        sincos_reduced(__builtin_fma(-(double)i0, dphi, ep.rem_carrier), &sb, &cb);
 
         double gr[NT], gi[NT];
 #pragma unroll
@@ -239,12 +265,243 @@ __device__ __forceinline__ void correlate_epoch(const void* __restrict__ ring, i
         }
     };
 
+    // carrier phase at the lane's first sample: one exact evaluation, then a fixed rotation per iteration
+    double sb, cb;
+    sincos_reduced(__builtin_fma(-(double)(tid * kGroup - head), dphi, ep.rem_carrier), &sb, &cb);
     for (int g = tid; g < n_groups; g += THREADS) {
         const int i0 = g * kGroup - head;
         if (i0 >= 0 && i0 + kGroup <= n)
-            group(g, std::false_type{});
+            group(g, sb, cb, std::false_type{});
         else
-            group(g, std::true_type{});
+            group(g, sb, cb, std::true_type{});
+        const double cbn = __builtin_fma(cb, c_it, -sb * s_it);
+        sb = __builtin_fma(sb, c_it, cb * s_it);
+        cb = cbn;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Boundary variant (used when 16*code_step < 1, i.e. fs above ~17 MHz for C/A code).
+ *
+ * A lane owns 16 consecutive samples (two 16-byte loads), i.e. < 1 chip, so for every tap the
+ * reference chip index takes at most two values p0, p0+1 inside the group and the sequence is
+ * monotone.  Instead of evaluating ceil(i*step+shift) for every sample, the kernel evaluates
+ * that exact reference expression at the two ends, predicts the switch position from
+ * (p0 - y0)/step, and VERIFIES the prediction with two more exact evaluations (the prediction
+ * can only be off by one when the crossing falls within ~1e-11 samples of an integer; the
+ * verification repairs exactly that case).  Every sample therefore still gets precisely the chip
+ * NumPy's linspace/ceil would give it -- but with 4 exact evaluations per tap per 16 samples
+ * instead of 16, and 2 LDS gathers instead of 16.
+ * ------------------------------------------------------------------------------------------------ */
+constexpr int kWide = 16;
+constexpr double kFastMaxCodeStep = 0.06;  // 15 * step <= 0.9 chip
+
+template <int FMT>
+struct Raw8;  // 8 consecutive samples kept in their storage format until they are needed
+
+template <>
+struct Raw8<SDR_FMT_CI8> {
+    int4 v;
+    __device__ __forceinline__ void load(const void* ring, int64_t pos) {
+        v = *reinterpret_cast<const int4*>(static_cast<const char*>(ring) + pos * 2);
+    }
+    __device__ __forceinline__ void get(int j, double& xr, double& xi) const {
+        const int w = (j >> 1) == 0 ? v.x : ((j >> 1) == 1 ? v.y : ((j >> 1) == 2 ? v.z : v.w));
+        if (j & 1) {
+            xr = (double)(int)(int8_t)(w >> 16);
+            xi = (double)(w >> 24);
+        } else {
+            xr = (double)(int)(int8_t)(w);
+            xi = (double)(int)(int8_t)(w >> 8);
+        }
+    }
+};
+
+template <>
+struct Raw8<SDR_FMT_CI16> {
+    int4 v[2];
+    __device__ __forceinline__ void load(const void* ring, int64_t pos) {
+        const int4* p = reinterpret_cast<const int4*>(static_cast<const char*>(ring) + pos * 4);
+        v[0] = p[0];
+        v[1] = p[1];
+    }
+    __device__ __forceinline__ void get(int j, double& xr, double& xi) const {
+        const int4 q = v[j >> 2];
+        const int w = (j & 3) == 0 ? q.x : ((j & 3) == 1 ? q.y : ((j & 3) == 2 ? q.z : q.w));
+        xr = (double)(int)(int16_t)(w);
+        xi = (double)(w >> 16);
+    }
+};
+
+template <>
+struct Raw8<SDR_FMT_CF32> {
+    float4 v[4];
+    __device__ __forceinline__ void load(const void* ring, int64_t pos) {
+        const float4* p = reinterpret_cast<const float4*>(static_cast<const char*>(ring) + pos * 8);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) v[h] = p[h];
+    }
+    __device__ __forceinline__ void get(int j, double& xr, double& xi) const {
+        const float4 q = v[j >> 1];
+        xr = (j & 1) ? q.z : q.x;
+        xi = (j & 1) ? q.w : q.y;
+    }
+};
+
+template <>
+struct Raw8<SDR_FMT_CF64> {
+    double2 v[8];
+    __device__ __forceinline__ void load(const void* ring, int64_t pos) {
+        const double2* p = reinterpret_cast<const double2*>(static_cast<const char*>(ring) + pos * 16);
+#pragma unroll
+        for (int h = 0; h < 8; ++h) v[h] = p[h];
+    }
+    __device__ __forceinline__ void get(int j, double& xr, double& xi) const {
+        xr = v[j].x;
+        xi = v[j].y;
+    }
+};
+
+template <int FMT, int NT, int THREADS>
+__device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ring, int64_t capacity,
+                                                     const EpochParams& ep, double dphi, const double* kc,
+                                                     const uint32_t* lut, int tid, double* accr, double* acci) {
+    const int n = ep.n;
+    double rc[kGroup], rs[kGroup];
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) {
+        rc[j] = uniform(kc[2 * j]);
+        rs[j] = uniform(kc[2 * j + 1]);
+    }
+    const double c8 = uniform(kc[16]), s8 = uniform(kc[17]);      // first -> second half of a group
+    const double c_it = uniform(kc[20]), s_it = uniform(kc[21]);  // lane stride of this loop
+    const double dphi_u = uniform(dphi), rem_carrier_u = uniform(ep.rem_carrier);
+    double shift[NT], step[NT], inv_step[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        shift[t] = uniform(kc[22 + 3 * t]);
+        step[t] = uniform(kc[23 + 3 * t]);
+        inv_step[t] = uniform(kc[24 + 3 * t]);  // only used to PREDICT the switch position
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) accr[t] = acci[t] = 0.0;
+
+    const int64_t aligned = ep.start_sample & ~(int64_t)(kGroup - 1);
+    const int head = (int)(ep.start_sample - aligned);
+    const int n_groups = (head + n + kWide - 1) / kWide;
+    const int64_t base = aligned % capacity;
+
+    auto load_group = [&](int g, Raw8<FMT>* raw) {
+        int64_t pos = base + (int64_t)g * kWide;
+        if (pos >= capacity) pos -= capacity;
+        int64_t pos2 = pos + kGroup;
+        if (pos2 >= capacity) pos2 -= capacity;
+        raw[0].load(ring, pos);
+        raw[1].load(ring, pos2);
+    };
+
+    auto group = [&](int g, const Raw8<FMT>* raw, double sb, double cb, auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+
+        const int i0 = g * kWide - head;
+        auto clampi = [&](int i) { return EDGE ? (i < 0 ? 0 : (i >= n ? n - 1 : i)) : i; };
+        // the reference's chip index, exactly: separate multiply, add, ceil
+        auto chip = [&](int i, int t, double* yout) {
+            double y = (double)i * step[t];
+            y = y + shift[t];
+            if (yout) *yout = y;
+            return (int)ceil(y);
+        };
+
+        // signs[t]: bit j = 1 when sample j of the group multiplies by -1 (chip p0 up to the switch
+        // position, chip p0+1 after it).  A shift + and-or per sample then rebuilds the high word
+        // of +-1.0 without compare/select pairs (VALU->SGPR->VALU costs wait states on gfx950).
+        uint32_t signs[NT];
+        const int ia = clampi(i0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double y0;
+            const int p0 = chip(ia, t, &y0);
+            // predicted first sample (group-relative) whose chip is p0+1; a prediction beyond the
+            // group is clamped to the last sample, where the check below then finds "no switch"
+            const double e = ((double)p0 - y0) * inv_step[t];
+            int b = (ia - i0) + (int)e + 1;
+            b = b < 1 ? 1 : (b > kWide - 1 ? kWide - 1 : b);
+            const int pa = chip(clampi(i0 + b - 1), t, nullptr);
+            const int pb = chip(clampi(i0 + b), t, nullptr);
+            b = (pa != p0) ? b - 1 : ((pb == p0) ? b + 1 : b);   // b in [1,16]; 16 = whole group on chip p0
+            const uint32_t lead = (1u << b) - 1u;                 // samples that use chip p0
+            const uint32_t neg0 = 0u - (lut[p0 + SDR_LUT_PAD] >> 31);        // all ones when chip p0 is -1
+            const uint32_t neg1 = 0u - (lut[p0 + 1 + SDR_LUT_PAD] >> 31);
+            signs[t] = (neg0 & lead) | (neg1 & ~lead);
+        }
+
+        uint32_t one_hi = 0x3FF00000u;  // high word of +1.0, kept in a VGPR for v_and_or_b32
+        asm volatile("" : "+v"(one_hi));
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            double gr[NT], gi[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) gr[t] = gi[t] = 0.0;
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+                const int jj = half * kGroup + j;
+                double ar, ai;
+                raw[half].get(j, ar, ai);
+                if (EDGE) {
+                    const bool valid = (unsigned)(i0 + jj) < (unsigned)n;
+                    ar = valid ? ar : 0.0;
+                    ai = valid ? ai : 0.0;
+                }
+                const double zr = __builtin_fma(-ai, rs[j], ar * rc[j]);
+                const double zi = __builtin_fma(ai, rc[j], ar * rs[j]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    // hi = 0x3FF00000 | ((signs << (31-jj)) & 0x80000000): one shift + one v_and_or_b32
+                    uint32_t hi;
+                    asm("v_and_or_b32 %0, %1, %2, %3"
+                        : "=v"(hi)
+                        : "v"(signs[t] << (31 - jj)), "s"(0x80000000u), "v"(one_hi));
+                    const double c = __hiloint2double((int)hi, 0);
+                    gr[t] = __builtin_fma(c, zr, gr[t]);
+                    gi[t] = __builtin_fma(c, zi, gi[t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                accr[t] += __builtin_fma(cb, gr[t], -sb * gi[t]);
+                acci[t] += __builtin_fma(cb, gi[t], sb * gr[t]);
+            }
+            // advance the base phase by 8 samples for the second half
+            const double cb2 = __builtin_fma(cb, c8, -sb * s8);
+            sb = __builtin_fma(sb, c8, cb * s8);
+            cb = cb2;
+        }
+    };
+
+    // Software prefetch: the next group's two 16-byte loads are in flight while this one is computed.
+    Raw8<FMT> cur[2], nxt[2];
+    int g = tid;
+    if (g < n_groups) load_group(g, cur);
+    // Carrier phase at the lane's first sample: one exact evaluation, then a fixed rotation per
+    // iteration (the lane's groups are kWide*THREADS samples apart; <= a few dozen steps, so the
+    // recurrence stays within ~1e-15 of a fresh evaluation).
+    double sb, cb;
+    sincos_reduced(__builtin_fma(-(double)(tid * kWide - head), dphi_u, rem_carrier_u), &sb, &cb);
+    while (g < n_groups) {
+        const int gn = g + THREADS;
+        if (gn < n_groups) load_group(gn, nxt);
+        const int i0 = g * kWide - head;
+        if (i0 >= 0 && i0 + kWide <= n)
+            group(g, cur, sb, cb, std::false_type{});
+        else
+            group(g, cur, sb, cb, std::true_type{});
+        cur[0] = nxt[0];
+        cur[1] = nxt[1];
+        const double cbn = __builtin_fma(cb, c_it, -sb * s_it);
+        sb = __builtin_fma(sb, c_it, cb * s_it);
+        cb = cbn;
+        g = gn;
     }
 }
 

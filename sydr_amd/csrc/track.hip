@@ -79,8 +79,8 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
                                                               const int32_t* __restrict__ code_len,
                                                               int code_stride) {
     extern __shared__ double smem[];
-    double* rot = smem;                                   // 16
-    double* red = rot + 2 * kGroup;                       // kTrackWaves * 6
+    double* kc = smem;                                    // per-epoch constants (correlator.h)
+    double* red = kc + kConstDoubles;                     // kTrackWaves * 6
     EpochShared* sh = reinterpret_cast<EpochShared*>(red + kTrackWaves * 2 * kTaps);
     uint32_t* lut = reinterpret_cast<uint32_t*>(sh + 1);
 
@@ -130,11 +130,14 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
         double sp[kTaps];
 #pragma unroll
         for (int t = 0; t < kTaps; ++t) sp[t] = sh->spacing[t];
-        stage_rotations(rot, dphi, tid);
+        stage_constants<kTaps, kTrackThreads>(kc, ep, sp, dphi, tid);
         __syncthreads();
 
         double accr[kTaps], acci[kTaps];
-        correlate_epoch<FMT, kTaps, kTrackThreads>(ring, capacity, ep, sp, dphi, rot, lut, tid, accr, acci);
+        if (ep.code_step <= kFastMaxCodeStep)   // uniform branch: 16-sample boundary variant above ~17 MHz
+            correlate_epoch_wide<FMT, kTaps, kTrackThreads>(ring, capacity, ep, dphi, kc, lut, tid, accr, acci);
+        else
+            correlate_epoch<FMT, kTaps, kTrackThreads>(ring, capacity, ep, dphi, kc, lut, tid, accr, acci);
         const double total = reduce_taps<kTaps, kTrackThreads>(accr, acci, red, tid);
 
         // lanes 0..5 of wave 0 hold [IE,QE,IP,QP,IL,QL]; hand them to lane 0 without a barrier
@@ -335,7 +338,7 @@ int sdr_track_closed_loop(sdr_engine* e, int n_ch, sdr_track_state* st, const sd
     SDR_HIP(hipMemcpyAsync(e->track_state.ptr, st, (size_t)n_ch * sizeof(sdr_track_state), hipMemcpyHostToDevice, e->stream));
     SDR_HIP(hipMemcpyAsync(e->track_cfg.ptr, cfg, sizeof(sdr_loop_cfg), hipMemcpyHostToDevice, e->stream));
     const int lut_words = maxlen + 2 * SDR_LUT_PAD + 2;
-    const size_t shmem = (2 * kGroup + kTrackWaves * 2 * kTaps) * sizeof(double) + sizeof(EpochShared) +
+    const size_t shmem = (kConstDoubles + kTrackWaves * 2 * kTaps) * sizeof(double) + sizeof(EpochShared) +
                          (size_t)lut_words * sizeof(uint32_t);
     sdr_track_state* d_st = (sdr_track_state*)e->track_state.ptr;
     const sdr_loop_cfg* d_cfg = (const sdr_loop_cfg*)e->track_cfg.ptr;
