@@ -71,6 +71,16 @@ __global__ __launch_bounds__(256) void upsample_kernel(const int8_t* __restrict_
     out[k] = code[idx];
 }
 
+// Replica in LDS form: out[q] = high word of (double)chip[(q - PAD - 1) mod L] for q < L + 2*PAD + 2.
+__global__ __launch_bounds__(256) void expand_lut_kernel(const int8_t* __restrict__ chips, int L,
+                                                         uint32_t* __restrict__ out, int words) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= words) return;
+    int c = (q - SDR_LUT_PAD - 1) % L;
+    if (c < 0) c += L;
+    out[q] = (q < L + 2 * SDR_LUT_PAD + 2 && chips[c] > 0) ? 0x3FF00000u : 0xBFF00000u;
+}
+
 /* ------------------------------------------------ synthetic IQ generator */
 
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
@@ -152,6 +162,8 @@ int sdr_code_slots(sdr_engine* e, int n_slots, int max_chips) {
         return sdr_fail(SDR_ERR_INVALID, "bad code slot geometry (%d slots, %d chips)", n_slots, max_chips);
     SDR_HIP(hipStreamSynchronize(e->stream));
     if (e->codes) SDR_HIP(hipFree(e->codes));
+    if (e->luts) SDR_HIP(hipFree(e->luts));
+    e->luts = nullptr;
     if (e->code_len) SDR_HIP(hipFree(e->code_len));
     e->codes = nullptr;
     e->code_len = nullptr;
@@ -161,6 +173,10 @@ int sdr_code_slots(sdr_engine* e, int n_slots, int max_chips) {
         return sdr_fail(SDR_ERR_NOMEM, "hipMalloc for code slots failed");
     if (hipMalloc(&e->code_len, (size_t)n_slots * sizeof(int32_t)) != hipSuccess)
         return sdr_fail(SDR_ERR_NOMEM, "hipMalloc for code lengths failed");
+    const int lut_stride = (stride + 2 * SDR_LUT_PAD + 2 + 3) & ~3;
+    if (hipMalloc(&e->luts, (size_t)n_slots * lut_stride * sizeof(uint32_t)) != hipSuccess)
+        return sdr_fail(SDR_ERR_NOMEM, "hipMalloc for replica LUTs failed");
+    e->lut_stride = lut_stride;
     SDR_HIP(hipMemsetAsync(e->codes, 0, (size_t)n_slots * stride, e->stream));
     SDR_HIP(hipMemsetAsync(e->code_len, 0, (size_t)n_slots * sizeof(int32_t), e->stream));
     e->code_len_host.assign(n_slots, 0);
@@ -192,6 +208,10 @@ int sdr_code_gps_l1ca(sdr_engine* e, int slot, int prn) {
     }
     SDR_HIP(hipGetLastError());
     SDR_HIP(hipMemcpyAsync(e->code_len + slot, &len, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(expand_lut_kernel, dim3((e->lut_stride + 255) / 256), dim3(256), 0, e->stream,
+                       e->codes + (size_t)slot * e->code_stride, len, e->luts + (size_t)slot * e->lut_stride,
+                       e->lut_stride);
+    SDR_HIP(hipGetLastError());
     SDR_HIP(hipStreamSynchronize(e->stream));
     e->code_len_host[slot] = len;
     return SDR_OK;
@@ -210,6 +230,10 @@ int sdr_code_custom(sdr_engine* e, int slot, const int8_t* chips, int n_chips) {
     SDR_HIP(hipMemcpyAsync(e->codes + (size_t)slot * e->code_stride, chips, n_chips, hipMemcpyHostToDevice,
                            e->stream));
     SDR_HIP(hipMemcpyAsync(e->code_len + slot, &len, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(expand_lut_kernel, dim3((e->lut_stride + 255) / 256), dim3(256), 0, e->stream,
+                       e->codes + (size_t)slot * e->code_stride, len, e->luts + (size_t)slot * e->lut_stride,
+                       e->lut_stride);
+    SDR_HIP(hipGetLastError());
     SDR_HIP(hipStreamSynchronize(e->stream));
     e->code_len_host[slot] = len;
     return SDR_OK;

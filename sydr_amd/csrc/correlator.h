@@ -133,17 +133,14 @@ struct Loader<SDR_FMT_CF64> {
     }
 };
 
-// Stage a PRN replica into LDS: lut[q] = chip[(q - PAD - 1) mod L] as the HIGH WORD of +-1.0
-// (so a gathered entry becomes an fp64 multiplier with no conversion).
+// Stage a PRN replica into LDS: the per-slot table prepared by expand_lut_kernel (high words of +-1.0,
+// lut[q] = chip[(q - PAD - 1) mod L]) is copied with 16-byte loads -- two per lane for a C/A code.
 template <int THREADS>
-__device__ __forceinline__ void stage_lut(uint32_t* lut, const int8_t* __restrict__ chips, int L, int tid) {
-    const int words = L + 2 * SDR_LUT_PAD + 2;
-    for (int q = tid; q < words; q += THREADS) {
-        int c = q - SDR_LUT_PAD - 1;
-        c = c < 0 ? c + L : (c >= L ? c - L : c);
-        c = c < 0 ? c + L : (c >= L ? c - L : c);  // PAD + 1 < L is checked on the host
-        lut[q] = chips[c] > 0 ? 0x3FF00000u : 0xBFF00000u;
-    }
+__device__ __forceinline__ void stage_lut(uint32_t* lut, const uint32_t* __restrict__ glut, int L, int tid) {
+    const int quads = (L + 2 * SDR_LUT_PAD + 2 + 3) >> 2;
+    const uint4* src = reinterpret_cast<const uint4*>(glut);
+    uint4* dst = reinterpret_cast<uint4*>(lut);
+    for (int q = tid; q < quads; q += THREADS) dst[q] = src[q];
 }
 
 // Per-epoch NCO inputs of one channel (what the reference passes to EPL).
@@ -158,72 +155,141 @@ __device__ __forceinline__ double carrier_step(double carrier_hz, double fs) {
     return w / fs;
 }
 
-// Per-epoch constants, computed ONCE per workgroup by a few lanes of wave 0 (each lane a different
-// quantity, so the sincos / fp64-division sequences are issued once instead of once per quantity per
-// wave) and handed to every lane through LDS.  Layout in doubles:
-//   [2j],[2j+1]  j=0..7   cos,sin(-j*dphi)          per-sample rotations inside a group
-//   [16],[17]             cos,sin(-8*dphi)          first -> second half of a 16-sample group
-//   [18],[19]             cos,sin(-8*THREADS*dphi)  lane stride of the 8-sample loop
-//   [20],[21]             cos,sin(-16*THREADS*dphi) lane stride of the 16-sample loop
-//   [22+3t .. 24+3t]      shift_t, step_t, 1/step_t (np.linspace of tracking.py:111-112; 1/step only predicts)
-constexpr int kConstDoubles = 22 + 3 * SDR_MAX_TAPS;
+// One ring sample, widened to fp64 (edge samples only).
+template <int FMT>
+__device__ __forceinline__ void load_one(const void* ring, int64_t pos, double& xr, double& xi) {
+    if (FMT == SDR_FMT_CI8) {
+        const char2 v = static_cast<const char2*>(ring)[pos];
+        xr = (double)v.x;
+        xi = (double)v.y;
+    } else if (FMT == SDR_FMT_CI16) {
+        const short2 v = static_cast<const short2*>(ring)[pos];
+        xr = (double)v.x;
+        xi = (double)v.y;
+    } else if (FMT == SDR_FMT_CF32) {
+        const float2 v = static_cast<const float2*>(ring)[pos];
+        xr = (double)v.x;
+        xi = (double)v.y;
+    } else {
+        const double2 v = static_cast<const double2*>(ring)[pos];
+        xr = v.x;
+        xi = v.y;
+    }
+}
+
+// The few samples of an epoch that do not fill a whole aligned group -- [0, head_end) and
+// [tail_start, n), at most 2*(group-1) of them -- are correlated one per lane with the plain
+// per-sample form of the reference arithmetic, in a single pass of the first wave.  (Routing them
+// through a masked copy of the group body cost two extra ~1000-instruction passes per epoch.)
+template <int FMT, int NT>
+__device__ __forceinline__ void edge_samples(const void* __restrict__ ring, int64_t capacity,
+                                             const EpochParams& ep, double dphi, const double* shift,
+                                             const double* step, const uint32_t* lut, int lane, int head_end,
+                                             int tail_start, double* accr, double* acci) {
+    const int count = head_end + (ep.n - tail_start);
+    if (lane >= count) return;
+    const int i = lane < head_end ? lane : tail_start + (lane - head_end);
+    int64_t pos = (ep.start_sample + i) % capacity;
+    double xr, xi;
+    load_one<FMT>(ring, pos, xr, xi);
+    double sn, cs;
+    sincos_reduced(__builtin_fma(-(double)i, dphi, ep.rem_carrier), &sn, &cs);
+    const double zr = __builtin_fma(-xi, sn, xr * cs);
+    const double zi = __builtin_fma(xi, cs, xr * sn);
+    const double di = (double)i;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        double y = di * step[t];  // reference arithmetic: separate mul, add, ceil
+        y = y + shift[t];
+        const int p = (int)ceil(y);
+        const double c = __hiloint2double((int)lut[p + SDR_LUT_PAD], 0);
+        accr[t] = __builtin_fma(c, zr, accr[t]);
+        acci[t] = __builtin_fma(c, zi, acci[t]);
+    }
+}
+
+// Per-epoch constants.  Every wave computes them for itself in ONE pass -- lane l evaluates a different
+// quantity (lanes 0..10: sin/cos of -m_l*dphi; lanes 16..16+NT-1: the np.linspace constants of tap
+// l-16) -- and v_readlane hands each result to the whole wave as an SGPR pair.  No LDS, no barrier,
+// and ~60 fewer VGPRs per lane than keeping them in vector registers.
+template <int NT>
+struct EpochConsts {
+    double rc[kGroup], rs[kGroup];  // cos,sin(-j*dphi): per-sample rotations inside a group
+    double c8, s8;                  // -8*dphi:  first -> second half of a 16-sample group
+    double cN, sN;                  // -8*THREADS*dphi:  lane stride of the 8-sample loop
+    double cW, sW;                  // -16*THREADS*dphi: lane stride of the 16-sample loop
+    double shift[NT], step[NT];     // np.linspace(shift, code_step*n+shift, n, endpoint=False) (tracking.py:111-112)
+    double inv_step[NT];            // 1/step: only ever used to PREDICT a chip-switch position
+};
+
+__device__ __forceinline__ double lane_value(double x, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
 
 template <int NT, int THREADS>
-__device__ __forceinline__ void stage_constants(double* kc, const EpochParams& ep, const double* spacing,
-                                                double dphi, int tid) {
-    if (tid < 11) {
-        const double mult = tid < 8 ? (double)tid : (tid == 8 ? 8.0 : (tid == 9 ? (double)(kGroup * THREADS)
-                                                                                  : (double)(2 * kGroup * THREADS)));
-        double sn, cs;
-        sincos_reduced(-mult * dphi, &sn, &cs);
-        kc[2 * tid] = cs;
-        kc[2 * tid + 1] = sn;
-    } else if (tid >= 16 && tid < 16 + NT) {
-        const int t = tid - 16;
-        const double nd = (double)ep.n;
-        const double shift = ep.rem_code + spacing[t];  // reference arithmetic, operation for operation
-        double stop = ep.code_step * nd;
-        stop = stop + shift;
-        const double delta = stop - shift;
-        const double step = delta / nd;
-        kc[22 + 3 * t] = shift;
-        kc[23 + 3 * t] = step;
-        kc[24 + 3 * t] = 1.0 / step;
+__device__ __forceinline__ void compute_constants(EpochConsts<NT>& k, const EpochParams& ep,
+                                                  const double* __restrict__ spacing, double dphi) {
+    const int lane = threadIdx.x & 63;
+    const double mult = lane < 8 ? (double)lane
+                                 : (lane == 8 ? 8.0 : (lane == 9 ? (double)(kGroup * THREADS) : (double)(2 * kGroup * THREADS)));
+    double sn, cs;
+    sincos_reduced(-mult * dphi, &sn, &cs);
+    int t = lane - 16;
+    t = t < 0 ? 0 : (t > NT - 1 ? NT - 1 : t);
+    const double nd = (double)ep.n;
+    const double shift = ep.rem_code + spacing[t];  // reference arithmetic, operation for operation
+    double stop = ep.code_step * nd;
+    stop = stop + shift;
+    const double delta = stop - shift;
+    const double step = delta / nd;
+    const double inv = 1.0 / step;
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) {
+        k.rc[j] = lane_value(cs, j);
+        k.rs[j] = lane_value(sn, j);
+    }
+    k.c8 = lane_value(cs, 8);
+    k.s8 = lane_value(sn, 8);
+    k.cN = lane_value(cs, 9);
+    k.sN = lane_value(sn, 9);
+    k.cW = lane_value(cs, 10);
+    k.sW = lane_value(sn, 10);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        k.shift[q] = lane_value(shift, 16 + q);
+        k.step[q] = lane_value(step, 16 + q);
+        k.inv_step[q] = lane_value(inv, 16 + q);
     }
 }
 
 // Correlate this thread's share (groups tid, tid+THREADS, ...) of one epoch.
-// accr/acci[NT] receive the thread-partial fp64 accumulators.  kc = staged constants (after a barrier).
+// accr/acci[NT] receive the thread-partial fp64 accumulators.
 template <int FMT, int NT, int THREADS>
 __device__ __forceinline__ void correlate_epoch(const void* __restrict__ ring, int64_t capacity,
-                                                const EpochParams& ep, double dphi, const double* kc,
+                                                const EpochParams& ep, double dphi, const EpochConsts<NT>& K,
                                                 const uint32_t* lut, int tid, double* accr, double* acci) {
     const int n = ep.n;
-    double rc[kGroup], rs[kGroup];
-#pragma unroll
-    for (int j = 0; j < kGroup; ++j) {
-        rc[j] = uniform(kc[2 * j]);
-        rs[j] = uniform(kc[2 * j + 1]);
-    }
-    const double c_it = uniform(kc[18]), s_it = uniform(kc[19]);
-    double shift[NT], step[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        shift[t] = uniform(kc[22 + 3 * t]);
-        step[t] = uniform(kc[23 + 3 * t]);
-    }
+    const double* rc = K.rc;
+    const double* rs = K.rs;
+    const double c_it = K.cN, s_it = K.sN;
+    const double* shift = K.shift;
+    const double* step = K.step;
 #pragma unroll
     for (int t = 0; t < NT; ++t) accr[t] = acci[t] = 0.0;
 
     const int64_t aligned = ep.start_sample & ~(int64_t)(kGroup - 1);
     const int head = (int)(ep.start_sample - aligned);
-    const int n_groups = (head + n + kGroup - 1) / kGroup;
     const int64_t base = aligned % capacity;
+    // whole groups g in [g_lo, g_hi) lie inside the epoch; the rest are edge samples
+    const int g_lo = head ? 1 : 0;
+    const int g_hi = (head + n) / kGroup;
+    const int head_end = g_hi > g_lo ? g_lo * kGroup - head : n;   // no whole group: every sample is "edge"
+    const int tail_start = g_hi > g_lo ? g_hi * kGroup - head : n;
 
-    // One 8-sample group.  EDGE = the group straddles the start or the end of the epoch:
-    // samples outside [0,n) are zeroed and their (unused) chip index is clamped into range.
-    auto group = [&](int g, double sb, double cb, auto edge_tag) {
-        constexpr bool EDGE = decltype(edge_tag)::value;
+    // One whole 8-sample group.
+    auto group = [&](int g, double sb, double cb) {
         int64_t pos = base + (int64_t)g * kGroup;
         if (pos >= capacity) pos -= capacity;
         double xr[kGroup], xi[kGroup];
@@ -237,14 +303,8 @@ __device__ __forceinline__ void correlate_epoch(const void* __restrict__ ring, i
 
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) {
-            int i = i0 + j;
-            double ar = xr[j], ai = xi[j];
-            if (EDGE) {
-                const bool valid = (unsigned)i < (unsigned)n;
-                ar = valid ? ar : 0.0;
-                ai = valid ? ai : 0.0;
-                i = i < 0 ? 0 : (i >= n ? n - 1 : i);
-            }
+            const int i = i0 + j;
+            const double ar = xr[j], ai = xi[j];
             const double zr = __builtin_fma(-ai, rs[j], ar * rc[j]);
             const double zi = __builtin_fma(ai, rc[j], ar * rs[j]);
             const double di = (double)i;
@@ -267,16 +327,19 @@ __device__ __forceinline__ void correlate_epoch(const void* __restrict__ ring, i
 
     // carrier phase at the lane's first sample: one exact evaluation, then a fixed rotation per iteration
     double sb, cb;
-    sincos_reduced(__builtin_fma(-(double)(tid * kGroup - head), dphi, ep.rem_carrier), &sb, &cb);
-    for (int g = tid; g < n_groups; g += THREADS) {
-        const int i0 = g * kGroup - head;
-        if (i0 >= 0 && i0 + kGroup <= n)
-            group(g, sb, cb, std::false_type{});
-        else
-            group(g, sb, cb, std::true_type{});
+    sincos_reduced(__builtin_fma(-(double)((g_lo + tid) * kGroup - head), dphi, ep.rem_carrier), &sb, &cb);
+    for (int g = g_lo + tid; g < g_hi; g += THREADS) {
+        group(g, sb, cb);
         const double cbn = __builtin_fma(cb, c_it, -sb * s_it);
         sb = __builtin_fma(sb, c_it, cb * s_it);
         cb = cbn;
+    }
+    if (tid < 64 && head_end + (n - tail_start) > 64) {
+        // (only when n < 8 + 64: a tiny epoch; walk the edge list in wave-sized pieces)
+        for (int off = 0; off < head_end + (n - tail_start); off += 64)
+            edge_samples<FMT, NT>(ring, capacity, ep, dphi, shift, step, lut, tid + off, head_end, tail_start, accr, acci);
+    } else if (tid < 64) {
+        edge_samples<FMT, NT>(ring, capacity, ep, dphi, shift, step, lut, tid, head_end, tail_start, accr, acci);
     }
 }
 
@@ -364,32 +427,28 @@ struct Raw8<SDR_FMT_CF64> {
 
 template <int FMT, int NT, int THREADS>
 __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ring, int64_t capacity,
-                                                     const EpochParams& ep, double dphi, const double* kc,
+                                                     const EpochParams& ep, double dphi, const EpochConsts<NT>& K,
                                                      const uint32_t* lut, int tid, double* accr, double* acci) {
     const int n = ep.n;
-    double rc[kGroup], rs[kGroup];
-#pragma unroll
-    for (int j = 0; j < kGroup; ++j) {
-        rc[j] = uniform(kc[2 * j]);
-        rs[j] = uniform(kc[2 * j + 1]);
-    }
-    const double c8 = uniform(kc[16]), s8 = uniform(kc[17]);      // first -> second half of a group
-    const double c_it = uniform(kc[20]), s_it = uniform(kc[21]);  // lane stride of this loop
+    const double* rc = K.rc;
+    const double* rs = K.rs;
+    const double c8 = K.c8, s8 = K.s8;      // first -> second half of a group
+    const double c_it = K.cW, s_it = K.sW;  // lane stride of this loop
     const double dphi_u = uniform(dphi), rem_carrier_u = uniform(ep.rem_carrier);
-    double shift[NT], step[NT], inv_step[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        shift[t] = uniform(kc[22 + 3 * t]);
-        step[t] = uniform(kc[23 + 3 * t]);
-        inv_step[t] = uniform(kc[24 + 3 * t]);  // only used to PREDICT the switch position
-    }
+    const double* shift = K.shift;
+    const double* step = K.step;
+    const double* inv_step = K.inv_step;
 #pragma unroll
     for (int t = 0; t < NT; ++t) accr[t] = acci[t] = 0.0;
 
     const int64_t aligned = ep.start_sample & ~(int64_t)(kGroup - 1);
     const int head = (int)(ep.start_sample - aligned);
-    const int n_groups = (head + n + kWide - 1) / kWide;
     const int64_t base = aligned % capacity;
+    // whole 16-sample groups g in [g_lo, g_hi); everything else is an edge sample (<= 30 of them)
+    const int g_lo = head ? 1 : 0;
+    const int g_hi = (head + n) / kWide;
+    const int head_end = g_hi > g_lo ? g_lo * kWide - head : n;
+    const int tail_start = g_hi > g_lo ? g_hi * kWide - head : n;
 
     auto load_group = [&](int g, Raw8<FMT>* raw) {
         int64_t pos = base + (int64_t)g * kWide;
@@ -400,11 +459,8 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
         raw[1].load(ring, pos2);
     };
 
-    auto group = [&](int g, const Raw8<FMT>* raw, double sb, double cb, auto edge_tag) {
-        constexpr bool EDGE = decltype(edge_tag)::value;
-
+    auto group = [&](int g, const Raw8<FMT>* raw, double sb, double cb) {
         const int i0 = g * kWide - head;
-        auto clampi = [&](int i) { return EDGE ? (i < 0 ? 0 : (i >= n ? n - 1 : i)) : i; };
         // the reference's chip index, exactly: separate multiply, add, ceil
         auto chip = [&](int i, int t, double* yout) {
             double y = (double)i * step[t];
@@ -417,18 +473,17 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
         // position, chip p0+1 after it).  A shift + and-or per sample then rebuilds the high word
         // of +-1.0 without compare/select pairs (VALU->SGPR->VALU costs wait states on gfx950).
         uint32_t signs[NT];
-        const int ia = clampi(i0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             double y0;
-            const int p0 = chip(ia, t, &y0);
+            const int p0 = chip(i0, t, &y0);
             // predicted first sample (group-relative) whose chip is p0+1; a prediction beyond the
             // group is clamped to the last sample, where the check below then finds "no switch"
             const double e = ((double)p0 - y0) * inv_step[t];
-            int b = (ia - i0) + (int)e + 1;
+            int b = (int)e + 1;
             b = b < 1 ? 1 : (b > kWide - 1 ? kWide - 1 : b);
-            const int pa = chip(clampi(i0 + b - 1), t, nullptr);
-            const int pb = chip(clampi(i0 + b), t, nullptr);
+            const int pa = chip(i0 + b - 1, t, nullptr);
+            const int pb = chip(i0 + b, t, nullptr);
             b = (pa != p0) ? b - 1 : ((pb == p0) ? b + 1 : b);   // b in [1,16]; 16 = whole group on chip p0
             const uint32_t lead = (1u << b) - 1u;                 // samples that use chip p0
             const uint32_t neg0 = 0u - (lut[p0 + SDR_LUT_PAD] >> 31);        // all ones when chip p0 is -1
@@ -448,11 +503,6 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
                 const int jj = half * kGroup + j;
                 double ar, ai;
                 raw[half].get(j, ar, ai);
-                if (EDGE) {
-                    const bool valid = (unsigned)(i0 + jj) < (unsigned)n;
-                    ar = valid ? ar : 0.0;
-                    ai = valid ? ai : 0.0;
-                }
                 const double zr = __builtin_fma(-ai, rs[j], ar * rc[j]);
                 const double zi = __builtin_fma(ai, rc[j], ar * rs[j]);
 #pragma unroll
@@ -481,27 +531,31 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
 
     // Software prefetch: the next group's two 16-byte loads are in flight while this one is computed.
     Raw8<FMT> cur[2], nxt[2];
-    int g = tid;
-    if (g < n_groups) load_group(g, cur);
+    int g = g_lo + tid;
+    if (g < g_hi) load_group(g, cur);
     // Carrier phase at the lane's first sample: one exact evaluation, then a fixed rotation per
     // iteration (the lane's groups are kWide*THREADS samples apart; <= a few dozen steps, so the
     // recurrence stays within ~1e-15 of a fresh evaluation).
     double sb, cb;
-    sincos_reduced(__builtin_fma(-(double)(tid * kWide - head), dphi_u, rem_carrier_u), &sb, &cb);
-    while (g < n_groups) {
+    sincos_reduced(__builtin_fma(-(double)((g_lo + tid) * kWide - head), dphi_u, rem_carrier_u), &sb, &cb);
+    while (g < g_hi) {
         const int gn = g + THREADS;
-        if (gn < n_groups) load_group(gn, nxt);
-        const int i0 = g * kWide - head;
-        if (i0 >= 0 && i0 + kWide <= n)
-            group(g, cur, sb, cb, std::false_type{});
-        else
-            group(g, cur, sb, cb, std::true_type{});
+        if (gn < g_hi) load_group(gn, nxt);
+        group(g, cur, sb, cb);
         cur[0] = nxt[0];
         cur[1] = nxt[1];
         const double cbn = __builtin_fma(cb, c_it, -sb * s_it);
         sb = __builtin_fma(sb, c_it, cb * s_it);
         cb = cbn;
         g = gn;
+    }
+    if (tid < 64) {
+        if (head_end + (n - tail_start) > 64) {   // epoch shorter than a group + a wave: walk the list
+            for (int off = 0; off < head_end + (n - tail_start); off += 64)
+                edge_samples<FMT, NT>(ring, capacity, ep, dphi, shift, step, lut, tid + off, head_end, tail_start, accr, acci);
+        } else {
+            edge_samples<FMT, NT>(ring, capacity, ep, dphi, shift, step, lut, tid, head_end, tail_start, accr, acci);
+        }
     }
 }
 
@@ -513,6 +567,22 @@ template <int NT, int THREADS>
 __device__ __forceinline__ double reduce_taps(const double* accr, const double* acci, double* red, int tid) {
     constexpr int kWaves = THREADS / 64;
     const int lane = tid & 63, wave = tid >> 6;
+    if (kWaves == 1) {
+        // one wave: lane 0 ends up with every total; deal them to lanes 0..2*NT-1 without LDS or barrier
+        double mine = 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double a = accr[t], b = acci[t];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                a += __shfl_down(a, off, 64);
+                b += __shfl_down(b, off, 64);
+            }
+            const double ta = lane_value(a, 0), tb = lane_value(b, 0);
+            mine = lane == 2 * t ? ta : (lane == 2 * t + 1 ? tb : mine);
+        }
+        return mine;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         double a = accr[t], b = acci[t];

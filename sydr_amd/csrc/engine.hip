@@ -136,6 +136,7 @@ void sdr_engine_destroy(sdr_engine* e) {
         if (b->ptr) (void)hipFree(b->ptr);
     if (e->iq) (void)hipFree(e->iq);
     if (e->codes) (void)hipFree(e->codes);
+    if (e->luts) (void)hipFree(e->luts);
     if (e->code_len) (void)hipFree(e->code_len);
     (void)hipStreamDestroy(e->stream);
     delete e;

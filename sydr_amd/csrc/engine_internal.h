@@ -55,6 +55,10 @@ struct sdr_engine {
     std::vector<int32_t> code_len_host;
     int n_slots = 0;
     int code_stride = 0;
+    // per slot: the replica as the kernels want it in LDS -- uint32 high words of +-1.0 with the periodic
+    // padding already applied (lut[q] = chip[(q - SDR_LUT_PAD - 1) mod L]); copied with 16-byte loads
+    uint32_t* luts = nullptr;  // [n_slots][lut_stride]
+    int lut_stride = 0;
 
     // workspaces
     DevBuf ws_items, ws_out, ws_spacing;

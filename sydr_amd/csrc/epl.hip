@@ -21,10 +21,10 @@ namespace {
 
 using namespace sdr;
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 64;  // one wave per channel-epoch: the ~5 us fixed latency of a workgroup is amortised over 4x more work
 constexpr int kWaves = kThreads / 64;
 
-// Dynamic LDS: [kc: kConstDoubles][red: kWaves*2*NT doubles][lut: lut_words uint32]
+// Dynamic LDS: [red: kWaves*2*NT doubles][lut: lut_words uint32]
 //
 // One workgroup per item.  (A persistent grid-stride variant that keeps the replica in LDS across
 // items was measured slower: holding two items' parameters pushed the kernel from 4 to 2 resident
@@ -33,19 +33,18 @@ constexpr int kWaves = kThreads / 64;
 template <int FMT, int NT, bool WIDE>
 __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ ring, int64_t capacity,
                                                        const sdr_epl_item* __restrict__ items,
-                                                       const int8_t* __restrict__ codes,
-                                                       const int32_t* __restrict__ code_len, int code_stride,
+                                                       const uint32_t* __restrict__ luts,
+                                                       const int32_t* __restrict__ code_len, int lut_stride,
                                                        const double* __restrict__ spacing, double fs,
                                                        int tap0, int n_taps_total,
                                                        double* __restrict__ out) {
     extern __shared__ double smem[];
-    double* kc = smem;
-    double* red = smem + kConstDoubles;
+    double* red = smem;
     uint32_t* lut = reinterpret_cast<uint32_t*>(red + kWaves * 2 * NT);
 
     const int tid = threadIdx.x;
     const sdr_epl_item it = items[blockIdx.x];
-    stage_lut<kThreads>(lut, codes + (size_t)it.code_slot * code_stride, code_len[it.code_slot], tid);
+    stage_lut<kThreads>(lut, luts + (size_t)it.code_slot * lut_stride, code_len[it.code_slot], tid);
     const double dphi = carrier_step(it.carrier_hz, fs);
     EpochParams ep;
     ep.start_sample = it.start_sample;
@@ -54,14 +53,15 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
     ep.rem_carrier = it.rem_carrier;
     ep.rem_code = it.rem_code;
     ep.code_step = it.code_step;
-    stage_constants<NT, kThreads>(kc, ep, spacing + tap0, dphi, tid);
-    __syncthreads();
+    EpochConsts<NT> K;
+    compute_constants<NT, kThreads>(K, ep, spacing + tap0, dphi);
+    __syncthreads();  // replica staged
 
     double accr[NT], acci[NT];
     if (WIDE)
-        correlate_epoch_wide<FMT, NT, kThreads>(ring, capacity, ep, dphi, kc, lut, tid, accr, acci);
+        correlate_epoch_wide<FMT, NT, kThreads>(ring, capacity, ep, dphi, K, lut, tid, accr, acci);
     else
-        correlate_epoch<FMT, NT, kThreads>(ring, capacity, ep, dphi, kc, lut, tid, accr, acci);
+        correlate_epoch<FMT, NT, kThreads>(ring, capacity, ep, dphi, K, lut, tid, accr, acci);
     const double total = reduce_taps<NT, kThreads>(accr, acci, red, tid);
     if (tid < 2 * NT) out[(size_t)blockIdx.x * 2 * n_taps_total + 2 * tap0 + tid] = total;
 }
@@ -69,14 +69,14 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
 template <int FMT, int NT>
 void launch_one(sdr_engine* e, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
                 int tap0, int n_taps_total, int lut_words, bool wide, double* d_out) {
-    size_t shmem = (kConstDoubles + kWaves * 2 * NT) * sizeof(double) + (size_t)lut_words * sizeof(uint32_t);
+    size_t shmem = (size_t)(kWaves * 2 * NT) * sizeof(double) + (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
     if (wide)
         hipLaunchKernelGGL((epl_kernel<FMT, NT, true>), dim3(n_items), dim3(kThreads), shmem, e->stream, e->iq,
-                           e->iq_capacity, d_items, e->codes, e->code_len, e->code_stride, d_spacing, fs, tap0,
+                           e->iq_capacity, d_items, e->luts, e->code_len, e->lut_stride, d_spacing, fs, tap0,
                            n_taps_total, d_out);
     else
         hipLaunchKernelGGL((epl_kernel<FMT, NT, false>), dim3(n_items), dim3(kThreads), shmem, e->stream, e->iq,
-                           e->iq_capacity, d_items, e->codes, e->code_len, e->code_stride, d_spacing, fs, tap0,
+                           e->iq_capacity, d_items, e->luts, e->code_len, e->lut_stride, d_spacing, fs, tap0,
                            n_taps_total, d_out);
 }
 

@@ -59,7 +59,7 @@ __device__ __forceinline__ double borre_filter(double x, double mem, double tau1
     return out;
 }
 
-struct EpochShared {
+struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind it is copied with 16-byte stores)
     EpochParams ep;
     double spacing[kTaps];
     double dphi;
@@ -75,12 +75,11 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
                                                               const sdr_loop_cfg* __restrict__ cfg_ptr,
                                                               int n_epochs, sdr_track_epoch* __restrict__ traj,
                                                               int keep_traj,
-                                                              const int8_t* __restrict__ codes,
+                                                              const uint32_t* __restrict__ luts,
                                                               const int32_t* __restrict__ code_len,
-                                                              int code_stride) {
+                                                              int lut_stride) {
     extern __shared__ double smem[];
-    double* kc = smem;                                    // per-epoch constants (correlator.h)
-    double* red = kc + kConstDoubles;                     // kTrackWaves * 6
+    double* red = smem;                                   // kTrackWaves * 6
     EpochShared* sh = reinterpret_cast<EpochShared*>(red + kTrackWaves * 2 * kTaps);
     uint32_t* lut = reinterpret_cast<uint32_t*>(sh + 1);
 
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
     }
     const int slot = states[ch].code_slot;
     const int L = code_len[slot];
-    stage_lut<kTrackThreads>(lut, codes + (size_t)slot * code_stride, L, tid);
+    stage_lut<kTrackThreads>(lut, luts + (size_t)slot * lut_stride, L, tid);
     const double fs = cfg_ptr->fs;
     sdr_track_state& st = sh->st;
     const sdr_loop_cfg& cfg = sh->cfg;
@@ -127,17 +126,14 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
         if (sh->stop) break;
         const EpochParams ep = sh->ep;
         const double dphi = sh->dphi;
-        double sp[kTaps];
-#pragma unroll
-        for (int t = 0; t < kTaps; ++t) sp[t] = sh->spacing[t];
-        stage_constants<kTaps, kTrackThreads>(kc, ep, sp, dphi, tid);
-        __syncthreads();
+        EpochConsts<kTaps> K;
+        compute_constants<kTaps, kTrackThreads>(K, ep, sh->spacing, dphi);
 
         double accr[kTaps], acci[kTaps];
         if (ep.code_step <= kFastMaxCodeStep)   // uniform branch: 16-sample boundary variant above ~17 MHz
-            correlate_epoch_wide<FMT, kTaps, kTrackThreads>(ring, capacity, ep, dphi, kc, lut, tid, accr, acci);
+            correlate_epoch_wide<FMT, kTaps, kTrackThreads>(ring, capacity, ep, dphi, K, lut, tid, accr, acci);
         else
-            correlate_epoch<FMT, kTaps, kTrackThreads>(ring, capacity, ep, dphi, kc, lut, tid, accr, acci);
+            correlate_epoch<FMT, kTaps, kTrackThreads>(ring, capacity, ep, dphi, K, lut, tid, accr, acci);
         const double total = reduce_taps<kTaps, kTrackThreads>(accr, acci, red, tid);
 
         // lanes 0..5 of wave 0 hold [IE,QE,IP,QP,IL,QL]; hand them to lane 0 without a barrier
@@ -338,8 +334,8 @@ int sdr_track_closed_loop(sdr_engine* e, int n_ch, sdr_track_state* st, const sd
     SDR_HIP(hipMemcpyAsync(e->track_state.ptr, st, (size_t)n_ch * sizeof(sdr_track_state), hipMemcpyHostToDevice, e->stream));
     SDR_HIP(hipMemcpyAsync(e->track_cfg.ptr, cfg, sizeof(sdr_loop_cfg), hipMemcpyHostToDevice, e->stream));
     const int lut_words = maxlen + 2 * SDR_LUT_PAD + 2;
-    const size_t shmem = (kConstDoubles + kTrackWaves * 2 * kTaps) * sizeof(double) + sizeof(EpochShared) +
-                         (size_t)lut_words * sizeof(uint32_t);
+    const size_t shmem = (size_t)(kTrackWaves * 2 * kTaps) * sizeof(double) + sizeof(EpochShared) +
+                         (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
     sdr_track_state* d_st = (sdr_track_state*)e->track_state.ptr;
     const sdr_loop_cfg* d_cfg = (const sdr_loop_cfg*)e->track_cfg.ptr;
     sdr_track_epoch* d_traj = (sdr_track_epoch*)e->track_traj.ptr;
@@ -348,16 +344,16 @@ int sdr_track_closed_loop(sdr_engine* e, int n_ch, sdr_track_state* st, const sd
         ProfScope ps(e, "track_kernel");
         switch (e->iq_fmt) {
             case SDR_FMT_CI8:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CI8>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->codes, e->code_len, e->code_stride);
+                hipLaunchKernelGGL(track_kernel<SDR_FMT_CI8>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, e->code_len, e->lut_stride);
                 break;
             case SDR_FMT_CI16:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CI16>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->codes, e->code_len, e->code_stride);
+                hipLaunchKernelGGL(track_kernel<SDR_FMT_CI16>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, e->code_len, e->lut_stride);
                 break;
             case SDR_FMT_CF32:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CF32>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->codes, e->code_len, e->code_stride);
+                hipLaunchKernelGGL(track_kernel<SDR_FMT_CF32>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, e->code_len, e->lut_stride);
                 break;
             default:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CF64>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->codes, e->code_len, e->code_stride);
+                hipLaunchKernelGGL(track_kernel<SDR_FMT_CF64>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, e->code_len, e->lut_stride);
                 break;
         }
     }
