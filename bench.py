@@ -134,8 +134,138 @@ def closed_loop_leg(eng, items, n_epochs):
             "us_per_epoch": kern_ms * 1e3 / n_epochs, "channels_lost": int(lost)}
 
 
+def multignss_workload(args, rank, local_rank, world, torch, dist):
+    """BASELINE configs 4-5: per GPU 32 GPS L1 C/A + 32 E1-like (seeded 4092-chip codes, BOC(1,1)) channels,
+    5 taps VE/E/P/L/VL, fs = 50 MHz, 4 ms epochs.  Not the headline metric: selected with --workload multignss."""
+    from sydr_amd.engine import FMT_CI8, Engine, make_items
+    fs, n_gps, n_e1, taps = 50e6, 32, 32, (-1.0, -0.5, 0.0, 0.5, 1.0)
+    eng = Engine(local_rank)
+    total = int(args.stream_seconds * fs) // 8 * 8
+    eng.iq_alloc(total, FMT_CI8)
+    eng.code_slots(n_gps + 2 * n_e1, 8184)
+    rng = np.random.default_rng(20260004 + 1000 * rank)
+    sats = []
+    for s in range(n_gps):
+        eng.load_gps_code(s, s + 1)
+        sats.append(dict(prn=s + 1, doppler=float(rng.uniform(-4500, 4500)), code_phase=float(rng.uniform(0, 1023)),
+                         phase=float(rng.random()), amp=2.5, chips=1023, corr_slot=s, half=1))
+    for s in range(n_e1):
+        code = np.where(rng.random(4092) < 0.5, -1, 1).astype(np.int8)   # seeded stand-in for an E1 memory code
+        half = np.empty(8184, dtype=np.int8)
+        half[0::2], half[1::2] = code, -code
+        eng.set_code(n_gps + s, code)                # chip-rate code: read by the generator
+        eng.set_code(n_gps + n_e1 + s, half)         # half-chip code: read by the correlator
+        sats.append(dict(slot=n_gps + s, boc=True, doppler=float(rng.uniform(-4500, 4500)),
+                         code_phase=float(rng.uniform(0, 4092)), phase=float(rng.random()), amp=2.5, chips=4092,
+                         corr_slot=n_gps + n_e1 + s, half=2))
+    eng.iq_synth(sats, fs, 12.0, 20260004 + rank, 0, total)
+
+    def items_for(group):
+        dop = np.array([s["doppler"] for s in group])
+        chips = float(group[0]["chips"])
+        half = group[0]["half"]
+        periods = 4 if chips == 1023 else 1                        # 4 ms of code
+        cstep = CODE_RATE * (1.0 + dop / L1) / fs
+        cp0 = np.array([s["code_phase"] for s in group])
+        ph0 = np.array([s["phase"] for s in group])
+        start = np.ceil((chips - cp0) / cstep).astype(np.int64)
+        rem = cp0 + start * cstep - chips
+        span = chips * periods
+        rows = []
+        while np.all(start + np.ceil(span / cstep) + 2 < total):
+            n = np.ceil((span - rem) / cstep).astype(np.int64)
+            cyc = dop / fs * start + ph0
+            rows.append((n.copy(), start.copy(), (-2.0 * np.pi * (cyc - np.floor(cyc))) % (2.0 * np.pi), rem.copy()))
+            rem = rem + n * cstep - span
+            start = start + n
+        e = len(rows)
+        slots = np.tile([s["corr_slot"] for s in group], e)
+        return make_items(slots, np.stack([r[0] for r in rows]).reshape(-1), np.stack([r[1] for r in rows]).reshape(-1),
+                          np.tile(dop, e), np.stack([r[2] for r in rows]).reshape(-1),
+                          half * np.stack([r[3] for r in rows]).reshape(-1), np.tile(half * cstep, e)), e
+
+    gps_items, e_gps = items_for(sats[:n_gps])
+    e1_items, e_e1 = items_for(sats[n_gps:])
+    plans = [(eng.epl_plan(gps_items, taps, fs), n_gps, e_gps, gps_items),
+             (eng.epl_plan(e1_items, tuple(2 * t for t in taps), fs), n_e1, e_e1, e1_items)]
+    per_step = 250                                                   # epochs per step = 1 s of stream
+    n_avail = max(1, min(e_gps, e_e1) // per_step)
+
+    def run_step(k):
+        for plan, n_ch, _, _ in plans:
+            plan.run((k % n_avail) * per_step * n_ch, per_step * n_ch)
+
+    for k in range(args.warmup):
+        run_step(k)
+    eng.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    eng.prof_reset()
+    eng.prof_enable(True)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        run_step(k)
+    eng.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    eng.prof_enable(False)
+    kern_ms, launches = eng.prof_read("epl_kernel")
+    ch_samples = 0
+    for k in range(args.steps):
+        for _, n_ch, _, items in plans:
+            lo = (k % n_avail) * per_step * n_ch
+            ch_samples += int(items["n_samples"][lo:lo + per_step * n_ch].sum())
+    stream_samples = ch_samples / (n_gps + n_e1)
+    value = world * stream_samples / elapsed / 1e6
+    achieved = 2.0 * ch_samples / (kern_ms * 1e-3) / 1e9 if launches else 0.0
+    result = {"metric": "IQ Msamples/s through 64-ch 5-tap VE/E/P/L/VL correlators @50 MHz fs, 4 ms integration",
+              "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": "f64", "data": "synthetic",
+              "config": {"workload": "GPS L1 C/A (32 ch) + E1-like BOC(1,1) with seeded 4092-chip codes (32 ch) per GPU, "
+                                     f"5 taps, fs=50 MHz, 4 ms epochs, {args.stream_seconds:g} s ci8 stream, 1 step = 1 s",
+                         "channels_per_gpu": n_gps + n_e1, "fs_hz": fs, "taps": 5, "iq_format": "ci8",
+                         "note": "no reference implementation exists for this configuration (SURVEY.md section 0); "
+                                 "parity is against the oracle's generalised restatement"},
+              "x_realtime": value * 1e6 / fs / world,
+              "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "epl_kernel",
+                           "avg_launch_ms": kern_ms / max(1, launches), "launches": int(launches)}}
+    if rank == 0 and world == 1:
+        from oracle import sydr_oracle as orc
+        got = plans[1][0].fetch()
+        it = e1_items[0]
+        raw = eng.iq_download(int(it["start_sample"] + it["n_samples"]), 0)
+        chips = eng.read_code(int(it["code_slot"])).astype(np.float64)
+        t0 = time.perf_counter()
+        ref = np.array(orc.epl(orc.iq_to_complex(raw)[int(it["start_sample"]):], orc.pad_code(chips), fs,
+                               float(it["carrier_hz"]), float(it["rem_carrier"]), float(it["rem_code"]),
+                               float(it["code_step"]), tuple(2 * t for t in taps)))
+        dt = time.perf_counter() - t0
+        scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), 1.0), 2)
+        err = float(np.max(np.abs(got[0] - ref) / scale))
+        if err > 1e-6:
+            raise SystemExit(f"GPU/oracle mismatch in multignss bench: {err:.3e}")
+        result["cpu_baseline"] = {"value": float(it["n_samples"]) / (n_gps + n_e1) / dt / 1e6, "unit": "Msamples/s", "cores": 1,
+                                  "kind": "port", "sample": "one E1-like channel-epoch (200 000 samples, 5 taps) through "
+                                  "oracle/sydr_oracle.py:epl, scaled to 64 channels", "max_rel_err_gpu_vs_oracle": err}
+    for plan, *_ in plans:
+        plan.close()
+    eng.close()
+    if rank == 0:
+        print(json.dumps(result))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["l1ca32", "multignss"], default="l1ca32",
+                    help="l1ca32 = BASELINE configs[2] (headline); multignss = configs[3]/[4] geometry")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=2)
@@ -160,6 +290,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    if args.workload == "multignss":
+        if args.stream_seconds == 60.0:
+            args.stream_seconds = 10.0
+        multignss_workload(args, rank, local_rank, world, torch, dist)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from sydr_amd.engine import FMT_CI8, Engine
 

@@ -93,9 +93,11 @@ int sdr_iq_download(sdr_engine* e, void* iq, int64_t n_samples, int64_t ring_off
  * rounded and clipped to the ring's integer format.  chip_s(n) =
  * code_phase_s + n * 1.023e6*(1+doppler_s/1575.42e6)/fs (chips, mod 1023); d_s is a
  * seeded +-1 sequence changing every 20 code periods.  Deterministic in (seed, n). */
+#define SDR_SYNTH_CODE_SLOT 1 /* `prn` is a staged code slot (any length), not a GPS PRN number      */
+#define SDR_SYNTH_BOC11 2     /* multiply by the BOC(1,1) square sub-carrier (flip every half chip)  */
 typedef struct sdr_synth_sat {
-    int32_t prn;        /* GPS PRN 1..210                              */
-    int32_t reserved;
+    int32_t prn;        /* GPS PRN 1..210, or a code slot with SDR_SYNTH_CODE_SLOT */
+    int32_t flags;
     double doppler_hz;  /* carrier Doppler                             */
     double code_phase;  /* chips into the code at ring sample 0        */
     double carrier_phase; /* cycles at ring sample 0                   */
@@ -110,6 +112,9 @@ int sdr_iq_synth(sdr_engine* e, const sdr_synth_sat* sats, int n_sats, double fs
  * delay table) and replaces GenerateGPSGoldCode (sydr/signal/gnsssignal.py:9-31
  * -> sydr/signal/ca.py:70-112; chip mapping bit 1 -> +1, bit 0 -> -1). */
 int sdr_code_slots(sdr_engine* e, int n_slots, int max_chips);
+/* Same, with the replicas staged over max_periods code periods so that one correlator epoch may span
+ * several periods (e.g. 4 ms of C/A code) or taps may sit many chips out; chips*periods <= 32768. */
+int sdr_code_slots_ex(sdr_engine* e, int n_slots, int max_chips, int max_periods);
 int sdr_code_gps_l1ca(sdr_engine* e, int slot, int prn);
 /* Stage an arbitrary +-1 code (e.g. a synthetic 4092-chip E1-like code). */
 int sdr_code_custom(sdr_engine* e, int slot, const int8_t* chips, int n_chips);

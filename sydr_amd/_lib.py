@@ -38,7 +38,7 @@ EPL_ITEM_DTYPE = np.dtype([("code_slot", np.int32), ("n_samples", np.int32), ("s
 
 
 class SynthSat(C.Structure):
-    _fields_ = [("prn", C.c_int32), ("reserved", C.c_int32), ("doppler_hz", C.c_double),
+    _fields_ = [("prn", C.c_int32), ("flags", C.c_int32), ("doppler_hz", C.c_double),
                 ("code_phase", C.c_double), ("carrier_phase", C.c_double), ("amplitude", C.c_double)]
 
 
@@ -103,6 +103,7 @@ _PROTOTYPES = {
     "sdr_iq_synth": (C.c_int, [_VP, C.POINTER(SynthSat), C.c_int, C.c_double, C.c_double, C.c_uint64,
                                C.c_int64, C.c_int64]),
     "sdr_code_slots": (C.c_int, [_VP, C.c_int, C.c_int]),
+    "sdr_code_slots_ex": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int]),
     "sdr_code_gps_l1ca": (C.c_int, [_VP, C.c_int, C.c_int]),
     "sdr_code_custom": (C.c_int, [_VP, C.c_int, _VP, C.c_int]),
     "sdr_code_read": (C.c_int, [_VP, C.c_int, _VP, C.c_int, C.POINTER(C.c_int)]),

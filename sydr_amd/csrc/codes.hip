@@ -71,14 +71,15 @@ __global__ __launch_bounds__(256) void upsample_kernel(const int8_t* __restrict_
     out[k] = code[idx];
 }
 
-// Replica in LDS form: out[q] = high word of (double)chip[(q - PAD - 1) mod L] for q < L + 2*PAD + 2.
+// Replica in LDS form: out[q] = high word of (double)chip[(q - PAD - 1) mod L], periodic over the whole
+// row, so that multi-period epochs (4 ms of C/A code) and far-out taps index it without a modulo.
 __global__ __launch_bounds__(256) void expand_lut_kernel(const int8_t* __restrict__ chips, int L,
                                                          uint32_t* __restrict__ out, int words) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= words) return;
     int c = (q - SDR_LUT_PAD - 1) % L;
     if (c < 0) c += L;
-    out[q] = (q < L + 2 * SDR_LUT_PAD + 2 && chips[c] > 0) ? 0x3FF00000u : 0xBFF00000u;
+    out[q] = chips[c] > 0 ? 0x3FF00000u : 0xBFF00000u;
 }
 
 /* ------------------------------------------------ synthetic IQ generator */
@@ -111,7 +112,11 @@ struct SynthSatDev {
     double fcyc;      // carrier cycles per sample
     double phase0;    // cycles at sample 0
     float amp;
-    int32_t prn;
+    int32_t id;          // seeds the data-bit stream
+    int32_t code_off;    // first chip of this satellite's code in the packed chip buffer
+    int32_t code_len;    // chips per code period
+    int32_t boc;         // 1: multiply by the BOC(1,1) square sub-carrier (sign flips every half chip)
+    int32_t bit_periods; // code periods per data bit
 };
 
 template <typename T>
@@ -126,12 +131,14 @@ __global__ __launch_bounds__(256) void synth_kernel(T* __restrict__ ring, int64_
     for (int s = 0; s < n_sats; ++s) {
         const SynthSatDev sat = sats[s];
         double chips = sat.code0 + (double)n * sat.cstep;
-        double period = floor(chips / (double)SDR_GPS_L1CA_CHIPS);
-        int chip = (int)floor(chips - period * (double)SDR_GPS_L1CA_CHIPS);
-        chip = chip < 0 ? 0 : (chip >= SDR_GPS_L1CA_CHIPS ? SDR_GPS_L1CA_CHIPS - 1 : chip);
-        int64_t bit_index = (int64_t)floor(period / 20.0);
-        uint64_t h = mix64(seed ^ mix64((uint64_t)sat.prn * 0x100000001B3ull + (uint64_t)bit_index));
-        float sgn = (float)codes[(size_t)s * SDR_GPS_L1CA_CHIPS + chip] * ((h & 1ull) ? 1.f : -1.f);
+        double period = floor(chips / (double)sat.code_len);
+        double in_period = chips - period * (double)sat.code_len;
+        int chip = (int)floor(in_period);
+        chip = chip < 0 ? 0 : (chip >= sat.code_len ? sat.code_len - 1 : chip);
+        int64_t bit_index = (int64_t)floor(period / (double)sat.bit_periods);
+        uint64_t h = mix64(seed ^ mix64((uint64_t)sat.id * 0x100000001B3ull + (uint64_t)bit_index));
+        float sgn = (float)codes[sat.code_off + chip] * ((h & 1ull) ? 1.f : -1.f);
+        if (sat.boc && (in_period - floor(in_period)) >= 0.5) sgn = -sgn;
         double cyc = sat.phase0 + (double)n * sat.fcyc;
         cyc -= rint(cyc);
         float sn, cs;
@@ -156,10 +163,14 @@ __global__ __launch_bounds__(256) void synth_kernel(T* __restrict__ ring, int64_
 
 extern "C" {
 
-int sdr_code_slots(sdr_engine* e, int n_slots, int max_chips) {
+int sdr_code_slots(sdr_engine* e, int n_slots, int max_chips) { return sdr_code_slots_ex(e, n_slots, max_chips, 1); }
+
+int sdr_code_slots_ex(sdr_engine* e, int n_slots, int max_chips, int max_periods) {
     if (int rc = sdr_set_device(e)) return rc;
-    if (n_slots <= 0 || max_chips < 1 || max_chips > 65536)
-        return sdr_fail(SDR_ERR_INVALID, "bad code slot geometry (%d slots, %d chips)", n_slots, max_chips);
+    if (n_slots <= 0 || max_chips < 1 || max_chips > 65536 || max_periods < 1 ||
+        (int64_t)max_chips * max_periods > 32768)
+        return sdr_fail(SDR_ERR_INVALID, "bad code slot geometry (%d slots, %d chips, %d periods; chips*periods <= 32768)",
+                        n_slots, max_chips, max_periods);
     SDR_HIP(hipStreamSynchronize(e->stream));
     if (e->codes) SDR_HIP(hipFree(e->codes));
     if (e->luts) SDR_HIP(hipFree(e->luts));
@@ -173,7 +184,7 @@ int sdr_code_slots(sdr_engine* e, int n_slots, int max_chips) {
         return sdr_fail(SDR_ERR_NOMEM, "hipMalloc for code slots failed");
     if (hipMalloc(&e->code_len, (size_t)n_slots * sizeof(int32_t)) != hipSuccess)
         return sdr_fail(SDR_ERR_NOMEM, "hipMalloc for code lengths failed");
-    const int lut_stride = (stride + 2 * SDR_LUT_PAD + 2 + 3) & ~3;
+    const int lut_stride = (stride * max_periods + 2 * SDR_LUT_PAD + 2 + 3) & ~3;
     if (hipMalloc(&e->luts, (size_t)n_slots * lut_stride * sizeof(uint32_t)) != hipSuccess)
         return sdr_fail(SDR_ERR_NOMEM, "hipMalloc for replica LUTs failed");
     e->lut_stride = lut_stride;
@@ -286,30 +297,50 @@ int sdr_iq_synth(sdr_engine* e, const sdr_synth_sat* sats, int n_sats, double fs
                         (long long)e->iq_capacity);
     if (n_samples == 0) return SDR_OK;
     std::vector<SynthSatDev> host(n_sats > 0 ? n_sats : 1);
-    std::vector<int32_t> prns(n_sats > 0 ? n_sats : 1, 1);
+    size_t total_chips = 0;
     for (int s = 0; s < n_sats; ++s) {
-        if (sats[s].prn < 1 || sats[s].prn > 210) return sdr_fail(SDR_ERR_INVALID, "synth PRN %d outside 1..210", sats[s].prn);
+        const bool from_slot = (sats[s].flags & SDR_SYNTH_CODE_SLOT) != 0;
+        int len = SDR_GPS_L1CA_CHIPS;
+        if (from_slot) {
+            if (!e->codes || sats[s].prn < 0 || sats[s].prn >= e->n_slots || e->code_len_host[sats[s].prn] <= 0)
+                return sdr_fail(SDR_ERR_INVALID, "synth satellite %d: code slot %d is not staged", s, sats[s].prn);
+            len = e->code_len_host[sats[s].prn];
+        } else if (sats[s].prn < 1 || sats[s].prn > 210) {
+            return sdr_fail(SDR_ERR_INVALID, "synth PRN %d outside 1..210", sats[s].prn);
+        }
         host[s].cstep = 1.023e6 * (1.0 + sats[s].doppler_hz / 1575.42e6) / fs;
         host[s].code0 = sats[s].code_phase;
         host[s].fcyc = sats[s].doppler_hz / fs;
         host[s].phase0 = sats[s].carrier_phase;
         host[s].amp = (float)sats[s].amplitude;
-        host[s].prn = sats[s].prn;
-        prns[s] = sats[s].prn;
+        host[s].id = sats[s].prn + (from_slot ? 1000 : 0);
+        host[s].code_off = (int32_t)total_chips;
+        host[s].code_len = len;
+        host[s].boc = (sats[s].flags & SDR_SYNTH_BOC11) ? 1 : 0;
+        host[s].bit_periods = len == SDR_GPS_L1CA_CHIPS ? 20 : 1;
+        total_chips += (size_t)len;
     }
     DevBuf dsat, dprn, dcode;
     int rc = sdr_devbuf_reserve(e, &dsat, host.size() * sizeof(SynthSatDev));
-    if (!rc) rc = sdr_devbuf_reserve(e, &dprn, prns.size() * sizeof(int32_t));
-    if (!rc) rc = sdr_devbuf_reserve(e, &dcode, prns.size() * SDR_GPS_L1CA_CHIPS);
+    if (!rc) rc = sdr_devbuf_reserve(e, &dprn, sizeof(int32_t) * (n_sats > 0 ? n_sats : 1));
+    if (!rc) rc = sdr_devbuf_reserve(e, &dcode, total_chips ? total_chips : 16);
     hipError_t err = hipSuccess;
     if (!rc) {
         err = hipMemcpyAsync(dsat.ptr, host.data(), host.size() * sizeof(SynthSatDev), hipMemcpyHostToDevice, e->stream);
-        if (err == hipSuccess)
-            err = hipMemcpyAsync(dprn.ptr, prns.data(), prns.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
-        if (err == hipSuccess && n_sats > 0) {
-            hipLaunchKernelGGL(gold_code_kernel, dim3(n_sats), dim3(256), 0, e->stream, (const int32_t*)dprn.ptr,
-                               (int8_t*)dcode.ptr, SDR_GPS_L1CA_CHIPS);
-            err = hipGetLastError();
+        for (int s = 0; s < n_sats && err == hipSuccess; ++s) {
+            int8_t* dst = (int8_t*)dcode.ptr + host[s].code_off;
+            if (sats[s].flags & SDR_SYNTH_CODE_SLOT) {
+                err = hipMemcpyAsync(dst, e->codes + (size_t)sats[s].prn * e->code_stride, host[s].code_len,
+                                     hipMemcpyDeviceToDevice, e->stream);
+            } else {
+                int32_t* dp = (int32_t*)dprn.ptr + s;
+                err = hipMemcpyAsync(dp, &sats[s].prn, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+                if (err == hipSuccess) {
+                    hipLaunchKernelGGL(gold_code_kernel, dim3(1), dim3(256), 0, e->stream, (const int32_t*)dp, dst,
+                                       SDR_GPS_L1CA_CHIPS);
+                    err = hipGetLastError();
+                }
+            }
         }
         if (err == hipSuccess) {
             ProfScope ps(e, "synth_kernel");

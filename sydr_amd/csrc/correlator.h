@@ -136,8 +136,8 @@ struct Loader<SDR_FMT_CF64> {
 // Stage a PRN replica into LDS: the per-slot table prepared by expand_lut_kernel (high words of +-1.0,
 // lut[q] = chip[(q - PAD - 1) mod L]) is copied with 16-byte loads -- two per lane for a C/A code.
 template <int THREADS>
-__device__ __forceinline__ void stage_lut(uint32_t* lut, const uint32_t* __restrict__ glut, int L, int tid) {
-    const int quads = (L + 2 * SDR_LUT_PAD + 2 + 3) >> 2;
+__device__ __forceinline__ void stage_lut(uint32_t* lut, const uint32_t* __restrict__ glut, int words, int tid) {
+    const int quads = (words + 3) >> 2;
     const uint4* src = reinterpret_cast<const uint4*>(glut);
     uint4* dst = reinterpret_cast<uint4*>(lut);
     for (int q = tid; q < quads; q += THREADS) dst[q] = src[q];

@@ -34,7 +34,7 @@ template <int FMT, int NT, bool WIDE>
 __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ ring, int64_t capacity,
                                                        const sdr_epl_item* __restrict__ items,
                                                        const uint32_t* __restrict__ luts,
-                                                       const int32_t* __restrict__ code_len, int lut_stride,
+                                                       int lut_words, int lut_stride,
                                                        const double* __restrict__ spacing, double fs,
                                                        int tap0, int n_taps_total,
                                                        double* __restrict__ out) {
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
 
     const int tid = threadIdx.x;
     const sdr_epl_item it = items[blockIdx.x];
-    stage_lut<kThreads>(lut, luts + (size_t)it.code_slot * lut_stride, code_len[it.code_slot], tid);
+    stage_lut<kThreads>(lut, luts + (size_t)it.code_slot * lut_stride, lut_words, tid);
     const double dphi = carrier_step(it.carrier_hz, fs);
     EpochParams ep;
     ep.start_sample = it.start_sample;
@@ -72,11 +72,11 @@ void launch_one(sdr_engine* e, const sdr_epl_item* d_items, int n_items, const d
     size_t shmem = (size_t)(kWaves * 2 * NT) * sizeof(double) + (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
     if (wide)
         hipLaunchKernelGGL((epl_kernel<FMT, NT, true>), dim3(n_items), dim3(kThreads), shmem, e->stream, e->iq,
-                           e->iq_capacity, d_items, e->luts, e->code_len, e->lut_stride, d_spacing, fs, tap0,
+                           e->iq_capacity, d_items, e->luts, lut_words, e->lut_stride, d_spacing, fs, tap0,
                            n_taps_total, d_out);
     else
         hipLaunchKernelGGL((epl_kernel<FMT, NT, false>), dim3(n_items), dim3(kThreads), shmem, e->stream, e->iq,
-                           e->iq_capacity, d_items, e->luts, e->code_len, e->lut_stride, d_spacing, fs, tap0,
+                           e->iq_capacity, d_items, e->luts, lut_words, e->lut_stride, d_spacing, fs, tap0,
                            n_taps_total, d_out);
 }
 
@@ -137,16 +137,16 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
         if (!(it.code_step > 0.0) || !std::isfinite(it.rem_code) || !std::isfinite(it.rem_carrier) ||
             !std::isfinite(it.carrier_hz))
             return sdr_fail(SDR_ERR_INVALID, "item %d: non-finite or non-positive NCO parameter", i);
-        const int L = e->code_len_host[it.code_slot];
         const double lo = std::ceil(it.rem_code + smin);
         const double hi = std::ceil(it.code_step * (double)it.n_samples + it.rem_code + smax);
-        if (lo < -(double)SDR_LUT_PAD || hi > (double)(L + SDR_LUT_PAD))
+        const int reach = e->lut_stride - SDR_LUT_PAD - 2;  // largest padded index the staged row serves
+        if (lo < -(double)SDR_LUT_PAD || hi > (double)reach)
             return sdr_fail(SDR_ERR_RANGE,
-                            "item %d: code phase range [%g, %g] leaves the staged replica [-%d, %d]", i, lo, hi,
-                            SDR_LUT_PAD, L + SDR_LUT_PAD);
-        if (L > maxlen) maxlen = L;
+                            "item %d: code phase range [%g, %g] leaves the staged replica [-%d, %d] "
+                            "(stage more code periods with sdr_code_slots_ex)", i, lo, hi, SDR_LUT_PAD, reach);
+        if ((int)hi > maxlen) maxlen = (int)hi;
     }
-    *lut_words = maxlen + 2 * SDR_LUT_PAD + 2;
+    *lut_words = maxlen + SDR_LUT_PAD + 2;
     *wide = max_step <= sdr::kFastMaxCodeStep;
     return SDR_OK;
 }

@@ -76,8 +76,7 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
                                                               int n_epochs, sdr_track_epoch* __restrict__ traj,
                                                               int keep_traj,
                                                               const uint32_t* __restrict__ luts,
-                                                              const int32_t* __restrict__ code_len,
-                                                              int lut_stride) {
+                                                              int lut_words, int lut_stride) {
     extern __shared__ double smem[];
     double* red = smem;                                   // kTrackWaves * 6
     EpochShared* sh = reinterpret_cast<EpochShared*>(red + kTrackWaves * 2 * kTaps);
@@ -91,8 +90,7 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
         sh->epochs_done = 0;
     }
     const int slot = states[ch].code_slot;
-    const int L = code_len[slot];
-    stage_lut<kTrackThreads>(lut, luts + (size_t)slot * lut_stride, L, tid);
+    stage_lut<kTrackThreads>(lut, luts + (size_t)slot * lut_stride, lut_words, tid);
     const double fs = cfg_ptr->fs;
     sdr_track_state& st = sh->st;
     const sdr_loop_cfg& cfg = sh->cfg;
@@ -110,7 +108,7 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
             const double lo = ceil(st.rem_code + smin);
             const double hi = ceil(st.code_step * (double)st.n_samples + st.rem_code + smax);
             const bool ok = st.n_samples > 0 && (int64_t)st.n_samples <= capacity && st.code_step > 0.0 &&
-                            lo >= -(double)SDR_LUT_PAD && hi <= (double)(L + SDR_LUT_PAD) &&
+                            lo >= -(double)SDR_LUT_PAD && hi <= (double)(lut_words - SDR_LUT_PAD - 2) &&
                             st.carrier_hz == st.carrier_hz && fabs(st.carrier_hz) < 1e9 && st.current_sample >= 0;
             sh->stop = ok ? 0 : 1;
             sh->ep.start_sample = st.current_sample;
@@ -333,7 +331,8 @@ int sdr_track_closed_loop(sdr_engine* e, int n_ch, sdr_track_state* st, const sd
     if (rc) return rc;
     SDR_HIP(hipMemcpyAsync(e->track_state.ptr, st, (size_t)n_ch * sizeof(sdr_track_state), hipMemcpyHostToDevice, e->stream));
     SDR_HIP(hipMemcpyAsync(e->track_cfg.ptr, cfg, sizeof(sdr_loop_cfg), hipMemcpyHostToDevice, e->stream));
-    const int lut_words = maxlen + 2 * SDR_LUT_PAD + 2;
+    (void)maxlen;
+    const int lut_words = e->lut_stride;  // the whole staged row (every code period the slots were sized for)
     const size_t shmem = (size_t)(kTrackWaves * 2 * kTaps) * sizeof(double) + sizeof(EpochShared) +
                          (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
     sdr_track_state* d_st = (sdr_track_state*)e->track_state.ptr;
@@ -344,16 +343,16 @@ int sdr_track_closed_loop(sdr_engine* e, int n_ch, sdr_track_state* st, const sd
         ProfScope ps(e, "track_kernel");
         switch (e->iq_fmt) {
             case SDR_FMT_CI8:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CI8>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, e->code_len, e->lut_stride);
+                hipLaunchKernelGGL(track_kernel<SDR_FMT_CI8>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, lut_words, e->lut_stride);
                 break;
             case SDR_FMT_CI16:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CI16>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, e->code_len, e->lut_stride);
+                hipLaunchKernelGGL(track_kernel<SDR_FMT_CI16>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, lut_words, e->lut_stride);
                 break;
             case SDR_FMT_CF32:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CF32>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, e->code_len, e->lut_stride);
+                hipLaunchKernelGGL(track_kernel<SDR_FMT_CF32>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, lut_words, e->lut_stride);
                 break;
             default:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CF64>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, e->code_len, e->lut_stride);
+                hipLaunchKernelGGL(track_kernel<SDR_FMT_CF64>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, lut_words, e->lut_stride);
                 break;
         }
     }

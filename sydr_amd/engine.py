@@ -120,7 +120,8 @@ class Engine:
     def iq_synth(self, sats, fs, noise_sigma, seed, first_sample, n_samples):
         arr = (SynthSat * max(1, len(sats)))()
         for i, s in enumerate(sats):
-            arr[i].prn = int(s["prn"])
+            arr[i].prn = int(s["slot"]) if "slot" in s else int(s["prn"])
+            arr[i].flags = (1 if "slot" in s else 0) | (2 if s.get("boc") else 0)
             arr[i].doppler_hz = float(s["doppler"])
             arr[i].code_phase = float(s["code_phase"])
             arr[i].carrier_phase = float(s.get("phase", 0.0))
@@ -129,8 +130,8 @@ class Engine:
                                      int(first_sample), int(n_samples)))
 
     # ------------------------------------------------------------------ PRN replicas
-    def code_slots(self, n_slots: int, max_chips: int = 1023):
-        check(self._lib.sdr_code_slots(self._h, int(n_slots), int(max_chips)))
+    def code_slots(self, n_slots: int, max_chips: int = 1023, max_periods: int = 1):
+        check(self._lib.sdr_code_slots_ex(self._h, int(n_slots), int(max_chips), int(max_periods)))
         self.n_slots = int(n_slots)
         self.code_generation = getattr(self, "code_generation", 0) + 1  # staged codes are gone
 
