@@ -217,6 +217,11 @@ typedef struct sdr_track_state {
     int32_t track_flags;      /* TrackingFlags bit set                              */
     int32_t time_in_state;    /* Kaplan timeSinceLastState                          */
     int32_t spacing_sel;      /* Kaplan: 0 = wide taps, 1 = narrow taps             */
+    /* navigation-bit accumulation on device: decodeBit of
+     * channel_l1ca_kaplan.py:728-754 / channel_l1ca_borre.py:470-491 + Prompt2Bit (dsp/decoding.py:16-27) */
+    double nav_prompt_sum;    /* navPromptSum                                       */
+    int32_t nav_sum_counter;  /* navPromptSumCounter                                */
+    int32_t nav_bits_emitted; /* bits produced so far (navBitsCounter without the reference's flushes) */
 } sdr_track_state;
 
 typedef struct sdr_loop_cfg {
@@ -245,11 +250,17 @@ typedef struct sdr_track_epoch {
     double carrier_hz, code_hz;           /* after the update */
     double cn0, pll_lock, fll_lock;
     int32_t track_flags;
-    int32_t reserved;
+    int32_t nav_bit;                      /* -1: none this epoch; 0/1: bit closed by this epoch (20 prompts) */
 } sdr_track_epoch;
 
 int sdr_track_closed_loop(sdr_engine* e, int n_ch, sdr_track_state* st, const sdr_loop_cfg* cfg,
                           int n_epochs, sdr_track_epoch* traj /* [n_ch][n_epochs], nullable */);
+/* Same run; additionally the navigation bits decided during it leave the device as one byte each
+ * (only 1 bit per 20 ms per channel has to cross PCIe): nav_bits[n_ch][max_bits] (0/1), bit k of
+ * channel c at nav_bits[c*max_bits + k]; n_bits[c] = number written for channel c. */
+int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, const sdr_loop_cfg* cfg,
+                               int n_epochs, sdr_track_epoch* traj, int8_t* nav_bits, int max_bits,
+                               int32_t* n_bits);
 
 #ifdef __cplusplus
 }

@@ -311,6 +311,10 @@ class BorreLoop:
         self.current_sample = current_sample
         self.code_err_mem = 0.0
         self.carrier_err_mem = 0.0
+        self.flags = 0
+        self.code_counter = 0
+        self.ip_prev = 0.0
+        self.nav_sum, self.nav_count, self.nav_bits = 0.0, 0, []
 
     def step(self, samples):
         """One epoch on `samples` (the n samples starting at current_sample).  Returns a record."""
@@ -326,6 +330,13 @@ class BorreLoop:
         phase_err = pll_costas(corr[2], corr[3])
         nco_carrier = borre_filter(phase_err, self.carrier_err_mem, self.pll_tau1, self.pll_tau2, self.pll_pdi)
         self.carrier_err_mem = phase_err
+        # bit sync: first prompt sign flip after 100 epochs (channel_l1ca_borre.py:384-391,401)
+        if not (self.flags & FLAG_BIT_SYNC) and (self.flags & FLAG_CODE_LOCK) and self.code_counter > 100 \
+                and np.sign(self.ip_prev) != np.sign(corr[2]):
+            self.flags |= FLAG_BIT_SYNC
+        self.flags |= FLAG_CODE_LOCK
+        self.ip_prev = corr[2]
+        self.code_counter += 1
         self.code_hz -= nco_code
         self.carrier_hz += nco_carrier
         self.rem_code += self.n * self.code_step - CODE_CHIPS
@@ -333,7 +344,8 @@ class BorreLoop:
         self.current_sample += self.n
         self.n = int(np.ceil((CODE_CHIPS - self.rem_code) / self.code_step))
         rec.update(corr=list(corr), dll=nco_code, pll=nco_carrier, carrier_hz=self.carrier_hz,
-                   code_hz=self.code_hz, code_err=code_err, carrier_err=phase_err)
+                   code_hz=self.code_hz, code_err=code_err, carrier_err=phase_err, flags=self.flags,
+                   nav_bit=_decode_bit(self, corr[2]))
         return rec
 
 
@@ -376,6 +388,7 @@ class KaplanLoop:
         self.carrier_hz = carrier_hz
         self.code_hz = CODE_RATE
         self.current_sample = current_sample
+        self.nav_sum, self.nav_count, self.nav_bits = 0.0, 0, []
 
     def step(self, samples):
         c = self.cfg
@@ -455,8 +468,25 @@ class KaplanLoop:
             self.time_in_state += 1
         rec.update(corr=list(self.corr), dll=dll_d, pll=pll_d, fll=fll_d, carrier_err=carrier_err,
                    code_err=code_err, carrier_hz=self.carrier_hz, code_hz=self.code_hz, cn0=self.cn0,
-                   pll_lock=self.pll_lock, fll_lock=self.fll_lock, lock_state=self.lock_state, flags=self.flags)
+                   pll_lock=self.pll_lock, fll_lock=self.fll_lock, lock_state=self.lock_state, flags=self.flags,
+                   nav_bit=_decode_bit(self, ip))
         return rec
+
+
+def _decode_bit(loop, i_prompt):
+    """decodeBit (channel_l1ca_kaplan.py:728-754, channel_l1ca_borre.py:470-491) + Prompt2Bit
+    (dsp/decoding.py:16-27): after bit sync, 20 prompt values decide one bit.  Returns 0/1 or -1."""
+    if not (loop.flags & FLAG_BIT_SYNC):
+        loop.nav_sum, loop.nav_count = 0.0, 0
+        return -1
+    loop.nav_sum += i_prompt
+    loop.nav_count += 1
+    if loop.nav_count != MS_PER_BIT:
+        return -1
+    bit = 1 if loop.nav_sum > 0 else 0
+    loop.nav_bits.append(bit)
+    loop.nav_sum, loop.nav_count = 0.0, 0
+    return bit
 
 
 def post_acquisition(if_hz, doppler_range, doppler_step, peak, current_sample, acq_required, track_required):

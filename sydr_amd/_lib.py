@@ -50,7 +50,8 @@ class TrackState(C.Structure):
                 ("fll_lock", C.c_double), ("pll_lock", C.c_double), ("cn0", C.c_double),
                 ("cn0_ratio_acc", C.c_double), ("fll_bw", C.c_double), ("pll_bw", C.c_double),
                 ("code_counter", C.c_int32), ("accum_counter", C.c_int32), ("lock_state", C.c_int32),
-                ("track_flags", C.c_int32), ("time_in_state", C.c_int32), ("spacing_sel", C.c_int32)]
+                ("track_flags", C.c_int32), ("time_in_state", C.c_int32), ("spacing_sel", C.c_int32),
+                ("nav_prompt_sum", C.c_double), ("nav_sum_counter", C.c_int32), ("nav_bits_emitted", C.c_int32)]
 
 
 class LoopCfg(C.Structure):
@@ -73,7 +74,7 @@ class TrackEpoch(C.Structure):
                 ("carrier_err", C.c_double), ("code_err", C.c_double),
                 ("carrier_hz", C.c_double), ("code_hz", C.c_double),
                 ("cn0", C.c_double), ("pll_lock", C.c_double), ("fll_lock", C.c_double),
-                ("track_flags", C.c_int32), ("reserved", C.c_int32)]
+                ("track_flags", C.c_int32), ("nav_bit", C.c_int32)]
 
 
 TRACK_EPOCH_DTYPE = np.dtype([("start_sample", np.int64), ("n_samples", np.int32), ("lock_state", np.int32),
@@ -84,7 +85,7 @@ TRACK_EPOCH_DTYPE = np.dtype([("start_sample", np.int64), ("n_samples", np.int32
                               ("carrier_err", np.float64), ("code_err", np.float64),
                               ("carrier_hz", np.float64), ("code_hz", np.float64),
                               ("cn0", np.float64), ("pll_lock", np.float64), ("fll_lock", np.float64),
-                              ("track_flags", np.int32), ("reserved", np.int32)], align=True)
+                              ("track_flags", np.int32), ("nav_bit", np.int32)], align=True)
 
 _VP = C.c_void_p
 _PROTOTYPES = {
@@ -122,6 +123,7 @@ _PROTOTYPES = {
     "sdr_two_peak_compare": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64),
                                        C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "sdr_track_closed_loop": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(LoopCfg), C.c_int, _VP]),
+    "sdr_track_closed_loop_bits": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(LoopCfg), C.c_int, _VP, _VP, C.c_int, _VP]),
 }
 
 _lib = None

@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 from ..dsp.tracking import BorreLoopFilter, DLL_NNEML, LoopFiltersCoefficients, PLL_costa
-from ..utils.constants import GPS_L1CA_CODE_FREQ, GPS_L1CA_CODE_MS, GPS_L1CA_CODE_SIZE_BITS
+from ..utils.constants import GPS_L1CA_CODE_FREQ, GPS_L1CA_CODE_MS, GPS_L1CA_CODE_SIZE_BITS, LNAV_MS_PER_BIT
 from ..utils.enumerations import ChannelMessage, ChannelState, GNSSSignalType, GNSSSystems, TrackingFlags
 from .base import Channel
 from .seams import GpuCorrelatorSeams
@@ -36,6 +36,10 @@ class ChannelL1CA(GpuCorrelatorSeams, Channel):
         self.fll = 0.0
         self.setAcquisition(configuration['ACQUISITION'])
         self.setTracking(configuration['TRACKING'])
+        self.navPromptSum, self.navPromptSumCounter, self.navBits = 0.0, 0, []
+
+    def _lastPromptI(self):
+        return self.iPrompt
 
     # NCO state lives under the Borre plugin's names
     def _nco_rem_carrier(self):
@@ -171,4 +175,19 @@ class ChannelL1CA(GpuCorrelatorSeams, Channel):
         return results
 
     def runDecoding(self):
+        """Bit accumulation only (decodeBit: 20 prompts after bit sync -> Prompt2Bit); LNAV word / subframe
+        decoding stays with the reference's sydr/dsp/decoding.py, which is outside the accelerated path."""
+        self.decodeBit()
         return None
+
+    def decodeBit(self):
+        if not (self.trackFlags & TrackingFlags.BIT_SYNC):
+            self.navPromptSum, self.navPromptSumCounter = 0.0, 0
+            return False
+        self.navPromptSum += self._lastPromptI()
+        self.navPromptSumCounter += 1
+        if self.navPromptSumCounter != LNAV_MS_PER_BIT:
+            return False
+        self.navBits.append(1 if self.navPromptSum > 0 else 0)
+        self.navPromptSum, self.navPromptSumCounter = 0.0, 0
+        return True

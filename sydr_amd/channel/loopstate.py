@@ -46,6 +46,9 @@ def export_state(channel) -> TrackState:
     st.code_step = float(channel.codeStep)
     st.code_counter = int(channel.codeCounter)
     st.track_flags = int(channel.trackFlags)
+    st.nav_prompt_sum = float(getattr(channel, "navPromptSum", 0.0))
+    st.nav_sum_counter = int(getattr(channel, "navPromptSumCounter", 0))
+    st.nav_bits_emitted = len(getattr(channel, "navBits", []))
     if loop_kind(channel) == KIND_KAPLAN:
         st.rem_carrier, st.rem_code = float(channel.remainingCarrier), float(channel.remainingCode)
         st.dll_mem, st.pll_mem = float(channel.dllDiscrim), float(channel.fll_vel_memory)
@@ -73,6 +76,7 @@ def import_state(channel, st: TrackState, epochs: int, last=None):
     channel.codeStep = st.code_step
     channel.codeCounter = int(st.code_counter)
     channel.codeSinceTOW += epochs
+    channel.navPromptSum, channel.navPromptSumCounter = st.nav_prompt_sum, int(st.nav_sum_counter)
     channel.trackFlags = TrackingFlags(int(st.track_flags)) if int(st.track_flags) in TrackingFlags._value2member_map_ \
         else int(st.track_flags)
     if loop_kind(channel) == KIND_KAPLAN:

@@ -148,9 +148,11 @@ class ChannelManager:
             group = [ch for ch in chans if loopstate.loop_kind(ch) == kind]
             cfg = loopstate.export_cfg(group[0])
             states = [loopstate.export_state(ch) for ch in group]
-            states, traj = self.engine.track_closed_loop(states, cfg, nbEpochs, want_traj=True)
-            for ch, st, tr in zip(group, states, traj):
+            states, traj, bits = self.engine.track_closed_loop(states, cfg, nbEpochs, want_traj=True, want_bits=True)
+            for ch, st, tr, nav in zip(group, states, traj, bits):
                 results.extend(loopstate.tracking_packet(ch, rec) for rec in tr)
                 loopstate.import_state(ch, st, nbEpochs, last=tr[-1])
+                if hasattr(ch, "navBits"):
+                    ch.navBits.extend(int(b) for b in nav)   # bits decided on the device: 1 byte per 20 ms per channel
         results.extend(ch.prepareChannelUpdate() for ch in chans)
         return results

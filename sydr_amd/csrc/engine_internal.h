@@ -63,7 +63,7 @@ struct sdr_engine {
     // workspaces
     DevBuf ws_items, ws_out, ws_spacing;
     DevBuf pcps_fwd, pcps_a, pcps_b, pcps_code, pcps_tw, pcps_map, pcps_csum, pcps_part, pcps_res;
-    DevBuf track_state, track_cfg, track_traj;
+    DevBuf track_state, track_cfg, track_traj, track_bits;
     int64_t pcps_tw_n = 0;
 
     // profiling

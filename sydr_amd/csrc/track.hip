@@ -65,6 +65,8 @@ struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind 
     double dphi;
     int stop;
     int epochs_done;
+    int bits_this_run;
+    int pad_;
     sdr_track_state st;  // lane 0's working copy lives in LDS, not in 1024 x VGPRs
     sdr_loop_cfg cfg;
 };
@@ -74,7 +76,8 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
                                                               sdr_track_state* __restrict__ states,
                                                               const sdr_loop_cfg* __restrict__ cfg_ptr,
                                                               int n_epochs, sdr_track_epoch* __restrict__ traj,
-                                                              int keep_traj,
+                                                              int keep_traj, int8_t* __restrict__ nav_bits, int max_bits,
+                                                              int32_t* __restrict__ n_bits,
                                                               const uint32_t* __restrict__ luts,
                                                               int lut_words, int lut_stride) {
     extern __shared__ double smem[];
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
         sh->st = states[ch];
         sh->cfg = *cfg_ptr;
         sh->epochs_done = 0;
+        sh->bits_this_run = 0;
     }
     const int slot = states[ch].code_slot;
     stage_lut<kTrackThreads>(lut, luts + (size_t)slot * lut_stride, lut_words, tid);
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
             rec.rem_code_in = st.rem_code;
             rec.code_step_in = st.code_step;
             for (int k = 0; k < 2 * SDR_MAX_TAPS; ++k) rec.corr[k] = k < 2 * kTaps ? corr[k] : 0.0;
-            rec.reserved = 0;
+            rec.nav_bit = -1;
 
             if (cfg.loop_kind == 0) {
                 // ---- Borre: channel_l1ca_borre.py:364-429
@@ -284,6 +288,23 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
                 rec.pll_lock = st.pll_lock;
                 rec.fll_lock = st.fll_lock;
             }
+            // decodeBit (kaplan:728-754, borre:470-491): 20 prompts after bit sync -> one bit (Prompt2Bit)
+            if (!(st.track_flags & FLAG_BIT_SYNC)) {
+                st.nav_prompt_sum = 0.0;
+                st.nav_sum_counter = 0;
+            } else {
+                st.nav_prompt_sum += ip;
+                st.nav_sum_counter += 1;
+                if (st.nav_sum_counter == kMsPerBit) {
+                    const int bit = st.nav_prompt_sum > 0.0 ? 1 : 0;
+                    rec.nav_bit = bit;
+                    if (nav_bits && sh->bits_this_run < max_bits) nav_bits[(size_t)ch * max_bits + sh->bits_this_run] = (int8_t)bit;
+                    sh->bits_this_run += 1;
+                    st.nav_bits_emitted += 1;
+                    st.nav_prompt_sum = 0.0;
+                    st.nav_sum_counter = 0;
+                }
+            }
             rec.carrier_hz = st.carrier_hz;
             rec.code_hz = st.code_hz;
             rec.lock_state = st.lock_state;
@@ -300,6 +321,7 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
                 for (int k = epochs_done; k < n_epochs; ++k) traj[(size_t)ch * n_epochs + k].n_samples = 0;
         }
         states[ch] = st;
+        if (n_bits) n_bits[ch] = sh->bits_this_run < max_bits ? sh->bits_this_run : max_bits;
     }
 }
 
@@ -309,7 +331,14 @@ extern "C" {
 
 int sdr_track_closed_loop(sdr_engine* e, int n_ch, sdr_track_state* st, const sdr_loop_cfg* cfg, int n_epochs,
                           sdr_track_epoch* traj) {
+    return sdr_track_closed_loop_bits(e, n_ch, st, cfg, n_epochs, traj, nullptr, 0, nullptr);
+}
+
+int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, const sdr_loop_cfg* cfg, int n_epochs,
+                               sdr_track_epoch* traj, int8_t* nav_bits, int max_bits, int32_t* n_bits) {
     if (int rc = sdr_set_device(e)) return rc;
+    if ((nav_bits && (max_bits < 1 || !n_bits)) || (!nav_bits && n_bits))
+        return sdr_fail(SDR_ERR_INVALID, "nav_bits, max_bits and n_bits go together");
     if (!e->iq) return sdr_fail(SDR_ERR_STATE, "IQ ring not allocated");
     if (!e->codes) return sdr_fail(SDR_ERR_STATE, "code slots not allocated");
     if (!st || !cfg || n_ch < 1 || n_epochs < 1) return sdr_fail(SDR_ERR_INVALID, "bad closed-loop request");
@@ -328,7 +357,12 @@ int sdr_track_closed_loop(sdr_engine* e, int n_ch, sdr_track_state* st, const sd
     int rc = sdr_devbuf_reserve(e, &e->track_state, (size_t)n_ch * sizeof(sdr_track_state));
     if (!rc) rc = sdr_devbuf_reserve(e, &e->track_cfg, sizeof(sdr_loop_cfg));
     if (!rc) rc = sdr_devbuf_reserve(e, &e->track_traj, traj ? traj_bytes : (size_t)n_ch * sizeof(sdr_track_epoch));
+    const size_t bits_bytes = nav_bits ? (size_t)n_ch * max_bits : 0;
+    if (!rc && nav_bits) rc = sdr_devbuf_reserve(e, &e->track_bits, bits_bytes + (size_t)n_ch * sizeof(int32_t) + 16);
     if (rc) return rc;
+    int32_t* d_nbits = nav_bits ? (int32_t*)e->track_bits.ptr : nullptr;
+    int8_t* d_bits = nav_bits ? (int8_t*)e->track_bits.ptr + (((size_t)n_ch * sizeof(int32_t) + 15) & ~(size_t)15) : nullptr;
+    if (nav_bits) SDR_HIP(hipMemsetAsync(e->track_bits.ptr, 0, e->track_bits.bytes, e->stream));
     SDR_HIP(hipMemcpyAsync(e->track_state.ptr, st, (size_t)n_ch * sizeof(sdr_track_state), hipMemcpyHostToDevice, e->stream));
     SDR_HIP(hipMemcpyAsync(e->track_cfg.ptr, cfg, sizeof(sdr_loop_cfg), hipMemcpyHostToDevice, e->stream));
     (void)maxlen;
@@ -343,22 +377,26 @@ int sdr_track_closed_loop(sdr_engine* e, int n_ch, sdr_track_state* st, const sd
         ProfScope ps(e, "track_kernel");
         switch (e->iq_fmt) {
             case SDR_FMT_CI8:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CI8>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, lut_words, e->lut_stride);
+                hipLaunchKernelGGL(track_kernel<SDR_FMT_CI8>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, d_bits, max_bits, d_nbits, e->luts, lut_words, e->lut_stride);
                 break;
             case SDR_FMT_CI16:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CI16>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, lut_words, e->lut_stride);
+                hipLaunchKernelGGL(track_kernel<SDR_FMT_CI16>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, d_bits, max_bits, d_nbits, e->luts, lut_words, e->lut_stride);
                 break;
             case SDR_FMT_CF32:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CF32>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, lut_words, e->lut_stride);
+                hipLaunchKernelGGL(track_kernel<SDR_FMT_CF32>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, d_bits, max_bits, d_nbits, e->luts, lut_words, e->lut_stride);
                 break;
             default:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CF64>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, e->luts, lut_words, e->lut_stride);
+                hipLaunchKernelGGL(track_kernel<SDR_FMT_CF64>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, d_bits, max_bits, d_nbits, e->luts, lut_words, e->lut_stride);
                 break;
         }
     }
     SDR_HIP(hipGetLastError());
     SDR_HIP(hipMemcpyAsync(st, e->track_state.ptr, (size_t)n_ch * sizeof(sdr_track_state), hipMemcpyDeviceToHost, e->stream));
     if (traj) SDR_HIP(hipMemcpyAsync(traj, e->track_traj.ptr, traj_bytes, hipMemcpyDeviceToHost, e->stream));
+    if (nav_bits) {
+        SDR_HIP(hipMemcpyAsync(nav_bits, d_bits, bits_bytes, hipMemcpyDeviceToHost, e->stream));
+        SDR_HIP(hipMemcpyAsync(n_bits, d_nbits, (size_t)n_ch * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    }
     SDR_HIP(hipStreamSynchronize(e->stream));
     for (int c = 0; c < n_ch; ++c)
         if (st[c].n_samples < 0)

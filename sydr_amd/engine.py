@@ -206,10 +206,18 @@ class Engine:
         return [pb.value, pc.value], pr.value
 
     # ------------------------------------------------------------------ closed loop
-    def track_closed_loop(self, states, cfg: LoopCfg, n_epochs: int, want_traj=True):
+    def track_closed_loop(self, states, cfg: LoopCfg, n_epochs: int, want_traj=True, want_bits=False):
+        """Returns (end states, trajectory or None[, list of per-channel nav-bit arrays])."""
         n_ch = len(states)
         arr = (TrackState * n_ch)(*states)
         traj = np.zeros((n_ch, n_epochs), dtype=TRACK_EPOCH_DTYPE) if want_traj else None
-        check(self._lib.sdr_track_closed_loop(self._h, n_ch, arr, C.byref(cfg), int(n_epochs),
-                                              ptr(traj) if want_traj else None))
-        return list(arr), traj
+        if not want_bits:
+            check(self._lib.sdr_track_closed_loop(self._h, n_ch, arr, C.byref(cfg), int(n_epochs),
+                                                  ptr(traj) if want_traj else None))
+            return list(arr), traj
+        max_bits = n_epochs // 20 + 2
+        bits = np.zeros((n_ch, max_bits), dtype=np.int8)
+        n_bits = np.zeros(n_ch, dtype=np.int32)
+        check(self._lib.sdr_track_closed_loop_bits(self._h, n_ch, arr, C.byref(cfg), int(n_epochs),
+                                                   ptr(traj) if want_traj else None, ptr(bits), max_bits, ptr(n_bits)))
+        return list(arr), traj, [bits[c, :n_bits[c]].copy() for c in range(n_ch)]

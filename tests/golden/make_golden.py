@@ -273,7 +273,10 @@ def make_trajectories(fname="g6_trajectories.npz", ms=510, amp=8.0, sigma=20.0, 
                 rem_c = ch.NCO_remainingCarrier if tag == "borre" else ch.remainingCarrier
                 rem_k = ch.NCO_remainingCode if tag == "borre" else ch.remainingCode
                 pre = [ch.currentSample, ch.track_requiredSamples, ch.carrierFrequency, rem_c, rem_k, ch.codeStep]
+            bits_before = getattr(ch, "navBitsCounter", 0)
             results = ch._processHandler()
+            bits_after = getattr(ch, "navBitsCounter", 0)
+            nav_bit = float(ch.navBitsBuffer[bits_after - 1]) if bits_after == bits_before + 1 else -1.0
             for r in results:
                 if "correlation_map" in r:
                     acq = [r["frequency_idx"], r["code_idx"], r["peak_ratio"], r["carrierFrequency"], r["codeOffset"],
@@ -283,14 +286,14 @@ def make_trajectories(fname="g6_trajectories.npz", ms=510, amp=8.0, sigma=20.0, 
                                          r["q_late"], r["dll"], r["pll"], r["fll"], r["carrier_frequency"],
                                          r["code_frequency"], r["carrier_frequency_error"],
                                          r["code_frequency_error"], r["cn0"], r["pll_lock"], r["fll_lock"],
-                                         float(int(r["lock_state"])), float(int(ch.trackFlags))])
+                                         float(int(r["lock_state"])), float(int(ch.trackFlags)), nav_bit])
         out[f"{tag}_acq"] = np.array(acq, dtype=np.float64)
         out[f"{tag}_epochs"] = np.array(epochs, dtype=np.float64)
         print(tag, "acq", acq, "epochs", len(epochs))
     out["epoch_columns"] = np.array(["currentSample", "n", "carrier_in", "rem_carrier_in", "rem_code_in",
                                      "code_step_in", "ie", "qe", "ip", "qp", "il", "ql", "dll", "pll", "fll",
                                      "carrier_hz", "code_hz", "carrier_err", "code_err", "cn0", "pll_lock",
-                                     "fll_lock", "lock_state", "flags"])
+                                     "fll_lock", "lock_state", "flags", "nav_bit"])
     save(fname, **out)
 
 

@@ -78,8 +78,12 @@ def test_closed_loop_kernel_matches_reference_trajectory(engine, case):
     engine.code_slots(2)
     engine.load_gps_code(1, 7)
     st = initial_state(kind, fs, acq[3], int(acq[5]), c, slot=1)
-    states, traj = engine.track_closed_loop([st], loop_cfg(kind, fs, c), len(ref))
+    states, traj, bits = engine.track_closed_loop([st], loop_cfg(kind, fs, c), len(ref), want_bits=True)
     tr = traj[0]
+    # navigation bits (20-prompt sums after bit sync) decided on the device == the reference's
+    assert np.array_equal(tr["nav_bit"], ref[:, 24].astype(np.int32))
+    assert np.array_equal(bits[0], ref[ref[:, 24] >= 0, 24].astype(np.int8))
+    assert states[0].nav_bits_emitted == len(bits[0])
     ring = 100 * int(fs * 1e-3)
     # integers: exact
     assert np.array_equal(tr["start_sample"] % ring, ref[:, 0].astype(np.int64))

@@ -125,6 +125,7 @@ def test_manager_reproduces_reference_trajectory(plugin):
             assert p["fll"] == row[14] and int(p["lock_state"]) == int(row[22]), k
             np.testing.assert_equal([p["cn0"], p["pll_lock"], p["fll_lock"]], row[19:22])
     assert int(ch.trackFlags) == int(ref[-1][23])
+    assert ch.navBits == [int(b) for b in ref[ref[:, 24] >= 0, 24]]      # decodeBit on the host plugin
     if plugin == "kaplan":
         assert ch.loopLockState is LoopLockState(int(ref[-1][22]))  # (transitions: see the g6b test below)
     # packet contract (keys become DB columns in the reference: database.py:76-93)
@@ -156,6 +157,7 @@ def test_manager_kaplan_lock_state_machine():
         assert (p["carrier_frequency"], p["code_frequency"], int(p["lock_state"])) == (row[15], row[16], int(row[22])), k
     assert ch.loopLockState is LoopLockState.NARROW_TRACK and ch.track_correlatorsSpacing == [-0.25, 0.0, 0.25]
     assert int(ch.trackFlags) == int(TrackingFlags.CODE_LOCK | TrackingFlags.BIT_SYNC)
+    assert ch.navBits == [int(b) for b in ref[ref[:, 24] >= 0, 24]] and len(ch.navBits) >= 40
 
 
 def test_manager_batches_channels_into_single_launches():

@@ -188,6 +188,7 @@ def test_closed_loop_trajectory(plugin):
         rec = loop.step(rf[loop.current_sample:loop.current_sample + loop.n])
         assert rec["corr"] == list(row[6:12]), k
         assert rec["carrier_hz"] == row[15] and rec["code_hz"] == row[16], k
+        assert rec["nav_bit"] == int(row[24]), k     # navigation bit closed by this epoch (or -1)
         if plugin == "kaplan":
             assert (rec["dll"], rec["pll"], rec["fll"]) == tuple(row[12:15]), k
             np.testing.assert_equal([rec["cn0"], rec["pll_lock"], rec["fll_lock"]], row[19:22])
@@ -218,4 +219,6 @@ def test_closed_loop_kaplan_lock_state_machine():
             (row[15], row[16], row[12], row[13], row[14]), k
         np.testing.assert_equal([rec["cn0"], rec["pll_lock"], rec["fll_lock"]], row[19:22])
         assert (rec["lock_state"], rec["flags"]) == (int(row[22]), int(row[23])), k
+        assert rec["nav_bit"] == int(row[24]), k
     assert {int(r[22]) for r in ref} == {1, 2, 3} and int(ref[-1][23]) == 3
+    assert loop.nav_bits == [int(b) for b in ref[ref[:, 24] >= 0, 24]] and len(loop.nav_bits) >= 40
