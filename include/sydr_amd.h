@@ -186,6 +186,18 @@ int sdr_two_peak_compare(sdr_engine* e, const double* corr_map, int n_bins, int 
                          int samples_per_chip, int64_t* peak_bin, int64_t* peak_code,
                          double* peak_ratio);
 
+/* SerialSearch acquisition (sydr/dsp/acquisition.py:119-155; plugin sydr/channel/channel_l1ca_kaplan_ss.py):
+ *   map[prn][b][k] = sum over `noncoh` successive code periods of
+ *                    |sum_n x[n]*exp(+1j*bins[b]*n*2*pi/fs) * code[(trunc((ts*n)/tc) - k) mod L]|^2
+ * for the L circular chip shifts k, and TwoCorrelationPeakComparison_SS (:159-193) on each map
+ * (second peak = maximum outside the 3x3 block around the first, with Python's slice semantics).
+ * corr_map (nullable) is [n_prn][bins][L]. */
+int sdr_serial_search(sdr_engine* e, const int32_t* code_slots, int n_prn, int64_t start_sample, double fs,
+                      double doppler_range, double doppler_step, int noncoh, int64_t* peak_bin,
+                      int64_t* peak_code, double* peak_ratio, double* corr_map, int* n_bins_out);
+int sdr_two_peak_compare_ss(sdr_engine* e, const double* corr_map, int n_rows, int n_cols,
+                            int64_t* peak_bin, int64_t* peak_code, double* peak_ratio);
+
 /* ------------------------------------------------- closed-loop tracking
  * On-device loop closure: one persistent workgroup per
  * channel runs n_epochs of correlate -> discriminators -> loop filters -> NCO

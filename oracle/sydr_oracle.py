@@ -173,6 +173,45 @@ def two_peak_compare(cmap: np.ndarray, n_code: int, samples_per_chip: int):
     return top, p1 / p2
 
 
+def _shift(arr, num):
+    """Circular right shift used by SerialSearch (acquisition.py:196-206)."""
+    out = np.empty_like(arr)
+    if num > 0:
+        out[:num] = arr[-num:]
+        out[num:] = arr[:-num]
+    else:
+        out[:] = arr
+    return out
+
+
+def serial_search(rf, code, doppler_range, doppler_step, fs, n_code):
+    """Brute-force acquisition map [bins][len(code)] (acquisition.py:119-155)."""
+    bins = doppler_bins(doppler_range, doppler_step)
+    phase_points = np.array(range(n_code)) * 2 * np.pi / fs
+    out = np.zeros((len(bins), len(code)))
+    up = upsample_index(fs, n_code)
+    for row, freq in enumerate(bins):
+        carrier = np.exp(-1j * -freq * phase_points)
+        signal = np.multiply(rf, carrier)
+        for k in range(len(code)):
+            shifted = _shift(code, k)[up]
+            i_sig = np.multiply(np.real(signal), shifted)
+            q_sig = np.multiply(np.imag(signal), shifted)
+            out[row, k] += np.sum(i_sig) ** 2 + np.sum(q_sig) ** 2
+    return np.squeeze(np.squeeze(out))
+
+
+def two_peak_compare_ss(cmap):
+    """([bin, chip], ratio) of acquisition.py:159-193: second peak outside the 3x3 block around the first
+    (Python slices: a block starting at index -1 selects nothing)."""
+    top = np.unravel_index(cmap.argmax(), cmap.shape)
+    top = [int(top[0]), int(top[1])]
+    p1 = cmap[top[0], top[1]]
+    work = np.copy(cmap)
+    work[top[0] - 1:top[0] + 2, top[1] - 1:top[1] + 2] = 0.0
+    return top, p1 / np.amax(work)
+
+
 def epl_indices(n, rem_code, code_step, spacing):
     """Padded-code index per sample for one tap (tracking.py:111-112)."""
     shift = rem_code + spacing

@@ -667,3 +667,224 @@ int sdr_pcps_spectra(sdr_engine* e, const double* code_spectra, int n_prn, int n
 }
 
 }  // extern "C"
+
+/* =====================================================================================================
+ * SerialSearch acquisition (sydr/dsp/acquisition.py:119-193; plugin sydr/channel/channel_l1ca_kaplan_ss.py).
+ *
+ *   map[b][k] = | sum_n x[n]*exp(+1j*bin_b*((2n)*pi/fs)) * code[(u(n) - k) mod L] |^2 ,  u(n) = trunc((ts*n)/tc)
+ *
+ * The reference evaluates 41 x 1023 dot products of length N.  Every sample enters only through its
+ * chip number u(n), so the device first folds the Doppler-mixed millisecond into L per-chip sums
+ * (PRN independent, once per bin) and then correlates those L sums circularly with each PRN's chips.
+ * ===================================================================================================== */
+namespace {
+
+constexpr int kSsMaxChips = 4096;
+
+// A[b][m] = sum over the samples of chip m of x[n] * exp(+1j*bin_b*((2n)*pi/fs))   (acquisition.py:125-131)
+template <int FMT>
+__global__ __launch_bounds__(kThreads) void ss_chipsum_kernel(const void* __restrict__ ring, int64_t capacity,
+                                                              int64_t first_sample, int N, int L, double fs,
+                                                              double bin_start, double bin_delta,
+                                                              double2* __restrict__ A) {
+    const int b = blockIdx.x;
+    const double freq = bin_start + (double)b * bin_delta;
+    const double ts = 1.0 / fs, tc = 1.0 / 1.023e6;
+    const double per_chip = tc / ts;
+    for (int m = threadIdx.x; m < L; m += kThreads) {
+        int n = (int)floor((double)m * per_chip) - 1;
+        if (n < 0) n = 0;
+        double sr = 0.0, si = 0.0;
+        for (; n < N; ++n) {
+            const double v = (ts * (double)n) / tc;  // UpsampleCode index (gnsssignal.py:53)
+            const int u = (int)trunc(v);
+            if (u < m) continue;
+            if (u > m) break;
+            const double2 x = ring_sample<FMT>(ring, (first_sample + n) % capacity);
+            double pp = (double)((int64_t)n * 2) * M_PI;
+            pp = pp / fs;
+            double s, c;
+            sincos(freq * pp, &s, &c);
+            sr += x.x * c - x.y * s;
+            si += x.x * s + x.y * c;
+        }
+        A[(size_t)b * L + m] = make_double2(sr, si);
+    }
+}
+
+// map[p][b][k] (+)= |sum_m A[b][m] * chip_p[(m - k) mod L]|^2
+__global__ __launch_bounds__(kThreads) void ss_correlate_kernel(const double2* __restrict__ A,
+                                                                const int8_t* __restrict__ codes, int code_stride,
+                                                                const int32_t* __restrict__ slots, int L, int nbins,
+                                                                double* __restrict__ map, int accumulate) {
+    __shared__ double2 a_s[kSsMaxChips];
+    __shared__ float c_s[2 * kSsMaxChips];
+    const int b = blockIdx.x, p = blockIdx.y;
+    const int8_t* chips = codes + (size_t)slots[p] * code_stride;
+    for (int m = threadIdx.x; m < L; m += kThreads) {
+        a_s[m] = A[(size_t)b * L + m];
+        const float c = chips[m] > 0 ? 1.f : -1.f;
+        c_s[m] = c;
+        c_s[m + L] = c;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < L; k += kThreads) {
+        double sr = 0.0, si = 0.0;
+        const float* c = c_s + (L - k);  // c[m] = chip[(m - k) mod L]
+        for (int m = 0; m < L; ++m) {
+            const double w = (double)c[m];
+            sr += w * a_s[m].x;
+            si += w * a_s[m].y;
+        }
+        const size_t o = ((size_t)p * nbins + b) * L + k;
+        const double v = sr * sr + si * si;
+        map[o] = accumulate ? map[o] + v : 0.0 + v;
+    }
+}
+
+// TwoCorrelationPeakComparison_SS (acquisition.py:159-193): second peak = max outside the 3x3 block around
+// the first, with Python's slice semantics (a block that starts at index -1 selects nothing).
+__global__ __launch_bounds__(kThreads) void peak_finish_ss_kernel(const double* __restrict__ map, int nrows, int ncols,
+                                                                  const Best* __restrict__ parts,
+                                                                  long long* __restrict__ out_bin,
+                                                                  long long* __restrict__ out_code,
+                                                                  double* __restrict__ out_ratio) {
+    __shared__ Best sh[kThreads / 64];
+    const int prn = blockIdx.x;
+    Best mine = {-1.0, 0x7fffffffffffffffLL};
+    if (threadIdx.x < kPeakParts) mine = parts[(size_t)prn * kPeakParts + threadIdx.x];
+    Best top = block_best(mine, sh);
+    const int i0 = (int)(top.i / ncols), i1 = (int)(top.i - (long long)i0 * ncols);
+    int r0 = i0 - 1, r1 = i0 + 2 < nrows ? i0 + 2 : nrows;
+    int c0 = i1 - 1, c1 = i1 + 2 < ncols ? i1 + 2 : ncols;
+    if (r0 < 0) r0 += nrows;
+    if (c0 < 0) c0 += ncols;
+    const bool block_empty = r0 >= r1 || c0 >= c1;
+    const double* m = map + (size_t)prn * nrows * ncols;
+    Best second = {-1.0, 0x7fffffffffffffffLL};
+    for (long long i = threadIdx.x; i < (long long)nrows * ncols; i += kThreads) {
+        const int r = (int)(i / ncols), c = (int)(i - (long long)r * ncols);
+        const bool excluded = !block_empty && r >= r0 && r < r1 && c >= c0 && c < c1;
+        if (!excluded) {
+            Best cand = {m[i], i};
+            second = better(second, cand);
+        }
+    }
+    Best p2 = block_best(second, sh);
+    if (threadIdx.x == 0) {
+        out_bin[prn] = i0;
+        out_code[prn] = i1;
+        out_ratio[prn] = top.v / p2.v;
+    }
+}
+
+template <int FMT>
+void ss_launch_chipsum(sdr_engine* e, int64_t first, int N, int L, double fs, double bin_start, double bin_delta,
+                       int nbins, double2* A) {
+    hipLaunchKernelGGL(ss_chipsum_kernel<FMT>, dim3(nbins), dim3(kThreads), 0, e->stream, e->iq, e->iq_capacity, first,
+                       N, L, fs, bin_start, bin_delta, A);
+}
+
+int ss_finish(sdr_engine* e, const double* d_map, int n_prn, int nbins, int L, int64_t* peak_bin, int64_t* peak_code,
+              double* peak_ratio, double* corr_map) {
+    Best* parts = (Best*)e->pcps_part.ptr;
+    long long* res_bin = (long long*)e->pcps_res.ptr;
+    long long* res_code = res_bin + n_prn;
+    double* res_ratio = (double*)(res_code + n_prn);
+    {
+        ProfScope ps(e, "ss_peak");
+        hipLaunchKernelGGL(argmax_part_kernel, dim3(kPeakParts, n_prn), dim3(kThreads), 0, e->stream, d_map,
+                           (long long)nbins * L, parts);
+        hipLaunchKernelGGL(peak_finish_ss_kernel, dim3(n_prn), dim3(kThreads), 0, e->stream, d_map, nbins, L, parts,
+                           res_bin, res_code, res_ratio);
+    }
+    SDR_HIP(hipGetLastError());
+    std::vector<long long> hb(2 * (size_t)n_prn);
+    SDR_HIP(hipMemcpyAsync(hb.data(), res_bin, 2 * (size_t)n_prn * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
+    SDR_HIP(hipMemcpyAsync(peak_ratio, res_ratio, (size_t)n_prn * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (corr_map)
+        SDR_HIP(hipMemcpyAsync(corr_map, d_map, (size_t)n_prn * nbins * L * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    SDR_HIP(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < n_prn; ++i) {
+        peak_bin[i] = hb[i];
+        peak_code[i] = hb[n_prn + i];
+    }
+    return SDR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdr_serial_search(sdr_engine* e, const int32_t* code_slots, int n_prn, int64_t start_sample, double fs,
+                      double doppler_range, double doppler_step, int noncoh, int64_t* peak_bin, int64_t* peak_code,
+                      double* peak_ratio, double* corr_map, int* n_bins_out) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!e->iq) return sdr_fail(SDR_ERR_STATE, "IQ ring not allocated");
+    if (!e->codes) return sdr_fail(SDR_ERR_STATE, "code slots not allocated");
+    if (!code_slots || n_prn <= 0 || n_prn > 65535) return sdr_fail(SDR_ERR_INVALID, "no PRN to search");
+    if (!peak_bin || !peak_code || !peak_ratio) return sdr_fail(SDR_ERR_INVALID, "NULL peak outputs");
+    if (!(fs > 0.0) || noncoh < 1) return sdr_fail(SDR_ERR_INVALID, "bad fs / integration count");
+    const int nbins = sdr_pcps_bins(doppler_range, doppler_step);
+    if (nbins <= 0 || nbins > 65535) return sdr_fail(SDR_ERR_INVALID, "bad Doppler grid");
+    if (n_bins_out) *n_bins_out = nbins;
+    const int N = (int)std::nearbyint(fs * 1023.0 / 1.023e6);
+    if (N < 2 || (int64_t)N * noncoh > e->iq_capacity || start_sample < 0)
+        return sdr_fail(SDR_ERR_RANGE, "serial search needs %lld samples, ring holds %lld", (long long)N * noncoh,
+                        (long long)e->iq_capacity);
+    int L = 0;
+    for (int i = 0; i < n_prn; ++i) {
+        const int s = code_slots[i];
+        if (s < 0 || s >= e->n_slots || e->code_len_host[s] <= 0)
+            return sdr_fail(SDR_ERR_INVALID, "PRN entry %d: code slot %d is not staged", i, s);
+        if (L && e->code_len_host[s] != L) return sdr_fail(SDR_ERR_INVALID, "serial search needs codes of one length");
+        L = e->code_len_host[s];
+    }
+    if (L > kSsMaxChips) return sdr_fail(SDR_ERR_UNSUPPORTED, "codes longer than %d chips", kSsMaxChips);
+    int rc = sdr_devbuf_reserve(e, &e->pcps_a, (size_t)nbins * L * sizeof(double2));
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_map, (size_t)n_prn * nbins * L * sizeof(double));
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_part, (size_t)n_prn * kPeakParts * sizeof(Best));
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_res, (size_t)n_prn * 3 * sizeof(double) + n_prn * sizeof(int32_t));
+    if (rc) return rc;
+    int32_t* d_slots = (int32_t*)((char*)e->pcps_res.ptr + (size_t)n_prn * 3 * sizeof(double));
+    SDR_HIP(hipMemcpyAsync(d_slots, code_slots, n_prn * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    const double bin_start = -doppler_range;
+    const double bin_delta = (bin_start + doppler_step) - bin_start;
+    double2* A = (double2*)e->pcps_a.ptr;
+    double* map = (double*)e->pcps_map.ptr;
+    for (int k = 0; k < noncoh; ++k) {  // channel_l1ca_kaplan_ss.py:14-21: maps of successive milliseconds are added
+        const int64_t first = start_sample + (int64_t)k * N;
+        {
+            ProfScope ps(e, "ss_chipsum");
+            switch (e->iq_fmt) {
+                case SDR_FMT_CI8: ss_launch_chipsum<SDR_FMT_CI8>(e, first, N, L, fs, bin_start, bin_delta, nbins, A); break;
+                case SDR_FMT_CI16: ss_launch_chipsum<SDR_FMT_CI16>(e, first, N, L, fs, bin_start, bin_delta, nbins, A); break;
+                case SDR_FMT_CF32: ss_launch_chipsum<SDR_FMT_CF32>(e, first, N, L, fs, bin_start, bin_delta, nbins, A); break;
+                default: ss_launch_chipsum<SDR_FMT_CF64>(e, first, N, L, fs, bin_start, bin_delta, nbins, A); break;
+            }
+        }
+        {
+            ProfScope ps(e, "ss_correlate");
+            hipLaunchKernelGGL(ss_correlate_kernel, dim3(nbins, n_prn), dim3(kThreads), 0, e->stream, A, e->codes,
+                               e->code_stride, d_slots, L, nbins, map, k > 0 ? 1 : 0);
+        }
+        SDR_HIP(hipGetLastError());
+    }
+    return ss_finish(e, map, n_prn, nbins, L, peak_bin, peak_code, peak_ratio, corr_map);
+}
+
+int sdr_two_peak_compare_ss(sdr_engine* e, const double* corr_map, int n_rows, int n_cols, int64_t* peak_bin,
+                            int64_t* peak_code, double* peak_ratio) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!corr_map || !peak_bin || !peak_code || !peak_ratio || n_rows < 1 || n_cols < 1)
+        return sdr_fail(SDR_ERR_INVALID, "bad map");
+    const size_t count = (size_t)n_rows * n_cols;
+    int rc = sdr_devbuf_reserve(e, &e->pcps_map, count * sizeof(double));
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_part, kPeakParts * sizeof(Best));
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_res, 3 * sizeof(double) + sizeof(int32_t));
+    if (rc) return rc;
+    SDR_HIP(hipMemcpyAsync(e->pcps_map.ptr, corr_map, count * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    return ss_finish(e, (const double*)e->pcps_map.ptr, 1, n_rows, n_cols, peak_bin, peak_code, peak_ratio, nullptr);
+}
+
+}  // extern "C"

@@ -34,3 +34,27 @@ def TwoCorrelationPeakComparison(correlationMap, samplesPerCode, samplesPerCodeC
     if cmap.shape[1] != samplesPerCode:
         raise ValueError("correlationMap row length must equal samplesPerCode")
     return get_engine(0).two_peak_compare(cmap, int(samplesPerCodeChip))
+
+
+def SerialSearch(rfdata, code, dopplerRange, dopplerStep, samplingFrequency, samplesPerCode):
+    """Brute-force map [bins][len(code)] of acquisition.py:119-155 (one code period of `rfdata`), on the GPU."""
+    rf = np.squeeze(np.asarray(rfdata, dtype=np.complex128))
+    if rf.size < samplesPerCode:
+        raise ValueError(f"SerialSearch needs {samplesPerCode} samples, got {rf.size}")
+    chips = np.asarray(code)
+    eng = get_engine(0)
+    if getattr(eng, "n_slots", 0) < 4:
+        eng.code_slots(4, 4092)
+    eng.set_code(3, chips.astype(np.int8))
+    cap = (int(samplesPerCode) + 7) // 8 * 8
+    if eng.iq_fmt != FMT_CF64 or eng.iq_capacity < cap:
+        eng.iq_alloc(cap, FMT_CF64)
+    eng.iq_upload(rf[:samplesPerCode], 0)
+    _, _, _, cmap = eng.serial_search([3], 0, samplingFrequency, dopplerRange, dopplerStep, want_map=True,
+                                      n_chips=len(chips))
+    return np.squeeze(np.squeeze(cmap[0]))
+
+
+def TwoCorrelationPeakComparison_SS(correlationMap):
+    """([bin, chip], ratio) of acquisition.py:159-193 (3x3 exclusion block, Python slice semantics), on the GPU."""
+    return get_engine(0).two_peak_compare_ss(np.atleast_2d(np.asarray(correlationMap, dtype=np.float64)))

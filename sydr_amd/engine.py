@@ -198,6 +198,26 @@ class Engine:
                                          ptr(pc), ptr(pr), ptr(cmap) if want_map else None, C.byref(nb)))
         return pb, pc, pr, cmap
 
+    def serial_search(self, code_slots, start_sample, fs, doppler_range, doppler_step, noncoh=1, want_map=False,
+                      n_chips=1023):
+        slots = np.ascontiguousarray(code_slots, dtype=np.int32)
+        n = len(slots)
+        nbins = self._lib.sdr_pcps_bins(float(doppler_range), float(doppler_step))
+        pb, pc, pr = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64), np.empty(n, dtype=np.float64)
+        cmap = np.empty((n, nbins, n_chips), dtype=np.float64) if want_map else None
+        nb = C.c_int(0)
+        check(self._lib.sdr_serial_search(self._h, ptr(slots), n, int(start_sample), float(fs), float(doppler_range),
+                                          float(doppler_step), int(noncoh), ptr(pb), ptr(pc), ptr(pr),
+                                          ptr(cmap) if want_map else None, C.byref(nb)))
+        return pb, pc, pr, cmap
+
+    def two_peak_compare_ss(self, cmap: np.ndarray):
+        cmap = np.ascontiguousarray(cmap, dtype=np.float64)
+        pb, pc, pr = C.c_int64(0), C.c_int64(0), C.c_double(0)
+        check(self._lib.sdr_two_peak_compare_ss(self._h, ptr(cmap), cmap.shape[0], cmap.shape[1], C.byref(pb),
+                                                C.byref(pc), C.byref(pr)))
+        return [pb.value, pc.value], pr.value
+
     def two_peak_compare(self, cmap: np.ndarray, samples_per_chip: int):
         cmap = np.ascontiguousarray(cmap, dtype=np.float64)
         pb, pc, pr = C.c_int64(0), C.c_int64(0), C.c_double(0)

@@ -84,3 +84,25 @@ class OracleEngine:
             out[k] = orc.epl(x, orc.pad_code(self.codes[int(it["code_slot"])]), fs, float(it["carrier_hz"]),
                              float(it["rem_carrier"]), float(it["rem_code"]), float(it["code_step"]), spacing)
         return out
+
+
+def _serial_search(self, code_slots, start_sample, fs, doppler_range, doppler_step, noncoh=1, want_map=False,
+                   n_chips=1023):
+    n = orc.samples_per_code(fs)
+    maps, pb, pc, pr = [], [], [], []
+    for s in code_slots:
+        m = None
+        for k in range(noncoh):
+            rf = self._complex(start_sample + k * n, n).reshape(1, -1)
+            part = orc.serial_search(rf, self.codes[int(s)], doppler_range, doppler_step, fs, n)
+            m = part if m is None else m + part
+        peak, ratio = orc.two_peak_compare_ss(m)
+        maps.append(m)
+        pb.append(peak[0])
+        pc.append(peak[1])
+        pr.append(ratio)
+    return np.array(pb), np.array(pc), np.array(pr), (np.stack(maps) if want_map else None)
+
+
+OracleEngine.serial_search = _serial_search
+OracleEngine.two_peak_compare_ss = lambda self, cmap: orc.two_peak_compare_ss(np.asarray(cmap))

@@ -297,6 +297,58 @@ def make_trajectories(fname="g6_trajectories.npz", ms=510, amp=8.0, sigma=20.0, 
     save(fname, **out)
 
 
+# ---------------------------------------------------------------------------------------------- G9
+def make_serial():
+    """SerialSearch + TwoCorrelationPeakComparison_SS (acquisition.py:119-193), reduced Doppler grid."""
+    fs, n = 4e6, 4000
+    sats = [dict(prn=11, doppler=500.0, code_phase=700.5, phase=0.3, amp=9.0)]
+    raw = orc.synth_iq(fs, 2 * n, sats, 15.0, 20260900)
+    rf = (raw[0::2] + 1j * raw[1::2])
+    code = ref_sig.GenerateGPSGoldCode(11)
+    maps = [ref_acq.SerialSearch(rf[k * n:(k + 1) * n].reshape(1, -1), code, 750.0, 250.0, fs, n) for k in range(2)]
+    idx, ratio = ref_acq.TwoCorrelationPeakComparison_SS(maps[0].copy())
+    idx2, ratio2 = ref_acq.TwoCorrelationPeakComparison_SS((maps[0] + maps[1]).copy())
+    rng = np.random.default_rng(20260901)
+    edge_maps, edge_idx, edge_ratio = [], [], []
+    for (r, c) in ((0, 5), (3, 0), (0, 0), (6, 1022), (3, 500), (6, 0), (1, 1)):
+        m = rng.random((7, 1023))
+        m[r, c] = 9.0
+        m[min(6, r + 1), min(1022, c + 1)] = 8.0     # inside the 3x3 block when the block is not empty
+        m[(r + 3) % 7, (c + 300) % 1023] = 7.0
+        i, q = ref_acq.TwoCorrelationPeakComparison_SS(m.copy())
+        edge_maps.append(m)
+        edge_idx.append(i)
+        edge_ratio.append(q)
+    # the SerialSearch plugin end to end: acquisition packet + the first tracking epochs after it
+    from sydr.channel.channel_l1ca_kaplan_ss import ChannelL1CA_Kaplan_SS as RefSS
+    sats7 = [dict(prn=7, doppler=1750.0, code_phase=300.25, phase=0.1, amp=8.0)]
+    spms = int(fs * 1e-3)
+    raw7 = orc.synth_iq(fs, 40 * spms, sats7, 20.0, 20260001)
+    rf7 = raw7[0::2] + 1j * raw7[1::2]
+    cfg = _channel_config(os.path.join(REF, "config/channels/channel_GPS_L1CA_kaplan.ini"),
+                          {"ACQUISITION": dict(doppler_range=2000, doppler_steps=250, coherent_integration=1,
+                                               non_coherent_integration=2)})
+    rfs = RFSignal(dict(filepath="none", sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0, data_size=8))
+    buf = CircularBuffer(100 * spms, complex)
+    ch = RefSS(0, buf, None, rfs, cfg)
+    ch.setSatellite(7)
+    ss_acq, ss_epochs = None, []
+    for k in range(40):
+        buf.shift(rf7[k * spms:(k + 1) * spms])
+        for r in ch._processHandler():
+            if "correlation_map" in r:
+                ss_acq = [r["frequency_idx"], r["code_idx"], r["peak_ratio"], r["carrierFrequency"], r["codeOffset"],
+                          ch.currentSample, ch.track_requiredSamples]
+            elif "i_prompt" in r:
+                ss_epochs.append([r["i_early"], r["q_early"], r["i_prompt"], r["q_prompt"], r["i_late"], r["q_late"],
+                                  r["carrier_frequency"], r["code_frequency"]])
+    print("SS plugin acq", ss_acq, "epochs", len(ss_epochs))
+    save("g9_serial.npz", ss_iq_sha256=iq_hash(raw7), ss_acq=np.array(ss_acq, dtype=np.float64),
+         ss_epochs=np.array(ss_epochs), iq=raw, params=np.array([fs, n, 11, 750.0, 250.0]), map0=maps[0], map1=maps[1],
+         peak=np.array(idx), ratio=np.array(ratio), peak_sum=np.array(idx2), ratio_sum=np.array(ratio2),
+         edge_maps=np.stack(edge_maps), edge_idx=np.array(edge_idx), edge_ratio=np.array(edge_ratio))
+
+
 # ---------------------------------------------------------------------------------------------- G7
 def make_loopmath():
     rng = np.random.default_rng(20260700)
@@ -321,7 +373,9 @@ def make_loopmath():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["codes", "pcps", "peaks", "epl", "traj", "loop"]
+    which = sys.argv[1:] or ["codes", "pcps", "peaks", "epl", "traj", "loop", "serial"]
+    if "serial" in which:
+        make_serial()
     if "codes" in which:
         make_codes()
     if "pcps" in which:

@@ -273,3 +273,29 @@ def test_two_rank_gloo_sharding_and_gather(tmp_path):
     import json
     res = json.loads(line)
     assert res == dict(n=32, ok=True, sizes=[16, 16], tmax=pytest.approx(0.2))
+
+
+def test_serial_search_plugin_reproduces_reference():
+    """ChannelL1CA_Kaplan_SS (three overridden seams, channel_l1ca_kaplan_ss.py:10-54) end to end."""
+    import hashlib
+    from oracle import sydr_oracle as orc
+    from sydr_amd.channel.l1ca_kaplan_ss import ChannelL1CA_Kaplan_SS
+    g = load_golden("g9_serial.npz")
+    fs, spms = 4e6, 4000
+    raw = orc.synth_iq(fs, 40 * spms, [dict(prn=7, doppler=1750.0, code_phase=300.25, phase=0.1, amp=8.0)], 20.0, 20260001)
+    assert np.array_equal(np.frombuffer(hashlib.sha256(raw.tobytes()).digest(), dtype=np.uint8), g["ss_iq_sha256"])
+    cfg = channel_config(KAPLAN_INI)
+    cfg["ACQUISITION"].update(doppler_range="2000", doppler_steps="250", non_coherent_integration="2")
+    mgr = ChannelManager(rf_signal(fs), engine=OracleEngine())
+    mgr.addChannel(ChannelL1CA_Kaplan_SS, cfg, 1)
+    ch = mgr.requestTracking(7)
+    ticks = drive(mgr, raw, spms, 40)
+    acq = [p for t in ticks for p in t if p["type"] is ChannelMessage.ACQUISITION_UPDATE][0]
+    trk = [p for t in ticks for p in t if p["type"] is ChannelMessage.TRACKING_UPDATE]
+    ref = g["ss_acq"]
+    assert (acq["frequency_idx"], acq["code_idx"], acq["peak_ratio"], acq["carrierFrequency"], acq["codeOffset"]) == \
+        (int(ref[0]), int(ref[1]), ref[2], ref[3], int(ref[4]))
+    assert acq["correlation_map"].shape == (17, 1023) and len(trk) == len(g["ss_epochs"])
+    for p, row in zip(trk, g["ss_epochs"]):
+        assert [p["i_early"], p["q_early"], p["i_prompt"], p["q_prompt"], p["i_late"], p["q_late"],
+                p["carrier_frequency"], p["code_frequency"]] == list(row)

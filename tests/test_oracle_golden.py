@@ -222,3 +222,18 @@ def test_closed_loop_kaplan_lock_state_machine():
         assert rec["nav_bit"] == int(row[24]), k
     assert {int(r[22]) for r in ref} == {1, 2, 3} and int(ref[-1][23]) == 3
     assert loop.nav_bits == [int(b) for b in ref[ref[:, 24] >= 0, 24]] and len(loop.nav_bits) >= 40
+
+
+# ------------------------------------------------------------------------------------------------ G9 SerialSearch
+def test_serial_search_matches_reference():
+    g = load_golden("g9_serial.npz")
+    fs, n, prn, rng_hz, step = g["params"]
+    rf = orc.iq_to_complex(g["iq"])
+    code = orc.gold_code(int(prn))
+    m0 = orc.serial_search(rf[:int(n)].reshape(1, -1), code, rng_hz, step, fs, int(n))
+    assert np.array_equal(m0, g["map0"])
+    idx, ratio = orc.two_peak_compare_ss(m0)
+    assert idx == list(g["peak"]) and ratio == float(g["ratio"])
+    for m, i, q in zip(g["edge_maps"], g["edge_idx"], g["edge_ratio"]):
+        gi, gq = orc.two_peak_compare_ss(m)
+        assert gi == list(i) and gq == q
