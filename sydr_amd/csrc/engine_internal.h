@@ -65,6 +65,7 @@ struct sdr_engine {
     DevBuf pcps_fwd, pcps_a, pcps_b, pcps_code, pcps_tw, pcps_map, pcps_csum, pcps_part, pcps_res;
     DevBuf track_state, track_cfg, track_traj, track_bits;
     int64_t pcps_tw_n = 0;
+    bool pcps_force_passes = false;  // diagnostics: use the one-kernel-per-radix-pass transform instead of the four-step one
 
     // profiling
     bool prof = false;

@@ -407,12 +407,212 @@ void launch_pass(sdr_engine* e, const PassArgs& a, int batch) {
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Four-step transform: N = N1*N2, both sub-transforms done in LDS, two kernels and ONE round trip
+ * through HBM per transform instead of one per radix pass (7 passes at N = 25000):
+ *   A  columns:  Y[k1][n2] = sum_n1 x[N2*n1 + n2] W_N1^(n1 k1),  Z[k1][n2] = Y[k1][n2] * W_N^(n2 k1)
+ *   B  rows:     X[k1 + N1*k2] = sum_n2 Z[k1][n2] W_N2^(n2 k2)
+ * A workgroup owns a tile of T adjacent columns (A) or rows (B) so that every global access is a run
+ * of T*16 contiguous bytes; the fused loads (Doppler mix / code spectrum product) sit in A and the
+ * fused stores (conj / |.|/N accumulate) in B.  LDS rows are padded to T+1 complex (odd multiple of
+ * 16 B: conflict-free 16-byte accesses).
+ * ------------------------------------------------------------------------------------------------ */
+struct Radices {
+    int n;
+    int r[10];
+};
+
+struct FourStep {
+    bool ok = false;
+    int N1 = 0, N2 = 0;
+    Radices rad1{}, rad2{};
+};
+
+FourStep plan_four_step(int N) {
+    FourStep f;
+    int best = 0;
+    for (int d = 2; (int64_t)d * d <= N; ++d)
+        if (N % d == 0) best = d;  // largest divisor <= sqrt(N)
+    if (best < 4 || N / best > 512) return f;
+    std::vector<int> r1 = factor_radices(best), r2 = factor_radices(N / best);
+    if (r1.empty() || r2.empty() || r1.size() > 10 || r2.size() > 10) return f;
+    f.N1 = best;
+    f.N2 = N / best;
+    f.rad1.n = (int)r1.size();
+    f.rad2.n = (int)r2.size();
+    for (size_t i = 0; i < r1.size(); ++i) f.rad1.r[i] = r1[i];
+    for (size_t i = 0; i < r2.size(); ++i) f.rad2.r[i] = r2[i];
+    f.ok = true;
+    return f;
+}
+
+// x / d for x*d < 2^32 with magic = 2^32/d + 1: three integer ops instead of a ~25-instruction division.
+__device__ __forceinline__ int fast_div(int x, uint32_t magic) { return (int)__umulhi((uint32_t)x, magic); }
+__host__ __device__ __forceinline__ uint32_t div_magic(int d) { return (uint32_t)(0x100000000ull / (uint32_t)d) + 1u; }
+
+// One radix-R butterfly of a Stockham pass over data laid out [index][pitch] in LDS, column c.
+template <int R, bool INV>
+__device__ __forceinline__ void lds_butterfly(const double2* in, double2* out, int j, int c, int pitch, int nbf,
+                                              int Ns, int tws, const double2* wsub, uint32_t ns_magic) {
+    const int k = Ns == 1 ? 0 : j - fast_div(j, ns_magic) * Ns;
+    double2 v[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) v[t] = in[(j + t * nbf) * pitch + c];
+    if (Ns > 1) {
+#pragma unroll
+        for (int t = 1; t < R; ++t) {
+            double2 w = wsub[t * k * tws];
+            if (INV) w.y = -w.y;
+            v[t] = cmul(v[t], w);
+        }
+    }
+    Butterfly<R, INV>::run(v);
+    const int o = (j - k) * R + k;
+#pragma unroll
+    for (int t = 0; t < R; ++t) out[(o + t * Ns) * pitch + c] = v[t];
+}
+
+template <bool INV>
+__device__ __forceinline__ void lds_butterfly_generic(const double2* in, double2* out, int R, int j, int c, int pitch,
+                                                      int nbf, int Ns, int tws, int Nsub, const double2* wsub,
+                                                      uint32_t ns_magic) {
+    const int k = Ns == 1 ? 0 : j - fast_div(j, ns_magic) * Ns;
+    const int o = (j - k) * R + k;
+    const int root = Nsub / R;
+    for (int q = 0; q < R; ++q) {
+        double2 acc = make_double2(0.0, 0.0);
+        for (int t = 0; t < R; ++t) {
+            double2 x = in[(j + t * nbf) * pitch + c];
+            if (Ns > 1 && t > 0) {
+                double2 w = wsub[t * k * tws];
+                if (INV) w.y = -w.y;
+                x = cmul(x, w);
+            }
+            double2 r = wsub[((t * q) % R) * root];
+            if (INV) r.y = -r.y;
+            acc = cadd(acc, cmul(x, r));
+        }
+        out[(o + q * Ns) * pitch + c] = acc;
+    }
+}
+
+// In-LDS Stockham transform of `T` columns of length Nsub; returns the buffer holding the result.
+template <bool INV, int T>
+__device__ __forceinline__ double2* lds_fft(double2* a, double2* b, int Nsub, const Radices& rad, const double2* wsub) {
+    constexpr int pitch = T + 1;
+    int Ns = 1;
+    double2* in = a;
+    double2* out = b;
+    for (int p = 0; p < rad.n; ++p) {
+        const int R = rad.r[p];
+        const int nbf = Nsub / R;
+        const int tws = Nsub / (Ns * R);
+        const uint32_t ns_magic = div_magic(Ns);
+        for (int bf = threadIdx.x; bf < nbf * T; bf += kThreads) {
+            const int j = bf / T, c = bf - j * T;
+            switch (R) {
+                case 2: lds_butterfly<2, INV>(in, out, j, c, pitch, nbf, Ns, tws, wsub, ns_magic); break;
+                case 3: lds_butterfly<3, INV>(in, out, j, c, pitch, nbf, Ns, tws, wsub, ns_magic); break;
+                case 4: lds_butterfly<4, INV>(in, out, j, c, pitch, nbf, Ns, tws, wsub, ns_magic); break;
+                case 5: lds_butterfly<5, INV>(in, out, j, c, pitch, nbf, Ns, tws, wsub, ns_magic); break;
+                case 8: lds_butterfly<8, INV>(in, out, j, c, pitch, nbf, Ns, tws, wsub, ns_magic); break;
+                default: lds_butterfly_generic<INV>(in, out, R, j, c, pitch, nbf, Ns, tws, Nsub, wsub, ns_magic); break;
+            }
+        }
+        __syncthreads();
+        double2* tmp = in;
+        in = out;
+        out = tmp;
+        Ns *= R;
+    }
+    return in;
+}
+
+// Kernel A: T adjacent columns n2 of one transform.  Dynamic LDS: 2 * N1*(T+1) + N1 double2.
+template <bool INV, int LOAD, int FMT, int T>
+__global__ __launch_bounds__(kThreads) void fft4_cols_kernel(const PassArgs a, int N1, int N2, const Radices rad,
+                                                             double2* __restrict__ Z) {
+    extern __shared__ double2 lds4[];
+    constexpr int pitch = T + 1;
+    double2* bufA = lds4;
+    double2* bufB = bufA + N1 * pitch;
+    double2* wsub = bufB + N1 * pitch;
+    const int batch = blockIdx.y;
+    const int n2_0 = blockIdx.x * T;
+    for (int m = threadIdx.x; m < N1; m += kThreads) wsub[m] = a.tw[(size_t)m * N2];  // W_N1^m = W_N^(m*N2)
+    for (int e = threadIdx.x; e < N1 * T; e += kThreads) {
+        const int n1 = e / T, c = e - n1 * T;
+        const int n2 = n2_0 + c;
+        bufA[n1 * pitch + c] = n2 < N2 ? load_elem<LOAD, FMT, INV>(a, batch, N2 * n1 + n2) : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    const double2* res = lds_fft<INV, T>(bufA, bufB, N1, rad, wsub);
+    for (int e = threadIdx.x; e < N1 * T; e += kThreads) {
+        const int k1 = e / T, c = e - k1 * T;
+        const int n2 = n2_0 + c;
+        if (n2 < N2) {
+            double2 w = a.tw[(size_t)n2 * k1];  // n2*k1 < N
+            if (INV) w.y = -w.y;
+            Z[((size_t)batch * N1 + k1) * N2 + n2] = cmul(res[k1 * pitch + c], w);
+        }
+    }
+}
+
+// Kernel B: T adjacent rows k1 of one transform.  Dynamic LDS: 2 * N2*(T+1) + N2 double2.
+template <bool INV, int STORE, int T>
+__global__ __launch_bounds__(kThreads) void fft4_rows_kernel(const PassArgs a, int N1, int N2, const Radices rad,
+                                                             const double2* __restrict__ Z) {
+    extern __shared__ double2 lds4[];
+    constexpr int pitch = T + 1;
+    double2* bufA = lds4;
+    double2* bufB = bufA + N2 * pitch;
+    double2* wsub = bufB + N2 * pitch;
+    const int batch = blockIdx.y;
+    const int k1_0 = blockIdx.x * T;
+    for (int m = threadIdx.x; m < N2; m += kThreads) wsub[m] = a.tw[(size_t)m * N1];  // W_N2^m = W_N^(m*N1)
+    const uint32_t n2_magic = div_magic(N2);
+    for (int e = threadIdx.x; e < N2 * T; e += kThreads) {
+        const int c = fast_div(e, n2_magic), n2 = e - c * N2;  // n2 fastest: each row of Z is read as one contiguous run
+        const int k1 = k1_0 + c;
+        bufA[n2 * pitch + c] = k1 < N1 ? Z[((size_t)batch * N1 + k1) * N2 + n2] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    const double2* res = lds_fft<INV, T>(bufA, bufB, N2, rad, wsub);
+    for (int e = threadIdx.x; e < N2 * T; e += kThreads) {
+        const int k2 = e / T, c = e - k2 * T;
+        const int k1 = k1_0 + c;
+        if (k1 < N1) store_elem<STORE>(a, batch, k1 + N1 * k2, res[k2 * pitch + c]);
+    }
+}
+
+template <bool INV, int LOAD0, int STORE_LAST, int FMT>
+void run_four_step(sdr_engine* e, const FourStep& f, PassArgs a, int batch, double2* Z, double2* final_out) {
+    a.out = final_out;
+    constexpr int T = 8;
+    const size_t shA = (size_t)(2 * f.N1 * (T + 1) + f.N1) * sizeof(double2);
+    const size_t shB = (size_t)(2 * f.N2 * (T + 1) + f.N2) * sizeof(double2);
+    // more than 64 KiB of dynamic LDS has to be requested explicitly (160 KiB per CU on MI355X)
+    (void)hipFuncSetAttribute((const void*)fft4_cols_kernel<INV, LOAD0, FMT, T>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shA);
+    (void)hipFuncSetAttribute((const void*)fft4_rows_kernel<INV, STORE_LAST, T>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shB);
+    hipLaunchKernelGGL((fft4_cols_kernel<INV, LOAD0, FMT, T>), dim3((f.N2 + T - 1) / T, batch), dim3(kThreads), shA,
+                       e->stream, a, f.N1, f.N2, f.rad1, Z);
+    hipLaunchKernelGGL((fft4_rows_kernel<INV, STORE_LAST, T>), dim3((f.N1 + T - 1) / T, batch), dim3(kThreads), shB,
+                       e->stream, a, f.N1, f.N2, f.rad2, Z);
+}
+
 // Runs all passes of one batched transform.  `first` carries the fused load of
 // pass 0, `last_store` the fused store of the final pass.  Ping-pongs bufA/bufB.
 template <bool INV, int LOAD0, int STORE_LAST, int FMT>
 void run_fft(sdr_engine* e, const std::vector<int>& radices, PassArgs a, int batch, double2* bufA, double2* bufB,
              double2* final_out, const char* prof_name) {
     ProfScope ps(e, prof_name);
+    const FourStep four = plan_four_step(a.N);
+    if (four.ok && !e->pcps_force_passes) {
+        run_four_step<INV, LOAD0, STORE_LAST, FMT>(e, four, a, batch, bufA, final_out);
+        return;
+    }
     const int np = (int)radices.size();
     int Ns = 1;
     const double2* src = a.in;

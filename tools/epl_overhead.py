@@ -1,7 +1,7 @@
 """Per-workgroup fixed cost of epl_kernel: tiny epochs, different item counts."""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sydr_amd.engine import Engine, make_items, FMT_CI8
 e = Engine(0)
 cap = 8 * 400000

@@ -1,7 +1,7 @@
 """Fixed-vs-proportional cost of epl_kernel: time per workgroup as a function of samples per item."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sydr_amd.engine import Engine, make_items, FMT_CI8
 e = Engine(0)
 cap = 8 * 400000
