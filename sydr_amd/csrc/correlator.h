@@ -357,6 +357,7 @@ __device__ __forceinline__ void correlate_epoch(const void* __restrict__ ring, i
  * instead of 16, and 2 LDS gathers instead of 16.
  * ------------------------------------------------------------------------------------------------ */
 constexpr int kWide = 16;
+constexpr int kPrefixSlots = kGroup + 1;  // double2 slots of LDS per lane used by the boundary variant
 constexpr double kFastMaxCodeStep = 0.06;  // 15 * step <= 0.9 chip
 
 template <int FMT>
@@ -428,8 +429,11 @@ struct Raw8<SDR_FMT_CF64> {
 template <int FMT, int NT, int THREADS>
 __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ring, int64_t capacity,
                                                      const EpochParams& ep, double dphi, const EpochConsts<NT>& K,
-                                                     const uint32_t* lut, int tid, double* accr, double* acci) {
+                                                     const uint32_t* lut, double2* prefix_lds, int tid, double* accr,
+                                                     double* acci) {
     const int n = ep.n;
+    double2* strip = prefix_lds + tid * kPrefixSlots;  // this lane's 9 x 16 B (odd multiple of 16 B: conflict-free)
+    strip[0] = make_double2(0.0, 0.0);
     const double* rc = K.rc;
     const double* rs = K.rs;
     const double c8 = K.c8, s8 = K.s8;      // first -> second half of a group
@@ -469,10 +473,9 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
             return (int)ceil(y);
         };
 
-        // signs[t]: bit j = 1 when sample j of the group multiplies by -1 (chip p0 up to the switch
-        // position, chip p0+1 after it).  A shift + and-or per sample then rebuilds the high word
-        // of +-1.0 without compare/select pairs (VALU->SGPR->VALU costs wait states on gfx950).
-        uint32_t signs[NT];
+        // Per tap: nlead = number of leading samples on chip p0 (1..16), ca / cb = +-1.0 for chip p0 / p0+1.
+        int nlead[NT];
+        double cb_sign[NT], diff[NT];  // contribution = cb*P8 + (ca - cb)*P_nlead  (per 8-sample half)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             double y0;
@@ -484,43 +487,36 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
             b = b < 1 ? 1 : (b > kWide - 1 ? kWide - 1 : b);
             const int pa = chip(i0 + b - 1, t, nullptr);
             const int pb = chip(i0 + b, t, nullptr);
-            b = (pa != p0) ? b - 1 : ((pb == p0) ? b + 1 : b);   // b in [1,16]; 16 = whole group on chip p0
-            const uint32_t lead = (1u << b) - 1u;                 // samples that use chip p0
-            const uint32_t neg0 = 0u - (lut[p0 + SDR_LUT_PAD] >> 31);        // all ones when chip p0 is -1
-            const uint32_t neg1 = 0u - (lut[p0 + 1 + SDR_LUT_PAD] >> 31);
-            signs[t] = (neg0 & lead) | (neg1 & ~lead);
+            nlead[t] = (pa != p0) ? b - 1 : ((pb == p0) ? b + 1 : b);   // in [1,16]; 16 = whole group on chip p0
+            const double ca = __hiloint2double((int)lut[p0 + SDR_LUT_PAD], 0);
+            cb_sign[t] = __hiloint2double((int)lut[p0 + 1 + SDR_LUT_PAD], 0);
+            diff[t] = ca - cb_sign[t];
         }
 
-        uint32_t one_hi = 0x3FF00000u;  // high word of +1.0, kept in a VGPR for v_and_or_b32
-        asm volatile("" : "+v"(one_hi));
+        // Within a half the lane keeps the running sums P_1..P_8 of its mixed samples in its private LDS
+        // strip (slot 0 holds 0).  A tap's share of the half is then cb*P_8 + (ca-cb)*P_m with
+        // m = clamp(nlead - 8*half, 0, 8): ONE indexed 16-byte LDS read per tap instead of a sign
+        // select + two FMAs per tap per sample.
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            double gr[NT], gi[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) gr[t] = gi[t] = 0.0;
+            double pr = 0.0, pi = 0.0;
 #pragma unroll
             for (int j = 0; j < kGroup; ++j) {
-                const int jj = half * kGroup + j;
                 double ar, ai;
                 raw[half].get(j, ar, ai);
-                const double zr = __builtin_fma(-ai, rs[j], ar * rc[j]);
-                const double zi = __builtin_fma(ai, rc[j], ar * rs[j]);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    // hi = 0x3FF00000 | ((signs << (31-jj)) & 0x80000000): one shift + one v_and_or_b32
-                    uint32_t hi;
-                    asm("v_and_or_b32 %0, %1, %2, %3"
-                        : "=v"(hi)
-                        : "v"(signs[t] << (31 - jj)), "s"(0x80000000u), "v"(one_hi));
-                    const double c = __hiloint2double((int)hi, 0);
-                    gr[t] = __builtin_fma(c, zr, gr[t]);
-                    gi[t] = __builtin_fma(c, zi, gi[t]);
-                }
+                pr += __builtin_fma(-ai, rs[j], ar * rc[j]);
+                pi += __builtin_fma(ai, rc[j], ar * rs[j]);
+                strip[1 + j] = make_double2(pr, pi);
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                accr[t] += __builtin_fma(cb, gr[t], -sb * gi[t]);
-                acci[t] += __builtin_fma(cb, gi[t], sb * gr[t]);
+                int m = nlead[t] - half * kGroup;
+                m = m < 0 ? 0 : (m > kGroup ? kGroup : m);
+                const double2 pm = strip[m];
+                const double gr = __builtin_fma(diff[t], pm.x, cb_sign[t] * pr);
+                const double gi = __builtin_fma(diff[t], pm.y, cb_sign[t] * pi);
+                accr[t] += __builtin_fma(cb, gr, -sb * gi);
+                acci[t] += __builtin_fma(cb, gi, sb * gr);
             }
             // advance the base phase by 8 samples for the second half
             const double cb2 = __builtin_fma(cb, c8, -sb * s8);

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
                                                        double* __restrict__ out) {
     extern __shared__ double smem[];
     double* red = smem;
-    uint32_t* lut = reinterpret_cast<uint32_t*>(red + kWaves * 2 * NT);
+    double2* prefix = reinterpret_cast<double2*>(red + kWaves * 2 * NT);          // WIDE only: kThreads*9 slots
+    uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + (WIDE ? kThreads * kPrefixSlots : 0));
 
     const int tid = threadIdx.x;
     const sdr_epl_item it = items[blockIdx.x];
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
 
     double accr[NT], acci[NT];
     if (WIDE)
-        correlate_epoch_wide<FMT, NT, kThreads>(ring, capacity, ep, dphi, K, lut, tid, accr, acci);
+        correlate_epoch_wide<FMT, NT, kThreads>(ring, capacity, ep, dphi, K, lut, prefix, tid, accr, acci);
     else
         correlate_epoch<FMT, NT, kThreads>(ring, capacity, ep, dphi, K, lut, tid, accr, acci);
     const double total = reduce_taps<NT, kThreads>(accr, acci, red, tid);
@@ -69,15 +70,18 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
 template <int FMT, int NT>
 void launch_one(sdr_engine* e, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
                 int tap0, int n_taps_total, int lut_words, bool wide, double* d_out) {
-    size_t shmem = (size_t)(kWaves * 2 * NT) * sizeof(double) + (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
+    size_t shmem = (size_t)(kWaves * 2 * NT) * sizeof(double) + (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t) +
+                   (wide ? (size_t)kThreads * kPrefixSlots * sizeof(double2) : 0);
+    auto launch = [&](auto kernel) {
+        if (shmem > 64u * 1024u)  // beyond the default dynamic-LDS grant (long multi-period replicas)
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(kernel, dim3(n_items), dim3(kThreads), shmem, e->stream, e->iq, e->iq_capacity, d_items,
+                           e->luts, lut_words, e->lut_stride, d_spacing, fs, tap0, n_taps_total, d_out);
+    };
     if (wide)
-        hipLaunchKernelGGL((epl_kernel<FMT, NT, true>), dim3(n_items), dim3(kThreads), shmem, e->stream, e->iq,
-                           e->iq_capacity, d_items, e->luts, lut_words, e->lut_stride, d_spacing, fs, tap0,
-                           n_taps_total, d_out);
+        launch(epl_kernel<FMT, NT, true>);
     else
-        hipLaunchKernelGGL((epl_kernel<FMT, NT, false>), dim3(n_items), dim3(kThreads), shmem, e->stream, e->iq,
-                           e->iq_capacity, d_items, e->luts, lut_words, e->lut_stride, d_spacing, fs, tap0,
-                           n_taps_total, d_out);
+        launch(epl_kernel<FMT, NT, false>);
 }
 
 template <int FMT>

@@ -83,7 +83,8 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
     extern __shared__ double smem[];
     double* red = smem;                                   // kTrackWaves * 6
     EpochShared* sh = reinterpret_cast<EpochShared*>(red + kTrackWaves * 2 * kTaps);
-    uint32_t* lut = reinterpret_cast<uint32_t*>(sh + 1);
+    double2* prefix = reinterpret_cast<double2*>(sh + 1);                          // kTrackThreads * 9 slots
+    uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + kTrackThreads * kPrefixSlots);
 
     const int tid = threadIdx.x;
     const int ch = blockIdx.x;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
 
         double accr[kTaps], acci[kTaps];
         if (ep.code_step <= kFastMaxCodeStep)   // uniform branch: 16-sample boundary variant above ~17 MHz
-            correlate_epoch_wide<FMT, kTaps, kTrackThreads>(ring, capacity, ep, dphi, K, lut, tid, accr, acci);
+            correlate_epoch_wide<FMT, kTaps, kTrackThreads>(ring, capacity, ep, dphi, K, lut, prefix, tid, accr, acci);
         else
             correlate_epoch<FMT, kTaps, kTrackThreads>(ring, capacity, ep, dphi, K, lut, tid, accr, acci);
         const double total = reduce_taps<kTaps, kTrackThreads>(accr, acci, red, tid);
@@ -368,26 +369,27 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
     (void)maxlen;
     const int lut_words = e->lut_stride;  // the whole staged row (every code period the slots were sized for)
     const size_t shmem = (size_t)(kTrackWaves * 2 * kTaps) * sizeof(double) + sizeof(EpochShared) +
+                         (size_t)kTrackThreads * kPrefixSlots * sizeof(double2) +
                          (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
     sdr_track_state* d_st = (sdr_track_state*)e->track_state.ptr;
     const sdr_loop_cfg* d_cfg = (const sdr_loop_cfg*)e->track_cfg.ptr;
     sdr_track_epoch* d_traj = (sdr_track_epoch*)e->track_traj.ptr;
     const int keep = traj ? 1 : 0;
+    if (shmem > 160u * 1024u) return sdr_fail(SDR_ERR_RANGE, "closed-loop tracking: code table does not fit the LDS");
     {
         ProfScope ps(e, "track_kernel");
+        auto launch = [&](auto kernel) {
+            // more than 64 KB of dynamic LDS has to be granted per kernel
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            hipLaunchKernelGGL(kernel, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st,
+                               d_cfg, n_epochs, d_traj, keep, d_bits, max_bits, d_nbits, e->luts, lut_words,
+                               e->lut_stride);
+        };
         switch (e->iq_fmt) {
-            case SDR_FMT_CI8:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CI8>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, d_bits, max_bits, d_nbits, e->luts, lut_words, e->lut_stride);
-                break;
-            case SDR_FMT_CI16:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CI16>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, d_bits, max_bits, d_nbits, e->luts, lut_words, e->lut_stride);
-                break;
-            case SDR_FMT_CF32:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CF32>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, d_bits, max_bits, d_nbits, e->luts, lut_words, e->lut_stride);
-                break;
-            default:
-                hipLaunchKernelGGL(track_kernel<SDR_FMT_CF64>, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st, d_cfg, n_epochs, d_traj, keep, d_bits, max_bits, d_nbits, e->luts, lut_words, e->lut_stride);
-                break;
+            case SDR_FMT_CI8: launch(track_kernel<SDR_FMT_CI8>); break;
+            case SDR_FMT_CI16: launch(track_kernel<SDR_FMT_CI16>); break;
+            case SDR_FMT_CF32: launch(track_kernel<SDR_FMT_CF32>); break;
+            default: launch(track_kernel<SDR_FMT_CF64>); break;
         }
     }
     SDR_HIP(hipGetLastError());
