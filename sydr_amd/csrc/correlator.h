@@ -28,6 +28,7 @@
 namespace sdr {
 
 constexpr int kGroup = 8;  // samples per lane per iteration (one 16-byte load of ci8)
+constexpr int kWide = 16;  // samples per lane per iteration of the boundary variant
 
 constexpr double kHalfPiHi = 1.57079632679489655800e+00;  // fl(pi/2)
 constexpr double kHalfPiLo = 6.12323399573676603587e-17;  // pi/2 - fl(pi/2)
@@ -214,12 +215,11 @@ __device__ __forceinline__ void edge_samples(const void* __restrict__ ring, int6
 // and ~60 fewer VGPRs per lane than keeping them in vector registers.
 template <int NT>
 struct EpochConsts {
-    double rc[kGroup], rs[kGroup];  // cos,sin(-j*dphi): per-sample rotations inside a group
-    double c8, s8;                  // -8*dphi:  first -> second half of a 16-sample group
-    double cN, sN;                  // -8*THREADS*dphi:  lane stride of the 8-sample loop
-    double cW, sW;                  // -16*THREADS*dphi: lane stride of the 16-sample loop
-    double shift[NT], step[NT];     // np.linspace(shift, code_step*n+shift, n, endpoint=False) (tracking.py:111-112)
-    double inv_step[NT];            // 1/step: only ever used to PREDICT a chip-switch position
+    double rc[kWide], rs[kWide];  // cos,sin(-j*dphi): per-sample rotations inside a group (the 8-sample loop uses 0..7)
+    double cN, sN;                // -8*THREADS*dphi:  lane stride of the 8-sample loop
+    double cW, sW;                // -16*THREADS*dphi: lane stride of the 16-sample loop
+    double shift[NT], step[NT];   // np.linspace(shift, code_step*n+shift, n, endpoint=False) (tracking.py:111-112)
+    double inv_step[NT];          // 1/step: only ever used to PREDICT a chip-switch position
 };
 
 __device__ __forceinline__ double lane_value(double x, int lane) {
@@ -228,15 +228,17 @@ __device__ __forceinline__ double lane_value(double x, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+constexpr int kConstTapLane = 24;  // lanes 0..15: in-group rotations, 16/17: lane strides, 24..: taps
+
 template <int NT, int THREADS>
 __device__ __forceinline__ void compute_constants(EpochConsts<NT>& k, const EpochParams& ep,
                                                   const double* __restrict__ spacing, double dphi) {
     const int lane = threadIdx.x & 63;
-    const double mult = lane < 8 ? (double)lane
-                                 : (lane == 8 ? 8.0 : (lane == 9 ? (double)(kGroup * THREADS) : (double)(2 * kGroup * THREADS)));
+    const double mult = lane < kWide ? (double)lane
+                                     : (lane == kWide ? (double)(kGroup * THREADS) : (double)(kWide * THREADS));
     double sn, cs;
     sincos_reduced(-mult * dphi, &sn, &cs);
-    int t = lane - 16;
+    int t = lane - kConstTapLane;
     t = t < 0 ? 0 : (t > NT - 1 ? NT - 1 : t);
     const double nd = (double)ep.n;
     const double shift = ep.rem_code + spacing[t];  // reference arithmetic, operation for operation
@@ -246,21 +248,19 @@ __device__ __forceinline__ void compute_constants(EpochConsts<NT>& k, const Epoc
     const double step = delta / nd;
     const double inv = 1.0 / step;
 #pragma unroll
-    for (int j = 0; j < kGroup; ++j) {
+    for (int j = 0; j < kWide; ++j) {
         k.rc[j] = lane_value(cs, j);
         k.rs[j] = lane_value(sn, j);
     }
-    k.c8 = lane_value(cs, 8);
-    k.s8 = lane_value(sn, 8);
-    k.cN = lane_value(cs, 9);
-    k.sN = lane_value(sn, 9);
-    k.cW = lane_value(cs, 10);
-    k.sW = lane_value(sn, 10);
+    k.cN = lane_value(cs, kWide);
+    k.sN = lane_value(sn, kWide);
+    k.cW = lane_value(cs, kWide + 1);
+    k.sW = lane_value(sn, kWide + 1);
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
-        k.shift[q] = lane_value(shift, 16 + q);
-        k.step[q] = lane_value(step, 16 + q);
-        k.inv_step[q] = lane_value(inv, 16 + q);
+        k.shift[q] = lane_value(shift, kConstTapLane + q);
+        k.step[q] = lane_value(step, kConstTapLane + q);
+        k.inv_step[q] = lane_value(inv, kConstTapLane + q);
     }
 }
 
@@ -348,17 +348,27 @@ __device__ __forceinline__ void correlate_epoch(const void* __restrict__ ring, i
  *
  * A lane owns 16 consecutive samples (two 16-byte loads), i.e. < 1 chip, so for every tap the
  * reference chip index takes at most two values p0, p0+1 inside the group and the sequence is
- * monotone.  Instead of evaluating ceil(i*step+shift) for every sample, the kernel evaluates
- * that exact reference expression at the two ends, predicts the switch position from
- * (p0 - y0)/step, and VERIFIES the prediction with two more exact evaluations (the prediction
- * can only be off by one when the crossing falls within ~1e-11 samples of an integer; the
- * verification repairs exactly that case).  Every sample therefore still gets precisely the chip
- * NumPy's linspace/ceil would give it -- but with 4 exact evaluations per tap per 16 samples
- * instead of 16, and 2 LDS gathers instead of 16.
+ * monotone: the first `nlead` samples sit on chip p0, the rest on p0+1.  The lane mixes its 16
+ * samples with the carrier once, keeps the running sums P_1..P_16 in a private LDS strip
+ * (P_0 = 0; 8 slots, used twice), and a tap's share of the group is then
+ *        c(p0+1) * P_16 + (c(p0) - c(p0+1)) * P_nlead
+ * -- two indexed 16-byte LDS reads and a handful of FMAs per tap per 16 samples, instead of a chip
+ * index, a gather and two FMAs per tap per sample.
+ *
+ * nlead has to be EXACTLY what NumPy's linspace/ceil gives.  y0 = fl(fl(i0*step)+shift) and
+ * p0 = ceil(y0) are the reference expression itself.  The crossing is predicted as
+ * e = (p0 - y0)/step, nlead = floor(e)+1.  The reference's y_k differ from the real line
+ * y0 + k*step by at most ~4 ulp(y) (< 2^-33 for y < 2^18), i.e. by < 2^-33/step samples; the
+ * launcher admits this variant only for step >= 1e-4, so the prediction can be wrong only when e
+ * lies within 2^-19 of an integer.  Whenever any tap of any lane of the wave is within 2^-16
+ * (kNearInteger) of one, the whole wave recomputes nlead from exact evaluations of the reference
+ * expression on both sides of the predicted crossing (a branch taken by < 1 % of the groups).
  * ------------------------------------------------------------------------------------------------ */
-constexpr int kWide = 16;
 constexpr int kPrefixSlots = kGroup + 1;  // double2 slots of LDS per lane used by the boundary variant
+constexpr double kNearInteger = 1.0 / 65536.0;  // predicted crossings this close to a sample are re-checked exactly
 constexpr double kFastMaxCodeStep = 0.06;  // 15 * step <= 0.9 chip
+constexpr double kFastMinCodeStep = 1e-4;  // keeps the switch prediction's error far below kNearInteger (see above)
+constexpr int kFastMaxLutWords = 1 << 18;   // chip coordinates below 2^18: ulp(y) <= 2^-35
 
 template <int FMT>
 struct Raw8;  // 8 consecutive samples kept in their storage format until they are needed
@@ -426,6 +436,13 @@ struct Raw8<SDR_FMT_CF64> {
     }
 };
 
+// True when the epoch's samples cross the end of the ring (once per ring revolution per channel): such
+// an epoch goes through the per-sample variant, whose group loop re-wraps every position.
+__device__ __forceinline__ bool epoch_wraps(const EpochParams& ep, int64_t capacity) {
+    const int64_t aligned = ep.start_sample & ~(int64_t)(kGroup - 1);
+    return aligned % capacity + (ep.start_sample - aligned) + ep.n + kWide > capacity;
+}
+
 template <int FMT, int NT, int THREADS>
 __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ring, int64_t capacity,
                                                      const EpochParams& ep, double dphi, const EpochConsts<NT>& K,
@@ -434,9 +451,18 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
     const int n = ep.n;
     double2* strip = prefix_lds + tid * kPrefixSlots;  // this lane's 9 x 16 B (odd multiple of 16 B: conflict-free)
     strip[0] = make_double2(0.0, 0.0);
-    const double* rc = K.rc;
-    const double* rs = K.rs;
-    const double c8 = K.c8, s8 = K.s8;      // first -> second half of a group
+    // 16 rotations = 64 scalar registers would overflow the SGPR file (and the spills come back as
+    // v_readlane in the loop): the second half lives in vector registers instead, which are plentiful here.
+    double rc[kWide], rs[kWide];
+#pragma unroll
+    for (int j = 0; j < kWide; ++j) {
+        rc[j] = K.rc[j];
+        rs[j] = K.rs[j];
+        if (j >= kGroup) {
+            asm volatile("" : "+v"(rc[j]));
+            asm volatile("" : "+v"(rs[j]));
+        }
+    }
     const double c_it = K.cW, s_it = K.sW;  // lane stride of this loop
     const double dphi_u = uniform(dphi), rem_carrier_u = uniform(ep.rem_carrier);
     const double* shift = K.shift;
@@ -454,96 +480,135 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
     const int head_end = g_hi > g_lo ? g_lo * kWide - head : n;
     const int tail_start = g_hi > g_lo ? g_hi * kWide - head : n;
 
-    auto load_group = [&](int g, Raw8<FMT>* raw) {
-        int64_t pos = base + (int64_t)g * kWide;
-        if (pos >= capacity) pos -= capacity;
-        int64_t pos2 = pos + kGroup;
-        if (pos2 >= capacity) pos2 -= capacity;
+    // (the caller guarantees that the whole groups do not wrap around the ring: see epoch_wraps())
+    auto load_group = [&](int64_t pos, Raw8<FMT>* raw) {
         raw[0].load(ring, pos);
-        raw[1].load(ring, pos2);
+        raw[1].load(ring, pos + kGroup);
     };
 
     auto group = [&](int g, const Raw8<FMT>* raw, double sb, double cb) {
         const int i0 = g * kWide - head;
-        // the reference's chip index, exactly: separate multiply, add, ceil
-        auto chip = [&](int i, int t, double* yout) {
-            double y = (double)i * step[t];
-            y = y + shift[t];
-            if (yout) *yout = y;
-            return (int)ceil(y);
-        };
+        const double di0 = (double)i0;
 
-        // Per tap: nlead = number of leading samples on chip p0 (1..16), ca / cb = +-1.0 for chip p0 / p0+1.
-        int nlead[NT];
-        double cb_sign[NT], diff[NT];  // contribution = cb*P8 + (ca - cb)*P_nlead  (per 8-sample half)
+        int nlead[NT];                    // leading samples on chip p0, 1..16 (16: the whole group)
+        double sign_b[NT], sign_diff[NT];  // c(p0+1) and c(p0) - c(p0+1)
+        double y0[NT];
+        int p0[NT];
+        bool near = false;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            double y0;
-            const int p0 = chip(i0, t, &y0);
-            // predicted first sample (group-relative) whose chip is p0+1; a prediction beyond the
-            // group is clamped to the last sample, where the check below then finds "no switch"
-            const double e = ((double)p0 - y0) * inv_step[t];
-            int b = (int)e + 1;
-            b = b < 1 ? 1 : (b > kWide - 1 ? kWide - 1 : b);
-            const int pa = chip(i0 + b - 1, t, nullptr);
-            const int pb = chip(i0 + b, t, nullptr);
-            nlead[t] = (pa != p0) ? b - 1 : ((pb == p0) ? b + 1 : b);   // in [1,16]; 16 = whole group on chip p0
-            const double ca = __hiloint2double((int)lut[p0 + SDR_LUT_PAD], 0);
-            cb_sign[t] = __hiloint2double((int)lut[p0 + 1 + SDR_LUT_PAD], 0);
-            diff[t] = ca - cb_sign[t];
+            double y = di0 * step[t];  // the reference's chip index, exactly: separate multiply, add, ceil
+            y = y + shift[t];
+            const double cy = ceil(y);
+            y0[t] = y;
+            p0[t] = (int)cy;
+            const double e = (cy - y) * inv_step[t];  // >= 0
+            const double fr = e - floor(e);
+            near |= fabs(fr - 0.5) > 0.5 - kNearInteger;
+            const double ec = fmin(e, (double)(kWide - 1));
+            nlead[t] = (int)ec + 1;
         }
-
-        // Within a half the lane keeps the running sums P_1..P_8 of its mixed samples in its private LDS
-        // strip (slot 0 holds 0).  A tap's share of the half is then cb*P_8 + (ca-cb)*P_m with
-        // m = clamp(nlead - 8*half, 0, 8): ONE indexed 16-byte LDS read per tap instead of a sign
-        // select + two FMAs per tap per sample.
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            double pr = 0.0, pi = 0.0;
-#pragma unroll
-            for (int j = 0; j < kGroup; ++j) {
-                double ar, ai;
-                raw[half].get(j, ar, ai);
-                pr += __builtin_fma(-ai, rs[j], ar * rc[j]);
-                pi += __builtin_fma(ai, rc[j], ar * rs[j]);
-                strip[1 + j] = make_double2(pr, pi);
-            }
+        if (__builtin_expect(__any(near), 0)) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                int m = nlead[t] - half * kGroup;
-                m = m < 0 ? 0 : (m > kGroup ? kGroup : m);
-                const double2 pm = strip[m];
-                const double gr = __builtin_fma(diff[t], pm.x, cb_sign[t] * pr);
-                const double gi = __builtin_fma(diff[t], pm.y, cb_sign[t] * pi);
-                accr[t] += __builtin_fma(cb, gr, -sb * gi);
-                acci[t] += __builtin_fma(cb, gi, sb * gr);
+                auto chip = [&](int i) {
+                    double y = (double)i * step[t];
+                    y = y + shift[t];
+                    return (int)ceil(y);
+                };
+                const int b = nlead[t] > kWide - 1 ? kWide - 1 : nlead[t];  // compare samples b-1 | b, both in the group
+                const int pa = chip(i0 + b - 1);
+                const int pb = chip(i0 + b);
+                nlead[t] = (pa != p0[t]) ? b - 1 : ((pb == p0[t]) ? b + 1 : b);
             }
-            // advance the base phase by 8 samples for the second half
-            const double cb2 = __builtin_fma(cb, c8, -sb * s8);
-            sb = __builtin_fma(sb, c8, cb * s8);
-            cb = cb2;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const double ca = __hiloint2double((int)lut[p0[t] + SDR_LUT_PAD], 0);
+            sign_b[t] = __hiloint2double((int)lut[p0[t] + 1 + SDR_LUT_PAD], 0);
+            sign_diff[t] = ca - sign_b[t];
+        }
+
+        // First half: P_1..P_8 into slots 1..8 (slot 0 stays 0); every tap reads P_min(nlead,8).
+        // Second half: the sums restart at sample 8 (Q_1..Q_8) and reuse the same slots -- LDS operations
+        // of a wave execute in order, so the reads above are served first; every tap reads Q_max(nlead-8,0).
+        // P_nlead = P_min(nlead,8) + Q_max(nlead-8,0), and P_16 = P_8 + Q_8.
+        double pr = 0.0, pi = 0.0;
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+            double ar, ai;
+            raw[0].get(j, ar, ai);
+            pr = __builtin_fma(-ai, rs[j], __builtin_fma(ar, rc[j], pr));
+            pi = __builtin_fma(ai, rc[j], __builtin_fma(ar, rs[j], pi));
+            strip[1 + j] = make_double2(pr, pi);
+        }
+        double2 pa[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pa[t] = strip[nlead[t] < kGroup ? nlead[t] : kGroup];
+        double qr = 0.0, qi = 0.0;
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+            double ar, ai;
+            raw[1].get(j, ar, ai);
+            qr = __builtin_fma(-ai, rs[kGroup + j], __builtin_fma(ar, rc[kGroup + j], qr));
+            qi = __builtin_fma(ai, rc[kGroup + j], __builtin_fma(ar, rs[kGroup + j], qi));
+            strip[1 + j] = make_double2(qr, qi);
+        }
+        pr += qr;
+        pi += qi;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const double2 qb = strip[(nlead[t] > kGroup ? nlead[t] : kGroup) - kGroup];
+            const double gr = __builtin_fma(sign_diff[t], pa[t].x + qb.x, sign_b[t] * pr);
+            const double gi = __builtin_fma(sign_diff[t], pa[t].y + qb.y, sign_b[t] * pi);
+            accr[t] = __builtin_fma(-sb, gi, __builtin_fma(cb, gr, accr[t]));
+            acci[t] = __builtin_fma(sb, gr, __builtin_fma(cb, gi, acci[t]));
         }
     };
 
-    // Software prefetch: the next group's two 16-byte loads are in flight while this one is computed.
-    Raw8<FMT> cur[2], nxt[2];
-    int g = g_lo + tid;
-    if (g < g_hi) load_group(g, cur);
-    // Carrier phase at the lane's first sample: one exact evaluation, then a fixed rotation per
-    // iteration (the lane's groups are kWide*THREADS samples apart; <= a few dozen steps, so the
-    // recurrence stays within ~1e-15 of a fresh evaluation).
-    double sb, cb;
-    sincos_reduced(__builtin_fma(-(double)((g_lo + tid) * kWide - head), dphi_u, rem_carrier_u), &sb, &cb);
-    while (g < g_hi) {
-        const int gn = g + THREADS;
-        if (gn < g_hi) load_group(gn, nxt);
-        group(g, cur, sb, cb);
-        cur[0] = nxt[0];
-        cur[1] = nxt[1];
-        const double cbn = __builtin_fma(cb, c_it, -sb * s_it);
-        sb = __builtin_fma(sb, c_it, cb * s_it);
-        cb = cbn;
-        g = gn;
+    // Software prefetch: the next group's 16-byte loads are in flight while this one is computed.  The
+    // loop is unrolled by two over a ping-pong pair of buffers and is free of divergent control flow:
+    // the trip count is wave-uniform, every load is unconditional (a lane that has run out of groups
+    // stays on its last one) and such a lane's carrier phasor is zeroed, so what it computes adds 0.
+    // (Handing prefetched registers over by copy, or loading under a lane mask, makes the compiler
+    // wait for a load in the iteration that issued it.)
+    const int n_groups = g_hi - g_lo;
+    if (n_groups > 0) {
+        Raw8<FMT> buf_a[2], buf_b[2];
+        int g = g_lo + tid;
+        bool alive = g < g_hi;
+        g = alive ? g : g_hi - 1;
+        int64_t pos = base + (int64_t)g * kWide;
+        load_group(pos, buf_a);
+        // Carrier phase at the lane's first sample: one exact evaluation, then a fixed rotation per
+        // iteration (the lane's groups are kWide*THREADS samples apart; <= a few dozen steps, so the
+        // recurrence stays within ~1e-15 of a fresh evaluation).
+        double sb, cb;
+        sincos_reduced(__builtin_fma(-(double)(g * kWide - head), dphi_u, rem_carrier_u), &sb, &cb);
+        sb = alive ? sb : 0.0;
+        cb = alive ? cb : 0.0;
+        auto advance = [&]() {  // to the lane's next group, or stay (with a zero phasor) when there is none
+            const bool more = g + THREADS < g_hi;
+            const double cbn = __builtin_fma(cb, c_it, -sb * s_it);
+            const double sbn = __builtin_fma(sb, c_it, cb * s_it);
+            sb = more ? sbn : 0.0;
+            cb = more ? cbn : 0.0;
+            g += more ? THREADS : 0;
+            pos += more ? kWide * THREADS : 0;
+        };
+        const int pairs = (n_groups + 2 * THREADS - 1) / (2 * THREADS);
+        for (int it = 0; it < pairs; ++it) {
+            const double sb0 = sb, cb0 = cb;
+            const int g0 = g;
+            advance();
+            load_group(pos, buf_b);
+            group(g0, buf_a, sb0, cb0);
+            const double sb1 = sb, cb1 = cb;
+            const int g1 = g;
+            advance();
+            load_group(pos, buf_a);
+            group(g1, buf_b, sb1, cb1);
+        }
     }
     if (tid < 64) {
         if (head_end + (n - tail_start) > 64) {   // epoch shorter than a group + a wave: walk the list

@@ -17,6 +17,14 @@
 // the reference to ~1e-12 rad (far inside the 1e-6 relative bar on accumulators).
 #include "correlator.h"
 
+#ifdef SDR_TRACE_WG
+// Debug build only (tools/wg_trace.py): per-workgroup start/end clock and hardware id.
+__device__ unsigned long long g_wg_trace[3 * 65536];
+extern "C" int sdr_debug_read_trace(unsigned long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wg_trace), (size_t)n * 3 * sizeof(unsigned long long));
+}
+#endif
+
 namespace {
 
 using namespace sdr;
@@ -44,6 +52,9 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
     uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + (WIDE ? kThreads * kPrefixSlots : 0));
 
     const int tid = threadIdx.x;
+#ifdef SDR_TRACE_WG
+    const unsigned long long t_start = wall_clock64();
+#endif
     const sdr_epl_item it = items[blockIdx.x];
     stage_lut<kThreads>(lut, luts + (size_t)it.code_slot * lut_stride, lut_words, tid);
     const double dphi = carrier_step(it.carrier_hz, fs);
@@ -59,12 +70,23 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
     __syncthreads();  // replica staged
 
     double accr[NT], acci[NT];
-    if (WIDE)
+    if (WIDE && !epoch_wraps(ep, capacity))
         correlate_epoch_wide<FMT, NT, kThreads>(ring, capacity, ep, dphi, K, lut, prefix, tid, accr, acci);
     else
         correlate_epoch<FMT, NT, kThreads>(ring, capacity, ep, dphi, K, lut, tid, accr, acci);
     const double total = reduce_taps<NT, kThreads>(accr, acci, red, tid);
     if (tid < 2 * NT) out[(size_t)blockIdx.x * 2 * n_taps_total + 2 * tap0 + tid] = total;
+#ifdef SDR_TRACE_WG
+    if (tid == 0 && blockIdx.x < 65536) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_wg_trace[3 * blockIdx.x] = t_start;
+        g_wg_trace[3 * blockIdx.x + 1] = wall_clock64();
+        g_wg_trace[3 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
 
 template <int FMT, int NT>
@@ -129,10 +151,11 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
         smax = spacing[t] > smax ? spacing[t] : smax;
     }
     int maxlen = 0;
-    double max_step = 0.0;
+    double max_step = 0.0, min_step = 1e300;
     for (int i = 0; i < n_items; ++i) {
         const sdr_epl_item& it = items[i];
         if (it.code_step > max_step) max_step = it.code_step;
+        if (it.code_step < min_step) min_step = it.code_step;
         if (it.code_slot < 0 || it.code_slot >= e->n_slots || e->code_len_host[it.code_slot] <= 0)
             return sdr_fail(SDR_ERR_INVALID, "item %d: code slot %d is not staged", i, it.code_slot);
         if (it.n_samples <= 0 || it.n_samples > e->iq_capacity)
@@ -151,7 +174,7 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
         if ((int)hi > maxlen) maxlen = (int)hi;
     }
     *lut_words = maxlen + SDR_LUT_PAD + 2;
-    *wide = max_step <= sdr::kFastMaxCodeStep;
+    *wide = max_step <= sdr::kFastMaxCodeStep && min_step >= sdr::kFastMinCodeStep && e->lut_stride < sdr::kFastMaxLutWords;
     return SDR_OK;
 }
 

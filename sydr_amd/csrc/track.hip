@@ -79,12 +79,12 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
                                                               int keep_traj, int8_t* __restrict__ nav_bits, int max_bits,
                                                               int32_t* __restrict__ n_bits,
                                                               const uint32_t* __restrict__ luts,
-                                                              int lut_words, int lut_stride) {
+                                                              int lut_words, int lut_stride, int use_prefix) {
     extern __shared__ double smem[];
     double* red = smem;                                   // kTrackWaves * 6
     EpochShared* sh = reinterpret_cast<EpochShared*>(red + kTrackWaves * 2 * kTaps);
-    double2* prefix = reinterpret_cast<double2*>(sh + 1);                          // kTrackThreads * 9 slots
-    uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + kTrackThreads * kPrefixSlots);
+    double2* prefix = reinterpret_cast<double2*>(sh + 1);  // kTrackThreads * kPrefixSlots, when the launcher found room
+    uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + (use_prefix ? kTrackThreads * kPrefixSlots : 0));
 
     const int tid = threadIdx.x;
     const int ch = blockIdx.x;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
         compute_constants<kTaps, kTrackThreads>(K, ep, sh->spacing, dphi);
 
         double accr[kTaps], acci[kTaps];
-        if (ep.code_step <= kFastMaxCodeStep)   // uniform branch: 16-sample boundary variant above ~17 MHz
+        if (use_prefix && ep.code_step <= kFastMaxCodeStep && ep.code_step >= kFastMinCodeStep && !epoch_wraps(ep, capacity))   // uniform branch: 16-sample boundary variant above ~17 MHz
             correlate_epoch_wide<FMT, kTaps, kTrackThreads>(ring, capacity, ep, dphi, K, lut, prefix, tid, accr, acci);
         else
             correlate_epoch<FMT, kTaps, kTrackThreads>(ring, capacity, ep, dphi, K, lut, tid, accr, acci);
@@ -368,9 +368,13 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
     SDR_HIP(hipMemcpyAsync(e->track_cfg.ptr, cfg, sizeof(sdr_loop_cfg), hipMemcpyHostToDevice, e->stream));
     (void)maxlen;
     const int lut_words = e->lut_stride;  // the whole staged row (every code period the slots were sized for)
-    const size_t shmem = (size_t)(kTrackWaves * 2 * kTaps) * sizeof(double) + sizeof(EpochShared) +
-                         (size_t)kTrackThreads * kPrefixSlots * sizeof(double2) +
-                         (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
+    const size_t shmem_base = (size_t)(kTrackWaves * 2 * kTaps) * sizeof(double) + sizeof(EpochShared) +
+                              (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
+    const size_t prefix_bytes = (size_t)kTrackThreads * kPrefixSlots * sizeof(double2);
+    // The boundary variant of the correlator needs a 272-byte LDS strip per lane; long multi-period
+    // replicas that leave no room for it are tracked with the per-sample variant.
+    const int use_prefix = shmem_base + prefix_bytes <= 160u * 1024u && e->lut_stride < kFastMaxLutWords ? 1 : 0;
+    const size_t shmem = shmem_base + (use_prefix ? prefix_bytes : 0);
     sdr_track_state* d_st = (sdr_track_state*)e->track_state.ptr;
     const sdr_loop_cfg* d_cfg = (const sdr_loop_cfg*)e->track_cfg.ptr;
     sdr_track_epoch* d_traj = (sdr_track_epoch*)e->track_traj.ptr;
@@ -383,7 +387,7 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
             hipLaunchKernelGGL(kernel, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st,
                                d_cfg, n_epochs, d_traj, keep, d_bits, max_bits, d_nbits, e->luts, lut_words,
-                               e->lut_stride);
+                               e->lut_stride, use_prefix);
         };
         switch (e->iq_fmt) {
             case SDR_FMT_CI8: launch(track_kernel<SDR_FMT_CI8>); break;

@@ -173,6 +173,52 @@ def test_epl_tiny_and_ragged_epochs(engine):
         assert_corr_close(got[k], ref)
 
 
+def test_epl_chip_crossings_exactly_on_samples(engine):
+    """The boundary variant predicts where a lane's 16 samples change chip and re-checks predictions that
+    fall on (or within 2^-16 of) a sample.  Steps that are exact binary fractions with integer / half-integer
+    shifts put EVERY crossing exactly on a sample -- the tie ceil() resolves downwards; a single wrong chip
+    moves an accumulator by far more than the tolerance."""
+    rng = np.random.default_rng(21)
+    cap = 1 << 17
+    raw = rng.integers(-100, 100, 2 * cap).astype(np.int8)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(1)
+    engine.load_gps_code(0, 14)
+    rf = orc.iq_to_complex(raw)
+    code = orc.pad_code(orc.gold_code(14))
+    for step, fs in [(1 / 32, 32 * 1.023e6), (1 / 64, 64 * 1.023e6), (3 / 64, 1.023e6 * 64 / 3), (1 / 17, 17 * 1.023e6)]:
+        n = int(1000 / step)
+        for rem, start in [(0.0, 0), (0.5, 3), (0.25, 16), (1 / 32, 37), (0.999999999999, 8), (1e-12, 5)]:
+            items = make_items(0, n, start, 1234.5, 0.1, rem, step)
+            for spacing in [(-0.5, 0.0, 0.5), (-0.25, 0.0, 0.25), (-0.0625, 0.0, 0.0625)]:
+                got = engine.epl_batch(items, spacing, fs)[0]
+                ref = orc.epl(orc.ring_slice(rf, start, n), code, fs, 1234.5, 0.1, rem, step, spacing)
+                assert_corr_close(got, ref)
+
+
+def test_epl_high_rate_random_sweep(engine):
+    """Random code steps across the boundary variant's whole range (fs 17 MHz .. 200 MHz), random phases."""
+    rng = np.random.default_rng(22)
+    cap = 1 << 18
+    raw = rng.integers(-100, 100, 2 * cap).astype(np.int8)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(2)
+    engine.load_gps_code(1, 30)
+    rf = orc.iq_to_complex(raw)
+    code = orc.pad_code(orc.gold_code(30))
+    for _ in range(24):
+        step = float(rng.uniform(0.005, 0.06))
+        n = int(rng.integers(2000, min(cap - 100, int(1022.0 / step))))
+        start = int(rng.integers(0, cap))
+        f, rc, rk = float(rng.uniform(-6e3, 6e3)), float(rng.uniform(0, 6.28)), float(rng.uniform(0, 1))
+        fs = 1.023e6 / step
+        got = engine.epl_batch(make_items(1, n, start, f, rc, rk, step), (-0.5, 0.0, 0.5), fs)[0]
+        ref = orc.epl(orc.ring_slice(rf, start, n), code, fs, f, rc, rk, step, (-0.5, 0.0, 0.5))
+        assert_corr_close(got, ref)
+
+
 def test_epl_linearity_and_sign(engine):
     """Size-independent property: correlators are linear in the IQ (x -> -x flips every sign exactly)."""
     rng = np.random.default_rng(10)

@@ -12,7 +12,10 @@ for s in range(32):
     e.load_gps_code(s, s + 1)
 rng = np.random.default_rng(1)
 n_items = 32000
+only = int(sys.argv[sys.argv.index('--only') + 1]) if '--only' in sys.argv else None
 for n, step in ((3125, 0.32), (6250, 0.16), (12500, 0.0818), (25000, 0.04092), (50000, 0.02046), (100000, 0.01023)):
+    if only and n != only:
+        continue
     items = make_items(np.arange(n_items) % 32, n, rng.integers(0, cap, n_items), 1000.0, 0.3, 0.01, step)
     plan = e.epl_plan(items, (-0.5, 0.0, 0.5), 25e6)
     plan.run(); e.sync()
