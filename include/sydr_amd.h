@@ -265,6 +265,12 @@ typedef struct sdr_track_epoch {
     int32_t nav_bit;                      /* -1: none this epoch; 0/1: bit closed by this epoch (20 prompts) */
 } sdr_track_epoch;
 
+/* A channel is tracked by a cluster of 1, 2, 4 or 8 cooperating workgroups (one per compute unit; the
+ * partial sums of an epoch are added in a fixed order, so a given cluster size always gives the same
+ * bits).  parts = 0 (default) lets the library fill the GPU: min(8, CUs / n_ch) rounded down to a power
+ * of two.  The reference has no counterpart: its channels are one Python process each
+ * (sydr/channel/channel.py:90-151). */
+int sdr_track_cluster(sdr_engine* e, int parts);
 int sdr_track_closed_loop(sdr_engine* e, int n_ch, sdr_track_state* st, const sdr_loop_cfg* cfg,
                           int n_epochs, sdr_track_epoch* traj /* [n_ch][n_epochs], nullable */);
 /* Same run; additionally the navigation bits decided during it leave the device as one byte each

@@ -126,6 +126,7 @@ _PROTOTYPES = {
                                     _VP, _VP, C.POINTER(C.c_int)]),
     "sdr_two_peak_compare_ss": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                           C.POINTER(C.c_double)]),
+    "sdr_track_cluster": (C.c_int, [_VP, C.c_int]),
     "sdr_track_closed_loop": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(LoopCfg), C.c_int, _VP]),
     "sdr_track_closed_loop_bits": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(LoopCfg), C.c_int, _VP, _VP, C.c_int, _VP]),
 }

@@ -230,12 +230,14 @@ __device__ __forceinline__ double lane_value(double x, int lane) {
 
 constexpr int kConstTapLane = 24;  // lanes 0..15: in-group rotations, 16/17: lane strides, 24..: taps
 
-template <int NT, int THREADS>
+// `stride` = number of lanes that share the epoch (the workgroup's threads, or all threads of the
+// workgroups that cooperate on one channel).
+template <int NT>
 __device__ __forceinline__ void compute_constants(EpochConsts<NT>& k, const EpochParams& ep,
-                                                  const double* __restrict__ spacing, double dphi) {
+                                                  const double* __restrict__ spacing, double dphi, int stride) {
     const int lane = threadIdx.x & 63;
     const double mult = lane < kWide ? (double)lane
-                                     : (lane == kWide ? (double)(kGroup * THREADS) : (double)(kWide * THREADS));
+                                     : (lane == kWide ? (double)(kGroup * stride) : (double)(kWide * stride));
     double sn, cs;
     sincos_reduced(-mult * dphi, &sn, &cs);
     int t = lane - kConstTapLane;
@@ -264,12 +266,14 @@ __device__ __forceinline__ void compute_constants(EpochConsts<NT>& k, const Epoc
     }
 }
 
-// Correlate this thread's share (groups tid, tid+THREADS, ...) of one epoch.
-// accr/acci[NT] receive the thread-partial fp64 accumulators.
-template <int FMT, int NT, int THREADS>
+// Correlate this lane's share (groups lane, lane+stride, ...) of one epoch; `lane` is the index among
+// the `stride` lanes that share the epoch.  edge_lane = 0..63 in the ONE wave that also takes the
+// epoch's edge samples, -1 elsewhere.  accr/acci[NT] receive the lane-partial fp64 accumulators.
+template <int FMT, int NT>
 __device__ __forceinline__ void correlate_epoch(const void* __restrict__ ring, int64_t capacity,
                                                 const EpochParams& ep, double dphi, const EpochConsts<NT>& K,
-                                                const uint32_t* lut, int tid, double* accr, double* acci) {
+                                                const uint32_t* lut, int lane, int stride, int edge_lane,
+                                                double* accr, double* acci) {
     const int n = ep.n;
     const double* rc = K.rc;
     const double* rs = K.rs;
@@ -327,19 +331,19 @@ __device__ __forceinline__ void correlate_epoch(const void* __restrict__ ring, i
 
     // carrier phase at the lane's first sample: one exact evaluation, then a fixed rotation per iteration
     double sb, cb;
-    sincos_reduced(__builtin_fma(-(double)((g_lo + tid) * kGroup - head), dphi, ep.rem_carrier), &sb, &cb);
-    for (int g = g_lo + tid; g < g_hi; g += THREADS) {
+    sincos_reduced(__builtin_fma(-(double)((g_lo + lane) * kGroup - head), dphi, ep.rem_carrier), &sb, &cb);
+    for (int g = g_lo + lane; g < g_hi; g += stride) {
         group(g, sb, cb);
         const double cbn = __builtin_fma(cb, c_it, -sb * s_it);
         sb = __builtin_fma(sb, c_it, cb * s_it);
         cb = cbn;
     }
-    if (tid < 64 && head_end + (n - tail_start) > 64) {
+    if (edge_lane >= 0 && head_end + (n - tail_start) > 64) {
         // (only when n < 8 + 64: a tiny epoch; walk the edge list in wave-sized pieces)
         for (int off = 0; off < head_end + (n - tail_start); off += 64)
-            edge_samples<FMT, NT>(ring, capacity, ep, dphi, shift, step, lut, tid + off, head_end, tail_start, accr, acci);
-    } else if (tid < 64) {
-        edge_samples<FMT, NT>(ring, capacity, ep, dphi, shift, step, lut, tid, head_end, tail_start, accr, acci);
+            edge_samples<FMT, NT>(ring, capacity, ep, dphi, shift, step, lut, edge_lane + off, head_end, tail_start, accr, acci);
+    } else if (edge_lane >= 0) {
+        edge_samples<FMT, NT>(ring, capacity, ep, dphi, shift, step, lut, edge_lane, head_end, tail_start, accr, acci);
     }
 }
 
@@ -443,11 +447,13 @@ __device__ __forceinline__ bool epoch_wraps(const EpochParams& ep, int64_t capac
     return aligned % capacity + (ep.start_sample - aligned) + ep.n + kWide > capacity;
 }
 
-template <int FMT, int NT, int THREADS>
+// tid = index of the thread in its workgroup (selects the LDS strip); lane/stride/edge_lane as in
+// correlate_epoch.  SINGLE_WAVE: the epoch belongs to one wave alone (the batched kernel).
+template <int FMT, int NT, bool SINGLE_WAVE>
 __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ring, int64_t capacity,
                                                      const EpochParams& ep, double dphi, const EpochConsts<NT>& K,
-                                                     const uint32_t* lut, double2* prefix_lds, int tid, double* accr,
-                                                     double* acci) {
+                                                     const uint32_t* lut, double2* prefix_lds, int tid, int lane,
+                                                     int stride, int edge_lane, double* accr, double* acci) {
     const int n = ep.n;
     double2* strip = prefix_lds + tid * kPrefixSlots;  // this lane's 9 x 16 B (odd multiple of 16 B: conflict-free)
     strip[0] = make_double2(0.0, 0.0);
@@ -575,7 +581,7 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
     const int n_groups = g_hi - g_lo;
     if (n_groups > 0) {
         Raw8<FMT> buf_a[2], buf_b[2];
-        int g = g_lo + tid;
+        int g = g_lo + lane;
         bool alive = g < g_hi;
         g = alive ? g : g_hi - 1;
         int64_t pos = base + (int64_t)g * kWide;
@@ -588,75 +594,77 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
         sb = alive ? sb : 0.0;
         cb = alive ? cb : 0.0;
         auto advance = [&]() {  // to the lane's next group, or stay (with a zero phasor) when there is none
-            const bool more = g + THREADS < g_hi;
+            const bool more = g + stride < g_hi;
             const double cbn = __builtin_fma(cb, c_it, -sb * s_it);
             const double sbn = __builtin_fma(sb, c_it, cb * s_it);
             sb = more ? sbn : 0.0;
             cb = more ? cbn : 0.0;
-            g += more ? THREADS : 0;
-            pos += more ? kWide * THREADS : 0;
+            alive = more;
+            g += more ? stride : 0;
+            pos += more ? kWide * stride : 0;
         };
-        const int pairs = (n_groups + 2 * THREADS - 1) / (2 * THREADS);
-        for (int it = 0; it < pairs; ++it) {
+        // A wave all of whose lanes have run out (the last, partial round of a multi-wave workgroup)
+        // skips the group body; the single-wave kernel never pays for the test.
+        auto wave_has_work = [&](bool lane_alive) { return SINGLE_WAVE || __any(lane_alive) != 0; };
+        const int rounds = (n_groups + stride - 1) / stride;
+        for (int it = 0; it < rounds / 2; ++it) {
             const double sb0 = sb, cb0 = cb;
             const int g0 = g;
+            const bool alive0 = alive;
             advance();
             load_group(pos, buf_b);
-            group(g0, buf_a, sb0, cb0);
+            if (wave_has_work(alive0)) group(g0, buf_a, sb0, cb0);
             const double sb1 = sb, cb1 = cb;
             const int g1 = g;
+            const bool alive1 = alive;
             advance();
             load_group(pos, buf_a);
-            group(g1, buf_b, sb1, cb1);
+            if (wave_has_work(alive1)) group(g1, buf_b, sb1, cb1);
         }
+        if ((rounds & 1) && wave_has_work(alive)) group(g, buf_a, sb, cb);
     }
-    if (tid < 64) {
+    // (callers give the edge samples to the LAST wave: the partial last round lands on the first ones)
+    if (edge_lane >= 0) {
         if (head_end + (n - tail_start) > 64) {   // epoch shorter than a group + a wave: walk the list
             for (int off = 0; off < head_end + (n - tail_start); off += 64)
-                edge_samples<FMT, NT>(ring, capacity, ep, dphi, shift, step, lut, tid + off, head_end, tail_start, accr, acci);
+                edge_samples<FMT, NT>(ring, capacity, ep, dphi, shift, step, lut, edge_lane + off, head_end, tail_start, accr, acci);
         } else {
-            edge_samples<FMT, NT>(ring, capacity, ep, dphi, shift, step, lut, tid, head_end, tail_start, accr, acci);
+            edge_samples<FMT, NT>(ring, capacity, ep, dphi, shift, step, lut, edge_lane, head_end, tail_start, accr, acci);
         }
     }
 }
 
-// Workgroup reduction of 2*NT fp64 accumulators: wavefront shuffles (64 lanes), then the waves
-// through LDS in a fixed order -- deterministic, so results do not depend on GPU sharding.
-// red needs (THREADS/64)*2*NT doubles.  After the call threads 0..2*NT-1 hold the totals
+// Sum of x over the 64 lanes of the wave, returned to every lane: xor-butterfly inside each row of
+// 16 lanes with DPP moves (no LDS traffic, no address arithmetic), then the four row sums in a
+// fixed order through v_readlane.  The order never depends on the data: results are deterministic.
+__device__ __forceinline__ double wave_sum(double x) {
+    auto dpp_add = [](double v, auto ctrl) {
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), decltype(ctrl)::value, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), decltype(ctrl)::value, 0xf, 0xf, true);
+        return v + __hiloint2double(hi, lo);
+    };
+    x = dpp_add(x, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]: lane ^ 1
+    x = dpp_add(x, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]: lane ^ 2
+    x = dpp_add(x, std::integral_constant<int, 0x141>{});  // row_half_mirror: the other quad of the 8
+    x = dpp_add(x, std::integral_constant<int, 0x140>{});  // row_mirror: the other half of the 16
+    return ((lane_value(x, 0) + lane_value(x, 16)) + lane_value(x, 32)) + lane_value(x, 48);
+}
+
+// Workgroup reduction of 2*NT fp64 accumulators: wave sums, then the waves through LDS in a fixed
+// order.  red needs (THREADS/64)*2*NT doubles.  After the call threads 0..2*NT-1 hold the totals
 // (thread 2t: I_t, thread 2t+1: Q_t) in the return value.
 template <int NT, int THREADS>
 __device__ __forceinline__ double reduce_taps(const double* accr, const double* acci, double* red, int tid) {
     constexpr int kWaves = THREADS / 64;
     const int lane = tid & 63, wave = tid >> 6;
-    if (kWaves == 1) {
-        // one wave: lane 0 ends up with every total; deal them to lanes 0..2*NT-1 without LDS or barrier
-        double mine = 0.0;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            double a = accr[t], b = acci[t];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                a += __shfl_down(a, off, 64);
-                b += __shfl_down(b, off, 64);
-            }
-            const double ta = lane_value(a, 0), tb = lane_value(b, 0);
-            mine = lane == 2 * t ? ta : (lane == 2 * t + 1 ? tb : mine);
-        }
-        return mine;
-    }
+    double mine = 0.0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        double a = accr[t], b = acci[t];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            a += __shfl_down(a, off, 64);
-            b += __shfl_down(b, off, 64);
-        }
-        if (lane == 0) {
-            red[wave * 2 * NT + 2 * t] = a;
-            red[wave * 2 * NT + 2 * t + 1] = b;
-        }
+        const double ta = wave_sum(accr[t]), tb = wave_sum(acci[t]);
+        mine = lane == 2 * t ? ta : (lane == 2 * t + 1 ? tb : mine);
     }
+    if (kWaves == 1) return mine;  // one wave: lanes 0..2*NT-1 already hold the totals, no LDS, no barrier
+    if (lane < 2 * NT) red[wave * 2 * NT + lane] = mine;
     __syncthreads();
     double s = 0.0;
     if (tid < 2 * NT) {

@@ -111,6 +111,7 @@ int sdr_engine_create(int device_id, sdr_engine** out) {
     sdr_engine* e = new (std::nothrow) sdr_engine();
     if (!e) return sdr_fail(SDR_ERR_NOMEM, "host allocation failed");
     e->device = device_id;
+    e->n_cus = prop.multiProcessorCount;
     err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err != hipSuccess) {
         delete e;
@@ -131,7 +132,7 @@ void sdr_engine_destroy(sdr_engine* e) {
     for (auto ev : e->prof_pool) (void)hipEventDestroy(ev);
     DevBuf* bufs[] = {&e->ws_items,  &e->ws_out,   &e->ws_spacing, &e->pcps_fwd,   &e->pcps_a,
                       &e->pcps_b,    &e->pcps_code, &e->pcps_tw,   &e->pcps_map,   &e->pcps_csum,
-                      &e->pcps_part, &e->pcps_res,  &e->track_state, &e->track_cfg, &e->track_traj, &e->track_bits};
+                      &e->pcps_part, &e->pcps_res,  &e->track_state, &e->track_cfg, &e->track_traj, &e->track_bits, &e->track_xchg};
     for (DevBuf* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (e->iq) (void)hipFree(e->iq);

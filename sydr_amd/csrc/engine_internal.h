@@ -63,7 +63,9 @@ struct sdr_engine {
     // workspaces
     DevBuf ws_items, ws_out, ws_spacing;
     DevBuf pcps_fwd, pcps_a, pcps_b, pcps_code, pcps_tw, pcps_map, pcps_csum, pcps_part, pcps_res;
-    DevBuf track_state, track_cfg, track_traj, track_bits;
+    DevBuf track_state, track_cfg, track_traj, track_bits, track_xchg;
+    int n_cus = 0;              // compute units of the device (sizes the closed-loop clusters)
+    int track_force_parts = 0;  // diagnostics / tests: 0 = choose, else 1, 2, 4 or 8 workgroups per channel
     int64_t pcps_tw_n = 0;
     bool pcps_force_passes = false;  // diagnostics: use the one-kernel-per-radix-pass transform instead of the four-step one
 

@@ -66,14 +66,14 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
     ep.rem_code = it.rem_code;
     ep.code_step = it.code_step;
     EpochConsts<NT> K;
-    compute_constants<NT, kThreads>(K, ep, spacing + tap0, dphi);
+    compute_constants<NT>(K, ep, spacing + tap0, dphi, kThreads);
     __syncthreads();  // replica staged
 
     double accr[NT], acci[NT];
     if (WIDE && !epoch_wraps(ep, capacity))
-        correlate_epoch_wide<FMT, NT, kThreads>(ring, capacity, ep, dphi, K, lut, prefix, tid, accr, acci);
+        correlate_epoch_wide<FMT, NT, true>(ring, capacity, ep, dphi, K, lut, prefix, tid, tid, kThreads, tid, accr, acci);
     else
-        correlate_epoch<FMT, NT, kThreads>(ring, capacity, ep, dphi, K, lut, tid, accr, acci);
+        correlate_epoch<FMT, NT>(ring, capacity, ep, dphi, K, lut, tid, kThreads, tid, accr, acci);
     const double total = reduce_taps<NT, kThreads>(accr, acci, red, tid);
     if (tid < 2 * NT) out[(size_t)blockIdx.x * 2 * n_taps_total + 2 * tap0 + tid] = total;
 #ifdef SDR_TRACE_WG

@@ -1,20 +1,45 @@
-// On-device loop closure: one persistent 512-lane workgroup per channel runs
+// On-device loop closure: persistent workgroups run
 // correlate -> discriminators -> loop filters -> NCO update for n_epochs without leaving the
-// GPU.  The PRN replica stays in LDS for the whole run; the scalar loop
-// arithmetic runs on lane 0 in fp64, following the two reference plugins statement by statement:
+// GPU.  A channel is served by a CLUSTER of `parts` workgroups (1, 2, 4 or 8,
+// chosen so that the launch fills the GPU: 32 channels x 8 parts = 256 CUs): every epoch each part
+// correlates its share of the samples, publishes six partial sums through global memory, waits for
+// its peers' and adds all of them in the same fixed order -- so every part holds bit-identical
+// totals and runs the (cheap) scalar loop update redundantly; there is no second exchange.  The
+// PRN replica stays in LDS for the whole run; the scalar loop arithmetic runs on lane 0 in fp64,
+// following the two reference plugins statement by statement:
 //   kind 0  Borre  : channel_l1ca_borre.py:333-451  (DLL NNEML + Costas PLL, Borre filters, np.pi NCO)
 //   kind 1  Kaplan : channel_l1ca_kaplan.py:342-619 (FLL-assisted 2nd-order PLL, lock-state machine,
 //                    GPS-ICD pi in the NCO and the discriminators: SURVEY.md T3)
 // built on sydr/dsp/tracking.py:120-186,246-279 and sydr/dsp/lockindicator.py:6-122.
 #include "correlator.h"
 
+#ifdef SDR_TRACE_TRACK
+// Debug build only (tools/track_phases.py): per-phase clock totals of channel 0's epoch loop.
+__device__ unsigned long long g_track_phase[32];
+extern "C" int sdr_debug_track_phases(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_track_phase), sizeof(g_track_phase));
+}
+#define TRACK_MARK(k)                                                     \
+    do {                                                                  \
+        if (tid == 0 && ch == 0 && part == 0) {                           \
+            const unsigned long long now_ = wall_clock64();               \
+            g_track_phase[k] += now_ - mark_;                             \
+            mark_ = now_;                                                 \
+        }                                                                 \
+    } while (0)
+#else
+#define TRACK_MARK(k) ((void)0)
+#endif
+
 namespace {
 
 using namespace sdr;
 
-constexpr int kTrackThreads = 512;
-constexpr int kTrackWaves = kTrackThreads / 64;
 constexpr int kTaps = 3;
+constexpr int kMaxParts = 8;
+constexpr int red_doubles(int threads) { return (threads / 64) * 2 * kTaps > 64 ? (threads / 64) * 2 * kTaps : 64; }
+constexpr int kXchgWords = 16;             // 12 tagged half-values + padding: one 128-byte line per part and parity
+constexpr long kSpinLimit = 1L << 20;      // peer polls before a part gives up (about a second): never hang the GPU
 
 constexpr double kGpsPi = 3.1415926535898;  // sydr/utils/constants.py:4
 constexpr double kGpsTwoPi = kGpsPi * 2.0;
@@ -38,26 +63,9 @@ __device__ __forceinline__ double py_mod(double a, double b) {
 }
 __device__ __forceinline__ double np_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : (x == 0.0 ? 0.0 : x)); }
 
-__device__ __forceinline__ double dll_nneml(double ie, double qe, double il, double ql) {  // tracking.py:120-129
-    const double e = sqrt(ie * ie + qe * qe), l = sqrt(il * il + ql * ql);
-    return (e - l) / (e + l);
-}
-__device__ __forceinline__ double pll_costas(double ip, double qp) {  // tracking.py:133-142
-    return atan(qp / ip) / kGpsTwoPi;
-}
-__device__ __forceinline__ double fll_atan(double ip, double qp, double ipp, double qpp, double dt) {  // :156-176
-    double err = atan(qp / ip) - atan(qpp / ipp);
-    if (err != err) err = 0.0;
-    if (err >= kGpsHalfPi) err = err - kGpsPi;
-    else if (err <= -kGpsHalfPi) err = err + kGpsPi;
-    err = err / dt;
-    return err / kGpsTwoPi;
-}
-__device__ __forceinline__ double borre_filter(double x, double mem, double tau1, double tau2, double pdi) {  // :180-186
-    double out = tau2 / tau1 * (x - mem);
-    out += pdi / tau1 * x;
-    return out;
-}
+// The discriminators and filters of sydr/dsp/tracking.py -- DLL NNEML (:120-129), Costas PLL (:133-142),
+// FLL atan (:156-176), BorreLoopFilter (:180-186) -- are evaluated inside the kernel's loop update, their
+// divisions / square roots / arctangents spread over lanes (see there).
 
 struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind it is copied with 16-byte stores)
     EpochParams ep;
@@ -66,91 +74,246 @@ struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind 
     int stop;
     int epochs_done;
     int bits_this_run;
-    int pad_;
+    int fault;                 // a peer part never showed up: leave the epoch loop (reported to the host)
     sdr_track_state st;  // lane 0's working copy lives in LDS, not in 1024 x VGPRs
     sdr_loop_cfg cfg;
 };
 
-template <int FMT>
-__global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __restrict__ ring, int64_t capacity,
-                                                              sdr_track_state* __restrict__ states,
-                                                              const sdr_loop_cfg* __restrict__ cfg_ptr,
-                                                              int n_epochs, sdr_track_epoch* __restrict__ traj,
-                                                              int keep_traj, int8_t* __restrict__ nav_bits, int max_bits,
-                                                              int32_t* __restrict__ n_bits,
-                                                              const uint32_t* __restrict__ luts,
-                                                              int lut_words, int lut_stride, int use_prefix) {
+template <int FMT, int THREADS>
+__global__ __launch_bounds__(THREADS) void track_kernel(const void* __restrict__ ring, int64_t capacity,
+                                                        sdr_track_state* __restrict__ states,
+                                                        const sdr_loop_cfg* __restrict__ cfg_ptr,
+                                                        int n_epochs, sdr_track_epoch* __restrict__ traj,
+                                                        int keep_traj, int8_t* __restrict__ nav_bits, int max_bits,
+                                                        int32_t* __restrict__ n_bits,
+                                                        const uint32_t* __restrict__ luts,
+                                                        int lut_words, int lut_stride, int use_prefix,
+                                                        int n_ch, int parts, unsigned long long* xchg,
+                                                        int* __restrict__ fault) {
     extern __shared__ double smem[];
-    double* red = smem;                                   // kTrackWaves * 6
-    EpochShared* sh = reinterpret_cast<EpochShared*>(red + kTrackWaves * 2 * kTaps);
-    double2* prefix = reinterpret_cast<double2*>(sh + 1);  // kTrackThreads * kPrefixSlots, when the launcher found room
-    uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + (use_prefix ? kTrackThreads * kPrefixSlots : 0));
+    double* red = smem;                                   // kWaves * 6 wave sums; reused by the cluster exchange
+    EpochShared* sh = reinterpret_cast<EpochShared*>(red + red_doubles(THREADS));
+    double2* prefix = reinterpret_cast<double2*>(sh + 1);  // THREADS * kPrefixSlots, when the launcher found room
+    uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + (use_prefix ? THREADS * kPrefixSlots : 0));
 
     const int tid = threadIdx.x;
-    const int ch = blockIdx.x;
+    // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8): the parts of one channel are
+    // blockIdx-es with the same residue, so a cluster shares one XCD's L2 for its exchange lines.
+    int ch, part;
+    if (parts == 1 || gridDim.x % (8 * parts) != 0) {
+        ch = blockIdx.x / parts;
+        part = blockIdx.x % parts;
+    } else {
+        const int per_xcd = gridDim.x / 8;               // workgroups per XCD = channels per XCD * parts
+        const int xcd = blockIdx.x % 8, q = blockIdx.x / 8;
+        ch = xcd * (per_xcd / parts) + q / parts;
+        part = q % parts;
+    }
+    const int lane_global = part * THREADS + tid;          // index among the cluster's lanes
+    const int cluster_lanes = parts * THREADS;
+    const bool edge_wave = lane_global >= cluster_lanes - 64;
+    const int edge_lane = edge_wave ? lane_global - (cluster_lanes - 64) : -1;
     if (tid == 0) {
         sh->st = states[ch];
         sh->cfg = *cfg_ptr;
         sh->epochs_done = 0;
         sh->bits_this_run = 0;
+        sh->fault = 0;
     }
     const int slot = states[ch].code_slot;
-    stage_lut<kTrackThreads>(lut, luts + (size_t)slot * lut_stride, lut_words, tid);
+    stage_lut<THREADS>(lut, luts + (size_t)slot * lut_stride, lut_words, tid);
     const double fs = cfg_ptr->fs;
     sdr_track_state& st = sh->st;
     const sdr_loop_cfg& cfg = sh->cfg;
+    const bool writer = part == 0;                         // one part records trajectory, bits and the end state
 
-    for (int epoch = 0; epoch < n_epochs; ++epoch) {
-        if (tid == 0) {
-            const double* sp = st.spacing_sel ? cfg.spacing_narrow : cfg.spacing_wide;
-            double smin = sp[0], smax = sp[0];
-            for (int t = 1; t < kTaps; ++t) {
-                smin = fmin(smin, sp[t]);
-                smax = fmax(smax, sp[t]);
-            }
-            // The replica LUT and the ring bound what an epoch may touch; a loop that has run
-            // away (loss of lock) stops here instead of reading out of range.
-            const double lo = ceil(st.rem_code + smin);
-            const double hi = ceil(st.code_step * (double)st.n_samples + st.rem_code + smax);
-            const bool ok = st.n_samples > 0 && (int64_t)st.n_samples <= capacity && st.code_step > 0.0 &&
-                            lo >= -(double)SDR_LUT_PAD && hi <= (double)(lut_words - SDR_LUT_PAD - 2) &&
-                            st.carrier_hz == st.carrier_hz && fabs(st.carrier_hz) < 1e9 && st.current_sample >= 0;
-            sh->stop = ok ? 0 : 1;
-            sh->ep.start_sample = st.current_sample;
-            sh->ep.n = st.n_samples;
-            sh->ep.carrier_hz = st.carrier_hz;
-            sh->ep.rem_carrier = st.rem_carrier;
-            sh->ep.rem_code = st.rem_code;
-            sh->ep.code_step = st.code_step;
-            for (int t = 0; t < kTaps; ++t) sh->spacing[t] = sp[t];
-            sh->dphi = carrier_step(st.carrier_hz, fs);
+#ifdef SDR_TRACE_TRACK
+    unsigned long long mark_ = wall_clock64();
+    if (tid == 0 && ch == 0 && part == 0) for (int k = 0; k < 32; ++k) g_track_phase[k] = 0;
+    __syncthreads();
+#endif
+    // Lane 0 hands the next epoch's NCO parameters to the workgroup (from registers: the state struct in
+    // LDS is only touched at the start and the end of a loop update).
+    auto publish = [&](const sdr_track_state& s, const sdr_loop_cfg& c) {
+        const double* sp = s.spacing_sel ? c.spacing_narrow : c.spacing_wide;
+        double smin = sp[0], smax = sp[0];
+        for (int t = 1; t < kTaps; ++t) {
+            smin = fmin(smin, sp[t]);
+            smax = fmax(smax, sp[t]);
         }
+        // The replica LUT and the ring bound what an epoch may touch; a loop that has run
+        // away (loss of lock) stops here instead of reading out of range.
+        const double lo = ceil(s.rem_code + smin);
+        const double hi = ceil(s.code_step * (double)s.n_samples + s.rem_code + smax);
+        const bool ok = s.n_samples > 0 && (int64_t)s.n_samples <= capacity && s.code_step > 0.0 &&
+                        lo >= -(double)SDR_LUT_PAD && hi <= (double)(lut_words - SDR_LUT_PAD - 2) &&
+                        s.carrier_hz == s.carrier_hz && fabs(s.carrier_hz) < 1e9 && s.current_sample >= 0;
+        sh->stop = (ok && !sh->fault) ? 0 : 1;
+        sh->ep.start_sample = s.current_sample;
+        sh->ep.n = s.n_samples;
+        sh->ep.carrier_hz = s.carrier_hz;
+        sh->ep.rem_carrier = s.rem_carrier;
+        sh->ep.rem_code = s.rem_code;
+        sh->ep.code_step = s.code_step;
+        for (int t = 0; t < kTaps; ++t) sh->spacing[t] = sp[t];
+        sh->dphi = carrier_step(s.carrier_hz, fs);
+    };
+    if (tid == 0) {
+        const sdr_track_state s0 = states[ch];
+        const sdr_loop_cfg c0 = *cfg_ptr;
+        publish(s0, c0);
+    }
+    for (int epoch = 0; epoch < n_epochs; ++epoch) {
+        TRACK_MARK(5);
         __syncthreads();
+        TRACK_MARK(0);
+#ifdef SDR_TRACE_TRACK
+        const unsigned long long wave_mark_ = wall_clock64();
+#endif
         if (sh->stop) break;
         const EpochParams ep = sh->ep;
         const double dphi = sh->dphi;
         EpochConsts<kTaps> K;
-        compute_constants<kTaps, kTrackThreads>(K, ep, sh->spacing, dphi);
+        compute_constants<kTaps>(K, ep, sh->spacing, dphi, cluster_lanes);
+        TRACK_MARK(1);
 
         double accr[kTaps], acci[kTaps];
         if (use_prefix && ep.code_step <= kFastMaxCodeStep && ep.code_step >= kFastMinCodeStep && !epoch_wraps(ep, capacity))   // uniform branch: 16-sample boundary variant above ~17 MHz
-            correlate_epoch_wide<FMT, kTaps, kTrackThreads>(ring, capacity, ep, dphi, K, lut, prefix, tid, accr, acci);
+            correlate_epoch_wide<FMT, kTaps, false>(ring, capacity, ep, dphi, K, lut, prefix, tid, lane_global, cluster_lanes, edge_lane, accr, acci);
         else
-            correlate_epoch<FMT, kTaps, kTrackThreads>(ring, capacity, ep, dphi, K, lut, tid, accr, acci);
-        const double total = reduce_taps<kTaps, kTrackThreads>(accr, acci, red, tid);
+            correlate_epoch<FMT, kTaps>(ring, capacity, ep, dphi, K, lut, lane_global, cluster_lanes, edge_lane, accr, acci);
+#ifdef SDR_TRACE_TRACK
+        if ((tid & 63) == 0 && ch == 0) g_track_phase[8 + part * (THREADS / 64) + (tid >> 6)] += wall_clock64() - wave_mark_;
+#endif
+        TRACK_MARK(2);
+        double total = reduce_taps<kTaps, THREADS>(accr, acci, red, tid);
+        TRACK_MARK(3);
 
-        // lanes 0..5 of wave 0 hold [IE,QE,IP,QP,IL,QL]; hand them to lane 0 without a barrier
-        double corr[2 * kTaps];
-        if (tid < 64) {
+        // Cluster exchange (wave 0): publish this part's six sums, collect the peers', add all parts in
+        // part order.  No fences, no separate flag: every 64-bit word carries half a double and the epoch
+        // tag (epoch+1), is written and read whole, and validates itself (the "LL" idea of collective
+        // libraries) -- an agent-scope release/acquire pair would write back and invalidate the whole L2
+        // every epoch (measured: 2.9 us); a relaxed device-scope word costs ~0.4 us one way
+        // (tools/ubench_xchg.hip), on the same XCD or across XCDs.
+        // Lines are double-buffered by epoch parity: a part can run at most one exchange ahead of a peer.
+        if (parts > 1 && tid < 64) {
+            unsigned long long* lines = xchg + ((size_t)ch * 2 + (epoch & 1)) * kMaxParts * kXchgWords;
+            const unsigned long long tag = (unsigned long long)(unsigned)(epoch + 1) << 32;
+            if (tid < 4 * kTaps) {  // lane 2v+h publishes half h of value v (lanes 0..5 hold the values)
+                const double v = __shfl(total, tid >> 1, 64);
+                const unsigned half = (tid & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+                __hip_atomic_store(lines + part * kXchgWords + tid, tag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // lane l polls word l%16 of parts l/16 and l/16+4 (words 12..15 of a line are padding)
+            const int k = tid & 15, p0 = tid >> 4, p1 = p0 + 4;
+            const bool want0 = k < 4 * kTaps && p0 < parts, want1 = k < 4 * kTaps && p1 < parts;
+            const unsigned long long* a0 = lines + (want0 ? p0 : part) * kXchgWords + (want0 ? k : 0);
+            const unsigned long long* a1 = lines + (want1 ? p1 : part) * kXchgWords + (want1 ? k : 0);
+            unsigned long long w0 = 0, w1 = 0;
+            bool done = false;
+            for (long spins = 0; spins < kSpinLimit; ++spins) {
+                w0 = __hip_atomic_load(a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w1 = __hip_atomic_load(a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = (!want0 || (w0 >> 32 << 32) == tag) && (!want1 || (w1 >> 32 << 32) == tag);
+                if (__all(ok)) {
+                    done = true;
+                    break;
+                }
+            }
+            if (!done) {
+                if (tid == 0) {
+                    sh->fault = 1;
+                    sh->stop = 1;
+                    *fault = 1;
+                }
+            } else {
+                unsigned* halves = reinterpret_cast<unsigned*>(red);  // (the wave sums in `red` have been consumed)
+                halves[tid] = (unsigned)w0;            // [p*16 + k], p < 4
+                halves[64 + tid] = (unsigned)w1;       // p >= 4
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (LDS serves a wave's operations in order)
+                __builtin_amdgcn_wave_barrier();
+                if (tid < 2 * kTaps) {
+                    double sum = 0.0;
+                    for (int p = 0; p < parts; ++p)
+                        sum += __hiloint2double((int)halves[p * 16 + 2 * tid + 1], (int)halves[p * 16 + 2 * tid]);
+                    total = sum;
+                }
+            }
+        }
+        TRACK_MARK(6);
+
+        // Loop update, wave 0.  Lanes 0..5 hold [IE,QE,IP,QP,IL,QL]; every lane of the wave gets all six.
+        // The update is scalar arithmetic whose cost is the LATENCY of ~15 fp64 divisions, two square
+        // roots and two arctangents.  The ones that depend only on the correlator outputs and the old
+        // state are evaluated side by side, one per lane, in a single pass each (same IEEE operations on
+        // the same operands as the reference's statements, so the results are bit-identical to doing them
+        // one after the other); lane 0 then runs what is left of the reference's sequence.
+        if (tid < 64 && !sh->fault) {
+            double corr[2 * kTaps];
 #pragma unroll
             for (int k = 0; k < 2 * kTaps; ++k) corr[k] = __shfl(total, k, 64);
-        }
-
-        if (tid == 0) {
             const double ie = corr[0], qe = corr[1], ip = corr[2], qp = corr[3], il = corr[4], ql = corr[5];
             const int n = st.n_samples;
-            // keep_traj = 0: one record per channel, overwritten every epoch (nobody reads it)
-            sdr_track_epoch& rec = traj[keep_traj ? (size_t)ch * n_epochs + epoch : (size_t)ch];
+            const bool kaplan = cfg.loop_kind != 0;
+            const double ipp = st.i_prompt_prev, qpp = st.q_prompt_prev;
+
+            // pass 1: square roots (lane 2: early, lane 3: late envelope; tracking.py:120-129)
+            const double env = sqrt(tid == 3 ? il * il + ql * ql : ie * ie + qe * qe);
+            const double env_e = lane_value(env, 2), env_l = lane_value(env, 3);
+            // pass 2: one division per lane
+            const double pw = ip * ip + qp * qp;
+            double num = 0.0, den = 1.0;
+            switch (tid) {
+                case 0: num = qp, den = ip; break;                                   // atan(qP/iP): Costas PLL, FLL
+                case 1: num = qpp, den = ipp; break;                                 // atan(qP'/iP'): FLL (tracking.py:156-176)
+                case 2: num = env_e - env_l, den = env_e + env_l; break;             // DLL NNEML
+                case 3: {                                                            // FLL lock (lockindicator.py)
+                    double v = ip * ipp - qp * qpp;
+                    v *= np_sign(ip * ipp + qp * qpp);
+                    num = v, den = pw;
+                    break;
+                }
+                case 4: num = ip * ip - qp * qp, den = pw; break;                    // PLL lock
+                case 5: {                                                            // C/N0 (Beaulieu) ratio term
+                    const double d = fabs(ip) - fabs(qp);
+                    num = pw, den = d * d;
+                    break;
+                }
+                case 6: num = st.fll_bw, den = kW0Bw1; break;
+                case 7: num = st.pll_bw, den = kW0Bw2; break;
+                case 8: num = cfg.dll_tau2, den = cfg.dll_tau1; break;               // BorreLoopFilter (tracking.py:180-186)
+                case 9: num = kaplan ? cfg.dll_pdi * 1.0 : cfg.dll_pdi, den = cfg.dll_tau1; break;
+                case 10:                                                             // carrier NCO advance over the epoch
+                    num = kaplan ? st.carrier_hz * kGpsTwoPi * (double)n : st.carrier_hz * 2.0 * M_PI * (double)n;
+                    den = fs;
+                    break;
+                case 11: num = cfg.pll_tau2, den = cfg.pll_tau1; break;              // (Borre PLL filter)
+                case 12: num = cfg.pll_pdi, den = cfg.pll_tau1; break;
+                default: break;
+            }
+            const double quot = num / den;
+            // pass 3: arctangents (lanes 0, 1)
+            const double at = atan(quot);
+            const double at_now = lane_value(at, 0), at_prev = lane_value(at, 1);
+            double fll_err = at_now - at_prev;
+            if (fll_err != fll_err) fll_err = 0.0;
+            if (fll_err >= kGpsHalfPi) fll_err = fll_err - kGpsPi;
+            else if (fll_err <= -kGpsHalfPi) fll_err = fll_err + kGpsPi;
+            // pass 4: lane 0: atan/2pi (pll_costas), lane 1: err/dt;  pass 5: lane 1: (err/dt)/2pi (fll_atan)
+            const double q4 = (tid == 1 ? fll_err : at_now) / (tid == 1 ? 1e-3 : kGpsTwoPi);
+            const double q5 = q4 / kGpsTwoPi;
+            const double costas = lane_value(q4, 0), fll_full = lane_value(q5, 1);
+            const double dll_nn = lane_value(quot, 2), fll_lock_v = lane_value(quot, 3), pll_lock_v = lane_value(quot, 4);
+            const double cn0_term = lane_value(quot, 5), w0f = lane_value(quot, 6), w0p = lane_value(quot, 7);
+            const double dll_r1 = lane_value(quot, 8), dll_r2 = lane_value(quot, 9), carrier_adv = lane_value(quot, 10);
+            const double pll_r1 = lane_value(quot, 11), pll_r2 = lane_value(quot, 12);
+
+          if (tid == 0) {
+            // Work on register copies: through references the compiler has to assume that the record and the
+            // state alias, and every statement becomes a dependent LDS round trip (measured: 2.7 us of them).
+            sdr_track_state st = sh->st;
+            const sdr_loop_cfg cfg = sh->cfg;
+            sdr_track_epoch rec;
             rec.start_sample = st.current_sample;
             rec.n_samples = n;
             rec.carrier_hz_in = st.carrier_hz;
@@ -160,15 +323,17 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
             for (int k = 0; k < 2 * SDR_MAX_TAPS; ++k) rec.corr[k] = k < 2 * kTaps ? corr[k] : 0.0;
             rec.nav_bit = -1;
 
-            if (cfg.loop_kind == 0) {
+            if (!kaplan) {
                 // ---- Borre: channel_l1ca_borre.py:364-429
-                st.rem_carrier -= st.carrier_hz * 2.0 * M_PI * (double)n / fs;
+                st.rem_carrier -= carrier_adv;
                 st.rem_carrier = py_mod(st.rem_carrier, 2.0 * M_PI);
-                const double code_err = dll_nneml(ie, qe, il, ql);
-                const double nco_code = borre_filter(code_err, st.dll_mem, cfg.dll_tau1, cfg.dll_tau2, cfg.dll_pdi);
+                const double code_err = dll_nn;
+                double nco_code = dll_r1 * (code_err - st.dll_mem);
+                nco_code += dll_r2 * code_err;
                 st.dll_mem = code_err;
-                const double phase_err = pll_costas(ip, qp);
-                const double nco_carrier = borre_filter(phase_err, st.pll_mem, cfg.pll_tau1, cfg.pll_tau2, cfg.pll_pdi);
+                const double phase_err = costas;
+                double nco_carrier = pll_r1 * (phase_err - st.pll_mem);
+                nco_carrier += pll_r2 * phase_err;
                 st.pll_mem = phase_err;
                 // bit sync: first prompt sign flip after MIN_CONVERGENCE_TIME = 100 epochs (borre:384-391)
                 if (!(st.track_flags & FLAG_BIT_SYNC) && (st.track_flags & FLAG_CODE_LOCK) && st.code_counter > 100 &&
@@ -197,36 +362,28 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
                 if (st.accum_counter == kMsPerBit) st.accum_counter = 0;
                 st.accum_counter += 1;
                 // runDiscriminators (:405-430)
-                double fll_d = 0.0, pll_d = 0.0, dll_d;
+                double fll_d = 0.0, pll_d = 0.0;
+                const double dll_d = dll_nn;
                 if (st.lock_state == LOCK_PULL_IN) {
-                    if (st.code_counter > 1) fll_d = fll_atan(ip, qp, st.i_prompt_prev, st.q_prompt_prev, 1e-3);
-                    dll_d = dll_nneml(ie, qe, il, ql);
+                    if (st.code_counter > 1) fll_d = fll_full;
                 } else {
-                    fll_d = fll_atan(ip, qp, st.i_prompt_prev, st.q_prompt_prev, 1e-3);
-                    pll_d = pll_costas(ip, qp);
-                    dll_d = dll_nneml(ie, qe, il, ql);
+                    fll_d = fll_full;
+                    pll_d = costas;
                 }
                 // FLLassistedPLL_2ndOrder (tracking.py:246-279) via runCarrierFrequencyFilter (:434-447)
-                const double w0f = st.fll_bw / kW0Bw1, w0p = st.pll_bw / kW0Bw2;
                 const double upd = (pll_d * (w0p * w0p) + fll_d * w0f) * 1e-3;
                 double carrier_err = upd + st.pll_mem;
                 st.pll_mem = upd;
                 carrier_err += pll_d * kW0A2 * w0p;
                 // BorreLoopFilter via runCodeFrequencyFilter (:451-461)
-                const double code_err = borre_filter(dll_d, st.dll_mem, cfg.dll_tau1, cfg.dll_tau2, cfg.dll_pdi * 1.0);
+                double code_err = dll_r1 * (dll_d - st.dll_mem);
+                code_err += dll_r2 * dll_d;
                 // runLoopIndicators (:465-502)
                 if (st.code_counter != 0) {
-                    double v = ip * st.i_prompt_prev - qp * st.q_prompt_prev;
-                    v *= np_sign(ip * st.i_prompt_prev + qp * st.q_prompt_prev);
-                    v /= (ip * ip + qp * qp);
-                    v = fabs(v);
+                    const double v = fabs(fll_lock_v);
                     st.fll_lock = (1.0 - 0.005) * st.fll_lock + 0.005 * v;
-                    if (st.lock_state > LOCK_PULL_IN) {
-                        const double nbd = ip * ip - qp * qp, nbp = ip * ip + qp * qp;
-                        st.pll_lock = (1.0 - 0.005) * st.pll_lock + 0.005 * (nbd / nbp);
-                    }
-                    const double d = fabs(ip) - fabs(qp);
-                    st.cn0_ratio_acc += (ip * ip + qp * qp) / (d * d);
+                    if (st.lock_state > LOCK_PULL_IN) st.pll_lock = (1.0 - 0.005) * st.pll_lock + 0.005 * pll_lock_v;
+                    st.cn0_ratio_acc += cn0_term;
                     if (st.accum_counter == kMsPerBit) {
                         const double lam = 1.0 / (st.cn0_ratio_acc / (double)st.accum_counter);
                         const double c = lam * (1.0 / ((double)st.accum_counter * 1e-3));
@@ -237,7 +394,7 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
                 // postTrackingUpdate (:506-534)
                 st.code_counter += 1;
                 st.dll_mem = dll_d;
-                st.rem_carrier -= st.carrier_hz * kGpsTwoPi * (double)n / fs;
+                st.rem_carrier -= carrier_adv;
                 st.rem_carrier = py_mod(st.rem_carrier, kGpsTwoPi);
                 st.code_hz -= code_err;
                 st.carrier_hz += carrier_err;
@@ -299,7 +456,7 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
                 if (st.nav_sum_counter == kMsPerBit) {
                     const int bit = st.nav_prompt_sum > 0.0 ? 1 : 0;
                     rec.nav_bit = bit;
-                    if (nav_bits && sh->bits_this_run < max_bits) nav_bits[(size_t)ch * max_bits + sh->bits_this_run] = (int8_t)bit;
+                    if (writer && nav_bits && sh->bits_this_run < max_bits) nav_bits[(size_t)ch * max_bits + sh->bits_this_run] = (int8_t)bit;
                     sh->bits_this_run += 1;
                     st.nav_bits_emitted += 1;
                     st.nav_prompt_sum = 0.0;
@@ -311,10 +468,16 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
             rec.lock_state = st.lock_state;
             rec.track_flags = st.track_flags;
             sh->epochs_done = epoch + 1;
+            publish(st, cfg);
+            sh->st = st;
+            // keep_traj = 0: one record per channel, overwritten every epoch (nobody reads it)
+            if (writer) traj[keep_traj ? (size_t)ch * n_epochs + epoch : (size_t)ch] = rec;
+          }
         }
+        TRACK_MARK(4);
         // the next iteration's first barrier orders lane 0's LDS writes against everyone's reads
     }
-    if (tid == 0) {
+    if (tid == 0 && writer) {
         const int epochs_done = sh->epochs_done;
         if (epochs_done < n_epochs) {
             st.n_samples = -1 - epochs_done;  // stopped early: -(1 + epochs completed)
@@ -329,6 +492,14 @@ __global__ __launch_bounds__(kTrackThreads) void track_kernel(const void* __rest
 }  // namespace
 
 extern "C" {
+
+int sdr_track_cluster(sdr_engine* e, int parts) {
+    if (!e) return sdr_fail(SDR_ERR_INVALID, "null engine");
+    if (parts != 0 && parts != 1 && parts != 2 && parts != 4 && parts != 8)
+        return sdr_fail(SDR_ERR_INVALID, "cluster size %d: must be 0 (automatic), 1, 2, 4 or 8", parts);
+    e->track_force_parts = parts;
+    return SDR_OK;
+}
 
 int sdr_track_closed_loop(sdr_engine* e, int n_ch, sdr_track_state* st, const sdr_loop_cfg* cfg, int n_epochs,
                           sdr_track_epoch* traj) {
@@ -368,34 +539,68 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
     SDR_HIP(hipMemcpyAsync(e->track_cfg.ptr, cfg, sizeof(sdr_loop_cfg), hipMemcpyHostToDevice, e->stream));
     (void)maxlen;
     const int lut_words = e->lut_stride;  // the whole staged row (every code period the slots were sized for)
-    const size_t shmem_base = (size_t)(kTrackWaves * 2 * kTaps) * sizeof(double) + sizeof(EpochShared) +
+    // Cluster size: as many workgroups per channel as the GPU has room for (1 per CU), up to 8.
+    int parts = 1;
+    if (e->track_force_parts) {
+        parts = e->track_force_parts;
+    } else {
+        while (parts < kMaxParts && (long)n_ch * parts * 2 <= (long)e->n_cus) parts *= 2;
+    }
+    const int threads = parts >= 2 ? 256 : 512;
+    const size_t shmem_base = (size_t)red_doubles(threads) * sizeof(double) + sizeof(EpochShared) +
                               (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
-    const size_t prefix_bytes = (size_t)kTrackThreads * kPrefixSlots * sizeof(double2);
-    // The boundary variant of the correlator needs a 272-byte LDS strip per lane; long multi-period
+    const size_t prefix_bytes = (size_t)threads * kPrefixSlots * sizeof(double2);
+    // The boundary variant of the correlator needs a 144-byte LDS strip per lane; long multi-period
     // replicas that leave no room for it are tracked with the per-sample variant.
     const int use_prefix = shmem_base + prefix_bytes <= 160u * 1024u && e->lut_stride < kFastMaxLutWords ? 1 : 0;
     const size_t shmem = shmem_base + (use_prefix ? prefix_bytes : 0);
     sdr_track_state* d_st = (sdr_track_state*)e->track_state.ptr;
     const sdr_loop_cfg* d_cfg = (const sdr_loop_cfg*)e->track_cfg.ptr;
     sdr_track_epoch* d_traj = (sdr_track_epoch*)e->track_traj.ptr;
-    const int keep = traj ? 1 : 0;
+    int keep = traj ? 1 : 0;
     if (shmem > 160u * 1024u) return sdr_fail(SDR_ERR_RANGE, "closed-loop tracking: code table does not fit the LDS");
+    // exchange lines [n_ch][2 parities][8 parts][16 words] (tags zeroed: epoch tags start at 1), then the fault word
+    const size_t xchg_bytes = (size_t)n_ch * 2 * kMaxParts * kXchgWords * sizeof(unsigned long long);
+    if (int rc2 = sdr_devbuf_reserve(e, &e->track_xchg, xchg_bytes + 16)) return rc2;
+    SDR_HIP(hipMemsetAsync(e->track_xchg.ptr, 0, xchg_bytes + 16, e->stream));
+    unsigned long long* d_xchg = (unsigned long long*)e->track_xchg.ptr;
+    int* d_fault = (int*)((char*)e->track_xchg.ptr + xchg_bytes);
+    const void* d_iq = e->iq;
+    int64_t cap = e->iq_capacity;
+    const uint32_t* d_luts = e->luts;
+    int lw = lut_words, ls = e->lut_stride, up = use_prefix, nch = n_ch, n_ep = n_epochs, mb = max_bits;
+    hipError_t launch_err = hipSuccess;
     {
         ProfScope ps(e, "track_kernel");
         auto launch = [&](auto kernel) {
             // more than 64 KB of dynamic LDS has to be granted per kernel
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-            hipLaunchKernelGGL(kernel, dim3(n_ch), dim3(kTrackThreads), shmem, e->stream, e->iq, e->iq_capacity, d_st,
-                               d_cfg, n_epochs, d_traj, keep, d_bits, max_bits, d_nbits, e->luts, lut_words,
-                               e->lut_stride, use_prefix);
+            void* args[] = {&d_iq, &cap, &d_st, &d_cfg, &n_ep, &d_traj, &keep, &d_bits, &mb, &d_nbits, &d_luts,
+                            &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault};
+            if (parts > 1)  // the parts of a cluster wait for each other: all workgroups must be resident
+                launch_err = hipLaunchCooperativeKernel((const void*)kernel, dim3(n_ch * parts), dim3(threads), args,
+                                                        (unsigned)shmem, e->stream);
+            else
+                launch_err = hipLaunchKernel((const void*)kernel, dim3(n_ch), dim3(threads), args, shmem, e->stream);
+        };
+        auto by_threads = [&](auto fmt) {
+            constexpr int F = decltype(fmt)::value;
+            if (threads == 128) launch(track_kernel<F, 128>);
+            else if (threads == 256) launch(track_kernel<F, 256>);
+            else launch(track_kernel<F, 512>);
         };
         switch (e->iq_fmt) {
-            case SDR_FMT_CI8: launch(track_kernel<SDR_FMT_CI8>); break;
-            case SDR_FMT_CI16: launch(track_kernel<SDR_FMT_CI16>); break;
-            case SDR_FMT_CF32: launch(track_kernel<SDR_FMT_CF32>); break;
-            default: launch(track_kernel<SDR_FMT_CF64>); break;
+            case SDR_FMT_CI8: by_threads(std::integral_constant<int, SDR_FMT_CI8>{}); break;
+            case SDR_FMT_CI16: by_threads(std::integral_constant<int, SDR_FMT_CI16>{}); break;
+            case SDR_FMT_CF32: by_threads(std::integral_constant<int, SDR_FMT_CF32>{}); break;
+            default: by_threads(std::integral_constant<int, SDR_FMT_CF64>{}); break;
         }
     }
+    if (launch_err != hipSuccess)
+        return sdr_fail(SDR_ERR_HIP, "closed-loop tracking launch (%d channels x %d parts) failed: %s", n_ch, parts,
+                        hipGetErrorString(launch_err));
+    int fault_host = 0;
+    SDR_HIP(hipMemcpyAsync(&fault_host, d_fault, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     SDR_HIP(hipGetLastError());
     SDR_HIP(hipMemcpyAsync(st, e->track_state.ptr, (size_t)n_ch * sizeof(sdr_track_state), hipMemcpyDeviceToHost, e->stream));
     if (traj) SDR_HIP(hipMemcpyAsync(traj, e->track_traj.ptr, traj_bytes, hipMemcpyDeviceToHost, e->stream));
@@ -404,6 +609,8 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
         SDR_HIP(hipMemcpyAsync(n_bits, d_nbits, (size_t)n_ch * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     }
     SDR_HIP(hipStreamSynchronize(e->stream));
+    if (fault_host)
+        return sdr_fail(SDR_ERR_HIP, "closed-loop tracking: a workgroup of a %d-part cluster never published its sums", parts);
     for (int c = 0; c < n_ch; ++c)
         if (st[c].n_samples < 0)
             return sdr_fail(SDR_ERR_RANGE, "channel %d stopped after %d epochs: NCO state left the staged replica / ring",

@@ -226,6 +226,10 @@ class Engine:
         return [pb.value, pc.value], pr.value
 
     # ------------------------------------------------------------------ closed loop
+    def track_cluster(self, parts: int = 0):
+        """Workgroups cooperating on one channel in `track_closed_loop` (0 = fill the GPU; 1, 2, 4, 8)."""
+        check(self._lib.sdr_track_cluster(self._h, int(parts)))
+
     def track_closed_loop(self, states, cfg: LoopCfg, n_epochs: int, want_traj=True, want_bits=False):
         """Returns (end states, trajectory or None[, list of per-channel nav-bit arrays])."""
         n_ch = len(states)

@@ -65,8 +65,18 @@ CASES = {"borre": ("g6_trajectories.npz", 0), "kaplan": ("g6_trajectories.npz", 
          "kaplan_strong": ("g6b_kaplan_strong.npz", 1)}
 
 
+@pytest.mark.parametrize("parts", [0, 1, 2, 4, 8])
 @pytest.mark.parametrize("case", list(CASES))
-def test_closed_loop_kernel_matches_reference_trajectory(engine, case):
+def test_closed_loop_kernel_matches_reference_trajectory(engine, case, parts):
+    """parts = workgroups cooperating on the channel (0: the library fills the GPU, i.e. 8 for one channel)."""
+    engine.track_cluster(parts)
+    try:
+        _check_closed_loop_against_reference(engine, case)
+    finally:
+        engine.track_cluster(0)
+
+
+def _check_closed_loop_against_reference(engine, case):
     fname, kind = CASES[case]
     g, fs, raw = trajectory_iq(fname)
     plugin = "borre" if kind == 0 else "kaplan"

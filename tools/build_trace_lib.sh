@@ -1,0 +1,12 @@
+#!/bin/bash
+# Builds the debug variant of the library (per-workgroup / per-phase clocks) into tools/libsydr_trace.so
+# without touching the product build.  On the GPU box:  cp tools/libsydr_trace.so sydr_amd/libsydr_amd.so
+set -e
+cd "$(dirname "$0")/../sydr_amd/csrc"
+mkdir -p /tmp/sdr_trace_build
+for f in engine codes epl pcps track; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DSDR_TRACE_WG -DSDR_TRACE_TRACK -I../../include -c $f.hip -o /tmp/sdr_trace_build/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 /tmp/sdr_trace_build/*.o -o ../../tools/libsydr_trace.so
+echo built tools/libsydr_trace.so

@@ -17,10 +17,10 @@ repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    for key in ("epl_kernel", "track_kernel", "fft_pass_kernel", "argmax_part", "peak_finish", "synth_kernel"):
+    for key in ("epl_kernel", "track_kernel", "fft4_rows_kernel", "fft4_cols_kernel", "fft_pass_kernel", "argmax_part", "peak_finish", "synth_kernel"):
         if key in name:
             return key + ("<inv>" if key == "fft_pass_kernel" and ", true," in name else "")
-    return name.split("(")[0][:40]
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]
 
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

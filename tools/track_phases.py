@@ -1,0 +1,26 @@
+"""Debug: where an epoch of the closed-loop kernel spends its time (needs a -DSDR_TRACE_TRACK build)."""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import sydr_amd._lib as L
+from sydr_amd.engine import FMT_CI8, Engine
+eng = Engine(0)
+total = int(3.0 * bench.FS) // 8 * 8
+eng.iq_alloc(total, FMT_CI8)
+eng.code_slots(bench.N_CH)
+sats = bench.satellites(0)
+for s, sat in enumerate(sats):
+    eng.load_gps_code(s, sat["prn"])
+eng.iq_synth(sats, bench.FS, 12.0, 20260003, 0, total)
+items, n_epochs = bench.truth_items(sats, bench.FS, total)
+print(bench.closed_loop_leg(eng, items, 2000))
+buf = np.zeros(32, dtype=np.uint64)
+lib = L.load()
+lib.sdr_debug_track_phases.argtypes = [ctypes.c_void_p]
+assert lib.sdr_debug_track_phases(buf.ctypes.data) == 0
+names = ["params+barrier", "constants", "correlate", "reduce", "scalar loop", "loop top", "exchange"]
+tot = float(buf[:7].sum())
+for n, v in zip(names, buf[:7]):
+    print(f"{n:16s} {float(v)*10/1e3/2000:8.2f} us/epoch  {100.0*float(v)/tot:5.1f} %")
+print("per-wave arrival at the reduction (us after the epoch's first barrier):", " ".join(f"{float(v)*10/1e3/2000:.2f}" for v in buf[8:24]))
