@@ -585,21 +585,27 @@ __global__ __launch_bounds__(kThreads) void fft4_rows_kernel(const PassArgs a, i
     }
 }
 
+template <bool INV, int LOAD0, int STORE_LAST, int FMT, int TA, int TB>
+void run_four_step_t(sdr_engine* e, const FourStep& f, PassArgs a, int batch, double2* Z, double2* final_out) {
+    a.out = final_out;
+    const size_t shA = (size_t)(2 * f.N1 * (TA + 1) + f.N1) * sizeof(double2);
+    const size_t shB = (size_t)(2 * f.N2 * (TB + 1) + f.N2) * sizeof(double2);
+    // more than 64 KiB of dynamic LDS has to be requested explicitly (160 KiB per CU on MI355X)
+    (void)hipFuncSetAttribute((const void*)fft4_cols_kernel<INV, LOAD0, FMT, TA>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shA);
+    (void)hipFuncSetAttribute((const void*)fft4_rows_kernel<INV, STORE_LAST, TB>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shB);
+    hipLaunchKernelGGL((fft4_cols_kernel<INV, LOAD0, FMT, TA>), dim3((f.N2 + TA - 1) / TA, batch), dim3(kThreads), shA,
+                       e->stream, a, f.N1, f.N2, f.rad1, Z);
+    hipLaunchKernelGGL((fft4_rows_kernel<INV, STORE_LAST, TB>), dim3((f.N1 + TB - 1) / TB, batch), dim3(kThreads), shB,
+                       e->stream, a, f.N1, f.N2, f.rad2, Z);
+}
+
+// Tile widths: 8 columns for kernel A (128-byte runs), 4 rows for kernel B -- its LDS footprint is the larger
+// one (N2 >= N1) and halving it (5 instead of 2 workgroups per CU at N = 25000) measured 9 % faster than 8.
 template <bool INV, int LOAD0, int STORE_LAST, int FMT>
 void run_four_step(sdr_engine* e, const FourStep& f, PassArgs a, int batch, double2* Z, double2* final_out) {
-    a.out = final_out;
-    constexpr int T = 8;
-    const size_t shA = (size_t)(2 * f.N1 * (T + 1) + f.N1) * sizeof(double2);
-    const size_t shB = (size_t)(2 * f.N2 * (T + 1) + f.N2) * sizeof(double2);
-    // more than 64 KiB of dynamic LDS has to be requested explicitly (160 KiB per CU on MI355X)
-    (void)hipFuncSetAttribute((const void*)fft4_cols_kernel<INV, LOAD0, FMT, T>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shA);
-    (void)hipFuncSetAttribute((const void*)fft4_rows_kernel<INV, STORE_LAST, T>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shB);
-    hipLaunchKernelGGL((fft4_cols_kernel<INV, LOAD0, FMT, T>), dim3((f.N2 + T - 1) / T, batch), dim3(kThreads), shA,
-                       e->stream, a, f.N1, f.N2, f.rad1, Z);
-    hipLaunchKernelGGL((fft4_rows_kernel<INV, STORE_LAST, T>), dim3((f.N1 + T - 1) / T, batch), dim3(kThreads), shB,
-                       e->stream, a, f.N1, f.N2, f.rad2, Z);
+    run_four_step_t<INV, LOAD0, STORE_LAST, FMT, 8, 4>(e, f, a, batch, Z, final_out);
 }
 
 // Runs all passes of one batched transform.  `first` carries the fused load of

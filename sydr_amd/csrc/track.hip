@@ -539,26 +539,10 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
     SDR_HIP(hipMemcpyAsync(e->track_cfg.ptr, cfg, sizeof(sdr_loop_cfg), hipMemcpyHostToDevice, e->stream));
     (void)maxlen;
     const int lut_words = e->lut_stride;  // the whole staged row (every code period the slots were sized for)
-    // Cluster size: as many workgroups per channel as the GPU has room for (1 per CU), up to 8.
-    int parts = 1;
-    if (e->track_force_parts) {
-        parts = e->track_force_parts;
-    } else {
-        while (parts < kMaxParts && (long)n_ch * parts * 2 <= (long)e->n_cus) parts *= 2;
-    }
-    const int threads = parts >= 2 ? 256 : 512;
-    const size_t shmem_base = (size_t)red_doubles(threads) * sizeof(double) + sizeof(EpochShared) +
-                              (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
-    const size_t prefix_bytes = (size_t)threads * kPrefixSlots * sizeof(double2);
-    // The boundary variant of the correlator needs a 144-byte LDS strip per lane; long multi-period
-    // replicas that leave no room for it are tracked with the per-sample variant.
-    const int use_prefix = shmem_base + prefix_bytes <= 160u * 1024u && e->lut_stride < kFastMaxLutWords ? 1 : 0;
-    const size_t shmem = shmem_base + (use_prefix ? prefix_bytes : 0);
     sdr_track_state* d_st = (sdr_track_state*)e->track_state.ptr;
     const sdr_loop_cfg* d_cfg = (const sdr_loop_cfg*)e->track_cfg.ptr;
     sdr_track_epoch* d_traj = (sdr_track_epoch*)e->track_traj.ptr;
     int keep = traj ? 1 : 0;
-    if (shmem > 160u * 1024u) return sdr_fail(SDR_ERR_RANGE, "closed-loop tracking: code table does not fit the LDS");
     // exchange lines [n_ch][2 parities][8 parts][16 words] (tags zeroed: epoch tags start at 1), then the fault word
     const size_t xchg_bytes = (size_t)n_ch * 2 * kMaxParts * kXchgWords * sizeof(unsigned long long);
     if (int rc2 = sdr_devbuf_reserve(e, &e->track_xchg, xchg_bytes + 16)) return rc2;
@@ -568,25 +552,35 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
     const void* d_iq = e->iq;
     int64_t cap = e->iq_capacity;
     const uint32_t* d_luts = e->luts;
-    int lw = lut_words, ls = e->lut_stride, up = use_prefix, nch = n_ch, n_ep = n_epochs, mb = max_bits;
-    hipError_t launch_err = hipSuccess;
-    {
-        ProfScope ps(e, "track_kernel");
+    int lw = lut_words, ls = e->lut_stride, nch = n_ch, n_ep = n_epochs, mb = max_bits;
+
+    // One attempt with `parts` workgroups per channel.
+    auto attempt = [&](int parts, bool* too_big) -> hipError_t {
+        const int threads = parts >= 2 ? 256 : 512;
+        const size_t shmem_base = (size_t)red_doubles(threads) * sizeof(double) + sizeof(EpochShared) +
+                                  (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
+        const size_t prefix_bytes = (size_t)threads * kPrefixSlots * sizeof(double2);
+        // The boundary variant of the correlator needs a 144-byte LDS strip per lane; long multi-period
+        // replicas that leave no room for it are tracked with the per-sample variant.
+        int up = shmem_base + prefix_bytes <= 160u * 1024u && e->lut_stride < kFastMaxLutWords ? 1 : 0;
+        const size_t shmem = shmem_base + (up ? prefix_bytes : 0);
+        *too_big = shmem > 160u * 1024u;
+        if (*too_big) return hipSuccess;
+        hipError_t err = hipSuccess;
         auto launch = [&](auto kernel) {
             // more than 64 KB of dynamic LDS has to be granted per kernel
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
             void* args[] = {&d_iq, &cap, &d_st, &d_cfg, &n_ep, &d_traj, &keep, &d_bits, &mb, &d_nbits, &d_luts,
                             &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault};
             if (parts > 1)  // the parts of a cluster wait for each other: all workgroups must be resident
-                launch_err = hipLaunchCooperativeKernel((const void*)kernel, dim3(n_ch * parts), dim3(threads), args,
-                                                        (unsigned)shmem, e->stream);
+                err = hipLaunchCooperativeKernel((const void*)kernel, dim3(n_ch * parts), dim3(threads), args,
+                                                 (unsigned)shmem, e->stream);
             else
-                launch_err = hipLaunchKernel((const void*)kernel, dim3(n_ch), dim3(threads), args, shmem, e->stream);
+                err = hipLaunchKernel((const void*)kernel, dim3(n_ch), dim3(threads), args, shmem, e->stream);
         };
         auto by_threads = [&](auto fmt) {
             constexpr int F = decltype(fmt)::value;
-            if (threads == 128) launch(track_kernel<F, 128>);
-            else if (threads == 256) launch(track_kernel<F, 256>);
+            if (threads == 256) launch(track_kernel<F, 256>);
             else launch(track_kernel<F, 512>);
         };
         switch (e->iq_fmt) {
@@ -594,6 +588,29 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
             case SDR_FMT_CI16: by_threads(std::integral_constant<int, SDR_FMT_CI16>{}); break;
             case SDR_FMT_CF32: by_threads(std::integral_constant<int, SDR_FMT_CF32>{}); break;
             default: by_threads(std::integral_constant<int, SDR_FMT_CF64>{}); break;
+        }
+        return err;
+    };
+
+    // Cluster size: as many workgroups per channel as the GPU has room for (1 per CU), up to 8.  When the
+    // cooperative launch is refused (GPU shared or partitioned: not every workgroup could be resident) the
+    // automatic choice halves the cluster until the launch goes through; a forced size fails instead.
+    int parts = 1;
+    if (e->track_force_parts) {
+        parts = e->track_force_parts;
+    } else {
+        while (parts < kMaxParts && (long)n_ch * parts * 2 <= (long)e->n_cus) parts *= 2;
+    }
+    hipError_t launch_err = hipSuccess;
+    {
+        ProfScope ps(e, "track_kernel");
+        for (;;) {
+            bool too_big = false;
+            launch_err = attempt(parts, &too_big);
+            if (too_big) return sdr_fail(SDR_ERR_RANGE, "closed-loop tracking: code table does not fit the LDS");
+            if (launch_err == hipSuccess || e->track_force_parts || parts == 1) break;
+            (void)hipGetLastError();
+            parts /= 2;
         }
     }
     if (launch_err != hipSuccess)
