@@ -96,9 +96,11 @@ def cpu_tracking_baseline(engine, items, n_items, budget_s):
     return out[:done], done, dt, rf
 
 
-def closed_loop_leg(eng, items, n_epochs):
-    """On-device loop closure (persistent workgroup per channel, Kaplan loops): latency-bound, so it is
-    reported beside, not instead of, the open-loop correlator throughput."""
+def closed_loop_leg(eng, items, n_epochs, n_ch=N_CH):
+    """On-device loop closure (persistent workgroups, Kaplan loops): latency-bound, so it is reported beside,
+    not instead of, the open-loop correlator throughput.  n_ch = 32: each channel on a cluster of 8 CUs (lowest
+    latency); n_ch = 512: channels beyond 32 re-track the same 32 satellites, two workgroups per CU (highest
+    aggregate channel x real-time rate)."""
     from sydr_amd._lib import LoopCfg, TrackState
     cfg = LoopCfg()
     cfg.loop_kind, cfg.n_taps, cfg.fs = 1, 3, FS
@@ -109,8 +111,8 @@ def closed_loop_leg(eng, items, n_epochs):
     cfg.fll_bw_pullin, cfg.fll_bw_wide, cfg.fll_bw_narrow, cfg.fll_thr_wide, cfg.fll_thr_narrow = 100.0, 50.0, 15.0, 0.5, 0.8
     cfg.pll_bw_wide, cfg.pll_bw_narrow, cfg.pll_thr_wide, cfg.pll_thr_narrow = 25.0, 15.0, 0.5, 0.8
     states = []
-    for c in range(N_CH):
-        it = items[c]
+    for c in range(n_ch):
+        it = items[c % N_CH]
         st = TrackState()
         st.code_slot, st.n_samples, st.current_sample = int(it["code_slot"]), int(it["n_samples"]), int(it["start_sample"])
         st.carrier_hz, st.code_hz = float(it["carrier_hz"]), CODE_RATE
@@ -128,9 +130,10 @@ def closed_loop_leg(eng, items, n_epochs):
     eng.prof_reset()
     samples = float(np.mean([e.current_sample - s.current_sample for e, s in zip(end, states)]))
     lost = sum(abs(e.carrier_hz - s.carrier_hz) > 100.0 for e, s in zip(end, states))
-    return {"metric": "closed-loop tracking, 32 channels, loop closure on device (Kaplan FLL/PLL/DLL)",
+    return {"metric": f"closed-loop tracking, {n_ch} channels, loop closure on device (Kaplan FLL/PLL/DLL)",
             "epochs": n_epochs, "kernel_ms": kern_ms, "wall_ms": wall * 1e3,
             "x_realtime": samples / FS / (kern_ms * 1e-3), "Msamples_per_s": samples / (kern_ms * 1e-3) / 1e6,
+            "channel_realtimes": n_ch * samples / FS / (kern_ms * 1e-3),
             "us_per_epoch": kern_ms * 1e3 / n_epochs, "channels_lost": int(lost)}
 
 
@@ -416,6 +419,7 @@ def main():
                                      "peaks_match_oracle": bool(ok)}
     if rank == 0 and world == 1 and not args.no_closed_loop:
         result["closed_loop"] = closed_loop_leg(eng, items, min(n_epochs, args.closed_loop_epochs))
+        result["closed_loop_dense"] = closed_loop_leg(eng, items, min(n_epochs, args.closed_loop_epochs, 1000), n_ch=512)
     plan.close()
     eng.close()
     if rank == 0:

@@ -79,8 +79,10 @@ struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind 
     sdr_loop_cfg cfg;
 };
 
-template <int FMT, int THREADS>
-__global__ __launch_bounds__(THREADS) void track_kernel(const void* __restrict__ ring, int64_t capacity,
+// WAVES: resident waves per SIMD the register allocation has to leave room for (2 = two 256-thread
+// workgroups can share a CU, at the price of a few spills).
+template <int FMT, int THREADS, int WAVES>
+__global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __restrict__ ring, int64_t capacity,
                                                         sdr_track_state* __restrict__ states,
                                                         const sdr_loop_cfg* __restrict__ cfg_ptr,
                                                         int n_epochs, sdr_track_epoch* __restrict__ traj,
@@ -89,7 +91,8 @@ __global__ __launch_bounds__(THREADS) void track_kernel(const void* __restrict__
                                                         const uint32_t* __restrict__ luts,
                                                         int lut_words, int lut_stride, int use_prefix,
                                                         int n_ch, int parts, unsigned long long* xchg,
-                                                        int* __restrict__ fault) {
+                                                        int* __restrict__ fault,
+                                                        sdr_track_epoch* __restrict__ traj_scratch) {
     extern __shared__ double smem[];
     double* red = smem;                                   // kWaves * 6 wave sums; reused by the cluster exchange
     EpochShared* sh = reinterpret_cast<EpochShared*>(red + red_doubles(THREADS));
@@ -171,8 +174,21 @@ __global__ __launch_bounds__(THREADS) void track_kernel(const void* __restrict__
         const unsigned long long wave_mark_ = wall_clock64();
 #endif
         if (sh->stop) break;
-        const EpochParams ep = sh->ep;
-        const double dphi = sh->dphi;
+        // What comes out of LDS is the same in every lane, but only readfirstlane tells the compiler so:
+        // as scalars the epoch parameters (and everything derived from them: group counts, ring positions,
+        // linspace constants) live in SGPRs and are computed on the scalar unit -- ~100 VGPRs per lane.
+        EpochParams ep;
+        {
+            const EpochParams v = sh->ep;
+            ep.start_sample = ((int64_t)__builtin_amdgcn_readfirstlane((int)(v.start_sample >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)v.start_sample);
+            ep.n = __builtin_amdgcn_readfirstlane(v.n);
+            ep.carrier_hz = uniform(v.carrier_hz);
+            ep.rem_carrier = uniform(v.rem_carrier);
+            ep.rem_code = uniform(v.rem_code);
+            ep.code_step = uniform(v.code_step);
+        }
+        const double dphi = uniform(sh->dphi);
         EpochConsts<kTaps> K;
         compute_constants<kTaps>(K, ep, sh->spacing, dphi, cluster_lanes);
         TRACK_MARK(1);
@@ -312,8 +328,11 @@ __global__ __launch_bounds__(THREADS) void track_kernel(const void* __restrict__
             // Work on register copies: through references the compiler has to assume that the record and the
             // state alias, and every statement becomes a dependent LDS round trip (measured: 2.7 us of them).
             sdr_track_state st = sh->st;
-            const sdr_loop_cfg cfg = sh->cfg;
-            sdr_track_epoch rec;
+            const sdr_loop_cfg& cfg = sh->cfg;  // read-only: stays in LDS
+            // The epoch record is write-only global memory: the recording part writes the trajectory (or, with
+            // keep_traj = 0, one record per channel that is overwritten every epoch), the others a scratch slot.
+            sdr_track_epoch& rec = writer ? traj[keep_traj ? (size_t)ch * n_epochs + epoch : (size_t)ch]
+                                          : traj_scratch[(size_t)ch * kMaxParts + part];
             rec.start_sample = st.current_sample;
             rec.n_samples = n;
             rec.carrier_hz_in = st.carrier_hz;
@@ -470,8 +489,6 @@ __global__ __launch_bounds__(THREADS) void track_kernel(const void* __restrict__
             sh->epochs_done = epoch + 1;
             publish(st, cfg);
             sh->st = st;
-            // keep_traj = 0: one record per channel, overwritten every epoch (nobody reads it)
-            if (writer) traj[keep_traj ? (size_t)ch * n_epochs + epoch : (size_t)ch] = rec;
           }
         }
         TRACK_MARK(4);
@@ -528,7 +545,8 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
     const size_t traj_bytes = traj ? (size_t)n_ch * n_epochs * sizeof(sdr_track_epoch) : 0;
     int rc = sdr_devbuf_reserve(e, &e->track_state, (size_t)n_ch * sizeof(sdr_track_state));
     if (!rc) rc = sdr_devbuf_reserve(e, &e->track_cfg, sizeof(sdr_loop_cfg));
-    if (!rc) rc = sdr_devbuf_reserve(e, &e->track_traj, traj ? traj_bytes : (size_t)n_ch * sizeof(sdr_track_epoch));
+    const size_t traj_main = traj ? traj_bytes : (size_t)n_ch * sizeof(sdr_track_epoch);
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->track_traj, traj_main + (size_t)n_ch * kMaxParts * sizeof(sdr_track_epoch));
     const size_t bits_bytes = nav_bits ? (size_t)n_ch * max_bits : 0;
     if (!rc && nav_bits) rc = sdr_devbuf_reserve(e, &e->track_bits, bits_bytes + (size_t)n_ch * sizeof(int32_t) + 16);
     if (rc) return rc;
@@ -543,6 +561,7 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
     const sdr_loop_cfg* d_cfg = (const sdr_loop_cfg*)e->track_cfg.ptr;
     sdr_track_epoch* d_traj = (sdr_track_epoch*)e->track_traj.ptr;
     int keep = traj ? 1 : 0;
+    sdr_track_epoch* d_traj_scratch = (sdr_track_epoch*)((char*)e->track_traj.ptr + traj_main);
     // exchange lines [n_ch][2 parities][8 parts][16 words] (tags zeroed: epoch tags start at 1), then the fault word
     const size_t xchg_bytes = (size_t)n_ch * 2 * kMaxParts * kXchgWords * sizeof(unsigned long long);
     if (int rc2 = sdr_devbuf_reserve(e, &e->track_xchg, xchg_bytes + 16)) return rc2;
@@ -556,7 +575,10 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
 
     // One attempt with `parts` workgroups per channel.
     auto attempt = [&](int parts, bool* too_big) -> hipError_t {
-        const int threads = parts >= 2 ? 256 : 512;
+        // more channels than CUs: smaller workgroups, two of which share a CU, so that one channel's loop
+        // update overlaps another's correlation (measured: 512 channels 20.2 -> 14.9 us per epoch)
+        const bool dense = parts == 1 && n_ch > e->n_cus;
+        const int threads = (parts >= 2 || dense) ? 256 : 512;
         const size_t shmem_base = (size_t)red_doubles(threads) * sizeof(double) + sizeof(EpochShared) +
                                   (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
         const size_t prefix_bytes = (size_t)threads * kPrefixSlots * sizeof(double2);
@@ -571,7 +593,7 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
             // more than 64 KB of dynamic LDS has to be granted per kernel
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
             void* args[] = {&d_iq, &cap, &d_st, &d_cfg, &n_ep, &d_traj, &keep, &d_bits, &mb, &d_nbits, &d_luts,
-                            &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault};
+                            &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault, &d_traj_scratch};
             if (parts > 1)  // the parts of a cluster wait for each other: all workgroups must be resident
                 err = hipLaunchCooperativeKernel((const void*)kernel, dim3(n_ch * parts), dim3(threads), args,
                                                  (unsigned)shmem, e->stream);
@@ -580,8 +602,9 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
         };
         auto by_threads = [&](auto fmt) {
             constexpr int F = decltype(fmt)::value;
-            if (threads == 256) launch(track_kernel<F, 256>);
-            else launch(track_kernel<F, 512>);
+            if (dense) launch(track_kernel<F, 256, 2>);
+            else if (threads == 256) launch(track_kernel<F, 256, 1>);
+            else launch(track_kernel<F, 512, 2>);
         };
         switch (e->iq_fmt) {
             case SDR_FMT_CI8: by_threads(std::integral_constant<int, SDR_FMT_CI8>{}); break;
