@@ -370,7 +370,12 @@ def main():
     result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "epl_kernel",
                           "avg_launch_ms": avg_kernel_s * 1e3, "launches": int(launches),
-                          "algorithmic_bytes_per_launch": algo_bytes_per_launch}
+                          "algorithmic_bytes_per_launch": algo_bytes_per_launch,
+                          # the same launch against the OTHER roof (6 + 4*taps flops per channel-sample;
+                          # fp64 vector peak 78.6 TFLOP/s): the kernel is VALU-issue-bound, not HBM-bound
+                          "fp64_vector": {"achieved_tflops": (6 + 4 * len(SPACING)) * ch_samples / max(1, args.steps) / avg_kernel_s / 1e12 if launches else 0.0,
+                                          "peak_tflops": 78.6,
+                                          "frac": (6 + 4 * len(SPACING)) * ch_samples / max(1, args.steps) / avg_kernel_s / 78.6e12 if launches else 0.0}}
     pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
