@@ -120,6 +120,52 @@ def _check_closed_loop_against_reference(engine, case):
     assert states[0].code_counter == len(ref)
 
 
+@pytest.mark.parametrize("kind,parts", [(1, 0), (1, 1), (1, 4), (0, 0), (0, 2)])
+def test_closed_loop_at_25_mhz_matches_the_oracle_loops(engine, kind, parts):
+    """The golden trajectories are 4 MHz runs (per-sample correlator variant).  At 25 MHz the tracking kernel
+    uses the boundary variant; the same loops (oracle restatement of the plugins, pinned by the goldens) run on
+    the CPU over the same synthetic stream must give the same integers and the same loop quantities."""
+    fs, ms, prn = 25e6, 130, 11
+    n = int(ms * fs * 1e-3)
+    sat = dict(prn=prn, doppler=2250.0, code_phase=417.3, phase=0.2, amp=9.0)
+    engine.iq_alloc(n, FMT_CI8)
+    engine.code_slots(1)
+    engine.load_gps_code(0, prn)
+    engine.iq_synth([sat], fs, 14.0, 991, 0, n)
+    rf = orc.iq_to_complex(engine.iq_download(n, 0))
+    pb, pc, _, _ = engine.pcps([0], 0, fs, 0.0, 5000.0, 250.0, 1, 1)
+    n_code = orc.samples_per_code(fs)
+    n0 = orc.required_samples(0.0, orc.CODE_RATE / fs)
+    carrier, _, cur = orc.post_acquisition(0.0, 5000.0, 250.0, [int(pb[0]), int(pc[0])], 0, n_code, n0)
+    c = KAPLAN_CFG if kind == 1 else BORRE_CFG
+    loop = (orc.KaplanLoop if kind == 1 else orc.BorreLoop)(fs, orc.gold_code(prn), c, carrier, cur)
+    epochs = 120
+    ref = [loop.step(rf[loop.current_sample:loop.current_sample + loop.n]) for _ in range(epochs)]
+    engine.track_cluster(parts)
+    try:
+        states, traj = engine.track_closed_loop([initial_state(kind, fs, carrier, cur, c)], loop_cfg(kind, fs, c), epochs)
+    finally:
+        engine.track_cluster(0)
+    tr = traj[0]
+    assert np.array_equal(tr["start_sample"], [r["start"] for r in ref])
+    assert np.array_equal(tr["n_samples"], [r["n"] for r in ref])
+    corr_ref = np.array([r["corr"] for r in ref])
+    for t in range(3):
+        mag = np.hypot(corr_ref[:, 2 * t], corr_ref[:, 2 * t + 1])
+        err = np.hypot(tr["corr"][:, 2 * t] - corr_ref[:, 2 * t], tr["corr"][:, 2 * t + 1] - corr_ref[:, 2 * t + 1])
+        assert np.all(err <= RTOL * np.maximum(mag, 1.0)), (t, (err / mag).max())
+    assert close(tr["carrier_hz"], [r["carrier_hz"] for r in ref]) and close(tr["code_hz"], [r["code_hz"] for r in ref])
+    assert close(tr["carrier_err"], [r["carrier_err"] for r in ref], scale=1.0)
+    assert close(tr["code_err"], [r["code_err"] for r in ref], scale=1.0)
+    if kind == 1:
+        assert np.array_equal(tr["lock_state"], [r["lock_state"] for r in ref])
+        assert np.array_equal(tr["track_flags"], [r["flags"] for r in ref])
+        assert close(tr["fll_lock"], [r["fll_lock"] for r in ref], scale=1.0)
+    # the loop is on the signal: prompt dominates and the carrier sits on the Doppler
+    assert abs(tr["carrier_hz"][-1] - sat["doppler"]) < 40.0
+    assert np.hypot(tr["corr"][-1, 2], tr["corr"][-1, 3]) > np.hypot(tr["corr"][-1, 0], tr["corr"][-1, 1])
+
+
 def test_closed_loop_many_channels_and_resume(engine):
     """8 channels in one launch == each channel alone; 2 x 100 epochs == 200 epochs (state round trip)."""
     fs, ms = 4e6, 260
