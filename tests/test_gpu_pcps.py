@@ -156,3 +156,14 @@ def test_pcps_rejects_bad_requests(engine):
         engine.pcps([0], 0, 4e6, 0.0, 5000.0, 0.0)          # empty grid
     with pytest.raises(SdrError):
         engine.pcps([0], 0, 4.079e6, 0.0, 5000.0, 250.0)    # N = 4079 is prime
+
+
+def test_pcps_randomised_stress(engine):
+    """tools/stress_pcps.py: random code lengths in samples (four-step, per-pass and generic-radix transforms), IF,
+    Doppler grids, integrations, present / absent PRNs -- peak indices identical, maps within 1e-9 of the oracle's."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("stress_pcps", os.path.join(os.path.dirname(__file__), "..", "tools", "stress_pcps.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    checked, worst, refused = mod.run(25, 20261003, engine)
+    assert checked >= 45 and worst <= 1e-9
