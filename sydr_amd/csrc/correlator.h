@@ -370,7 +370,8 @@ __device__ __forceinline__ void correlate_epoch(const void* __restrict__ ring, i
  * ------------------------------------------------------------------------------------------------ */
 constexpr int kPrefixSlots = kGroup + 1;  // double2 slots of LDS per lane used by the boundary variant
 constexpr double kNearInteger = 1.0 / 65536.0;  // predicted crossings this close to a sample are re-checked exactly
-constexpr double kFastMaxCodeStep = 0.06;  // 15 * step <= 0.9 chip
+constexpr double kFastMaxCodeStep = 0.06;  // 16-sample groups: 15 * step <= 0.9 chip
+constexpr double kFastMaxCodeStep8 = 0.125;  // 8-sample groups:  7 * step <= 0.875 chip (fs above ~8.2 MHz for C/A code)
 constexpr double kFastMinCodeStep = 1e-4;  // keeps the switch prediction's error far below kNearInteger (see above)
 constexpr int kFastMaxLutWords = 1 << 18;   // chip coordinates below 2^18: ulp(y) <= 2^-35
 
@@ -449,7 +450,7 @@ __device__ __forceinline__ bool epoch_wraps(const EpochParams& ep, int64_t capac
 
 // tid = index of the thread in its workgroup (selects the LDS strip); lane/stride/edge_lane as in
 // correlate_epoch.  SINGLE_WAVE: the epoch belongs to one wave alone (the batched kernel).
-template <int FMT, int NT, bool SINGLE_WAVE>
+template <int FMT, int NT, bool SINGLE_WAVE, int W = kWide>
 __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ring, int64_t capacity,
                                                      const EpochParams& ep, double dphi, const EpochConsts<NT>& K,
                                                      const uint32_t* lut, double2* prefix_lds, int tid, int lane,
@@ -459,9 +460,11 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
     strip[0] = make_double2(0.0, 0.0);
     // 16 rotations = 64 scalar registers would overflow the SGPR file (and the spills come back as
     // v_readlane in the loop): the second half lives in vector registers instead, which are plentiful here.
-    double rc[kWide], rs[kWide];
+    static_assert(W == kGroup || W == 2 * kGroup, "a lane owns one or two 16-byte loads of ci8");
+    constexpr int kHalves = W / kGroup;
+    double rc[W], rs[W];
 #pragma unroll
-    for (int j = 0; j < kWide; ++j) {
+    for (int j = 0; j < W; ++j) {
         rc[j] = K.rc[j];
         rs[j] = K.rs[j];
         if (j >= kGroup) {
@@ -469,7 +472,7 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
             asm volatile("" : "+v"(rs[j]));
         }
     }
-    const double c_it = K.cW, s_it = K.sW;  // lane stride of this loop
+    const double c_it = W == kWide ? K.cW : K.cN, s_it = W == kWide ? K.sW : K.sN;  // lane stride of this loop
     const double dphi_u = uniform(dphi), rem_carrier_u = uniform(ep.rem_carrier);
     const double* shift = K.shift;
     const double* step = K.step;
@@ -482,18 +485,18 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
     const int64_t base = aligned % capacity;
     // whole 16-sample groups g in [g_lo, g_hi); everything else is an edge sample (<= 30 of them)
     const int g_lo = head ? 1 : 0;
-    const int g_hi = (head + n) / kWide;
-    const int head_end = g_hi > g_lo ? g_lo * kWide - head : n;
-    const int tail_start = g_hi > g_lo ? g_hi * kWide - head : n;
+    const int g_hi = (head + n) / W;
+    const int head_end = g_hi > g_lo ? g_lo * W - head : n;
+    const int tail_start = g_hi > g_lo ? g_hi * W - head : n;
 
     // (the caller guarantees that the whole groups do not wrap around the ring: see epoch_wraps())
     auto load_group = [&](int64_t pos, Raw8<FMT>* raw) {
         raw[0].load(ring, pos);
-        raw[1].load(ring, pos + kGroup);
+        if (kHalves == 2) raw[kHalves - 1].load(ring, pos + kGroup);
     };
 
     auto group = [&](int g, const Raw8<FMT>* raw, double sb, double cb) {
-        const int i0 = g * kWide - head;
+        const int i0 = g * W - head;
         const double di0 = (double)i0;
 
         int nlead[NT];                    // leading samples on chip p0, 1..16 (16: the whole group)
@@ -511,7 +514,7 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
             const double e = (cy - y) * inv_step[t];  // >= 0
             const double fr = e - floor(e);
             near |= fabs(fr - 0.5) > 0.5 - kNearInteger;
-            const double ec = fmin(e, (double)(kWide - 1));
+            const double ec = fmin(e, (double)(W - 1));
             nlead[t] = (int)ec + 1;
         }
         if (__builtin_expect(__any(near), 0)) {
@@ -522,7 +525,7 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
                     y = y + shift[t];
                     return (int)ceil(y);
                 };
-                const int b = nlead[t] > kWide - 1 ? kWide - 1 : nlead[t];  // compare samples b-1 | b, both in the group
+                const int b = nlead[t] > W - 1 ? W - 1 : nlead[t];  // compare samples b-1 | b, both in the group
                 const int pa = chip(i0 + b - 1);
                 const int pb = chip(i0 + b);
                 nlead[t] = (pa != p0[t]) ? b - 1 : ((pb == p0[t]) ? b + 1 : b);
@@ -548,6 +551,17 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
             pi = __builtin_fma(ai, rc[j], __builtin_fma(ar, rs[j], pi));
             strip[1 + j] = make_double2(pr, pi);
         }
+        if (kHalves == 1) {  // 8-sample groups: the strip holds everything, P_nlead is one read
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const double2 pm = strip[nlead[t]];
+                const double gr = __builtin_fma(sign_diff[t], pm.x, sign_b[t] * pr);
+                const double gi = __builtin_fma(sign_diff[t], pm.y, sign_b[t] * pi);
+                accr[t] = __builtin_fma(-sb, gi, __builtin_fma(cb, gr, accr[t]));
+                acci[t] = __builtin_fma(sb, gr, __builtin_fma(cb, gi, acci[t]));
+            }
+            return;
+        }
         double2 pa[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) pa[t] = strip[nlead[t] < kGroup ? nlead[t] : kGroup];
@@ -555,9 +569,9 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) {
             double ar, ai;
-            raw[1].get(j, ar, ai);
-            qr = __builtin_fma(-ai, rs[kGroup + j], __builtin_fma(ar, rc[kGroup + j], qr));
-            qi = __builtin_fma(ai, rc[kGroup + j], __builtin_fma(ar, rs[kGroup + j], qi));
+            raw[kHalves - 1].get(j, ar, ai);
+            qr = __builtin_fma(-ai, rs[(kHalves - 1) * kGroup + j], __builtin_fma(ar, rc[(kHalves - 1) * kGroup + j], qr));
+            qi = __builtin_fma(ai, rc[(kHalves - 1) * kGroup + j], __builtin_fma(ar, rs[(kHalves - 1) * kGroup + j], qi));
             strip[1 + j] = make_double2(qr, qi);
         }
         pr += qr;
@@ -580,17 +594,17 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
     // wait for a load in the iteration that issued it.)
     const int n_groups = g_hi - g_lo;
     if (n_groups > 0) {
-        Raw8<FMT> buf_a[2], buf_b[2];
+        Raw8<FMT> buf_a[kHalves], buf_b[kHalves];
         int g = g_lo + lane;
         bool alive = g < g_hi;
         g = alive ? g : g_hi - 1;
-        int64_t pos = base + (int64_t)g * kWide;
+        int64_t pos = base + (int64_t)g * W;
         load_group(pos, buf_a);
         // Carrier phase at the lane's first sample: one exact evaluation, then a fixed rotation per
         // iteration (the lane's groups are kWide*THREADS samples apart; <= a few dozen steps, so the
         // recurrence stays within ~1e-15 of a fresh evaluation).
         double sb, cb;
-        sincos_reduced(__builtin_fma(-(double)(g * kWide - head), dphi_u, rem_carrier_u), &sb, &cb);
+        sincos_reduced(__builtin_fma(-(double)(g * W - head), dphi_u, rem_carrier_u), &sb, &cb);
         sb = alive ? sb : 0.0;
         cb = alive ? cb : 0.0;
         auto advance = [&]() {  // to the lane's next group, or stay (with a zero phasor) when there is none
@@ -601,7 +615,7 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
             cb = more ? cbn : 0.0;
             alive = more;
             g += more ? stride : 0;
-            pos += more ? kWide * stride : 0;
+            pos += more ? W * stride : 0;
         };
         // A wave all of whose lanes have run out (the last, partial round of a multi-wave workgroup)
         // skips the group body; the single-wave kernel never pays for the test.

@@ -38,7 +38,8 @@ constexpr int kWaves = kThreads / 64;
 // items was measured slower: holding two items' parameters pushed the kernel from 4 to 2 resident
 // waves per SIMD -- 1.15 ms vs 0.87 ms per 32 000-item launch -- so hardware workgroup dispatch does
 // the scheduling.)
-template <int FMT, int NT, bool WIDE>
+// W: samples a lane owns per iteration of the boundary variant (16 or 8), 0 = the per-sample variant.
+template <int FMT, int NT, int W>
 __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ ring, int64_t capacity,
                                                        const sdr_epl_item* __restrict__ items,
                                                        const uint32_t* __restrict__ luts,
@@ -48,8 +49,8 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
                                                        double* __restrict__ out) {
     extern __shared__ double smem[];
     double* red = smem;
-    double2* prefix = reinterpret_cast<double2*>(red + kWaves * 2 * NT);          // WIDE only: kThreads*9 slots
-    uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + (WIDE ? kThreads * kPrefixSlots : 0));
+    double2* prefix = reinterpret_cast<double2*>(red + kWaves * 2 * NT);          // boundary variants only: kThreads*9 slots
+    uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + (W ? kThreads * kPrefixSlots : 0));
 
     const int tid = threadIdx.x;
 #ifdef SDR_TRACE_WG
@@ -70,8 +71,8 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
     __syncthreads();  // replica staged
 
     double accr[NT], acci[NT];
-    if (WIDE && !epoch_wraps(ep, capacity))
-        correlate_epoch_wide<FMT, NT, true>(ring, capacity, ep, dphi, K, lut, prefix, tid, tid, kThreads, tid, accr, acci);
+    if (W != 0 && !epoch_wraps(ep, capacity))
+        correlate_epoch_wide<FMT, NT, true, (W ? W : kWide)>(ring, capacity, ep, dphi, K, lut, prefix, tid, tid, kThreads, tid, accr, acci);
     else
         correlate_epoch<FMT, NT>(ring, capacity, ep, dphi, K, lut, tid, kThreads, tid, accr, acci);
     const double total = reduce_taps<NT, kThreads>(accr, acci, red, tid);
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
 
 template <int FMT, int NT>
 void launch_one(sdr_engine* e, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
-                int tap0, int n_taps_total, int lut_words, bool wide, double* d_out) {
+                int tap0, int n_taps_total, int lut_words, int wide, double* d_out) {
     size_t shmem = (size_t)(kWaves * 2 * NT) * sizeof(double) + (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t) +
                    (wide ? (size_t)kThreads * kPrefixSlots * sizeof(double2) : 0);
     auto launch = [&](auto kernel) {
@@ -100,15 +101,17 @@ void launch_one(sdr_engine* e, const sdr_epl_item* d_items, int n_items, const d
         hipLaunchKernelGGL(kernel, dim3(n_items), dim3(kThreads), shmem, e->stream, e->iq, e->iq_capacity, d_items,
                            e->luts, lut_words, e->lut_stride, d_spacing, fs, tap0, n_taps_total, d_out);
     };
-    if (wide)
-        launch(epl_kernel<FMT, NT, true>);
+    if (wide == 16)
+        launch(epl_kernel<FMT, NT, 16>);
+    else if (wide == 8)
+        launch(epl_kernel<FMT, NT, 8>);
     else
-        launch(epl_kernel<FMT, NT, false>);
+        launch(epl_kernel<FMT, NT, 0>);
 }
 
 template <int FMT>
 void launch_fmt(sdr_engine* e, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
-                int n_taps, int lut_words, bool wide, double* d_out) {
+                int n_taps, int lut_words, int wide, double* d_out) {
     // Taps are served in register-resident chunks of 5/3/2/1.
     int t0 = 0;
     while (t0 < n_taps) {
@@ -138,13 +141,13 @@ struct sdr_epl_plan {
     int n_items = 0;
     int n_taps = 0;
     int lut_words = 0;
-    bool wide = false;  // every item has 16*code_step < 1: the boundary variant of the correlator applies
+    int wide = 0;  // 16 / 8: every item has 16 (8) * code_step < 1, the boundary variant with that group width applies
     double fs = 0.0;
 };
 
 // Host-side check that no item can index outside the ring or the staged LUT.
 static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items, const double* spacing,
-                          int n_taps, int* lut_words, bool* wide) {
+                          int n_taps, int* lut_words, int* wide) {
     double smin = spacing[0], smax = spacing[0];
     for (int t = 1; t < n_taps; ++t) {
         smin = spacing[t] < smin ? spacing[t] : smin;
@@ -174,7 +177,8 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
         if ((int)hi > maxlen) maxlen = (int)hi;
     }
     *lut_words = maxlen + SDR_LUT_PAD + 2;
-    *wide = max_step <= sdr::kFastMaxCodeStep && min_step >= sdr::kFastMinCodeStep && e->lut_stride < sdr::kFastMaxLutWords;
+    const bool boundary_ok = min_step >= sdr::kFastMinCodeStep && e->lut_stride < sdr::kFastMaxLutWords;
+    *wide = !boundary_ok ? 0 : (max_step <= sdr::kFastMaxCodeStep ? 16 : (max_step <= sdr::kFastMaxCodeStep8 ? 8 : 0));
     return SDR_OK;
 }
 
@@ -192,7 +196,7 @@ int sdr_epl_plan_create(sdr_engine* e, const sdr_epl_item* items, int n_items, c
         return sdr_fail(SDR_ERR_INVALID, "n_taps %d outside 1..%d", n_taps, SDR_MAX_TAPS);
     if (!(fs > 0.0)) return sdr_fail(SDR_ERR_INVALID, "fs must be positive");
     int lut_words = 0;
-    bool wide = false;
+    int wide = 0;
     if (int rc = validate_items(e, items, n_items, spacing, n_taps, &lut_words, &wide)) return rc;
 
     sdr_epl_plan* p = new (std::nothrow) sdr_epl_plan();

@@ -194,8 +194,11 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         TRACK_MARK(1);
 
         double accr[kTaps], acci[kTaps];
-        if (use_prefix && ep.code_step <= kFastMaxCodeStep && ep.code_step >= kFastMinCodeStep && !epoch_wraps(ep, capacity))   // uniform branch: 16-sample boundary variant above ~17 MHz
-            correlate_epoch_wide<FMT, kTaps, false>(ring, capacity, ep, dphi, K, lut, prefix, tid, lane_global, cluster_lanes, edge_lane, accr, acci);
+        const bool boundary_ok = use_prefix && ep.code_step >= kFastMinCodeStep && !epoch_wraps(ep, capacity);  // (uniform)
+        if (boundary_ok && ep.code_step <= kFastMaxCodeStep)         // 16-sample boundary variant above ~17 MHz
+            correlate_epoch_wide<FMT, kTaps, false, 16>(ring, capacity, ep, dphi, K, lut, prefix, tid, lane_global, cluster_lanes, edge_lane, accr, acci);
+        else if (boundary_ok && ep.code_step <= kFastMaxCodeStep8)   // 8-sample boundary variant above ~8.2 MHz
+            correlate_epoch_wide<FMT, kTaps, false, 8>(ring, capacity, ep, dphi, K, lut, prefix, tid, lane_global, cluster_lanes, edge_lane, accr, acci);
         else
             correlate_epoch<FMT, kTaps>(ring, capacity, ep, dphi, K, lut, lane_global, cluster_lanes, edge_lane, accr, acci);
 #ifdef SDR_TRACE_TRACK

@@ -187,7 +187,9 @@ def test_epl_chip_crossings_exactly_on_samples(engine):
     engine.load_gps_code(0, 14)
     rf = orc.iq_to_complex(raw)
     code = orc.pad_code(orc.gold_code(14))
-    for step, fs in [(1 / 32, 32 * 1.023e6), (1 / 64, 64 * 1.023e6), (3 / 64, 1.023e6 * 64 / 3), (1 / 17, 17 * 1.023e6)]:
+    for step, fs in [(1 / 32, 32 * 1.023e6), (1 / 64, 64 * 1.023e6), (3 / 64, 1.023e6 * 64 / 3), (1 / 17, 17 * 1.023e6),
+                     # 8-sample groups (0.06 < step <= 0.125)
+                     (1 / 16, 16 * 1.023e6), (3 / 32, 1.023e6 * 32 / 3), (1 / 8, 8 * 1.023e6), (0.1023, 10e6)]:
         n = int(1000 / step)
         for rem, start in [(0.0, 0), (0.5, 3), (0.25, 16), (1 / 32, 37), (0.999999999999, 8), (1e-12, 5)]:
             items = make_items(0, n, start, 1234.5, 0.1, rem, step)

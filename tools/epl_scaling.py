@@ -24,5 +24,5 @@ for n, step in ((3125, 0.32), (6250, 0.16), (12500, 0.0818), (25000, 0.04092), (
         plan.run()
     ms, cnt = e.prof_read("epl_kernel"); e.prof_enable(False)
     t = ms / cnt
-    print(f"n={n:6d} step={step:.5f} wide={step<=0.06}  {t:.4f} ms/launch  {t*1e6/n_items:.1f} ns/WG-slot  {t*1e6/(n_items*n)*1e3:.3f} ps/ch-sample")
+    print(f"n={n:6d} step={step:.5f} variant={16 if step<=0.06 else (8 if step<=0.125 else 0)}  {t:.4f} ms/launch  {t*1e6/n_items:.1f} ns/WG-slot  {t*1e6/(n_items*n)*1e3:.3f} ps/ch-sample")
     plan.close()

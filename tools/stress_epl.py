@@ -42,7 +42,7 @@ def run(rounds, seed, eng=None):
           if regime == 0:      # boundary variant, generic
               st = float(rng.uniform(0.004, 0.0599))
           elif regime == 1:    # boundary variant, steps that are exact binary fractions (switches exactly on samples)
-              st = float(rng.choice([1 / 32, 1 / 64, 3 / 64, 1 / 128, 5 / 128, 7 / 128]))
+              st = float(rng.choice([1 / 32, 1 / 64, 3 / 64, 1 / 128, 5 / 128, 7 / 128, 1 / 16, 3 / 32, 1 / 8, 7 / 64]))
           elif regime == 2:    # per-sample variant
               st = float(rng.uniform(0.0601, 0.6))
           else:                # mixed launch: one slow item forces the per-sample variant for all
