@@ -132,7 +132,8 @@ void sdr_engine_destroy(sdr_engine* e) {
     for (auto ev : e->prof_pool) (void)hipEventDestroy(ev);
     DevBuf* bufs[] = {&e->ws_items,  &e->ws_out,   &e->ws_spacing, &e->pcps_fwd,   &e->pcps_a,
                       &e->pcps_b,    &e->pcps_code, &e->pcps_tw,   &e->pcps_map,   &e->pcps_csum,
-                      &e->pcps_part, &e->pcps_res,  &e->track_state, &e->track_cfg, &e->track_traj, &e->track_bits, &e->track_xchg};
+                      &e->pcps_part, &e->pcps_res,  &e->track_state, &e->track_cfg, &e->track_traj, &e->track_bits, &e->track_xchg,
+                      &e->pcps_blu,  &e->pcps_blu_x, &e->pcps_blu_a, &e->pcps_blu_b};
     for (DevBuf* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (e->iq) (void)hipFree(e->iq);

@@ -67,6 +67,9 @@ struct sdr_engine {
     int n_cus = 0;              // compute units of the device (sizes the closed-loop clusters)
     int track_force_parts = 0;  // diagnostics / tests: 0 = choose, else 1, 2, 4 or 8 workgroups per channel
     int64_t pcps_tw_n = 0;
+    // chirp-z (Bluestein) plan for code lengths the mixed-radix planner cannot factor: [chirp N][B_fwd M][B_inv M][tw M]
+    DevBuf pcps_blu, pcps_blu_x, pcps_blu_a, pcps_blu_b;
+    int64_t pcps_blu_n = 0;
     bool pcps_force_passes = false;  // diagnostics: use the one-kernel-per-radix-pass transform instead of the four-step one
 
     // profiling

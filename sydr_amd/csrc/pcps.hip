@@ -608,12 +608,108 @@ void run_four_step(sdr_engine* e, const FourStep& f, PassArgs a, int batch, doub
     run_four_step_t<INV, LOAD0, STORE_LAST, FMT, 8, 4>(e, f, a, batch, Z, final_out);
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Chirp-z (Bluestein) transform for a length N the planner cannot factor (a prime factor above 64):
+ * what NumPy's pocketfft does for such sizes.  With c[m] = exp(+i*pi*m^2/N) (m^2 taken mod 2N in
+ * integers, so the phase is exact to an ulp):
+ *   forward  X[k] = conj(c[k]) * sum_n (x[n] conj(c[n])) * c[k-n]
+ *   inverse  Y[n] =      c[n]  * sum_k (X[k]      c[k] ) * conj(c[n-k])          (unnormalised)
+ * The sums are circular convolutions of length M >= 2N-1 (M = 2^a 3^b 5^c), done with the ordinary
+ * transforms above.  The fused loads / stores of the PCPS stages sit in the pre / post kernels.
+ * ------------------------------------------------------------------------------------------------ */
+struct BluPlan {
+    int N = 0, M = 0;
+    const double2* chirp = nullptr;   // [N]
+    const double2* spec_fwd = nullptr;  // FFT_M of the forward kernel, [M]
+    const double2* spec_inv = nullptr;  // FFT_M of the inverse kernel, [M]
+    const double2* twM = nullptr;     // twiddles of the length-M transform
+    double2 *x = nullptr, *a = nullptr, *b = nullptr;  // [max batch][M] work buffers
+    std::vector<int> radM;
+};
+
+__global__ __launch_bounds__(kThreads) void blu_chirp_kernel(double2* chirp, double2* kern_fwd, double2* kern_inv, int N, int M) {
+    const int m = blockIdx.x * kThreads + threadIdx.x;
+    if (m >= M) return;
+    double2 c = make_double2(0.0, 0.0);
+    const int d = m < N ? m : (M - m < N ? M - m : -1);  // kernel index: b[m] = c[|m|] for |m| < N (wrapped), else 0
+    if (d >= 0) {
+        const long long r = ((long long)d * d) % (2LL * N);
+        double sn, cs;
+        sincospi((double)r / (double)N, &sn, &cs);
+        c = make_double2(cs, sn);
+    }
+    if (m < N) chirp[m] = c;
+    kern_fwd[m] = c;
+    kern_inv[m] = make_double2(c.x, -c.y);
+}
+
+template <int LOAD, int FMT, bool INV>
+__global__ __launch_bounds__(kThreads) void blu_pre_kernel(const PassArgs a, const double2* __restrict__ chirp, int M,
+                                                          double2* __restrict__ x) {
+    const int m = blockIdx.x * kThreads + threadIdx.x;
+    const int batch = blockIdx.y;
+    if (m >= M) return;
+    double2 v = make_double2(0.0, 0.0);
+    if (m < a.N) {
+        double2 c = chirp[m];
+        if (!INV) c.y = -c.y;
+        v = cmul(load_elem<LOAD, FMT, INV>(a, batch, m), c);
+    }
+    x[(size_t)batch * M + m] = v;
+}
+
+__global__ __launch_bounds__(kThreads) void blu_mul_kernel(double2* __restrict__ x, const double2* __restrict__ spec, int M) {
+    const int m = blockIdx.x * kThreads + threadIdx.x;
+    if (m >= M) return;
+    const size_t o = (size_t)blockIdx.y * M + m;
+    x[o] = cmul(x[o], spec[m]);
+}
+
+template <int STORE, bool INV>
+__global__ __launch_bounds__(kThreads) void blu_post_kernel(const PassArgs a, const double2* __restrict__ chirp, int M,
+                                                           const double2* __restrict__ x) {
+    const int k = blockIdx.x * kThreads + threadIdx.x;
+    const int batch = blockIdx.y;
+    if (k >= a.N) return;
+    double2 c = chirp[k];
+    if (!INV) c.y = -c.y;
+    const double inv_m = 1.0 / (double)M;
+    double2 v = cmul(x[(size_t)batch * M + k], c);
+    v.x *= inv_m;
+    v.y *= inv_m;
+    store_elem<STORE>(a, batch, k, v);
+}
+
 // Runs all passes of one batched transform.  `first` carries the fused load of
 // pass 0, `last_store` the fused store of the final pass.  Ping-pongs bufA/bufB.
 template <bool INV, int LOAD0, int STORE_LAST, int FMT>
 void run_fft(sdr_engine* e, const std::vector<int>& radices, PassArgs a, int batch, double2* bufA, double2* bufB,
-             double2* final_out, const char* prof_name) {
+             double2* final_out, const char* prof_name, const BluPlan* blu = nullptr);
+
+template <bool INV, int LOAD0, int STORE_LAST, int FMT>
+void run_bluestein(sdr_engine* e, const BluPlan& blu, PassArgs a, int batch, double2* final_out) {
+    a.out = final_out;
+    const int M = blu.M;
+    const dim3 gm((M + kThreads - 1) / kThreads, batch), gn((a.N + kThreads - 1) / kThreads, batch);
+    hipLaunchKernelGGL((blu_pre_kernel<LOAD0, FMT, INV>), gm, dim3(kThreads), 0, e->stream, a, blu.chirp, M, blu.x);
+    PassArgs p = {};
+    p.N = M;
+    p.tw = blu.twM;
+    p.in = blu.x;
+    run_fft<false, LOAD_PLAIN, STORE_PLAIN, FMT>(e, blu.radM, p, batch, blu.a, blu.b, blu.x, "pcps_bluestein_fft");
+    hipLaunchKernelGGL(blu_mul_kernel, gm, dim3(kThreads), 0, e->stream, blu.x, INV ? blu.spec_inv : blu.spec_fwd, M);
+    run_fft<true, LOAD_PLAIN, STORE_PLAIN, FMT>(e, blu.radM, p, batch, blu.a, blu.b, blu.x, "pcps_bluestein_fft");
+    hipLaunchKernelGGL((blu_post_kernel<STORE_LAST, INV>), gn, dim3(kThreads), 0, e->stream, a, blu.chirp, M, blu.x);
+}
+
+template <bool INV, int LOAD0, int STORE_LAST, int FMT>
+void run_fft(sdr_engine* e, const std::vector<int>& radices, PassArgs a, int batch, double2* bufA, double2* bufB,
+             double2* final_out, const char* prof_name, const BluPlan* blu) {
     ProfScope ps(e, prof_name);
+    if (blu) {
+        run_bluestein<INV, LOAD0, STORE_LAST, FMT>(e, *blu, a, batch, final_out);
+        return;
+    }
     const FourStep four = plan_four_step(a.N);
     if (four.ok && !e->pcps_force_passes) {
         run_four_step<INV, LOAD0, STORE_LAST, FMT>(e, four, a, batch, bufA, final_out);
@@ -643,7 +739,7 @@ void run_fft(sdr_engine* e, const std::vector<int>& radices, PassArgs a, int bat
 template <int FMT>
 int pcps_run(sdr_engine* e, const int32_t* d_slots, int n_prn, int64_t start, double fs, double if_hz,
              double bin_start, double bin_delta, int nbins, int N, int spc, int coh, int noncoh,
-             const std::vector<int>& radices, int prn_chunk, bool have_spectra) {
+             const std::vector<int>& radices, int prn_chunk, bool have_spectra, const BluPlan* blu) {
     double2* F = (double2*)e->pcps_fwd.ptr;
     double2* A = (double2*)e->pcps_a.ptr;
     double2* B = (double2*)e->pcps_b.ptr;
@@ -666,7 +762,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, int n_prn, int64_t start, do
         a.N = N;
         a.code_samples = up;
         // ping-pong inside A (two halves are not needed: code batch is small) -> use A and F as scratch
-        run_fft<false, LOAD_CODE_REAL, STORE_CONJ, FMT>(e, radices, a, n_prn, A, F, C, "pcps_code_fft");
+        run_fft<false, LOAD_CODE_REAL, STORE_CONJ, FMT>(e, radices, a, n_prn, A, F, C, "pcps_code_fft", blu);
     }
 
     for (int inc = 0; inc < noncoh; ++inc) {
@@ -683,7 +779,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, int n_prn, int64_t start, do
             f.if_hz = if_hz;
             f.bin_start = bin_start;
             f.bin_delta = bin_delta;
-            run_fft<false, LOAD_IQ_MIX, STORE_PLAIN, FMT>(e, radices, f, nbins, A, B, F, "pcps_fwd_fft");
+            run_fft<false, LOAD_IQ_MIX, STORE_PLAIN, FMT>(e, radices, f, nbins, A, B, F, "pcps_fwd_fft", blu);
 
             for (int p0 = 0; p0 < n_prn; p0 += prn_chunk) {
                 const int pc = n_prn - p0 < prn_chunk ? n_prn - p0 : prn_chunk;
@@ -698,10 +794,10 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, int n_prn, int64_t start, do
                 g.csum = csum ? csum + (size_t)p0 * nbins * N : nullptr;
                 if (coh == 1) {
                     g.first_block = inc == 0;
-                    run_fft<true, LOAD_MUL_CODE, STORE_MAG_ACC, FMT>(e, radices, g, pc * nbins, A, B, nullptr, "pcps_inv_fft");
+                    run_fft<true, LOAD_MUL_CODE, STORE_MAG_ACC, FMT>(e, radices, g, pc * nbins, A, B, nullptr, "pcps_inv_fft", blu);
                 } else {
                     g.first_block = ic == 0;
-                    run_fft<true, LOAD_MUL_CODE, STORE_CPLX_ACC, FMT>(e, radices, g, pc * nbins, A, B, nullptr, "pcps_inv_fft");
+                    run_fft<true, LOAD_MUL_CODE, STORE_CPLX_ACC, FMT>(e, radices, g, pc * nbins, A, B, nullptr, "pcps_inv_fft", blu);
                 }
             }
         }
@@ -789,8 +885,21 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     if (N64 < 2 || N64 > (1 << 24)) return sdr_fail(SDR_ERR_UNSUPPORTED, "samples per code %lld unsupported", (long long)N64);
     const int N = (int)N64;
     const std::vector<int> radices = factor_radices(N);
-    if (radices.empty())
-        return sdr_fail(SDR_ERR_UNSUPPORTED, "N=%d has a prime factor above %d", N, kMaxGenericRadix);
+    // A code length the mixed-radix planner cannot factor (prime factor above 64) goes through the chirp-z
+    // transform with M = the next 2^a 3^b 5^c >= 2N-1.
+    const bool use_blu = radices.empty();
+    int M = 0;
+    if (use_blu) {
+        for (int64_t m = 2 * (int64_t)N - 1;; ++m) {
+            int64_t q = m;
+            for (int f : {2, 3, 5})
+                while (q % f == 0) q /= f;
+            if (q == 1) {
+                M = (int)m;
+                break;
+            }
+        }
+    }
     const int64_t need = (int64_t)N * coh * noncoh;
     if (start_sample < 0 || need > e->iq_capacity)
         return sdr_fail(SDR_ERR_RANGE, "acquisition needs %lld samples, ring holds %lld", (long long)need,
@@ -801,7 +910,8 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
 
     // Work-buffer sizing: transforms in flight per inverse sweep are capped at 8 GiB per buffer.
     const size_t tbytes = (size_t)N * sizeof(double2);
-    int prn_chunk = (int)std::min<int64_t>(n_prn, std::max<int64_t>(1, (int64_t)((8ull << 30) / (tbytes * nbins))));
+    const size_t mbytes = (size_t)M * sizeof(double2);  // (0 without the chirp-z path)
+    int prn_chunk = (int)std::min<int64_t>(n_prn, std::max<int64_t>(1, (int64_t)((8ull << 30) / (std::max(tbytes, mbytes) * nbins))));
     if ((int64_t)prn_chunk * nbins > 65535) prn_chunk = std::max(1, 65535 / nbins);
     if (nbins > 65535 || n_prn > 65535) return sdr_fail(SDR_ERR_UNSUPPORTED, "grid too large");
     const size_t work = tbytes * (size_t)std::max(prn_chunk * nbins, std::max(n_prn, nbins));
@@ -821,6 +931,41 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
         SDR_HIP(hipGetLastError());
         e->pcps_tw_n = N;
     }
+    BluPlan blu;
+    if (use_blu) {
+        const size_t max_batch = (size_t)std::max(2, std::max(prn_chunk * nbins, std::max(n_prn, nbins)));
+        if ((rc = sdr_devbuf_reserve(e, &e->pcps_blu, tbytes + 3 * mbytes))) return rc;
+        if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_blu_x, mbytes * max_batch);
+        if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_blu_a, mbytes * max_batch);
+        if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_blu_b, mbytes * max_batch);
+        if (rc) return rc;
+        double2* chirp = (double2*)e->pcps_blu.ptr;
+        double2* spec_fwd = chirp + N;
+        double2* spec_inv = spec_fwd + M;
+        double2* twM = spec_inv + M;
+        blu.N = N;
+        blu.M = M;
+        blu.chirp = chirp;
+        blu.spec_fwd = spec_fwd;
+        blu.spec_inv = spec_inv;
+        blu.twM = twM;
+        blu.x = (double2*)e->pcps_blu_x.ptr;
+        blu.a = (double2*)e->pcps_blu_a.ptr;
+        blu.b = (double2*)e->pcps_blu_b.ptr;
+        blu.radM = factor_radices(M);
+        if (e->pcps_blu_n != N) {  // plan cached per code length: chirp, length-M twiddles, spectra of both kernels
+            hipLaunchKernelGGL(twiddle_kernel, dim3((M + kThreads - 1) / kThreads), dim3(kThreads), 0, e->stream, twM, M);
+            hipLaunchKernelGGL(blu_chirp_kernel, dim3((M + kThreads - 1) / kThreads), dim3(kThreads), 0, e->stream, chirp,
+                               blu.x, blu.x + M, N, M);
+            PassArgs p = {};
+            p.N = M;
+            p.tw = twM;
+            p.in = blu.x;  // two transforms at once: [kernel_fwd, kernel_inv] -> [spec_fwd, spec_inv] (adjacent)
+            run_fft<false, LOAD_PLAIN, STORE_PLAIN, SDR_FMT_CF64>(e, blu.radM, p, 2, blu.a, blu.b, spec_fwd, "pcps_bluestein_plan");
+            SDR_HIP(hipGetLastError());
+            e->pcps_blu_n = N;
+        }
+    }
     int32_t* d_slots = (int32_t*)((char*)e->pcps_res.ptr + (size_t)n_prn * 3 * sizeof(double));
     if (code_spectra)
         SDR_HIP(hipMemcpyAsync(e->pcps_code.ptr, code_spectra, tbytes * n_prn, hipMemcpyHostToDevice, e->stream));
@@ -833,10 +978,10 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     const double bin_delta = (bin_start + doppler_step) - bin_start;
 
     switch (e->iq_fmt) {
-        case SDR_FMT_CI8: rc = pcps_run<SDR_FMT_CI8>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs); break;
-        case SDR_FMT_CI16: rc = pcps_run<SDR_FMT_CI16>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs); break;
-        case SDR_FMT_CF32: rc = pcps_run<SDR_FMT_CF32>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs); break;
-        default: rc = pcps_run<SDR_FMT_CF64>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs); break;
+        case SDR_FMT_CI8: rc = pcps_run<SDR_FMT_CI8>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr); break;
+        case SDR_FMT_CI16: rc = pcps_run<SDR_FMT_CI16>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr); break;
+        case SDR_FMT_CF32: rc = pcps_run<SDR_FMT_CF32>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr); break;
+        default: rc = pcps_run<SDR_FMT_CF64>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr); break;
     }
     if (rc) return rc;
 

@@ -154,8 +154,30 @@ def test_pcps_rejects_bad_requests(engine):
         engine.pcps([0], 0, 4e6, 0.0, 5000.0, 250.0, 2, 1)  # needs 8000 samples
     with pytest.raises(SdrError):
         engine.pcps([0], 0, 4e6, 0.0, 5000.0, 0.0)          # empty grid
-    with pytest.raises(SdrError):
-        engine.pcps([0], 0, 4.079e6, 0.0, 5000.0, 250.0)    # N = 4079 is prime
+
+
+@pytest.mark.parametrize("n_code,coh,noncoh", [(4079, 1, 1), (4079, 2, 2), (10007, 1, 1), (2 * 4099, 1, 2)])
+def test_pcps_code_lengths_with_large_prime_factors(engine, n_code, coh, noncoh):
+    """fs such that a code period is a prime (or 2 x prime) number of samples: no mixed-radix plan exists, NumPy uses
+    Bluestein, and so does the library (chirp-z over the next 2^a 3^b 5^c length).  Same peaks, same map."""
+    fs = n_code * 1000.0
+    total = n_code * coh * noncoh + 8
+    cap = (total + 7) // 8 * 8
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.code_slots(2)
+    engine.load_gps_code(0, 9)
+    engine.load_gps_code(1, 23)      # absent
+    engine.iq_synth([dict(prn=9, doppler=-1250.0, code_phase=611.7, phase=0.4, amp=8.0)], fs, 12.0, 77, 0, cap)
+    rf = orc.iq_to_complex(engine.iq_download(cap, 0))
+    pb, pc, pr, cmap = engine.pcps([0, 1], 3, fs, 0.0, 5000.0, 250.0, coh, noncoh, want_map=True)
+    x = rf[3:3 + n_code * coh * noncoh].reshape(1, -1)
+    for s, prn in enumerate((9, 23)):
+        m = orc.pcps_map(x, 0.0, fs, orc.code_spectrum(orc.gold_code(prn), fs), 5000.0, 250.0, n_code, coh, noncoh)
+        peak, ratio = orc.two_peak_compare(m, n_code, round(fs / orc.CODE_RATE))
+        assert [int(pb[s]), int(pc[s])] == peak
+        assert pr[s] == pytest.approx(ratio, rel=1e-9)
+        assert np.max(np.abs(cmap[s] - m)) <= 1e-9 * m.max()
+    assert pr[0] > 2.5 > pr[1]
 
 
 def test_pcps_randomised_stress(engine):
