@@ -385,7 +385,7 @@ def main():
 
     if rank == 0 and world == 1:
         got = plan.fetch()
-        ref, done, dt, rf = cpu_tracking_baseline(eng, items, min(len(items), N_CH * 400), args.cpu_seconds)
+        ref, done, dt, rf = cpu_tracking_baseline(eng, items, min(len(items), N_CH * 1000), args.cpu_seconds)
         scale = np.repeat(np.maximum(np.hypot(ref[:, 0::2], ref[:, 1::2]), 1.0), 2, axis=1)
         err = float(np.max(np.abs(got[:done] - ref) / scale))
         if err > 1e-6:
