@@ -91,8 +91,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                                                         const uint32_t* __restrict__ luts,
                                                         int lut_words, int lut_stride, int use_prefix,
                                                         int n_ch, int parts, unsigned long long* xchg,
-                                                        int* __restrict__ fault,
-                                                        sdr_track_epoch* __restrict__ traj_scratch) {
+                                                        int* __restrict__ fault) {
     extern __shared__ double smem[];
     double* red = smem;                                   // kWaves * 6 wave sums; reused by the cluster exchange
     EpochShared* sh = reinterpret_cast<EpochShared*>(red + red_doubles(THREADS));
@@ -332,10 +331,9 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             // state alias, and every statement becomes a dependent LDS round trip (measured: 2.7 us of them).
             sdr_track_state st = sh->st;
             const sdr_loop_cfg& cfg = sh->cfg;  // read-only: stays in LDS
-            // The epoch record is write-only global memory: the recording part writes the trajectory (or, with
-            // keep_traj = 0, one record per channel that is overwritten every epoch), the others a scratch slot.
-            sdr_track_epoch& rec = writer ? traj[keep_traj ? (size_t)ch * n_epochs + epoch : (size_t)ch]
-                                          : traj_scratch[(size_t)ch * kMaxParts + part];
+            // The epoch record is assembled in registers and stored once, and only by the recording part when a
+            // trajectory was asked for (its assembly then sinks into that branch: 3 % of the epoch).
+            sdr_track_epoch rec;
             rec.start_sample = st.current_sample;
             rec.n_samples = n;
             rec.carrier_hz_in = st.carrier_hz;
@@ -492,6 +490,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             sh->epochs_done = epoch + 1;
             publish(st, cfg);
             sh->st = st;
+            if (writer && keep_traj) traj[(size_t)ch * n_epochs + epoch] = rec;
           }
         }
         TRACK_MARK(4);
@@ -548,8 +547,7 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
     const size_t traj_bytes = traj ? (size_t)n_ch * n_epochs * sizeof(sdr_track_epoch) : 0;
     int rc = sdr_devbuf_reserve(e, &e->track_state, (size_t)n_ch * sizeof(sdr_track_state));
     if (!rc) rc = sdr_devbuf_reserve(e, &e->track_cfg, sizeof(sdr_loop_cfg));
-    const size_t traj_main = traj ? traj_bytes : (size_t)n_ch * sizeof(sdr_track_epoch);
-    if (!rc) rc = sdr_devbuf_reserve(e, &e->track_traj, traj_main + (size_t)n_ch * kMaxParts * sizeof(sdr_track_epoch));
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->track_traj, traj ? traj_bytes : sizeof(sdr_track_epoch));
     const size_t bits_bytes = nav_bits ? (size_t)n_ch * max_bits : 0;
     if (!rc && nav_bits) rc = sdr_devbuf_reserve(e, &e->track_bits, bits_bytes + (size_t)n_ch * sizeof(int32_t) + 16);
     if (rc) return rc;
@@ -564,7 +562,6 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
     const sdr_loop_cfg* d_cfg = (const sdr_loop_cfg*)e->track_cfg.ptr;
     sdr_track_epoch* d_traj = (sdr_track_epoch*)e->track_traj.ptr;
     int keep = traj ? 1 : 0;
-    sdr_track_epoch* d_traj_scratch = (sdr_track_epoch*)((char*)e->track_traj.ptr + traj_main);
     // exchange lines [n_ch][2 parities][8 parts][16 words] (tags zeroed: epoch tags start at 1), then the fault word
     const size_t xchg_bytes = (size_t)n_ch * 2 * kMaxParts * kXchgWords * sizeof(unsigned long long);
     if (int rc2 = sdr_devbuf_reserve(e, &e->track_xchg, xchg_bytes + 16)) return rc2;
@@ -596,7 +593,7 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
             // more than 64 KB of dynamic LDS has to be granted per kernel
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
             void* args[] = {&d_iq, &cap, &d_st, &d_cfg, &n_ep, &d_traj, &keep, &d_bits, &mb, &d_nbits, &d_luts,
-                            &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault, &d_traj_scratch};
+                            &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault};
             if (parts > 1)  // the parts of a cluster wait for each other: all workgroups must be resident
                 err = hipLaunchCooperativeKernel((const void*)kernel, dim3(n_ch * parts), dim3(threads), args,
                                                  (unsigned)shmem, e->stream);
