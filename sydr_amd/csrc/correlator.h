@@ -512,7 +512,7 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
             y0[t] = y;
             p0[t] = (int)cy;
             const double e = (cy - y) * inv_step[t];  // >= 0
-            const double fr = e - floor(e);
+            const double fr = __builtin_amdgcn_fract(e);  // v_fract_f64: e - floor(e)
             near |= fabs(fr - 0.5) > 0.5 - kNearInteger;
             const double ec = fmin(e, (double)(W - 1));
             nlead[t] = (int)ec + 1;
