@@ -24,3 +24,12 @@ def CN0_Beaulieu(ratio, N, T, old):
     lambda_c = 1 / (ratio / N)
     cn0 = lambda_c * (1 / T)
     return lowPassFilter(cn0, old, alpha=0.1)
+
+
+def CN0_NWPR(iPromptSum, qPromptSum, iPromptSum2, qPromptSum2, nbAccum=20, integrationPeriod=1e-3):
+    """Narrow-band / wide-band power ratio C/N0 estimate in dB-Hz (lockindicator.py:40-71; imported by both
+    reference plugins, used only in their commented-out alternatives)."""
+    narrow = iPromptSum**2 + qPromptSum**2
+    wide = iPromptSum2 + qPromptSum2
+    ratio = narrow / wide
+    return 10 * np.log10(1 / integrationPeriod * (ratio - 1) / (nbAccum - ratio))

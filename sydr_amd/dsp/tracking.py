@@ -90,3 +90,41 @@ def FLLassistedPLL_2ndOrder(phaseInput, freqInput, w0f, w0p, a2, integrationTime
     velMemory = update
     output += phaseInput * a2 * w0p
     return output, velMemory
+
+
+def FLLassistedPLL_3rdOrder(phaseInput, freqInput, w0f, w0p, a2, a3, b3, integrationTime, velMemory, accMemory):
+    """3rd-order PLL assisted by a 2nd-order FLL (tracking.py:283-327, [Kaplan 2006] p.180-182).
+    Returns (output, velMemory, accMemory)."""
+    acc_update = (phaseInput * w0p**3 + freqInput * w0f**2) * integrationTime
+    output = acc_update + accMemory
+    accMemory = acc_update
+    vel_update = (output + (phaseInput * a3 * w0p**2 + freqInput * a2 * w0f)) * integrationTime
+    output = vel_update + velMemory
+    velMemory = vel_update
+    output += phaseInput * b3 * w0p
+    return output, velMemory, accMemory
+
+
+def EPL_nonvector(rfData, code, samplingFrequency, carrierFrequency, remainingCarrier, remainingCode, codeStep,
+                  correlatorsSpacing):
+    """The reference's sample-by-sample formulation of EPL (tracking.py:65-88).  Its chip index is
+    ceil(remCode + spacing + idx*codeStep) -- the same integers as EPL's linspace except where rounding differs in the
+    last ulp -- so it is served by the same kernel."""
+    return EPL(rfData, code, samplingFrequency, carrierFrequency, remainingCarrier, remainingCode, codeStep,
+               correlatorsSpacing)
+
+
+def generateReplica(time, nbSamples, carrierFrequency, remCarrier):
+    """Carrier replica exp(1j*(-(f*2*pi*t) + rem)) over nbSamples and the phase left over for the next block
+    (tracking.py:8-17).  Host arithmetic: the kernels generate their replica in registers and never store it."""
+    t = np.asarray(time)[0:nbSamples + 1]
+    phase = -(carrierFrequency * 2.0 * np.pi * t) + remCarrier
+    return np.exp(1j * phase[:nbSamples]), phase[nbSamples] % (2 * np.pi)
+
+
+def getCorrelator(iSignal, qSignal, correlatorSpacing, code, remainingCode, codeStep, nbSamples):
+    """(I, Q) correlation of an already carrier-wiped signal with one tap of the code (tracking.py:21-35): the
+    correlator kernel with a zero-frequency carrier and a single tap."""
+    x = np.asarray(iSignal, dtype=np.float64)[:nbSamples] + 1j * np.asarray(qSignal, dtype=np.float64)[:nbSamples]
+    i_corr, q_corr = EPL(x, code, 1.0, 0.0, 0.0, remainingCode, codeStep, (correlatorSpacing,))
+    return i_corr, q_corr

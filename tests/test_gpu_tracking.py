@@ -312,3 +312,35 @@ def test_function_level_dropins_read_like_the_reference():
     ref = e["r20_out"]
     scale = np.repeat(np.hypot(ref[0::2], ref[1::2]), 2)
     assert np.all(np.abs(np.array(out) - ref) <= RTOL * scale)
+
+
+def test_legacy_function_surface_of_the_tracking_module(engine):
+    """generateReplica / getCorrelator / EPL_nonvector / the 3rd-order loop filter / CN0_NWPR of the reference's dsp
+    modules: same signatures, same numbers (checked against direct NumPy restatements of the reference formulas)."""
+    from sydr_amd.dsp import lockindicator as li
+    from sydr_amd.dsp import tracking as tr
+    rng = np.random.default_rng(8)
+    fs, n = 10e6, 10000
+    t = np.arange(n + 1) / fs
+    rep, rem = tr.generateReplica(t, n, 1234.5, 0.7)
+    ph = -(1234.5 * 2.0 * np.pi * t) + 0.7
+    assert np.array_equal(rep, np.exp(1j * ph[:n])) and rem == ph[n] % (2 * np.pi)
+    code = orc.pad_code(orc.gold_code(5))
+    i_sig, q_sig = rng.normal(0, 30, n), rng.normal(0, 30, n)
+    step = orc.CODE_RATE / fs
+    got = tr.getCorrelator(i_sig, q_sig, -0.5, code, 0.3, step, n)
+    idx = np.ceil(np.linspace(0.3 - 0.5, n * step + 0.3 - 0.5, n, endpoint=False)).astype(int)
+    want = (np.sum(code[idx] * i_sig), np.sum(code[idx] * q_sig))
+    assert got == pytest.approx(want, rel=1e-9, abs=1e-6)
+    x = i_sig + 1j * q_sig
+    a = tr.EPL_nonvector(x, code, fs, 800.0, 0.2, 0.3, step, (-0.5, 0.0, 0.5))
+    b = orc.epl(x, code, fs, 800.0, 0.2, 0.3, step, (-0.5, 0.0, 0.5))
+    assert a == pytest.approx(list(b), rel=1e-9, abs=1e-6)
+    out, vel, acc = tr.FLLassistedPLL_3rdOrder(0.1, -2.0, 10.0, 20.0, 1.414, 1.1, 2.4, 1e-3, 0.5, 0.25)
+    u1 = (0.1 * 20.0**3 + -2.0 * 10.0**2) * 1e-3
+    o1 = u1 + 0.25
+    u2 = (o1 + (0.1 * 1.1 * 20.0**2 + -2.0 * 1.414 * 10.0)) * 1e-3
+    assert (out, vel, acc) == (u2 + 0.5 + 0.1 * 2.4 * 20.0, u2, u1)
+    nb = (li.CN0_NWPR(400.0, 30.0, 9000.0, 1000.0))
+    np_ = (400.0**2 + 30.0**2) / (9000.0 + 1000.0)
+    assert nb == 10 * np.log10(1 / 1e-3 * (np_ - 1) / (20 - np_))
