@@ -55,3 +55,28 @@ class RFSignal:
         else:
             fid.close()
         return data
+
+    def readFileBySamples(self, nb_values, skip=0, keep_open=False):
+        """Interleaved I,Q integers for `nb_values` samples, skipping `skip` samples first (rfsignal.py:138-181)."""
+        count = int(2 * nb_values)
+        offset = int(np.dtype(self.fileDataType).itemsize * skip * 2)
+        fid = open(self.filepath, 'rb') if self.file_id is None else self.file_id
+        data = np.fromfile(fid, self.fileDataType, offset=offset, count=count)
+        if keep_open:
+            self.file_id = fid
+        else:
+            fid.close()
+        return data
+
+    def closeFile(self):
+        if self.file_id is None:
+            raise Warning("File was already close.")
+        self.file_id.close()
+        self.file_id = None
+
+    def getCurrentSampleIndex(self):
+        """Index of the next sample the open file will deliver (rfsignal.py:195-203: byte position / 2 for I,Q files of
+        one byte per component, as the reference computes it)."""
+        if self.file_id is None:
+            raise Warning("Signal file not open, cannot return current cursor position.")
+        return int(self.file_id.tell() / 2)

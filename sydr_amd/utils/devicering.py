@@ -30,6 +30,7 @@ class CircularBuffer:
         engine.iq_alloc(self.maxSize, self.fmt)
         self.full = False
         self.idxWrite = 0
+        self.idxRead = 0
         self.size = 0
 
     # ---------------------------------------------------------------- writes (circularbuffer.py:54-108)
@@ -66,12 +67,16 @@ class CircularBuffer:
             if self.size > self.maxSize:
                 self.size = self.maxSize
 
+    def shiftIdxRead(self, shift: int):
+        self.idxRead += shift
+        self.idxRead %= self.maxSize
+
     # ---------------------------------------------------------------- reads (circularbuffer.py:114-148)
     def getSlice(self, idxStart: int = None, samplesRequired: int = 0):
         """Host copy of a slice as complex128 (1, n) -- diagnostics / compatibility only; the kernels
         never need it."""
         if idxStart is None:
-            idxStart = 0
+            idxStart = self.idxRead
         raw = self.engine.iq_download(int(samplesRequired), int(idxStart) % self.maxSize)
         raw = raw.astype(np.float64)
         return (raw[0::2] + 1j * raw[1::2]).reshape(1, -1)

@@ -299,3 +299,26 @@ def test_serial_search_plugin_reproduces_reference():
     for p, row in zip(trk, g["ss_epochs"]):
         assert [p["i_early"], p["q_early"], p["i_prompt"], p["q_prompt"], p["i_late"], p["q_late"],
                 p["carrier_frequency"], p["code_frequency"]] == list(row)
+
+
+def test_rfsignal_reads_the_file_like_the_reference(tmp_path):
+    """RFSignal keeps the reference's method surface (rfsignal.py): chunked getMilliseconds, readFile / readFileBySamples
+    with skip, closeFile, getCurrentSampleIndex -- handing out raw interleaved integers (or complex128 on request)."""
+    fs = 4e6
+    raw = (np.arange(2 * 4000 * 130) % 251 - 125).astype(np.int8)
+    path = tmp_path / "iq.bin"
+    raw.tofile(path)
+    sig = RFSignal(dict(filepath=str(path), sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0, data_size=8))
+    a = sig.getMilliseconds(1)
+    b = sig.getMilliseconds(2, raw=False)
+    assert np.array_equal(a, raw[:8000])
+    assert np.array_equal(b, raw[8000:24000:2] + 1j * raw[8001:24000:2])
+    assert sig.getCurrentSampleIndex() == 120 * 4000          # one 120 ms chunk has been read
+    with pytest.raises(ValueError):
+        sig.getMilliseconds(7)                                   # not a divisor of the chunk length
+    assert np.array_equal(sig.readFileBySamples(10, skip=0, keep_open=True), raw[2 * 120 * 4000:2 * 120 * 4000 + 20])
+    sig.closeFile()
+    with pytest.raises(Warning):
+        sig.closeFile()
+    assert np.array_equal(sig.readFile(1, skip=5), raw[10:8010])
+    assert np.array_equal(sig.readFileBySamples(6, skip=3), raw[6:18])
