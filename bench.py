@@ -99,7 +99,7 @@ def cpu_tracking_baseline(engine, items, n_items, budget_s):
 def closed_loop_leg(eng, items, n_epochs, n_ch=N_CH):
     """On-device loop closure (persistent workgroups, Kaplan loops): latency-bound, so it is reported beside,
     not instead of, the open-loop correlator throughput.  n_ch = 32: each channel on a cluster of 8 CUs (lowest
-    latency); n_ch = 512: channels beyond 32 re-track the same 32 satellites, two workgroups per CU (highest
+    latency); n_ch = 768: channels beyond 32 re-track the same 32 satellites, three workgroups per CU (highest
     aggregate channel x real-time rate)."""
     from sydr_amd._lib import LoopCfg, TrackState
     cfg = LoopCfg()
@@ -424,7 +424,7 @@ def main():
                                      "peaks_match_oracle": bool(ok)}
     if rank == 0 and world == 1 and not args.no_closed_loop:
         result["closed_loop"] = closed_loop_leg(eng, items, min(n_epochs, args.closed_loop_epochs))
-        result["closed_loop_dense"] = closed_loop_leg(eng, items, min(n_epochs, args.closed_loop_epochs, 1000), n_ch=512)
+        result["closed_loop_dense"] = closed_loop_leg(eng, items, min(n_epochs, args.closed_loop_epochs, 1000), n_ch=768)
     plan.close()
     eng.close()
     if rank == 0:

@@ -510,6 +510,26 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
 
 }  // namespace
 
+#ifdef SDR_TRACK_DENSE_TU
+// This translation unit (track_dense.hip) carries only the variant of the kernel for more channels than CUs:
+// 256-thread workgroups capped at 168 registers so that THREE share a CU.  It is compiled with
+// -mllvm -disable-machine-licm: hoisting the fp64 polynomial constants of sincos / atan / division out of the
+// epoch loop parks ~80 of them in VGPRs for the whole kernel (256 instead of 173 registers).
+hipError_t sdr_track_dense_launch(int fmt, int n_ch, size_t shmem, hipStream_t stream, void** args) {
+    auto launch = [&](auto kernel) {
+        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        return hipLaunchKernel((const void*)kernel, dim3(n_ch), dim3(256), args, shmem, stream);
+    };
+    switch (fmt) {
+        case SDR_FMT_CI8: return launch(track_kernel<SDR_FMT_CI8, 256, 3>);
+        case SDR_FMT_CI16: return launch(track_kernel<SDR_FMT_CI16, 256, 3>);
+        case SDR_FMT_CF32: return launch(track_kernel<SDR_FMT_CF32, 256, 3>);
+        default: return launch(track_kernel<SDR_FMT_CF64, 256, 3>);
+    }
+}
+#else
+hipError_t sdr_track_dense_launch(int fmt, int n_ch, size_t shmem, hipStream_t stream, void** args);  // track_dense.hip
+
 extern "C" {
 
 int sdr_track_cluster(sdr_engine* e, int parts) {
@@ -575,8 +595,9 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
 
     // One attempt with `parts` workgroups per channel.
     auto attempt = [&](int parts, bool* too_big) -> hipError_t {
-        // more channels than CUs: smaller workgroups, two of which share a CU, so that one channel's loop
-        // update overlaps another's correlation (measured: 512 channels 20.2 -> 14.9 us per epoch)
+        // more channels than CUs: smaller workgroups, two or three of which share a CU, so that one channel's
+        // loop update overlaps another's correlation (measured: 512 channels 20.2 -> 14.6 us per epoch,
+        // 768 channels 22.3 -> 18.6)
         const bool dense = parts == 1 && n_ch > e->n_cus;
         const int threads = (parts >= 2 || dense) ? 256 : 512;
         const size_t shmem_base = (size_t)red_doubles(threads) * sizeof(double) + sizeof(EpochShared) +
@@ -600,10 +621,14 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
             else
                 err = hipLaunchKernel((const void*)kernel, dim3(n_ch), dim3(threads), args, shmem, e->stream);
         };
+        if (dense) {
+            void* args[] = {&d_iq, &cap, &d_st, &d_cfg, &n_ep, &d_traj, &keep, &d_bits, &mb, &d_nbits, &d_luts,
+                            &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault};
+            return sdr_track_dense_launch(e->iq_fmt, n_ch, shmem, e->stream, args);
+        }
         auto by_threads = [&](auto fmt) {
             constexpr int F = decltype(fmt)::value;
-            if (dense) launch(track_kernel<F, 256, 2>);
-            else if (threads == 256) launch(track_kernel<F, 256, 1>);
+            if (threads == 256) launch(track_kernel<F, 256, 1>);
             else launch(track_kernel<F, 512, 2>);
         };
         switch (e->iq_fmt) {
@@ -659,3 +684,4 @@ int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, con
 }
 
 }  // extern "C"
+#endif  // SDR_TRACK_DENSE_TU

@@ -166,6 +166,32 @@ def test_closed_loop_at_25_mhz_matches_the_oracle_loops(engine, kind, parts):
     assert np.hypot(tr["corr"][-1, 2], tr["corr"][-1, 3]) > np.hypot(tr["corr"][-1, 0], tr["corr"][-1, 1])
 
 
+def test_closed_loop_more_channels_than_compute_units(engine):
+    """Beyond one channel per CU the launcher switches to the 256-thread kernel built for three workgroups per CU.
+    260 channels tracking the golden stream from the same state: every one reproduces the reference trajectory."""
+    g, fs, raw = trajectory_iq("g6b_kaplan_strong.npz")
+    c = kaplan_strong_cfg(g)
+    ref, acq = g["kaplan_epochs"], g["kaplan_acq"]
+    n = raw.size // 2
+    engine.iq_alloc((n + 7) // 8 * 8, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(2)
+    engine.load_gps_code(1, 7)
+    n_ch, epochs = 260, 400
+    states = [initial_state(1, fs, acq[3], int(acq[5]), c, slot=1) for _ in range(n_ch)]
+    end, traj = engine.track_closed_loop(states, loop_cfg(1, fs, c), epochs)
+    ring = 100 * int(fs * 1e-3)
+    for k in (0, 137, 259):
+        tr = traj[k]
+        assert np.array_equal(tr["start_sample"] % ring, ref[:epochs, 0].astype(np.int64))
+        assert np.array_equal(tr["n_samples"], ref[:epochs, 1].astype(np.int32))
+        assert np.array_equal(tr["lock_state"], ref[:epochs, 22].astype(np.int32))
+        assert np.array_equal(tr["track_flags"], ref[:epochs, 23].astype(np.int32))
+        assert np.array_equal(tr["nav_bit"], ref[:epochs, 24].astype(np.int32))
+        assert close(tr["carrier_hz"], ref[:epochs, 15]) and close(tr["code_hz"], ref[:epochs, 16])
+    assert traj[5].tobytes() == traj[200].tobytes()      # same inputs, same kernel: bitwise the same
+
+
 def test_closed_loop_many_channels_and_resume(engine):
     """8 channels in one launch == each channel alone; 2 x 100 epochs == 200 epochs (state round trip)."""
     fs, ms = 4e6, 260
