@@ -192,6 +192,57 @@ def test_closed_loop_more_channels_than_compute_units(engine):
     assert traj[5].tobytes() == traj[200].tobytes()      # same inputs, same kernel: bitwise the same
 
 
+def test_closed_loop_across_the_ring_seam_at_25_mhz(engine):
+    """A 100 ms ring (the reference's size) fed block by block: epochs that straddle the end of the ring take the
+    per-sample correlator, the others the boundary variant -- the trajectory is that of the uninterrupted stream."""
+    fs, prn, ms_total = 25e6, 19, 260
+    spms = int(fs * 1e-3)
+    n = ms_total * spms
+    sat = dict(prn=prn, doppler=-3100.0, code_phase=88.8, phase=0.7, amp=9.0)
+    engine.iq_alloc(n, FMT_CI8)
+    engine.code_slots(1)
+    engine.load_gps_code(0, prn)
+    engine.iq_synth([sat], fs, 14.0, 4242, 0, n)
+    raw = engine.iq_download(n, 0).copy()
+    rf = orc.iq_to_complex(raw)
+    pb, pc, _, _ = engine.pcps([0], 0, fs, 0.0, 5000.0, 250.0, 1, 1)
+    n_code = orc.samples_per_code(fs)
+    n0 = orc.required_samples(0.0, orc.CODE_RATE / fs)
+    carrier, _, cur = orc.post_acquisition(0.0, 5000.0, 250.0, [int(pb[0]), int(pc[0])], 0, n_code, n0)
+    loop = orc.KaplanLoop(fs, orc.gold_code(prn), KAPLAN_CFG, carrier, cur)
+    ref = [loop.step(rf[loop.current_sample:loop.current_sample + loop.n]) for _ in range(240)]
+    # now the same through a 100 ms ring, 80 epochs at a time
+    ring = 100 * spms
+    engine.iq_alloc(ring, FMT_CI8)
+    engine.code_slots(1)
+    engine.load_gps_code(0, prn)
+    engine.iq_upload(raw[:2 * ring], 0)
+    written = ring                                   # samples of the stream that have entered the ring
+    st = initial_state(1, fs, carrier, cur, KAPLAN_CFG)
+    cfg = loop_cfg(1, fs, KAPLAN_CFG)
+    got = []
+    for block in range(3):
+        (st,), traj = engine.track_closed_loop([st], cfg, 80)
+        got.append(traj[0])
+        consumed = int(st.current_sample)            # absolute stream position (the kernel wraps ring addresses itself)
+        # refill everything behind the channel: the next 80 epochs need ~80.1 ms ahead of it
+        new_written = min(n, consumed + ring - spms)
+        for a in range(written, new_written, spms):  # 1 ms pieces, each placed at its ring position
+            b = min(a + spms, new_written)
+            engine.iq_upload(raw[2 * a:2 * b], a % ring)
+        written = new_written
+    tr = np.concatenate(got)
+    assert np.array_equal(tr["start_sample"], [r["start"] for r in ref])
+    assert np.array_equal(tr["n_samples"], [r["n"] for r in ref])
+    corr_ref = np.array([r["corr"] for r in ref])
+    mag = np.maximum(np.hypot(corr_ref[:, 2], corr_ref[:, 3]), 1.0)
+    assert np.all(np.hypot(tr["corr"][:, 2] - corr_ref[:, 2], tr["corr"][:, 3] - corr_ref[:, 3]) <= RTOL * mag)
+    assert close(tr["carrier_hz"], [r["carrier_hz"] for r in ref]) and close(tr["code_hz"], [r["code_hz"] for r in ref])
+    assert np.array_equal(tr["lock_state"], [r["lock_state"] for r in ref])
+    wraps = sum((int(s) % ring) + int(m) > ring for s, m in zip(tr["start_sample"], tr["n_samples"]))
+    assert wraps >= 2                                # the seam was crossed (twice in 240 ms)
+
+
 def test_closed_loop_many_channels_and_resume(engine):
     """8 channels in one launch == each channel alone; 2 x 100 epochs == 200 epochs (state round trip)."""
     fs, ms = 4e6, 260
