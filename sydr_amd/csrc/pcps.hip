@@ -528,6 +528,40 @@ __device__ __forceinline__ double2* lds_fft(double2* a, double2* b, int Nsub, co
     return in;
 }
 
+// The same transform with the radix sequence known at compile time (every index constant folds: no
+// runtime division, no radix switch, twiddle strides are immediates).
+template <bool INV, int T, int NSUB, int NS, int R0, int... Rs>
+__device__ __forceinline__ double2* lds_fft_static(double2* in, double2* out, const double2* wsub) {
+    constexpr int pitch = T + 1;
+    constexpr int nbf = NSUB / R0;
+    constexpr int tws = NSUB / (NS * R0);
+    for (int bf = threadIdx.x; bf < nbf * T; bf += kThreads) {
+        const int j = bf / T, c = bf - j * T;
+        lds_butterfly<R0, INV>(in, out, j, c, pitch, nbf, NS, tws, wsub, div_magic(NS));
+    }
+    __syncthreads();
+    if constexpr (sizeof...(Rs) == 0)
+        return out;
+    else
+        return lds_fft_static<INV, T, NSUB, NS * R0, Rs...>(out, in, wsub);
+}
+
+// Sub-transform lengths of the usual sampling rates (N = 4000: 50 x 80, 10000: 100 x 100, 25000: 125 x 200,
+// 50000: 200 x 250) run the compile-time version -- 13 % off a whole acquisition at N = 25000; the sequences are
+// those factor_radices() produces, so both versions do the same arithmetic in the same order.
+template <bool INV, int T>
+__device__ __forceinline__ double2* lds_fft_auto(double2* a, double2* b, int Nsub, const Radices& rad, const double2* wsub) {
+    switch (Nsub) {
+        case 50: return lds_fft_static<INV, T, 50, 1, 5, 5, 2>(a, b, wsub);
+        case 80: return lds_fft_static<INV, T, 80, 1, 5, 8, 2>(a, b, wsub);
+        case 100: return lds_fft_static<INV, T, 100, 1, 5, 5, 4>(a, b, wsub);
+        case 125: return lds_fft_static<INV, T, 125, 1, 5, 5, 5>(a, b, wsub);
+        case 200: return lds_fft_static<INV, T, 200, 1, 5, 5, 8>(a, b, wsub);
+        case 250: return lds_fft_static<INV, T, 250, 1, 5, 5, 5, 2>(a, b, wsub);
+        default: return lds_fft<INV, T>(a, b, Nsub, rad, wsub);
+    }
+}
+
 // Kernel A: T adjacent columns n2 of one transform.  Dynamic LDS: 2 * N1*(T+1) + N1 double2.
 template <bool INV, int LOAD, int FMT, int T>
 __global__ __launch_bounds__(kThreads) void fft4_cols_kernel(const PassArgs a, int N1, int N2, const Radices rad,
@@ -546,7 +580,7 @@ __global__ __launch_bounds__(kThreads) void fft4_cols_kernel(const PassArgs a, i
         bufA[n1 * pitch + c] = n2 < N2 ? load_elem<LOAD, FMT, INV>(a, batch, N2 * n1 + n2) : make_double2(0.0, 0.0);
     }
     __syncthreads();
-    const double2* res = lds_fft<INV, T>(bufA, bufB, N1, rad, wsub);
+    const double2* res = lds_fft_auto<INV, T>(bufA, bufB, N1, rad, wsub);
     for (int e = threadIdx.x; e < N1 * T; e += kThreads) {
         const int k1 = e / T, c = e - k1 * T;
         const int n2 = n2_0 + c;
@@ -577,7 +611,7 @@ __global__ __launch_bounds__(kThreads) void fft4_rows_kernel(const PassArgs a, i
         bufA[n2 * pitch + c] = k1 < N1 ? Z[((size_t)batch * N1 + k1) * N2 + n2] : make_double2(0.0, 0.0);
     }
     __syncthreads();
-    const double2* res = lds_fft<INV, T>(bufA, bufB, N2, rad, wsub);
+    const double2* res = lds_fft_auto<INV, T>(bufA, bufB, N2, rad, wsub);
     for (int e = threadIdx.x; e < N2 * T; e += kThreads) {
         const int k2 = e / T, c = e - k2 * T;
         const int k1 = k1_0 + c;
