@@ -580,12 +580,17 @@ __global__ __launch_bounds__(kThreads) void fft4_cols_kernel(const PassArgs a, i
         bufA[n1 * pitch + c] = n2 < N2 ? load_elem<LOAD, FMT, INV>(a, batch, N2 * n1 + n2) : make_double2(0.0, 0.0);
     }
     __syncthreads();
-    const double2* res = lds_fft_auto<INV, T>(bufA, bufB, N1, rad, wsub);
+    double2* res = lds_fft_auto<INV, T>(bufA, bufB, N1, rad, wsub);
+    // Twiddle W_N^(n2*k1) = W_N^(n2_0*k1) * W_N^(c*k1): the first factor is one scattered table read per ROW
+    // (kept in the now free wsub), the second comes from the first T*N1 entries of the table -- cache resident --
+    // instead of one scattered read per element.
+    for (int m = threadIdx.x; m < N1; m += kThreads) wsub[m] = a.tw[(size_t)n2_0 * m];  // n2_0*m < N
+    __syncthreads();
     for (int e = threadIdx.x; e < N1 * T; e += kThreads) {
         const int k1 = e / T, c = e - k1 * T;
         const int n2 = n2_0 + c;
         if (n2 < N2) {
-            double2 w = a.tw[(size_t)n2 * k1];  // n2*k1 < N
+            double2 w = cmul(wsub[k1], a.tw[c * k1]);
             if (INV) w.y = -w.y;
             Z[((size_t)batch * N1 + k1) * N2 + n2] = cmul(res[k1 * pitch + c], w);
         }
