@@ -75,6 +75,14 @@ struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind 
     int epochs_done;
     int bits_this_run;
     int fault;                 // a peer part never showed up: leave the epoch loop (reported to the host)
+    // what the three update roles hand to each other (written before an epoch's first barrier, read after it)
+    double corr[2 * kTaps];    // this epoch's correlator totals, for the roles on waves 1 and 2
+    double fll_bw, pll_bw;     // Kaplan bandwidths chosen by the lock-state machine, for the carrier loop
+    int lock_state;            // lock state the NEXT epoch's discriminators run under
+    int c_code_counter, l_code_counter, l_bits_run;  // private copies of the roles on waves 0 and 2
+    int stop_code, stop_carrier;  // the next epoch would leave the staged replica / the ring, or the carrier NCO is not finite
+    double smin, smax;         // extreme tap offsets over both tap sets (constant for the run)
+    double l_ipp, l_qpp;       // the lock role's copy of the previous prompt (the carrier role owns st.i/q_prompt_prev)
     sdr_track_state st;  // lane 0's working copy lives in LDS, not in 1024 x VGPRs
     sdr_loop_cfg cfg;
 };
@@ -121,6 +129,9 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         sh->epochs_done = 0;
         sh->bits_this_run = 0;
         sh->fault = 0;
+        sh->fll_bw = states[ch].fll_bw;
+        sh->pll_bw = states[ch].pll_bw;
+        sh->lock_state = states[ch].lock_state;
     }
     const int slot = states[ch].code_slot;
     stage_lut<THREADS>(lut, luts + (size_t)slot * lut_stride, lut_words, tid);
@@ -134,36 +145,43 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     if (tid == 0 && ch == 0 && part == 0) for (int k = 0; k < 32; ++k) g_track_phase[k] = 0;
     __syncthreads();
 #endif
-    // Lane 0 hands the next epoch's NCO parameters to the workgroup (from registers: the state struct in
-    // LDS is only touched at the start and the end of a loop update).
-    auto publish = [&](const sdr_track_state& s, const sdr_loop_cfg& c) {
-        const double* sp = s.spacing_sel ? c.spacing_narrow : c.spacing_wide;
-        double smin = sp[0], smax = sp[0];
-        for (int t = 1; t < kTaps; ++t) {
-            smin = fmin(smin, sp[t]);
-            smax = fmax(smax, sp[t]);
-        }
-        // The replica LUT and the ring bound what an epoch may touch; a loop that has run
-        // away (loss of lock) stops here instead of reading out of range.
-        const double lo = ceil(s.rem_code + smin);
-        const double hi = ceil(s.code_step * (double)s.n_samples + s.rem_code + smax);
-        const bool ok = s.n_samples > 0 && (int64_t)s.n_samples <= capacity && s.code_step > 0.0 &&
-                        lo >= -(double)SDR_LUT_PAD && hi <= (double)(lut_words - SDR_LUT_PAD - 2) &&
-                        s.carrier_hz == s.carrier_hz && fabs(s.carrier_hz) < 1e9 && s.current_sample >= 0;
-        sh->stop = (ok && !sh->fault) ? 0 : 1;
-        sh->ep.start_sample = s.current_sample;
-        sh->ep.n = s.n_samples;
-        sh->ep.carrier_hz = s.carrier_hz;
-        sh->ep.rem_carrier = s.rem_carrier;
-        sh->ep.rem_code = s.rem_code;
-        sh->ep.code_step = s.code_step;
-        for (int t = 0; t < kTaps; ++t) sh->spacing[t] = sp[t];
-        sh->dphi = carrier_step(s.carrier_hz, fs);
+    // The loop update is split over three waves by dependency (see below); each role owns a disjoint set of fields of
+    // the state's LDS copy (loaded into registers for the duration of its update only: carried across the correlation
+    // they cost ~50 VGPRs and spill) and publishes its part of the next epoch's parameters.
+    const int role = tid >> 6, rlane = tid & 63;
+    const sdr_track_state s_init = states[ch];
+    // The replica LUT and the ring bound what an epoch may touch; a loop that has run away (loss of lock) stops
+    // instead of reading out of range.  Checked by the role that produces the values, for the epoch it announces.
+    auto code_out_of_range = [&](int64_t start, int n, double rem_code, double code_step) {
+        const double lo = ceil(rem_code + sh->smin);
+        const double hi = ceil(code_step * (double)n + rem_code + sh->smax);
+        return !(n > 0 && (int64_t)n <= capacity && code_step > 0.0 && lo >= -(double)SDR_LUT_PAD &&
+                 hi <= (double)(lut_words - SDR_LUT_PAD - 2) && start >= 0);
     };
-    if (tid == 0) {
-        const sdr_track_state s0 = states[ch];
-        const sdr_loop_cfg c0 = *cfg_ptr;
-        publish(s0, c0);
+    auto carrier_bad = [&](double hz) { return !(hz == hz && fabs(hz) < 1e9); };
+    if (tid == 0) {  // parameters of the first epoch
+        double smin = cfg_ptr->spacing_wide[0], smax = smin;
+        for (int t = 0; t < kTaps; ++t) {
+            smin = fmin(smin, fmin(cfg_ptr->spacing_wide[t], cfg_ptr->spacing_narrow[t]));
+            smax = fmax(smax, fmax(cfg_ptr->spacing_wide[t], cfg_ptr->spacing_narrow[t]));
+        }
+        sh->smin = smin;
+        sh->smax = smax;
+        sh->stop_code = code_out_of_range(s_init.current_sample, s_init.n_samples, s_init.rem_code, s_init.code_step) ? 1 : 0;
+        sh->stop_carrier = carrier_bad(s_init.carrier_hz) ? 1 : 0;
+        const double* sp = s_init.spacing_sel ? cfg_ptr->spacing_narrow : cfg_ptr->spacing_wide;
+        sh->ep.start_sample = s_init.current_sample;
+        sh->ep.n = s_init.n_samples;
+        sh->ep.carrier_hz = s_init.carrier_hz;
+        sh->ep.rem_carrier = s_init.rem_carrier;
+        sh->ep.rem_code = s_init.rem_code;
+        sh->ep.code_step = s_init.code_step;
+        for (int t = 0; t < kTaps; ++t) sh->spacing[t] = sp[t];
+        sh->dphi = carrier_step(s_init.carrier_hz, fs);
+        sh->c_code_counter = sh->l_code_counter = s_init.code_counter;
+        sh->l_ipp = s_init.i_prompt_prev;
+        sh->l_qpp = s_init.q_prompt_prev;
+        sh->l_bits_run = 0;
     }
     for (int epoch = 0; epoch < n_epochs; ++epoch) {
         TRACK_MARK(5);
@@ -172,7 +190,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
 #ifdef SDR_TRACE_TRACK
         const unsigned long long wave_mark_ = wall_clock64();
 #endif
-        if (sh->stop) break;
+        if (sh->fault | sh->stop_code | sh->stop_carrier) break;
         // What comes out of LDS is the same in every lane, but only readfirstlane tells the compiler so:
         // as scalars the epoch parameters (and everything derived from them: group counts, ring positions,
         // linspace constants) live in SGPRs and are computed on the scalar unit -- ~100 VGPRs per lane.
@@ -188,6 +206,10 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             ep.code_step = uniform(v.code_step);
         }
         const double dphi = uniform(sh->dphi);
+        // what the carrier loop needs from the state machine's previous decision (captured now: the lock role
+        // rewrites these while the carrier role is still running)
+        const double cur_fll_bw = uniform(sh->fll_bw), cur_pll_bw = uniform(sh->pll_bw);
+        const int cur_lock_state = __builtin_amdgcn_readfirstlane(sh->lock_state);
         EpochConsts<kTaps> K;
         compute_constants<kTaps>(K, ep, sh->spacing, dphi, cluster_lanes);
         TRACK_MARK(1);
@@ -241,7 +263,6 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             if (!done) {
                 if (tid == 0) {
                     sh->fault = 1;
-                    sh->stop = 1;
                     *fault = 1;
                 }
             } else {
@@ -260,251 +281,296 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         }
         TRACK_MARK(6);
 
-        // Loop update, wave 0.  Lanes 0..5 hold [IE,QE,IP,QP,IL,QL]; every lane of the wave gets all six.
-        // The update is scalar arithmetic whose cost is the LATENCY of ~15 fp64 divisions, two square
-        // roots and two arctangents.  The ones that depend only on the correlator outputs and the old
-        // state are evaluated side by side, one per lane, in a single pass each (same IEEE operations on
-        // the same operands as the reference's statements, so the results are bit-identical to doing them
-        // one after the other); lane 0 then runs what is left of the reference's sequence.
-        if (tid < 64 && !sh->fault) {
-            double corr[2 * kTaps];
-#pragma unroll
-            for (int k = 0; k < 2 * kTaps; ++k) corr[k] = __shfl(total, k, 64);
-            const double ie = corr[0], qe = corr[1], ip = corr[2], qp = corr[3], il = corr[4], ql = corr[5];
-            const int n = st.n_samples;
+        // Loop update.  The reference's per-epoch sequence is scalar arithmetic whose cost is instruction LATENCY
+        // (~15 fp64 divisions, two square roots, two arctangents, a float modulo, ~1250 instructions when one lane
+        // does it all).  It splits into three chains that only meet through the previous epoch's results:
+        //   wave 0  carrier loop : FLL/PLL discriminators, carrier filter, carrier NCO        (kaplan:405-447,506-534)
+        //   wave 1  code loop    : DLL discriminator, code filter, code NCO, next epoch length (kaplan:451-461,506-534)
+        //   wave 2  lock role    : lock indicators, C/N0, lock-state machine, flags, bit sync, nav bits (kaplan:465-619)
+        // Each wave evaluates its divisions / roots / arctangents side by side, one per lane (same IEEE operations on
+        // the same operands as the reference's statements: bit-identical), then lane 0 runs the rest of its chain and
+        // publishes its share of the next epoch's parameters.
+        if (tid < 2 * kTaps) sh->corr[tid] = total;
+        __syncthreads();
+        TRACK_MARK(7);
+        if (!sh->fault && role < 3) {
+            const double ie = sh->corr[0], qe = sh->corr[1], ip = sh->corr[2], qp = sh->corr[3], il = sh->corr[4], ql = sh->corr[5];
+            const int n = ep.n;
             const bool kaplan = cfg.loop_kind != 0;
-            const double ipp = st.i_prompt_prev, qpp = st.q_prompt_prev;
-
-            // pass 1: square roots (lane 2: early, lane 3: late envelope; tracking.py:120-129)
-            const double env = sqrt(tid == 3 ? il * il + ql * ql : ie * ie + qe * qe);
-            const double env_e = lane_value(env, 2), env_l = lane_value(env, 3);
-            // pass 2: one division per lane
-            const double pw = ip * ip + qp * qp;
-            double num = 0.0, den = 1.0;
-            switch (tid) {
-                case 0: num = qp, den = ip; break;                                   // atan(qP/iP): Costas PLL, FLL
-                case 1: num = qpp, den = ipp; break;                                 // atan(qP'/iP'): FLL (tracking.py:156-176)
-                case 2: num = env_e - env_l, den = env_e + env_l; break;             // DLL NNEML
-                case 3: {                                                            // FLL lock (lockindicator.py)
-                    double v = ip * ipp - qp * qpp;
-                    v *= np_sign(ip * ipp + qp * qpp);
-                    num = v, den = pw;
-                    break;
+            sdr_track_epoch* rec = (writer && keep_traj) ? traj + ((size_t)ch * n_epochs + epoch) : nullptr;
+            if (role == 0) {
+                // ------------------------------------------------------------------ carrier loop
+                double num = 0.0, den = 1.0;
+                switch (rlane) {
+                    case 0: num = qp, den = ip; break;                    // atan(qP/iP): Costas PLL, FLL (tracking.py:133-176)
+                    case 1: num = st.q_prompt_prev, den = st.i_prompt_prev; break;  // atan(qP'/iP')
+                    case 2: num = cur_fll_bw, den = kW0Bw1; break;
+                    case 3: num = cur_pll_bw, den = kW0Bw2; break;
+                    case 4:                                               // carrier NCO advance over the epoch
+                        num = kaplan ? ep.carrier_hz * kGpsTwoPi * (double)n : ep.carrier_hz * 2.0 * M_PI * (double)n;
+                        den = fs;
+                        break;
+                    case 5: num = cfg.pll_tau2, den = cfg.pll_tau1; break;  // (Borre PLL filter, tracking.py:180-186)
+                    case 6: num = cfg.pll_pdi, den = cfg.pll_tau1; break;
+                    default: break;
                 }
-                case 4: num = ip * ip - qp * qp, den = pw; break;                    // PLL lock
-                case 5: {                                                            // C/N0 (Beaulieu) ratio term
-                    const double d = fabs(ip) - fabs(qp);
-                    num = pw, den = d * d;
-                    break;
-                }
-                case 6: num = st.fll_bw, den = kW0Bw1; break;
-                case 7: num = st.pll_bw, den = kW0Bw2; break;
-                case 8: num = cfg.dll_tau2, den = cfg.dll_tau1; break;               // BorreLoopFilter (tracking.py:180-186)
-                case 9: num = kaplan ? cfg.dll_pdi * 1.0 : cfg.dll_pdi, den = cfg.dll_tau1; break;
-                case 10:                                                             // carrier NCO advance over the epoch
-                    num = kaplan ? st.carrier_hz * kGpsTwoPi * (double)n : st.carrier_hz * 2.0 * M_PI * (double)n;
-                    den = fs;
-                    break;
-                case 11: num = cfg.pll_tau2, den = cfg.pll_tau1; break;              // (Borre PLL filter)
-                case 12: num = cfg.pll_pdi, den = cfg.pll_tau1; break;
-                default: break;
-            }
-            const double quot = num / den;
-            // pass 3: arctangents (lanes 0, 1)
-            const double at = atan(quot);
-            const double at_now = lane_value(at, 0), at_prev = lane_value(at, 1);
-            double fll_err = at_now - at_prev;
-            if (fll_err != fll_err) fll_err = 0.0;
-            if (fll_err >= kGpsHalfPi) fll_err = fll_err - kGpsPi;
-            else if (fll_err <= -kGpsHalfPi) fll_err = fll_err + kGpsPi;
-            // pass 4: lane 0: atan/2pi (pll_costas), lane 1: err/dt;  pass 5: lane 1: (err/dt)/2pi (fll_atan)
-            const double q4 = (tid == 1 ? fll_err : at_now) / (tid == 1 ? 1e-3 : kGpsTwoPi);
-            const double q5 = q4 / kGpsTwoPi;
-            const double costas = lane_value(q4, 0), fll_full = lane_value(q5, 1);
-            const double dll_nn = lane_value(quot, 2), fll_lock_v = lane_value(quot, 3), pll_lock_v = lane_value(quot, 4);
-            const double cn0_term = lane_value(quot, 5), w0f = lane_value(quot, 6), w0p = lane_value(quot, 7);
-            const double dll_r1 = lane_value(quot, 8), dll_r2 = lane_value(quot, 9), carrier_adv = lane_value(quot, 10);
-            const double pll_r1 = lane_value(quot, 11), pll_r2 = lane_value(quot, 12);
-
-          if (tid == 0) {
-            // Work on register copies: through references the compiler has to assume that the record and the
-            // state alias, and every statement becomes a dependent LDS round trip (measured: 2.7 us of them).
-            sdr_track_state st = sh->st;
-            const sdr_loop_cfg& cfg = sh->cfg;  // read-only: stays in LDS
-            // The epoch record is assembled in registers and stored once, and only by the recording part when a
-            // trajectory was asked for (its assembly then sinks into that branch: 3 % of the epoch).
-            sdr_track_epoch rec;
-            rec.start_sample = st.current_sample;
-            rec.n_samples = n;
-            rec.carrier_hz_in = st.carrier_hz;
-            rec.rem_carrier_in = st.rem_carrier;
-            rec.rem_code_in = st.rem_code;
-            rec.code_step_in = st.code_step;
-            for (int k = 0; k < 2 * SDR_MAX_TAPS; ++k) rec.corr[k] = k < 2 * kTaps ? corr[k] : 0.0;
-            rec.nav_bit = -1;
-
-            if (!kaplan) {
-                // ---- Borre: channel_l1ca_borre.py:364-429
-                st.rem_carrier -= carrier_adv;
-                st.rem_carrier = py_mod(st.rem_carrier, 2.0 * M_PI);
-                const double code_err = dll_nn;
-                double nco_code = dll_r1 * (code_err - st.dll_mem);
-                nco_code += dll_r2 * code_err;
-                st.dll_mem = code_err;
-                const double phase_err = costas;
-                double nco_carrier = pll_r1 * (phase_err - st.pll_mem);
-                nco_carrier += pll_r2 * phase_err;
-                st.pll_mem = phase_err;
-                // bit sync: first prompt sign flip after MIN_CONVERGENCE_TIME = 100 epochs (borre:384-391)
-                if (!(st.track_flags & FLAG_BIT_SYNC) && (st.track_flags & FLAG_CODE_LOCK) && st.code_counter > 100 &&
-                    np_sign(st.i_prompt_prev) != np_sign(ip))
-                    st.track_flags |= FLAG_BIT_SYNC;
-                st.track_flags |= FLAG_CODE_LOCK;
-                st.i_prompt_prev = ip;
-                st.q_prompt_prev = qp;
-                st.code_counter += 1;
-                st.code_hz -= nco_code;
-                st.carrier_hz += nco_carrier;
-                st.rem_code += (double)n * st.code_step - kChips;
-                st.code_step = st.code_hz / fs;
-                st.current_sample += n;
-                st.n_samples = (int)ceil((kChips - st.rem_code) / st.code_step);
-                rec.dll = nco_code;
-                rec.pll = nco_carrier;
-                rec.fll = 0.0;
-                rec.carrier_err = phase_err;
-                rec.code_err = code_err;
-                rec.cn0 = 0.0;
-                rec.pll_lock = 0.0;
-                rec.fll_lock = 0.0;
-            } else {
-                // ---- Kaplan: runCorrelators bookkeeping (channel_l1ca_kaplan.py:392-399)
-                if (st.accum_counter == kMsPerBit) st.accum_counter = 0;
-                st.accum_counter += 1;
-                // runDiscriminators (:405-430)
-                double fll_d = 0.0, pll_d = 0.0;
-                const double dll_d = dll_nn;
-                if (st.lock_state == LOCK_PULL_IN) {
-                    if (st.code_counter > 1) fll_d = fll_full;
-                } else {
-                    fll_d = fll_full;
-                    pll_d = costas;
-                }
-                // FLLassistedPLL_2ndOrder (tracking.py:246-279) via runCarrierFrequencyFilter (:434-447)
-                const double upd = (pll_d * (w0p * w0p) + fll_d * w0f) * 1e-3;
-                double carrier_err = upd + st.pll_mem;
-                st.pll_mem = upd;
-                carrier_err += pll_d * kW0A2 * w0p;
-                // BorreLoopFilter via runCodeFrequencyFilter (:451-461)
-                double code_err = dll_r1 * (dll_d - st.dll_mem);
-                code_err += dll_r2 * dll_d;
-                // runLoopIndicators (:465-502)
-                if (st.code_counter != 0) {
-                    const double v = fabs(fll_lock_v);
-                    st.fll_lock = (1.0 - 0.005) * st.fll_lock + 0.005 * v;
-                    if (st.lock_state > LOCK_PULL_IN) st.pll_lock = (1.0 - 0.005) * st.pll_lock + 0.005 * pll_lock_v;
-                    st.cn0_ratio_acc += cn0_term;
-                    if (st.accum_counter == kMsPerBit) {
-                        const double lam = 1.0 / (st.cn0_ratio_acc / (double)st.accum_counter);
-                        const double c = lam * (1.0 / ((double)st.accum_counter * 1e-3));
-                        st.cn0 = (1.0 - 0.1) * st.cn0 + 0.1 * c;
-                        st.cn0_ratio_acc = 0.0;
+                const double quot = num / den;
+                const double at = atan(quot);
+                const double at_now = lane_value(at, 0), at_prev = lane_value(at, 1);
+                double fll_err = at_now - at_prev;
+                if (fll_err != fll_err) fll_err = 0.0;
+                if (fll_err >= kGpsHalfPi) fll_err = fll_err - kGpsPi;
+                else if (fll_err <= -kGpsHalfPi) fll_err = fll_err + kGpsPi;
+                // lane 0: atan/2pi (pll_costas), lane 1: err/dt, then lane 1: (err/dt)/2pi (fll_atan)
+                const double q4 = (rlane == 1 ? fll_err : at_now) / (rlane == 1 ? 1e-3 : kGpsTwoPi);
+                const double q5 = q4 / kGpsTwoPi;
+                const double costas = lane_value(q4, 0), fll_full = lane_value(q5, 1);
+                const double w0f = lane_value(quot, 2), w0p = lane_value(quot, 3), carrier_adv = lane_value(quot, 4);
+                const double pll_r1 = lane_value(quot, 5), pll_r2 = lane_value(quot, 6);
+                __builtin_amdgcn_wave_barrier();  // (every lane has read the previous prompt before lane 0 replaces it)
+                if (rlane == 0) {
+                    double c_pll_mem = st.pll_mem;
+                    const int c_code_counter = sh->c_code_counter;
+                    double rem_carrier = ep.rem_carrier, carrier_hz = ep.carrier_hz;
+                    double rec_pll, rec_fll, rec_carrier_err;
+                    if (!kaplan) {  // Borre: channel_l1ca_borre.py:364-429
+                        rem_carrier -= carrier_adv;
+                        rem_carrier = py_mod(rem_carrier, 2.0 * M_PI);
+                        const double phase_err = costas;
+                        double nco_carrier = pll_r1 * (phase_err - c_pll_mem);
+                        nco_carrier += pll_r2 * phase_err;
+                        c_pll_mem = phase_err;
+                        carrier_hz += nco_carrier;
+                        rec_pll = nco_carrier, rec_fll = 0.0, rec_carrier_err = phase_err;
+                    } else {        // Kaplan: runDiscriminators / runCarrierFrequencyFilter / postTrackingUpdate
+                        double fll_d = 0.0, pll_d = 0.0;
+                        if (cur_lock_state == LOCK_PULL_IN) {
+                            if (c_code_counter > 1) fll_d = fll_full;
+                        } else {
+                            fll_d = fll_full;
+                            pll_d = costas;
+                        }
+                        const double upd = (pll_d * (w0p * w0p) + fll_d * w0f) * 1e-3;  // FLLassistedPLL_2ndOrder (tracking.py:246-279)
+                        double carrier_err = upd + c_pll_mem;
+                        c_pll_mem = upd;
+                        carrier_err += pll_d * kW0A2 * w0p;
+                        rem_carrier -= carrier_adv;
+                        rem_carrier = py_mod(rem_carrier, kGpsTwoPi);
+                        carrier_hz += carrier_err;
+                        rec_pll = pll_d, rec_fll = fll_d, rec_carrier_err = carrier_err;
+                    }
+                    st.pll_mem = c_pll_mem;
+                    st.i_prompt_prev = ip;
+                    st.q_prompt_prev = qp;
+                    sh->c_code_counter = c_code_counter + 1;
+                    sh->ep.carrier_hz = carrier_hz;
+                    sh->stop_carrier = carrier_bad(carrier_hz) ? 1 : 0;
+                    sh->ep.rem_carrier = rem_carrier;
+                    sh->dphi = carrier_step(carrier_hz, fs);
+                    if (rec) {
+                        rec->carrier_hz_in = ep.carrier_hz;
+                        rec->rem_carrier_in = ep.rem_carrier;
+                        rec->pll = rec_pll;
+                        rec->fll = rec_fll;
+                        rec->carrier_err = rec_carrier_err;
+                        rec->carrier_hz = carrier_hz;
                     }
                 }
-                // postTrackingUpdate (:506-534)
-                st.code_counter += 1;
-                st.dll_mem = dll_d;
-                st.rem_carrier -= carrier_adv;
-                st.rem_carrier = py_mod(st.rem_carrier, kGpsTwoPi);
-                st.code_hz -= code_err;
-                st.carrier_hz += carrier_err;
-                st.rem_code += (double)n * st.code_step - kChips;
-                st.code_step = st.code_hz / fs;
-                st.current_sample += n;
-                st.n_samples = (int)ceil((kChips - st.rem_code) / st.code_step);
-                // trackingStateUpdate (:538-619)
-                if (st.lock_state != LOCK_PULL_IN && st.cn0 > cfg.dll_threshold && !(st.track_flags & FLAG_CODE_LOCK))
-                    st.track_flags |= FLAG_CODE_LOCK;
-                else if (st.cn0 < cfg.dll_threshold && (st.track_flags & FLAG_CODE_LOCK))
-                    st.track_flags ^= FLAG_CODE_LOCK;
-                if ((st.track_flags & FLAG_CODE_LOCK) && !(st.track_flags & FLAG_BIT_SYNC)) {
-                    if (np_sign(st.i_prompt_prev) != np_sign(ip)) {
-                        st.track_flags |= FLAG_BIT_SYNC;
-                        st.accum_counter = 1;
-                        st.cn0_ratio_acc = 0.0;
+            } else if (role == 1) {
+                // ------------------------------------------------------------------ code loop
+                const double env = sqrt(rlane == 1 ? il * il + ql * ql : ie * ie + qe * qe);  // DLL NNEML envelopes (tracking.py:120-129)
+                const double env_e = lane_value(env, 0), env_l = lane_value(env, 1);
+                double num = 0.0, den = 1.0;
+                switch (rlane) {
+                    case 0: num = env_e - env_l, den = env_e + env_l; break;
+                    case 1: num = cfg.dll_tau2, den = cfg.dll_tau1; break;              // BorreLoopFilter (tracking.py:180-186)
+                    case 2: num = kaplan ? cfg.dll_pdi * 1.0 : cfg.dll_pdi, den = cfg.dll_tau1; break;
+                    default: break;
+                }
+                const double quot = num / den;
+                const double dll_nn = lane_value(quot, 0), dll_r1 = lane_value(quot, 1), dll_r2 = lane_value(quot, 2);
+                if (rlane == 0) {
+                    const double dll_d = dll_nn;
+                    double code_err = dll_r1 * (dll_d - st.dll_mem);
+                    code_err += dll_r2 * dll_d;
+                    st.dll_mem = dll_d;
+                    st.code_counter += 1;
+                    const double k_code_hz = st.code_hz - code_err;
+                    st.code_hz = k_code_hz;
+                    double rem_code = ep.rem_code;
+                    rem_code += (double)n * ep.code_step - kChips;
+                    const double code_step = k_code_hz / fs;
+                    const int64_t next_start = ep.start_sample + n;
+                    const int next_n = (int)ceil((kChips - rem_code) / code_step);
+                    sh->stop_code = code_out_of_range(next_start, next_n, rem_code, code_step) ? 1 : 0;
+                    sh->ep.start_sample = next_start;
+                    sh->ep.n = next_n;
+                    sh->ep.rem_code = rem_code;
+                    sh->ep.code_step = code_step;
+                    sh->epochs_done = epoch + 1;
+                    if (rec) {
+                        rec->start_sample = ep.start_sample;
+                        rec->n_samples = n;
+                        rec->rem_code_in = ep.rem_code;
+                        rec->code_step_in = ep.code_step;
+                        for (int k = 0; k < 2 * SDR_MAX_TAPS; ++k) rec->corr[k] = k < 2 * kTaps ? sh->corr[k] : 0.0;
+                        // Kaplan records the discriminator and the filter output; Borre the NCO command and the error
+                        rec->dll = kaplan ? dll_d : code_err;
+                        rec->code_err = kaplan ? code_err : dll_d;
+                        rec->code_hz = k_code_hz;
                     }
                 }
-                st.i_prompt_prev = ip;
-                st.q_prompt_prev = qp;
-                if (st.lock_state != LOCK_NARROW && st.fll_lock >= cfg.fll_thr_narrow && st.pll_lock >= cfg.pll_thr_narrow) {
-                    st.lock_state = LOCK_NARROW;
-                    st.fll_bw = cfg.fll_bw_narrow;
-                    st.pll_bw = cfg.pll_bw_narrow;
-                    st.spacing_sel = 1;
-                    st.time_in_state = 0;
-                } else if (st.lock_state != LOCK_WIDE && st.fll_lock >= cfg.fll_thr_wide && st.fll_lock < cfg.fll_thr_narrow) {
-                    st.lock_state = LOCK_WIDE;
-                    st.fll_bw = cfg.fll_bw_wide;
-                    st.pll_bw = cfg.pll_bw_wide;
-                    st.spacing_sel = 0;
-                    st.time_in_state = 0;
-                } else if (st.lock_state != LOCK_PULL_IN && st.fll_lock <= cfg.fll_thr_wide) {
-                    st.lock_state = LOCK_PULL_IN;
-                    st.fll_bw = cfg.fll_bw_pullin;
-                    st.pll_bw = 0.0;
-                    st.spacing_sel = 0;
-                    st.time_in_state = 0;
-                } else {
-                    st.time_in_state += 1;
-                }
-                rec.dll = dll_d;
-                rec.pll = pll_d;
-                rec.fll = fll_d;
-                rec.carrier_err = carrier_err;
-                rec.code_err = code_err;
-                rec.cn0 = st.cn0;
-                rec.pll_lock = st.pll_lock;
-                rec.fll_lock = st.fll_lock;
-            }
-            // decodeBit (kaplan:728-754, borre:470-491): 20 prompts after bit sync -> one bit (Prompt2Bit)
-            if (!(st.track_flags & FLAG_BIT_SYNC)) {
-                st.nav_prompt_sum = 0.0;
-                st.nav_sum_counter = 0;
             } else {
-                st.nav_prompt_sum += ip;
-                st.nav_sum_counter += 1;
-                if (st.nav_sum_counter == kMsPerBit) {
-                    const int bit = st.nav_prompt_sum > 0.0 ? 1 : 0;
-                    rec.nav_bit = bit;
-                    if (writer && nav_bits && sh->bits_this_run < max_bits) nav_bits[(size_t)ch * max_bits + sh->bits_this_run] = (int8_t)bit;
-                    sh->bits_this_run += 1;
-                    st.nav_bits_emitted += 1;
-                    st.nav_prompt_sum = 0.0;
-                    st.nav_sum_counter = 0;
+                // ------------------------------------------------------------------ lock indicators, state machine, bits
+                const double pw = ip * ip + qp * qp;
+                double num = 0.0, den = 1.0;
+                switch (rlane) {
+                    case 0: {                                             // FLL lock (lockindicator.py:6-18)
+                        const double l_ipp = sh->l_ipp, l_qpp = sh->l_qpp;
+                        double v = ip * l_ipp - qp * l_qpp;
+                        v *= np_sign(ip * l_ipp + qp * l_qpp);
+                        num = v, den = pw;
+                        break;
+                    }
+                    case 1: num = ip * ip - qp * qp, den = pw; break;     // PLL lock (:22-36)
+                    case 2: {                                             // C/N0 (Beaulieu) ratio term (kaplan:488)
+                        const double d = fabs(ip) - fabs(qp);
+                        num = pw, den = d * d;
+                        break;
+                    }
+                    default: break;
+                }
+                const double quot = num / den;
+                const double fll_lock_v = lane_value(quot, 0), pll_lock_v = lane_value(quot, 1), cn0_term = lane_value(quot, 2);
+                if (rlane == 0) {
+                    double l_fll_lock = st.fll_lock, l_pll_lock = st.pll_lock, l_cn0 = st.cn0, l_ratio_acc = st.cn0_ratio_acc;
+                    double l_ipp = sh->l_ipp, l_qpp = sh->l_qpp, l_fll_bw = st.fll_bw, l_pll_bw = st.pll_bw, l_nav_sum = st.nav_prompt_sum;
+                    int l_accum = st.accum_counter, l_lock_state = st.lock_state, l_time_in_state = st.time_in_state;
+                    int l_spacing_sel = st.spacing_sel, l_flags = st.track_flags, l_code_counter = sh->l_code_counter;
+                    int l_nav_count = st.nav_sum_counter, l_bits_emitted = st.nav_bits_emitted, l_bits_run = sh->l_bits_run;
+                    int nav_bit = -1;
+                    if (!kaplan) {
+                        // Borre bit sync: first prompt sign flip after MIN_CONVERGENCE_TIME = 100 epochs (borre:384-391)
+                        if (!(l_flags & FLAG_BIT_SYNC) && (l_flags & FLAG_CODE_LOCK) && l_code_counter > 100 &&
+                            np_sign(l_ipp) != np_sign(ip))
+                            l_flags |= FLAG_BIT_SYNC;
+                        l_flags |= FLAG_CODE_LOCK;
+                        l_ipp = ip;
+                        l_qpp = qp;
+                        l_code_counter += 1;
+                    } else {
+                        // runCorrelators bookkeeping (kaplan:392-399)
+                        if (l_accum == kMsPerBit) l_accum = 0;
+                        l_accum += 1;
+                        // runLoopIndicators (:465-502)
+                        if (l_code_counter != 0) {
+                            const double v = fabs(fll_lock_v);
+                            l_fll_lock = (1.0 - 0.005) * l_fll_lock + 0.005 * v;
+                            if (l_lock_state > LOCK_PULL_IN) l_pll_lock = (1.0 - 0.005) * l_pll_lock + 0.005 * pll_lock_v;
+                            l_ratio_acc += cn0_term;
+                            if (l_accum == kMsPerBit) {
+                                const double lam = 1.0 / (l_ratio_acc / (double)l_accum);
+                                const double c = lam * (1.0 / ((double)l_accum * 1e-3));
+                                l_cn0 = (1.0 - 0.1) * l_cn0 + 0.1 * c;
+                                l_ratio_acc = 0.0;
+                            }
+                        }
+                        l_code_counter += 1;
+                        // trackingStateUpdate (:538-619)
+                        if (l_lock_state != LOCK_PULL_IN && l_cn0 > cfg.dll_threshold && !(l_flags & FLAG_CODE_LOCK))
+                            l_flags |= FLAG_CODE_LOCK;
+                        else if (l_cn0 < cfg.dll_threshold && (l_flags & FLAG_CODE_LOCK))
+                            l_flags ^= FLAG_CODE_LOCK;
+                        if ((l_flags & FLAG_CODE_LOCK) && !(l_flags & FLAG_BIT_SYNC)) {
+                            if (np_sign(l_ipp) != np_sign(ip)) {
+                                l_flags |= FLAG_BIT_SYNC;
+                                l_accum = 1;
+                                l_ratio_acc = 0.0;
+                            }
+                        }
+                        l_ipp = ip;
+                        l_qpp = qp;
+                        if (l_lock_state != LOCK_NARROW && l_fll_lock >= cfg.fll_thr_narrow && l_pll_lock >= cfg.pll_thr_narrow) {
+                            l_lock_state = LOCK_NARROW;
+                            l_fll_bw = cfg.fll_bw_narrow;
+                            l_pll_bw = cfg.pll_bw_narrow;
+                            l_spacing_sel = 1;
+                            l_time_in_state = 0;
+                        } else if (l_lock_state != LOCK_WIDE && l_fll_lock >= cfg.fll_thr_wide && l_fll_lock < cfg.fll_thr_narrow) {
+                            l_lock_state = LOCK_WIDE;
+                            l_fll_bw = cfg.fll_bw_wide;
+                            l_pll_bw = cfg.pll_bw_wide;
+                            l_spacing_sel = 0;
+                            l_time_in_state = 0;
+                        } else if (l_lock_state != LOCK_PULL_IN && l_fll_lock <= cfg.fll_thr_wide) {
+                            l_lock_state = LOCK_PULL_IN;
+                            l_fll_bw = cfg.fll_bw_pullin;
+                            l_pll_bw = 0.0;
+                            l_spacing_sel = 0;
+                            l_time_in_state = 0;
+                        } else {
+                            l_time_in_state += 1;
+                        }
+                    }
+                    // decodeBit (kaplan:728-754, borre:470-491): 20 prompts after bit sync -> one bit (Prompt2Bit)
+                    if (!(l_flags & FLAG_BIT_SYNC)) {
+                        l_nav_sum = 0.0;
+                        l_nav_count = 0;
+                    } else {
+                        l_nav_sum += ip;
+                        l_nav_count += 1;
+                        if (l_nav_count == kMsPerBit) {
+                            nav_bit = l_nav_sum > 0.0 ? 1 : 0;
+                            if (writer && nav_bits && l_bits_run < max_bits) nav_bits[(size_t)ch * max_bits + l_bits_run] = (int8_t)nav_bit;
+                            l_bits_run += 1;
+                            l_bits_emitted += 1;
+                            l_nav_sum = 0.0;
+                            l_nav_count = 0;
+                        }
+                    }
+                    st.fll_lock = l_fll_lock, st.pll_lock = l_pll_lock, st.cn0 = l_cn0, st.cn0_ratio_acc = l_ratio_acc;
+                    sh->l_ipp = l_ipp, sh->l_qpp = l_qpp, st.fll_bw = l_fll_bw, st.pll_bw = l_pll_bw, st.nav_prompt_sum = l_nav_sum;
+                    st.accum_counter = l_accum, st.lock_state = l_lock_state, st.time_in_state = l_time_in_state;
+                    st.spacing_sel = l_spacing_sel, st.track_flags = l_flags, sh->l_code_counter = l_code_counter;
+                    st.nav_sum_counter = l_nav_count, st.nav_bits_emitted = l_bits_emitted, sh->l_bits_run = l_bits_run;
+                    // hand-over to the other roles / the next epoch
+                    const double* sp = l_spacing_sel ? cfg.spacing_narrow : cfg.spacing_wide;
+                    for (int t = 0; t < kTaps; ++t) sh->spacing[t] = sp[t];
+                    sh->fll_bw = l_fll_bw;
+                    sh->pll_bw = l_pll_bw;
+                    sh->lock_state = l_lock_state;
+                    if (rec) {
+                        rec->cn0 = kaplan ? l_cn0 : 0.0;
+                        rec->pll_lock = kaplan ? l_pll_lock : 0.0;
+                        rec->fll_lock = kaplan ? l_fll_lock : 0.0;
+                        rec->lock_state = l_lock_state;
+                        rec->track_flags = l_flags;
+                        rec->nav_bit = nav_bit;
+                    }
                 }
             }
-            rec.carrier_hz = st.carrier_hz;
-            rec.code_hz = st.code_hz;
-            rec.lock_state = st.lock_state;
-            rec.track_flags = st.track_flags;
-            sh->epochs_done = epoch + 1;
-            publish(st, cfg);
-            sh->st = st;
-            if (writer && keep_traj) traj[(size_t)ch * n_epochs + epoch] = rec;
-          }
         }
         TRACK_MARK(4);
         // the next iteration's first barrier orders lane 0's LDS writes against everyone's reads
     }
+    // End state: the roles kept the LDS copy of the state current; one lane of the recording part writes it out.
+    __syncthreads();
     if (tid == 0 && writer) {
         const int epochs_done = sh->epochs_done;
+        // the NCO values of the next epoch are the ones the roles published last
+        st.current_sample = sh->ep.start_sample;
+        st.n_samples = sh->ep.n;
+        st.carrier_hz = sh->ep.carrier_hz;
+        st.rem_carrier = sh->ep.rem_carrier;
+        st.rem_code = sh->ep.rem_code;
+        st.code_step = sh->ep.code_step;
         if (epochs_done < n_epochs) {
             st.n_samples = -1 - epochs_done;  // stopped early: -(1 + epochs completed)
             if (keep_traj)
                 for (int k = epochs_done; k < n_epochs; ++k) traj[(size_t)ch * n_epochs + k].n_samples = 0;
         }
         states[ch] = st;
-        if (n_bits) n_bits[ch] = sh->bits_this_run < max_bits ? sh->bits_this_run : max_bits;
+        if (n_bits) n_bits[ch] = sh->l_bits_run < max_bits ? sh->l_bits_run : max_bits;
     }
 }
 

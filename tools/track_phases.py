@@ -19,8 +19,8 @@ buf = np.zeros(32, dtype=np.uint64)
 lib = L.load()
 lib.sdr_debug_track_phases.argtypes = [ctypes.c_void_p]
 assert lib.sdr_debug_track_phases(buf.ctypes.data) == 0
-names = ["params+barrier", "constants", "correlate", "reduce", "scalar loop", "loop top", "exchange"]
-tot = float(buf[:7].sum())
-for n, v in zip(names, buf[:7]):
+names = ["first barrier", "constants", "correlate", "reduce", "update (wave 0 role)", "loop top", "exchange", "corr hand-over barrier"]
+tot = float(buf[:8].sum())
+for n, v in zip(names, buf[:8]):
     print(f"{n:16s} {float(v)*10/1e3/2000:8.2f} us/epoch  {100.0*float(v)/tot:5.1f} %")
 print("per-wave arrival at the reduction (us after the epoch's first barrier):", " ".join(f"{float(v)*10/1e3/2000:.2f}" for v in buf[8:24]))
