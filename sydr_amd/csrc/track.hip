@@ -4,9 +4,11 @@
 // chosen so that the launch fills the GPU: 32 channels x 8 parts = 256 CUs): every epoch each part
 // correlates its share of the samples, publishes six partial sums through global memory, waits for
 // its peers' and adds all of them in the same fixed order -- so every part holds bit-identical
-// totals and runs the (cheap) scalar loop update redundantly; there is no second exchange.  The
-// PRN replica stays in LDS for the whole run; the scalar loop arithmetic runs on lane 0 in fp64,
-// following the two reference plugins statement by statement:
+// totals and runs the scalar loop update redundantly; there is no second exchange.  The PRN replica
+// stays in LDS for the whole run; the loop arithmetic is fp64, spread over three waves by dependency
+// (carrier loop / code loop / lock indicators + state machine + bit decisions) and, inside each,
+// over lanes for the divisions, roots and arctangents -- following the two reference plugins
+// statement by statement:
 //   kind 0  Borre  : channel_l1ca_borre.py:333-451  (DLL NNEML + Costas PLL, Borre filters, np.pi NCO)
 //   kind 1  Kaplan : channel_l1ca_kaplan.py:342-619 (FLL-assisted 2nd-order PLL, lock-state machine,
 //                    GPS-ICD pi in the NCO and the discriminators: SURVEY.md T3)
