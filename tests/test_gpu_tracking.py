@@ -166,6 +166,32 @@ def test_closed_loop_at_25_mhz_matches_the_oracle_loops(engine, kind, parts):
     assert np.hypot(tr["corr"][-1, 2], tr["corr"][-1, 3]) > np.hypot(tr["corr"][-1, 0], tr["corr"][-1, 1])
 
 
+@pytest.mark.parametrize("fmt_name", ["ci16", "cf32", "cf64"])
+def test_closed_loop_other_ring_formats(engine, fmt_name):
+    """The tracking kernel is instantiated per ring format: the golden stream stored as int16 / float32 / float64
+    pairs gives the trajectory of the int8 run, bit for bit (same values, same arithmetic)."""
+    from sydr_amd.engine import FMT_CF32, FMT_CF64, FMT_CI16
+    g, fs, raw = trajectory_iq("g6b_kaplan_strong.npz")
+    c = kaplan_strong_cfg(g)
+    acq = g["kaplan_acq"]
+    n = raw.size // 2
+    cap = (n + 7) // 8 * 8
+
+    def run(fmt, data):
+        engine.iq_alloc(cap, fmt)
+        engine.iq_upload(data, 0)
+        engine.code_slots(2)
+        engine.load_gps_code(1, 7)
+        st = initial_state(1, fs, acq[3], int(acq[5]), c, slot=1)
+        return engine.track_closed_loop([st], loop_cfg(1, fs, c), 300)[1][0]
+
+    base = run(FMT_CI8, raw)
+    fmt, data = {"ci16": (FMT_CI16, raw.astype(np.int16)), "cf32": (FMT_CF32, raw.astype(np.float32)),
+                 "cf64": (FMT_CF64, raw.astype(np.float64))}[fmt_name]
+    other = run(fmt, data)
+    assert other.tobytes() == base.tobytes()
+
+
 def test_closed_loop_more_channels_than_compute_units(engine):
     """Beyond one channel per CU the launcher switches to the 256-thread kernel built for three workgroups per CU.
     260 channels tracking the golden stream from the same state: every one reproduces the reference trajectory."""
