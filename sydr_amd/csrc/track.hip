@@ -73,9 +73,7 @@ struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind 
     EpochParams ep;
     double spacing[kTaps];
     double dphi;
-    int stop;
     int epochs_done;
-    int bits_this_run;
     int fault;                 // a peer part never showed up: leave the epoch loop (reported to the host)
     // what the three update roles hand to each other (written before an epoch's first barrier, read after it)
     double corr[2 * kTaps];    // this epoch's correlator totals, for the roles on waves 1 and 2
@@ -85,7 +83,7 @@ struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind 
     int stop_code, stop_carrier;  // the next epoch would leave the staged replica / the ring, or the carrier NCO is not finite
     double smin, smax;         // extreme tap offsets over both tap sets (constant for the run)
     double l_ipp, l_qpp;       // the lock role's copy of the previous prompt (the carrier role owns st.i/q_prompt_prev)
-    sdr_track_state st;  // lane 0's working copy lives in LDS, not in 1024 x VGPRs
+    sdr_track_state st;        // the loop state; each update role owns a disjoint set of its fields
     sdr_loop_cfg cfg;
 };
 
@@ -129,7 +127,6 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         sh->st = states[ch];
         sh->cfg = *cfg_ptr;
         sh->epochs_done = 0;
-        sh->bits_this_run = 0;
         sh->fault = 0;
         sh->fll_bw = states[ch].fll_bw;
         sh->pll_bw = states[ch].pll_bw;
