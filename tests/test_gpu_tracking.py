@@ -447,3 +447,46 @@ def test_legacy_function_surface_of_the_tracking_module(engine):
     nb = (li.CN0_NWPR(400.0, 30.0, 9000.0, 1000.0))
     np_ = (400.0**2 + 30.0**2) / (9000.0 + 1000.0)
     assert nb == 10 * np.log10(1 / 1e-3 * (np_ - 1) / (20 - np_))
+
+
+def test_file_driven_example_with_the_reference_ini_layout(engine, tmp_path, capsys):
+    """examples/run_file.py: the reference's receiver.ini / channel ini layout, an int8 I/Q file, per-tick acquisition,
+    then closed-loop blocks -- every requested PRN ends up tracking on its Doppler."""
+    import importlib.util
+    import os
+    fs, ms = 10e6, 700
+    n = int(fs * 1e-3) * ms
+    sats = [dict(prn=4, doppler=2100.0, code_phase=200.5, phase=0.1, amp=9.0),
+            dict(prn=9, doppler=-3300.0, code_phase=777.0, phase=0.5, amp=9.0)]
+    engine.iq_alloc(n, FMT_CI8)
+    engine.code_slots(2)
+    engine.iq_synth(sats, fs, 14.0, 555, 0, n)
+    engine.iq_download(n, 0).tofile(tmp_path / "iq.bin")
+    (tmp_path / "channel.ini").write_text(KAPLAN_INI)
+    (tmp_path / "receiver.ini").write_text(f"""
+[DEFAULT]
+name = test
+nb_channels = 2
+ms_to_process = 600
+[RFSIGNAL]
+filepath = {tmp_path / 'iq.bin'}
+sampling_frequency = {fs}
+intermediate_frequency = 0.0
+data_size = 8
+is_complex = true
+[SATELLITES]
+include_prn = 4,9
+[CHANNELS]
+gps_l1ca = ./channel.ini
+""")
+    spec = importlib.util.spec_from_file_location("run_file", os.path.join(os.path.dirname(__file__), "..", "examples", "run_file.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main([str(tmp_path / "receiver.ini"), "--block", "80", "--csv", str(tmp_path / "out.csv")])
+    out = capsys.readouterr().out
+    import re
+    carriers = {int(p): float(f) for p, f in re.findall(r"G(\d+): state TRACKING, carrier ([-+0-9.]+) Hz", out)}
+    assert set(carriers) == {4, 9}, out
+    assert abs(carriers[4] - 2100.0) < 30.0 and abs(carriers[9] + 3300.0) < 30.0, out
+    rows = np.loadtxt(tmp_path / "out.csv", delimiter=",", skiprows=1)
+    assert rows.shape[0] > 2 * 400                  # both channels, most of the 600 ms
