@@ -73,7 +73,7 @@ def main(argv=None):
         if args.block and all_tracking and ms + args.block <= ms_total and args.block < ring_ms - 2:
             for _ in range(args.block):                       # fill the ring ahead of the channels, then one launch
                 mgr.addNewRFData(rf.getMilliseconds(1))
-            emit(mgr.runBlock(args.block - 1), ms + args.block)
+            emit(mgr.runBlock(args.block), ms + args.block)            # (as many whole epochs as the ring holds)
             ms += args.block
         else:
             mgr.addNewRFData(rf.getMilliseconds(1))

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SDR_ABI_VERSION 1
+#define SDR_ABI_VERSION 2
 
 typedef struct sdr_engine sdr_engine;
 
@@ -238,7 +238,8 @@ typedef struct sdr_track_state {
 
 typedef struct sdr_loop_cfg {
     int32_t loop_kind;        /* 0 Borre, 1 Kaplan                                  */
-    int32_t n_taps;           /* 3                                                  */
+    int32_t n_taps;           /* 3 (E/P/L, the reference) or 5 (VE/E/P/L/VL); the discriminators use the centre
+                               * tap as prompt and its two neighbours as early / late                           */
     double fs;
     double spacing_wide[SDR_MAX_TAPS];
     double spacing_narrow[SDR_MAX_TAPS];
@@ -247,6 +248,12 @@ typedef struct sdr_loop_cfg {
     double dll_threshold;                     /* Kaplan                             */
     double fll_bw_pullin, fll_bw_wide, fll_bw_narrow, fll_thr_wide, fll_thr_narrow;
     double pll_bw_wide, pll_bw_narrow, pll_thr_wide, pll_thr_narrow;
+    /* generalisation beyond the reference's GPS L1 C/A epoch (BASELINE configs 4-5; no reference counterpart):
+     * chips per correlator epoch (code length x code periods; 0 = 1023, the reference's GPS_L1CA_CODE_SIZE_BITS at
+     * channel_l1ca_kaplan.py:529-532) and epochs per navigation symbol (0 = 20 = LNAV_MS_PER_BIT). */
+    double epoch_chips;
+    int32_t epochs_per_bit;
+    int32_t reserved;
 } sdr_loop_cfg;
 
 /* Per-epoch record written when traj != NULL (what the reference's tracking
@@ -279,6 +286,50 @@ int sdr_track_closed_loop(sdr_engine* e, int n_ch, sdr_track_state* st, const sd
 int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, const sdr_loop_cfg* cfg,
                                int n_epochs, sdr_track_epoch* traj, int8_t* nav_bits, int max_bits,
                                int32_t* n_bits);
+
+/* Same run with a per-channel outcome instead of one status for the call: epochs_done[c] = epochs channel c
+ * completed (< n_epochs when its NCO left the staged replica / the ring: that channel stops, st[c] holds its last
+ * valid state, the others are unaffected -- the reference likewise lets a channel that lost lock run on alone,
+ * sydr/channel/channel.py:121-160).  cfgs: one sdr_loop_cfg per channel when cfg_per_channel != 0, else cfgs[0]
+ * serves all (channelManager.addChannel takes a configuration per call, channelManager.py:70-93). */
+int sdr_track_closed_loop_ex(sdr_engine* e, int n_ch, sdr_track_state* st, const sdr_loop_cfg* cfgs,
+                             int cfg_per_channel, int n_epochs, sdr_track_epoch* traj, int8_t* nav_bits,
+                             int max_bits, int32_t* n_bits, int32_t* epochs_done);
+
+/* ------------------------------------------------- device-resident channel bank
+ * The tracking state of every channel of one GPU lives in HBM (sdr_track_state + sdr_loop_cfg per channel) and
+ * is advanced there; the host keeps views.  This replaces the reference's one-process-per-channel fan-out with
+ * its per-millisecond Event barrier (sydr/channel/channelManager.py:70-127,149-188, sydr/channel/channel.py:121-160):
+ * one sdr_bank_step = "every listed channel runs n_epochs tracking epochs", one sdr_bank_tick = one iteration of the
+ * receiver's outer loop (receiver.py:120-131: addNewRFData of one slab, then run) in a single call.
+ * Channels are independent; a call on one stream never touches channels that are not listed. */
+typedef struct sdr_bank sdr_bank;
+int sdr_bank_create(sdr_engine* e, int max_channels, sdr_bank** out);
+void sdr_bank_destroy(sdr_engine* e, sdr_bank* b);
+/* Host -> HBM: (re)initialise channel ch (after acquisition: postAcquisitionUpdate, channel_l1ca_kaplan.py:217-235). */
+int sdr_bank_put(sdr_engine* e, sdr_bank* b, int ch, const sdr_track_state* st, const sdr_loop_cfg* cfg);
+/* HBM -> host. */
+int sdr_bank_get(sdr_engine* e, sdr_bank* b, int ch, sdr_track_state* st);
+/* Advance the listed channels by n_epochs each.  records[n_ch][n_epochs] (nullable) receives the per-epoch
+ * packets' contents, states_out[n_ch] (nullable) the states after the run, epochs_done[n_ch] (nullable) the epochs
+ * each channel completed, nav_bits/n_bits as in sdr_track_closed_loop_bits.  stream_id: 0 = the engine's stream,
+ * else a stream from sdr_stream_create (one stream per channel batch).  Synchronous on that stream. */
+int sdr_bank_step(sdr_engine* e, sdr_bank* b, const int32_t* channels, int n_ch, int n_epochs,
+                  sdr_track_epoch* records, sdr_track_state* states_out, int32_t* epochs_done,
+                  int8_t* nav_bits, int max_bits, int32_t* n_bits, int stream_id);
+/* One receiver tick: copy n_samples new host samples into the ring at ring_offset (CircularBuffer.shift), then
+ * one epoch for the listed channels (n_ch may be 0: ingest only).  One stream synchronisation in all. */
+int sdr_bank_tick(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
+                  const int32_t* channels, int n_ch, sdr_track_epoch* records, sdr_track_state* states_out,
+                  int32_t* epochs_done);
+
+/* ------------------------------------------------- streams (one per channel batch)
+ * north_star: "one HIP stream per channel batch".  Stream ids are small positive integers owned by the engine;
+ * 0 always names the engine's default stream. */
+int sdr_stream_create(sdr_engine* e, int* stream_id);
+int sdr_stream_sync(sdr_engine* e, int stream_id);
+/* sdr_epl_plan_run_range on a chosen stream (asynchronous; sdr_stream_sync or sdr_epl_plan_fetch completes it). */
+int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int64_t count, int stream_id);
 
 #ifdef __cplusplus
 }

@@ -63,7 +63,13 @@ class LoopCfg(C.Structure):
                 ("fll_bw_pullin", C.c_double), ("fll_bw_wide", C.c_double), ("fll_bw_narrow", C.c_double),
                 ("fll_thr_wide", C.c_double), ("fll_thr_narrow", C.c_double),
                 ("pll_bw_wide", C.c_double), ("pll_bw_narrow", C.c_double),
-                ("pll_thr_wide", C.c_double), ("pll_thr_narrow", C.c_double)]
+                ("pll_thr_wide", C.c_double), ("pll_thr_narrow", C.c_double),
+                ("epoch_chips", C.c_double), ("epochs_per_bit", C.c_int32), ("reserved", C.c_int32)]
+
+
+# The same records as NumPy dtypes: the host keeps the channel bank's mirror as structured arrays.
+TRACK_STATE_DTYPE = np.dtype(TrackState)
+LOOP_CFG_DTYPE = np.dtype(LoopCfg)
 
 
 class TrackEpoch(C.Structure):
@@ -129,7 +135,18 @@ _PROTOTYPES = {
     "sdr_track_cluster": (C.c_int, [_VP, C.c_int]),
     "sdr_track_closed_loop": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(LoopCfg), C.c_int, _VP]),
     "sdr_track_closed_loop_bits": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(LoopCfg), C.c_int, _VP, _VP, C.c_int, _VP]),
+    "sdr_track_closed_loop_ex": (C.c_int, [_VP, C.c_int, _VP, _VP, C.c_int, C.c_int, _VP, _VP, C.c_int, _VP, _VP]),
+    "sdr_bank_create": (C.c_int, [_VP, C.c_int, C.POINTER(_VP)]),
+    "sdr_bank_destroy": (None, [_VP, _VP]),
+    "sdr_bank_put": (C.c_int, [_VP, _VP, C.c_int, _VP, _VP]),
+    "sdr_bank_get": (C.c_int, [_VP, _VP, C.c_int, _VP]),
+    "sdr_bank_step": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP, _VP, C.c_int, _VP, C.c_int]),
+    "sdr_bank_tick": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int, _VP, _VP, _VP]),
+    "sdr_stream_create": (C.c_int, [_VP, C.POINTER(C.c_int)]),
+    "sdr_stream_sync": (C.c_int, [_VP, C.c_int]),
+    "sdr_epl_plan_run_range_on": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int]),
 }
+ABI_VERSION = 2
 
 _lib = None
 
@@ -147,7 +164,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.sdr_abi_version() != 1:
+    if lib.sdr_abi_version() != ABI_VERSION:
         raise ImportError("libsydr_amd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -1,312 +1,65 @@
-"""GPS L1 C/A channel plugin, Kaplan-style loops, with the hot path on the MI355X.
+"""GPS L1 C/A channel, Kaplan-style loops (FLL-assisted PLL, PULL_IN / WIDE / NARROW lock states, C/N0) --
+the plugin surface of sydr/channel/channel_l1ca_kaplan.py with the tracking state on the GPU.
 
-Host state machine of the reference's `ChannelL1CA_Kaplan` (sydr/channel/channel_l1ca_kaplan.py):
-same configuration keys, method names (the override seams included), attribute names, packet keys
-and arithmetic order.  The three hot-path seams come from `GpuCorrelatorSeams`; everything else
-here is scalar per-epoch bookkeeping that the reference also keeps on the host.
-
-Navigation-bit decoding (runDecoding, kaplan:703-868) is outside the accelerated path
-(BASELINE.json: navigation untouched); `runDecoding` is a hook that returns None unless a
-subclass provides it.
-"""
+Everything per-epoch (kaplan:342-619: correlators, discriminators, loop filters, lock indicators, NCO update,
+lock-state machine, bit sync) runs in `track_kernel` (sydr_amd/csrc/track.hip, loop_kind 1); this file only says
+which INI key feeds which `sdr_loop_cfg` field and under which of the reference's attribute names each state
+field is visible.  LNAV word / subframe decoding (kaplan:703-868, sydr/dsp/decoding.py) is outside the
+accelerated path (BASELINE.json: navigation untouched): the device delivers the bits (`navBits`)."""
 from __future__ import annotations
 
-import numpy as np
-
-from ..dsp.lockindicator import CN0_Beaulieu, FLL_Lock_Borre, PLL_Lock_Borre
-from ..dsp.tracking import (BorreLoopFilter, DLL_NNEML, FLL_ATAN, FLLassistedPLL_2ndOrder, LoopFiltersCoefficients,
-                            PLL_costa)
-from ..utils.constants import (GPS_L1CA_CODE_FREQ, GPS_L1CA_CODE_MS, GPS_L1CA_CODE_SIZE_BITS, LNAV_MS_PER_BIT,
-                               TWO_PI, W0_BANDWIDTH_1, W0_BANDWIDTH_2, W0_SCALE_A2)
-from ..utils.enumerations import (ChannelMessage, ChannelState, GNSSSignalType, GNSSSystems, LoopLockState,
-                                  TrackingFlags)
-from .base import Channel
-from .seams import GpuCorrelatorSeams
+from ..utils.enumerations import LoopLockState
+from .bank import KIND_KAPLAN
+from .tracked import DeviceTrackedChannel
 
 
-class ChannelL1CA_Kaplan(GpuCorrelatorSeams, Channel):
+class ChannelL1CA_Kaplan(DeviceTrackedChannel):
+    LOOP_KIND = KIND_KAPLAN
     IDX_I_EARLY, IDX_Q_EARLY, IDX_I_PROMPT, IDX_Q_PROMPT, IDX_I_LATE, IDX_Q_LATE = range(6)
 
-    def __init__(self, cid, sharedBuffer, resultQueue, rfSignal, configuration):
-        super().__init__(cid, sharedBuffer, resultQueue, rfSignal, configuration)
-        self.setAcquisition(configuration['ACQUISITION'])
-        self.setTracking(configuration['TRACKING'])
-        self.carrierFrequency = 0.0
-        self.navPromptSum, self.navPromptSumCounter, self.navBits = 0.0, 0, []
+    # config/channels/channel_GPS_L1CA_kaplan.ini [TRACKING] -> sdr_loop_cfg
+    CFG_KEYS = {
+        "dll_pdi": "dll_pdi", "dll_threshold": "dll_threshold",
+        "fll_bandwidth_pullin": "fll_bw_pullin", "fll_bandwidth_wide": "fll_bw_wide", "fll_bandwidth_narrow": "fll_bw_narrow",
+        "fll_threshold_wide": "fll_thr_wide", "fll_threshold_narrow": "fll_thr_narrow",
+        "pll_bandwidth_wide": "pll_bw_wide", "pll_bandwidth_narrow": "pll_bw_narrow",
+        "pll_threshold_wide": "pll_thr_wide", "pll_threshold_narrow": "pll_thr_narrow",
+    }
+    FILTERS = (("dll", "dll"),)
 
-    def _lastPromptI(self):
-        return self.correlatorsResults[self.IDX_I_PROMPT]
+    # the reference's attribute names over the device state (sdr_track_state) ...
+    STATE_VIEW = {
+        "carrierFrequency": ("carrier_hz", float), "codeFrequency": ("code_hz", float),
+        "remainingCarrier": ("rem_carrier", float), "remainingCode": ("rem_code", float),
+        "codeStep": ("code_step", float), "track_requiredSamples": ("n_samples", int),
+        "codeCounter": ("code_counter", int), "correlatorsAccumCounter": ("accum_counter", int),
+        "dllDiscrim": ("dll_mem", float), "fll_vel_memory": ("pll_mem", float),
+        "iPromptPrev": ("i_prompt_prev", float), "qPromptPrev": ("q_prompt_prev", float),
+        "fllLockIndicator": ("fll_lock", float), "pllLockIndicator": ("pll_lock", float),
+        "cn0": ("cn0", float), "dllLockIndicator": ("cn0", float), "cn0_PdPnRatio": ("cn0_ratio_acc", float),
+        "fllBandwidth": ("fll_bw", float), "pllBandwidth": ("pll_bw", float),
+        "timeSinceLastState": ("time_in_state", int), "loopLockState": ("lock_state", LoopLockState),
+        "navPromptSum": ("nav_prompt_sum", float), "navPromptSumCounter": ("nav_sum_counter", int),
+    }
+    # ... and over the latest epoch record (sdr_track_epoch)
+    RECORD_VIEW = {"pllDiscrim": "pll", "fllDiscrim": "fll", "carrierFrequencyError": "carrier_err",
+                   "codeFrequencyError": "code_err"}
 
-    # ================================================================= state machine (kaplan:47-80)
-    def _processHandler(self):
-        out = []
-        if self.channelState == ChannelState.IDLE:
-            raise Warning(f"Tracking channel {self.channelID} is in IDLE.")
-        elif self.channelState == ChannelState.ACQUIRING:
-            out.append(self.runAcquisition())
-        elif self.channelState == ChannelState.TRACKING:
-            out.append(self.runTracking())
-            out.append(self.runDecoding())
-        else:
-            raise ValueError(f"Channel state {self.channelState} is not valid.")
-        return [r for r in out if r is not None]
+    def _configure_taps(self, configuration, cfg):
+        wide, narrow = float(configuration["correlator_epl_wide"]), float(configuration["correlator_epl_narrow"])
+        self.dll_epl_wide, self.dll_epl_narrow = [-wide, 0.0, wide], [-narrow, 0.0, narrow]
+        cfg["spacing_wide"][:3], cfg["spacing_narrow"][:3] = self.dll_epl_wide, self.dll_epl_narrow
 
-    def setSatellite(self, satelliteID):
-        super().setSatellite(satelliteID)
-        self.systemID = GNSSSystems.GPS
-        self.signalID = GNSSSignalType.GPS_L1_CA
-        eng = self._ensure_code()                       # Gold code generated by the device LFSR kernel
-        code = eng.read_code(self.codeSlot).astype(np.float64)
-        self.code = np.r_[code[-1], code, code[0]]      # kept for API compatibility (kaplan:104-107)
-        self.codeFrequency = GPS_L1CA_CODE_FREQ
+    def _initial_loop_state(self, st, cfg):
+        st["lock_state"] = int(LoopLockState.PULL_IN)
+        st["fll_bw"], st["pll_bw"] = cfg["fll_bw_pullin"], cfg["pll_bw_wide"]
 
-    def getTimeSinceTOW(self):
-        t = self.codeSinceTOW * GPS_L1CA_CODE_MS
-        t += self.rfBuffer.getNbUnreadSamples(self.currentSample) / (self.rfSignal.samplingFrequency / 1e3)
-        return t
+    @property
+    def track_correlatorsSpacing(self):
+        return self.dll_epl_narrow if self._bank.state["spacing_sel"][self._row] else self.dll_epl_wide
 
-    # ================================================================= acquisition (kaplan:138-251)
-    def setAcquisition(self, configuration):
-        self.acq_dopplerRange = float(configuration['doppler_range'])
-        self.acq_dopplerSteps = float(configuration['doppler_steps'])
-        self.acq_coherentIntegration = int(configuration['coherent_integration'])
-        self.acq_nonCoherentIntegration = int(configuration['non_coherent_integration'])
-        self.acq_threshold = float(configuration['threshold'])
-        self.acq_requiredSamples = int(self.rfSignal.samplingFrequency * 1e-3 *
-                                       self.acq_nonCoherentIntegration * self.acq_coherentIntegration)
-
-    def runAcquisition(self):
-        if self.rfBuffer.getNbUnreadSamples(self.currentSample) < self.acq_requiredSamples:
-            return None
-        correlationMap = self.runSignalSearch()
-        acqIndices, acqPeakRatio = self.runPeakFinder(correlationMap)
-        self.postAcquisitionUpdate(acqIndices)
-        return self.prepareResultsAcquisition(correlationMap, acqIndices, acqPeakRatio)
-
-    def postAcquisitionUpdate(self, acqIndices):
-        dopplerShift = -((-self.acq_dopplerRange) + self.acq_dopplerSteps * acqIndices[0])
-        self.codeOffset = int(np.round(acqIndices[1]))
-        self.carrierFrequency = self.rfSignal.interFrequency + dopplerShift
-        self.currentSample = self.currentSample + self.acq_requiredSamples
-        self.currentSample -= self.track_requiredSamples
-        self.currentSample += self.codeOffset + 1
-        self.channelState = ChannelState.TRACKING
-
-    def prepareResultsAcquisition(self, correlationMap, acqIndices, acqPeakRatio):
-        results = self.prepareResults()
-        results["type"] = ChannelMessage.ACQUISITION_UPDATE
-        results["carrierFrequency"] = self.carrierFrequency
-        results["codeOffset"] = self.codeOffset
-        results["frequency_idx"] = acqIndices[0]
-        results["code_idx"] = acqIndices[1]
-        results["correlation_map"] = correlationMap
-        results["peak_ratio"] = acqPeakRatio
-        return results
-
-    # ================================================================= tracking (kaplan:256-676)
-    def setTracking(self, configuration):
-        wide = float(configuration['correlator_epl_wide'])
-        narrow = float(configuration['correlator_epl_narrow'])
-        self.dll_epl_wide = [-wide, 0.0, wide]
-        self.dll_epl_narrow = [-narrow, 0.0, narrow]
-        self.track_correlatorsSpacing = self.dll_epl_wide
-        self.correlatorsResults = np.zeros(6)
-        self.correlatorsAccum = np.zeros(6)
-        self.correlatorsAccumCounter = 0
-        self.iPromptPrev = 0.0
-        self.qPromptPrev = 0.0
-        self.track_dll_tau1, self.track_dll_tau2 = LoopFiltersCoefficients(
-            loopNoiseBandwidth=float(configuration['dll_noise_bandwidth']),
-            dampingRatio=float(configuration['dll_damping_ratio']),
-            loopGain=float(configuration['dll_loop_gain']))
-        self.track_dll_pdi = float(configuration['dll_pdi'])
-        self.dllLockThreshold = float(configuration['dll_threshold'])
-        self.cn0_PdPnRatio = 0.0
-        self.cn0 = 0.0
-        self.fll_bandwidth_pullin = float(configuration['fll_bandwidth_pullin'])
-        self.fll_bandwidth_wide = float(configuration['fll_bandwidth_wide'])
-        self.fll_bandwidth_narrow = float(configuration['fll_bandwidth_narrow'])
-        self.fll_threshold_wide = float(configuration['fll_threshold_wide'])
-        self.fll_threshold_narrow = float(configuration['fll_threshold_narrow'])
-        self.pll_bandwidth_wide = float(configuration['pll_bandwidth_wide'])
-        self.pll_bandwidth_narrow = float(configuration['pll_bandwidth_narrow'])
-        self.pll_threshold_wide = float(configuration['pll_threshold_wide'])
-        self.pll_threshold_narrow = float(configuration['pll_threshold_narrow'])
-        self.dllDiscrim = 0.0
-        self.pllDiscrim = 0.0
-        self.fllDiscrim = 0.0
-        self.fllBandwidth = self.fll_bandwidth_pullin
-        self.pllBandwidth = self.pll_bandwidth_wide
-        self.dllLockIndicator = 0.0
-        self.fllLockIndicator = 0.0
-        self.pllLockIndicator = 0.0
-        self.fll_vel_memory = 0.0
-        self.carrierFrequencyError = 0.0
-        self.codeFrequencyError = 0.0
-        self.timeSinceLastState = 0
-        self.loopLockState = LoopLockState.PULL_IN
-        self.trackFlags = TrackingFlags.UNKNOWN
-        self.remainingCode = 0.0
-        self.remainingCarrier = 0.0
-        self.codeStep = GPS_L1CA_CODE_FREQ / self.rfSignal.samplingFrequency
-        self.track_requiredSamples = int(np.ceil((GPS_L1CA_CODE_SIZE_BITS - self.remainingCode) / self.codeStep))
-        self.codeCounter = 0
-
-    def runTracking(self):
-        if self.rfBuffer.getNbUnreadSamples(self.currentSample) < self.track_requiredSamples:
-            return None
-        self.runCorrelators()                                   # <- GPU (GpuCorrelatorSeams)
-        dllDiscrim, fllDiscrim, pllDiscrim = self.runDiscriminators()
-        carrierFrequencyError = self.runCarrierFrequencyFilter(fllDiscrim=fllDiscrim, pllDiscrim=pllDiscrim)
-        codeFrequencyError = self.runCodeFrequencyFilter(dllDiscrim=dllDiscrim)
-        self.runLoopIndicators()
-        self.postTrackingUpdate(dllDiscrim, fllDiscrim, pllDiscrim, carrierFrequencyError, codeFrequencyError)
-        self.trackingStateUpdate()
-        return self.prepareResultsTracking()
-
-    def runDiscriminators(self):
-        fllDiscrim = pllDiscrim = dllDiscrim = 0.0
-        if self.loopLockState == LoopLockState.PULL_IN:
-            if self.codeCounter > 1:
-                fllDiscrim = self.runFrequencyDiscriminator(self.correlatorsResults)
-            dllDiscrim = self.runCodeDiscriminator(self.correlatorsResults)
-        else:
-            fllDiscrim = self.runFrequencyDiscriminator(self.correlatorsResults)
-            pllDiscrim = self.runPhaseDiscriminator(self.correlatorsResults)
-            dllDiscrim = self.runCodeDiscriminator(self.correlatorsResults)
-        return dllDiscrim, fllDiscrim, pllDiscrim
-
-    def runCarrierFrequencyFilter(self, fllDiscrim=0.0, pllDiscrim=0.0, coherentIntegration=1):
-        carrierFrequencyError, self.fll_vel_memory = FLLassistedPLL_2ndOrder(
-            pllDiscrim, fllDiscrim, w0f=self.fllBandwidth / W0_BANDWIDTH_1, w0p=self.pllBandwidth / W0_BANDWIDTH_2,
-            a2=W0_SCALE_A2, integrationTime=coherentIntegration * 1e-3, velMemory=self.fll_vel_memory)
-        return carrierFrequencyError
-
-    def runCodeFrequencyFilter(self, dllDiscrim, coherentIntegration=1):
-        return BorreLoopFilter(dllDiscrim, self.dllDiscrim, self.track_dll_tau1, self.track_dll_tau2,
-                               self.track_dll_pdi * coherentIntegration)
-
-    def runLoopIndicators(self):
-        if self.codeCounter == 0:
-            return
-        iprompt = self.correlatorsResults[self.IDX_I_PROMPT]
-        qprompt = self.correlatorsResults[self.IDX_Q_PROMPT]
-        self.fllLockIndicator = FLL_Lock_Borre(iprompt=iprompt, qprompt=qprompt, iprompt_prev=self.iPromptPrev,
-                                               qprompt_prev=self.qPromptPrev, fll_lock_prev=self.fllLockIndicator,
-                                               alpha=0.005)
-        if self.loopLockState > LoopLockState.PULL_IN:
-            self.pllLockIndicator = PLL_Lock_Borre(iprompt=iprompt, qprompt=qprompt,
-                                                   pll_lock_prev=self.pllLockIndicator, alpha=0.005)
-        self.cn0_PdPnRatio += (iprompt**2 + qprompt**2) / (abs(iprompt) - abs(qprompt)) ** 2
-        if self.correlatorsAccumCounter == LNAV_MS_PER_BIT:
-            self.cn0 = CN0_Beaulieu(self.cn0_PdPnRatio, self.correlatorsAccumCounter,
-                                    self.correlatorsAccumCounter * 1e-3, self.cn0)
-            self.cn0_PdPnRatio = 0.0
-        self.dllLockIndicator = self.cn0
-
-    def postTrackingUpdate(self, dllDiscrim, fllDiscrim, pllDiscrim, carrierFrequencyError, codeFrequencyError):
-        self.codeCounter += 1
-        self.codeSinceTOW += 1
-        self.dllDiscrim = dllDiscrim
-        self.fllDiscrim = fllDiscrim
-        self.pllDiscrim = pllDiscrim
-        self.carrierFrequencyError = carrierFrequencyError
-        self.codeFrequencyError = codeFrequencyError
-        # NCO update -- GPS-ICD pi here
-        self.remainingCarrier -= self.carrierFrequency * TWO_PI * self.track_requiredSamples / self.rfSignal.samplingFrequency
-        self.remainingCarrier %= TWO_PI
-        self.codeFrequency -= self.codeFrequencyError
-        self.carrierFrequency += self.carrierFrequencyError
-        self.remainingCode += self.track_requiredSamples * self.codeStep - GPS_L1CA_CODE_SIZE_BITS
-        self.codeStep = self.codeFrequency / self.rfSignal.samplingFrequency
-        self.currentSample = (self.currentSample + self.track_requiredSamples) % self.rfBuffer.maxSize
-        self.track_requiredSamples = int(np.ceil((GPS_L1CA_CODE_SIZE_BITS - self.remainingCode) / self.codeStep))
-
-    def trackingStateUpdate(self):
-        if self.loopLockState != LoopLockState.PULL_IN and self.dllLockIndicator > self.dllLockThreshold \
-                and not (self.trackFlags & TrackingFlags.CODE_LOCK):
-            self.trackFlags |= TrackingFlags.CODE_LOCK
-        elif self.dllLockIndicator < self.dllLockThreshold and (self.trackFlags & TrackingFlags.CODE_LOCK):
-            self.trackFlags ^= TrackingFlags.CODE_LOCK
-        if (self.trackFlags & TrackingFlags.CODE_LOCK) and not (self.trackFlags & TrackingFlags.BIT_SYNC):
-            if np.sign(self.iPromptPrev) != np.sign(self.correlatorsResults[self.IDX_I_PROMPT]):
-                self.trackFlags |= TrackingFlags.BIT_SYNC
-                self.correlatorsAccum[:] = self.correlatorsResults[:]
-                self.correlatorsAccumCounter = 1
-                self.cn0_PdPnRatio = 0.0
-        self.iPromptPrev = self.correlatorsResults[self.IDX_I_PROMPT]
-        self.qPromptPrev = self.correlatorsResults[self.IDX_Q_PROMPT]
-
-        if self.loopLockState != LoopLockState.NARROW_TRACK and self.fllLockIndicator >= self.fll_threshold_narrow \
-                and self.pllLockIndicator >= self.pll_threshold_narrow:
-            self.loopLockState = LoopLockState.NARROW_TRACK
-            self.fllBandwidth = self.fll_bandwidth_narrow
-            self.pllBandwidth = self.pll_bandwidth_narrow
-            self.track_correlatorsSpacing = self.dll_epl_narrow
-        elif self.loopLockState != LoopLockState.WIDE_TRACK and self.fllLockIndicator >= self.fll_threshold_wide \
-                and self.fllLockIndicator < self.fll_threshold_narrow:
-            self.loopLockState = LoopLockState.WIDE_TRACK
-            self.fllBandwidth = self.fll_bandwidth_wide
-            self.pllBandwidth = self.pll_bandwidth_wide
-            self.track_correlatorsSpacing = self.dll_epl_wide
-        elif self.loopLockState != LoopLockState.PULL_IN and self.fllLockIndicator <= self.fll_threshold_wide:
-            self.loopLockState = LoopLockState.PULL_IN
-            self.fllBandwidth = self.fll_bandwidth_pullin
-            self.pllBandwidth = 0.0
-            self.track_correlatorsSpacing = self.dll_epl_wide
-        else:
-            self.timeSinceLastState += 1
-            return
-        self.timeSinceLastState = 0
-
-    def runFrequencyDiscriminator(self, correlatorResults):
-        return FLL_ATAN(iPrompt=correlatorResults[self.IDX_I_PROMPT], iPromptPrev=self.iPromptPrev,
-                        qPrompt=correlatorResults[self.IDX_Q_PROMPT], qPromptPrev=self.qPromptPrev, deltaT=1e-3)
-
-    def runPhaseDiscriminator(self, correlatorResults):
-        return PLL_costa(iPrompt=correlatorResults[self.IDX_I_PROMPT], qPrompt=correlatorResults[self.IDX_Q_PROMPT])
-
-    def runCodeDiscriminator(self, correlatorResults):
-        return DLL_NNEML(iEarly=correlatorResults[self.IDX_I_EARLY], qEarly=correlatorResults[self.IDX_Q_EARLY],
-                         iLate=correlatorResults[self.IDX_I_LATE], qLate=correlatorResults[self.IDX_Q_LATE])
-
-    def prepareResultsTracking(self):
-        results = self.prepareResults()
-        results['type'] = ChannelMessage.TRACKING_UPDATE
-        results["i_early"] = self.correlatorsResults[0]
-        results["q_early"] = self.correlatorsResults[1]
-        results["i_prompt"] = self.correlatorsResults[2]
-        results["q_prompt"] = self.correlatorsResults[3]
-        results["i_late"] = self.correlatorsResults[4]
-        results["q_late"] = self.correlatorsResults[5]
-        results["carrier_frequency"] = self.carrierFrequency
-        results["code_frequency"] = self.codeFrequency
-        results["carrier_frequency_error"] = self.carrierFrequencyError
-        results["code_frequency_error"] = self.codeFrequencyError
-        results["cn0"] = self.cn0
-        results["pll_lock"] = self.pllLockIndicator
-        results["fll_lock"] = self.fllLockIndicator
-        results["dll"] = self.dllDiscrim
-        results["pll"] = self.pllDiscrim
-        results["fll"] = self.fllDiscrim
-        results["lock_state"] = self.loopLockState
-        return results
-
-    # ================================================================= decoding hook
-    def runDecoding(self):
-        """Bit accumulation only (decodeBit: 20 prompts after bit sync -> Prompt2Bit); LNAV word / subframe
-        decoding stays with the reference's sydr/dsp/decoding.py, which is outside the accelerated path."""
-        self.decodeBit()
-        return None
-
-    def decodeBit(self):
-        if not (self.trackFlags & TrackingFlags.BIT_SYNC):
-            self.navPromptSum, self.navPromptSumCounter = 0.0, 0
-            return False
-        self.navPromptSum += self._lastPromptI()
-        self.navPromptSumCounter += 1
-        if self.navPromptSumCounter != LNAV_MS_PER_BIT:
-            return False
-        self.navBits.append(1 if self.navPromptSum > 0 else 0)
-        self.navPromptSum, self.navPromptSumCounter = 0.0, 0
-        return True
+    # thresholds / bandwidths under the reference's names (read-only views of the configuration row)
+    dllLockThreshold = property(lambda self: float(self._bank.cfg["dll_threshold"][self._row]))
+    track_dll_tau1 = property(lambda self: float(self._bank.cfg["dll_tau1"][self._row]))
+    track_dll_tau2 = property(lambda self: float(self._bank.cfg["dll_tau2"][self._row]))
+    track_dll_pdi = property(lambda self: float(self._bank.cfg["dll_pdi"][self._row]))

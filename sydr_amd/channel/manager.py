@@ -1,24 +1,26 @@
 """ChannelManager with the reference's surface (sydr/channel/channelManager.py:34-231) -- `addChannel`,
-`requestTracking`, `addNewRFData`, `run`, `getChannel`, `close` -- and none of its plumbing:
-no shared memory, no child processes, no Events, no pickled Queue.  One manager
-drives the channels of ONE GPU in-process; the RF ring lives in HBM.
+`requestTracking`, `addNewRFData`, `run`, `getChannel`, `close` -- and none of its plumbing: no shared
+memory, no child processes, no Events, no pickled Queue.  One manager drives the channels
+of ONE GPU in-process; the RF ring and the channels' tracking state both live in HBM.
 
-`run()` is the per-millisecond tick of the reference, but batched: every channel that is ready for
-an epoch is correlated in ONE `sdr_epl_batch` launch, every channel ready for acquisition in ONE
-`sdr_pcps` call; then each channel finishes its scalar bookkeeping and emits the reference's packets.
+A tick (`addNewRFData(slab)` + `run()`, the body of the receiver's outer loop, receiver.py:120-131) is
+ONE device call: the slab goes into the ring and every tracking channel whose next epoch is complete
+advances by one epoch on the device (`sdr_bank_tick`).  Channels still acquiring are searched together in
+one `sdr_pcps` call.  `runBlock(n)` advances by up to n epochs per channel in one launch (loops closed
+on the device for the whole block).
 
-`runBlock(n)` is the fast path the reference has no counterpart for: n epochs of closed-loop
-tracking for all tracking channels inside one persistent kernel (loop closure on the device),
-returning the same per-epoch packets afterwards.
+Multi-GPU (north_star: channels shard across the GPUs of a node, IQ replicated, no collective): give each
+process / device its own manager with `channels=shard_channels(total, rank, world)`.
 """
 from __future__ import annotations
 
 import numpy as np
 
-from ..engine import FMT_CF64, FMT_CI16, FMT_CI8, Engine, make_items
+from ..engine import FMT_CF64, FMT_CI16, FMT_CI8, Engine
 from ..utils.devicering import CircularBuffer
 from ..utils.enumerations import ChannelState
-from . import loopstate
+from .bank import TickPackets, channel_update_builder, tracking_packet
+from .tracked import DeviceTrackedChannel
 
 
 def shard_channels(n_items: int, rank: int, world_size: int) -> list[int]:
@@ -34,7 +36,8 @@ def shard_channels(n_items: int, rank: int, world_size: int) -> list[int]:
 class ChannelManager:
     TIMEOUT = 1
 
-    def __init__(self, rfSignal, engine: Engine | None = None, device_id: int = 0, keepCorrelationMap: bool = True):
+    def __init__(self, rfSignal, engine: Engine | None = None, device_id: int = 0, keepCorrelationMap: bool = True,
+                 ring_ms: int = 100):
         self.rfSignal = rfSignal
         self.channels = {}
         self.nbChannels = 0
@@ -42,19 +45,29 @@ class ChannelManager:
             from ..runtime import get_engine
             engine = get_engine(device_id)
         self.engine = engine
-        buffersize = int(self.rfSignal.samplingFrequency * 1e-3 * 100)   # 100 ms, as channelManager.py:57
+        buffersize = int(self.rfSignal.samplingFrequency * 1e-3 * ring_ms)   # 100 ms, as channelManager.py:57
         fmt = {np.int8: FMT_CI8, np.int16: FMT_CI16}.get(getattr(rfSignal, "fileDataType", None), FMT_CF64)
         self.sharedBuffer = CircularBuffer(buffersize, rfSignal.dtype, engine=engine, fmt=fmt)
         self.resultQueue = None
         self.keepCorrelationMap = keepCorrelationMap
         self._slots = 0
+        self._pending = None          # slab handed to addNewRFData, uploaded by the next run()
+
+    @property
+    def bank(self):
+        return self.sharedBuffer.channelBank
 
     # ------------------------------------------------------------------ reference surface
     def addChannel(self, ChannelObject, configuration, nbChannels=1):
         total = self.nbChannels + nbChannels
         if total > self._slots:
+            self._flush_pending()
             self._slots = max(32, total)
             self.engine.code_slots(self._slots)
+            for ch in self.channels.values():        # the tables were re-allocated: stage the codes again
+                if ch.channelState is not ChannelState.IDLE:
+                    ch._stagedPrn = None
+                    ch._ensure_code()
         for _ in range(nbChannels):
             cid = self.nbChannels
             ch = ChannelObject(cid, self.sharedBuffer, self.resultQueue, self.rfSignal, configuration)
@@ -71,7 +84,32 @@ class ChannelManager:
         raise Warning(f"Could not find an IDLE channel for tracking satellite [G{satelliteID}].")
 
     def addNewRFData(self, data):
-        self.sharedBuffer.shift(data)
+        """Queue one slab for the ring.  The copy itself rides in the next run()'s device call (one call per tick);
+        anything that looks at the ring before that (another addNewRFData, getSlice, runBlock) flushes it first."""
+        self._flush_pending()
+        staged, offset, count = self.sharedBuffer.stage(data)
+        self._guard_unread(count)
+        self._pending = (staged, offset)
+        self.sharedBuffer.shiftIdxWrite(count)
+
+    def _guard_unread(self, count: int):
+        """Refuse to overwrite samples a tracking channel has not consumed yet (the reference would silently wrap:
+        circularbuffer.py:54-82 -- and then track garbage)."""
+        bank = self.bank
+        if bank is None or not self.sharedBuffer.full:
+            return
+        idx = np.flatnonzero(bank.tracking & ~bank.lost)
+        if idx.size and int(bank.unread(idx).max()) + count > self.sharedBuffer.maxSize:
+            ch = int(idx[int(np.argmax(bank.unread(idx)))])
+            raise ValueError(f"addNewRFData: {count} more samples would overwrite what channel {ch} has not read yet "
+                             f"({int(bank.unread(idx).max())} unread of a {self.sharedBuffer.maxSize}-sample ring); "
+                             "run the channels first")
+
+    def _flush_pending(self):
+        if self._pending is not None:
+            staged, offset = self._pending
+            self._pending = None
+            self.engine.iq_upload(staged, offset)
 
     def getChannel(self, channelID):
         if channelID not in self.channels:
@@ -79,80 +117,108 @@ class ChannelManager:
         return self.channels[channelID]
 
     def close(self):
+        self._flush_pending()
         self.channels.clear()
+        if self.bank is not None:
+            self.bank.close()
+            self.sharedBuffer.channelBank = None
 
     # ------------------------------------------------------------------ the tick
     def run(self):
-        """Flat list of result packets for this tick (channelManager.py:149-188)."""
+        """Flat sequence of result packets for this tick (channelManager.py:149-188)."""
+        out = TickPackets()
         active = [ch for ch in self.channels.values() if ch.channelState is not ChannelState.IDLE]
-        self._batchAcquisition(active)
-        self._batchCorrelators(active)
-        results = []
-        for ch in active:
-            packets = ch._processHandler()
-            packets.append(ch.prepareChannelUpdate())
-            results.extend(packets)
-        return results
+        if not active:
+            self._flush_pending()
+            return out
+        acquiring = [ch for ch in active if ch.channelState is ChannelState.ACQUIRING]
+        bank = self.bank
+        ready = bank.ready() if bank is not None else np.zeros(0, dtype=np.int32)
+        # one device call: ring ingest + one epoch for every ready channel
+        staged, offset = self._pending if self._pending is not None else (None, 0)
+        self._pending = None
+        if bank is not None:
+            rec, done = bank.tick(staged, offset, ready)
+        elif staged is not None:
+            self.engine.iq_upload(staged, offset)
+        if acquiring:
+            out.add_ready(self._acquire(acquiring))
+        for ch in active:   # plugins that keep their loops on the host (e.g. the reference's class behind the seams mixin)
+            if ch.channelState is ChannelState.TRACKING and not isinstance(ch, DeviceTrackedChannel):
+                out.add_ready(ch._processHandler())
+        if len(ready):
+            ran = np.flatnonzero(done > 0)
+            cids, kinds, rec = ready[ran], bank.cfg["loop_kind"][ready[ran]], rec[ran]
+            out.add(len(ran), lambda i: tracking_packet(int(cids[i]), int(kinds[i]), rec[i]))
+        # channel updates: everything they report is captured now, the dicts are made when read
+        cids = np.array([ch.channelID for ch in active], dtype=np.int64)
+        states = [ch.channelState for ch in active]
+        if bank is not None:
+            unread = bank.unread(cids)
+            since = bank.code_since_tow[cids] * 1 + unread / (self.rfSignal.samplingFrequency / 1e3)
+            out.add(len(active), channel_update_builder(cids, states, bank.state["track_flags"][cids].copy(),
+                                                        bank.tow[cids].copy(), since, unread,
+                                                        bank.code_since_tow[cids].copy()))
+        else:
+            out.add_ready(ch.prepareChannelUpdate() for ch in active)
+        return out
 
-    def _batchAcquisition(self, active):
-        groups = {}
-        for ch in active:
-            if ch.channelState is ChannelState.ACQUIRING and hasattr(ch, "acquisitionRequest") \
-                    and self.sharedBuffer.getNbUnreadSamples(ch.currentSample) >= ch.acq_requiredSamples:
-                ch._ensure_code()
-                r = ch.acquisitionRequest()
-                key = (r["start"], r["fs"], r["if_hz"], r["doppler_range"], r["doppler_step"], r["coh"], r["noncoh"])
-                groups.setdefault(key, []).append(ch)
-        for key, chans in groups.items():
-            start, fs, if_hz, rng, step, coh, noncoh = key
+    def _acquire(self, acquiring):
+        """Channels with enough samples for their search, grouped by search geometry: ONE sdr_pcps call per group
+        (the forward transforms of the Doppler-mixed slab are shared by all PRNs).  Plugins that replace the
+        search seam (e.g. the SerialSearch plugin) run their own."""
+        packets, groups = [], {}
+        for ch in acquiring:
+            if self.sharedBuffer.getNbUnreadSamples(ch.currentSample) < ch.acq_requiredSamples:
+                continue
+            if getattr(type(ch), "runSignalSearch", None) is not _default_search():
+                packets.extend(ch._processHandler())
+                continue
+            ch._ensure_code()
+            r = ch.acquisitionRequest()
+            key = (r["start"], r["fs"], r["if_hz"], r["doppler_range"], r["doppler_step"], r["coh"], r["noncoh"])
+            groups.setdefault(key, []).append(ch)
+        for (start, fs, if_hz, rng, step, coh, noncoh), chans in groups.items():
             pb, pc, pr, cmap = self.engine.pcps([c.codeSlot for c in chans], start, fs, if_hz, rng, step, coh, noncoh,
                                                 want_map=self.keepCorrelationMap)
             for k, ch in enumerate(chans):
                 ch._injectedAcquisition = (cmap[k] if cmap is not None else None, [int(pb[k]), int(pc[k])], float(pr[k]))
+                packets.append(ch.runAcquisition())
+        return [p for p in packets if p is not None]
 
-    def _batchCorrelators(self, active):
-        groups = {}
-        for ch in active:
-            if ch.channelState is ChannelState.TRACKING and hasattr(ch, "correlatorRequest"):
-                req = ch.correlatorRequest()
-                if req is not None:
-                    groups.setdefault(req["spacing"], []).append((ch, req))
-        for spacing, entries in groups.items():
-            reqs = [r for _, r in entries]
-            items = make_items([r["code_slot"] for r in reqs], [r["n_samples"] for r in reqs],
-                               [r["start_sample"] for r in reqs], [r["carrier_hz"] for r in reqs],
-                               [r["rem_carrier"] for r in reqs], [r["rem_code"] for r in reqs],
-                               [r["code_step"] for r in reqs])
-            out = self.engine.epl_batch(items, spacing, self.rfSignal.samplingFrequency)
-            for (ch, _), row in zip(entries, out):
-                ch._injectedCorrelators = row
-
-    # ------------------------------------------------------------------ closed loop on the device
+    # ------------------------------------------------------------------ many epochs per call
     def runBlock(self, nbEpochs: int):
-        """Track every TRACKING channel for `nbEpochs` code periods inside one persistent kernel.
+        """Up to `nbEpochs` code periods for every TRACKING channel inside one persistent launch.
 
-        The ring must already hold the samples those epochs will consume (a long resident ring, or
-        a block of milliseconds added beforehand).  Returns the per-epoch TRACKING_UPDATE packets,
-        channel by channel, epoch by epoch, followed by one CHANNEL_UPDATE per channel."""
-        chans = [ch for ch in self.channels.values() if ch.channelState is ChannelState.TRACKING]
-        if not chans:
-            return []
-        for ch in chans:
-            need = nbEpochs * (int(ch.track_requiredSamples) + 1)
-            if self.sharedBuffer.getNbUnreadSamples(ch.currentSample) < need:
-                raise ValueError(f"runBlock({nbEpochs}): channel {ch.channelID} needs ~{need} unread samples in the "
-                                 f"ring, has {self.sharedBuffer.getNbUnreadSamples(ch.currentSample)}")
-        kinds ={loopstate.loop_kind(ch) for ch in chans}
-        results = []
-        for kind in sorted(kinds):
-            group = [ch for ch in chans if loopstate.loop_kind(ch) == kind]
-            cfg = loopstate.export_cfg(group[0])
-            states = [loopstate.export_state(ch) for ch in group]
-            states, traj, bits = self.engine.track_closed_loop(states, cfg, nbEpochs, want_traj=True, want_bits=True)
-            for ch, st, tr, nav in zip(group, states, traj, bits):
-                results.extend(loopstate.tracking_packet(ch, rec) for rec in tr)
-                loopstate.import_state(ch, st, nbEpochs, last=tr[-1])
-                if hasattr(ch, "navBits"):
-                    ch.navBits.extend(int(b) for b in nav)   # bits decided on the device: 1 byte per 20 ms per channel
-        results.extend(ch.prepareChannelUpdate() for ch in chans)
-        return results
+        Each channel runs as many whole epochs as the ring already holds for it (at most nbEpochs): nothing is
+        read that has not been written.  Returns the per-epoch TRACKING_UPDATE packets, channel by channel, epoch
+        by epoch, followed by one CHANNEL_UPDATE per tracking channel."""
+        self._flush_pending()
+        out = TickPackets()
+        bank = self.bank
+        chans = [ch for ch in self.channels.values() if ch.channelState is ChannelState.TRACKING and not ch.lostLock]
+        if not chans or bank is None:
+            return out
+        cids = np.array([ch.channelID for ch in chans], dtype=np.int32)
+        # epochs the ring holds: every epoch is at most n_samples + 1 long (the NCO moves it by a sample at most)
+        budget = bank.unread(cids) // (bank.state["n_samples"][cids] + 1)
+        groups = {}
+        for cid, n in zip(cids, np.minimum(budget, nbEpochs)):
+            if n > 0:
+                groups.setdefault((int(n), int(bank.cfg["n_taps"][cid])), []).append(int(cid))
+        for (n, _), members in sorted(groups.items()):
+            members = np.array(members, dtype=np.int32)
+            rec, done = bank.step(members, n)
+            kinds = bank.cfg["loop_kind"][members]
+            flat = [(int(c), int(k), rec[r, e]) for r, (c, k) in enumerate(zip(members, kinds)) for e in range(done[r])]
+            out.add(len(flat), lambda i, flat=flat: tracking_packet(*flat[i]))
+        out.add_ready(ch.prepareChannelUpdate() for ch in chans)
+        return out
+
+
+def _default_search():
+    from .seams import GpuCorrelatorSeams
+    return GpuCorrelatorSeams.runSignalSearch
+
+
+__all__ = ["ChannelManager", "shard_channels", "FMT_CF64"]

@@ -171,7 +171,8 @@ int sdr_code_slots_ex(sdr_engine* e, int n_slots, int max_chips, int max_periods
         (int64_t)max_chips * max_periods > 32768)
         return sdr_fail(SDR_ERR_INVALID, "bad code slot geometry (%d slots, %d chips, %d periods; chips*periods <= 32768)",
                         n_slots, max_chips, max_periods);
-    SDR_HIP(hipStreamSynchronize(e->stream));
+    SDR_HIP(hipDeviceSynchronize());   // launches on any of the engine's streams may still read the old tables
+    e->code_generation += 1;             // plans and bank entries made against the old tables are stale from here on
     if (e->codes) SDR_HIP(hipFree(e->codes));
     if (e->luts) SDR_HIP(hipFree(e->luts));
     e->luts = nullptr;

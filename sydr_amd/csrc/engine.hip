@@ -30,10 +30,38 @@ int sdr_set_device(sdr_engine* e) {
     return SDR_OK;
 }
 
-int sdr_devbuf_reserve(sdr_engine* e, DevBuf* b, size_t bytes) {
+int sdr_devbuf_reserve(sdr_engine* e, DevBuf* b, size_t bytes) { return sdr_devbuf_reserve_on(e, e->stream, b, bytes); }
+
+int sdr_pinned_reserve(sdr_engine* e, StreamCtx* ctx, size_t bytes) {
+    if (bytes <= ctx->pinned_bytes && ctx->pinned) return SDR_OK;
+    if (ctx->pinned) {
+        SDR_HIP(hipStreamSynchronize(ctx->stream));
+        SDR_HIP(hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+    }
+    const size_t want = bytes < 65536 ? 65536 : bytes * 2;
+    hipError_t err = hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault);
+    if (err != hipSuccess) {
+        ctx->pinned = nullptr;
+        return sdr_fail(SDR_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(err));
+    }
+    ctx->pinned_bytes = want;
+    (void)e;
+    return SDR_OK;
+}
+
+StreamCtx* sdr_stream_ctx(sdr_engine* e, int stream_id) {
+    if (stream_id == 0) return &e->ctx0;
+    if (stream_id < 0 || stream_id > (int)e->streams.size()) return nullptr;
+    return e->streams[(size_t)stream_id - 1];
+}
+
+int sdr_devbuf_reserve_on(sdr_engine* e, hipStream_t stream, DevBuf* b, size_t bytes) {
+    (void)e;
     if (bytes <= b->bytes && b->ptr) return SDR_OK;
     if (b->ptr) {
-        SDR_HIP(hipStreamSynchronize(e->stream));
+        SDR_HIP(hipStreamSynchronize(stream));
         SDR_HIP(hipFree(b->ptr));
         b->ptr = nullptr;
         b->bytes = 0;
@@ -48,7 +76,8 @@ int sdr_devbuf_reserve(sdr_engine* e, DevBuf* b, size_t bytes) {
     return SDR_OK;
 }
 
-ProfScope::ProfScope(sdr_engine* eng, const char* name) : e(eng), active(eng->prof) {
+ProfScope::ProfScope(sdr_engine* eng, const char* name, hipStream_t on)
+    : e(eng), active(eng->prof), stream(on ? on : eng->stream) {
     rec.name = name;
     rec.start = rec.stop = nullptr;
     if (!active) return;
@@ -63,12 +92,12 @@ ProfScope::ProfScope(sdr_engine* eng, const char* name) : e(eng), active(eng->pr
         }
         (i == 0 ? rec.start : rec.stop) = ev;
     }
-    (void)hipEventRecord(rec.start, e->stream);
+    (void)hipEventRecord(rec.start, stream);
 }
 
 ProfScope::~ProfScope() {
     if (!active) return;
-    (void)hipEventRecord(rec.stop, e->stream);
+    (void)hipEventRecord(rec.stop, stream);
     e->prof_records.push_back(rec);
 }
 
@@ -117,14 +146,27 @@ int sdr_engine_create(int device_id, sdr_engine** out) {
         delete e;
         return sdr_fail(SDR_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(err));
     }
+    e->ctx0.stream = e->stream;
     *out = e;
     return SDR_OK;
+}
+
+static void free_ctx(StreamCtx* c) {
+    for (DevBuf* b : {&c->traj, &c->bits, &c->xchg})
+        if (b->ptr) (void)hipFree(b->ptr);
+    if (c->pinned) (void)hipHostFree(c->pinned);
 }
 
 void sdr_engine_destroy(sdr_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    (void)hipStreamSynchronize(e->stream);
+    (void)hipDeviceSynchronize();
+    free_ctx(&e->ctx0);
+    for (StreamCtx* c : e->streams) {
+        free_ctx(c);
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+    }
     for (auto& r : e->prof_records) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
@@ -132,7 +174,7 @@ void sdr_engine_destroy(sdr_engine* e) {
     for (auto ev : e->prof_pool) (void)hipEventDestroy(ev);
     DevBuf* bufs[] = {&e->ws_items,  &e->ws_out,   &e->ws_spacing, &e->pcps_fwd,   &e->pcps_a,
                       &e->pcps_b,    &e->pcps_code, &e->pcps_tw,   &e->pcps_map,   &e->pcps_csum,
-                      &e->pcps_part, &e->pcps_res,  &e->track_state, &e->track_cfg, &e->track_traj, &e->track_bits, &e->track_xchg,
+                      &e->pcps_part, &e->pcps_res,  &e->track_state, &e->track_cfg,
                       &e->pcps_blu,  &e->pcps_blu_x, &e->pcps_blu_a, &e->pcps_blu_b};
     for (DevBuf* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
@@ -147,6 +189,29 @@ void sdr_engine_destroy(sdr_engine* e) {
 int sdr_engine_sync(sdr_engine* e) {
     if (int rc = sdr_set_device(e)) return rc;
     SDR_HIP(hipStreamSynchronize(e->stream));
+    return SDR_OK;
+}
+
+int sdr_stream_create(sdr_engine* e, int* stream_id) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!stream_id) return sdr_fail(SDR_ERR_INVALID, "stream_id is NULL");
+    StreamCtx* c = new (std::nothrow) StreamCtx();
+    if (!c) return sdr_fail(SDR_ERR_NOMEM, "host allocation failed");
+    hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (err != hipSuccess) {
+        delete c;
+        return sdr_fail(SDR_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(err));
+    }
+    e->streams.push_back(c);
+    *stream_id = (int)e->streams.size();
+    return SDR_OK;
+}
+
+int sdr_stream_sync(sdr_engine* e, int stream_id) {
+    if (int rc = sdr_set_device(e)) return rc;
+    StreamCtx* c = sdr_stream_ctx(e, stream_id);
+    if (!c) return sdr_fail(SDR_ERR_INVALID, "stream id %d does not exist", stream_id);
+    SDR_HIP(hipStreamSynchronize(c->stream));
     return SDR_OK;
 }
 
@@ -213,7 +278,7 @@ int sdr_iq_alloc(sdr_engine* e, int64_t capacity_samples, int fmt) {
     return SDR_OK;
 }
 
-static int iq_copy(sdr_engine* e, void* host, int64_t n, int64_t off, bool upload) {
+static int iq_copy(sdr_engine* e, void* host, int64_t n, int64_t off, bool upload, bool wait = true) {
     if (int rc = sdr_set_device(e)) return rc;
     if (!e->iq) return sdr_fail(SDR_ERR_STATE, "IQ ring not allocated");
     if (!host && n > 0) return sdr_fail(SDR_ERR_INVALID, "host pointer is NULL");
@@ -235,10 +300,11 @@ static int iq_copy(sdr_engine* e, void* host, int64_t n, int64_t off, bool uploa
         if (n > first)
             SDR_HIP(hipMemcpyAsync(h + first * sb, dev, (n - first) * sb, hipMemcpyDeviceToHost, e->stream));
     }
-    // The caller owns `host`; do not keep it past return.
-    SDR_HIP(hipStreamSynchronize(e->stream));
+    // The caller owns `host`; do not keep it past return (wait == false: the caller of this file synchronises).
+    if (wait) SDR_HIP(hipStreamSynchronize(e->stream));
     return SDR_OK;
 }
+
 
 int sdr_iq_upload(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset) {
     return iq_copy(e, const_cast<void*>(iq), n_samples, ring_offset, true);
@@ -249,3 +315,7 @@ int sdr_iq_download(sdr_engine* e, void* iq, int64_t n_samples, int64_t ring_off
 }
 
 }  // extern "C"
+
+int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset) {
+    return iq_copy(e, const_cast<void*>(iq), n_samples, ring_offset, true, false);
+}

@@ -40,9 +40,21 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+// What one HIP stream of the engine needs for itself so that launches on different streams (one per channel
+// batch) never share a scratch buffer.
+struct StreamCtx {
+    hipStream_t stream = nullptr;
+    DevBuf traj, bits, xchg;     // closed-loop launch scratch: epoch records, [list][n_bits][done] + bits, cluster exchange lines
+    void* pinned = nullptr;      // page-locked host staging for the small per-step results
+    size_t pinned_bytes = 0;
+};
+
 struct sdr_engine {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // == ctx0.stream
+    StreamCtx ctx0;                 // stream id 0
+    std::vector<StreamCtx*> streams;  // ids 1..
+    int64_t code_generation = 0;    // bumped whenever the code slots are re-allocated (live plans are then stale)
 
     // IQ ring
     void* iq = nullptr;
@@ -63,7 +75,7 @@ struct sdr_engine {
     // workspaces
     DevBuf ws_items, ws_out, ws_spacing;
     DevBuf pcps_fwd, pcps_a, pcps_b, pcps_code, pcps_tw, pcps_map, pcps_csum, pcps_part, pcps_res;
-    DevBuf track_state, track_cfg, track_traj, track_bits, track_xchg;
+    DevBuf track_state, track_cfg;
     int n_cus = 0;              // compute units of the device (sizes the closed-loop clusters)
     int track_force_parts = 0;  // diagnostics / tests: 0 = choose, else 1, 2, 4 or 8 workgroups per channel
     int64_t pcps_tw_n = 0;
@@ -79,6 +91,12 @@ struct sdr_engine {
 };
 
 int sdr_devbuf_reserve(sdr_engine* e, DevBuf* b, size_t bytes);
+// Same for a buffer only ever used on `stream` (waits for that stream alone before a re-allocation).
+int sdr_devbuf_reserve_on(sdr_engine* e, hipStream_t stream, DevBuf* b, size_t bytes);
+int sdr_pinned_reserve(sdr_engine* e, StreamCtx* ctx, size_t bytes);
+StreamCtx* sdr_stream_ctx(sdr_engine* e, int stream_id);   // nullptr when the id does not exist
+// Queue the ring write of sdr_iq_upload on the engine's stream without waiting for it.
+int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset);
 
 static inline size_t sdr_fmt_bytes(int fmt) {
     switch (fmt) {
@@ -95,7 +113,8 @@ struct ProfScope {
     sdr_engine* e;
     ProfRecord rec;
     bool active;
-    ProfScope(sdr_engine* eng, const char* name);
+    hipStream_t stream;
+    ProfScope(sdr_engine* eng, const char* name, hipStream_t on = nullptr);
     ~ProfScope();
 };
 

@@ -91,14 +91,14 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
 }
 
 template <int FMT, int NT>
-void launch_one(sdr_engine* e, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
+void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
                 int tap0, int n_taps_total, int lut_words, int wide, double* d_out) {
     size_t shmem = (size_t)(kWaves * 2 * NT) * sizeof(double) + (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t) +
                    (wide ? (size_t)kThreads * kPrefixSlots * sizeof(double2) : 0);
     auto launch = [&](auto kernel) {
         if (shmem > 64u * 1024u)  // beyond the default dynamic-LDS grant (long multi-period replicas)
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(kernel, dim3(n_items), dim3(kThreads), shmem, e->stream, e->iq, e->iq_capacity, d_items,
+        hipLaunchKernelGGL(kernel, dim3(n_items), dim3(kThreads), shmem, stream, e->iq, e->iq_capacity, d_items,
                            e->luts, lut_words, e->lut_stride, d_spacing, fs, tap0, n_taps_total, d_out);
     };
     if (wide == 16)
@@ -110,23 +110,23 @@ void launch_one(sdr_engine* e, const sdr_epl_item* d_items, int n_items, const d
 }
 
 template <int FMT>
-void launch_fmt(sdr_engine* e, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
+void launch_fmt(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
                 int n_taps, int lut_words, int wide, double* d_out) {
     // Taps are served in register-resident chunks of 5/3/2/1.
     int t0 = 0;
     while (t0 < n_taps) {
         int left = n_taps - t0;
         if (left >= 5) {
-            launch_one<FMT, 5>(e, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, d_out);
+            launch_one<FMT, 5>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, d_out);
             t0 += 5;
         } else if (left >= 3) {
-            launch_one<FMT, 3>(e, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, d_out);
+            launch_one<FMT, 3>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, d_out);
             t0 += 3;
         } else if (left == 2) {
-            launch_one<FMT, 2>(e, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, d_out);
+            launch_one<FMT, 2>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, d_out);
             t0 += 2;
         } else {
-            launch_one<FMT, 1>(e, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, d_out);
+            launch_one<FMT, 1>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, d_out);
             t0 += 1;
         }
     }
@@ -143,6 +143,8 @@ struct sdr_epl_plan {
     int lut_words = 0;
     int wide = 0;  // 16 / 8: every item has 16 (8) * code_step < 1, the boundary variant with that group width applies
     double fs = 0.0;
+    int64_t code_generation = 0;  // of the engine's code tables the plan was validated against
+    int64_t ring_capacity = 0;    // and of the ring
 };
 
 // Host-side check that no item can index outside the ring or the staged LUT.
@@ -206,6 +208,8 @@ int sdr_epl_plan_create(sdr_engine* e, const sdr_epl_item* items, int n_items, c
     p->fs = fs;
     p->lut_words = lut_words;
     p->wide = wide;
+    p->code_generation = e->code_generation;
+    p->ring_capacity = e->iq_capacity;
     hipError_t err = hipMalloc(&p->d_items, (size_t)n_items * sizeof(sdr_epl_item));
     if (err == hipSuccess) err = hipMalloc(&p->d_out, (size_t)n_items * 2 * n_taps * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&p->d_spacing, SDR_MAX_TAPS * sizeof(double));
@@ -225,8 +229,18 @@ int sdr_epl_plan_create(sdr_engine* e, const sdr_epl_item* items, int n_items, c
 }
 
 int sdr_epl_plan_run_range(sdr_engine* e, sdr_epl_plan* p, int64_t first, int64_t count) {
+    return sdr_epl_plan_run_range_on(e, p, first, count, 0);
+}
+
+int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int64_t count, int stream_id) {
     if (int rc = sdr_set_device(e)) return rc;
     if (!p) return sdr_fail(SDR_ERR_INVALID, "plan is NULL");
+    StreamCtx* ctx = sdr_stream_ctx(e, stream_id);
+    if (!ctx) return sdr_fail(SDR_ERR_INVALID, "stream id %d does not exist", stream_id);
+    // A plan is validated against the code tables and the ring as they were at sdr_epl_plan_create; after
+    // sdr_code_slots(_ex) / sdr_iq_alloc its slot indices, LUT length and ring bounds mean something else.
+    if (p->code_generation != e->code_generation || p->ring_capacity != e->iq_capacity || p->lut_words > e->lut_stride)
+        return sdr_fail(SDR_ERR_STATE, "plan is stale: the code slots or the IQ ring were re-allocated after it was created");
     if (first < 0 || count <= 0 || first + count > p->n_items)
         return sdr_fail(SDR_ERR_RANGE, "item range [%lld, %lld) outside the plan's %d items", (long long)first,
                         (long long)(first + count), p->n_items);
@@ -234,12 +248,13 @@ int sdr_epl_plan_run_range(sdr_engine* e, sdr_epl_plan* p, int64_t first, int64_
     double* out = p->d_out + (size_t)first * 2 * p->n_taps;
     const int n = (int)count;
     {
-        ProfScope ps(e, "epl_kernel");
+        hipStream_t st = ctx->stream;
+        ProfScope ps(e, "epl_kernel", st);
         switch (e->iq_fmt) {
-            case SDR_FMT_CI8: launch_fmt<SDR_FMT_CI8>(e, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, out); break;
-            case SDR_FMT_CI16: launch_fmt<SDR_FMT_CI16>(e, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, out); break;
-            case SDR_FMT_CF32: launch_fmt<SDR_FMT_CF32>(e, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, out); break;
-            default: launch_fmt<SDR_FMT_CF64>(e, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, out); break;
+            case SDR_FMT_CI8: launch_fmt<SDR_FMT_CI8>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, out); break;
+            case SDR_FMT_CI16: launch_fmt<SDR_FMT_CI16>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, out); break;
+            case SDR_FMT_CF32: launch_fmt<SDR_FMT_CF32>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, out); break;
+            default: launch_fmt<SDR_FMT_CF64>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, out); break;
         }
     }
     SDR_HIP(hipGetLastError());
@@ -254,6 +269,7 @@ int sdr_epl_plan_run(sdr_engine* e, sdr_epl_plan* p) {
 int sdr_epl_plan_fetch(sdr_engine* e, sdr_epl_plan* p, double* out) {
     if (int rc = sdr_set_device(e)) return rc;
     if (!p || !out) return sdr_fail(SDR_ERR_INVALID, "NULL plan or output");
+    SDR_HIP(hipDeviceSynchronize());   // ranges of the plan may have been launched on several streams
     SDR_HIP(hipMemcpyAsync(out, p->d_out, (size_t)p->n_items * 2 * p->n_taps * sizeof(double),
                            hipMemcpyDeviceToHost, e->stream));
     SDR_HIP(hipStreamSynchronize(e->stream));

@@ -15,6 +15,8 @@
 // built on sydr/dsp/tracking.py:120-186,246-279 and sydr/dsp/lockindicator.py:6-122.
 #include "correlator.h"
 
+#include <cstring>
+
 #ifdef SDR_TRACE_TRACK
 // Debug build only (tools/track_phases.py): per-phase clock totals of channel 0's epoch loop.
 __device__ unsigned long long g_track_phase[32];
@@ -37,17 +39,20 @@ namespace {
 
 using namespace sdr;
 
-constexpr int kTaps = 3;
 constexpr int kMaxParts = 8;
-constexpr int red_doubles(int threads) { return (threads / 64) * 2 * kTaps > 64 ? (threads / 64) * 2 * kTaps : 64; }
-constexpr int kXchgWords = 16;             // 12 tagged half-values + padding: one 128-byte line per part and parity
+// LDS doubles of the reduction scratch; the cluster exchange reuses it for 8 parts x xchg_words(NT) halves (as 32-bit words)
+constexpr int red_doubles(int threads, int nt) { return (threads / 64) * 2 * nt > 128 ? (threads / 64) * 2 * nt : 128; }
+// Exchange line of one part and parity: 4*NT tagged half-values padded to whole 128-byte lines (16 words for E/P/L,
+// 32 for five taps).
+constexpr int xchg_words(int nt) { return 4 * nt <= 16 ? 16 : 32; }
+constexpr int kXchgWordsMax = 32;
 constexpr long kSpinLimit = 1L << 20;      // peer polls before a part gives up (about a second): never hang the GPU
 
 constexpr double kGpsPi = 3.1415926535898;  // sydr/utils/constants.py:4
 constexpr double kGpsTwoPi = kGpsPi * 2.0;
 constexpr double kGpsHalfPi = kGpsPi / 2.0;
-constexpr double kChips = 1023.0;
-constexpr int kMsPerBit = 20;
+constexpr double kDefaultEpochChips = 1023.0;  // GPS_L1CA_CODE_SIZE_BITS (kaplan:529-532)
+constexpr int kDefaultEpochsPerBit = 20;       // LNAV_MS_PER_BIT
 constexpr double kW0Bw1 = 0.25, kW0Bw2 = 0.53, kW0A2 = 1.414;
 
 enum { FLAG_CODE_LOCK = 1, FLAG_BIT_SYNC = 2 };
@@ -71,12 +76,12 @@ __device__ __forceinline__ double np_sign(double x) { return x > 0.0 ? 1.0 : (x 
 
 struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind it is copied with 16-byte stores)
     EpochParams ep;
-    double spacing[kTaps];
+    double spacing[SDR_MAX_TAPS];
     double dphi;
     int epochs_done;
     int fault;                 // a peer part never showed up: leave the epoch loop (reported to the host)
     // what the three update roles hand to each other (written before an epoch's first barrier, read after it)
-    double corr[2 * kTaps];    // this epoch's correlator totals, for the roles on waves 1 and 2
+    double corr[2 * SDR_MAX_TAPS];  // this epoch's correlator totals, for the roles on waves 1 and 2
     double fll_bw, pll_bw;     // Kaplan bandwidths chosen by the lock-state machine, for the carrier loop
     int lock_state;            // lock state the NEXT epoch's discriminators run under
     int c_code_counter, l_code_counter, l_bits_run;  // private copies of the roles on waves 0 and 2
@@ -89,20 +94,28 @@ struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind 
 
 // WAVES: resident waves per SIMD the register allocation has to leave room for (2 = two 256-thread
 // workgroups can share a CU, at the price of a few spills).
-template <int FMT, int THREADS, int WAVES>
+// states / cfgs are indexed through ch_map when it is given (the device-resident channel bank: the launch serves
+// the listed channels of a larger array); everything this launch produces (trajectory, bits, epochs_done) is
+// indexed by the position in the list.
+template <int FMT, int THREADS, int WAVES, int NT>
 __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __restrict__ ring, int64_t capacity,
                                                         sdr_track_state* __restrict__ states,
-                                                        const sdr_loop_cfg* __restrict__ cfg_ptr,
+                                                        const int32_t* __restrict__ ch_map,
+                                                        const sdr_loop_cfg* __restrict__ cfgs, int cfg_stride,
                                                         int n_epochs, sdr_track_epoch* __restrict__ traj,
                                                         int keep_traj, int8_t* __restrict__ nav_bits, int max_bits,
                                                         int32_t* __restrict__ n_bits,
+                                                        int32_t* __restrict__ epochs_done_out,
                                                         const uint32_t* __restrict__ luts,
                                                         int lut_words, int lut_stride, int use_prefix,
                                                         int n_ch, int parts, unsigned long long* xchg,
                                                         int* __restrict__ fault) {
+    constexpr int kTaps = NT;
+    constexpr int kPrompt = NT / 2;                       // centre tap; its neighbours are early and late
+    constexpr int kXchgWords = xchg_words(NT);
     extern __shared__ double smem[];
-    double* red = smem;                                   // kWaves * 6 wave sums; reused by the cluster exchange
-    EpochShared* sh = reinterpret_cast<EpochShared*>(red + red_doubles(THREADS));
+    double* red = smem;                                   // kWaves * 2*NT wave sums; reused by the cluster exchange
+    EpochShared* sh = reinterpret_cast<EpochShared*>(red + red_doubles(THREADS, NT));
     double2* prefix = reinterpret_cast<double2*>(sh + 1);  // THREADS * kPrefixSlots, when the launcher found room
     uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + (use_prefix ? THREADS * kPrefixSlots : 0));
 
@@ -123,18 +136,22 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     const int cluster_lanes = parts * THREADS;
     const bool edge_wave = lane_global >= cluster_lanes - 64;
     const int edge_lane = edge_wave ? lane_global - (cluster_lanes - 64) : -1;
+    const int sidx = ch_map ? ch_map[ch] : ch;             // where this channel's state and configuration live
+    const sdr_loop_cfg* __restrict__ cfg_ptr = cfgs + (size_t)sidx * cfg_stride;
     if (tid == 0) {
-        sh->st = states[ch];
+        sh->st = states[sidx];
         sh->cfg = *cfg_ptr;
         sh->epochs_done = 0;
         sh->fault = 0;
-        sh->fll_bw = states[ch].fll_bw;
-        sh->pll_bw = states[ch].pll_bw;
-        sh->lock_state = states[ch].lock_state;
+        sh->fll_bw = states[sidx].fll_bw;
+        sh->pll_bw = states[sidx].pll_bw;
+        sh->lock_state = states[sidx].lock_state;
     }
-    const int slot = states[ch].code_slot;
+    const int slot = states[sidx].code_slot;
     stage_lut<THREADS>(lut, luts + (size_t)slot * lut_stride, lut_words, tid);
     const double fs = cfg_ptr->fs;
+    const double kChips = cfg_ptr->epoch_chips > 0.0 ? cfg_ptr->epoch_chips : kDefaultEpochChips;
+    const int kMsPerBit = cfg_ptr->epochs_per_bit > 0 ? cfg_ptr->epochs_per_bit : kDefaultEpochsPerBit;
     sdr_track_state& st = sh->st;
     const sdr_loop_cfg& cfg = sh->cfg;
     const bool writer = part == 0;                         // one part records trajectory, bits and the end state
@@ -148,7 +165,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     // the state's LDS copy (loaded into registers for the duration of its update only: carried across the correlation
     // they cost ~50 VGPRs and spill) and publishes its part of the next epoch's parameters.
     const int role = tid >> 6, rlane = tid & 63;
-    const sdr_track_state s_init = states[ch];
+    const sdr_track_state s_init = states[sidx];
     // The replica LUT and the ring bound what an epoch may touch; a loop that has run away (loss of lock) stops
     // instead of reading out of range.  Checked by the role that produces the values, for the epoch it announces.
     auto code_out_of_range = [&](int64_t start, int n, double rem_code, double code_step) {
@@ -236,24 +253,36 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         // (tools/ubench_xchg.hip), on the same XCD or across XCDs.
         // Lines are double-buffered by epoch parity: a part can run at most one exchange ahead of a peer.
         if (parts > 1 && tid < 64) {
-            unsigned long long* lines = xchg + ((size_t)ch * 2 + (epoch & 1)) * kMaxParts * kXchgWords;
+            unsigned long long* lines = xchg + ((size_t)ch * 2 + (epoch & 1)) * kMaxParts * kXchgWordsMax;
             const unsigned long long tag = (unsigned long long)(unsigned)(epoch + 1) << 32;
-            if (tid < 4 * kTaps) {  // lane 2v+h publishes half h of value v (lanes 0..5 hold the values)
-                const double v = __shfl(total, tid >> 1, 64);
-                const unsigned half = (tid & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
-                __hip_atomic_store(lines + part * kXchgWords + tid, tag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            {   // lane 2v+h publishes half h of value v (lanes 0..2*NT-1 hold the values)
+                const double v = __shfl(total, (tid >> 1) & 15, 64);
+                if (tid < 4 * kTaps) {
+                    const unsigned half = (tid & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+                    __hip_atomic_store(lines + part * kXchgWords + tid, tag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
-            // lane l polls word l%16 of parts l/16 and l/16+4 (words 12..15 of a line are padding)
-            const int k = tid & 15, p0 = tid >> 4, p1 = p0 + 4;
-            const bool want0 = k < 4 * kTaps && p0 < parts, want1 = k < 4 * kTaps && p1 < parts;
-            const unsigned long long* a0 = lines + (want0 ? p0 : part) * kXchgWords + (want0 ? k : 0);
-            const unsigned long long* a1 = lines + (want1 ? p1 : part) * kXchgWords + (want1 ? k : 0);
-            unsigned long long w0 = 0, w1 = 0;
+            // lane l polls word l % W of parts l / W + j * (64 / W), j = 0 .. W/8 - 1 (words 4*NT.. of a line are padding)
+            constexpr int kPerPass = 64 / kXchgWords;      // parts covered by one wave-wide load
+            constexpr int kPasses = kMaxParts / kPerPass;  // 2 (16-word lines) or 4 (32-word lines)
+            const int k = tid & (kXchgWords - 1), pbase = tid / kXchgWords;
+            bool want[kPasses];
+            const unsigned long long* addr[kPasses];
+#pragma unroll
+            for (int j = 0; j < kPasses; ++j) {
+                const int p = pbase + j * kPerPass;
+                want[j] = k < 4 * kTaps && p < parts;
+                addr[j] = lines + (want[j] ? p : part) * kXchgWords + (want[j] ? k : 0);
+            }
+            unsigned long long w[kPasses];
             bool done = false;
             for (long spins = 0; spins < kSpinLimit; ++spins) {
-                w0 = __hip_atomic_load(a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                w1 = __hip_atomic_load(a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool ok = (!want0 || (w0 >> 32 << 32) == tag) && (!want1 || (w1 >> 32 << 32) == tag);
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < kPasses; ++j) {
+                    w[j] = __hip_atomic_load(addr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (!want[j] || (w[j] >> 32 << 32) == tag);
+                }
                 if (__all(ok)) {
                     done = true;
                     break;
@@ -266,14 +295,16 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                 }
             } else {
                 unsigned* halves = reinterpret_cast<unsigned*>(red);  // (the wave sums in `red` have been consumed)
-                halves[tid] = (unsigned)w0;            // [p*16 + k], p < 4
-                halves[64 + tid] = (unsigned)w1;       // p >= 4
+#pragma unroll
+                for (int j = 0; j < kPasses; ++j) halves[j * 64 + tid] = (unsigned)w[j];  // [(p)*W + k], p = pbase + j*kPerPass
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (LDS serves a wave's operations in order)
                 __builtin_amdgcn_wave_barrier();
                 if (tid < 2 * kTaps) {
                     double sum = 0.0;
-                    for (int p = 0; p < parts; ++p)
-                        sum += __hiloint2double((int)halves[p * 16 + 2 * tid + 1], (int)halves[p * 16 + 2 * tid]);
+                    for (int p = 0; p < parts; ++p) {
+                        const int at = ((p / kPerPass) * 64) + (p % kPerPass) * kXchgWords;
+                        sum += __hiloint2double((int)halves[at + 2 * tid + 1], (int)halves[at + 2 * tid]);
+                    }
                     total = sum;
                 }
             }
@@ -293,7 +324,8 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         __syncthreads();
         TRACK_MARK(7);
         if (!sh->fault && role < 3) {
-            const double ie = sh->corr[0], qe = sh->corr[1], ip = sh->corr[2], qp = sh->corr[3], il = sh->corr[4], ql = sh->corr[5];
+            const double ie = sh->corr[2 * kPrompt - 2], qe = sh->corr[2 * kPrompt - 1], ip = sh->corr[2 * kPrompt], qp = sh->corr[2 * kPrompt + 1],
+                         il = sh->corr[2 * kPrompt + 2], ql = sh->corr[2 * kPrompt + 3];
             const int n = ep.n;
             const bool kaplan = cfg.loop_kind != 0;
             sdr_track_epoch* rec = (writer && keep_traj) ? traj + ((size_t)ch * n_epochs + epoch) : nullptr;
@@ -563,12 +595,12 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         st.rem_carrier = sh->ep.rem_carrier;
         st.rem_code = sh->ep.rem_code;
         st.code_step = sh->ep.code_step;
-        if (epochs_done < n_epochs) {
-            st.n_samples = -1 - epochs_done;  // stopped early: -(1 + epochs completed)
-            if (keep_traj)
-                for (int k = epochs_done; k < n_epochs; ++k) traj[(size_t)ch * n_epochs + k].n_samples = 0;
-        }
-        states[ch] = st;
+        // stopped early (the NCO left the staged replica / the ring, or a peer part never showed up): the state is
+        // the one after the last completed epoch; the records of the epochs that did not run are marked empty
+        if (epochs_done < n_epochs && keep_traj)
+            for (int k = epochs_done; k < n_epochs; ++k) traj[(size_t)ch * n_epochs + k].n_samples = 0;
+        states[sidx] = st;
+        if (epochs_done_out) epochs_done_out[ch] = epochs_done;
         if (n_bits) n_bits[ch] = sh->l_bits_run < max_bits ? sh->l_bits_run : max_bits;
     }
 }
@@ -580,20 +612,179 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
 // 256-thread workgroups capped at 168 registers so that THREE share a CU.  It is compiled with
 // -mllvm -disable-machine-licm: hoisting the fp64 polynomial constants of sincos / atan / division out of the
 // epoch loop parks ~80 of them in VGPRs for the whole kernel (256 instead of 173 registers).
-hipError_t sdr_track_dense_launch(int fmt, int n_ch, size_t shmem, hipStream_t stream, void** args) {
+hipError_t sdr_track_dense_launch(int fmt, int n_taps, int n_ch, size_t shmem, hipStream_t stream, void** args) {
     auto launch = [&](auto kernel) {
         (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         return hipLaunchKernel((const void*)kernel, dim3(n_ch), dim3(256), args, shmem, stream);
     };
+    auto by_taps = [&](auto fmt_c) {
+        constexpr int F = decltype(fmt_c)::value;
+        return n_taps == 5 ? launch(track_kernel<F, 256, 3, 5>) : launch(track_kernel<F, 256, 3, 3>);
+    };
     switch (fmt) {
-        case SDR_FMT_CI8: return launch(track_kernel<SDR_FMT_CI8, 256, 3>);
-        case SDR_FMT_CI16: return launch(track_kernel<SDR_FMT_CI16, 256, 3>);
-        case SDR_FMT_CF32: return launch(track_kernel<SDR_FMT_CF32, 256, 3>);
-        default: return launch(track_kernel<SDR_FMT_CF64, 256, 3>);
+        case SDR_FMT_CI8: return by_taps(std::integral_constant<int, SDR_FMT_CI8>{});
+        case SDR_FMT_CI16: return by_taps(std::integral_constant<int, SDR_FMT_CI16>{});
+        case SDR_FMT_CF32: return by_taps(std::integral_constant<int, SDR_FMT_CF32>{});
+        default: return by_taps(std::integral_constant<int, SDR_FMT_CF64>{});
     }
 }
 #else
-hipError_t sdr_track_dense_launch(int fmt, int n_ch, size_t shmem, hipStream_t stream, void** args);  // track_dense.hip
+hipError_t sdr_track_dense_launch(int fmt, int n_taps, int n_ch, size_t shmem, hipStream_t stream, void** args);  // track_dense.hip
+
+namespace {
+
+// Device-side operands of one closed-loop launch.
+struct TrackRun {
+    sdr_track_state* d_states = nullptr;  // indexed through d_map when given
+    const int32_t* d_map = nullptr;
+    const sdr_loop_cfg* d_cfgs = nullptr;
+    int cfg_stride = 0;                   // 0: d_cfgs[0] serves every channel; 1: one per state index
+    int n_ch = 0, n_epochs = 0, n_taps = 3;
+    sdr_track_epoch* d_traj = nullptr;    // [n_ch][n_epochs] or one scratch record when keep == 0
+    int keep = 0;
+    int8_t* d_bits = nullptr;
+    int max_bits = 0;
+    int32_t* d_nbits = nullptr;
+    int32_t* d_done = nullptr;            // [n_ch] epochs completed
+    int force_parts = 0;                  // 0: choose
+};
+
+// Enqueue one closed-loop launch on ctx's stream.  *d_fault_out points at the launch's fault word.
+int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_used, int** d_fault_out) {
+    const int lut_words = e->lut_stride;  // the whole staged row (every code period the slots were sized for)
+    // exchange lines [n_ch][2 parities][8 parts][32 words] (tags zeroed: epoch tags start at 1), then the fault word
+    const size_t xchg_bytes = (size_t)r.n_ch * 2 * kMaxParts * kXchgWordsMax * sizeof(unsigned long long);
+    if (int rc = sdr_devbuf_reserve_on(e, ctx->stream, &ctx->xchg, xchg_bytes + 16)) return rc;
+    unsigned long long* d_xchg = (unsigned long long*)ctx->xchg.ptr;
+    int* d_fault = (int*)((char*)ctx->xchg.ptr + xchg_bytes);
+    *d_fault_out = d_fault;
+    const void* d_iq = e->iq;
+    int64_t cap = e->iq_capacity;
+    const uint32_t* d_luts = e->luts;
+    int lw = lut_words, ls = e->lut_stride, nch = r.n_ch, n_ep = r.n_epochs, mb = r.max_bits, keep = r.keep;
+    sdr_track_state* d_st = r.d_states;
+    const int32_t* d_map = r.d_map;
+    const sdr_loop_cfg* d_cfgs = r.d_cfgs;
+    int cfg_stride = r.cfg_stride;
+    sdr_track_epoch* d_traj = r.d_traj;
+    int8_t* d_bits = r.d_bits;
+    int32_t* d_nbits = r.d_nbits;
+    int32_t* d_done = r.d_done;
+    const int nt = r.n_taps;
+
+    // One attempt with `parts` workgroups per channel.
+    auto attempt = [&](int parts, bool* too_big) -> hipError_t {
+        // more channels than CUs: smaller workgroups, two or three of which share a CU, so that one channel's
+        // loop update overlaps another's correlation (measured: 512 channels 20.2 -> 14.6 us per epoch,
+        // 768 channels 22.3 -> 18.6)
+        const bool dense = parts == 1 && r.n_ch > e->n_cus;
+        const int threads = (parts >= 2 || dense) ? 256 : 512;
+        const size_t shmem_base = (size_t)red_doubles(threads, nt) * sizeof(double) + sizeof(EpochShared) +
+                                  (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
+        const size_t prefix_bytes = (size_t)threads * kPrefixSlots * sizeof(double2);
+        // The boundary variant of the correlator needs a 144-byte LDS strip per lane; long multi-period
+        // replicas that leave no room for it are tracked with the per-sample variant.
+        int up = shmem_base + prefix_bytes <= 160u * 1024u && e->lut_stride < kFastMaxLutWords ? 1 : 0;
+        const size_t shmem = shmem_base + (up ? prefix_bytes : 0);
+        *too_big = shmem > 160u * 1024u;
+        if (*too_big) return hipSuccess;
+        if (parts > 1)  // tags of a previous launch must not validate this one's polls
+            if (hipError_t me = hipMemsetAsync(ctx->xchg.ptr, 0, xchg_bytes + 16, ctx->stream)) return me;
+        void* args[] = {&d_iq, &cap, &d_st, &d_map, &d_cfgs, &cfg_stride, &n_ep, &d_traj, &keep, &d_bits, &mb,
+                        &d_nbits, &d_done, &d_luts, &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault};
+        if (dense) return sdr_track_dense_launch(e->iq_fmt, nt, r.n_ch, shmem, ctx->stream, args);
+        hipError_t err = hipSuccess;
+        auto launch = [&](auto kernel) {
+            // more than 64 KB of dynamic LDS has to be granted per kernel
+            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            if (parts > 1)  // the parts of a cluster wait for each other: all workgroups must be resident
+                err = hipLaunchCooperativeKernel((const void*)kernel, dim3(r.n_ch * parts), dim3(threads), args,
+                                                 (unsigned)shmem, ctx->stream);
+            else
+                err = hipLaunchKernel((const void*)kernel, dim3(r.n_ch), dim3(threads), args, shmem, ctx->stream);
+        };
+        auto by_shape = [&](auto fmt) {
+            constexpr int F = decltype(fmt)::value;
+            if (threads == 256) {
+                if (nt == 5) launch(track_kernel<F, 256, 1, 5>);
+                else launch(track_kernel<F, 256, 1, 3>);
+            } else {
+                if (nt == 5) launch(track_kernel<F, 512, 2, 5>);
+                else launch(track_kernel<F, 512, 2, 3>);
+            }
+        };
+        switch (e->iq_fmt) {
+            case SDR_FMT_CI8: by_shape(std::integral_constant<int, SDR_FMT_CI8>{}); break;
+            case SDR_FMT_CI16: by_shape(std::integral_constant<int, SDR_FMT_CI16>{}); break;
+            case SDR_FMT_CF32: by_shape(std::integral_constant<int, SDR_FMT_CF32>{}); break;
+            default: by_shape(std::integral_constant<int, SDR_FMT_CF64>{}); break;
+        }
+        return err;
+    };
+
+    // Cluster size: as many workgroups per channel as the GPU has room for (1 per CU), up to 8.  When the
+    // cooperative launch is refused (GPU shared or partitioned: not every workgroup could be resident) the
+    // automatic choice halves the cluster until the launch goes through; a forced size fails instead.
+    // Runs of a few epochs (a receiver tick) are not worth a cooperative launch (+15-19 us on the host).
+    const int forced = r.force_parts ? r.force_parts : e->track_force_parts;
+    int parts = 1;
+    if (forced) {
+        parts = forced;
+    } else if (r.n_epochs > 4) {
+        while (parts < kMaxParts && (long)r.n_ch * parts * 2 <= (long)e->n_cus) parts *= 2;
+    }
+    SDR_HIP(hipMemsetAsync(d_fault, 0, 16, ctx->stream));
+    hipError_t launch_err = hipSuccess;
+    {
+        ProfScope ps(e, "track_kernel", ctx->stream);
+        for (;;) {
+            bool too_big = false;
+            launch_err = attempt(parts, &too_big);
+            if (too_big) return sdr_fail(SDR_ERR_RANGE, "closed-loop tracking: code table does not fit the LDS");
+            if (launch_err == hipSuccess || forced || parts == 1) break;
+            (void)hipGetLastError();
+            parts /= 2;
+        }
+    }
+    if (launch_err != hipSuccess)
+        return sdr_fail(SDR_ERR_HIP, "closed-loop tracking launch (%d channels x %d parts) failed: %s", r.n_ch, parts,
+                        hipGetErrorString(launch_err));
+    SDR_HIP(hipGetLastError());
+    if (parts_used) *parts_used = parts;
+    return SDR_OK;
+}
+
+int check_cfg(const sdr_loop_cfg* cfg, int index) {
+    if (cfg->n_taps != 3 && cfg->n_taps != 5)
+        return sdr_fail(SDR_ERR_UNSUPPORTED, "channel %d: closed-loop tracking runs 3 (E/P/L) or 5 (VE/E/P/L/VL) taps, got %d",
+                        index, cfg->n_taps);
+    if (cfg->loop_kind != 0 && cfg->loop_kind != 1)
+        return sdr_fail(SDR_ERR_INVALID, "channel %d: loop_kind %d is neither 0 (Borre) nor 1 (Kaplan)", index, cfg->loop_kind);
+    if (!(cfg->fs > 0.0)) return sdr_fail(SDR_ERR_INVALID, "channel %d: fs must be positive", index);
+    if (cfg->epoch_chips < 0.0 || cfg->epochs_per_bit < 0)
+        return sdr_fail(SDR_ERR_INVALID, "channel %d: negative epoch_chips / epochs_per_bit", index);
+    return SDR_OK;
+}
+
+int check_state(sdr_engine* e, const sdr_track_state* st, int index) {
+    const int slot = st->code_slot;
+    if (slot < 0 || slot >= e->n_slots || e->code_len_host[slot] <= 0)
+        return sdr_fail(SDR_ERR_INVALID, "channel %d: code slot %d is not staged", index, slot);
+    if (st->n_samples <= 0) return sdr_fail(SDR_ERR_INVALID, "channel %d: n_samples must be positive", index);
+    return SDR_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------- channel bank
+struct sdr_bank {
+    int max_channels = 0;
+    sdr_track_state* d_states = nullptr;  // [max_channels] -- the tracking state of this GPU's channels lives here
+    sdr_loop_cfg* d_cfgs = nullptr;       // [max_channels]
+    std::vector<int32_t> n_taps;          // host mirror of what was put: taps per channel, 0 = channel never put
+    std::vector<int32_t> slot;
+    int64_t code_generation = 0;
+};
 
 extern "C" {
 
@@ -612,140 +803,251 @@ int sdr_track_closed_loop(sdr_engine* e, int n_ch, sdr_track_state* st, const sd
 
 int sdr_track_closed_loop_bits(sdr_engine* e, int n_ch, sdr_track_state* st, const sdr_loop_cfg* cfg, int n_epochs,
                                sdr_track_epoch* traj, int8_t* nav_bits, int max_bits, int32_t* n_bits) {
+    if (n_ch < 1) return sdr_fail(SDR_ERR_INVALID, "bad closed-loop request");
+    std::vector<int32_t> done((size_t)n_ch, 0);
+    if (int rc = sdr_track_closed_loop_ex(e, n_ch, st, cfg, 0, n_epochs, traj, nav_bits, max_bits, n_bits, done.data()))
+        return rc;
+    // one status for the whole call (the per-channel outcome is what sdr_track_closed_loop_ex reports); the
+    // states handed back are valid either way
+    for (int c = 0; c < n_ch; ++c)
+        if (done[c] < n_epochs)
+            return sdr_fail(SDR_ERR_RANGE, "channel %d stopped after %d epochs: NCO state left the staged replica / ring",
+                            c, done[c]);
+    return SDR_OK;
+}
+
+int sdr_track_closed_loop_ex(sdr_engine* e, int n_ch, sdr_track_state* st, const sdr_loop_cfg* cfgs,
+                             int cfg_per_channel, int n_epochs, sdr_track_epoch* traj, int8_t* nav_bits,
+                             int max_bits, int32_t* n_bits, int32_t* epochs_done) {
     if (int rc = sdr_set_device(e)) return rc;
     if ((nav_bits && (max_bits < 1 || !n_bits)) || (!nav_bits && n_bits))
         return sdr_fail(SDR_ERR_INVALID, "nav_bits, max_bits and n_bits go together");
     if (!e->iq) return sdr_fail(SDR_ERR_STATE, "IQ ring not allocated");
     if (!e->codes) return sdr_fail(SDR_ERR_STATE, "code slots not allocated");
-    if (!st || !cfg || n_ch < 1 || n_epochs < 1) return sdr_fail(SDR_ERR_INVALID, "bad closed-loop request");
-    if (cfg->n_taps != kTaps) return sdr_fail(SDR_ERR_UNSUPPORTED, "closed-loop tracking uses 3 taps (E/P/L), got %d", cfg->n_taps);
-    if (cfg->loop_kind != 0 && cfg->loop_kind != 1) return sdr_fail(SDR_ERR_INVALID, "loop_kind %d is neither 0 (Borre) nor 1 (Kaplan)", cfg->loop_kind);
-    if (!(cfg->fs > 0.0)) return sdr_fail(SDR_ERR_INVALID, "fs must be positive");
-    int maxlen = 0;
-    for (int c = 0; c < n_ch; ++c) {
-        const int slot = st[c].code_slot;
-        if (slot < 0 || slot >= e->n_slots || e->code_len_host[slot] <= 0)
-            return sdr_fail(SDR_ERR_INVALID, "channel %d: code slot %d is not staged", c, slot);
-        if (st[c].n_samples <= 0) return sdr_fail(SDR_ERR_INVALID, "channel %d: n_samples must be positive", c);
-        if (e->code_len_host[slot] > maxlen) maxlen = e->code_len_host[slot];
+    if (!st || !cfgs || n_ch < 1 || n_epochs < 1) return sdr_fail(SDR_ERR_INVALID, "bad closed-loop request");
+    const int n_cfg = cfg_per_channel ? n_ch : 1;
+    for (int c = 0; c < n_cfg; ++c) {
+        if (int rc = check_cfg(&cfgs[c], c)) return rc;
+        if (cfgs[c].n_taps != cfgs[0].n_taps)
+            return sdr_fail(SDR_ERR_UNSUPPORTED, "channels of one launch must run the same number of taps (%d vs %d)",
+                            cfgs[c].n_taps, cfgs[0].n_taps);
     }
+    for (int c = 0; c < n_ch; ++c)
+        if (int rc = check_state(e, &st[c], c)) return rc;
+    StreamCtx* ctx = &e->ctx0;
     const size_t traj_bytes = traj ? (size_t)n_ch * n_epochs * sizeof(sdr_track_epoch) : 0;
     int rc = sdr_devbuf_reserve(e, &e->track_state, (size_t)n_ch * sizeof(sdr_track_state));
-    if (!rc) rc = sdr_devbuf_reserve(e, &e->track_cfg, sizeof(sdr_loop_cfg));
-    if (!rc) rc = sdr_devbuf_reserve(e, &e->track_traj, traj ? traj_bytes : sizeof(sdr_track_epoch));
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->track_cfg, (size_t)n_cfg * sizeof(sdr_loop_cfg));
+    if (!rc) rc = sdr_devbuf_reserve(e, &ctx->traj, traj ? traj_bytes : sizeof(sdr_track_epoch));
     const size_t bits_bytes = nav_bits ? (size_t)n_ch * max_bits : 0;
-    if (!rc && nav_bits) rc = sdr_devbuf_reserve(e, &e->track_bits, bits_bytes + (size_t)n_ch * sizeof(int32_t) + 16);
+    const size_t head = ((size_t)2 * n_ch * sizeof(int32_t) + 15) & ~(size_t)15;   // [n_bits][epochs_done] then the bits
+    if (!rc) rc = sdr_devbuf_reserve(e, &ctx->bits, head + bits_bytes + 16);
     if (rc) return rc;
-    int32_t* d_nbits = nav_bits ? (int32_t*)e->track_bits.ptr : nullptr;
-    int8_t* d_bits = nav_bits ? (int8_t*)e->track_bits.ptr + (((size_t)n_ch * sizeof(int32_t) + 15) & ~(size_t)15) : nullptr;
-    if (nav_bits) SDR_HIP(hipMemsetAsync(e->track_bits.ptr, 0, e->track_bits.bytes, e->stream));
-    SDR_HIP(hipMemcpyAsync(e->track_state.ptr, st, (size_t)n_ch * sizeof(sdr_track_state), hipMemcpyHostToDevice, e->stream));
-    SDR_HIP(hipMemcpyAsync(e->track_cfg.ptr, cfg, sizeof(sdr_loop_cfg), hipMemcpyHostToDevice, e->stream));
-    (void)maxlen;
-    const int lut_words = e->lut_stride;  // the whole staged row (every code period the slots were sized for)
-    sdr_track_state* d_st = (sdr_track_state*)e->track_state.ptr;
-    const sdr_loop_cfg* d_cfg = (const sdr_loop_cfg*)e->track_cfg.ptr;
-    sdr_track_epoch* d_traj = (sdr_track_epoch*)e->track_traj.ptr;
-    int keep = traj ? 1 : 0;
-    // exchange lines [n_ch][2 parities][8 parts][16 words] (tags zeroed: epoch tags start at 1), then the fault word
-    const size_t xchg_bytes = (size_t)n_ch * 2 * kMaxParts * kXchgWords * sizeof(unsigned long long);
-    if (int rc2 = sdr_devbuf_reserve(e, &e->track_xchg, xchg_bytes + 16)) return rc2;
-    SDR_HIP(hipMemsetAsync(e->track_xchg.ptr, 0, xchg_bytes + 16, e->stream));
-    unsigned long long* d_xchg = (unsigned long long*)e->track_xchg.ptr;
-    int* d_fault = (int*)((char*)e->track_xchg.ptr + xchg_bytes);
-    const void* d_iq = e->iq;
-    int64_t cap = e->iq_capacity;
-    const uint32_t* d_luts = e->luts;
-    int lw = lut_words, ls = e->lut_stride, nch = n_ch, n_ep = n_epochs, mb = max_bits;
-
-    // One attempt with `parts` workgroups per channel.
-    auto attempt = [&](int parts, bool* too_big) -> hipError_t {
-        // more channels than CUs: smaller workgroups, two or three of which share a CU, so that one channel's
-        // loop update overlaps another's correlation (measured: 512 channels 20.2 -> 14.6 us per epoch,
-        // 768 channels 22.3 -> 18.6)
-        const bool dense = parts == 1 && n_ch > e->n_cus;
-        const int threads = (parts >= 2 || dense) ? 256 : 512;
-        const size_t shmem_base = (size_t)red_doubles(threads) * sizeof(double) + sizeof(EpochShared) +
-                                  (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
-        const size_t prefix_bytes = (size_t)threads * kPrefixSlots * sizeof(double2);
-        // The boundary variant of the correlator needs a 144-byte LDS strip per lane; long multi-period
-        // replicas that leave no room for it are tracked with the per-sample variant.
-        int up = shmem_base + prefix_bytes <= 160u * 1024u && e->lut_stride < kFastMaxLutWords ? 1 : 0;
-        const size_t shmem = shmem_base + (up ? prefix_bytes : 0);
-        *too_big = shmem > 160u * 1024u;
-        if (*too_big) return hipSuccess;
-        hipError_t err = hipSuccess;
-        auto launch = [&](auto kernel) {
-            // more than 64 KB of dynamic LDS has to be granted per kernel
-            (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-            void* args[] = {&d_iq, &cap, &d_st, &d_cfg, &n_ep, &d_traj, &keep, &d_bits, &mb, &d_nbits, &d_luts,
-                            &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault};
-            if (parts > 1)  // the parts of a cluster wait for each other: all workgroups must be resident
-                err = hipLaunchCooperativeKernel((const void*)kernel, dim3(n_ch * parts), dim3(threads), args,
-                                                 (unsigned)shmem, e->stream);
-            else
-                err = hipLaunchKernel((const void*)kernel, dim3(n_ch), dim3(threads), args, shmem, e->stream);
-        };
-        if (dense) {
-            void* args[] = {&d_iq, &cap, &d_st, &d_cfg, &n_ep, &d_traj, &keep, &d_bits, &mb, &d_nbits, &d_luts,
-                            &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault};
-            return sdr_track_dense_launch(e->iq_fmt, n_ch, shmem, e->stream, args);
-        }
-        auto by_threads = [&](auto fmt) {
-            constexpr int F = decltype(fmt)::value;
-            if (threads == 256) launch(track_kernel<F, 256, 1>);
-            else launch(track_kernel<F, 512, 2>);
-        };
-        switch (e->iq_fmt) {
-            case SDR_FMT_CI8: by_threads(std::integral_constant<int, SDR_FMT_CI8>{}); break;
-            case SDR_FMT_CI16: by_threads(std::integral_constant<int, SDR_FMT_CI16>{}); break;
-            case SDR_FMT_CF32: by_threads(std::integral_constant<int, SDR_FMT_CF32>{}); break;
-            default: by_threads(std::integral_constant<int, SDR_FMT_CF64>{}); break;
-        }
-        return err;
-    };
-
-    // Cluster size: as many workgroups per channel as the GPU has room for (1 per CU), up to 8.  When the
-    // cooperative launch is refused (GPU shared or partitioned: not every workgroup could be resident) the
-    // automatic choice halves the cluster until the launch goes through; a forced size fails instead.
+    TrackRun r;
+    r.d_states = (sdr_track_state*)e->track_state.ptr;
+    r.d_cfgs = (const sdr_loop_cfg*)e->track_cfg.ptr;
+    r.cfg_stride = cfg_per_channel ? 1 : 0;
+    r.n_ch = n_ch, r.n_epochs = n_epochs, r.n_taps = cfgs[0].n_taps;
+    r.d_traj = (sdr_track_epoch*)ctx->traj.ptr;
+    r.keep = traj ? 1 : 0;
+    r.d_nbits = nav_bits ? (int32_t*)ctx->bits.ptr : nullptr;
+    r.d_done = (int32_t*)ctx->bits.ptr + n_ch;
+    r.d_bits = nav_bits ? (int8_t*)ctx->bits.ptr + head : nullptr;
+    r.max_bits = max_bits;
+    SDR_HIP(hipMemsetAsync(ctx->bits.ptr, 0, head + bits_bytes, ctx->stream));
+    SDR_HIP(hipMemcpyAsync(e->track_state.ptr, st, (size_t)n_ch * sizeof(sdr_track_state), hipMemcpyHostToDevice, ctx->stream));
+    SDR_HIP(hipMemcpyAsync(e->track_cfg.ptr, cfgs, (size_t)n_cfg * sizeof(sdr_loop_cfg), hipMemcpyHostToDevice, ctx->stream));
     int parts = 1;
-    if (e->track_force_parts) {
-        parts = e->track_force_parts;
-    } else {
-        while (parts < kMaxParts && (long)n_ch * parts * 2 <= (long)e->n_cus) parts *= 2;
-    }
-    hipError_t launch_err = hipSuccess;
-    {
-        ProfScope ps(e, "track_kernel");
-        for (;;) {
-            bool too_big = false;
-            launch_err = attempt(parts, &too_big);
-            if (too_big) return sdr_fail(SDR_ERR_RANGE, "closed-loop tracking: code table does not fit the LDS");
-            if (launch_err == hipSuccess || e->track_force_parts || parts == 1) break;
-            (void)hipGetLastError();
-            parts /= 2;
-        }
-    }
-    if (launch_err != hipSuccess)
-        return sdr_fail(SDR_ERR_HIP, "closed-loop tracking launch (%d channels x %d parts) failed: %s", n_ch, parts,
-                        hipGetErrorString(launch_err));
+    int* d_fault = nullptr;
+    if (int rc2 = launch_track(e, ctx, r, &parts, &d_fault)) return rc2;
     int fault_host = 0;
-    SDR_HIP(hipMemcpyAsync(&fault_host, d_fault, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    SDR_HIP(hipGetLastError());
-    SDR_HIP(hipMemcpyAsync(st, e->track_state.ptr, (size_t)n_ch * sizeof(sdr_track_state), hipMemcpyDeviceToHost, e->stream));
-    if (traj) SDR_HIP(hipMemcpyAsync(traj, e->track_traj.ptr, traj_bytes, hipMemcpyDeviceToHost, e->stream));
+    std::vector<int32_t> done_host((size_t)n_ch, 0);
+    SDR_HIP(hipMemcpyAsync(&fault_host, d_fault, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SDR_HIP(hipMemcpyAsync(st, e->track_state.ptr, (size_t)n_ch * sizeof(sdr_track_state), hipMemcpyDeviceToHost, ctx->stream));
+    SDR_HIP(hipMemcpyAsync(done_host.data(), r.d_done, (size_t)n_ch * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (traj) SDR_HIP(hipMemcpyAsync(traj, ctx->traj.ptr, traj_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (nav_bits) {
-        SDR_HIP(hipMemcpyAsync(nav_bits, d_bits, bits_bytes, hipMemcpyDeviceToHost, e->stream));
-        SDR_HIP(hipMemcpyAsync(n_bits, d_nbits, (size_t)n_ch * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        SDR_HIP(hipMemcpyAsync(nav_bits, r.d_bits, bits_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        SDR_HIP(hipMemcpyAsync(n_bits, r.d_nbits, (size_t)n_ch * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     }
-    SDR_HIP(hipStreamSynchronize(e->stream));
+    SDR_HIP(hipStreamSynchronize(ctx->stream));
     if (fault_host)
         return sdr_fail(SDR_ERR_HIP, "closed-loop tracking: a workgroup of a %d-part cluster never published its sums", parts);
-    for (int c = 0; c < n_ch; ++c)
-        if (st[c].n_samples < 0)
-            return sdr_fail(SDR_ERR_RANGE, "channel %d stopped after %d epochs: NCO state left the staged replica / ring",
-                            c, -1 - st[c].n_samples);
+    if (epochs_done)
+        for (int c = 0; c < n_ch; ++c) epochs_done[c] = done_host[c];
     return SDR_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ channel bank */
+
+int sdr_bank_create(sdr_engine* e, int max_channels, sdr_bank** out) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!out) return sdr_fail(SDR_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (max_channels < 1 || max_channels > 65536) return sdr_fail(SDR_ERR_INVALID, "max_channels %d outside 1..65536", max_channels);
+    sdr_bank* b = new (std::nothrow) sdr_bank();
+    if (!b) return sdr_fail(SDR_ERR_NOMEM, "host allocation failed");
+    b->max_channels = max_channels;
+    b->n_taps.assign((size_t)max_channels, 0);
+    b->slot.assign((size_t)max_channels, -1);
+    hipError_t err = hipMalloc(&b->d_states, (size_t)max_channels * sizeof(sdr_track_state));
+    if (err == hipSuccess) err = hipMalloc(&b->d_cfgs, (size_t)max_channels * sizeof(sdr_loop_cfg));
+    if (err == hipSuccess) err = hipMemsetAsync(b->d_states, 0, (size_t)max_channels * sizeof(sdr_track_state), e->ctx0.stream);
+    if (err == hipSuccess) err = hipMemsetAsync(b->d_cfgs, 0, (size_t)max_channels * sizeof(sdr_loop_cfg), e->ctx0.stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->ctx0.stream);
+    if (err != hipSuccess) {
+        sdr_bank_destroy(e, b);
+        return sdr_fail(err == hipErrorOutOfMemory ? SDR_ERR_NOMEM : SDR_ERR_HIP, "bank setup failed: %s", hipGetErrorString(err));
+    }
+    *out = b;
+    return SDR_OK;
+}
+
+void sdr_bank_destroy(sdr_engine* e, sdr_bank* b) {
+    if (!b) return;
+    if (e) {
+        (void)hipSetDevice(e->device);
+        (void)hipDeviceSynchronize();
+    }
+    if (b->d_states) (void)hipFree(b->d_states);
+    if (b->d_cfgs) (void)hipFree(b->d_cfgs);
+    delete b;
+}
+
+int sdr_bank_put(sdr_engine* e, sdr_bank* b, int ch, const sdr_track_state* st, const sdr_loop_cfg* cfg) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!b || !st || !cfg) return sdr_fail(SDR_ERR_INVALID, "NULL bank, state or configuration");
+    if (ch < 0 || ch >= b->max_channels) return sdr_fail(SDR_ERR_RANGE, "channel %d outside the bank's %d", ch, b->max_channels);
+    if (!e->codes) return sdr_fail(SDR_ERR_STATE, "code slots not allocated");
+    if (int rc = check_cfg(cfg, ch)) return rc;
+    if (int rc = check_state(e, st, ch)) return rc;
+    hipStream_t s = e->ctx0.stream;
+    SDR_HIP(hipMemcpyAsync(b->d_states + ch, st, sizeof(*st), hipMemcpyHostToDevice, s));
+    SDR_HIP(hipMemcpyAsync(b->d_cfgs + ch, cfg, sizeof(*cfg), hipMemcpyHostToDevice, s));
+    SDR_HIP(hipStreamSynchronize(s));
+    b->n_taps[ch] = cfg->n_taps;
+    b->slot[ch] = st->code_slot;
+    return SDR_OK;
+}
+
+int sdr_bank_get(sdr_engine* e, sdr_bank* b, int ch, sdr_track_state* st) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!b || !st) return sdr_fail(SDR_ERR_INVALID, "NULL bank or state");
+    if (ch < 0 || ch >= b->max_channels) return sdr_fail(SDR_ERR_RANGE, "channel %d outside the bank's %d", ch, b->max_channels);
+    if (!b->n_taps[ch]) return sdr_fail(SDR_ERR_STATE, "channel %d was never put into the bank", ch);
+    SDR_HIP(hipMemcpyAsync(st, b->d_states + ch, sizeof(*st), hipMemcpyDeviceToHost, e->ctx0.stream));
+    SDR_HIP(hipStreamSynchronize(e->ctx0.stream));
+    return SDR_OK;
+}
+
+// Shared by sdr_bank_step / sdr_bank_tick: everything between the optional ingest and the final synchronisation.
+static int bank_run(sdr_engine* e, sdr_bank* b, StreamCtx* ctx, const int32_t* channels, int n_ch, int n_epochs,
+                    sdr_track_epoch* records, sdr_track_state* states_out, int32_t* epochs_done, int8_t* nav_bits,
+                    int max_bits, int32_t* n_bits) {
+    if (!e->iq) return sdr_fail(SDR_ERR_STATE, "IQ ring not allocated");
+    if (!e->codes) return sdr_fail(SDR_ERR_STATE, "code slots not allocated");
+    if ((nav_bits && (max_bits < 1 || !n_bits)) || (!nav_bits && n_bits))
+        return sdr_fail(SDR_ERR_INVALID, "nav_bits, max_bits and n_bits go together");
+    if (!channels || n_ch < 1 || n_epochs < 1) return sdr_fail(SDR_ERR_INVALID, "bad bank step request");
+    int nt = 0;
+    for (int c = 0; c < n_ch; ++c) {
+        const int ch = channels[c];
+        if (ch < 0 || ch >= b->max_channels || !b->n_taps[ch])
+            return sdr_fail(SDR_ERR_INVALID, "entry %d: channel %d is not in the bank", c, ch);
+        if (b->slot[ch] >= e->n_slots || e->code_len_host[b->slot[ch]] <= 0)
+            return sdr_fail(SDR_ERR_STATE, "entry %d: channel %d's code slot %d is no longer staged", c, ch, b->slot[ch]);
+        if (nt && b->n_taps[ch] != nt)
+            return sdr_fail(SDR_ERR_UNSUPPORTED, "channels of one step must run the same number of taps (%d vs %d)", b->n_taps[ch], nt);
+        nt = b->n_taps[ch];
+        for (int d = 0; d < c; ++d)
+            if (channels[d] == ch) return sdr_fail(SDR_ERR_INVALID, "channel %d listed twice", ch);
+    }
+    const size_t rec_bytes = records ? (size_t)n_ch * n_epochs * sizeof(sdr_track_epoch) : 0;
+    const size_t st_bytes = (size_t)n_ch * sizeof(sdr_track_state);
+    const size_t bits_bytes = nav_bits ? (size_t)n_ch * max_bits : 0;
+    const size_t head = ((size_t)3 * n_ch * sizeof(int32_t) + 15) & ~(size_t)15;  // [map][n_bits][epochs_done], then the bits
+    int rc = sdr_devbuf_reserve_on(e, ctx->stream, &ctx->traj, records ? rec_bytes : sizeof(sdr_track_epoch));
+    if (!rc) rc = sdr_devbuf_reserve_on(e, ctx->stream, &ctx->bits, head + bits_bytes + 16);
+    // pinned staging: [fault (4 words)][epochs_done n][n_bits n][channel list n] [states][records][bits]
+    const size_t pin_head = ((size_t)(4 + 3 * n_ch) * sizeof(int32_t) + 15) & ~(size_t)15;
+    const size_t pin_bytes = pin_head + st_bytes + rec_bytes + bits_bytes;
+    if (!rc) rc = sdr_pinned_reserve(e, ctx, pin_bytes);
+    if (rc) return rc;
+    int32_t* d_map = (int32_t*)ctx->bits.ptr;
+    TrackRun r;
+    r.d_states = b->d_states;
+    r.d_map = d_map;
+    r.d_cfgs = b->d_cfgs;
+    r.cfg_stride = 1;
+    r.n_ch = n_ch, r.n_epochs = n_epochs, r.n_taps = nt;
+    r.d_traj = (sdr_track_epoch*)ctx->traj.ptr;
+    r.keep = records ? 1 : 0;
+    r.d_nbits = nav_bits ? d_map + n_ch : nullptr;
+    r.d_done = d_map + 2 * n_ch;
+    r.d_bits = nav_bits ? (int8_t*)ctx->bits.ptr + head : nullptr;
+    r.max_bits = max_bits;
+    char* pin = (char*)ctx->pinned;
+    int32_t* p_head = (int32_t*)pin;
+    SDR_HIP(hipMemsetAsync(ctx->bits.ptr, 0, head + bits_bytes, ctx->stream));
+    memcpy(p_head + 4 + 2 * n_ch, channels, (size_t)n_ch * sizeof(int32_t));  // (the caller's list is not kept past return)
+    SDR_HIP(hipMemcpyAsync(d_map, p_head + 4 + 2 * n_ch, (size_t)n_ch * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    int parts = 1;
+    int* d_fault = nullptr;
+    if (int rc2 = launch_track(e, ctx, r, &parts, &d_fault)) return rc2;
+    sdr_track_state* p_states = (sdr_track_state*)(pin + pin_head);
+    sdr_track_epoch* p_rec = (sdr_track_epoch*)(pin + pin_head + st_bytes);
+    int8_t* p_bits = (int8_t*)(pin + pin_head + st_bytes + rec_bytes);
+    SDR_HIP(hipMemcpyAsync(p_head, d_fault, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SDR_HIP(hipMemcpyAsync(p_head + 4, r.d_done, (size_t)n_ch * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (nav_bits) SDR_HIP(hipMemcpyAsync(p_head + 4 + n_ch, r.d_nbits, (size_t)n_ch * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (states_out) {
+        // contiguous runs of channel indices come back in one copy each
+        int c = 0;
+        while (c < n_ch) {
+            int run = 1;
+            while (c + run < n_ch && channels[c + run] == channels[c] + run) ++run;
+            SDR_HIP(hipMemcpyAsync(p_states + c, b->d_states + channels[c], (size_t)run * sizeof(sdr_track_state),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+            c += run;
+        }
+    }
+    if (records) SDR_HIP(hipMemcpyAsync(p_rec, ctx->traj.ptr, rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (nav_bits) SDR_HIP(hipMemcpyAsync(p_bits, r.d_bits, bits_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SDR_HIP(hipStreamSynchronize(ctx->stream));
+    if (p_head[0])
+        return sdr_fail(SDR_ERR_HIP, "closed-loop tracking: a workgroup of a %d-part cluster never published its sums", parts);
+    if (epochs_done) memcpy(epochs_done, p_head + 4, (size_t)n_ch * sizeof(int32_t));
+    if (nav_bits) {
+        memcpy(n_bits, p_head + 4 + n_ch, (size_t)n_ch * sizeof(int32_t));
+        memcpy(nav_bits, p_bits, bits_bytes);
+    }
+    if (states_out) memcpy(states_out, p_states, st_bytes);
+    if (records) memcpy(records, p_rec, rec_bytes);
+    return SDR_OK;
+}
+
+int sdr_bank_step(sdr_engine* e, sdr_bank* b, const int32_t* channels, int n_ch, int n_epochs,
+                  sdr_track_epoch* records, sdr_track_state* states_out, int32_t* epochs_done,
+                  int8_t* nav_bits, int max_bits, int32_t* n_bits, int stream_id) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!b) return sdr_fail(SDR_ERR_INVALID, "bank is NULL");
+    StreamCtx* ctx = sdr_stream_ctx(e, stream_id);
+    if (!ctx) return sdr_fail(SDR_ERR_INVALID, "stream id %d does not exist", stream_id);
+    return bank_run(e, b, ctx, channels, n_ch, n_epochs, records, states_out, epochs_done, nav_bits, max_bits, n_bits);
+}
+
+int sdr_bank_tick(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
+                  const int32_t* channels, int n_ch, sdr_track_epoch* records, sdr_track_state* states_out,
+                  int32_t* epochs_done) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!b) return sdr_fail(SDR_ERR_INVALID, "bank is NULL");
+    if (n_samples > 0)
+        if (int rc = sdr_iq_upload_async(e, iq, n_samples, ring_offset)) return rc;
+    if (n_ch == 0) {
+        SDR_HIP(hipStreamSynchronize(e->ctx0.stream));
+        return SDR_OK;
+    }
+    return bank_run(e, b, &e->ctx0, channels, n_ch, 1, records, states_out, epochs_done, nullptr, 0, nullptr);
 }
 
 }  // extern "C"

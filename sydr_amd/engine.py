@@ -8,10 +8,10 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (EPL_ITEM_DTYPE, FMT_CF32, FMT_CF64, FMT_CI16, FMT_CI8, TRACK_EPOCH_DTYPE, LoopCfg, SynthSat,
-                   TrackState, check, ptr)
+from ._lib import (EPL_ITEM_DTYPE, FMT_CF32, FMT_CF64, FMT_CI16, FMT_CI8, LOOP_CFG_DTYPE, TRACK_EPOCH_DTYPE,
+                   TRACK_STATE_DTYPE, LoopCfg, SynthSat, TrackState, check, ptr)
 
-__all__ = ["Engine", "EplPlan", "make_items", "FMT_CI8", "FMT_CI16", "FMT_CF32", "FMT_CF64"]
+__all__ = ["Engine", "EplPlan", "Bank", "make_items", "FMT_CI8", "FMT_CI16", "FMT_CF32", "FMT_CF64"]
 
 
 def make_items(code_slot, n_samples, start_sample, carrier_hz, rem_carrier, rem_code, code_step) -> np.ndarray:
@@ -37,11 +37,12 @@ class EplPlan:
         check(self._lib.sdr_epl_plan_create(engine._h, ptr(items), self.n_items, ptr(spacing), self.n_taps,
                                             float(fs), C.byref(self._h)))
 
-    def run(self, first=None, count=None):
+    def run(self, first=None, count=None, stream=0):
+        """Asynchronous launch of the whole plan or of items [first, first+count), on the engine's stream or on
+        one made by Engine.stream_create() (one stream per channel batch)."""
         if first is None:
-            check(self._lib.sdr_epl_plan_run(self._e._h, self._h))
-        else:
-            check(self._lib.sdr_epl_plan_run_range(self._e._h, self._h, int(first), int(count)))
+            first, count = 0, self.n_items
+        check(self._lib.sdr_epl_plan_run_range_on(self._e._h, self._h, int(first), int(count), int(stream)))
 
     def fetch(self) -> np.ndarray:
         out = np.empty((self.n_items, 2 * self.n_taps), dtype=np.float64)
@@ -52,6 +53,73 @@ class EplPlan:
         if self._h:
             self._lib.sdr_epl_plan_destroy(self._e._h, self._h)
             self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Bank:
+    """The tracking state of one GPU's channels, resident in HBM (sdr_bank_*): `put` a channel after acquisition,
+    `step` / `tick` advance the listed channels on the device and hand back the epoch records and the new states."""
+
+    def __init__(self, engine: "Engine", max_channels: int):
+        self._e = engine
+        self._lib = _lib.load()
+        self.max_channels = int(max_channels)
+        self._h = C.c_void_p()
+        check(self._lib.sdr_bank_create(engine._h, self.max_channels, C.byref(self._h)))
+
+    def put(self, ch: int, state: np.ndarray, cfg: np.ndarray):
+        state = np.ascontiguousarray(state, dtype=TRACK_STATE_DTYPE).reshape(1)
+        cfg = np.ascontiguousarray(cfg, dtype=LOOP_CFG_DTYPE).reshape(1)
+        check(self._lib.sdr_bank_put(self._e._h, self._h, int(ch), ptr(state), ptr(cfg)))
+
+    def get(self, ch: int) -> np.ndarray:
+        out = np.zeros(1, dtype=TRACK_STATE_DTYPE)
+        check(self._lib.sdr_bank_get(self._e._h, self._h, int(ch), ptr(out)))
+        return out[0]
+
+    def step(self, channels, n_epochs: int = 1, want_records=True, want_bits=False, stream=0, epochs_per_bit=20):
+        """-> (records[n][n_epochs] or None, states[n], epochs_done[n], list of nav-bit arrays or None)"""
+        channels = np.ascontiguousarray(channels, dtype=np.int32)
+        n = len(channels)
+        rec = np.zeros((n, n_epochs), dtype=TRACK_EPOCH_DTYPE) if want_records else None
+        states = np.zeros(n, dtype=TRACK_STATE_DTYPE)
+        done = np.zeros(n, dtype=np.int32)
+        max_bits = n_epochs // max(1, int(epochs_per_bit)) + 2
+        bits = np.zeros((n, max_bits), dtype=np.int8) if want_bits else None
+        n_bits = np.zeros(n, dtype=np.int32) if want_bits else None
+        check(self._lib.sdr_bank_step(self._e._h, self._h, ptr(channels), n, int(n_epochs),
+                                      ptr(rec) if want_records else None, ptr(states), ptr(done),
+                                      ptr(bits) if want_bits else None, max_bits if want_bits else 0,
+                                      ptr(n_bits) if want_bits else None, int(stream)))
+        nav = [bits[c, :n_bits[c]].copy() for c in range(n)] if want_bits else None
+        return rec, states, done, nav
+
+    def tick(self, raw, ring_offset: int, channels):
+        """One receiver tick: `raw` (the ring's format, may be None) goes into the ring at ring_offset, then the
+        listed channels run one epoch.  -> (records[n], states[n], epochs_done[n])"""
+        channels = np.ascontiguousarray(channels, dtype=np.int32)
+        n = len(channels)
+        rec = np.zeros(n, dtype=TRACK_EPOCH_DTYPE)
+        states = np.zeros(n, dtype=TRACK_STATE_DTYPE)
+        done = np.zeros(n, dtype=np.int32)
+        n_samples = 0
+        if raw is not None:
+            raw = self._e._ring_samples(raw)
+            n_samples = raw.size // 2
+        check(self._lib.sdr_bank_tick(self._e._h, self._h, ptr(raw) if n_samples else None, n_samples, int(ring_offset),
+                                      ptr(channels) if n else None, n, ptr(rec) if n else None,
+                                      ptr(states) if n else None, ptr(done) if n else None))
+        return rec, states, done
+
+    def close(self):
+        if self._h and self._e._h:
+            self._lib.sdr_bank_destroy(self._e._h, self._h)
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -100,8 +168,8 @@ class Engine:
         check(self._lib.sdr_iq_alloc(self._h, int(capacity_samples), int(fmt)))
         self.iq_fmt, self.iq_capacity = fmt, int(capacity_samples)
 
-    def iq_upload(self, raw: np.ndarray, ring_offset: int = 0):
-        """raw: interleaved I,Q in the ring's element type (complex128 accepted for FMT_CF64)."""
+    def _ring_samples(self, raw) -> np.ndarray:
+        """Interleaved I,Q in the ring's element type (complex input is split; no copy when already right)."""
         dt = _lib.fmt_dtype(self.iq_fmt)
         if np.iscomplexobj(raw):
             raw = np.ascontiguousarray(raw, dtype=np.complex128).view(np.float64)
@@ -110,6 +178,11 @@ class Engine:
         raw = np.ascontiguousarray(raw, dtype=dt).reshape(-1)
         if raw.size % 2:
             raise ValueError("interleaved IQ needs an even number of elements")
+        return raw
+
+    def iq_upload(self, raw: np.ndarray, ring_offset: int = 0):
+        """raw: interleaved I,Q in the ring's element type (complex128 accepted for FMT_CF64)."""
+        raw = self._ring_samples(raw)
         check(self._lib.sdr_iq_upload(self._h, ptr(raw), raw.size // 2, int(ring_offset)))
 
     def iq_download(self, n_samples: int, ring_offset: int = 0) -> np.ndarray:
@@ -229,6 +302,37 @@ class Engine:
     def track_cluster(self, parts: int = 0):
         """Workgroups cooperating on one channel in `track_closed_loop` (0 = fill the GPU; 1, 2, 4, 8)."""
         check(self._lib.sdr_track_cluster(self._h, int(parts)))
+
+    def stream_create(self) -> int:
+        """A further HIP stream of this engine (north_star: one stream per channel batch); 0 is the default one."""
+        sid = C.c_int(0)
+        check(self._lib.sdr_stream_create(self._h, C.byref(sid)))
+        return sid.value
+
+    def stream_sync(self, stream: int = 0):
+        check(self._lib.sdr_stream_sync(self._h, int(stream)))
+
+    def bank(self, max_channels: int) -> Bank:
+        return Bank(self, max_channels)
+
+    def track_closed_loop_ex(self, states, cfgs, n_epochs: int, want_traj=True, want_bits=False, epochs_per_bit=20):
+        """Per-channel outcome: -> (end states, trajectory or None, bits or None, epochs_done[n_ch]).  `cfgs`: one
+        LoopCfg for all channels or a sequence with one per channel."""
+        n_ch = len(states)
+        arr = (TrackState * n_ch)(*states)
+        per_channel = not isinstance(cfgs, LoopCfg)
+        carr = (LoopCfg * n_ch)(*cfgs) if per_channel else (LoopCfg * 1)(cfgs)
+        traj = np.zeros((n_ch, n_epochs), dtype=TRACK_EPOCH_DTYPE) if want_traj else None
+        max_bits = n_epochs // max(1, int(epochs_per_bit)) + 2
+        bits = np.zeros((n_ch, max_bits), dtype=np.int8) if want_bits else None
+        n_bits = np.zeros(n_ch, dtype=np.int32) if want_bits else None
+        done = np.zeros(n_ch, dtype=np.int32)
+        check(self._lib.sdr_track_closed_loop_ex(self._h, n_ch, arr, carr, 1 if per_channel else 0, int(n_epochs),
+                                                 ptr(traj) if want_traj else None, ptr(bits) if want_bits else None,
+                                                 max_bits if want_bits else 0, ptr(n_bits) if want_bits else None,
+                                                 ptr(done)))
+        nav = [bits[c, :n_bits[c]].copy() for c in range(n_ch)] if want_bits else None
+        return list(arr), traj, nav, done
 
     def track_closed_loop(self, states, cfg: LoopCfg, n_epochs: int, want_traj=True, want_bits=False):
         """Returns (end states, trajectory or None[, list of per-channel nav-bit arrays])."""

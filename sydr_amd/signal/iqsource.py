@@ -1,82 +1,85 @@
-"""RF front-end description + IQ file reader with the reference's configuration contract
-(sydr/signal/rfsignal.py:13-132; config/receiver.ini [RFSIGNAL]).  Unlike the reference it hands
-out the file's native interleaved integers (2 B per ci8 sample) rather than complex128 (16 B):
-that is the layout the device ring stores."""
+"""IQ recording -> slabs for the device ring.
+
+Reads the [RFSIGNAL] section of the reference's receiver.ini (keys `filepath`, `sampling_frequency`,
+`is_complex`, `intermediate_frequency`, `data_size`; sydr/signal/rfsignal.py:13-54) and serves the file the way
+the GPU wants it: the recording is memory-mapped and a slab is a zero-copy view of its native interleaved
+integers (int8 / int16 I,Q -- 2 or 4 bytes per sample), which is byte for byte what the device ring stores.
+The reference instead reads 120 ms chunks and inflates every sample to complex128 (16 bytes) before anything
+else touches it (rfsignal.py:58-132).  Only what the hot path's callers use is kept of that class's surface:
+the front-end attributes and `getMilliseconds`.
+"""
 from __future__ import annotations
+
+import os
 
 import numpy as np
 
+_TRUE, _FALSE = {"1", "true", "yes", "on"}, {"0", "false", "no", "off"}
+
+
+def _as_bool(value) -> bool:
+    text = str(value).strip().lower()
+    if text in _TRUE:
+        return True
+    if text in _FALSE:
+        return False
+    raise ValueError(f"is_complex = {value!r} is not a boolean")
+
 
 class RFSignal:
-    CHUNCK_SIZE_MS = 120
-
-    def __init__(self, configuration: dict):
-        self.filepath = str(configuration['filepath'])
-        self.samplingFrequency = float(configuration['sampling_frequency'])
-        self.isComplex = bool(configuration['is_complex'])  # reference behaviour: any non-empty string is True
-        self.interFrequency = float(configuration['intermediate_frequency'])
-        dataSize = int(configuration['data_size'])
-        if dataSize == 8:
-            self.fileDataType = np.int8
-        elif dataSize == 16:
-            self.fileDataType = np.int16
-        else:
-            raise ValueError(f"Data type of {dataSize} bit(s) is not valid.")
-        self.dtype = np.complex128 if self.isComplex else self.fileDataType
-        self.file_id = None
+    def __init__(self, configuration):
+        self.filepath = str(configuration["filepath"])
+        self.samplingFrequency = float(configuration["sampling_frequency"])
+        self.interFrequency = float(configuration["intermediate_frequency"])
+        self.isComplex = _as_bool(configuration["is_complex"])
+        bits = int(configuration["data_size"])
+        if bits not in (8, 16):
+            raise ValueError(f"Data type of {bits} bit(s) is not valid.")
+        self.fileDataType = np.int8 if bits == 8 else np.int16
+        if not self.isComplex:
+            raise ValueError("real-valued recordings are not supported: the correlators take I,Q samples")
+        self.dtype = np.complex128                      # what a sample IS (the reference's rfSignal.dtype); storage stays integer
         self.samplesPerMs = int(self.samplingFrequency * 1e-3)
-        self.chunck = None
-        self.chunckMsCounter = self.CHUNCK_SIZE_MS
+        self._map = None
+        self._next = 0                                  # samples handed out so far
 
-    def getMilliseconds(self, nbMilliseconds: int, raw: bool = True):
-        """Next block of samples: interleaved integers (raw=True, default) or complex128 like the reference."""
-        if self.CHUNCK_SIZE_MS % nbMilliseconds:
-            raise ValueError(f"The number of millisecond requested should be a multiple of the chunck size for "
-                             f"optimal read ({nbMilliseconds} not multiple of {self.CHUNCK_SIZE_MS}).")
-        if self.chunckMsCounter == self.CHUNCK_SIZE_MS:
-            self.chunck = self.readFile(timeLength=self.CHUNCK_SIZE_MS, keep_open=True)
-            self.chunckMsCounter = 0
-        start = self.chunckMsCounter * self.samplesPerMs
-        stop = start + self.samplesPerMs * nbMilliseconds
-        self.chunckMsCounter += nbMilliseconds
-        block = self.chunck[2 * start:2 * stop]
+    # ------------------------------------------------------------------ the recording
+    def _recording(self) -> np.ndarray:
+        if self._map is None:
+            if not os.path.isfile(self.filepath):
+                raise FileNotFoundError(f"IQ recording {self.filepath!r} does not exist")
+            self._map = np.memmap(self.filepath, dtype=self.fileDataType, mode="r")
+        return self._map
+
+    @property
+    def totalSamples(self) -> int:
+        return self._recording().size // 2
+
+    @property
+    def position(self) -> int:
+        """Index of the next sample `getMilliseconds` will deliver."""
+        return self._next
+
+    def seek(self, sample: int):
+        if not 0 <= sample <= self.totalSamples:
+            raise ValueError(f"sample {sample} outside the recording's {self.totalSamples}")
+        self._next = int(sample)
+
+    def slab(self, n_samples: int) -> np.ndarray:
+        """The next n_samples as interleaved integers [I0, Q0, I1, Q1, ...] -- a view of the mapped file."""
+        rec = self._recording()
+        stop = self._next + int(n_samples)
+        if stop > rec.size // 2:
+            raise EOFError(f"recording ends at sample {rec.size // 2}, {stop} requested")
+        out = rec[2 * self._next:2 * stop]
+        self._next = stop
+        return out
+
+    # ------------------------------------------------------------------ the reference's call (receiver.py:124)
+    def getMilliseconds(self, nbMilliseconds: int = 1, raw: bool = True):
+        """Next `nbMilliseconds` of signal.  raw=True (default): interleaved integers for the device ring;
+        raw=False: complex128 like the reference's RFSignal.getMilliseconds (rfsignal.py:58-88)."""
+        block = self.slab(self.samplesPerMs * int(nbMilliseconds))
         if raw:
             return block
-        return block[0::2] + 1j * block[1::2]
-
-    def readFile(self, timeLength, skip=0, keep_open=False):
-        """Interleaved I,Q integers for `timeLength` ms (complex files only, as the reference's data)."""
-        count = int(2 * (timeLength * 1e-3) * self.samplingFrequency)
-        offset = int(np.dtype(self.fileDataType).itemsize * skip * 2)
-        fid = open(self.filepath, 'rb') if self.file_id is None else self.file_id
-        data = np.fromfile(fid, self.fileDataType, offset=offset, count=count)
-        if keep_open:
-            self.file_id = fid
-        else:
-            fid.close()
-        return data
-
-    def readFileBySamples(self, nb_values, skip=0, keep_open=False):
-        """Interleaved I,Q integers for `nb_values` samples, skipping `skip` samples first (rfsignal.py:138-181)."""
-        count = int(2 * nb_values)
-        offset = int(np.dtype(self.fileDataType).itemsize * skip * 2)
-        fid = open(self.filepath, 'rb') if self.file_id is None else self.file_id
-        data = np.fromfile(fid, self.fileDataType, offset=offset, count=count)
-        if keep_open:
-            self.file_id = fid
-        else:
-            fid.close()
-        return data
-
-    def closeFile(self):
-        if self.file_id is None:
-            raise Warning("File was already close.")
-        self.file_id.close()
-        self.file_id = None
-
-    def getCurrentSampleIndex(self):
-        """Index of the next sample the open file will deliver (rfsignal.py:195-203: byte position / 2 for I,Q files of
-        one byte per component, as the reference computes it)."""
-        if self.file_id is None:
-            raise Warning("Signal file not open, cannot return current cursor position.")
-        return int(self.file_id.tell() / 2)
+        return block[0::2].astype(np.float64) + 1j * block[1::2].astype(np.float64)

@@ -32,10 +32,22 @@ class CircularBuffer:
         self.idxWrite = 0
         self.idxRead = 0
         self.size = 0
+        self.channelBank = None   # the tracking state of this ring's channels, resident on the same GPU
+
+    def bankFor(self, cid: int):
+        """The device-resident channel bank that goes with this ring, grown to hold channel `cid`."""
+        from ..channel.bank import ChannelBank
+        if self.channelBank is None:
+            self.channelBank = ChannelBank(self.engine, max(32, int(cid) + 1), self)
+        elif self.channelBank.max_channels <= int(cid):
+            self.channelBank = self.channelBank.grown(max(2 * self.channelBank.max_channels, int(cid) + 1))
+        return self.channelBank
 
     # ---------------------------------------------------------------- writes (circularbuffer.py:54-108)
-    def shift(self, data):
-        """Append one block.  `data` is complex (one value per sample) or raw interleaved I,Q integers."""
+    def stage(self, data):
+        """What shift() would upload and where: (samples in the ring's format, ring offset, sample count).  The
+        caller uploads them (ChannelManager fuses the copy into the tick's device call) and then advances the
+        write index with shiftIdxWrite(count)."""
         data = np.asarray(data)
         if np.iscomplexobj(data):
             shift = data.size
@@ -52,8 +64,13 @@ class CircularBuffer:
             shift = data.size // 2
         if self.maxSize % shift != 0:
             raise ValueError("Data shift need to be a multiple from the max buffer size.")
-        self.engine.iq_upload(data, self.idxWrite)
-        self.shiftIdxWrite(shift)
+        return data, self.idxWrite, shift
+
+    def shift(self, data):
+        """Append one block.  `data` is complex (one value per sample) or raw interleaved I,Q integers."""
+        data, offset, count = self.stage(data)
+        self.engine.iq_upload(data, offset)
+        self.shiftIdxWrite(count)
 
     def shiftIdxWrite(self, shift: int):
         self.idxWrite += shift
@@ -66,10 +83,6 @@ class CircularBuffer:
                 self.idxWrite %= self.maxSize
             if self.size > self.maxSize:
                 self.size = self.maxSize
-
-    def shiftIdxRead(self, shift: int):
-        self.idxRead += shift
-        self.idxRead %= self.maxSize
 
     # ---------------------------------------------------------------- reads (circularbuffer.py:114-148)
     def getSlice(self, idxStart: int = None, samplesRequired: int = 0):

@@ -6,6 +6,7 @@ trajectories captured from the reference.  The product never imports this."""
 import numpy as np
 
 from oracle import sydr_oracle as orc
+from sydr_amd._lib import TRACK_EPOCH_DTYPE, TRACK_STATE_DTYPE
 from sydr_amd.engine import FMT_CF64, FMT_CI16, FMT_CI8
 
 _NP = {FMT_CI8: np.int8, FMT_CI16: np.int16, FMT_CF64: np.float64}
@@ -84,6 +85,124 @@ class OracleEngine:
             out[k] = orc.epl(x, orc.pad_code(self.codes[int(it["code_slot"])]), fs, float(it["carrier_hz"]),
                              float(it["rem_carrier"]), float(it["rem_code"]), float(it["code_step"]), spacing)
         return out
+
+
+class OracleBank:
+    """sydr_amd.engine.Bank on the oracle's closed-loop channel models (oracle.KaplanLoop / BorreLoop): every step
+    rebuilds the model from the sdr_track_state / sdr_loop_cfg rows, runs it, and writes the rows back."""
+
+    def __init__(self, engine, max_channels):
+        self.e, self.max_channels = engine, int(max_channels)
+        self.states, self.cfgs = {}, {}
+        self.calls = dict(step=0, tick=0, channels=0)
+
+    def put(self, ch, state, cfg):
+        self.states[int(ch)] = np.array(state, dtype=TRACK_STATE_DTYPE).reshape(1)[0].copy()
+        self.cfgs[int(ch)] = np.array(cfg).reshape(1)[0].copy()
+
+    def get(self, ch):
+        return self.states[int(ch)].copy()
+
+    def close(self):
+        pass
+
+    def _model(self, st, cfg):
+        kaplan = int(cfg["loop_kind"]) == 1
+        m = object.__new__(orc.KaplanLoop if kaplan else orc.BorreLoop)
+        m.fs = float(cfg["fs"])
+        m.code = orc.pad_code(self.e.codes[int(st["code_slot"])])
+        m.dll_tau1, m.dll_tau2, m.dll_pdi = float(cfg["dll_tau1"]), float(cfg["dll_tau2"]), float(cfg["dll_pdi"])
+        m.carrier_hz, m.code_hz = float(st["carrier_hz"]), float(st["code_hz"])
+        m.rem_carrier, m.rem_code, m.code_step = float(st["rem_carrier"]), float(st["rem_code"]), float(st["code_step"])
+        m.n, m.current_sample = int(st["n_samples"]), int(st["current_sample"])
+        m.flags, m.code_counter = int(st["track_flags"]), int(st["code_counter"])
+        m.nav_sum, m.nav_count, m.nav_bits = float(st["nav_prompt_sum"]), int(st["nav_sum_counter"]), []
+        if kaplan:
+            m.sp_wide, m.sp_narrow = list(cfg["spacing_wide"][:3]), list(cfg["spacing_narrow"][:3])
+            m.spacing = m.sp_narrow if int(st["spacing_sel"]) else m.sp_wide
+            m.cfg = dict(fll_threshold_narrow=cfg["fll_thr_narrow"], pll_threshold_narrow=cfg["pll_thr_narrow"],
+                         fll_threshold_wide=cfg["fll_thr_wide"], pll_threshold_wide=cfg["pll_thr_wide"],
+                         fll_bandwidth_narrow=cfg["fll_bw_narrow"], pll_bandwidth_narrow=cfg["pll_bw_narrow"],
+                         fll_bandwidth_wide=cfg["fll_bw_wide"], pll_bandwidth_wide=cfg["pll_bw_wide"],
+                         fll_bandwidth_pullin=cfg["fll_bw_pullin"])
+            m.cfg = {k: float(v) for k, v in m.cfg.items()}
+            m.dll_thr = float(cfg["dll_threshold"])
+            m.corr, m.accum_counter = [0.0] * 6, int(st["accum_counter"])
+            m.ip_prev, m.qp_prev = float(st["i_prompt_prev"]), float(st["q_prompt_prev"])
+            m.cn0_ratio, m.cn0 = float(st["cn0_ratio_acc"]), float(st["cn0"])
+            m.dll, m.pll, m.fll = float(st["dll_mem"]), 0.0, 0.0
+            m.fll_bw, m.pll_bw = float(st["fll_bw"]), float(st["pll_bw"])
+            m.dll_lock, m.fll_lock, m.pll_lock = float(st["cn0"]), float(st["fll_lock"]), float(st["pll_lock"])
+            m.vel_mem, m.time_in_state, m.lock_state = float(st["pll_mem"]), int(st["time_in_state"]), int(st["lock_state"])
+        else:
+            m.spacing = list(cfg["spacing_wide"][:3])
+            m.pll_tau1, m.pll_tau2, m.pll_pdi = float(cfg["pll_tau1"]), float(cfg["pll_tau2"]), float(cfg["pll_pdi"])
+            m.code_err_mem, m.carrier_err_mem = float(st["dll_mem"]), float(st["pll_mem"])
+            m.ip_prev = float(st["i_prompt_prev"])
+        return m, kaplan
+
+    @staticmethod
+    def _store(m, kaplan, st, qp):
+        st["carrier_hz"], st["code_hz"] = m.carrier_hz, m.code_hz
+        st["rem_carrier"], st["rem_code"], st["code_step"] = m.rem_carrier, m.rem_code, m.code_step
+        st["n_samples"], st["current_sample"] = m.n, m.current_sample
+        st["track_flags"], st["code_counter"] = m.flags, m.code_counter
+        st["nav_prompt_sum"], st["nav_sum_counter"] = m.nav_sum, m.nav_count
+        st["nav_bits_emitted"] += len(m.nav_bits)
+        if kaplan:
+            st["spacing_sel"] = 1 if m.spacing is m.sp_narrow else 0
+            st["accum_counter"], st["i_prompt_prev"], st["q_prompt_prev"] = m.accum_counter, m.ip_prev, m.qp_prev
+            st["cn0_ratio_acc"], st["cn0"], st["dll_mem"] = m.cn0_ratio, m.cn0, m.dll
+            st["fll_bw"], st["pll_bw"], st["fll_lock"], st["pll_lock"] = m.fll_bw, m.pll_bw, m.fll_lock, m.pll_lock
+            st["pll_mem"], st["time_in_state"], st["lock_state"] = m.vel_mem, m.time_in_state, m.lock_state
+        else:
+            st["dll_mem"], st["pll_mem"], st["i_prompt_prev"], st["q_prompt_prev"] = m.code_err_mem, m.carrier_err_mem, m.ip_prev, qp
+
+    def step(self, channels, n_epochs=1, want_records=True, want_bits=False, stream=0, epochs_per_bit=20):
+        self.calls["step"] += 1
+        self.calls["channels"] += len(channels)
+        n = len(channels)
+        rec = np.zeros((n, n_epochs), dtype=TRACK_EPOCH_DTYPE)
+        rec["nav_bit"] = -1
+        done = np.zeros(n, dtype=np.int32)
+        bits = []
+        for r, ch in enumerate(int(c) for c in channels):
+            st, cfg = self.states[ch], self.cfgs[ch]
+            m, kaplan = self._model(st, cfg)
+            qp = float(st["q_prompt_prev"])
+            for k in range(n_epochs):
+                if not (0 < m.n <= self.e.iq_capacity and m.code_step > 0 and abs(m.carrier_hz) < 1e9):
+                    break
+                out = m.step(self.e._complex(m.current_sample, m.n))
+                e = rec[r, k]
+                e["start_sample"], e["n_samples"] = out["start"], out["n"]
+                e["carrier_hz_in"], e["rem_carrier_in"] = out["carrier_hz_in"], out["rem_carrier_in"]
+                e["rem_code_in"], e["code_step_in"] = out["rem_code_in"], out["code_step_in"]
+                e["corr"][:6] = out["corr"]
+                e["dll"], e["pll"], e["fll"] = out["dll"], out["pll"], out.get("fll", 0.0)
+                e["carrier_err"], e["code_err"] = out["carrier_err"], out["code_err"]
+                e["carrier_hz"], e["code_hz"] = out["carrier_hz"], out["code_hz"]
+                e["cn0"], e["pll_lock"], e["fll_lock"] = out.get("cn0", 0.0), out.get("pll_lock", 0.0), out.get("fll_lock", 0.0)
+                e["lock_state"], e["track_flags"], e["nav_bit"] = out.get("lock_state", 0), out["flags"], out["nav_bit"]
+                qp = out["corr"][3]
+                done[r] = k + 1
+            self._store(m, kaplan, st, qp)
+            bits.append(np.array(m.nav_bits, dtype=np.int8))
+        states = np.array([self.states[int(c)] for c in channels], dtype=TRACK_STATE_DTYPE)
+        return (rec if want_records else None), states, done, (bits if want_bits else None)
+
+    def tick(self, raw, ring_offset, channels):
+        self.calls["tick"] += 1
+        if raw is not None:
+            self.e.iq_upload(raw, ring_offset)
+        if not len(channels):
+            return np.zeros(0, dtype=TRACK_EPOCH_DTYPE), np.zeros(0, dtype=TRACK_STATE_DTYPE), np.zeros(0, dtype=np.int32)
+        rec, states, done, _ = self.step(channels, 1)
+        return rec[:, 0], states, done
+
+
+OracleEngine.bank = lambda self, max_channels: OracleBank(self, max_channels)
+OracleEngine._ring_samples = lambda self, raw: np.asarray(raw)
 
 
 def _serial_search(self, code_slots, start_sample, fs, doppler_range, doppler_step, noncoh=1, want_map=False,

@@ -1,0 +1,186 @@
+"""GPU tests of the device-resident channel bank (sdr_bank_*), the per-batch streams and the multi-GPU
+partition of north_star exercised on ONE GPU: the same stream in two engines, channels split 16/16, outputs
+bitwise equal to the 32-in-one launch (per-channel outputs must not depend on the sharding)."""
+import numpy as np
+import pytest
+
+from oracle import sydr_oracle as orc
+from test_gpu_tracking import initial_state, loop_cfg
+from test_oracle_golden import BORRE_CFG, KAPLAN_CFG, trajectory_iq
+
+from sydr_amd._lib import LOOP_CFG_DTYPE, TRACK_STATE_DTYPE
+from sydr_amd.channel.manager import shard_channels
+from sydr_amd.engine import FMT_CI8, Engine, make_items
+
+pytestmark = pytest.mark.gpu
+
+
+def as_row(struct, dtype):
+    return np.frombuffer(bytes(struct), dtype=dtype)[0].copy()
+
+
+def test_bank_steps_equal_the_closed_loop_run(engine):
+    """One epoch per call from the bank == the same epochs inside one closed-loop launch (one workgroup per channel
+    either way: the summation order, hence every bit, is the same); states stay on the device in between."""
+    g, fs, raw = trajectory_iq()
+    n = raw.size // 2 // 8 * 8
+    engine.iq_alloc(n, FMT_CI8)
+    engine.iq_upload(raw[:2 * n], 0)
+    engine.code_slots(2)
+    engine.load_gps_code(1, 7)
+    acq = g["kaplan_acq"]
+    st_k = initial_state(1, fs, acq[3], int(acq[5]), KAPLAN_CFG, slot=1)
+    st_b = initial_state(0, fs, acq[3], int(acq[5]), BORRE_CFG, slot=1)
+    engine.track_cluster(1)
+    try:
+        _bank_vs_closed_loop(engine, fs, st_k, st_b)
+    finally:
+        engine.track_cluster(0)
+
+
+def _bank_vs_closed_loop(engine, fs, st_k, st_b):
+    ref_k, traj_k = engine.track_closed_loop([st_k], loop_cfg(1, fs, KAPLAN_CFG), 60)
+    ref_b, traj_b = engine.track_closed_loop([st_b], loop_cfg(0, fs, BORRE_CFG), 60)
+    bank = engine.bank(8)
+    bank.put(5, as_row(st_k, TRACK_STATE_DTYPE), as_row(loop_cfg(1, fs, KAPLAN_CFG), LOOP_CFG_DTYPE))
+    bank.put(2, as_row(st_b, TRACK_STATE_DTYPE), as_row(loop_cfg(0, fs, BORRE_CFG), LOOP_CFG_DTYPE))
+    recs = []
+    for k in range(40):
+        rec, states, done, _ = bank.step([5, 2], 1)
+        assert list(done) == [1, 1]
+        recs.append(rec[:, 0])
+    rec, states, done, _ = bank.step([2, 5], 20)            # a block, other order: continues from the device state
+    assert list(done) == [20, 20]
+    got_k = np.concatenate([np.array([r[0] for r in recs]), rec[1]])
+    got_b = np.concatenate([np.array([r[1] for r in recs]), rec[0]])
+    assert got_k.tobytes() == traj_k[0].tobytes() and got_b.tobytes() == traj_b[0].tobytes()
+    assert states[1].tobytes() == bytes(ref_k[0]) and bank.get(2).tobytes() == bytes(ref_b[0])
+    with pytest.raises(Exception, match="not in the bank"):
+        bank.step([1], 1)
+    with pytest.raises(Exception, match="listed twice"):
+        bank.step([5, 5], 1)
+    bank.close()
+
+
+def test_bank_tick_ingests_and_tracks_in_one_call(engine):
+    """sdr_bank_tick == CircularBuffer.shift of one slab followed by one epoch of the ready channels."""
+    g, fs, raw = trajectory_iq()
+    spms = int(fs * 1e-3)
+    ring = 100 * spms
+    acq = g["kaplan_acq"]
+    st = initial_state(1, fs, acq[3], int(acq[5]), KAPLAN_CFG, slot=0)
+    row_s, row_c = as_row(st, TRACK_STATE_DTYPE), as_row(loop_cfg(1, fs, KAPLAN_CFG), LOOP_CFG_DTYPE)
+
+    def run(fused):
+        engine.iq_alloc(ring, FMT_CI8)
+        engine.code_slots(1)
+        engine.load_gps_code(0, 7)
+        bank = engine.bank(1)
+        bank.put(0, row_s, row_c)
+        out, cur, n_next = [], int(acq[5]), int(st.n_samples)
+        for ms in range(120):
+            slab, off = raw[2 * ms * spms:2 * (ms + 1) * spms], (ms * spms) % ring
+            written = (ms + 1) * spms
+            ready = [0] if written - cur >= n_next else []
+            if fused:
+                rec, states, done = bank.tick(slab, off, ready)
+            else:
+                engine.iq_upload(slab, off)
+                rec, states, done = bank.tick(None, 0, ready)
+            if ready:
+                out.append(rec[0].copy())
+                cur, n_next = int(states[0]["current_sample"]), int(states[0]["n_samples"])
+        bank.close()
+        return np.array(out)
+
+    a, b = run(True), run(False)
+    assert len(a) > 100 and a.tobytes() == b.tobytes()
+    ref = g["kaplan_epochs"][:len(a)]
+    assert np.array_equal(a["n_samples"], ref[:, 1].astype(np.int32))
+    assert np.allclose(a["carrier_hz"], ref[:, 15], rtol=1e-9, atol=0)
+
+
+def _stream_and_items(fs, n_ch, n_ms, seed=77):
+    """A synthetic multi-satellite stream description + open-loop items for every channel-epoch."""
+    rng = np.random.default_rng(seed)
+    sats = [dict(prn=1 + c, doppler=float(rng.uniform(-4500, 4500)), code_phase=float(rng.uniform(0, 1023)),
+                 phase=float(rng.uniform(0, 1)), amp=6.0) for c in range(n_ch)]
+    spms = int(fs * 1e-3)
+    items = []
+    for c, s in enumerate(sats):
+        step = orc.CODE_RATE * (1.0 + s["doppler"] / 1575.42e6) / fs
+        start0 = int(np.ceil((1023.0 - s["code_phase"]) % 1023.0 / step))
+        for k in range(n_ms - 2):
+            start = start0 + int(round(k * 1023.0 / step))
+            items.append((c, spms, start, s["doppler"], 0.1 * k, 0.0, step))
+    cols = list(zip(*items))
+    return sats, make_items(*[np.array(col) for col in cols])
+
+
+def test_two_engines_on_one_gpu_split_channels_bitwise():
+    """north_star's partition on one GPU: the SAME stream replicated in two engines, 32 channels split 16/16 with
+    shard_channels -- open-loop correlators and closed-loop trajectories of every channel bitwise equal to the
+    32-in-one launch."""
+    fs, n_ch, n_ms = 25e6, 32, 12
+    spms = int(fs * 1e-3)
+    sats, items = _stream_and_items(fs, n_ch, n_ms)
+    engines = [Engine(0) for _ in range(3)]
+    try:
+        for e in engines:                                    # stream replicated: same seed, same satellites
+            e.iq_alloc(n_ms * spms, FMT_CI8)
+            e.code_slots(n_ch)
+            for c in range(n_ch):
+                e.load_gps_code(c, sats[c]["prn"])
+            e.iq_synth(sats, fs, 12.0, 4242, 0, n_ms * spms)
+        assert engines[0].iq_download(4096, 12345).tobytes() == engines[2].iq_download(4096, 12345).tobytes()
+        whole = engines[0].epl_batch(items, (-0.5, 0.0, 0.5), fs)
+        cfg = loop_cfg(1, fs, KAPLAN_CFG)
+        mk = lambda c: initial_state(1, fs, sats[c]["doppler"] + 40.0, int(items["start_sample"][items["code_slot"] == c][0]),
+                                     KAPLAN_CFG, slot=c)
+        engines[0].track_cluster(4)
+        all_states, all_traj = engines[0].track_closed_loop([mk(c) for c in range(n_ch)], cfg, 8)
+        for rank, e in enumerate(engines[1:]):
+            mine = shard_channels(n_ch, rank, 2)
+            assert len(mine) == 16
+            sel = np.isin(items["code_slot"], mine)
+            part = e.epl_batch(items[sel], (-0.5, 0.0, 0.5), fs)
+            assert part.tobytes() == whole[sel].tobytes()
+            e.track_cluster(4)
+            st, traj = e.track_closed_loop([mk(c) for c in mine], cfg, 8)
+            assert traj.tobytes() == all_traj[mine].tobytes()
+            assert b"".join(bytes(s) for s in st) == b"".join(bytes(all_states[c]) for c in mine)
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_one_stream_per_channel_batch(engine):
+    """Ranges of a plan launched on two streams of one engine (one per channel batch) == the single-stream run."""
+    fs, n_ch, n_ms = 25e6, 8, 10
+    spms = int(fs * 1e-3)
+    sats, items = _stream_and_items(fs, n_ch, n_ms, seed=5)
+    engine.iq_alloc(n_ms * spms, FMT_CI8)
+    engine.code_slots(n_ch)
+    for c in range(n_ch):
+        engine.load_gps_code(c, sats[c]["prn"])
+    engine.iq_synth(sats, fs, 12.0, 99, 0, n_ms * spms)
+    plan = engine.epl_plan(items, (-0.5, 0.0, 0.5), fs)
+    plan.run()
+    ref = plan.fetch()
+    s1, s2 = engine.stream_create(), engine.stream_create()
+    assert (s1, s2) == (1, 2) or s2 == s1 + 1
+    plan2 = engine.epl_plan(items, (-0.5, 0.0, 0.5), fs)
+    half = len(items) // 2
+    plan2.run(0, half, stream=s1)
+    plan2.run(half, len(items) - half, stream=s2)
+    engine.stream_sync(s1)
+    engine.stream_sync(s2)
+    assert plan2.fetch().tobytes() == ref.tobytes()
+    with pytest.raises(Exception, match="stream id"):
+        plan2.run(0, 1, stream=99)
+    # a plan does not survive a re-allocation of the code tables (ADVICE: stale lut_words / slots)
+    engine.code_slots(n_ch + 1)
+    with pytest.raises(Exception, match="stale"):
+        plan.run()
+    plan.close()
+    plan2.close()

@@ -322,9 +322,38 @@ def test_closed_loop_stops_instead_of_reading_out_of_range(engine):
     with pytest.raises(SdrError, match="stopped after 0 epochs"):
         engine.track_closed_loop([st], loop_cfg(0, fs, BORRE_CFG), 10)
     cfg = loop_cfg(0, fs, BORRE_CFG)
-    cfg.n_taps = 5
+    cfg.n_taps = 4
     with pytest.raises(SdrError):
         engine.track_closed_loop([initial_state(0, fs, 0.0, 0, BORRE_CFG)], cfg, 1)
+    # per-channel outcome (sdr_track_closed_loop_ex): the runaway channel stops, its neighbour is unaffected and
+    # both states come back valid
+    good = initial_state(0, fs, 100.0, 0, BORRE_CFG)
+    alone, traj_alone = engine.track_closed_loop([good], loop_cfg(0, fs, BORRE_CFG), 5)
+    states, traj, _, done = engine.track_closed_loop_ex([st, good], loop_cfg(0, fs, BORRE_CFG), 5)
+    assert list(done) == [0, 5]
+    assert bytes(states[1]) == bytes(alone[0]) and traj[1].tobytes() == traj_alone[0].tobytes()
+    assert states[0].n_samples == st.n_samples and states[0].code_step == 0.4 and np.all(traj[0]["n_samples"] == 0)
+
+
+def test_closed_loop_with_one_configuration_per_channel(engine):
+    """channelManager.addChannel takes a configuration per call: channels of one launch may run different loop
+    parameters (and loop kinds).  Each must evolve exactly as it does alone with its own configuration."""
+    g, fs, raw = trajectory_iq()
+    engine.iq_alloc(len(raw) // 2 // 8 * 8, FMT_CI8)
+    engine.iq_upload(raw[:len(raw) // 16 * 16], 0)
+    engine.code_slots(1)
+    engine.load_gps_code(0, 7)
+    start = int(g["kaplan_acq"][5])
+    kap2 = dict(KAPLAN_CFG, dll_noise_bandwidth=4.0, fll_bandwidth_pullin=60.0)
+    cfgs = [loop_cfg(1, fs, KAPLAN_CFG), loop_cfg(0, fs, BORRE_CFG), loop_cfg(1, fs, kap2)]
+    mk = lambda: [initial_state(1, fs, 1750.0, start, KAPLAN_CFG), initial_state(0, fs, 1750.0, start, BORRE_CFG),
+                  initial_state(1, fs, 1750.0, start, kap2)]
+    states, traj, _, done = engine.track_closed_loop_ex(mk(), cfgs, 120)
+    assert list(done) == [120, 120, 120]
+    for k in range(3):
+        alone, t_alone = engine.track_closed_loop([mk()[k]], cfgs[k], 120)
+        assert traj[k].tobytes() == t_alone[0].tobytes() and bytes(states[k]) == bytes(alone[0])
+    assert traj[0].tobytes() != traj[2].tobytes()
 
 
 # ------------------------------------------------------------------------------------------------ host plugins on the GPU
@@ -362,10 +391,8 @@ def test_run_block_continues_a_per_tick_run(engine):
     from sydr_amd.utils.enumerations import ChannelMessage
     g, fs, raw = trajectory_iq()
     spms = int(fs * 1e-3)
-    mgr = ChannelManager(rf_signal(fs), engine=engine)
     # a ring long enough to hold the whole record, so the block run has its samples resident
-    from sydr_amd.utils.devicering import CircularBuffer
-    mgr.sharedBuffer = CircularBuffer(520 * spms, np.int8, engine=engine)
+    mgr = ChannelManager(rf_signal(fs), engine=engine, ring_ms=520)
     mgr.addChannel(ChannelL1CA_Kaplan, channel_config(KAPLAN_INI), 1)
     ch = mgr.requestTracking(7)
     ticks = drive(mgr, raw, spms, 150)
@@ -415,38 +442,6 @@ def test_function_level_dropins_read_like_the_reference():
     ref = e["r20_out"]
     scale = np.repeat(np.hypot(ref[0::2], ref[1::2]), 2)
     assert np.all(np.abs(np.array(out) - ref) <= RTOL * scale)
-
-
-def test_legacy_function_surface_of_the_tracking_module(engine):
-    """generateReplica / getCorrelator / EPL_nonvector / the 3rd-order loop filter / CN0_NWPR of the reference's dsp
-    modules: same signatures, same numbers (checked against direct NumPy restatements of the reference formulas)."""
-    from sydr_amd.dsp import lockindicator as li
-    from sydr_amd.dsp import tracking as tr
-    rng = np.random.default_rng(8)
-    fs, n = 10e6, 10000
-    t = np.arange(n + 1) / fs
-    rep, rem = tr.generateReplica(t, n, 1234.5, 0.7)
-    ph = -(1234.5 * 2.0 * np.pi * t) + 0.7
-    assert np.array_equal(rep, np.exp(1j * ph[:n])) and rem == ph[n] % (2 * np.pi)
-    code = orc.pad_code(orc.gold_code(5))
-    i_sig, q_sig = rng.normal(0, 30, n), rng.normal(0, 30, n)
-    step = orc.CODE_RATE / fs
-    got = tr.getCorrelator(i_sig, q_sig, -0.5, code, 0.3, step, n)
-    idx = np.ceil(np.linspace(0.3 - 0.5, n * step + 0.3 - 0.5, n, endpoint=False)).astype(int)
-    want = (np.sum(code[idx] * i_sig), np.sum(code[idx] * q_sig))
-    assert got == pytest.approx(want, rel=1e-9, abs=1e-6)
-    x = i_sig + 1j * q_sig
-    a = tr.EPL_nonvector(x, code, fs, 800.0, 0.2, 0.3, step, (-0.5, 0.0, 0.5))
-    b = orc.epl(x, code, fs, 800.0, 0.2, 0.3, step, (-0.5, 0.0, 0.5))
-    assert a == pytest.approx(list(b), rel=1e-9, abs=1e-6)
-    out, vel, acc = tr.FLLassistedPLL_3rdOrder(0.1, -2.0, 10.0, 20.0, 1.414, 1.1, 2.4, 1e-3, 0.5, 0.25)
-    u1 = (0.1 * 20.0**3 + -2.0 * 10.0**2) * 1e-3
-    o1 = u1 + 0.25
-    u2 = (o1 + (0.1 * 1.1 * 20.0**2 + -2.0 * 1.414 * 10.0)) * 1e-3
-    assert (out, vel, acc) == (u2 + 0.5 + 0.1 * 2.4 * 20.0, u2, u1)
-    nb = (li.CN0_NWPR(400.0, 30.0, 9000.0, 1000.0))
-    np_ = (400.0**2 + 30.0**2) / (9000.0 + 1000.0)
-    assert nb == 10 * np.log10(1 / 1e-3 * (np_ - 1) / (20 - np_))
 
 
 def test_file_driven_example_with_the_reference_ini_layout(engine, tmp_path, capsys):

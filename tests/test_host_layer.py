@@ -161,7 +161,8 @@ def test_manager_kaplan_lock_state_machine():
 
 
 def test_manager_batches_channels_into_single_launches():
-    """Three channels: one PCPS call for all of them, then one correlator launch per tick."""
+    """Three channels: one PCPS call for all of them, then ONE device call per tick (ring ingest + an epoch of every
+    ready channel)."""
     fs, spms = 4e6, 4000
     from oracle import sydr_oracle as orc
     sats = [dict(prn=p, doppler=d, code_phase=c, phase=0.1, amp=8.0) for p, d, c in
@@ -176,7 +177,8 @@ def test_manager_batches_channels_into_single_launches():
     ticks = drive(mgr, raw, spms, 30)
     assert eng.calls["pcps"] == 1
     n_trk = sum(p["type"] is ChannelMessage.TRACKING_UPDATE for t in ticks for p in t)
-    assert eng.calls["epl_items"] == n_trk and eng.calls["epl_batch"] <= 29
+    dev = mgr.bank.device
+    assert dev.calls == dict(step=dev.calls["step"], tick=30, channels=n_trk) and eng.calls["epl_batch"] == 0
     assert all(mgr.getChannel(c).channelState is ChannelState.TRACKING for c in range(3))
     for c, s in enumerate(sats):
         assert abs(mgr.getChannel(c).carrierFrequency - s["doppler"]) < 300.0
@@ -206,25 +208,35 @@ def test_ring_bookkeeping_matches_reference_semantics():
         ring.shift(np.array([0.5 + 1j] * 1000))            # non-integer samples into an int8 ring
 
 
-def test_rfsignal_reads_interleaved_int8(tmp_path):
+def test_rfsignal_serves_the_recording_as_raw_integer_slabs(tmp_path):
     rng = np.random.default_rng(2)
     raw = rng.integers(-128, 127, 2 * 4000 * 130).astype(np.int8)
     path = tmp_path / "iq.bin"
     raw.tofile(path)
     sig = RFSignal(dict(filepath=str(path), sampling_frequency=4e6, is_complex="true", intermediate_frequency=0.0,
                         data_size=8))
-    assert sig.samplesPerMs == 4000 and sig.dtype == np.complex128
+    assert sig.samplesPerMs == 4000 and sig.dtype == np.complex128 and sig.fileDataType is np.int8
+    assert sig.totalSamples == 4000 * 130
     first = sig.getMilliseconds(1)
-    assert np.array_equal(first, raw[:8000])
+    assert first.dtype == np.int8 and np.array_equal(first, raw[:8000])
+    assert np.shares_memory(first, sig._recording())                     # a view of the mapped file, not a copy
     cplx = sig.getMilliseconds(1, raw=False)
     assert np.array_equal(cplx, raw[8000:16000:2] + 1j * raw[8001:16000:2])
-    for _ in range(118):
+    assert np.array_equal(sig.getMilliseconds(7), raw[2 * 8000:2 * 8000 + 7 * 8000])   # any slab length
+    assert sig.position == 9 * 4000
+    sig.seek(120 * 4000)
+    assert np.array_equal(sig.getMilliseconds(10), raw[2 * 4000 * 120:])
+    with pytest.raises(EOFError):
         sig.getMilliseconds(1)
-    assert np.array_equal(sig.getMilliseconds(1), raw[2 * 4000 * 120:2 * 4000 * 121])   # second 120 ms chunk
-    with pytest.raises(ValueError):
-        sig.getMilliseconds(7)
     with pytest.raises(ValueError):
         RFSignal(dict(filepath="x", sampling_frequency=4e6, is_complex="true", intermediate_frequency=0, data_size=12))
+    with pytest.raises(ValueError):
+        RFSignal(dict(filepath="x", sampling_frequency=4e6, is_complex="false", intermediate_frequency=0, data_size=8))
+    raw16 = rng.integers(-3000, 3000, 2 * 1000).astype(np.int16)
+    raw16.tofile(tmp_path / "iq16.bin")
+    sig16 = RFSignal(dict(filepath=str(tmp_path / "iq16.bin"), sampling_frequency=1e6, is_complex="True",
+                          intermediate_frequency=0.0, data_size=16))
+    assert np.array_equal(sig16.getMilliseconds(1), raw16)
 
 
 def test_shard_channels_partitions_exactly():
@@ -299,26 +311,3 @@ def test_serial_search_plugin_reproduces_reference():
     for p, row in zip(trk, g["ss_epochs"]):
         assert [p["i_early"], p["q_early"], p["i_prompt"], p["q_prompt"], p["i_late"], p["q_late"],
                 p["carrier_frequency"], p["code_frequency"]] == list(row)
-
-
-def test_rfsignal_reads_the_file_like_the_reference(tmp_path):
-    """RFSignal keeps the reference's method surface (rfsignal.py): chunked getMilliseconds, readFile / readFileBySamples
-    with skip, closeFile, getCurrentSampleIndex -- handing out raw interleaved integers (or complex128 on request)."""
-    fs = 4e6
-    raw = (np.arange(2 * 4000 * 130) % 251 - 125).astype(np.int8)
-    path = tmp_path / "iq.bin"
-    raw.tofile(path)
-    sig = RFSignal(dict(filepath=str(path), sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0, data_size=8))
-    a = sig.getMilliseconds(1)
-    b = sig.getMilliseconds(2, raw=False)
-    assert np.array_equal(a, raw[:8000])
-    assert np.array_equal(b, raw[8000:24000:2] + 1j * raw[8001:24000:2])
-    assert sig.getCurrentSampleIndex() == 120 * 4000          # one 120 ms chunk has been read
-    with pytest.raises(ValueError):
-        sig.getMilliseconds(7)                                   # not a divisor of the chunk length
-    assert np.array_equal(sig.readFileBySamples(10, skip=0, keep_open=True), raw[2 * 120 * 4000:2 * 120 * 4000 + 20])
-    sig.closeFile()
-    with pytest.raises(Warning):
-        sig.closeFile()
-    assert np.array_equal(sig.readFile(1, skip=5), raw[10:8010])
-    assert np.array_equal(sig.readFileBySamples(6, skip=3), raw[6:18])
