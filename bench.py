@@ -10,8 +10,11 @@ The NCO parameters are the synthetic satellites' true code/carrier trajectories 
 all epochs of a step in flight at once) -- closed-loop numbers are reported separately under
 `closed_loop` because they are latency-, not bandwidth-, bound.
 
-Multi-GPU: channels shard across ranks (32 per GPU, weak scaling, no collective on the data
-path); torch.distributed is used only for the barrier and the max-over-ranks time.
+Multi-GPU (north_star): ONE stream with 32*N satellites, generated from the same seed on every
+rank (IQ replicated, no peer traffic); rank r tracks channels shard_channels(32*N, r, N) -- weak
+scaling, 32 channels per GPU, no collective on the data path.  torch.distributed is used only for
+the barrier, the max-over-ranks time and the sum of the ranks' channel-sample counts.  `value` is
+(channel-samples of ALL ranks / 32) / time: the job's throughput in the metric's unit.
 
     python bench.py --gpus 1 --steps 60 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
@@ -37,11 +40,14 @@ L1 = 1575.42e6
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def satellites(rank, seed=20260003):
-    """32 present satellites per GPU (PRN 1..32; other ranks reuse the PRNs with other Doppler/delay)."""
-    rng = np.random.default_rng(seed + 1000 * rank)
-    return [dict(prn=p, doppler=float(rng.uniform(-4500, 4500)), code_phase=float(rng.uniform(0, 1023)),
-                 phase=float(rng.random()), amp=3.0) for p in range(1, N_CH + 1)]
+def satellites(n_total=N_CH, seed=20260003):
+    """The satellites of THE stream -- the same list on every rank.  PRN 1..32 at N = 1; beyond 210 channels the
+    PRN numbers repeat with another Doppler / delay (config 5 is "multi-GNSS" anyway).  The amplitude shrinks with
+    the count so that the int8 stream does not clip."""
+    rng = np.random.default_rng(seed)
+    amp = 3.0 / np.sqrt(max(1, n_total // N_CH))
+    return [dict(prn=1 + i % 210, doppler=float(rng.uniform(-4500, 4500)), code_phase=float(rng.uniform(0, 1023)),
+                 phase=float(rng.random()), amp=float(amp)) for i in range(n_total)]
 
 
 def truth_items(sats, fs, total_samples):
@@ -96,6 +102,63 @@ def cpu_tracking_baseline(engine, items, n_items, budget_s):
     return out[:done], done, dt, rf
 
 
+def _mp_worker(args):
+    """One reference-style channel process: all epochs of one channel through the oracle's EPL."""
+    path, rows, code_prn = args
+    from oracle import sydr_oracle as orc
+    raw = np.load(path, mmap_mode="r")
+    code = orc.pad_code(orc.gold_code(code_prn))
+    acc = 0.0
+    n = 0
+    for (start, ns, f, rc, rk, cs) in rows:
+        x = orc.iq_to_complex(np.asarray(raw[2 * start:2 * (start + ns)]))
+        acc += orc.epl(x, code, FS, f, rc, rk, cs, SPACING)[2]
+        n += ns
+    return n, acc
+
+
+def _mp_warm(_):
+    from oracle import sydr_oracle as orc  # noqa: F401  (imports paid before the clock starts)
+    return os.getpid()
+
+
+def cpu_baseline_all_cores(raw, items, prns, n_epochs, budget_s):
+    """The oracle fanned out by CHANNEL over a process pool -- the reference's own parallelism (one OS process per
+    channel, sydr/channel/channel.py:21, channelManager.py:164-171).  Workers are spawned (never forked from this
+    GPU-holding process).  Returns (stream Msamples/s for the 32-channel batch, processes, wall s, epochs used)."""
+    import multiprocessing as mp
+    import tempfile
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    procs = max(1, min(usable, N_CH))
+    per_epoch_s = 0.6e-3                                  # ~1 channel-epoch of 25 000 samples on one core
+    epochs = int(max(8, min(n_epochs, budget_s * procs / (N_CH * per_epoch_s))))
+    hi = int((items["start_sample"][:epochs * N_CH] + items["n_samples"][:epochs * N_CH]).max())
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+        path = os.path.join(tmp, "iq.npy")
+        np.save(path, raw[:2 * hi])
+        jobs = []
+        for c in range(N_CH):
+            it = items[c:epochs * N_CH:N_CH]
+            rows = [(int(a), int(b), float(f), float(rc), float(rk), float(cs)) for a, b, f, rc, rk, cs in
+                    zip(it["start_sample"], it["n_samples"], it["carrier_hz"], it["rem_carrier"], it["rem_code"], it["code_step"])]
+            jobs.append((path, rows, int(prns[c])))
+        with mp.get_context("spawn").Pool(procs) as pool:
+            pool.map(_mp_warm, range(procs * 2))
+            t0 = time.perf_counter()
+            res = pool.map(_mp_worker, jobs, chunksize=1)
+            dt = time.perf_counter() - t0
+    ch_samples = sum(r[0] for r in res)
+    return ch_samples / N_CH / dt / 1e6, procs, dt, epochs
+
+
+def per_tick_leg(eng):
+    """ChannelManager.addNewRFData(1 ms) + run() from Python, 32 channels (tools/per_tick_rate.py)."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import per_tick_rate
+    return per_tick_rate.measure(300, N_CH, engine=eng)
+
+
 def closed_loop_leg(eng, items, n_epochs, n_ch=N_CH):
     """On-device loop closure (persistent workgroups, Kaplan loops): latency-bound, so it is reported beside,
     not instead of, the open-loop correlator throughput.  n_ch = 32: each channel on a cluster of 8 CUs (lowest
@@ -137,31 +200,48 @@ def closed_loop_leg(eng, items, n_epochs, n_ch=N_CH):
             "us_per_epoch": kern_ms * 1e3 / n_epochs, "channels_lost": int(lost)}
 
 
-def multignss_workload(args, rank, local_rank, world, torch, dist):
+def multignss_workload(args, rank, local_rank, world, torch, dist, eng=None, emit=True):
     """BASELINE configs 4-5: per GPU 32 GPS L1 C/A + 32 E1-like (seeded 4092-chip codes, BOC(1,1)) channels,
-    5 taps VE/E/P/L/VL, fs = 50 MHz, 4 ms epochs.  Not the headline metric: selected with --workload multignss."""
+    5 taps VE/E/P/L/VL, fs = 50 MHz, 4 ms epochs.  Selected with --workload multignss; the default run carries a
+    short version of it as the `multignss` key.  """
     from sydr_amd.engine import FMT_CI8, Engine, make_items
     fs, n_gps, n_e1, taps = 50e6, 32, 32, (-1.0, -0.5, 0.0, 0.5, 1.0)
-    eng = Engine(local_rank)
+    own_engine = eng is None
+    if own_engine:
+        eng = Engine(local_rank)
     total = int(args.stream_seconds * fs) // 8 * 8
     eng.iq_alloc(total, FMT_CI8)
-    eng.code_slots(n_gps + 2 * n_e1, 8184)
-    rng = np.random.default_rng(20260004 + 1000 * rank)
-    sats = []
-    for s in range(n_gps):
-        eng.load_gps_code(s, s + 1)
-        sats.append(dict(prn=s + 1, doppler=float(rng.uniform(-4500, 4500)), code_phase=float(rng.uniform(0, 1023)),
-                         phase=float(rng.random()), amp=2.5, chips=1023, corr_slot=s, half=1))
-    for s in range(n_e1):
+    # ONE stream for the whole job: 32*N GPS + 32*N E1-like satellites from one seed, generated on every rank; this
+    # rank tracks its shard of each constellation (64 channels per GPU)
+    from sydr_amd.channel.manager import shard_channels
+    n_gps_all, n_e1_all = n_gps * world, n_e1 * world
+    mine = shard_channels(n_gps_all, rank, world)
+    eng.code_slots(n_gps + n_e1_all + n_e1, 8184)           # [my GPS][every E1 chip-rate code][my E1 half-chip codes]
+    rng = np.random.default_rng(20260004)
+    amp = 2.5 / np.sqrt(world)
+    all_sats, sats_gps, sats_e1 = [], [], []
+    for i in range(n_gps_all):
+        sat = dict(prn=1 + i % 210, doppler=float(rng.uniform(-4500, 4500)), code_phase=float(rng.uniform(0, 1023)),
+                   phase=float(rng.random()), amp=amp, chips=1023, half=1)
+        all_sats.append(sat)
+        if i in mine:
+            sat["corr_slot"] = len(sats_gps)
+            eng.load_gps_code(sat["corr_slot"], sat["prn"])
+            sats_gps.append(sat)
+    for i in range(n_e1_all):
         code = np.where(rng.random(4092) < 0.5, -1, 1).astype(np.int8)   # seeded stand-in for an E1 memory code
-        half = np.empty(8184, dtype=np.int8)
-        half[0::2], half[1::2] = code, -code
-        eng.set_code(n_gps + s, code)                # chip-rate code: read by the generator
-        eng.set_code(n_gps + n_e1 + s, half)         # half-chip code: read by the correlator
-        sats.append(dict(slot=n_gps + s, boc=True, doppler=float(rng.uniform(-4500, 4500)),
-                         code_phase=float(rng.uniform(0, 4092)), phase=float(rng.random()), amp=2.5, chips=4092,
-                         corr_slot=n_gps + n_e1 + s, half=2))
-    eng.iq_synth(sats, fs, 12.0, 20260004 + rank, 0, total)
+        eng.set_code(n_gps + i, code)                # chip-rate code: read by the generator
+        sat = dict(slot=n_gps + i, boc=True, doppler=float(rng.uniform(-4500, 4500)),
+                   code_phase=float(rng.uniform(0, 4092)), phase=float(rng.random()), amp=amp, chips=4092, half=2)
+        all_sats.append(sat)
+        if i in mine:
+            half = np.empty(8184, dtype=np.int8)
+            half[0::2], half[1::2] = code, -code
+            sat["corr_slot"] = n_gps + n_e1_all + len(sats_e1)
+            eng.set_code(sat["corr_slot"], half)     # half-chip code: read by the correlator
+            sats_e1.append(sat)
+    sats = sats_gps + sats_e1
+    eng.iq_synth(all_sats, fs, 12.0, 20260004, 0, total)
 
     def items_for(group):
         dop = np.array([s["doppler"] for s in group])
@@ -225,7 +305,12 @@ def multignss_workload(args, rank, local_rank, world, torch, dist):
             lo = (k % n_avail) * per_step * n_ch
             ch_samples += int(items["n_samples"][lo:lo + per_step * n_ch].sum())
     stream_samples = ch_samples / (n_gps + n_e1)
-    value = world * stream_samples / elapsed / 1e6
+    job = float(ch_samples)
+    if world > 1:
+        t = torch.tensor([job], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        job = float(t.item())
+    value = job / (n_gps + n_e1) / elapsed / 1e6
     achieved = 2.0 * ch_samples / (kern_ms * 1e-3) / 1e9 if launches else 0.0
     result = {"metric": "IQ Msamples/s through 64-ch 5-tap VE/E/P/L/VL correlators @50 MHz fs, 4 ms integration",
               "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -236,7 +321,7 @@ def multignss_workload(args, rank, local_rank, world, torch, dist):
                          "channels_per_gpu": n_gps + n_e1, "fs_hz": fs, "taps": 5, "iq_format": "ci8",
                          "note": "no reference implementation exists for this configuration (SURVEY.md section 0); "
                                  "parity is against the oracle's generalised restatement"},
-              "x_realtime": value * 1e6 / fs / world,
+              "x_realtime": stream_samples / elapsed / fs,
               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "epl_kernel",
                            "avg_launch_ms": kern_ms / max(1, launches), "launches": int(launches)}}
@@ -260,9 +345,11 @@ def multignss_workload(args, rank, local_rank, world, torch, dist):
                                   "oracle/sydr_oracle.py:epl, scaled to 64 channels", "max_rel_err_gpu_vs_oracle": err}
     for plan, *_ in plans:
         plan.close()
-    eng.close()
-    if rank == 0:
+    if own_engine:
+        eng.close()
+    if rank == 0 and emit:
         print(json.dumps(result))
+    return result
 
 
 def main():
@@ -276,6 +363,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-acquisition", action="store_true")
     ap.add_argument("--no-closed-loop", action="store_true")
+    ap.add_argument("--no-per-tick", action="store_true")
+    ap.add_argument("--no-multignss", action="store_true")
+    ap.add_argument("--cpu-mp-seconds", type=float, default=10.0, help="budget of the all-cores CPU baseline (0: skip)")
     ap.add_argument("--closed-loop-epochs", type=int, default=2000)
     args = ap.parse_args()
 
@@ -302,27 +392,33 @@ def main():
             dist.destroy_process_group()
         return
 
+    from sydr_amd.channel.manager import shard_channels
     from sydr_amd.engine import FMT_CI8, Engine
 
     eng = Engine(local_rank)
     total = int(args.stream_seconds * FS) // 8 * 8
     eng.iq_alloc(total, FMT_CI8)
     eng.code_slots(N_CH)
-    sats = satellites(rank)
+    n_total = N_CH * world
+    all_sats = satellites(n_total)                          # the same stream on every rank ...
+    mine = shard_channels(n_total, rank, world)             # ... of which this rank tracks its 32 channels
+    sats = [all_sats[i] for i in mine]
     for s, sat in enumerate(sats):
         eng.load_gps_code(s, sat["prn"])
-    eng.iq_synth(sats, FS, 12.0, 20260003 + rank, 0, total)
+    eng.iq_synth(all_sats, FS, 12.0, 20260003, 0, total)
     items, n_epochs = truth_items(sats, FS, total)
     epochs_per_step = 1000
     n_steps_avail = max(1, n_epochs // epochs_per_step)
     per_step = epochs_per_step * N_CH if n_epochs >= epochs_per_step else n_epochs * N_CH
     plan = eng.epl_plan(items, SPACING, FS)
     step_samples = [int(items["n_samples"][k * per_step:(k + 1) * per_step].sum()) for k in range(n_steps_avail)]
+    batch_stream = eng.stream_create()                      # one HIP stream per channel batch (north_star)
 
     def run_step(k):
-        plan.run((k % n_steps_avail) * per_step, per_step)
+        plan.run((k % n_steps_avail) * per_step, per_step, stream=batch_stream)
 
     def barrier():
+        eng.stream_sync(batch_stream)
         eng.sync()
         torch.cuda.synchronize()
         if world > 1:
@@ -336,24 +432,29 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         run_step(k)
-    eng.sync()
+    eng.stream_sync(batch_stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    ch_samples = sum(step_samples[k % n_steps_avail] for k in range(args.steps))  # channel-samples, this rank
+    job_ch_samples = float(ch_samples)
     if world > 1:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        t = torch.tensor([job_ch_samples], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        job_ch_samples = float(t.item())
     eng.prof_enable(False)
     kern_ms, launches = eng.prof_read("epl_kernel")
     eng.prof_reset()
 
-    ch_samples = sum(step_samples[k % n_steps_avail] for k in range(args.steps))  # channel-samples, this rank
-    stream_samples = ch_samples / N_CH
-    value = world * stream_samples / elapsed / 1e6
+    stream_samples = ch_samples / N_CH                       # samples of THE stream consumed per rank (same on all)
+    value = job_ch_samples / N_CH / elapsed / 1e6            # the job's channel-samples, in units of 32-channel batches
     avg_kernel_s = kern_ms / max(1, launches) * 1e-3
     algo_bytes_per_launch = 2.0 * ch_samples / max(1, args.steps)  # 2 B per channel-sample (ci8)
     achieved = algo_bytes_per_launch / avg_kernel_s / 1e9 if launches else 0.0
+    flops = (6 + 4 * len(SPACING)) * ch_samples / max(1, args.steps)
 
     result = {
         "metric": "IQ Msamples/s through 32-ch E/P/L correlators @25 MHz fs",
@@ -362,10 +463,12 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "GPS L1 C/A tracking, 32 channels/GPU, E/P/L (3 taps), fs=25 MHz, 1 ms integration, "
                                f"{args.stream_seconds:g} s synthetic ci8 IQ stream, 1 step = 1 s of stream",
-                   "channels_per_gpu": N_CH, "fs_hz": FS, "taps": len(SPACING), "iq_format": "ci8",
+                   "channels_per_gpu": N_CH, "channels_total": n_total, "fs_hz": FS, "taps": len(SPACING), "iq_format": "ci8",
                    "mode": "open-loop batched (true NCO trajectory, 32000 channel-epochs per launch)",
-                   "sharding": f"channels x{world}, IQ replicated, no collective"},
-        "x_realtime": value * 1e6 / FS / world,
+                   "sharding": f"one stream of {n_total} satellites replicated on {world} GPU(s) (same seed), channels "
+                               f"sharded {N_CH} per GPU, one HIP stream per channel batch, no collective"},
+        "x_realtime": stream_samples / elapsed / FS,          # seconds of THE stream (all channels tracked) per second
+        "channel_Msamples_per_s": job_ch_samples / elapsed / 1e6,
     }
     result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "epl_kernel",
@@ -373,17 +476,26 @@ def main():
                           "algorithmic_bytes_per_launch": algo_bytes_per_launch,
                           # the same launch against the OTHER roof (6 + 4*taps flops per channel-sample;
                           # fp64 vector peak 78.6 TFLOP/s): the kernel is VALU-issue-bound, not HBM-bound
-                          "fp64_vector": {"achieved_tflops": (6 + 4 * len(SPACING)) * ch_samples / max(1, args.steps) / avg_kernel_s / 1e12 if launches else 0.0,
-                                          "peak_tflops": 78.6,
-                                          "frac": (6 + 4 * len(SPACING)) * ch_samples / max(1, args.steps) / avg_kernel_s / 78.6e12 if launches else 0.0}}
+                          "fp64_vector": {"achieved_tflops": flops / avg_kernel_s / 1e12 if launches else 0.0,
+                                          "peak_tflops": 78.6, "frac": flops / avg_kernel_s / 78.6e12 if launches else 0.0}}
     pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            result["roofline"]["traffic"] = json.load(open(pmc)).get("epl_kernel_hbm_bytes_per_launch")
+            info = json.load(open(pmc))
+            result["roofline"]["traffic"] = info.get("epl_kernel_hbm_bytes_per_launch")
+            if info.get("epl_kernel_valu_insts_per_launch"):
+                # VALU issue roof from the SQ counter pass (tools/summarize_pmc.py): wave-instructions x 4 cycles
+                # over 1024 SIMDs at 2.4 GHz against THIS run's launch duration
+                insts = float(info["epl_kernel_valu_insts_per_launch"])
+                result["roofline"]["valu_issue"] = {"insts_per_launch": insts,
+                                                    "busy_frac": insts * 4.0 / 1024.0 / 2.4e9 / avg_kernel_s if launches else None,
+                                                    "source": info.get("source")}
         except Exception:
             pass
 
     if rank == 0 and world == 1:
+        result["roofline"]["measured_copy_peak"] = {"GBps": eng.hbm_copy_rate(1 << 30, 10), "kernel": "hbm_copy_kernel (16 B/lane, read+write)"}
+        result["roofline"]["frac_of_measured_copy_peak"] = achieved / result["roofline"]["measured_copy_peak"]["GBps"]
         got = plan.fetch()
         ref, done, dt, rf = cpu_tracking_baseline(eng, items, min(len(items), N_CH * 1000), args.cpu_seconds)
         scale = np.repeat(np.maximum(np.hypot(ref[:, 0::2], ref[:, 1::2]), 1.0), 2, axis=1)
@@ -395,42 +507,83 @@ def main():
                                   "sample": f"first {done} channel-epochs ({done // N_CH} ms x 32 ch) of the same "
                                             f"stream through oracle/sydr_oracle.py:epl (NumPy), {dt:.1f} s",
                                   "max_rel_err_gpu_vs_oracle": err}
+        if args.cpu_mp_seconds > 0:
+            hi_ms = min(n_epochs, 700)
+            raw = eng.iq_download(int((items["start_sample"][:hi_ms * N_CH] + items["n_samples"][:hi_ms * N_CH]).max()), 0)
+            mval, procs, mdt, mep = cpu_baseline_all_cores(raw, items, [s["prn"] for s in sats], hi_ms, args.cpu_mp_seconds)
+            result["cpu_baseline_mp"] = {"value": mval, "unit": "Msamples/s", "cores": procs, "host_cpus": os.cpu_count(),
+                                         "kind": "port",
+                                         "sample": f"{mep} ms x 32 ch of the same stream, one oracle process per channel "
+                                                   f"(the reference's process-per-channel design) over a pool of {procs} "
+                                                   f"spawned workers, {mdt:.1f} s wall"}
+            del raw
         if not args.no_acquisition:
-            from oracle import sydr_oracle as orc
-            slots = np.arange(N_CH)
-            eng.pcps(slots, 0, FS, 0.0, 5000.0, 250.0, 1, 1)  # warm (allocations, twiddles)
-            reps = 5
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                pb, pc, pr, _ = eng.pcps(slots, 0, FS, 0.0, 5000.0, 250.0, 1, 1)
-            acq_ms = (time.perf_counter() - t0) / reps * 1e3
-            n_code = 25000
-            t0 = time.perf_counter()
-            n_cpu = 3
-            ok = True
-            for k in range(n_cpu):
-                cmap = orc.pcps_map(rf[:n_code].reshape(1, -1), 0.0, FS, orc.code_spectrum(orc.gold_code(k + 1), FS),
-                                    5000.0, 250.0, n_code)
-                peak, ratio = orc.two_peak_compare(cmap, n_code, 24)
-                ok &= peak == [int(pb[k]), int(pc[k])]
-            cpu_ms = (time.perf_counter() - t0) / n_cpu * 1e3
-            if not ok:
-                raise SystemExit("PCPS peak mismatch vs oracle in bench")
-            bins = 41
-            result["acquisition"] = {"metric": "acquisition ms/PRN", "value": acq_ms / N_CH, "unit": "ms/PRN",
-                                     "config": "PCPS, 32 PRNs, fs=25 MHz, +-5 kHz @250 Hz (41 bins), 1 ms coherent",
-                                     "ms_total_32_prn": acq_ms, "cpu_ms_per_prn_1core": cpu_ms,
-                                     "algorithmic_GBps": N_CH * bins * 40.0 * n_code / (acq_ms * 1e-3) / 1e9,
-                                     "peaks_match_oracle": bool(ok)}
+            result["acquisition"] = acquisition_leg(eng, rf)
     if rank == 0 and world == 1 and not args.no_closed_loop:
         result["closed_loop"] = closed_loop_leg(eng, items, min(n_epochs, args.closed_loop_epochs))
         result["closed_loop_dense"] = closed_loop_leg(eng, items, min(n_epochs, args.closed_loop_epochs, 1000), n_ch=768)
     plan.close()
+    if rank == 0 and world == 1 and not args.no_per_tick:
+        result["per_tick"] = per_tick_leg(eng)
     eng.close()
+    if rank == 0 and world == 1 and not args.no_multignss:
+        margs = argparse.Namespace(**vars(args))
+        margs.stream_seconds, margs.steps, margs.warmup = 10.0, 9, 1
+        m = multignss_workload(margs, rank, local_rank, world, torch, dist, emit=False)
+        result["multignss"] = {k: m[k] for k in ("metric", "value", "unit", "ms_per_step", "x_realtime", "config", "roofline",
+                                                  "cpu_baseline") if k in m}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def acquisition_leg(eng, rf):
+    """BASELINE configs[1]: PCPS, all 32 PRNs, +-5 kHz @ 250 Hz, 1 ms coherent, indices + ratio only."""
+    from oracle import sydr_oracle as orc
+    slots = np.arange(N_CH)
+    eng.pcps(slots, 0, FS, 0.0, 5000.0, 250.0, 1, 1)  # warm (allocations, twiddles)
+    reps = 5
+    eng.prof_reset()
+    eng.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pb, pc, pr, _ = eng.pcps(slots, 0, FS, 0.0, 5000.0, 250.0, 1, 1)
+    acq_ms = (time.perf_counter() - t0) / reps * 1e3
+    eng.prof_enable(False)
+    kern_ms, _ = eng.prof_read("pcps")
+    kern_ms /= reps
+    eng.prof_reset()
+    n_code = 25000
+    t0 = time.perf_counter()
+    n_cpu = 3
+    ok = True
+    for k in range(n_cpu):
+        cmap = orc.pcps_map(rf[:n_code].reshape(1, -1), 0.0, FS, orc.code_spectrum(orc.gold_code(k + 1), FS),
+                            5000.0, 250.0, n_code)
+        peak, ratio = orc.two_peak_compare(cmap, n_code, 24)
+        ok &= peak == [int(pb[k]), int(pc[k])]
+    cpu_ms = (time.perf_counter() - t0) / n_cpu * 1e3
+    if not ok:
+        raise SystemExit("PCPS peak mismatch vs oracle in bench")
+    bins = 41
+    # map not requested: SURVEY 8d charges 32*N bytes per (PRN, bin) -- 16 spectrum + 16 code spectrum
+    algo = N_CH * bins * 32.0 * n_code
+    out = {"metric": "acquisition ms/PRN", "value": acq_ms / N_CH, "unit": "ms/PRN",
+           "config": "PCPS, 32 PRNs, fs=25 MHz, +-5 kHz @250 Hz (41 bins), 1 ms coherent, indices + ratio (no map)",
+           "ms_total_32_prn": acq_ms, "kernel_ms_32_prn": kern_ms, "cpu_ms_per_prn_1core": cpu_ms,
+           "peaks_match_oracle": bool(ok),
+           "roofline": {"bound": "hbm", "achieved": algo / (kern_ms * 1e-3) / 1e9 if kern_ms else 0.0, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms else 0.0,
+                        "traffic": None, "kernel": "pcps_* (all kernels of one sdr_pcps call)",
+                        "algorithmic_bytes_per_call": algo}}
+    pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            out["roofline"]["traffic"] = json.load(open(pmc)).get("pcps_hbm_bytes_per_call")
+        except Exception:
+            pass
+    return out
 
 
 if __name__ == "__main__":

@@ -77,6 +77,11 @@ int sdr_prof_enable(sdr_engine* e, int enable);
 int sdr_prof_read(sdr_engine* e, const char* prefix, double* total_ms, int64_t* launches);
 int sdr_prof_reset(sdr_engine* e);
 
+/* Measured HBM copy rate of THIS GPU: a hand-written 16-byte-per-lane grid-stride copy kernel moves n_bytes
+ * from one buffer to another `reps` times; *gbps = (bytes read + bytes written) / time.  The second denominator
+ * beside the 8 TB/s datasheet peak; no counterpart in the reference. */
+int sdr_hbm_copy_rate(sdr_engine* e, int64_t n_bytes, int reps, double* gbps);
+
 /* ---------------------------------------------------------------- IQ ring
  * Replaces the host shm ring (sydr/channel/channelManager.py:57-61,
  * sydr/utils/circularbuffer.py:21-137): capacity_samples slots in HBM,

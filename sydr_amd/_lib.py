@@ -104,6 +104,7 @@ _PROTOTYPES = {
     "sdr_prof_enable": (C.c_int, [_VP, C.c_int]),
     "sdr_prof_read": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "sdr_prof_reset": (C.c_int, [_VP]),
+    "sdr_hbm_copy_rate": (C.c_int, [_VP, C.c_int64, C.c_int, C.POINTER(C.c_double)]),
     "sdr_iq_alloc": (C.c_int, [_VP, C.c_int64, C.c_int]),
     "sdr_iq_upload": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64]),
     "sdr_iq_download": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64]),

@@ -101,7 +101,53 @@ ProfScope::~ProfScope() {
     e->prof_records.push_back(rec);
 }
 
+// Stream copy: 16 bytes per lane, four loads in flight per lane, grid-stride.
+__global__ __launch_bounds__(256) void hbm_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a;
+        dst[i + stride] = b;
+        dst[i + 2 * stride] = c;
+        dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
 extern "C" {
+
+int sdr_hbm_copy_rate(sdr_engine* e, int64_t n_bytes, int reps, double* gbps) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!gbps || n_bytes < (1 << 20) || reps < 1) return sdr_fail(SDR_ERR_INVALID, "bad copy-rate request");
+    const size_t n16 = (size_t)n_bytes / 16;
+    void *a = nullptr, *b = nullptr;
+    hipError_t err = hipMalloc(&a, n16 * 16);
+    if (err == hipSuccess) err = hipMalloc(&b, n16 * 16);
+    if (err != hipSuccess) {
+        if (a) (void)hipFree(a);
+        return sdr_fail(SDR_ERR_NOMEM, "hipMalloc for the copy test failed: %s", hipGetErrorString(err));
+    }
+    hipEvent_t t0, t1;
+    SDR_HIP(hipEventCreate(&t0));
+    SDR_HIP(hipEventCreate(&t1));
+    SDR_HIP(hipMemsetAsync(a, 1, n16 * 16, e->stream));
+    const int blocks = e->n_cus * 8;
+    hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)a, (uint4*)b, n16);  // warm
+    SDR_HIP(hipEventRecord(t0, e->stream));
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)a, (uint4*)b, n16);
+    SDR_HIP(hipEventRecord(t1, e->stream));
+    SDR_HIP(hipStreamSynchronize(e->stream));
+    float ms = 0.f;
+    SDR_HIP(hipEventElapsedTime(&ms, t0, t1));
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    *gbps = 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9;
+    return SDR_OK;
+}
 
 const char* sdr_last_error(void) { return g_last_error.c_str(); }
 

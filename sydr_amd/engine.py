@@ -163,6 +163,12 @@ class Engine:
         check(self._lib.sdr_prof_read(self._h, prefix.encode(), C.byref(tot), C.byref(cnt)))
         return tot.value, cnt.value
 
+    def hbm_copy_rate(self, n_bytes: int = 1 << 30, reps: int = 10) -> float:
+        """Measured GB/s (read + written) of a hand-written stream-copy kernel on this GPU."""
+        g = C.c_double(0)
+        check(self._lib.sdr_hbm_copy_rate(self._h, int(n_bytes), int(reps), C.byref(g)))
+        return g.value
+
     # ------------------------------------------------------------------ IQ ring
     def iq_alloc(self, capacity_samples: int, fmt: int = FMT_CI8):
         check(self._lib.sdr_iq_alloc(self._h, int(capacity_samples), int(fmt)))

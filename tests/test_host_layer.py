@@ -251,20 +251,45 @@ def test_shard_channels_partitions_exactly():
 
 
 def test_two_rank_gloo_sharding_and_gather(tmp_path):
-    """world_size-2 CPU run of the multi-GPU plumbing: each rank owns its shard of the channels,
-    results are gathered without any data-path collective, timing uses max-over-ranks."""
+    """world_size-2 CPU run of the multi-GPU partition (north_star: same stream on every rank, channels sharded, no
+    data-path collective): each rank drives a ChannelManager over ITS shard of the channels on an oracle-backed
+    engine, the tracking packets are gathered, and rank 0 checks them -- bitwise -- against one manager that ran
+    all channels.  Timing uses max-over-ranks, as bench.py does."""
     script = tmp_path / "worker.py"
     script.write_text(textwrap.dedent(f"""
         import os, sys, json
         sys.path.insert(0, {REPO!r}); sys.path.insert(0, {os.path.join(REPO, 'tests')!r})
         import numpy as np, torch, torch.distributed as dist
-        from sydr_amd.channel.manager import shard_channels
+        from oracle import sydr_oracle as orc
+        from fake_engine import OracleEngine
+        from test_host_layer import KAPLAN_INI, channel_config, drive, rf_signal
+        from sydr_amd.channel.l1ca_kaplan import ChannelL1CA_Kaplan
+        from sydr_amd.channel.manager import ChannelManager, shard_channels
+        from sydr_amd.utils.enumerations import ChannelMessage
         dist.init_process_group("gloo")
         rank, world = dist.get_rank(), dist.get_world_size()
-        prns = list(range(1, 33))
+        fs, spms, ms = 4e6, 4000, 24
+        sats = [dict(prn=p, doppler=d, code_phase=c, phase=0.1, amp=7.0) for p, d, c in
+                ((7, 1750.0, 300.25), (12, -3000.0, 17.5), (30, 4250.0, 900.0), (3, -500.0, 512.0))]
+        raw = orc.synth_iq(fs, ms * spms, sats, 18.0, 4242)          # the SAME stream on every rank (same seed)
+
+        def run(prns):
+            mgr = ChannelManager(rf_signal(fs), engine=OracleEngine())
+            mgr.addChannel(ChannelL1CA_Kaplan, channel_config(KAPLAN_INI), len(prns))
+            for p in prns:
+                mgr.requestTracking(p)
+            out = {{}}
+            for tick in drive(mgr, raw, spms, ms):
+                for p in tick:
+                    if p["type"] is ChannelMessage.TRACKING_UPDATE:
+                        prn = mgr.getChannel(p["cid"]).satelliteID
+                        out.setdefault(prn, []).append([p["i_early"], p["q_early"], p["i_prompt"], p["q_prompt"],
+                                                        p["i_late"], p["q_late"], p["carrier_frequency"], p["code_frequency"]])
+            return out
+
+        prns = [s["prn"] for s in sats]
         mine = [prns[i] for i in shard_channels(len(prns), rank, world)]
-        # stand-in for the per-rank correlator outputs: a deterministic function of the PRN only
-        local = {{p: [float(p) * 1.5, float(p) ** 2] for p in mine}}
+        local = run(mine)
         gathered = [None] * world
         dist.all_gather_object(gathered, local)
         t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
@@ -272,19 +297,22 @@ def test_two_rank_gloo_sharding_and_gather(tmp_path):
         if rank == 0:
             merged = {{}}
             for g in gathered: merged.update(g)
-            print(json.dumps(dict(n=len(merged), ok=all(merged[p] == [p * 1.5, float(p) ** 2] for p in prns),
-                                  sizes=[len(g) for g in gathered], tmax=float(t))))
+            whole = run(prns)
+            same = all(np.array(merged[p]).tobytes() == np.array(whole[p]).tobytes() for p in prns)
+            print(json.dumps(dict(n=len(merged), same=bool(same), sizes=[len(g) for g in gathered],
+                                  epochs=[len(whole[p]) for p in prns], tmax=float(t))))
         dist.destroy_process_group()
     """))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
-                         capture_output=True, text=True, env=env, timeout=300)
+                         capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     import json
     res = json.loads(line)
-    assert res == dict(n=32, ok=True, sizes=[16, 16], tmax=pytest.approx(0.2))
+    assert res["n"] == 4 and res["same"] is True and res["sizes"] == [2, 2] and res["tmax"] == pytest.approx(0.2)
+    assert min(res["epochs"]) >= 20
 
 
 def test_serial_search_plugin_reproduces_reference():

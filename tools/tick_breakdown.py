@@ -1,0 +1,51 @@
+import sys, os, time, configparser
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/tools")
+import numpy as np
+import bench
+from test_host_layer import KAPLAN_INI
+from sydr_amd.engine import Engine, FMT_CI8
+from sydr_amd import engine as engmod
+from sydr_amd.channel.l1ca_kaplan import ChannelL1CA_Kaplan
+from sydr_amd.channel.manager import ChannelManager
+from sydr_amd.signal.iqsource import RFSignal
+FS = bench.FS
+n_ms, n_ch = 400, 32
+eng = Engine(0)
+total = int(n_ms * 1e-3 * FS) // 8 * 8
+eng.iq_alloc(total, FMT_CI8); eng.code_slots(32)
+sats = bench.satellites(0)[:n_ch]
+eng.iq_synth(sats, FS, 12.0, 20260003, 0, total)
+raw = eng.iq_download(total, 0)
+rf = RFSignal(dict(filepath="none", sampling_frequency=FS, is_complex="true", intermediate_frequency=0.0, data_size=8))
+cfg = configparser.ConfigParser(); cfg.read_string(KAPLAN_INI)
+mgr = ChannelManager(rf, engine=eng, keepCorrelationMap=False)
+mgr.addChannel(ChannelL1CA_Kaplan, cfg, n_ch)
+for s in sats: mgr.requestTracking(s["prn"])
+spms = int(FS * 1e-3)
+lib = eng._lib
+orig = lib.sdr_bank_tick
+acc = []
+def timed(*a):
+    t0 = time.perf_counter(); r = orig(*a); acc.append(time.perf_counter() - t0); return r
+class L: pass
+# monkeypatch through Bank object's lib handle
+bank_dev = None
+tt = []
+for k in range(n_ms):
+    if k == 50:
+        bank_dev = mgr.bank.device
+        class Wrap:
+            def __getattr__(self, n): return timed if n == "sdr_bank_tick" else getattr(lib, n)
+        bank_dev._lib = Wrap()
+    t0 = time.perf_counter()
+    mgr.addNewRFData(raw[2 * k * spms:2 * (k + 1) * spms])
+    t1 = time.perf_counter()
+    pk = mgr.run()
+    t2 = time.perf_counter()
+    tt.append((t1 - t0, t2 - t1))
+tt = np.array(tt[100:]); acc_a = np.array(acc[50:])
+print("addNewRFData us", np.median(tt[:,0])*1e6, "run us", np.median(tt[:,1])*1e6, "sdr_bank_tick us", np.median(acc_a)*1e6)
+# kernel-only: prof
+eng.prof_enable(True); eng.prof_reset()
+rec, st, done, _ = mgr.bank.device.step(np.arange(32, dtype=np.int32), 1)
+print("step done", done[:4], "kernel ms", eng.prof_read("track_kernel"))
