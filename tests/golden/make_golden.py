@@ -239,11 +239,10 @@ def _channel_config(path, overrides):
 
 
 def make_trajectories(fname="g6_trajectories.npz", ms=510, amp=8.0, sigma=20.0, seed=20260001,
-                      plugins=("borre", "kaplan"), track_over=None):
+                      plugins=("borre", "kaplan"), track_over=None, fs=4e6):
     from sydr.channel.channel_l1ca_borre import ChannelL1CA as RefBorre
     from sydr.channel.channel_l1ca_kaplan import ChannelL1CA_Kaplan as RefKaplan
 
-    fs = 4e6
     spms = int(fs * 1e-3)
     sats = [dict(prn=7, doppler=1750.0, code_phase=300.25, phase=0.1, amp=amp)]
     raw = orc.synth_iq(fs, ms * spms, sats, sigma, seed)
@@ -390,5 +389,8 @@ if __name__ == "__main__":
         make_trajectories("g6b_kaplan_strong.npz", ms=1200, amp=30.0, sigma=10.0, seed=20260611, plugins=("kaplan",),
                           track_over=dict(fll_threshold_wide=0.3, fll_threshold_narrow=0.7, pll_threshold_narrow=0.7,
                                           dll_threshold=3.0, correlator_epl_narrow=0.25))
+        # the headline sampling rate (BASELINE configs 2-3): both plugins at 25 MHz, PCPS + ~300 epochs.  The IQ
+        # (15 MB) is not stored: seed + sha256, regenerated by the tests
+        make_trajectories("g6c_25mhz.npz", ms=310, amp=8.0, sigma=20.0, seed=20260625, fs=25e6)
     if "loop" in which:
         make_loopmath()

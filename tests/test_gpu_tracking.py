@@ -62,7 +62,9 @@ def close(a, b, scale=None):
 
 
 CASES = {"borre": ("g6_trajectories.npz", 0), "kaplan": ("g6_trajectories.npz", 1),
-         "kaplan_strong": ("g6b_kaplan_strong.npz", 1)}
+         "kaplan_strong": ("g6b_kaplan_strong.npz", 1),
+         # the headline sampling rate: the reference's own plugins at 25 MHz (boundary variant of the correlator)
+         "borre_25mhz": ("g6c_25mhz.npz", 0), "kaplan_25mhz": ("g6c_25mhz.npz", 1)}
 
 
 @pytest.mark.parametrize("parts", [0, 1, 2, 4, 8])
@@ -357,23 +359,26 @@ def test_closed_loop_with_one_configuration_per_channel(engine):
 
 
 # ------------------------------------------------------------------------------------------------ host plugins on the GPU
+@pytest.mark.parametrize("fname", ["g6_trajectories.npz", "g6c_25mhz.npz"])
 @pytest.mark.parametrize("plugin", ["borre", "kaplan"])
-def test_manager_on_gpu_matches_reference_trajectory(engine, plugin):
+def test_manager_on_gpu_matches_reference_trajectory(engine, plugin, fname):
+    """The drop-in ChannelManager, one tick per millisecond (acquisition, then one device step per tick from the
+    channel bank), against the reference plugins' own packets -- at 4 MHz and at the headline 25 MHz."""
     from sydr_amd.channel.l1ca_borre import ChannelL1CA
     from sydr_amd.channel.l1ca_kaplan import ChannelL1CA_Kaplan
     from sydr_amd.channel.manager import ChannelManager
     from sydr_amd.utils.enumerations import ChannelMessage
-    g, fs, raw = trajectory_iq()
+    g, fs, raw = trajectory_iq(fname)
     mgr = ChannelManager(rf_signal(fs), engine=engine)
     cls, ini = (ChannelL1CA, BORRE_INI) if plugin == "borre" else (ChannelL1CA_Kaplan, KAPLAN_INI)
     mgr.addChannel(cls, channel_config(ini), 1)
     mgr.requestTracking(7)
-    ticks = drive(mgr, raw, int(fs * 1e-3), 510)
+    ticks = drive(mgr, raw, int(fs * 1e-3), raw.size // 2 // int(fs * 1e-3))
     acq = [p for t in ticks for p in t if p["type"] is ChannelMessage.ACQUISITION_UPDATE][0]
     trk = [p for t in ticks for p in t if p["type"] is ChannelMessage.TRACKING_UPDATE]
     ref_acq, ref = g[f"{plugin}_acq"], g[f"{plugin}_epochs"]
     assert (acq["frequency_idx"], acq["code_idx"], acq["codeOffset"]) == (int(ref_acq[0]), int(ref_acq[1]), int(ref_acq[4]))
-    assert acq["peak_ratio"] == pytest.approx(ref_acq[2], rel=RTOL) and acq["correlation_map"].shape == (41, 4000)
+    assert acq["peak_ratio"] == pytest.approx(ref_acq[2], rel=RTOL) and acq["correlation_map"].shape == (41, int(fs * 1e-3))
     assert len(trk) == len(ref)
     got = np.array([[p["i_early"], p["q_early"], p["i_prompt"], p["q_prompt"], p["i_late"], p["q_late"],
                      p["carrier_frequency"], p["code_frequency"]] for p in trk])
@@ -449,7 +454,7 @@ def test_file_driven_example_with_the_reference_ini_layout(engine, tmp_path, cap
     then closed-loop blocks -- every requested PRN ends up tracking on its Doppler."""
     import importlib.util
     import os
-    fs, ms = 10e6, 700
+    fs, ms = 10e6, 2700      # well past the 100 ms ring's capacity times twenty: the block mode must not build a backlog
     n = int(fs * 1e-3) * ms
     sats = [dict(prn=4, doppler=2100.0, code_phase=200.5, phase=0.1, amp=9.0),
             dict(prn=9, doppler=-3300.0, code_phase=777.0, phase=0.5, amp=9.0)]
@@ -462,7 +467,7 @@ def test_file_driven_example_with_the_reference_ini_layout(engine, tmp_path, cap
 [DEFAULT]
 name = test
 nb_channels = 2
-ms_to_process = 600
+ms_to_process = 2600
 [RFSIGNAL]
 filepath = {tmp_path / 'iq.bin'}
 sampling_frequency = {fs}
@@ -484,4 +489,4 @@ gps_l1ca = ./channel.ini
     assert set(carriers) == {4, 9}, out
     assert abs(carriers[4] - 2100.0) < 30.0 and abs(carriers[9] + 3300.0) < 30.0, out
     rows = np.loadtxt(tmp_path / "out.csv", delimiter=",", skiprows=1)
-    assert rows.shape[0] > 2 * 400                  # both channels, most of the 600 ms
+    assert rows.shape[0] > 2 * 2400                 # both channels, nearly all of the 2600 ms
