@@ -77,6 +77,11 @@ int sdr_prof_enable(sdr_engine* e, int enable);
 int sdr_prof_read(sdr_engine* e, const char* prefix, double* total_ms, int64_t* launches);
 int sdr_prof_reset(sdr_engine* e);
 
+/* Diagnostic switches (tests, A/B timing): "pcps_materialise_map" = 1 writes the whole correlation map even when the
+ * caller asks for indices and ratio only; "pcps_radix_passes" = 1 runs one kernel per radix pass instead of the
+ * four-step transform.  Results do not depend on either. */
+int sdr_set_option(sdr_engine* e, const char* name, int value);
+
 /* Measured HBM copy rate of THIS GPU: a hand-written 16-byte-per-lane grid-stride copy kernel moves n_bytes
  * from one buffer to another `reps` times; *gbps = (bytes read + bytes written) / time.  The second denominator
  * beside the 8 TB/s datasheet peak; no counterpart in the reference. */

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsydr_amd.so")
+LIB_PATH = os.environ.get("SYDR_AMD_LIB") or os.path.join(_HERE, "libsydr_amd.so")  # (override: A/B builds of tools/ab_compare.sh)
 
 SDR_MAX_TAPS = 8
 FMT_CI8, FMT_CI16, FMT_CF32, FMT_CF64 = 0, 1, 2, 3
@@ -104,6 +104,7 @@ _PROTOTYPES = {
     "sdr_prof_enable": (C.c_int, [_VP, C.c_int]),
     "sdr_prof_read": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "sdr_prof_reset": (C.c_int, [_VP]),
+    "sdr_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int]),
     "sdr_hbm_copy_rate": (C.c_int, [_VP, C.c_int64, C.c_int, C.POINTER(C.c_double)]),
     "sdr_iq_alloc": (C.c_int, [_VP, C.c_int64, C.c_int]),
     "sdr_iq_upload": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64]),

@@ -192,6 +192,7 @@ int sdr_code_slots_ex(sdr_engine* e, int n_slots, int max_chips, int max_periods
     SDR_HIP(hipMemsetAsync(e->codes, 0, (size_t)n_slots * stride, e->stream));
     SDR_HIP(hipMemsetAsync(e->code_len, 0, (size_t)n_slots * sizeof(int32_t), e->stream));
     e->code_len_host.assign(n_slots, 0);
+    e->code_stamp.assign(n_slots, 0);
     e->n_slots = n_slots;
     e->code_stride = stride;
     return SDR_OK;
@@ -226,6 +227,7 @@ int sdr_code_gps_l1ca(sdr_engine* e, int slot, int prn) {
     SDR_HIP(hipGetLastError());
     SDR_HIP(hipStreamSynchronize(e->stream));
     e->code_len_host[slot] = len;
+    e->code_stamp[slot] = ++e->code_stamp_counter;   // (cached code spectra of this slot are stale now)
     return SDR_OK;
 }
 
@@ -248,6 +250,7 @@ int sdr_code_custom(sdr_engine* e, int slot, const int8_t* chips, int n_chips) {
     SDR_HIP(hipGetLastError());
     SDR_HIP(hipStreamSynchronize(e->stream));
     e->code_len_host[slot] = len;
+    e->code_stamp[slot] = ++e->code_stamp_counter;   // (cached code spectra of this slot are stale now)
     return SDR_OK;
 }
 

@@ -117,6 +117,15 @@ __global__ __launch_bounds__(256) void hbm_copy_kernel(const uint4* __restrict__
 
 extern "C" {
 
+int sdr_set_option(sdr_engine* e, const char* name, int value) {
+    if (!e || !name) return sdr_fail(SDR_ERR_INVALID, "NULL engine or option name");
+    if (!strcmp(name, "pcps_materialise_map")) e->pcps_force_map = value != 0;
+    else if (!strcmp(name, "pcps_radix_passes")) e->pcps_force_passes = value != 0;
+    else if (!strcmp(name, "pcps_prn_chunk")) e->pcps_prn_chunk = value;
+    else return sdr_fail(SDR_ERR_INVALID, "unknown option '%s'", name);
+    return SDR_OK;
+}
+
 int sdr_hbm_copy_rate(sdr_engine* e, int64_t n_bytes, int reps, double* gbps) {
     if (int rc = sdr_set_device(e)) return rc;
     if (!gbps || n_bytes < (1 << 20) || reps < 1) return sdr_fail(SDR_ERR_INVALID, "bad copy-rate request");

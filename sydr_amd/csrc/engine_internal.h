@@ -65,6 +65,9 @@ struct sdr_engine {
     int8_t* codes = nullptr;  // [n_slots][code_stride] raw chips (+-1), no padding
     int32_t* code_len = nullptr;  // device [n_slots]
     std::vector<int32_t> code_len_host;
+    std::vector<int64_t> code_stamp;      // per slot: value of code_stamp_counter when the slot was last staged
+    int64_t code_stamp_counter = 0;
+    std::vector<int64_t> pcps_spec_key;   // what pcps_code currently holds: [N, fs bits, (slot, stamp) ...]
     int n_slots = 0;
     int code_stride = 0;
     // per slot: the replica as the kernels want it in LDS -- uint32 high words of +-1.0 with the periodic
@@ -82,6 +85,8 @@ struct sdr_engine {
     // chirp-z (Bluestein) plan for code lengths the mixed-radix planner cannot factor: [chirp N][B_fwd M][B_inv M][tw M]
     DevBuf pcps_blu, pcps_blu_x, pcps_blu_a, pcps_blu_b;
     int64_t pcps_blu_n = 0;
+    int pcps_prn_chunk = 0;          // diagnostics: PRNs per inverse sweep (0 = as many as the work buffers hold)
+    bool pcps_force_map = false;     // diagnostics / tests: materialise the map even when the caller does not ask for it
     bool pcps_force_passes = false;  // diagnostics: use the one-kernel-per-radix-pass transform instead of the four-step one
 
     // profiling

@@ -17,6 +17,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -25,8 +26,15 @@ namespace {
 
 constexpr int kThreads = 256;
 
-enum LoadMode { LOAD_PLAIN = 0, LOAD_IQ_MIX = 1, LOAD_MUL_CODE = 2, LOAD_CODE_REAL = 3 };
-enum StoreMode { STORE_PLAIN = 0, STORE_CONJ = 1, STORE_MAG_ACC = 2, STORE_CPLX_ACC = 3 };
+enum LoadMode { LOAD_PLAIN = 0, LOAD_IQ_MIX = 1, LOAD_MUL_CODE = 2, LOAD_CODE_REAL = 3, LOAD_MUL_CODE_SEL = 4 };
+// STORE_MAG_MAX: nothing is stored -- the last stage keeps a running (maximum, first index) of |.|/N per wave and
+// writes one 16-byte record per wave (the map-free search: the caller only wants indices and ratio).
+enum StoreMode { STORE_PLAIN = 0, STORE_CONJ = 1, STORE_MAG_ACC = 2, STORE_CPLX_ACC = 3, STORE_MAG_MAX = 4 };
+
+struct Best {
+    double v;
+    long long i;
+};
 
 struct PassArgs {
     const double2* in;    // [batch][N]
@@ -50,6 +58,13 @@ struct PassArgs {
     double2* csum;      // [batch][N]
     double scale;
     int first_block;    // 1: overwrite, 0: accumulate
+    // LOAD_MUL_CODE_SEL: transform p takes Doppler row sel_bin[p] (the winning row of PRN p)
+    const long long* sel_bin;
+    // STORE_MAG_MAX: per-wave records, [batch][tiles][waves]
+    Best* partials;
+    // STORE_MAG_MAX behind LOAD_MUL_CODE_SEL (second peak of the winning row): the first peaks and samples per chip
+    const Best* tops;
+    int spc;
 };
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
@@ -184,6 +199,11 @@ __device__ __forceinline__ double2 load_elem(const PassArgs& a, int batch, int i
         double2 f = a.in[(size_t)bin * a.N + idx];
         double2 c = a.code_spec[(size_t)prn * a.N + idx];
         return cmul(f, c);
+    } else if (LOAD == LOAD_MUL_CODE_SEL) {
+        const int bin = (int)a.sel_bin[batch];
+        double2 f = a.in[(size_t)bin * a.N + idx];
+        double2 c = a.code_spec[(size_t)batch * a.N + idx];
+        return cmul(f, c);
     } else {
         return make_double2((double)a.code_samples[(size_t)batch * a.N + idx], 0.0);
     }
@@ -199,6 +219,8 @@ __device__ __forceinline__ void store_elem(const PassArgs& a, int batch, int idx
     } else if (STORE == STORE_MAG_ACC) {
         double mag = hypot(v.x * a.scale, v.y * a.scale);
         a.map[o] = a.first_block ? 0.0 + mag : a.map[o] + mag;
+    } else if (STORE == STORE_MAG_MAX) {
+        // (only the four-step row kernel implements the running maximum; the launcher never selects it elsewhere)
     } else {
         double2 s = make_double2(v.x * a.scale, v.y * a.scale);
         a.csum[o] = a.first_block ? s : cadd(a.csum[o], s);
@@ -291,10 +313,6 @@ __global__ __launch_bounds__(kThreads) void mag_acc_kernel(const double2* __rest
 
 /* ------------------------------------------------------- peak search (K6) */
 
-struct Best {
-    double v;
-    long long i;
-};
 __device__ __forceinline__ Best better(Best a, Best b) {
     // larger value wins; on ties the smaller flat index (first occurrence, np.argmax)
     if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
@@ -378,6 +396,41 @@ __global__ __launch_bounds__(kThreads) void peak_finish_kernel(const double* __r
     }
 }
 
+// Map-free search, step 2: the first maximum of PRN p's (never materialised) map from the per-wave records of the
+// inverse row kernel.  Writes the winning (bin, code) and keeps the record for the ratio.
+__global__ __launch_bounds__(kThreads) void argmax_records_kernel(const Best* __restrict__ recs, int per_prn, int N,
+                                                                  Best* __restrict__ tops,
+                                                                  long long* __restrict__ out_bin,
+                                                                  long long* __restrict__ out_code) {
+    __shared__ Best sh[kThreads / 64];
+    const int prn = blockIdx.x;
+    Best mine = {-1.0, 0x7fffffffffffffffLL};
+    for (int i = threadIdx.x; i < per_prn; i += kThreads) mine = better(mine, recs[(size_t)prn * per_prn + i]);
+    const Best top = block_best(mine, sh);
+    if (threadIdx.x == 0) {
+        tops[prn] = top;
+        out_bin[prn] = top.i / N;
+        out_code[prn] = top.i - (top.i / N) * N;
+    }
+}
+
+// Map-free search, step 4: the second peak of PRN p from the per-wave records of the pass over its winning row
+// (which ran the maximum over the allowed columns only), and the ratio.
+__global__ __launch_bounds__(64) void ratio_kernel(const Best* __restrict__ seconds, int per_prn,
+                                                   const Best* __restrict__ tops, double* __restrict__ out_ratio) {
+    const int prn = blockIdx.x;
+    Best mine = {-1.0, 0x7fffffffffffffffLL};
+    for (int i = threadIdx.x; i < per_prn; i += 64) mine = better(mine, seconds[(size_t)prn * per_prn + i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.v = __shfl_down(mine.v, off, 64);
+        o.i = __shfl_down(mine.i, off, 64);
+        mine = better(mine, o);
+    }
+    if (threadIdx.x == 0) out_ratio[prn] = mine.v >= 0.0 ? tops[prn].v / mine.v : nan("");
+}
+
 /* ------------------------------------------------------------ host driver */
 
 std::vector<int> factor_radices(int64_t N) {
@@ -414,9 +467,14 @@ void launch_pass(sdr_engine* e, const PassArgs& a, int batch) {
  *   B  rows:     X[k1 + N1*k2] = sum_n2 Z[k1][n2] W_N2^(n2 k2)
  * A workgroup owns a tile of T adjacent columns (A) or rows (B) so that every global access is a run
  * of T*16 contiguous bytes; the fused loads (Doppler mix / code spectrum product) sit in A and the
- * fused stores (conj / |.|/N accumulate) in B.  LDS rows are padded to T+1 complex (odd multiple of
- * 16 B: conflict-free 16-byte accesses).
+ * fused stores (conj / |.|/N accumulate / running maximum) in B.
  * ------------------------------------------------------------------------------------------------ */
+// LDS row pitch (in complex values) of a tile of T columns.  No padding for the 4- and 8-column tiles in use: the
+// butterflies walk the tile row by row (consecutive lanes = consecutive columns, then the next row), so an unpadded
+// tile is read and written in contiguous 64- / 128-byte runs; a pad of one complex measured 7 % slower (47 % of the
+// LDS cycles of the row kernel were bank conflicts), two 16 % slower.
+constexpr int lds_pitch(int T) { return (T == 4 || T == 8) ? T : T + 1; }
+
 struct Radices {
     int n;
     int r[10];
@@ -499,7 +557,7 @@ __device__ __forceinline__ void lds_butterfly_generic(const double2* in, double2
 // In-LDS Stockham transform of `T` columns of length Nsub; returns the buffer holding the result.
 template <bool INV, int T>
 __device__ __forceinline__ double2* lds_fft(double2* a, double2* b, int Nsub, const Radices& rad, const double2* wsub) {
-    constexpr int pitch = T + 1;
+    constexpr int pitch = lds_pitch(T);
     int Ns = 1;
     double2* in = a;
     double2* out = b;
@@ -532,7 +590,7 @@ __device__ __forceinline__ double2* lds_fft(double2* a, double2* b, int Nsub, co
 // runtime division, no radix switch, twiddle strides are immediates).
 template <bool INV, int T, int NSUB, int NS, int R0, int... Rs>
 __device__ __forceinline__ double2* lds_fft_static(double2* in, double2* out, const double2* wsub) {
-    constexpr int pitch = T + 1;
+    constexpr int pitch = lds_pitch(T);
     constexpr int nbf = NSUB / R0;
     constexpr int tws = NSUB / (NS * R0);
     for (int bf = threadIdx.x; bf < nbf * T; bf += kThreads) {
@@ -562,22 +620,101 @@ __device__ __forceinline__ double2* lds_fft_auto(double2* a, double2* b, int Nsu
     }
 }
 
+// (value, index) maximum over the 64 lanes of a wave, left in lane 63: larger value, smaller index on ties.  DPP
+// row shifts inside each row of 16 lanes, then row broadcasts -- no LDS traffic.
+__device__ __forceinline__ void wave_best(double& v, int& i) {
+    auto step = [&](auto ctrl, auto rows) {
+        constexpr int C = decltype(ctrl)::value, RM = decltype(rows)::value;
+        const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), C, RM, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), C, RM, 0xf, false);
+        const int oi = __builtin_amdgcn_update_dpp(i, i, C, RM, 0xf, false);
+        const double ov = __hiloint2double(hi, lo);
+        const bool take = ov > v || (ov == v && oi < i);
+        v = take ? ov : v;
+        i = take ? oi : i;
+    };
+    step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});  // row_shr:1
+    step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});  // row_shr:2
+    step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});  // row_shr:4
+    step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});  // row_shr:8  -> lane 15 of each row holds the row's best
+    step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1 and 3
+    step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's best
+}
+
+// The raw operands of one element of the fused first stage, fetched without being combined: the global loads of
+// several elements are issued back to back and waited for once (a loop of load -> use pays one memory round trip per
+// iteration, ~1 us each under load, which is what these kernels' time was made of).
+struct Fetched {
+    double2 p, q;
+};
+template <int LOAD, int FMT, bool INV>
+__device__ __forceinline__ Fetched fetch_elem(const PassArgs& a, int batch, int bin, int prn, int idx) {
+    Fetched f;
+    if constexpr (LOAD == LOAD_MUL_CODE || LOAD == LOAD_MUL_CODE_SEL) {
+        f.p = a.in[(size_t)bin * a.N + idx];
+        f.q = a.code_spec[(size_t)prn * a.N + idx];
+    } else if constexpr (LOAD == LOAD_PLAIN) {
+        f.p = a.in[(size_t)batch * a.N + idx];
+        f.q = make_double2(0.0, 0.0);
+    } else {
+        f.p = load_elem<LOAD, FMT, INV>(a, batch, idx);
+        f.q = make_double2(0.0, 0.0);
+    }
+    return f;
+}
+template <int LOAD>
+__device__ __forceinline__ double2 combine_elem(const Fetched& f) {
+    if constexpr (LOAD == LOAD_MUL_CODE || LOAD == LOAD_MUL_CODE_SEL) return cmul(f.p, f.q);
+    else return f.p;
+}
+
+constexpr int kBatchLoads = 4;  // elements per lane whose loads are in flight together
+
 // Kernel A: T adjacent columns n2 of one transform.  Dynamic LDS: 2 * N1*(T+1) + N1 double2.
 template <bool INV, int LOAD, int FMT, int T>
 __global__ __launch_bounds__(kThreads) void fft4_cols_kernel(const PassArgs a, int N1, int N2, const Radices rad,
                                                              double2* __restrict__ Z) {
     extern __shared__ double2 lds4[];
-    constexpr int pitch = T + 1;
+    constexpr int pitch = lds_pitch(T);
     double2* bufA = lds4;
     double2* bufB = bufA + N1 * pitch;
     double2* wsub = bufB + N1 * pitch;
     const int batch = blockIdx.y;
     const int n2_0 = blockIdx.x * T;
-    for (int m = threadIdx.x; m < N1; m += kThreads) wsub[m] = a.tw[(size_t)m * N2];  // W_N1^m = W_N^(m*N2)
-    for (int e = threadIdx.x; e < N1 * T; e += kThreads) {
-        const int n1 = e / T, c = e - n1 * T;
-        const int n2 = n2_0 + c;
-        bufA[n1 * pitch + c] = n2 < N2 ? load_elem<LOAD, FMT, INV>(a, batch, N2 * n1 + n2) : make_double2(0.0, 0.0);
+    int prn = batch, bin = batch;
+    if constexpr (LOAD == LOAD_MUL_CODE) {
+        prn = batch / a.nbins;
+        bin = batch - prn * a.nbins;
+    } else if constexpr (LOAD == LOAD_MUL_CODE_SEL) {
+        bin = (int)a.sel_bin[batch];
+    }
+    const int total = N1 * T;
+    const uint32_t t_magic = div_magic(T);
+    // W_N1^m = W_N^(m*N2) for the sub-transform (read together with the first elements)
+    for (int base = 0; base < total; base += kBatchLoads * kThreads) {
+        Fetched f[kBatchLoads];
+        int slot[kBatchLoads];
+        double2 wv = make_double2(0.0, 0.0);
+        // (each chunk of kBatchLoads*256 elements also brings 256 entries of the sub-transform's twiddle table:
+        // T >= kBatchLoads chunks' worth cover all N1 of them)
+        static_assert(T >= kBatchLoads, "the twiddle table rides along with the element chunks");
+        const int m = base / kBatchLoads + threadIdx.x;
+        const bool wm = m < N1;
+        if (wm) wv = a.tw[(size_t)m * N2];
+#pragma unroll
+        for (int u = 0; u < kBatchLoads; ++u) {
+            const int e = base + u * kThreads + threadIdx.x;
+            const int n1 = fast_div(e, t_magic), c = e - n1 * T;
+            const int n2 = n2_0 + c;
+            const bool ok = e < total && n2 < N2;
+            slot[u] = e < total ? n1 * pitch + c : -1;
+            f[u].p = f[u].q = make_double2(0.0, 0.0);
+            if (ok) f[u] = fetch_elem<LOAD, FMT, INV>(a, batch, bin, prn, N2 * n1 + n2);
+        }
+        if (wm) wsub[m] = wv;
+#pragma unroll
+        for (int u = 0; u < kBatchLoads; ++u)
+            if (slot[u] >= 0) bufA[slot[u]] = combine_elem<LOAD>(f[u]);
     }
     __syncthreads();
     double2* res = lds_fft_auto<INV, T>(bufA, bufB, N1, rad, wsub);
@@ -586,37 +723,124 @@ __global__ __launch_bounds__(kThreads) void fft4_cols_kernel(const PassArgs a, i
     // instead of one scattered read per element.
     for (int m = threadIdx.x; m < N1; m += kThreads) wsub[m] = a.tw[(size_t)n2_0 * m];  // n2_0*m < N
     __syncthreads();
-    for (int e = threadIdx.x; e < N1 * T; e += kThreads) {
-        const int k1 = e / T, c = e - k1 * T;
-        const int n2 = n2_0 + c;
-        if (n2 < N2) {
-            double2 w = cmul(wsub[k1], a.tw[c * k1]);
-            if (INV) w.y = -w.y;
-            Z[((size_t)batch * N1 + k1) * N2 + n2] = cmul(res[k1 * pitch + c], w);
+    for (int base = 0; base < total; base += kBatchLoads * kThreads) {
+        double2 w2[kBatchLoads];
+        int k1s[kBatchLoads], cs[kBatchLoads];
+#pragma unroll
+        for (int u = 0; u < kBatchLoads; ++u) {
+            const int e = base + u * kThreads + threadIdx.x;
+            const int k1 = fast_div(e, t_magic), c = e - k1 * T;
+            const bool ok = e < total && n2_0 + c < N2;
+            k1s[u] = ok ? k1 : -1;
+            cs[u] = c;
+            w2[u] = make_double2(1.0, 0.0);
+            if (ok) w2[u] = a.tw[c * k1];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatchLoads; ++u) {
+            if (k1s[u] >= 0) {
+                double2 w = cmul(wsub[k1s[u]], w2[u]);
+                if (INV) w.y = -w.y;
+                Z[((size_t)batch * N1 + k1s[u]) * N2 + n2_0 + cs[u]] = cmul(res[k1s[u] * pitch + cs[u]], w);
+            }
         }
     }
 }
 
 // Kernel B: T adjacent rows k1 of one transform.  Dynamic LDS: 2 * N2*(T+1) + N2 double2.
-template <bool INV, int STORE, int T>
+template <bool INV, int STORE, int T, bool LOADSEL = false>
 __global__ __launch_bounds__(kThreads) void fft4_rows_kernel(const PassArgs a, int N1, int N2, const Radices rad,
                                                              const double2* __restrict__ Z) {
     extern __shared__ double2 lds4[];
-    constexpr int pitch = T + 1;
+    constexpr int pitch = lds_pitch(T);
     double2* bufA = lds4;
     double2* bufB = bufA + N2 * pitch;
     double2* wsub = bufB + N2 * pitch;
     const int batch = blockIdx.y;
     const int k1_0 = blockIdx.x * T;
-    for (int m = threadIdx.x; m < N2; m += kThreads) wsub[m] = a.tw[(size_t)m * N1];  // W_N2^m = W_N^(m*N1)
     const uint32_t n2_magic = div_magic(N2);
-    for (int e = threadIdx.x; e < N2 * T; e += kThreads) {
-        const int c = fast_div(e, n2_magic), n2 = e - c * N2;  // n2 fastest: each row of Z is read as one contiguous run
-        const int k1 = k1_0 + c;
-        bufA[n2 * pitch + c] = k1 < N1 ? Z[((size_t)batch * N1 + k1) * N2 + n2] : make_double2(0.0, 0.0);
+    const int total = N2 * T;
+    for (int base = 0; base < total; base += kBatchLoads * kThreads) {
+        double2 z[kBatchLoads];
+        int slot[kBatchLoads];
+        double2 wv = make_double2(0.0, 0.0);
+        static_assert(T >= kBatchLoads, "the twiddle table rides along with the element chunks");
+        const int m = base / kBatchLoads + threadIdx.x;
+        const bool wm = m < N2;
+        if (wm) wv = a.tw[(size_t)m * N1];     // W_N2^m = W_N^(m*N1)
+#pragma unroll
+        for (int u = 0; u < kBatchLoads; ++u) {
+            const int e = base + u * kThreads + threadIdx.x;
+            const int c = fast_div(e, n2_magic), n2 = e - c * N2;  // n2 fastest: each row of Z is read as one contiguous run
+            const int k1 = k1_0 + c;
+            slot[u] = e < total ? n2 * pitch + c : -1;
+            z[u] = make_double2(0.0, 0.0);
+            if (e < total && k1 < N1) z[u] = Z[((size_t)batch * N1 + k1) * N2 + n2];
+        }
+        if (wm) wsub[m] = wv;
+#pragma unroll
+        for (int u = 0; u < kBatchLoads; ++u)
+            if (slot[u] >= 0) bufA[slot[u]] = z[u];
     }
     __syncthreads();
     const double2* res = lds_fft_auto<INV, T>(bufA, bufB, N2, rad, wsub);
+    if constexpr (STORE == STORE_MAG_MAX) {
+        // map[p][b][k] = |v|/N is never written: each lane keeps the largest value it produced (first index on
+        // ties, as np.argmax over the row-major map), the wave reduces with DPP moves and lane 63 writes 16 bytes.
+        // Inside a lane the candidates are ordered by the squared magnitude (3 instructions instead of a ~40
+        // instruction hypot per point); hypot -- the reference's np.abs -- is monotone in it up to its rounding, so
+        // only candidates within 2^-48 (relative) of the lane's best are compared through hypot itself, and the
+        // lane's winner gets its exact hypot once, before lanes are compared.  With SECOND (the pass over the
+        // winning row alone) the same maximum runs over the columns TwoCorrelationPeakComparison allows.
+        const int prn = LOADSEL ? batch : batch / a.nbins;
+        const int bin = LOADSEL ? 0 : batch - prn * a.nbins;
+        int a1 = 0, b0 = 0, b1 = 0;                    // allowed columns [0,a1) U [b0,b1) (acquisition.py:98-111)
+        if constexpr (LOADSEL) {
+            const long long ti = a.tops[batch].i;
+            const int code = (int)(ti - (ti / a.N) * a.N);
+            const int e0 = code - a.spc, e1 = code + a.spc;
+            if (e0 < 1) {
+                b0 = e1;
+                b1 = a.N - 1;
+            } else if (e1 >= a.N) {
+                a1 = e0;
+            } else {
+                a1 = e0;
+                b0 = e1;
+                b1 = a.N - 1;
+            }
+        }
+        double best_sq = -1.0, best_x = 0.0, best_y = 0.0;
+        int best_i = 0x7fffffff;
+        for (int e = threadIdx.x; e < N2 * T; e += kThreads) {
+            const int k2 = e / T, c = e - k2 * T;
+            const int k1 = k1_0 + c;
+            const int col = k1 + N1 * k2;
+            const bool allowed = !LOADSEL || col < a1 || (col >= b0 && col < b1);
+            if (k1 < N1 && allowed) {
+                const double2 v = res[k2 * pitch + c];
+                const double x = v.x * a.scale, y = v.y * a.scale;
+                const double sq = x * x + y * y;
+                const int idx = bin * a.N + col;
+                bool take = sq > best_sq;
+                if (__builtin_expect(fabs(sq - best_sq) <= best_sq * 0x1p-48, 0)) {
+                    const double m_new = hypot(x, y), m_old = hypot(best_x, best_y);
+                    take = m_new > m_old || (m_new == m_old && idx < best_i);
+                }
+                best_sq = take ? sq : best_sq;
+                best_x = take ? x : best_x;
+                best_y = take ? y : best_y;
+                best_i = take ? idx : best_i;
+            }
+        }
+        double best_v = best_i != 0x7fffffff ? 0.0 + hypot(best_x, best_y) : -1.0;   // (0.0 + |.|: the map's own rounding)
+        wave_best(best_v, best_i);
+        if ((threadIdx.x & 63) == 63) {
+            Best r = {best_v, (long long)best_i};
+            a.partials[((size_t)batch * gridDim.x + blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6)] = r;
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < N2 * T; e += kThreads) {
         const int k2 = e / T, c = e - k2 * T;
         const int k1 = k1_0 + c;
@@ -627,25 +851,29 @@ __global__ __launch_bounds__(kThreads) void fft4_rows_kernel(const PassArgs a, i
 template <bool INV, int LOAD0, int STORE_LAST, int FMT, int TA, int TB>
 void run_four_step_t(sdr_engine* e, const FourStep& f, PassArgs a, int batch, double2* Z, double2* final_out) {
     a.out = final_out;
-    const size_t shA = (size_t)(2 * f.N1 * (TA + 1) + f.N1) * sizeof(double2);
-    const size_t shB = (size_t)(2 * f.N2 * (TB + 1) + f.N2) * sizeof(double2);
+    const size_t shA = (size_t)(2 * f.N1 * lds_pitch(TA) + f.N1) * sizeof(double2);
+    const size_t shB = (size_t)(2 * f.N2 * lds_pitch(TB) + f.N2) * sizeof(double2);
     // more than 64 KiB of dynamic LDS has to be requested explicitly (160 KiB per CU on MI355X)
     (void)hipFuncSetAttribute((const void*)fft4_cols_kernel<INV, LOAD0, FMT, TA>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shA);
-    (void)hipFuncSetAttribute((const void*)fft4_rows_kernel<INV, STORE_LAST, TB>,
+    constexpr bool SEL = LOAD0 == LOAD_MUL_CODE_SEL;
+    (void)hipFuncSetAttribute((const void*)fft4_rows_kernel<INV, STORE_LAST, TB, SEL>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shB);
     hipLaunchKernelGGL((fft4_cols_kernel<INV, LOAD0, FMT, TA>), dim3((f.N2 + TA - 1) / TA, batch), dim3(kThreads), shA,
                        e->stream, a, f.N1, f.N2, f.rad1, Z);
-    hipLaunchKernelGGL((fft4_rows_kernel<INV, STORE_LAST, TB>), dim3((f.N1 + TB - 1) / TB, batch), dim3(kThreads), shB,
+    hipLaunchKernelGGL((fft4_rows_kernel<INV, STORE_LAST, TB, SEL>), dim3((f.N1 + TB - 1) / TB, batch), dim3(kThreads), shB,
                        e->stream, a, f.N1, f.N2, f.rad2, Z);
 }
 
 // Tile widths: 8 columns for kernel A (128-byte runs), 4 rows for kernel B -- its LDS footprint is the larger
 // one (N2 >= N1) and halving it (5 instead of 2 workgroups per CU at N = 25000) measured 9 % faster than 8.
+constexpr int kRowTile = 4;
 template <bool INV, int LOAD0, int STORE_LAST, int FMT>
 void run_four_step(sdr_engine* e, const FourStep& f, PassArgs a, int batch, double2* Z, double2* final_out) {
-    run_four_step_t<INV, LOAD0, STORE_LAST, FMT, 8, 4>(e, f, a, batch, Z, final_out);
+    run_four_step_t<INV, LOAD0, STORE_LAST, FMT, 8, kRowTile>(e, f, a, batch, Z, final_out);
 }
+// per-wave records one map-free inverse sweep leaves per transform
+inline int records_per_transform(const FourStep& f) { return ((f.N1 + kRowTile - 1) / kRowTile) * (kThreads / 64); }
 
 /* ------------------------------------------------------------------------------------------------
  * Chirp-z (Bluestein) transform for a length N the planner cannot factor (a prime factor above 64):
@@ -776,9 +1004,9 @@ void run_fft(sdr_engine* e, const std::vector<int>& radices, PassArgs a, int bat
 }
 
 template <int FMT>
-int pcps_run(sdr_engine* e, const int32_t* d_slots, int n_prn, int64_t start, double fs, double if_hz,
+int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int n_prn, int64_t start, double fs, double if_hz,
              double bin_start, double bin_delta, int nbins, int N, int spc, int coh, int noncoh,
-             const std::vector<int>& radices, int prn_chunk, bool have_spectra, const BluPlan* blu) {
+             const std::vector<int>& radices, int prn_chunk, bool have_spectra, const BluPlan* blu, bool map_free) {
     double2* F = (double2*)e->pcps_fwd.ptr;
     double2* A = (double2*)e->pcps_a.ptr;
     double2* B = (double2*)e->pcps_b.ptr;
@@ -787,9 +1015,24 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, int n_prn, int64_t start, do
     double2* csum = (double2*)e->pcps_csum.ptr;
     const double2* tw = (const double2*)e->pcps_tw.ptr;
 
-    // K7/a3: upsample every code and take conj(fft(code)) (channel_l1ca_kaplan.py:184-185),
-    // unless the caller handed in its own codeFFT arrays (function-level drop-in of PCPS()).
+    // K7/a3: upsample every code and take conj(fft(code)) (channel_l1ca_kaplan.py:184-185), unless the caller
+    // handed in its own codeFFT arrays (function-level drop-in of PCPS()) -- or the spectra of exactly these
+    // staged codes at this rate are still in the buffer from the previous search (the reference recomputes them
+    // on every acquisition, kaplan:184-185; they only change when a slot is re-staged).
+    std::vector<int64_t> key;
     if (!have_spectra) {
+        int64_t fs_bits;
+        memcpy(&fs_bits, &fs, sizeof(fs_bits));
+        key = {(int64_t)N, fs_bits, e->code_generation};
+        for (int i = 0; i < n_prn; ++i) {
+            key.push_back(h_slots[i]);
+            key.push_back(e->code_stamp[h_slots[i]]);
+        }
+    }
+    const bool spectra_cached = !have_spectra && key == e->pcps_spec_key;
+    if (have_spectra) e->pcps_spec_key.clear();
+    if (!have_spectra && !spectra_cached) {
+        e->pcps_spec_key = key;
         int8_t* up = (int8_t*)B;  // scratch: n_prn*N bytes fits easily in a work buffer
         {
             ProfScope ps(e, "pcps_upsample");
@@ -831,7 +1074,10 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, int n_prn, int64_t start, do
                 g.scale = 1.0 / (double)N;
                 g.map = map + (size_t)p0 * nbins * N;
                 g.csum = csum ? csum + (size_t)p0 * nbins * N : nullptr;
-                if (coh == 1) {
+                if (map_free) {
+                    g.partials = (Best*)e->pcps_part.ptr + (size_t)p0 * nbins * records_per_transform(plan_four_step(N));
+                    run_fft<true, LOAD_MUL_CODE, STORE_MAG_MAX, FMT>(e, radices, g, pc * nbins, A, B, nullptr, "pcps_inv_fft", blu);
+                } else if (coh == 1) {
                     g.first_block = inc == 0;
                     run_fft<true, LOAD_MUL_CODE, STORE_MAG_ACC, FMT>(e, radices, g, pc * nbins, A, B, nullptr, "pcps_inv_fft", blu);
                 } else {
@@ -853,6 +1099,37 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, int n_prn, int64_t start, do
     long long* res_bin = (long long*)e->pcps_res.ptr;
     long long* res_code = res_bin + n_prn;
     double* res_ratio = (double*)(res_code + n_prn);
+    if (map_free) {
+        // the map was never written: maximum from the per-wave records, then the winning row of every PRN alone
+        // (1/nbins of one inverse sweep) for the second peak
+        const int per_prn = nbins * records_per_transform(plan_four_step(N));
+        Best* tops = parts + (size_t)n_prn * per_prn;
+        {
+            ProfScope ps(e, "pcps_peak");
+            hipLaunchKernelGGL(argmax_records_kernel, dim3(n_prn), dim3(kThreads), 0, e->stream, parts, per_prn, N, tops,
+                               res_bin, res_code);
+        }
+        PassArgs g = {};
+        g.tw = tw;
+        g.N = N;
+        g.in = F;
+        g.code_spec = C;
+        g.nbins = nbins;
+        g.scale = 1.0 / (double)N;
+        g.sel_bin = res_bin;
+        g.tops = tops;
+        g.spc = spc;
+        Best* seconds = tops + n_prn;      // [n_prn][records_per_transform]
+        g.partials = seconds;
+        run_fft<true, LOAD_MUL_CODE_SEL, STORE_MAG_MAX, FMT>(e, radices, g, n_prn, A, B, nullptr, "pcps_inv_fft", blu);
+        {
+            ProfScope ps(e, "pcps_peak");
+            hipLaunchKernelGGL(ratio_kernel, dim3(n_prn), dim3(64), 0, e->stream, seconds, records_per_transform(plan_four_step(N)),
+                               tops, res_ratio);
+        }
+        SDR_HIP(hipGetLastError());
+        return SDR_OK;
+    }
     {
         ProfScope ps(e, "pcps_peak");
         hipLaunchKernelGGL(argmax_part_kernel, dim3(kPeakParts, n_prn), dim3(kThreads), 0, e->stream, map,
@@ -952,15 +1229,21 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     const size_t mbytes = (size_t)M * sizeof(double2);  // (0 without the chirp-z path)
     int prn_chunk = (int)std::min<int64_t>(n_prn, std::max<int64_t>(1, (int64_t)((8ull << 30) / (std::max(tbytes, mbytes) * nbins))));
     if ((int64_t)prn_chunk * nbins > 65535) prn_chunk = std::max(1, 65535 / nbins);
+    if (e->pcps_prn_chunk > 0) prn_chunk = std::min(prn_chunk, e->pcps_prn_chunk);
     if (nbins > 65535 || n_prn > 65535) return sdr_fail(SDR_ERR_UNSUPPORTED, "grid too large");
     const size_t work = tbytes * (size_t)std::max(prn_chunk * nbins, std::max(n_prn, nbins));
     int rc = sdr_devbuf_reserve(e, &e->pcps_fwd, tbytes * (size_t)std::max(nbins, n_prn));
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_a, work);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_b, work);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_code, tbytes * n_prn);
-    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_map, (size_t)n_prn * nbins * N * sizeof(double));
+    // Indices and ratio only, one block, four-step transform available: the map is never materialised.
+    const FourStep four = plan_four_step(N);
+    const bool map_free = !corr_map && coh == 1 && noncoh == 1 && !use_blu && four.ok && !e->pcps_force_passes &&
+                          !e->pcps_force_map;
+    const size_t n_records = map_free ? (size_t)n_prn * (nbins + 1) * records_per_transform(four) + n_prn : 0;
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_map, (size_t)n_prn * (map_free ? 1 : nbins) * N * sizeof(double));
     if (!rc && coh > 1) rc = sdr_devbuf_reserve(e, &e->pcps_csum, (size_t)n_prn * nbins * tbytes);
-    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_part, (size_t)n_prn * kPeakParts * sizeof(Best));
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_part, std::max((size_t)n_prn * kPeakParts, n_records) * sizeof(Best));
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_res, (size_t)n_prn * 3 * sizeof(double) + n_prn * sizeof(int32_t));
     if (rc) return rc;
     if (e->pcps_tw_n != N) {
@@ -1006,10 +1289,16 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
         }
     }
     int32_t* d_slots = (int32_t*)((char*)e->pcps_res.ptr + (size_t)n_prn * 3 * sizeof(double));
-    if (code_spectra)
+    // small transfers go through page-locked staging: one copy each way, no hidden synchronisation
+    const size_t res_bytes = (size_t)n_prn * 3 * sizeof(double);
+    if ((rc = sdr_pinned_reserve(e, &e->ctx0, res_bytes + (size_t)n_prn * sizeof(int32_t)))) return rc;
+    char* pin = (char*)e->ctx0.pinned;
+    if (code_spectra) {
         SDR_HIP(hipMemcpyAsync(e->pcps_code.ptr, code_spectra, tbytes * n_prn, hipMemcpyHostToDevice, e->stream));
-    else
-        SDR_HIP(hipMemcpyAsync(d_slots, code_slots, n_prn * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    } else {
+        memcpy(pin + res_bytes, code_slots, (size_t)n_prn * sizeof(int32_t));
+        SDR_HIP(hipMemcpyAsync(d_slots, pin + res_bytes, n_prn * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    }
     const bool hs = code_spectra != nullptr;
 
     // np.arange(-R, R+1, S): element k = start + k*delta with delta = (start+step) - start
@@ -1017,25 +1306,24 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     const double bin_delta = (bin_start + doppler_step) - bin_start;
 
     switch (e->iq_fmt) {
-        case SDR_FMT_CI8: rc = pcps_run<SDR_FMT_CI8>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr); break;
-        case SDR_FMT_CI16: rc = pcps_run<SDR_FMT_CI16>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr); break;
-        case SDR_FMT_CF32: rc = pcps_run<SDR_FMT_CF32>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr); break;
-        default: rc = pcps_run<SDR_FMT_CF64>(e, d_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr); break;
+        case SDR_FMT_CI8: rc = pcps_run<SDR_FMT_CI8>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
+        case SDR_FMT_CI16: rc = pcps_run<SDR_FMT_CI16>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
+        case SDR_FMT_CF32: rc = pcps_run<SDR_FMT_CF32>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
+        default: rc = pcps_run<SDR_FMT_CF64>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
     }
     if (rc) return rc;
 
-    std::vector<long long> hb(2 * (size_t)n_prn);
-    SDR_HIP(hipMemcpyAsync(hb.data(), e->pcps_res.ptr, 2 * (size_t)n_prn * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
-    SDR_HIP(hipMemcpyAsync(peak_ratio, (char*)e->pcps_res.ptr + 2 * (size_t)n_prn * sizeof(long long),
-                           (size_t)n_prn * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    SDR_HIP(hipMemcpyAsync(pin, e->pcps_res.ptr, res_bytes, hipMemcpyDeviceToHost, e->stream));
     if (corr_map)
         SDR_HIP(hipMemcpyAsync(corr_map, e->pcps_map.ptr, (size_t)n_prn * nbins * N * sizeof(double),
                                hipMemcpyDeviceToHost, e->stream));
     SDR_HIP(hipStreamSynchronize(e->stream));
+    const long long* hb = (const long long*)pin;
     for (int i = 0; i < n_prn; ++i) {
         peak_bin[i] = hb[i];
         peak_code[i] = hb[n_prn + i];
     }
+    memcpy(peak_ratio, pin + 2 * (size_t)n_prn * sizeof(long long), (size_t)n_prn * sizeof(double));
     return SDR_OK;
 }
 

@@ -163,6 +163,9 @@ class Engine:
         check(self._lib.sdr_prof_read(self._h, prefix.encode(), C.byref(tot), C.byref(cnt)))
         return tot.value, cnt.value
 
+    def set_option(self, name: str, value: int):
+        check(self._lib.sdr_set_option(self._h, name.encode(), int(value)))
+
     def hbm_copy_rate(self, n_bytes: int = 1 << 30, reps: int = 10) -> float:
         """Measured GB/s (read + written) of a hand-written stream-copy kernel on this GPU."""
         g = C.c_double(0)

@@ -189,3 +189,61 @@ def test_pcps_randomised_stress(engine):
     spec.loader.exec_module(mod)
     checked, worst, refused = mod.run(25, 20261003, engine)
     assert checked >= 45 and worst <= 1e-9
+
+
+def test_map_free_search_equals_the_materialised_one(engine):
+    """Indices + ratio without writing the map (running maximum in the inverse row kernel, winning rows recomputed
+    alone) == the same search with the map written and re-read -- bit for bit, ties, edge windows and absent PRNs
+    included (every PRN x 4/10/25 MHz x two Doppler grids)."""
+    rng = np.random.default_rng(31)
+    for fs, grid in ((4e6, (5000.0, 250.0)), (10e6, (5000.0, 300.0)), (25e6, (5000.0, 250.0)), (25e6, (2000.0, 100.0))):
+        n = orc.samples_per_code(fs)
+        sats = [dict(prn=int(p), doppler=float(rng.uniform(-4000, 4000)), code_phase=float(rng.uniform(0, 1023)),
+                     phase=0.2, amp=7.0) for p in rng.choice(np.arange(1, 33), 9, replace=False)]
+        engine.iq_alloc(n, FMT_CI8)
+        engine.code_slots(32)
+        for s in range(32):
+            engine.load_gps_code(s, s + 1)
+        engine.iq_synth(sats, fs, 15.0, int(fs) % 1000 + 17, 0, n)
+        slots = np.arange(32)
+        pb, pc, pr, none = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1)
+        assert none is None
+        engine.set_option("pcps_materialise_map", 1)
+        try:
+            qb, qc, qr, _ = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1)
+        finally:
+            engine.set_option("pcps_materialise_map", 0)
+        mb, mc, mr, cmap = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1, want_map=True)
+        assert np.array_equal(pb, qb) and np.array_equal(pc, qc) and pr.tobytes() == qr.tobytes()
+        assert np.array_equal(pb, mb) and np.array_equal(pc, mc) and pr.tobytes() == mr.tobytes()
+        for p in range(32):                                   # and against NumPy's own argmax of the returned map
+            top = np.unravel_index(np.argmax(cmap[p]), cmap[p].shape)
+            assert (int(pb[p]), int(pc[p])) == (int(top[0]), int(top[1]))
+    # constant stream: every map value of a row ties -> first index must win in both paths
+    engine.iq_alloc(4000, FMT_CI8)
+    engine.iq_upload(np.zeros(8000, dtype=np.int8), 0)
+    pb, pc, pr, _ = engine.pcps(np.arange(4), 0, 4e6, 0.0, 5000.0, 250.0, 1, 1)
+    assert np.all(pb == 0) and np.all(pc == 0)
+
+
+def test_cached_code_spectra_follow_the_staged_codes(engine):
+    """conj(fft(code)) is kept between searches of the same staged codes (the reference rebuilds it every time,
+    kaplan:184-185); re-staging a slot, another slot list or another rate must not reuse it."""
+    fs = 4e6
+    n = orc.samples_per_code(fs)
+    sats = [dict(prn=5, doppler=1000.0, code_phase=100.5, phase=0.0, amp=9.0),
+            dict(prn=9, doppler=-2000.0, code_phase=700.25, phase=0.3, amp=9.0)]
+    raw = orc.synth_iq(fs, n, sats, 12.0, 77)
+    _stage(engine, raw, [5, 9, 11])
+    first = engine.pcps([0, 1, 2], 0, fs, 0.0, 5000.0, 250.0)
+    again = engine.pcps([0, 1, 2], 0, fs, 0.0, 5000.0, 250.0)            # served from the cached spectra
+    assert all(np.array_equal(a, b) for a, b in zip(first[:3], again[:3]))
+    engine.load_gps_code(2, 9)                                            # slot 2 now carries PRN 9
+    restaged = engine.pcps([0, 1, 2], 0, fs, 0.0, 5000.0, 250.0)
+    assert (restaged[0][2], restaged[1][2]) == (first[0][1], first[1][1]) and restaged[2][2] == first[2][1]
+    swapped = engine.pcps([1, 0], 0, fs, 0.0, 5000.0, 250.0)             # another slot list
+    assert (swapped[0][0], swapped[1][0], swapped[2][0]) == (first[0][1], first[1][1], first[2][1])
+    rf = orc.iq_to_complex(raw)
+    cmap = orc.pcps_map(rf.reshape(1, -1), 0.0, fs, orc.code_spectrum(orc.gold_code(9), fs), 5000.0, 250.0, n)
+    peak, ratio = orc.two_peak_compare(cmap, n, round(fs / orc.CODE_RATE))
+    assert [int(restaged[0][2]), int(restaged[1][2])] == peak and restaged[2][2] == pytest.approx(ratio, rel=1e-9)

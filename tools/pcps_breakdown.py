@@ -11,6 +11,8 @@ e.code_slots(32)
 for s in range(32):
     e.load_gps_code(s, s + 1)
 slots = np.arange(32)
+if len(sys.argv) > 1:
+    e.set_option('pcps_prn_chunk', int(sys.argv[1]))
 e.pcps(slots, 0, fs, 0.0, 5000.0, 250.0)
 e.prof_reset(); e.prof_enable(True)
 reps = 5
