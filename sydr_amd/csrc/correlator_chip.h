@@ -1,0 +1,361 @@
+// Chip-aligned variant of the E/P/L correlator core (ci8 rings, code steps of 1/26 .. 1/16 chip per sample:
+// GPS L1 C/A between ~16.4 and ~26.5 MHz, i.e. the 25 MHz of the headline configuration; BOC(1,1) half-chip codes
+// at 50 MHz).
+//
+// The boundary variant of correlator.h gives a lane 16 consecutive SAMPLES: the chip switch of every tap falls
+// somewhere inside, so all 16 running sums go through LDS (one 16-byte store per sample) and every tap pays its
+// switch arithmetic per 16 samples.  Here a lane owns one whole CHIP of the centre ("anchor") tap -- the samples
+// i with ceil(y_a(i)) == q, 24 or 25 of them at 25 MHz -- so
+//   * the anchor tap sees no switch at all inside a lane's block;
+//   * every other tap switches exactly once per block, and because all taps advance by the same step the switch
+//     position is the same in every lane up to +1: split_t in {m_t, m_t + 1}, block length n in {M, M + 1}
+//     with wave-uniform m_t, M;
+//   * so only the running sums at those 2*NT positions are kept (a uniform branch around one LDS store at ~6 of
+//     the 25 sample positions), and a tap's share of the block is
+//          c(p+1) * P_n + (c(p) - c(p+1)) * P_split       p = the tap's chip at the block's first sample
+//     with P_split read back from the lane's strip at a per-lane slot.
+// Per sample that leaves the unavoidable part -- int8 -> fp64 (4 instructions) and the complex mix into the running
+// sum (4 FMAs) -- plus ~5 instructions of amortised block overhead, against ~17.8 for the boundary variant.
+//
+// Exactness: a block boundary is "the first sample whose reference chip index exceeds q", with the reference's
+// y(i) = fl(fl(i*step) + shift) (np.linspace).  It is PREDICTED as floor((q - shift)/step) + 1; the
+// prediction can only be off when the crossing lies within ~1e-11 of a sample, and whenever any lane of the wave
+// is within 2^-16 of one the wave re-derives the boundary from exact evaluations of y on both sides (rare branch).
+// A lane that ever finds a split or a length outside its {m, m+1} pair (taps exactly aligned with the anchor whose
+// rounding jitters, degenerate steps) raises a flag: the caller then redoes the whole epoch with the per-sample
+// routine.  First and last (partial) chips of the epoch are edge samples (one per lane, per-sample arithmetic).
+#pragma once
+
+#include "correlator.h"
+
+#pragma clang fp contract(off)
+
+namespace sdr {
+
+constexpr int kChipMax = 26;                      // samples a lane's block may hold (k = 0..25)
+constexpr double kChipMinCodeStep = 1.0 / 25.9;   // blocks of at most 26 samples
+constexpr double kChipMaxCodeStep = 1.0 / 16.0;   // below ~16 samples per chip the 16-sample boundary variant is as good
+constexpr int kChipRawDwords = 13;                // 52 bytes: 26 samples
+template <int NT>
+constexpr int chip_strip_slots() { return 2 * NT + 1; }   // double2 slots per lane (odd multiple of 16 B: conflict-free)
+
+// Predicted first sample i with y(i) > thr on the line y = i*step + shift.
+__device__ __forceinline__ int chip_first_above(double thr, double shift, double inv_step, bool& near) {
+    const double u = (thr - shift) * inv_step;
+    const double fl = floor(u);
+    const double fr = u - fl;
+    near = near || fr < kNearInteger || fr > 1.0 - kNearInteger;
+    return (int)fl + 1;
+}
+// The same from exact evaluations of the reference expression around a prediction c.
+__device__ __forceinline__ int chip_first_above_exact(int c, double thr, double step, double shift) {
+    auto above = [&](int i) {
+        double y = (double)i * step;   // reference arithmetic: separate multiply and add
+        y = y + shift;
+        return y > thr;
+    };
+    if (c >= 1 && above(c - 1)) return (c >= 2 && above(c - 2)) ? c - 2 : c - 1;
+    if (c < 0) c = 0;
+    if (above(c)) return c;
+    return above(c + 1) ? c + 1 : c + 2;
+}
+
+__device__ __forceinline__ int wave_min_i32(int x) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_xor(x, off, 64);
+        x = o < x ? o : x;
+    }
+    return __builtin_amdgcn_readfirstlane(x);
+}
+
+// One lane's block, prepared one round ahead of its use (its loads are in flight while the previous block computes).
+template <int NT>
+struct ChipBlock {
+    uint32_t raw[kChipRawDwords];
+    int S;             // first sample of the block (epoch-relative)
+    int dn;            // block length - M            (0 or 1)
+    int ds[NT];        // per tap: switch position - m_t (0 or 1; anchor: unused)
+};
+
+// Returns false when a lane met a configuration the uniform-position scheme does not cover: the caller redoes the
+// epoch with correlate_epoch().  strip: this wave-group's [stride][chip_strip_slots<NT>()] double2; rot: 26 double2
+// private to the WAVE.
+//
+// Block boundaries come from a fixed-point line (Q32.32 samples): with T = 1/step samples per chip and
+// U = -shift/step, the first sample whose reference y exceeds thr is floor(U + thr*T) + 1.  One 64-bit add per
+// boundary per lane; a boundary whose fraction lies within 2^-16 of an integer (where fixed point, the real line
+// and the reference's rounded y might disagree) sends the wave through exact evaluations of the reference
+// expression instead.  Because every tap advances by the same T, the switch of tap t sits delta_t = const samples
+// after the block start on the real line, so its sample position is floor(delta_t) or floor(delta_t) + 1 in every
+// lane (floor(a + b) - floor(a) for b >= 0): the two LDS slots per tap are known for the whole epoch.
+template <int NT, bool SINGLE_WAVE>
+__device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ring, int64_t capacity,
+                                                     const EpochParams& ep, double dphi, const EpochConsts<NT>& K,
+                                                     const uint32_t* lut, double2* strip_lds, double2* rot, int tid,
+                                                     int lane, int stride, int edge_lane, double* accr, double* acci) {
+    constexpr int A = NT / 2;                       // anchor tap: the centre one (prompt)
+    constexpr int kSlots = chip_strip_slots<NT>();
+    const int n = ep.n;
+    const double* shift = K.shift;
+    const double* step = K.step;
+    const double* inv_step = K.inv_step;
+    double2* strip = strip_lds + tid * kSlots;
+    const int wlane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) accr[t] = acci[t] = 0.0;
+
+    // ---- epoch geometry (wave-uniform): chips q0 .. q_last of the anchor tap; q0+1 .. q_last-1 are whole
+    const double dphi_u = uniform(dphi), rem_carrier_u = uniform(ep.rem_carrier);
+    const int q0 = (int)ceil(shift[A]);
+    double y_last = (double)(n - 1) * step[A];
+    y_last = y_last + shift[A];
+    const int q_last = (int)ceil(y_last);
+    const int F = q_last - q0 - 1;                  // whole chips
+    int head_end = n, tail_start = n;
+    if (F > 0) {
+        bool nr = false;
+        head_end = chip_first_above_exact(chip_first_above((double)q0, shift[A], inv_step[A], nr), (double)q0, step[A], shift[A]);
+        tail_start = chip_first_above_exact(chip_first_above((double)(q_last - 1), shift[A], inv_step[A], nr),
+                                            (double)(q_last - 1), step[A], shift[A]);
+        head_end = __builtin_amdgcn_readfirstlane(head_end);
+        tail_start = __builtin_amdgcn_readfirstlane(tail_start);
+    }
+    const int64_t base = ep.start_sample % capacity;   // (the caller guarantees base + n + 32 <= capacity)
+    const char* ring_base = static_cast<const char*>(ring) + base * 2;
+
+    // in-block rotations exp(-1j*k*dphi), k = 0..25: one per lane, parked in LDS, read back as broadcasts
+    if (wlane < kChipMax) {
+        double sn, cs;
+        sincos_reduced(-(double)wlane * dphi_u, &sn, &cs);
+        rot[wlane] = make_double2(cs, sn);
+    }
+
+    bool bad = false;
+    const int rounds = F > 0 ? (F + stride - 1) / stride : 0;
+    if (rounds > 0) {
+        // ---- the fixed-point line of the anchor tap, and each tap's constant offset on it
+        const double two32 = 4294967296.0;
+        const int64_t Tfx = (int64_t)rint(inv_step[A] * two32);
+        const int64_t Ufx = (int64_t)floor(-shift[A] * inv_step[A] * two32);
+        const int M = (int)(Tfx >> 32);                                   // block length M or M + 1
+        bad = bad || M < 1 || M + 1 > kChipMax || F > 16384;
+        int m[NT], J[NT];
+        uint64_t delta[NT];
+        unsigned evmask = (1u << M) | (2u << M);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            m[t] = M, J[t] = 0, delta[t] = 0;
+            if (t == A) continue;
+            // tap t sits on chip q + J_t at the block start of anchor chip q; its switch to q + J_t + 1 comes
+            // delta_t >= 0 samples later (delta_t < T)
+            const int64_t Ut = (int64_t)floor(-shift[t] * inv_step[t] * two32);
+            int j = (int)ceil(shift[t] - shift[A]) - 1;
+            int64_t d = (Ut - Ufx) + (int64_t)(1 + j) * Tfx;
+            if (d < 0) {
+                d += Tfx;
+                ++j;
+            } else if (d >= Tfx) {
+                d -= Tfx;
+                --j;
+            }
+            bad = bad || d < 0 || d >= Tfx;
+            J[t] = j;
+            delta[t] = (uint64_t)d;
+            m[t] = (int)(d >> 32);
+            evmask |= (1u << m[t]) | (2u << m[t]);
+        }
+        const int k_last = M + 1;                       // no prefix beyond P_(M+1) is ever read
+        int rank[NT];                                   // strip slot of position m_t (m_t + 1 sits in the next one)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) rank[t] = __builtin_popcount(evmask & ((1u << m[t]) - 1u));
+        // distance to a lane's next block: D or D + 1 samples; the two carrier rotations over it
+        const int64_t stride_fx = (int64_t)stride * Tfx;
+        const int Dmin = (int)(stride_fx >> 32);
+        double rd0c, rd0s, rd1c, rd1s;
+        {
+            double sn, cs;
+            sincos_reduced(-(double)(Dmin + (wlane & 1)) * dphi_u, &sn, &cs);   // lane 0: Dmin, lane 1: Dmin + 1
+            rd0c = lane_value(cs, 0), rd0s = lane_value(sn, 0);
+            rd1c = lane_value(cs, 1), rd1s = lane_value(sn, 1);
+            asm volatile("" : "+v"(rd0c), "+v"(rd0s), "+v"(rd1c), "+v"(rd1s));   // (selected per lane: keep them in vector registers)
+        }
+        const uint64_t lane_fx = (uint64_t)((int64_t)lane * Tfx);
+        // u of the lane's block start in round 0, "+1 sample" folded in: S = u >> 32
+        uint64_t u_cur = (uint64_t)(Ufx + (int64_t)q0 * Tfx + (int64_t)two32) + lane_fx;
+        const int last_idx = F - 1;
+
+        auto prepare = [&](int round, uint64_t u0, ChipBlock<NT>& b) {
+            // (a lane beyond the last whole chip re-does the last one with a zero carrier phasor)
+            const int idx = round * stride + lane;
+            const bool inside = idx <= last_idx;
+            const uint64_t uS = inside ? u0 : (uint64_t)(Ufx + (int64_t)(q0 + last_idx) * Tfx + (int64_t)two32);
+            const uint64_t uE = uS + (uint64_t)Tfx;
+            int S = (int)(uS >> 32);
+            int E = (int)(uE >> 32);
+            bool near = (uint32_t)uS + 0x10000u < 0x20000u || (uint32_t)uE + 0x10000u < 0x20000u;
+            int split[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                split[t] = 0;
+                if (t == A) continue;
+                const uint64_t uT = uS + delta[t];
+                near = near || (uint32_t)uT + 0x10000u < 0x20000u;
+                split[t] = (int)(uT >> 32) - S;
+            }
+            if (__builtin_expect(__any(near), 0)) {
+                const int q = q0 + 1 + (inside ? idx : last_idx);
+                S = chip_first_above_exact(S, (double)(q - 1), step[A], shift[A]);
+                E = chip_first_above_exact(E, (double)q, step[A], shift[A]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (t == A) continue;
+                    const int p0 = q + J[t];
+                    // the tap must sit on p0 or p0 + 1 at S and switch to p0 + 1 at most once inside the block
+                    const int bt = chip_first_above_exact(S + split[t], (double)p0, step[t], shift[t]);
+                    double y = (double)S * step[t];
+                    y = y + shift[t];
+                    const int at_s = (int)ceil(y);
+                    bad = bad || (at_s != p0 && at_s != p0 + 1) || (at_s == p0 + 1 && bt > S);
+                    split[t] = bt < S ? 0 : bt - S;
+                }
+            }
+            b.S = S;
+            const int nn = E - S;
+            b.dn = nn - M;
+            bad = bad || (unsigned)b.dn > 1u;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                b.ds[t] = 0;
+                if (t == A) continue;
+                const int sp = split[t] > nn ? nn : split[t];
+                b.ds[t] = sp - m[t];
+                bad = bad || (unsigned)b.ds[t] > 1u;
+            }
+            // 13 dwords = 26 samples from the (2-byte aligned) address of sample S: gfx950 serves unaligned dword loads
+            const char* src = ring_base + (int64_t)S * 2;
+            const uint4 w0 = *reinterpret_cast<const uint4*>(src);
+            const uint4 w1 = *reinterpret_cast<const uint4*>(src + 16);
+            const uint4 w2 = *reinterpret_cast<const uint4*>(src + 32);
+            const uint32_t w3 = *reinterpret_cast<const uint32_t*>(src + 48);
+            b.raw[0] = w0.x, b.raw[1] = w0.y, b.raw[2] = w0.z, b.raw[3] = w0.w;
+            b.raw[4] = w1.x, b.raw[5] = w1.y, b.raw[6] = w1.z, b.raw[7] = w1.w;
+            b.raw[8] = w2.x, b.raw[9] = w2.y, b.raw[10] = w2.z, b.raw[11] = w2.w;
+            b.raw[12] = w3;
+        };
+
+        ChipBlock<NT> blk_a, blk_b;
+        prepare(0, u_cur, blk_a);
+        // carrier phase at the lane's first block: one exact evaluation; later blocks by a fixed rotation
+        double sb, cb;
+        sincos_reduced(__builtin_fma(-(double)blk_a.S, dphi_u, rem_carrier_u), &sb, &cb);
+        sb = lane <= last_idx ? sb : 0.0;
+        cb = lane <= last_idx ? cb : 0.0;
+        // per-lane LDS addresses: the strip slots of each tap's position m_t, and the lane's replica entry
+        const int q_lane = q0 + 1 + lane + SDR_LUT_PAD;
+
+        auto process = [&](const ChipBlock<NT>& b, int round, double sbk, double cbk) {
+            double pr = 0.0, pi = 0.0;
+            double2* wp = strip;
+            // the event positions as ONE scalar register, re-read per block: left to itself the compiler hoists the 27
+            // bit tests out of the round loop as 27 lane masks and spills them through v_writelane / v_readlane
+            unsigned evm = evmask;
+            int klast = k_last;
+            asm volatile("" : "+s"(evm), "+s"(klast));
+            // the in-block rotations come from LDS as broadcasts, fetched a few samples ahead of their use (the
+            // uniform branches below end a basic block at every sample: nothing is hoisted across them for us)
+            constexpr int kAhead = 4;
+            double2 rr[kChipMax + kAhead];
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) rr[k] = rot[k];
+#pragma unroll
+            for (int k = 0; k <= kChipMax; ++k) {
+                if (evm & (1u << k)) {                  // (wave-uniform) one of the positions somebody reads: park P_k
+                    *wp = make_double2(pr, pi);
+                    ++wp;
+                    asm volatile("" ::: "memory");
+                    if (k == klast) break;
+                }
+                if (k < kChipMax) {
+                    const int w = (int)b.raw[k >> 1];
+                    const double ar = (k & 1) ? (double)(int)(int8_t)(w >> 16) : (double)(int)(int8_t)w;
+                    const double ai = (k & 1) ? (double)(w >> 24) : (double)(int)(int8_t)(w >> 8);
+                    if (k + kAhead < kChipMax) rr[k + kAhead] = rot[k + kAhead];
+                    const double2 r = rr[k];
+                    pr = __builtin_fma(-ai, r.y, __builtin_fma(ar, r.x, pr));
+                    pi = __builtin_fma(ai, r.x, __builtin_fma(ar, r.y, pi));
+                }
+            }
+            const double2 ptot = strip[rank[A] + b.dn];
+            const int first = round * stride;           // (a lane beyond the last whole chip re-does the last one)
+            const uint32_t* lq = lut + q_lane + (first + lane <= last_idx ? first : last_idx - lane);   // replica entry of the block's anchor chip
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double gr, gi;
+                if (t == A) {
+                    const double c = __hiloint2double((int)lq[0], 0);
+                    gr = c * ptot.x;
+                    gi = c * ptot.y;
+                } else {
+                    const double2 ps = strip[rank[t] + b.ds[t]];
+                    const double ca = __hiloint2double((int)lq[J[t]], 0);
+                    const double cbn = __hiloint2double((int)lq[J[t] + 1], 0);
+                    const double diff = ca - cbn;
+                    gr = __builtin_fma(diff, ps.x, cbn * ptot.x);
+                    gi = __builtin_fma(diff, ps.y, cbn * ptot.y);
+                }
+                accr[t] = __builtin_fma(-sbk, gi, __builtin_fma(cbk, gr, accr[t]));
+                acci[t] = __builtin_fma(sbk, gr, __builtin_fma(cbk, gi, acci[t]));
+            }
+        };
+
+        auto wave_has_work = [&](int round) { return SINGLE_WAVE || round * stride + (lane - wlane) <= last_idx; };
+        // rotation to the next block of this lane
+        auto advance = [&](const ChipBlock<NT>& from, const ChipBlock<NT>& to, int to_round) {
+            const unsigned dd = (unsigned)(to.S - from.S - Dmin);
+            const bool alive = to_round * stride + lane <= last_idx;
+            bad = bad || (alive && dd > 1u);
+            const double rc_ = dd ? rd1c : rd0c, rs_ = dd ? rd1s : rd0s;
+            const double cbn = __builtin_fma(cb, rc_, -sb * rs_);
+            const double sbn = __builtin_fma(sb, rc_, cb * rs_);
+            cb = alive ? cbn : 0.0;
+            sb = alive ? sbn : 0.0;
+        };
+
+        for (int it = 0; it < rounds / 2; ++it) {
+            const double sb0 = sb, cb0 = cb;
+            u_cur += (uint64_t)stride_fx;
+            prepare(2 * it + 1, u_cur, blk_b);
+            advance(blk_a, blk_b, 2 * it + 1);
+            if (wave_has_work(2 * it)) process(blk_a, 2 * it, sb0, cb0);
+            const double sb1 = sb, cb1 = cb;
+            if (2 * it + 2 < rounds) {
+                u_cur += (uint64_t)stride_fx;
+                prepare(2 * it + 2, u_cur, blk_a);
+                advance(blk_b, blk_a, 2 * it + 2);
+            }
+            if (wave_has_work(2 * it + 1)) process(blk_b, 2 * it + 1, sb1, cb1);
+        }
+        if ((rounds & 1) && wave_has_work(rounds - 1)) process(blk_a, rounds - 1, sb, cb);
+    }
+
+    if (__any(bad)) return false;
+    if (edge_lane >= 0) {
+        if (head_end + (n - tail_start) > 64) {
+            for (int off = 0; off < head_end + (n - tail_start); off += 64)
+                edge_samples<SDR_FMT_CI8, NT>(ring, capacity, ep, dphi, shift, step, lut, edge_lane + off, head_end, tail_start, accr, acci);
+        } else {
+            edge_samples<SDR_FMT_CI8, NT>(ring, capacity, ep, dphi, shift, step, lut, edge_lane, head_end, tail_start, accr, acci);
+        }
+    }
+    return true;
+}
+
+// True when the epoch can go through the chip-aligned routine: the code step in its range and no ring wrap within
+// the epoch plus the slack the 56-byte windows may touch.
+__device__ __forceinline__ bool chip_variant_applies(const EpochParams& ep, int64_t capacity) {
+    return ep.code_step >= kChipMinCodeStep && ep.code_step <= kChipMaxCodeStep &&
+           ep.start_sample % capacity + ep.n + 32 <= capacity;
+}
+
+}  // namespace sdr

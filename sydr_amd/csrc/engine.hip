@@ -122,6 +122,7 @@ int sdr_set_option(sdr_engine* e, const char* name, int value) {
     if (!strcmp(name, "pcps_materialise_map")) e->pcps_force_map = value != 0;
     else if (!strcmp(name, "pcps_radix_passes")) e->pcps_force_passes = value != 0;
     else if (!strcmp(name, "pcps_prn_chunk")) e->pcps_prn_chunk = value;
+    else if (!strcmp(name, "epl_no_chip_variant")) e->epl_no_chip = value != 0;
     else return sdr_fail(SDR_ERR_INVALID, "unknown option '%s'", name);
     return SDR_OK;
 }
@@ -320,7 +321,9 @@ int sdr_iq_alloc(sdr_engine* e, int64_t capacity_samples, int fmt) {
         e->iq = nullptr;
         e->iq_capacity = 0;
     }
-    size_t bytes = (size_t)capacity_samples * sdr_fmt_bytes(fmt);
+    // (256 bytes of slack behind the ring: the chip-aligned correlator loads whole 56-byte windows, whose tail
+    // may reach past the last sample of the last epoch)
+    size_t bytes = (size_t)capacity_samples * sdr_fmt_bytes(fmt) + 256;
     hipError_t err = hipMalloc(&e->iq, bytes);
     if (err != hipSuccess) {
         e->iq = nullptr;

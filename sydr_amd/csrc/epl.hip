@@ -16,6 +16,7 @@
 // advanced inside the group by 8 precomputed fp64 rotations, which agrees with
 // the reference to ~1e-12 rad (far inside the 1e-6 relative bar on accumulators).
 #include "correlator.h"
+#include "correlator_chip.h"
 
 #ifdef SDR_TRACE_WG
 // Debug build only (tools/wg_trace.py): per-workgroup start/end clock and hardware id.
@@ -39,8 +40,11 @@ constexpr int kWaves = kThreads / 64;
 // waves per SIMD -- 1.15 ms vs 0.87 ms per 32 000-item launch -- so hardware workgroup dispatch does
 // the scheduling.)
 // W: samples a lane owns per iteration of the boundary variant (16 or 8), 0 = the per-sample variant.
+#ifndef SDR_EPL_WAVES
+#define SDR_EPL_WAVES 1
+#endif
 template <int FMT, int NT, int W>
-__global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ ring, int64_t capacity,
+__global__ __launch_bounds__(kThreads, SDR_EPL_WAVES) void epl_kernel(const void* __restrict__ ring, int64_t capacity,
                                                        const sdr_epl_item* __restrict__ items,
                                                        const uint32_t* __restrict__ luts,
                                                        int lut_words, int lut_stride,
@@ -49,8 +53,9 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
                                                        double* __restrict__ out) {
     extern __shared__ double smem[];
     double* red = smem;
-    double2* prefix = reinterpret_cast<double2*>(red + kWaves * 2 * NT);          // boundary variants only: kThreads*9 slots
-    uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + (W ? kThreads * kPrefixSlots : 0));
+    double2* prefix = reinterpret_cast<double2*>(red + kWaves * 2 * NT);          // boundary variants: kThreads*9 slots; chip variant: strips + rotations
+    constexpr int kScratchSlots = W == kChipMax ? kThreads * chip_strip_slots<NT>() + kWaves * kChipMax : (W ? kThreads * kPrefixSlots : 0);
+    uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + kScratchSlots);
 
     const int tid = threadIdx.x;
 #ifdef SDR_TRACE_WG
@@ -71,7 +76,19 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
     __syncthreads();  // replica staged
 
     double accr[NT], acci[NT];
-    if (W != 0 && !epoch_wraps(ep, capacity))
+    if constexpr (W == kChipMax && FMT == SDR_FMT_CI8) {
+        // chip-aligned blocks (correlator_chip.h); an epoch it does not cover is redone per sample
+        const bool done = chip_variant_applies(ep, capacity) &&
+                          correlate_epoch_chip<NT, true>(ring, capacity, ep, dphi, K, lut, prefix, prefix + kThreads * chip_strip_slots<NT>(),
+                                                         tid, tid, kThreads, tid, accr, acci);
+        if (!done) {
+            // (its own copy of the per-epoch constants: the in-group rotations the per-sample routine wants would
+            // otherwise sit in 64 scalar registers across the whole chip-aligned path)
+            EpochConsts<NT> K2;
+            compute_constants<NT>(K2, ep, spacing + tap0, dphi, kThreads);
+            correlate_epoch<FMT, NT>(ring, capacity, ep, dphi, K2, lut, tid, kThreads, tid, accr, acci);
+        }
+    } else if (W != 0 && !epoch_wraps(ep, capacity))
         correlate_epoch_wide<FMT, NT, true, (W ? W : kWide)>(ring, capacity, ep, dphi, K, lut, prefix, tid, tid, kThreads, tid, accr, acci);
     else
         correlate_epoch<FMT, NT>(ring, capacity, ep, dphi, K, lut, tid, kThreads, tid, accr, acci);
@@ -93,15 +110,19 @@ __global__ __launch_bounds__(kThreads) void epl_kernel(const void* __restrict__ 
 template <int FMT, int NT>
 void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
                 int tap0, int n_taps_total, int lut_words, int wide, double* d_out) {
+    const size_t scratch = wide == kChipMax ? (size_t)kThreads * chip_strip_slots<NT>() + kWaves * kChipMax
+                                            : (wide ? (size_t)kThreads * kPrefixSlots : 0);
     size_t shmem = (size_t)(kWaves * 2 * NT) * sizeof(double) + (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t) +
-                   (wide ? (size_t)kThreads * kPrefixSlots * sizeof(double2) : 0);
+                   scratch * sizeof(double2);
     auto launch = [&](auto kernel) {
         if (shmem > 64u * 1024u)  // beyond the default dynamic-LDS grant (long multi-period replicas)
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(kernel, dim3(n_items), dim3(kThreads), shmem, stream, e->iq, e->iq_capacity, d_items,
                            e->luts, lut_words, e->lut_stride, d_spacing, fs, tap0, n_taps_total, d_out);
     };
-    if (wide == 16)
+    if (wide == kChipMax && FMT == SDR_FMT_CI8)
+        launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16)>);
+    else if (wide == 16)
         launch(epl_kernel<FMT, NT, 16>);
     else if (wide == 8)
         launch(epl_kernel<FMT, NT, 8>);
@@ -181,6 +202,10 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
     *lut_words = maxlen + SDR_LUT_PAD + 2;
     const bool boundary_ok = min_step >= sdr::kFastMinCodeStep && e->lut_stride < sdr::kFastMaxLutWords;
     *wide = !boundary_ok ? 0 : (max_step <= sdr::kFastMaxCodeStep ? 16 : (max_step <= sdr::kFastMaxCodeStep8 ? 8 : 0));
+    // every item inside the chip-aligned variant's range (ci8 ring): lanes own whole chips instead of 16 samples
+    if (boundary_ok && e->iq_fmt == SDR_FMT_CI8 && min_step >= sdr::kChipMinCodeStep && max_step <= sdr::kChipMaxCodeStep &&
+        !e->epl_no_chip)
+        *wide = sdr::kChipMax;
     return SDR_OK;
 }
 

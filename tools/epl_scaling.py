@@ -4,6 +4,8 @@ import numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sydr_amd.engine import Engine, make_items, FMT_CI8
 e = Engine(0)
+if '--no-chip' in sys.argv:
+    e.set_option('epl_no_chip_variant', 1)
 cap = 8 * 400000
 e.iq_alloc(cap, FMT_CI8)
 e.iq_upload(np.random.default_rng(0).integers(-60, 60, 2 * cap).astype(np.int8), 0)
