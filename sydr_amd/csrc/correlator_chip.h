@@ -60,6 +60,15 @@ __device__ __forceinline__ int chip_first_above_exact(int c, double thr, double 
     return above(c + 1) ? c + 1 : c + 2;
 }
 
+// Compile-time loop: f(integral_constant<int, I>) for I in [B, E).
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
 __device__ __forceinline__ int wave_min_i32(int x) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -89,7 +98,12 @@ struct ChipBlock {
 // expression instead.  Because every tap advances by the same T, the switch of tap t sits delta_t = const samples
 // after the block start on the real line, so its sample position is floor(delta_t) or floor(delta_t) + 1 in every
 // lane (floor(a + b) - floor(a) for b >= 0): the two LDS slots per tap are known for the whole epoch.
-template <int NT, bool SINGLE_WAVE>
+// KM > 0: the block length M is known when the kernel is compiled (the host checked that every epoch of the launch
+// has floor(samples per chip) == KM, e.g. 24 at 25 MHz): the sample loop then has a fixed trip count and the stores
+// of P_M and P_(M+1) are unconditional -- two scalar instructions per sample (bit test + branch for a tap position)
+// instead of six with two branches (measured: 0.436 -> 0.40 ms per launch; testing two samples per branch with
+// both bodies duplicated was slower again: 0.415).
+template <int NT, bool SINGLE_WAVE, int KM = 0>
 __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ring, int64_t capacity,
                                                      const EpochParams& ep, double dphi, const EpochConsts<NT>& K,
                                                      const uint32_t* lut, double2* strip_lds, double2* rot, int tid,
@@ -139,7 +153,7 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
         const int64_t Tfx = (int64_t)rint(inv_step[A] * two32);
         const int64_t Ufx = (int64_t)floor(-shift[A] * inv_step[A] * two32);
         const int M = (int)(Tfx >> 32);                                   // block length M or M + 1
-        bad = bad || M < 1 || M + 1 > kChipMax || F > 16384;
+        bad = bad || M < 1 || M + 1 > kChipMax || F > 16384 || (KM != 0 && M != KM);
         int m[NT], J[NT];
         uint64_t delta[NT];
         unsigned evmask = (1u << M) | (2u << M);
@@ -263,27 +277,53 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
             int klast = k_last;
             asm volatile("" : "+s"(evm), "+s"(klast));
             // the in-block rotations come from LDS as broadcasts, fetched a few samples ahead of their use (the
-            // uniform branches below end a basic block at every sample: nothing is hoisted across them for us)
+            // uniform branches below end a basic block: nothing is hoisted across them for us)
             constexpr int kAhead = 4;
             double2 rr[kChipMax + kAhead];
 #pragma unroll
             for (int k = 0; k < kAhead; ++k) rr[k] = rot[k];
+            auto park = [&]() {                         // P_k -> the lane's next strip slot
+                *wp = make_double2(pr, pi);
+                ++wp;
+                asm volatile("" ::: "memory");
+            };
+            auto sample = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const int w = (int)b.raw[k >> 1];
+                const double ar = (k & 1) ? (double)(int)(int8_t)(w >> 16) : (double)(int)(int8_t)w;
+                const double ai = (k & 1) ? (double)(w >> 24) : (double)(int)(int8_t)(w >> 8);
+                if (k + kAhead < kChipMax) rr[k + kAhead] = rot[k + kAhead];
+                const double2 r = rr[k];
+                pr = __builtin_fma(-ai, r.y, __builtin_fma(ar, r.x, pr));
+                pi = __builtin_fma(ai, r.x, __builtin_fma(ar, r.y, pi));
+            };
+            if constexpr (KM != 0) {
+                // positions KM and KM + 1 are always events; the others (the taps' m_t, m_t + 1 < KM) are looked for
+                // two samples at a time
+                static_for<0, KM>([&](auto kc) {         // samples below KM: a tap's position may sit in front of any of them
+                    constexpr int k = decltype(kc)::value;
+                    if (evm & (1u << k)) park();
+                    sample(kc);
+                });
+                park();                                  // P_KM
+                sample(std::integral_constant<int, KM>{});
+                park();                                  // P_(KM+1)
+            } else {
 #pragma unroll
-            for (int k = 0; k <= kChipMax; ++k) {
-                if (evm & (1u << k)) {                  // (wave-uniform) one of the positions somebody reads: park P_k
-                    *wp = make_double2(pr, pi);
-                    ++wp;
-                    asm volatile("" ::: "memory");
-                    if (k == klast) break;
-                }
-                if (k < kChipMax) {
-                    const int w = (int)b.raw[k >> 1];
-                    const double ar = (k & 1) ? (double)(int)(int8_t)(w >> 16) : (double)(int)(int8_t)w;
-                    const double ai = (k & 1) ? (double)(w >> 24) : (double)(int)(int8_t)(w >> 8);
-                    if (k + kAhead < kChipMax) rr[k + kAhead] = rot[k + kAhead];
-                    const double2 r = rr[k];
-                    pr = __builtin_fma(-ai, r.y, __builtin_fma(ar, r.x, pr));
-                    pi = __builtin_fma(ai, r.x, __builtin_fma(ar, r.y, pi));
+                for (int k = 0; k <= kChipMax; ++k) {
+                    if (evm & (1u << k)) {              // (wave-uniform) one of the positions somebody reads: park P_k
+                        park();
+                        if (k == klast) break;
+                    }
+                    if (k < kChipMax) {
+                        const int w = (int)b.raw[k >> 1];
+                        const double ar = (k & 1) ? (double)(int)(int8_t)(w >> 16) : (double)(int)(int8_t)w;
+                        const double ai = (k & 1) ? (double)(w >> 24) : (double)(int)(int8_t)(w >> 8);
+                        if (k + kAhead < kChipMax) rr[k + kAhead] = rot[k + kAhead];
+                        const double2 r = rr[k];
+                        pr = __builtin_fma(-ai, r.y, __builtin_fma(ar, r.x, pr));
+                        pi = __builtin_fma(ai, r.x, __builtin_fma(ar, r.y, pi));
+                    }
                 }
             }
             const double2 ptot = strip[rank[A] + b.dn];

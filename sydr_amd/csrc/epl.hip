@@ -43,7 +43,7 @@ constexpr int kWaves = kThreads / 64;
 #ifndef SDR_EPL_WAVES
 #define SDR_EPL_WAVES 1
 #endif
-template <int FMT, int NT, int W>
+template <int FMT, int NT, int W, int KM = 0>
 __global__ __launch_bounds__(kThreads, SDR_EPL_WAVES) void epl_kernel(const void* __restrict__ ring, int64_t capacity,
                                                        const sdr_epl_item* __restrict__ items,
                                                        const uint32_t* __restrict__ luts,
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kThreads, SDR_EPL_WAVES) void epl_kernel(const void
     if constexpr (W == kChipMax && FMT == SDR_FMT_CI8) {
         // chip-aligned blocks (correlator_chip.h); an epoch it does not cover is redone per sample
         const bool done = chip_variant_applies(ep, capacity) &&
-                          correlate_epoch_chip<NT, true>(ring, capacity, ep, dphi, K, lut, prefix, prefix + kThreads * chip_strip_slots<NT>(),
+                          correlate_epoch_chip<NT, true, KM>(ring, capacity, ep, dphi, K, lut, prefix, prefix + kThreads * chip_strip_slots<NT>(),
                                                          tid, tid, kThreads, tid, accr, acci);
         if (!done) {
             // (its own copy of the per-epoch constants: the in-group rotations the per-sample routine wants would
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kThreads, SDR_EPL_WAVES) void epl_kernel(const void
 template <int FMT, int NT>
 void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
                 int tap0, int n_taps_total, int lut_words, int wide, double* d_out) {
-    const size_t scratch = wide == kChipMax ? (size_t)kThreads * chip_strip_slots<NT>() + kWaves * kChipMax
+    const size_t scratch = wide >= kChipMax ? (size_t)kThreads * chip_strip_slots<NT>() + kWaves * kChipMax
                                             : (wide ? (size_t)kThreads * kPrefixSlots : 0);
     size_t shmem = (size_t)(kWaves * 2 * NT) * sizeof(double) + (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t) +
                    scratch * sizeof(double2);
@@ -120,7 +120,9 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
         hipLaunchKernelGGL(kernel, dim3(n_items), dim3(kThreads), shmem, stream, e->iq, e->iq_capacity, d_items,
                            e->luts, lut_words, e->lut_stride, d_spacing, fs, tap0, n_taps_total, d_out);
     };
-    if (wide == kChipMax && FMT == SDR_FMT_CI8)
+    if (wide == kChipMax + 24 && FMT == SDR_FMT_CI8)   // chip-aligned, every epoch with 24 or 25 samples per chip
+        launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24>);
+    else if (wide == kChipMax && FMT == SDR_FMT_CI8)
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16)>);
     else if (wide == 16)
         launch(epl_kernel<FMT, NT, 16>);
@@ -178,8 +180,19 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
     }
     int maxlen = 0;
     double max_step = 0.0, min_step = 1e300;
+    const double s_anchor = spacing[n_taps < 5 ? n_taps / 2 : 2];   // centre tap of the first chunk of taps the kernels serve together
+    bool all_m24 = true;
     for (int i = 0; i < n_items; ++i) {
         const sdr_epl_item& it = items[i];
+        {   // samples per chip of the anchor tap's np.linspace step, exactly as the kernel derives it (correlator_chip.h)
+            const double nd = (double)it.n_samples;
+            const double sh = it.rem_code + s_anchor;
+            double stop = it.code_step * nd;
+            stop = stop + sh;
+            const double st = (stop - sh) / nd;
+            const double inv = 1.0 / st;
+            all_m24 = all_m24 && (int)((int64_t)std::rint(inv * 4294967296.0) >> 32) == 24;
+        }
         if (it.code_step > max_step) max_step = it.code_step;
         if (it.code_step < min_step) min_step = it.code_step;
         if (it.code_slot < 0 || it.code_slot >= e->n_slots || e->code_len_host[it.code_slot] <= 0)
@@ -205,7 +218,7 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
     // every item inside the chip-aligned variant's range (ci8 ring): lanes own whole chips instead of 16 samples
     if (boundary_ok && e->iq_fmt == SDR_FMT_CI8 && min_step >= sdr::kChipMinCodeStep && max_step <= sdr::kChipMaxCodeStep &&
         !e->epl_no_chip)
-        *wide = sdr::kChipMax;
+        *wide = sdr::kChipMax + ((all_m24 && (n_taps == 3 || n_taps == 1 || n_taps == 2)) ? 24 : 0);
     return SDR_OK;
 }
 

@@ -279,3 +279,55 @@ def test_epl_randomised_stress(engine):
     spec.loader.exec_module(mod)
     checked, worst = mod.run(120, 20261003, engine)
     assert checked == 120 * 24 and worst <= EPL_RTOL
+
+
+# ------------------------------------------------------------------------------------------------ chip-aligned variant
+@pytest.mark.parametrize("spacing", [(-0.5, 0.0, 0.5), (-0.1, 0.0, 0.1), (-0.25, 0.0, 0.25), (-1.0, -0.5, 0.0, 0.5, 1.0),
+                                     (0.0,), (-0.5, 0.5), (-0.7, -0.2, 0.3, 0.9)])
+def test_chip_aligned_variant_over_its_whole_range(engine, spacing):
+    """The chip-aligned correlator (lanes own whole chips; correlator_chip.h) over its range of code steps -- 16 to 26
+    samples per chip, every block length M, with and without the compile-time M = 24 kernel -- including steps
+    whose chip switches fall EXACTLY on samples (1/20, 1/24, 1/25: the exact-evaluation path and, where taps that
+    are whole chips apart jitter, the per-sample fallback), odd and even starts, short and multi-period epochs.
+    Against the oracle, and against the 16-sample boundary variant of the same library."""
+    rng = np.random.default_rng(len(spacing) * 1000 + int(abs(spacing[0]) * 100))
+    cap = 8 * 60000
+    raw = rng.integers(-100, 100, 2 * cap).astype(np.int8)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(8, 1023, 3)
+    for s in range(8):
+        engine.load_gps_code(s, 3 * s + 2)
+    rf = orc.iq_to_complex(raw)
+    for group in range(3):
+        n_items = 48
+        if group == 0:            # the headline geometry: every item 24/25 samples per chip -> the M = 24 kernel
+            step = (1.023e6 + rng.uniform(-4, 4, n_items)) / 25e6
+        elif group == 1:          # the whole range, mixed block lengths -> the run-time-M kernel
+            step = 1.0 / rng.uniform(16.05, 25.85, n_items)
+        else:                     # switches exactly on samples
+            step = np.array([1 / 20, 1 / 24, 1 / 25, 1 / 16.5, 1 / 18, 0.05, 0.0625, 1 / 25.5] * 6)
+        rem_code = rng.uniform(0, step)
+        rem_code[:6] = [0.0, 0.5, 0.25, 1e-9, step[4] / 2, step[5] * (1 - 1e-12)]
+        periods = rng.integers(1, 3, n_items)
+        n = np.ceil((1023 * periods - rem_code) / step).astype(np.int64) + rng.integers(-1, 2, n_items)
+        n[6:10] = [3, 40, 70, 26]                      # shorter than a chip, than a wave of chips
+        start = rng.integers(0, cap - 60000, n_items)
+        start[10:14] = [0, 1, cap - int(n[12]) - 1, 2 * (int(start[13]) // 2) + 1]
+        slot = rng.integers(0, 8, n_items)
+        f = rng.uniform(-6000, 6000, n_items)
+        rem_carrier = rng.uniform(0, 2 * np.pi, n_items)
+        items = make_items(slot, n, start, f, rem_carrier, rem_code, step)
+        got = engine.epl_batch(items, spacing, 25e6)
+        engine.set_option("epl_no_chip_variant", 1)
+        try:
+            other = engine.epl_batch(items, spacing, 25e6)
+        finally:
+            engine.set_option("epl_no_chip_variant", 0)
+        for k in range(n_items):
+            x = orc.ring_slice(rf, int(start[k]), int(n[k]))
+            ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(3 * int(slot[k]) + 2)), 25e6, f[k], rem_carrier[k],
+                                   rem_code[k], step[k], spacing))
+            scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 50.0), 2)
+            assert np.max(np.abs(got[k] - ref) / scale) < 1e-9, (group, k, step[k], n[k])
+            assert np.max(np.abs(other[k] - ref) / scale) < 1e-9, (group, k)
