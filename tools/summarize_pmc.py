@@ -2,25 +2,34 @@
 """Condense rocprofv3 --pmc counter_collection CSVs (one pass per counter group, as the gfx950 guide
 prescribes) into a per-kernel summary and profiles/pmc_traffic.json (read by bench.py).
 
-    python tools/summarize_pmc.py gpurun_out/prof_r01b r01
+    python tools/summarize_pmc.py gpurun_out/prof_r02a r02a
 HBM bytes per launch = 2 * FETCH_SIZE*1024 (gfx950: FETCH_SIZE reads exactly half of a 16-B/lane
-streaming read, MI355X_MICROARCH.md section HBM) + WRITE_SIZE*1024."""
+streaming read, MI355X_MICROARCH.md section HBM) + WRITE_SIZE*1024.
+
+Kernel variants are kept apart (`epl_kernel<0, 3, 26, 24>` is the headline launch, `<0, 5, ...>` the
+multi-GNSS one); the PCPS figure is the sum over every kernel of one sdr_pcps call (calls counted by
+their one ratio_kernel dispatch)."""
 import collections
 import csv
 import glob
 import json
 import os
+import re
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PCPS = ("fft4_rows_kernel", "fft4_cols_kernel", "fft_pass_kernel", "argmax", "ratio_kernel", "peak_", "second_peak",
+        "chirp", "upsample_batch_kernel", "mix_", "twiddle_kernel")
 
 
 def short(name):
-    for key in ("epl_kernel", "track_kernel", "fft4_rows_kernel", "fft4_cols_kernel", "fft_pass_kernel", "argmax_part", "peak_finish", "synth_kernel"):
-        if key in name:
-            return key + ("<inv>" if key == "fft_pass_kernel" and ", true," in name else "")
-    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    m = re.match(r"([A-Za-z0-9_]+)(<[^>]*>)?", name)
+    base, targs = m.group(1), m.group(2) or ""
+    if base in ("epl_kernel", "track_kernel", "fft4_rows_kernel", "fft4_cols_kernel", "fft_pass_kernel"):
+        return base + targs.replace(", ", ",")
+    return base[:48]
 
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -36,17 +45,46 @@ out_csv = os.path.join(repo, "profiles", f"{tag}_pmc_summary.csv")
 with open(out_csv, "w") as f:
     f.write("kernel,counter,dispatches,mean_per_dispatch,min,max\n")
     for r in rows:
-        f.write(",".join(str(x) for x in r) + "\n")
-epl = agg.get("epl_kernel", {})
-if "FETCH_SIZE" in epl and "WRITE_SIZE" in epl:
-    fetch = sum(epl["FETCH_SIZE"]) / len(epl["FETCH_SIZE"]) * 1024
-    write = sum(epl["WRITE_SIZE"]) / len(epl["WRITE_SIZE"]) * 1024
-    info = {"epl_kernel_hbm_bytes_per_launch": 2 * fetch + write, "fetch_size_bytes_raw": fetch,
-            "write_size_bytes": write, "correction": "FETCH_SIZE doubled (gfx950, 16-B/lane streaming reads)",
-            "workload": "bench.py step: 32 ch x 1000 epochs x ~25000 samples ci8 (1.6e9 algorithmic bytes)",
-            "source": f"profiles/{tag}_pmc_summary.csv"}
-    if "SQ_INSTS_VALU" in epl:
-        info["valu_insts_per_launch"] = sum(epl["SQ_INSTS_VALU"]) / len(epl["SQ_INSTS_VALU"])
-    json.dump(info, open(os.path.join(repo, "profiles", "pmc_traffic.json"), "w"), indent=1)
-    print(json.dumps(info, indent=1))
-print(open(out_csv).read())
+        f.write(",".join(f'"{x}"' if isinstance(x, str) and "," in x else str(x) for x in r) + "\n")
+
+
+def mean(v):
+    return sum(v) / len(v)
+
+
+info = {"correction": "FETCH_SIZE doubled (gfx950, 16-B/lane streaming reads)", "source": f"profiles/{tag}_pmc_summary.csv"}
+# the headline launch: ci8, 3 taps; the full 32000-epoch launches are the dispatches with the most waves
+head = [k for k in agg if k.startswith("epl_kernel<0,3,")]
+if head:
+    k = max(head, key=lambda k: len(agg[k].get("FETCH_SIZE", [])))
+    epl = agg[k]
+
+    def full(counter):  # only the full-size launches (bench steps), not the parity checks' small ones
+        v = epl.get(counter, [])
+        if not v:
+            return None
+        big = [x for x in v if x >= 0.5 * max(v)]
+        return mean(big)
+    if full("FETCH_SIZE") is not None and full("WRITE_SIZE") is not None:
+        fetch, write = full("FETCH_SIZE") * 1024, full("WRITE_SIZE") * 1024
+        info.update({"epl_kernel": k, "epl_kernel_hbm_bytes_per_launch": 2 * fetch + write,
+                     "epl_fetch_size_bytes_raw": fetch, "epl_write_size_bytes": write,
+                     "epl_workload": "bench.py step: 32 ch x 1000 epochs x ~25000 samples ci8 (1.6e9 algorithmic bytes)"})
+    for counter, key in (("SQ_INSTS_VALU", "epl_kernel_valu_insts_per_launch"), ("SQ_INSTS_SALU", "epl_kernel_salu_insts_per_launch"),
+                         ("SQ_INSTS_LDS", "epl_kernel_lds_insts_per_launch")):
+        if full(counter) is not None:
+            info[key] = full(counter)
+calls = len(agg.get("ratio_kernel", {}).get("FETCH_SIZE", []))
+if calls:
+    fetch = write = 0.0
+    per_kernel = {}
+    for k in agg:
+        if any(k.startswith(p) for p in PCPS) and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+            f_, w_ = sum(agg[k]["FETCH_SIZE"]) * 1024 / calls, sum(agg[k]["WRITE_SIZE"]) * 1024 / calls
+            per_kernel[k] = {"read": 2 * f_, "write": w_}
+            fetch += f_
+            write += w_
+    info.update({"pcps_hbm_bytes_per_call": 2 * fetch + write, "pcps_calls_profiled": calls, "pcps_per_kernel": per_kernel,
+                 "pcps_workload": "sdr_pcps: 32 PRNs x 41 bins x 25000 samples, no map (1.05e9 algorithmic bytes)"})
+json.dump(info, open(os.path.join(repo, "profiles", "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(info, indent=1))
