@@ -343,6 +343,9 @@ def multignss_workload(args, rank, local_rank, world, torch, dist, eng=None, emi
         result["cpu_baseline"] = {"value": float(it["n_samples"]) / (n_gps + n_e1) / dt / 1e6, "unit": "Msamples/s", "cores": 1,
                                   "kind": "port", "sample": "one E1-like channel-epoch (200 000 samples, 5 taps) through "
                                   "oracle/sydr_oracle.py:epl, scaled to 64 channels", "max_rel_err_gpu_vs_oracle": err}
+    if rank == 0 and world == 1 and not args.no_closed_loop:
+        result["closed_loop"] = closed_loop_multignss_leg(eng, gps_items[:n_gps], e1_items[:n_e1], fs, taps,
+                                                          min(e_gps, e_e1, 400))
     for plan, *_ in plans:
         plan.close()
     if own_engine:
@@ -350,6 +353,52 @@ def multignss_workload(args, rank, local_rank, world, torch, dist, eng=None, emi
     if rank == 0 and emit:
         print(json.dumps(result))
     return result
+
+
+def closed_loop_multignss_leg(eng, gps_first, e1_first, fs, taps, n_epochs):
+    """Configs 4-5 with the loops closed on the device: 64 channels, 5 taps, 4 ms epochs (GPS: 4 code periods,
+    5 epochs per bit; E1-like: 8184 half chips, one symbol per epoch), Kaplan loops scaled with dt = 4 ms, one
+    configuration per channel (sdr_track_closed_loop_ex)."""
+    from sydr_amd._lib import LoopCfg, TrackState
+    states, cfgs = [], []
+    for group, half, chips, per_bit in ((gps_first, 1, 4092.0, 5), (e1_first, 2, 8184.0, 1)):
+        for it in group:
+            cfg = LoopCfg()
+            cfg.loop_kind, cfg.n_taps, cfg.fs = 1, len(taps), fs
+            # GPS: VE/E/P/L/VL at (-1, -0.5, 0, 0.5, 1) chips.  BOC(1,1): the envelope discriminator only has the right
+            # sign inside +-1/3 chip of the main peak, so E/L sit at +-0.25 chip and VE/VL on the side peaks at +-0.5
+            # chip -- (-1, -0.5, 0, 0.5, 1) in the half-chip units the doubled code is tracked in.
+            for t, sp in enumerate(taps):
+                cfg.spacing_wide[t] = cfg.spacing_narrow[t] = sp
+            wn = 2.0 * 8.0 * 0.7 / (4.0 * 0.7**2 + 1)
+            cfg.dll_tau1, cfg.dll_tau2, cfg.dll_pdi, cfg.dll_threshold = 1.0 / wn**2, 2.0 * 0.7 / wn, 0.004, 10.0
+            cfg.fll_bw_pullin, cfg.fll_bw_wide, cfg.fll_bw_narrow, cfg.fll_thr_wide, cfg.fll_thr_narrow = 20.0, 10.0, 5.0, 0.5, 0.8
+            cfg.pll_bw_wide, cfg.pll_bw_narrow, cfg.pll_thr_wide, cfg.pll_thr_narrow = 15.0, 10.0, 0.5, 0.8
+            cfg.epoch_chips, cfg.epochs_per_bit, cfg.epoch_seconds = chips, per_bit, 4e-3
+            cfgs.append(cfg)
+            st = TrackState()
+            st.code_slot, st.n_samples, st.current_sample = int(it["code_slot"]), int(it["n_samples"]), int(it["start_sample"])
+            st.carrier_hz, st.code_hz = float(it["carrier_hz"]), half * CODE_RATE
+            st.rem_carrier, st.rem_code, st.code_step = float(it["rem_carrier"]), float(it["rem_code"]), half * CODE_RATE / fs
+            st.fll_bw, st.pll_bw, st.lock_state = 20.0, 15.0, 1
+            states.append(st)
+    n_ch = len(states)
+    eng.track_closed_loop_ex([TrackState.from_buffer_copy(s) for s in states], cfgs, 10, want_traj=False)  # warm
+    eng.prof_reset()
+    eng.prof_enable(True)
+    t0 = time.perf_counter()
+    end, _, _, done = eng.track_closed_loop_ex(states, cfgs, n_epochs, want_traj=False)
+    wall = time.perf_counter() - t0
+    eng.prof_enable(False)
+    kern_ms, _ = eng.prof_read("track_kernel")
+    eng.prof_reset()
+    samples = float(np.mean([e.current_sample - s.current_sample for e, s in zip(end, states)]))
+    lost = sum(abs(e.carrier_hz - s.carrier_hz) > 100.0 for e, s in zip(end, states)) + int(np.sum(done < n_epochs))
+    return {"metric": f"closed-loop tracking, {n_ch} channels (32 GPS 4-period + 32 E1-like BOC), 5 taps, 4 ms epochs, loop "
+                      "closure on device (Kaplan FLL/PLL/DLL, dt = 4 ms)",
+            "epochs": n_epochs, "kernel_ms": kern_ms, "wall_ms": wall * 1e3, "x_realtime": samples / fs / (kern_ms * 1e-3),
+            "channel_realtimes": n_ch * samples / fs / (kern_ms * 1e-3), "us_per_epoch": kern_ms * 1e3 / n_epochs,
+            "channels_lost": int(lost)}
 
 
 def main():
@@ -531,7 +580,7 @@ def main():
         margs.stream_seconds, margs.steps, margs.warmup = 10.0, 9, 1
         m = multignss_workload(margs, rank, local_rank, world, torch, dist, emit=False)
         result["multignss"] = {k: m[k] for k in ("metric", "value", "unit", "ms_per_step", "x_realtime", "config", "roofline",
-                                                  "cpu_baseline") if k in m}
+                                                  "cpu_baseline", "closed_loop") if k in m}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SDR_ABI_VERSION 2
+#define SDR_ABI_VERSION 3
 
 typedef struct sdr_engine sdr_engine;
 
@@ -264,6 +264,9 @@ typedef struct sdr_loop_cfg {
     double epoch_chips;
     int32_t epochs_per_bit;
     int32_t reserved;
+    /* epoch duration the Kaplan discriminators / filters / C/N0 estimator are scaled with; 0 = 1e-3 s, the constant
+     * the reference hard-codes (channel_l1ca_kaplan.py:417,425,443,494).  4e-3 for the 4 ms epochs of configs 4-5. */
+    double epoch_seconds;
 } sdr_loop_cfg;
 
 /* Per-epoch record written when traj != NULL (what the reference's tracking

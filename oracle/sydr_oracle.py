@@ -327,14 +327,27 @@ def ring_slice(ring: np.ndarray, start: int, n: int) -> np.ndarray:
 # These follow the per-epoch bookkeeping of the two reference plugins on a LINEAR sample array
 # (absolute sample indices; the reference's ring modulo at kaplan:531 / borre:428 is applied by the
 # caller when a ring is used).  Navigation-bit decoding is not part of the path and is left out.
+#
+# Generalisation (BASELINE configs 4-5; the reference has no counterpart, SURVEY.md 8c -- PARITY UNPINNED BY THE
+# REFERENCE for anything but the defaults): `taps` = (wide, narrow) lists of any odd length whose centre tap is
+# the prompt and whose neighbours feed the discriminators (the outer taps are only correlated and recorded),
+# `epoch_chips` = chips per correlator epoch (code length x periods, in the units of `code`: half chips for a
+# BOC(1,1) code passed as its doubled half-chip sequence), `epochs_per_bit` = epochs per navigation symbol,
+# `dt` = the epoch duration the discriminators and filters are scaled with, `code_rate` = nominal chip rate of
+# `code`.  With the defaults every statement below is the reference's, operation for operation (pinned by
+# g6 / g6b / g6c bit for bit); the generalised arguments only replace the constants 1023, 20, 1e-3 and 1.023e6.
 
 class BorreLoop:
     """runTracking of channel_l1ca_borre.py:333-451 (DLL NNEML + Costas PLL, Borre filters)."""
 
-    def __init__(self, fs, code, cfg, carrier_hz, current_sample):
+    def __init__(self, fs, code, cfg, carrier_hz, current_sample, *, taps=None, epoch_chips=CODE_CHIPS,
+                 epochs_per_bit=MS_PER_BIT, code_rate=CODE_RATE):
         self.fs = fs
         self.code = pad_code(code)
-        self.spacing = [cfg["correlator_early"], cfg["correlator_prompt"], cfg["correlator_late"]]
+        self.spacing = [cfg["correlator_early"], cfg["correlator_prompt"], cfg["correlator_late"]] if taps is None \
+            else list(taps[0])
+        self.prompt = len(self.spacing) // 2
+        self.epoch_chips, self.epochs_per_bit = epoch_chips, epochs_per_bit
         self.dll_tau1, self.dll_tau2 = loop_coefficients(cfg["dll_noise_bandwidth"], cfg["dll_damping_ratio"],
                                                          cfg["dll_loop_gain"])
         self.pll_tau1, self.pll_tau2 = loop_coefficients(cfg["pll_noise_bandwidth"], cfg["pll_damping_ratio"],
@@ -342,11 +355,11 @@ class BorreLoop:
         self.dll_pdi = cfg["dll_pdi"]
         self.pll_pdi = cfg["pll_pdi"]
         self.carrier_hz = carrier_hz
-        self.code_hz = CODE_RATE
+        self.code_hz = code_rate
         self.rem_carrier = 0.0
         self.rem_code = 0.0
-        self.code_step = CODE_RATE / fs
-        self.n = int(np.ceil((CODE_CHIPS - self.rem_code) / self.code_step))
+        self.code_step = code_rate / fs
+        self.n = int(np.ceil((self.epoch_chips - self.rem_code) / self.code_step))
         self.current_sample = current_sample
         self.code_err_mem = 0.0
         self.carrier_err_mem = 0.0
@@ -363,40 +376,45 @@ class BorreLoop:
                    self.code_step, self.spacing)
         self.rem_carrier -= self.carrier_hz * 2.0 * np.pi * self.n / self.fs
         self.rem_carrier %= (2 * np.pi)
-        code_err = dll_nneml(corr[0], corr[1], corr[4], corr[5])
+        p = self.prompt
+        ie, qe, ip, qp, il, ql = corr[2 * p - 2:2 * p + 4]
+        code_err = dll_nneml(ie, qe, il, ql)
         nco_code = borre_filter(code_err, self.code_err_mem, self.dll_tau1, self.dll_tau2, self.dll_pdi)
         self.code_err_mem = code_err
-        phase_err = pll_costas(corr[2], corr[3])
+        phase_err = pll_costas(ip, qp)
         nco_carrier = borre_filter(phase_err, self.carrier_err_mem, self.pll_tau1, self.pll_tau2, self.pll_pdi)
         self.carrier_err_mem = phase_err
         # bit sync: first prompt sign flip after 100 epochs (channel_l1ca_borre.py:384-391,401)
         if not (self.flags & FLAG_BIT_SYNC) and (self.flags & FLAG_CODE_LOCK) and self.code_counter > 100 \
-                and np.sign(self.ip_prev) != np.sign(corr[2]):
+                and np.sign(self.ip_prev) != np.sign(ip):
             self.flags |= FLAG_BIT_SYNC
         self.flags |= FLAG_CODE_LOCK
-        self.ip_prev = corr[2]
+        self.ip_prev = ip
         self.code_counter += 1
         self.code_hz -= nco_code
         self.carrier_hz += nco_carrier
-        self.rem_code += self.n * self.code_step - CODE_CHIPS
+        self.rem_code += self.n * self.code_step - self.epoch_chips
         self.code_step = self.code_hz / self.fs
         self.current_sample += self.n
-        self.n = int(np.ceil((CODE_CHIPS - self.rem_code) / self.code_step))
+        self.n = int(np.ceil((self.epoch_chips - self.rem_code) / self.code_step))
         rec.update(corr=list(corr), dll=nco_code, pll=nco_carrier, carrier_hz=self.carrier_hz,
                    code_hz=self.code_hz, code_err=code_err, carrier_err=phase_err, flags=self.flags,
-                   nav_bit=_decode_bit(self, corr[2]))
+                   nav_bit=_decode_bit(self, ip))
         return rec
 
 
 class KaplanLoop:
     """runTracking of channel_l1ca_kaplan.py:342-619 (FLL-assisted PLL, lock-state machine)."""
 
-    def __init__(self, fs, code, cfg, carrier_hz, current_sample):
+    def __init__(self, fs, code, cfg, carrier_hz, current_sample, *, taps=None, epoch_chips=CODE_CHIPS,
+                 epochs_per_bit=MS_PER_BIT, dt=1e-3, code_rate=CODE_RATE):
         self.fs = fs
         self.code = pad_code(code)
         wide, narrow = cfg["correlator_epl_wide"], cfg["correlator_epl_narrow"]
-        self.sp_wide = [-wide, 0.0, wide]
-        self.sp_narrow = [-narrow, 0.0, narrow]
+        self.sp_wide = [-wide, 0.0, wide] if taps is None else list(taps[0])
+        self.sp_narrow = [-narrow, 0.0, narrow] if taps is None else list(taps[1])
+        self.prompt = len(self.sp_wide) // 2
+        self.epoch_chips, self.epochs_per_bit, self.dt = epoch_chips, epochs_per_bit, dt
         self.spacing = self.sp_wide
         self.dll_tau1, self.dll_tau2 = loop_coefficients(cfg["dll_noise_bandwidth"], cfg["dll_damping_ratio"],
                                                          cfg["dll_loop_gain"])
@@ -421,11 +439,11 @@ class KaplanLoop:
         self.flags = 0
         self.rem_code = 0.0
         self.rem_carrier = 0.0
-        self.code_step = CODE_RATE / fs
-        self.n = int(np.ceil((CODE_CHIPS - self.rem_code) / self.code_step))
+        self.code_step = code_rate / fs
+        self.n = int(np.ceil((self.epoch_chips - self.rem_code) / self.code_step))
         self.code_counter = 0
         self.carrier_hz = carrier_hz
-        self.code_hz = CODE_RATE
+        self.code_hz = code_rate
         self.current_sample = current_sample
         self.nav_sum, self.nav_count, self.nav_bits = 0.0, 0, []
 
@@ -437,23 +455,24 @@ class KaplanLoop:
         # runCorrelators (:378-401)
         self.corr = epl(samples, self.code, self.fs, self.carrier_hz, self.rem_carrier, self.rem_code,
                         self.code_step, self.spacing)
-        if self.accum_counter == MS_PER_BIT:
+        if self.accum_counter == self.epochs_per_bit:
             self.accum_counter = 0
         self.accum_counter += 1
-        ie, qe, ip, qp, il, ql = self.corr
+        p, dt = self.prompt, self.dt
+        ie, qe, ip, qp, il, ql = self.corr[2 * p - 2:2 * p + 4]
         # runDiscriminators (:405-430)
         fll_d = pll_d = 0.0
         if self.lock_state == LOCK_PULL_IN:
             if self.code_counter > 1:
-                fll_d = fll_atan(ip, qp, self.ip_prev, self.qp_prev, 1e-3)
+                fll_d = fll_atan(ip, qp, self.ip_prev, self.qp_prev, dt)
             dll_d = dll_nneml(ie, qe, il, ql)
         else:
-            fll_d = fll_atan(ip, qp, self.ip_prev, self.qp_prev, 1e-3)
+            fll_d = fll_atan(ip, qp, self.ip_prev, self.qp_prev, dt)
             pll_d = pll_costas(ip, qp)
             dll_d = dll_nneml(ie, qe, il, ql)
         # loop filters (:434-461)
         carrier_err, self.vel_mem = fll_assisted_pll_2nd(pll_d, fll_d, self.fll_bw / W0_BW_1, self.pll_bw / W0_BW_2,
-                                                         W0_A2, 1 * 1e-3, self.vel_mem)
+                                                         W0_A2, 1 * dt, self.vel_mem)
         code_err = borre_filter(dll_d, self.dll, self.dll_tau1, self.dll_tau2, self.dll_pdi * 1)
         # runLoopIndicators (:465-502)
         if self.code_counter != 0:
@@ -461,8 +480,8 @@ class KaplanLoop:
             if self.lock_state > LOCK_PULL_IN:
                 self.pll_lock = pll_lock_borre(ip, qp, self.pll_lock, alpha=0.005)
             self.cn0_ratio += (ip**2 + qp**2) / (abs(ip) - abs(qp)) ** 2
-            if self.accum_counter == MS_PER_BIT:
-                self.cn0 = cn0_beaulieu(self.cn0_ratio, self.accum_counter, self.accum_counter * 1e-3, self.cn0)
+            if self.accum_counter == self.epochs_per_bit:
+                self.cn0 = cn0_beaulieu(self.cn0_ratio, self.accum_counter, self.accum_counter * dt, self.cn0)
                 self.cn0_ratio = 0.0
             self.dll_lock = self.cn0
         # postTrackingUpdate (:506-534)
@@ -472,10 +491,10 @@ class KaplanLoop:
         self.rem_carrier %= GPS_TWO_PI
         self.code_hz -= code_err
         self.carrier_hz += carrier_err
-        self.rem_code += self.n * self.code_step - CODE_CHIPS
+        self.rem_code += self.n * self.code_step - self.epoch_chips
         self.code_step = self.code_hz / self.fs
         self.current_sample += self.n
-        self.n = int(np.ceil((CODE_CHIPS - self.rem_code) / self.code_step))
+        self.n = int(np.ceil((self.epoch_chips - self.rem_code) / self.code_step))
         # trackingStateUpdate (:538-619)
         if self.lock_state != LOCK_PULL_IN and self.dll_lock > self.dll_thr and not (self.flags & FLAG_CODE_LOCK):
             self.flags |= FLAG_CODE_LOCK
@@ -520,7 +539,7 @@ def _decode_bit(loop, i_prompt):
         return -1
     loop.nav_sum += i_prompt
     loop.nav_count += 1
-    if loop.nav_count != MS_PER_BIT:
+    if loop.nav_count != getattr(loop, "epochs_per_bit", MS_PER_BIT):
         return -1
     bit = 1 if loop.nav_sum > 0 else 0
     loop.nav_bits.append(bit)

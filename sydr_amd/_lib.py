@@ -64,7 +64,8 @@ class LoopCfg(C.Structure):
                 ("fll_thr_wide", C.c_double), ("fll_thr_narrow", C.c_double),
                 ("pll_bw_wide", C.c_double), ("pll_bw_narrow", C.c_double),
                 ("pll_thr_wide", C.c_double), ("pll_thr_narrow", C.c_double),
-                ("epoch_chips", C.c_double), ("epochs_per_bit", C.c_int32), ("reserved", C.c_int32)]
+                ("epoch_chips", C.c_double), ("epochs_per_bit", C.c_int32), ("reserved", C.c_int32),
+                ("epoch_seconds", C.c_double)]
 
 
 # The same records as NumPy dtypes: the host keeps the channel bank's mirror as structured arrays.
@@ -148,7 +149,7 @@ _PROTOTYPES = {
     "sdr_stream_sync": (C.c_int, [_VP, C.c_int]),
     "sdr_epl_plan_run_range_on": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int]),
 }
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

@@ -53,6 +53,7 @@ constexpr double kGpsTwoPi = kGpsPi * 2.0;
 constexpr double kGpsHalfPi = kGpsPi / 2.0;
 constexpr double kDefaultEpochChips = 1023.0;  // GPS_L1CA_CODE_SIZE_BITS (kaplan:529-532)
 constexpr int kDefaultEpochsPerBit = 20;       // LNAV_MS_PER_BIT
+constexpr double kDefaultEpochSeconds = 1e-3;  // the dt the Kaplan plugin hard-codes (kaplan:417,425,443,494)
 constexpr double kW0Bw1 = 0.25, kW0Bw2 = 0.53, kW0A2 = 1.414;
 
 enum { FLAG_CODE_LOCK = 1, FLAG_BIT_SYNC = 2 };
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     const double fs = cfg_ptr->fs;
     const double kChips = cfg_ptr->epoch_chips > 0.0 ? cfg_ptr->epoch_chips : kDefaultEpochChips;
     const int kMsPerBit = cfg_ptr->epochs_per_bit > 0 ? cfg_ptr->epochs_per_bit : kDefaultEpochsPerBit;
+    const double kDt = cfg_ptr->epoch_seconds > 0.0 ? cfg_ptr->epoch_seconds : kDefaultEpochSeconds;
     sdr_track_state& st = sh->st;
     const sdr_loop_cfg& cfg = sh->cfg;
     const bool writer = part == 0;                         // one part records trajectory, bits and the end state
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                 if (fll_err >= kGpsHalfPi) fll_err = fll_err - kGpsPi;
                 else if (fll_err <= -kGpsHalfPi) fll_err = fll_err + kGpsPi;
                 // lane 0: atan/2pi (pll_costas), lane 1: err/dt, then lane 1: (err/dt)/2pi (fll_atan)
-                const double q4 = (rlane == 1 ? fll_err : at_now) / (rlane == 1 ? 1e-3 : kGpsTwoPi);
+                const double q4 = (rlane == 1 ? fll_err : at_now) / (rlane == 1 ? kDt : kGpsTwoPi);
                 const double q5 = q4 / kGpsTwoPi;
                 const double costas = lane_value(q4, 0), fll_full = lane_value(q5, 1);
                 const double w0f = lane_value(quot, 2), w0p = lane_value(quot, 3), carrier_adv = lane_value(quot, 4);
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                             fll_d = fll_full;
                             pll_d = costas;
                         }
-                        const double upd = (pll_d * (w0p * w0p) + fll_d * w0f) * 1e-3;  // FLLassistedPLL_2ndOrder (tracking.py:246-279)
+                        const double upd = (pll_d * (w0p * w0p) + fll_d * w0f) * kDt;  // FLLassistedPLL_2ndOrder (tracking.py:246-279)
                         double carrier_err = upd + c_pll_mem;
                         c_pll_mem = upd;
                         carrier_err += pll_d * kW0A2 * w0p;
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                             l_ratio_acc += cn0_term;
                             if (l_accum == kMsPerBit) {
                                 const double lam = 1.0 / (l_ratio_acc / (double)l_accum);
-                                const double c = lam * (1.0 / ((double)l_accum * 1e-3));
+                                const double c = lam * (1.0 / ((double)l_accum * kDt));
                                 l_cn0 = (1.0 - 0.1) * l_cn0 + 0.1 * c;
                                 l_ratio_acc = 0.0;
                             }
@@ -761,8 +763,8 @@ int check_cfg(const sdr_loop_cfg* cfg, int index) {
     if (cfg->loop_kind != 0 && cfg->loop_kind != 1)
         return sdr_fail(SDR_ERR_INVALID, "channel %d: loop_kind %d is neither 0 (Borre) nor 1 (Kaplan)", index, cfg->loop_kind);
     if (!(cfg->fs > 0.0)) return sdr_fail(SDR_ERR_INVALID, "channel %d: fs must be positive", index);
-    if (cfg->epoch_chips < 0.0 || cfg->epochs_per_bit < 0)
-        return sdr_fail(SDR_ERR_INVALID, "channel %d: negative epoch_chips / epochs_per_bit", index);
+    if (cfg->epoch_chips < 0.0 || cfg->epochs_per_bit < 0 || !(cfg->epoch_seconds >= 0.0))
+        return sdr_fail(SDR_ERR_INVALID, "channel %d: negative epoch_chips / epochs_per_bit / epoch_seconds", index);
     return SDR_OK;
 }
 

@@ -117,8 +117,13 @@ class OracleBank:
         m.n, m.current_sample = int(st["n_samples"]), int(st["current_sample"])
         m.flags, m.code_counter = int(st["track_flags"]), int(st["code_counter"])
         m.nav_sum, m.nav_count, m.nav_bits = float(st["nav_prompt_sum"]), int(st["nav_sum_counter"]), []
+        nt = int(cfg["n_taps"])
+        m.prompt = nt // 2
+        m.epoch_chips = float(cfg["epoch_chips"]) if float(cfg["epoch_chips"]) > 0 else orc.CODE_CHIPS   # 0: the reference's
+        m.epochs_per_bit = int(cfg["epochs_per_bit"]) if int(cfg["epochs_per_bit"]) > 0 else orc.MS_PER_BIT
         if kaplan:
-            m.sp_wide, m.sp_narrow = list(cfg["spacing_wide"][:3]), list(cfg["spacing_narrow"][:3])
+            m.dt = float(cfg["epoch_seconds"]) if float(cfg["epoch_seconds"]) > 0 else 1e-3
+            m.sp_wide, m.sp_narrow = list(cfg["spacing_wide"][:nt]), list(cfg["spacing_narrow"][:nt])
             m.spacing = m.sp_narrow if int(st["spacing_sel"]) else m.sp_wide
             m.cfg = dict(fll_threshold_narrow=cfg["fll_thr_narrow"], pll_threshold_narrow=cfg["pll_thr_narrow"],
                          fll_threshold_wide=cfg["fll_thr_wide"], pll_threshold_wide=cfg["pll_thr_wide"],
@@ -127,7 +132,7 @@ class OracleBank:
                          fll_bandwidth_pullin=cfg["fll_bw_pullin"])
             m.cfg = {k: float(v) for k, v in m.cfg.items()}
             m.dll_thr = float(cfg["dll_threshold"])
-            m.corr, m.accum_counter = [0.0] * 6, int(st["accum_counter"])
+            m.corr, m.accum_counter = [0.0] * (2 * nt), int(st["accum_counter"])
             m.ip_prev, m.qp_prev = float(st["i_prompt_prev"]), float(st["q_prompt_prev"])
             m.cn0_ratio, m.cn0 = float(st["cn0_ratio_acc"]), float(st["cn0"])
             m.dll, m.pll, m.fll = float(st["dll_mem"]), 0.0, 0.0
@@ -135,7 +140,7 @@ class OracleBank:
             m.dll_lock, m.fll_lock, m.pll_lock = float(st["cn0"]), float(st["fll_lock"]), float(st["pll_lock"])
             m.vel_mem, m.time_in_state, m.lock_state = float(st["pll_mem"]), int(st["time_in_state"]), int(st["lock_state"])
         else:
-            m.spacing = list(cfg["spacing_wide"][:3])
+            m.spacing = list(cfg["spacing_wide"][:nt])
             m.pll_tau1, m.pll_tau2, m.pll_pdi = float(cfg["pll_tau1"]), float(cfg["pll_tau2"]), float(cfg["pll_pdi"])
             m.code_err_mem, m.carrier_err_mem = float(st["dll_mem"]), float(st["pll_mem"])
             m.ip_prev = float(st["i_prompt_prev"])

@@ -46,7 +46,7 @@ def test_struct_layouts():
     for name, (_, off) in _lib.TRACK_EPOCH_DTYPE.fields.items():
         assert getattr(_lib.TrackEpoch, name).offset == off
     assert C.sizeof(_lib.TrackState) == 8 + 8 + 15 * 8 + 6 * 4 + 8 + 2 * 4
-    assert C.sizeof(_lib.LoopCfg) == 8 + 8 + 2 * 8 * 8 + 16 * 8 + 16
+    assert C.sizeof(_lib.LoopCfg) == 8 + 8 + 2 * 8 * 8 + 16 * 8 + 16 + 8
     assert _lib.TRACK_STATE_DTYPE.itemsize == C.sizeof(_lib.TrackState) and _lib.LOOP_CFG_DTYPE.itemsize == C.sizeof(_lib.LoopCfg)
 
 

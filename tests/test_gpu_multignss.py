@@ -98,3 +98,151 @@ def test_device_synth_of_staged_boc_code_correlates(engine):
     ref = orc.epl(orc.iq_to_complex(raw), orc.pad_code(boc_doubled(code.astype(float))), fs, dop, 0.0, 0.0, 2 * cstep,
                   tuple(2 * s for s in FIVE))
     assert close(out.reshape(-1), ref)
+
+
+# ------------------------------------------------------------------------------------------------ closed loop
+# Loop closure on the device for the configs-4/5 geometry (track.hip templated on the tap count; chips per epoch,
+# epochs per symbol and the epoch duration are per-channel configuration).  Checked against the oracle's
+# generalised loops, which reduce bit for bit to the reference's trajectories at 3 taps / 1023 chips / 20 / 1 ms
+# (tests/test_oracle_golden.py::test_generalised_loop_reduces_to_the_reference).
+KAPLAN_4MS = dict(correlator_epl_wide=0.5, correlator_epl_narrow=0.25, dll_threshold=10.0, dll_damping_ratio=0.7,
+                  dll_noise_bandwidth=2.0, dll_loop_gain=1.0, dll_pdi=0.004, pll_bandwidth_wide=15.0,
+                  pll_bandwidth_narrow=10.0, pll_threshold_wide=0.3, pll_threshold_narrow=0.6,
+                  fll_bandwidth_pullin=20.0, fll_bandwidth_wide=10.0, fll_bandwidth_narrow=5.0,
+                  fll_threshold_wide=0.3, fll_threshold_narrow=0.6)
+BORRE_4MS = dict(dll_damping_ratio=0.7, dll_noise_bandwidth=1.0, dll_loop_gain=1.0, dll_pdi=0.004, pll_damping_ratio=0.7,
+                 pll_noise_bandwidth=8.0, pll_loop_gain=0.25, pll_pdi=0.004, correlator_early=-0.5, correlator_prompt=0.0,
+                 correlator_late=0.5)
+
+
+def general_cfg(kind, fs, c, wide, narrow, epoch_chips, epochs_per_bit, dt):
+    from sydr_amd._lib import LoopCfg
+    cfg = LoopCfg()
+    cfg.loop_kind, cfg.n_taps, cfg.fs = kind, len(wide), fs
+    for t in range(len(wide)):
+        cfg.spacing_wide[t], cfg.spacing_narrow[t] = wide[t], narrow[t]
+    cfg.dll_tau1, cfg.dll_tau2 = orc.loop_coefficients(c["dll_noise_bandwidth"], c["dll_damping_ratio"], c["dll_loop_gain"])
+    cfg.dll_pdi = c["dll_pdi"]
+    if kind == 0:
+        cfg.pll_tau1, cfg.pll_tau2 = orc.loop_coefficients(c["pll_noise_bandwidth"], c["pll_damping_ratio"], c["pll_loop_gain"])
+        cfg.pll_pdi = c["pll_pdi"]
+    else:
+        cfg.dll_threshold = c["dll_threshold"]
+        cfg.fll_bw_pullin, cfg.fll_bw_wide, cfg.fll_bw_narrow = c["fll_bandwidth_pullin"], c["fll_bandwidth_wide"], c["fll_bandwidth_narrow"]
+        cfg.fll_thr_wide, cfg.fll_thr_narrow = c["fll_threshold_wide"], c["fll_threshold_narrow"]
+        cfg.pll_bw_wide, cfg.pll_bw_narrow = c["pll_bandwidth_wide"], c["pll_bandwidth_narrow"]
+        cfg.pll_thr_wide, cfg.pll_thr_narrow = c["pll_threshold_wide"], c["pll_threshold_narrow"]
+    cfg.epoch_chips, cfg.epochs_per_bit, cfg.epoch_seconds = epoch_chips, epochs_per_bit, dt
+    return cfg
+
+
+def general_state(kind, fs, slot, carrier, start, code_rate, epoch_chips, c):
+    from sydr_amd._lib import TrackState
+    st = TrackState()
+    st.code_slot, st.current_sample = slot, start
+    st.carrier_hz, st.code_hz = carrier, code_rate
+    st.code_step = code_rate / fs
+    st.n_samples = int(np.ceil((epoch_chips - 0.0) / st.code_step))
+    if kind == 1:
+        st.fll_bw, st.pll_bw, st.lock_state = c["fll_bandwidth_pullin"], c["pll_bandwidth_wide"], orc.LOCK_PULL_IN
+    return st
+
+
+def check_general_trajectory(tr, ref, n_taps, kind, rtol=1e-9):
+    assert np.array_equal(tr["start_sample"], [r["start"] for r in ref])
+    assert np.array_equal(tr["n_samples"], [r["n"] for r in ref])
+    corr_ref = np.array([r["corr"] for r in ref])
+    for t in range(n_taps):
+        mag = np.hypot(corr_ref[:, 2 * t], corr_ref[:, 2 * t + 1])
+        err = np.hypot(tr["corr"][:, 2 * t] - corr_ref[:, 2 * t], tr["corr"][:, 2 * t + 1] - corr_ref[:, 2 * t + 1])
+        assert np.all(err <= rtol * np.maximum(mag, 1.0)), (t, (err / np.maximum(mag, 1.0)).max())
+
+    def near(a, b, scale=None):
+        a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+        return np.all(np.abs(a - b) <= rtol * (np.maximum(np.abs(b), 1e-300) if scale is None else scale))
+    assert near(tr["carrier_hz"], [r["carrier_hz"] for r in ref]) and near(tr["code_hz"], [r["code_hz"] for r in ref])
+    assert near(tr["carrier_err"], [r["carrier_err"] for r in ref], 1.0) and near(tr["code_err"], [r["code_err"] for r in ref], 1.0)
+    assert np.array_equal(tr["nav_bit"], [r["nav_bit"] for r in ref])
+    assert np.array_equal(tr["track_flags"], [r["flags"] for r in ref])
+    if kind == 1:
+        assert np.array_equal(tr["lock_state"], [r["lock_state"] for r in ref])
+        assert near(tr["fll_lock"], [r["fll_lock"] for r in ref], 1.0) and near(tr["pll_lock"], [r["pll_lock"] for r in ref], 1.0)
+        assert near(tr["cn0"], [r["cn0"] for r in ref], 1.0)
+
+
+@pytest.mark.parametrize("kind,parts", [(1, 0), (1, 1), (0, 4)])
+def test_closed_loop_gps_4ms_five_taps(engine, kind, parts):
+    """GPS L1 C/A tracked with 4 ms epochs (4 code periods, 5 symbols... epochs per bit) and VE/E/P/L/VL taps at 50 MHz."""
+    fs, prn, epochs = 50e6, 19, 48
+    n = int((epochs + 3) * 4e-3 * fs) // 8 * 8
+    dop, cp0 = -1830.0, 611.37
+    engine.iq_alloc(n, FMT_CI8)
+    engine.code_slots(2, 1023, max_periods=5)
+    engine.load_gps_code(1, prn)
+    engine.iq_synth([dict(prn=prn, doppler=dop, code_phase=cp0, phase=0.3, amp=7.0)], fs, 14.0, 4041, 0, n)
+    rf = orc.iq_to_complex(engine.iq_download(n, 0))
+    cstep = 1.023e6 * (1.0 + dop / 1575.42e6) / fs
+    start = int(np.ceil((1023.0 - cp0) / cstep))                      # first sample of a code period
+    c = KAPLAN_4MS if kind == 1 else BORRE_4MS
+    wide = FIVE
+    narrow = tuple(0.5 * s for s in FIVE) if kind == 1 else FIVE
+    carrier0 = dop + 12.0                                             # acquisition-grade Doppler error
+    loop_cls = orc.KaplanLoop if kind == 1 else orc.BorreLoop
+    kw = dict(taps=(wide, narrow), epoch_chips=4092, epochs_per_bit=5)
+    if kind == 1:
+        kw["dt"] = 4e-3
+    loop = loop_cls(fs, orc.gold_code(prn), c, carrier0, start, **kw)
+    ref = [loop.step(rf[loop.current_sample:loop.current_sample + loop.n]) for _ in range(epochs)]
+    cfg = general_cfg(kind, fs, c, wide, narrow, 4092.0, 5, 4e-3)
+    engine.track_cluster(parts)
+    try:
+        states, traj, bits, done = engine.track_closed_loop_ex([general_state(kind, fs, 1, carrier0, start, 1.023e6, 4092.0, c)],
+                                                               cfg, epochs, want_bits=True, epochs_per_bit=5)
+    finally:
+        engine.track_cluster(0)
+    assert done[0] == epochs
+    check_general_trajectory(traj[0], ref, 5, kind)
+    assert list(bits[0]) == loop.nav_bits
+    # the loop is on the signal
+    assert abs(traj[0]["carrier_hz"][-1] - dop) < 10.0
+    mag = np.hypot(traj[0]["corr"][-1, 0:10:2], traj[0]["corr"][-1, 1:10:2])
+    assert mag[2] > mag[1] > mag[0] and mag[2] > mag[3] > mag[4]
+
+
+@pytest.mark.parametrize("kind", [1, 0])
+def test_closed_loop_e1_like_boc_five_taps(engine, kind):
+    """A 4092-chip code with a BOC(1,1) sub-carrier tracked in half chips (8184 per 4 ms epoch, one symbol per epoch)."""
+    fs, epochs = 50e6, 40
+    n = int((epochs + 3) * 4e-3 * fs) // 8 * 8
+    rng = np.random.default_rng(407)
+    code = np.where(rng.random(4092) < 0.5, -1, 1).astype(np.int8)
+    dop, cp0 = 2210.0, 1733.6
+    engine.iq_alloc(n, FMT_CI8)
+    engine.code_slots(2, 8184)
+    engine.set_code(0, code)
+    engine.set_code(1, boc_doubled(code))
+    engine.iq_synth([dict(slot=0, boc=True, doppler=dop, code_phase=cp0, phase=0.1, amp=7.0)], fs, 14.0, 4042, 0, n)
+    rf = orc.iq_to_complex(engine.iq_download(n, 0))
+    cstep = 1.023e6 * (1.0 + dop / 1575.42e6) / fs
+    start = int(np.ceil((4092.0 - cp0) / cstep))
+    c = KAPLAN_4MS if kind == 1 else BORRE_4MS
+    # in half chips: VE/VL on the BOC side peaks (+-0.5 chip), E/L at +-0.25 chip -- inside the +-1/3 chip where the
+    # envelope discriminator has the right sign on a BOC(1,1) main peak
+    wide = FIVE
+    narrow = tuple(0.5 * s for s in FIVE) if kind == 1 else wide
+    carrier0 = dop - 9.0
+    loop_cls = orc.KaplanLoop if kind == 1 else orc.BorreLoop
+    kw = dict(taps=(wide, narrow), epoch_chips=8184, epochs_per_bit=1, code_rate=2.046e6)
+    if kind == 1:
+        kw["dt"] = 4e-3
+    loop = loop_cls(fs, boc_doubled(code.astype(float)), c, carrier0, start, **kw)
+    ref = [loop.step(rf[loop.current_sample:loop.current_sample + loop.n]) for _ in range(epochs)]
+    cfg = general_cfg(kind, fs, c, wide, narrow, 8184.0, 1, 4e-3)
+    states, traj, bits, done = engine.track_closed_loop_ex([general_state(kind, fs, 1, carrier0, start, 2.046e6, 8184.0, c)],
+                                                           cfg, epochs, want_bits=True, epochs_per_bit=1)
+    assert done[0] == epochs
+    check_general_trajectory(traj[0], ref, 5, kind)
+    assert list(bits[0]) == loop.nav_bits
+    assert abs(traj[0]["carrier_hz"][-1] - dop) < 10.0
+    mag = np.hypot(traj[0]["corr"][:, 4], traj[0]["corr"][:, 5])
+    assert mag[-8:].min() > 0.8 * 7.0 * traj[0]["n_samples"][-1]        # stays on the main peak

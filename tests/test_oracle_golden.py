@@ -228,6 +228,35 @@ def test_closed_loop_kaplan_lock_state_machine():
     assert loop.nav_bits == [int(b) for b in ref[ref[:, 24] >= 0, 24]] and len(loop.nav_bits) >= 40
 
 
+@pytest.mark.parametrize("plugin", ["borre", "kaplan_strong"])
+def test_generalised_loop_reduces_to_the_reference(plugin):
+    """Configs 4-5 run 5 taps / multi-period epochs / BOC through the loops' generalised arguments (no reference
+    counterpart).  With the reference's constants spelled out, and with two outer taps added around the reference's
+    E/P/L, the generalised loop must reproduce the golden trajectory bit for bit: the outer taps are only correlated."""
+    g, fs, raw = trajectory_iq("g6_trajectories.npz" if plugin == "borre" else "g6b_kaplan_strong.npz")
+    rf = orc.iq_to_complex(raw)
+    code = orc.gold_code(7)
+    if plugin == "borre":
+        acq, ref = g["borre_acq"], g["borre_epochs"]
+        five = [-1.0, -0.5, 0.0, 0.5, 1.0]
+        loop = orc.BorreLoop(fs, code, BORRE_CFG, acq[3], int(acq[5]), taps=(five, five), epoch_chips=1023,
+                             epochs_per_bit=20, code_rate=1.023e6)
+    else:
+        acq, ref = g["kaplan_acq"], g["kaplan_epochs"]
+        c = kaplan_strong_cfg(g)
+        w, n = c["correlator_epl_wide"], c["correlator_epl_narrow"]
+        loop = orc.KaplanLoop(fs, code, c, acq[3], int(acq[5]), taps=([-2 * w, -w, 0.0, w, 2 * w], [-2 * n, -n, 0.0, n, 2 * n]),
+                              epoch_chips=1023, epochs_per_bit=20, dt=1e-3, code_rate=1.023e6)
+    for k, row in enumerate(ref[:260]):
+        assert loop.n == int(row[1]), k
+        rec = loop.step(rf[loop.current_sample:loop.current_sample + loop.n])
+        assert len(rec["corr"]) == 10 and rec["corr"][2:8] == list(row[6:12]), k
+        assert rec["carrier_hz"] == row[15] and rec["code_hz"] == row[16], k
+        assert rec["nav_bit"] == int(row[24]) and rec["flags"] == int(row[23]), k
+        if plugin != "borre":
+            assert rec["lock_state"] == int(row[22]), k
+
+
 # ------------------------------------------------------------------------------------------------ G9 SerialSearch
 def test_serial_search_matches_reference():
     g = load_golden("g9_serial.npz")

@@ -9,7 +9,7 @@ eng = Engine(0)
 total = int(3.0 * bench.FS) // 8 * 8
 eng.iq_alloc(total, FMT_CI8)
 eng.code_slots(bench.N_CH)
-sats = bench.satellites(0)
+sats = bench.satellites()
 for s, sat in enumerate(sats):
     eng.load_gps_code(s, sat["prn"])
 eng.iq_synth(sats, bench.FS, 12.0, 20260003, 0, total)
