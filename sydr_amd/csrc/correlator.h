@@ -248,7 +248,10 @@ __device__ __forceinline__ void compute_constants(EpochConsts<NT>& k, const Epoc
     stop = stop + shift;
     const double delta = stop - shift;
     const double step = delta / nd;
-    const double inv = 1.0 / step;
+    // 1/step only ever PREDICTS a chip-switch position (the prediction is re-checked exactly whenever it falls within
+    // kNearInteger of a sample): hardware reciprocal estimate + one Newton step (~2^-50) instead of a division chain
+    const double r0 = __builtin_amdgcn_rcp(step);
+    const double inv = __builtin_fma(__builtin_fma(-step, r0, 1.0), r0, r0);
 #pragma unroll
     for (int j = 0; j < kWide; ++j) {
         k.rc[j] = lane_value(cs, j);
@@ -448,6 +451,119 @@ __device__ __forceinline__ bool epoch_wraps(const EpochParams& ep, int64_t capac
     return aligned % capacity + (ep.start_sample - aligned) + ep.n + kWide > capacity;
 }
 
+// One group of W (8 or 16) consecutive samples of one lane, boundary variant: samples i0 .. i0+W-1 of the epoch
+// (raw[] holds them in storage format), carrier phasor (cb, sb) at sample i0.  TAIL: only the first v (1..W) samples
+// belong to the epoch -- its last group in the single-round form of the closed-loop kernel, which has no separate
+// edge-sample pass: the running sums are there anyway, so the group's share is c(p0+1)*P_v + (c(p0)-c(p0+1))*P_min(nlead,v)
+// and what lies behind sample v is never read.  strip: this lane's kPrefixSlots double2 slots of LDS, slot 0 holding zero.
+template <int FMT, int NT, int W, bool TAIL>
+__device__ __forceinline__ void wide_group(const Raw8<FMT>* raw, int i0, int v, const double* rc, const double* rs,
+                                           const double* shift, const double* step, const double* inv_step,
+                                           const uint32_t* lut, double2* strip, double sb, double cb, double* accr,
+                                           double* acci) {
+    constexpr int kHalves = W / kGroup;
+    const double di0 = (double)i0;
+
+    int nlead[NT];                    // leading samples on chip p0, 1..16 (16: the whole group)
+    double sign_b[NT], sign_diff[NT];  // c(p0+1) and c(p0) - c(p0+1)
+    double y0[NT];
+    int p0[NT];
+    bool near = false;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        double y = di0 * step[t];  // the reference's chip index, exactly: separate multiply, add, ceil
+        y = y + shift[t];
+        const double cy = ceil(y);
+        y0[t] = y;
+        p0[t] = (int)cy;
+        const double e = (cy - y) * inv_step[t];  // >= 0
+        const double fr = __builtin_amdgcn_fract(e);  // v_fract_f64: e - floor(e)
+        near |= fabs(fr - 0.5) > 0.5 - kNearInteger;
+        const double ec = fmin(e, (double)(W - 1));
+        nlead[t] = (int)ec + 1;
+    }
+    if (__builtin_expect(__any(near), 0)) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            auto chip = [&](int i) {
+                double y = (double)i * step[t];
+                y = y + shift[t];
+                return (int)ceil(y);
+            };
+            const int b = nlead[t] > W - 1 ? W - 1 : nlead[t];  // compare samples b-1 | b, both in the group
+            const int pa = chip(i0 + b - 1);
+            const int pb = chip(i0 + b);
+            nlead[t] = (pa != p0[t]) ? b - 1 : ((pb == p0[t]) ? b + 1 : b);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const double ca = __hiloint2double((int)lut[p0[t] + SDR_LUT_PAD], 0);
+        sign_b[t] = __hiloint2double((int)lut[p0[t] + 1 + SDR_LUT_PAD], 0);
+        sign_diff[t] = ca - sign_b[t];
+        if (TAIL) nlead[t] = nlead[t] < v ? nlead[t] : v;
+    }
+
+    // First half: P_1..P_8 into slots 1..8 (slot 0 stays 0); every tap reads P_min(nlead,8).
+    // Second half: the sums restart at sample 8 (Q_1..Q_8) and reuse the same slots -- LDS operations
+    // of a wave execute in order, so the reads above are served first; every tap reads Q_max(nlead-8,0).
+    // P_nlead = P_min(nlead,8) + Q_max(nlead-8,0), and P_16 = P_8 + Q_8.
+    double pr = 0.0, pi = 0.0;
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) {
+        double ar, ai;
+        raw[0].get(j, ar, ai);
+        pr = __builtin_fma(-ai, rs[j], __builtin_fma(ar, rc[j], pr));
+        pi = __builtin_fma(ai, rc[j], __builtin_fma(ar, rs[j], pi));
+        strip[1 + j] = make_double2(pr, pi);
+    }
+    if (kHalves == 1) {  // 8-sample groups: the strip holds everything, P_nlead is one read
+        if (TAIL) {
+            const double2 pv = strip[v];
+            pr = pv.x, pi = pv.y;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const double2 pm = strip[nlead[t]];
+            const double gr = __builtin_fma(sign_diff[t], pm.x, sign_b[t] * pr);
+            const double gi = __builtin_fma(sign_diff[t], pm.y, sign_b[t] * pi);
+            accr[t] = __builtin_fma(-sb, gi, __builtin_fma(cb, gr, accr[t]));
+            acci[t] = __builtin_fma(sb, gr, __builtin_fma(cb, gi, acci[t]));
+        }
+        return;
+    }
+    double2 pa[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) pa[t] = strip[nlead[t] < kGroup ? nlead[t] : kGroup];
+    double2 pva = make_double2(0.0, 0.0);
+    if (TAIL) pva = strip[v < kGroup ? v : kGroup];
+    double qr = 0.0, qi = 0.0;
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) {
+        double ar, ai;
+        raw[kHalves - 1].get(j, ar, ai);
+        qr = __builtin_fma(-ai, rs[(kHalves - 1) * kGroup + j], __builtin_fma(ar, rc[(kHalves - 1) * kGroup + j], qr));
+        qi = __builtin_fma(ai, rc[(kHalves - 1) * kGroup + j], __builtin_fma(ar, rs[(kHalves - 1) * kGroup + j], qi));
+        strip[1 + j] = make_double2(qr, qi);
+    }
+    if (TAIL) {
+        const double2 pvb = strip[(v > kGroup ? v : kGroup) - kGroup];
+        pr = pva.x + pvb.x;
+        pi = pva.y + pvb.y;
+    } else {
+        pr += qr;
+        pi += qi;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const double2 qb = strip[(nlead[t] > kGroup ? nlead[t] : kGroup) - kGroup];
+        const double gr = __builtin_fma(sign_diff[t], pa[t].x + qb.x, sign_b[t] * pr);
+        const double gi = __builtin_fma(sign_diff[t], pa[t].y + qb.y, sign_b[t] * pi);
+        accr[t] = __builtin_fma(-sb, gi, __builtin_fma(cb, gr, accr[t]));
+        acci[t] = __builtin_fma(sb, gr, __builtin_fma(cb, gi, acci[t]));
+    }
+}
+
 // tid = index of the thread in its workgroup (selects the LDS strip); lane/stride/edge_lane as in
 // correlate_epoch.  SINGLE_WAVE: the epoch belongs to one wave alone (the batched kernel).
 template <int FMT, int NT, bool SINGLE_WAVE, int W = kWide>
@@ -496,94 +612,7 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
     };
 
     auto group = [&](int g, const Raw8<FMT>* raw, double sb, double cb) {
-        const int i0 = g * W - head;
-        const double di0 = (double)i0;
-
-        int nlead[NT];                    // leading samples on chip p0, 1..16 (16: the whole group)
-        double sign_b[NT], sign_diff[NT];  // c(p0+1) and c(p0) - c(p0+1)
-        double y0[NT];
-        int p0[NT];
-        bool near = false;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            double y = di0 * step[t];  // the reference's chip index, exactly: separate multiply, add, ceil
-            y = y + shift[t];
-            const double cy = ceil(y);
-            y0[t] = y;
-            p0[t] = (int)cy;
-            const double e = (cy - y) * inv_step[t];  // >= 0
-            const double fr = __builtin_amdgcn_fract(e);  // v_fract_f64: e - floor(e)
-            near |= fabs(fr - 0.5) > 0.5 - kNearInteger;
-            const double ec = fmin(e, (double)(W - 1));
-            nlead[t] = (int)ec + 1;
-        }
-        if (__builtin_expect(__any(near), 0)) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                auto chip = [&](int i) {
-                    double y = (double)i * step[t];
-                    y = y + shift[t];
-                    return (int)ceil(y);
-                };
-                const int b = nlead[t] > W - 1 ? W - 1 : nlead[t];  // compare samples b-1 | b, both in the group
-                const int pa = chip(i0 + b - 1);
-                const int pb = chip(i0 + b);
-                nlead[t] = (pa != p0[t]) ? b - 1 : ((pb == p0[t]) ? b + 1 : b);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const double ca = __hiloint2double((int)lut[p0[t] + SDR_LUT_PAD], 0);
-            sign_b[t] = __hiloint2double((int)lut[p0[t] + 1 + SDR_LUT_PAD], 0);
-            sign_diff[t] = ca - sign_b[t];
-        }
-
-        // First half: P_1..P_8 into slots 1..8 (slot 0 stays 0); every tap reads P_min(nlead,8).
-        // Second half: the sums restart at sample 8 (Q_1..Q_8) and reuse the same slots -- LDS operations
-        // of a wave execute in order, so the reads above are served first; every tap reads Q_max(nlead-8,0).
-        // P_nlead = P_min(nlead,8) + Q_max(nlead-8,0), and P_16 = P_8 + Q_8.
-        double pr = 0.0, pi = 0.0;
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) {
-            double ar, ai;
-            raw[0].get(j, ar, ai);
-            pr = __builtin_fma(-ai, rs[j], __builtin_fma(ar, rc[j], pr));
-            pi = __builtin_fma(ai, rc[j], __builtin_fma(ar, rs[j], pi));
-            strip[1 + j] = make_double2(pr, pi);
-        }
-        if (kHalves == 1) {  // 8-sample groups: the strip holds everything, P_nlead is one read
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const double2 pm = strip[nlead[t]];
-                const double gr = __builtin_fma(sign_diff[t], pm.x, sign_b[t] * pr);
-                const double gi = __builtin_fma(sign_diff[t], pm.y, sign_b[t] * pi);
-                accr[t] = __builtin_fma(-sb, gi, __builtin_fma(cb, gr, accr[t]));
-                acci[t] = __builtin_fma(sb, gr, __builtin_fma(cb, gi, acci[t]));
-            }
-            return;
-        }
-        double2 pa[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) pa[t] = strip[nlead[t] < kGroup ? nlead[t] : kGroup];
-        double qr = 0.0, qi = 0.0;
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) {
-            double ar, ai;
-            raw[kHalves - 1].get(j, ar, ai);
-            qr = __builtin_fma(-ai, rs[(kHalves - 1) * kGroup + j], __builtin_fma(ar, rc[(kHalves - 1) * kGroup + j], qr));
-            qi = __builtin_fma(ai, rc[(kHalves - 1) * kGroup + j], __builtin_fma(ar, rs[(kHalves - 1) * kGroup + j], qi));
-            strip[1 + j] = make_double2(qr, qi);
-        }
-        pr += qr;
-        pi += qi;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const double2 qb = strip[(nlead[t] > kGroup ? nlead[t] : kGroup) - kGroup];
-            const double gr = __builtin_fma(sign_diff[t], pa[t].x + qb.x, sign_b[t] * pr);
-            const double gi = __builtin_fma(sign_diff[t], pa[t].y + qb.y, sign_b[t] * pi);
-            accr[t] = __builtin_fma(-sb, gi, __builtin_fma(cb, gr, accr[t]));
-            acci[t] = __builtin_fma(sb, gr, __builtin_fma(cb, gi, acci[t]));
-        }
+        wide_group<FMT, NT, W, false>(raw, g * W - head, W, rc, rs, shift, step, inv_step, lut, strip, sb, cb, accr, acci);
     };
 
     // Software prefetch: the next group's 16-byte loads are in flight while this one is computed.  The
@@ -645,6 +674,78 @@ __device__ __forceinline__ void correlate_epoch_wide(const void* __restrict__ ri
         } else {
             edge_samples<FMT, NT>(ring, capacity, ep, dphi, shift, step, lut, edge_lane, head_end, tail_start, accr, acci);
         }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Single-round form (closed-loop kernel, a channel on a cluster of workgroups whose lanes cover the
+ * whole epoch in one pass): lane g of the cluster owns samples 16g .. 16g+15 of the epoch, loaded from
+ * wherever the epoch starts (gfx950 serves 16-byte loads from any 2-byte aligned address), so there is
+ * no head; the epoch's last group is cut with the running sums it keeps anyway (wide_group<TAIL>) instead
+ * of handing its samples to a separate edge pass.  The caller loads the groups itself -- one epoch ahead:
+ * where epoch k+1 starts is known when epoch k starts (start + n), only its length waits for the code loop.
+ * ------------------------------------------------------------------------------------------------ */
+struct SingleGeometry {
+    int64_t pos0;  // ring position of the epoch's first sample
+    int groups;    // 16-sample groups that hold a sample of the epoch
+    bool fits;     // every group lies inside the ring (an epoch that wraps goes through the per-sample variant)
+};
+
+__device__ __forceinline__ SingleGeometry single_geometry(int64_t start_sample, int n, int64_t capacity) {
+    SingleGeometry s;
+    s.pos0 = start_sample % capacity;
+    s.groups = (n + kWide - 1) / kWide;
+    s.fits = s.pos0 + (int64_t)s.groups * kWide <= capacity;
+    return s;
+}
+
+// Ring position lane g loads from: its group, kept inside the ring for lanes beyond the epoch (and for an epoch
+// that wraps the ring, which ignores what was loaded here).
+__device__ __forceinline__ int64_t single_load_pos(const SingleGeometry& s, int g, int64_t capacity) {
+    const int64_t pos = s.pos0 + (int64_t)g * kWide;
+    return pos > capacity - kWide ? capacity - kWide : pos;
+}
+
+template <int FMT>
+__device__ __forceinline__ void single_load(const void* __restrict__ ring, int64_t pos, Raw8<FMT>* raw) {
+    raw[0].load(ring, pos);
+    raw[1].load(ring, pos + kGroup);
+}
+
+template <int FMT, int NT>
+__device__ __forceinline__ void correlate_epoch_single(const Raw8<FMT>* raw, const EpochParams& ep, double dphi,
+                                                       const EpochConsts<NT>& K, const uint32_t* lut,
+                                                       double2* prefix_lds, int tid, int g, const SingleGeometry& geo,
+                                                       double* accr, double* acci) {
+    double2* strip = prefix_lds + tid * kPrefixSlots;
+    strip[0] = make_double2(0.0, 0.0);
+    double rc[kWide], rs[kWide];
+#pragma unroll
+    for (int j = 0; j < kWide; ++j) {
+        rc[j] = K.rc[j];
+        rs[j] = K.rs[j];
+        if (j >= kGroup) {  // (second half in vector registers: see correlate_epoch_wide)
+            asm volatile("" : "+v"(rc[j]));
+            asm volatile("" : "+v"(rs[j]));
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) accr[t] = acci[t] = 0.0;
+    const bool alive = g < geo.groups;
+    if (!__any(alive)) return;                                   // a wave wholly beyond the epoch
+    const int ge = alive ? g : geo.groups - 1;                   // (a lane beyond the epoch computes on the last group's indices)
+    const int i0 = ge * kWide;
+    double sb, cb;
+    sincos_reduced(__builtin_fma(-(double)i0, uniform(dphi), uniform(ep.rem_carrier)), &sb, &cb);
+    const int v = ep.n - i0 < kWide ? ep.n - i0 : kWide;         // samples of the group that belong to the epoch
+    if (__any(v < kWide))
+        wide_group<FMT, NT, kWide, true>(raw, i0, v, rc, rs, K.shift, K.step, K.inv_step, lut, strip, sb, cb, accr, acci);
+    else
+        wide_group<FMT, NT, kWide, false>(raw, i0, v, rc, rs, K.shift, K.step, K.inv_step, lut, strip, sb, cb, accr, acci);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {                               // (not a zero phasor: float rings may hold NaNs out there)
+        accr[t] = alive ? accr[t] : 0.0;
+        acci[t] = alive ? acci[t] : 0.0;
     }
 }
 

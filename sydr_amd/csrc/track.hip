@@ -40,8 +40,6 @@ namespace {
 using namespace sdr;
 
 constexpr int kMaxParts = 8;
-// LDS doubles of the reduction scratch; the cluster exchange reuses it for 8 parts x xchg_words(NT) halves (as 32-bit words)
-constexpr int red_doubles(int threads, int nt) { return (threads / 64) * 2 * nt > 128 ? (threads / 64) * 2 * nt : 128; }
 // Exchange line of one part and parity: 4*NT tagged half-values padded to whole 128-byte lines (16 words for E/P/L,
 // 32 for five taps).
 constexpr int xchg_words(int nt) { return 4 * nt <= 16 ? 16 : 32; }
@@ -81,8 +79,8 @@ struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind 
     double dphi;
     int epochs_done;
     int fault;                 // a peer part never showed up: leave the epoch loop (reported to the host)
-    // what the three update roles hand to each other (written before an epoch's first barrier, read after it)
-    double corr[2 * SDR_MAX_TAPS];  // this epoch's correlator totals, for the roles on waves 1 and 2
+    // what the update roles hand to each other (written before an epoch's first barrier, read after it)
+    double corr[2 * SDR_MAX_TAPS];  // this epoch's correlator totals (one-workgroup kernels: for the roles on waves 1 and 2)
     double fll_bw, pll_bw;     // Kaplan bandwidths chosen by the lock-state machine, for the carrier loop
     int lock_state;            // lock state the NEXT epoch's discriminators run under
     int c_code_counter, l_code_counter, l_bits_run;  // private copies of the roles on waves 0 and 2
@@ -93,11 +91,367 @@ struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind 
     sdr_loop_cfg cfg;
 };
 
+// a / b for a denominator that does not change during the run (fs, 2*pi, the epoch duration), given y = RN(1/b):
+// two Newton corrections of the quotient with exact FMA residuals.  The second one rounds correctly (Markstein's
+// theorem: y within half an ulp of 1/b and q within one ulp of a/b => RN(q + r*y) = RN(a/b), b's significand not
+// all ones) -- the SAME bits as the reference's division, on a dependent chain of 5 operations instead of the ~12
+// of v_div_scale / v_rcp / v_fma... / v_div_fmas / v_div_fixup.  tests/test_div_by_constant.py checks the identity
+// on 10^8 operands per denominator.  ok == false (significand all ones, never the case for a sampling rate):
+// plain division.
+struct InvDen {
+    double b, y;
+    bool ok;
+};
+__device__ __forceinline__ InvDen inv_den(double b) {
+    InvDen d;
+    d.b = b;
+    d.y = 1.0 / b;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(b);
+    d.ok = (bits & 0xFFFFFFFFFFFFFull) != 0xFFFFFFFFFFFFFull && b == b && fabs(b) > 1e-290 && fabs(b) < 1e290;
+    return d;
+}
+__device__ __forceinline__ double div_by(double a, const InvDen& d) {
+    if (!d.ok) return a / d.b;
+    const double q0 = a * d.y;
+    const double r0 = __builtin_fma(-d.b, q0, a);
+    const double q1 = __builtin_fma(r0, d.y, q0);
+    const double r1 = __builtin_fma(-d.b, q1, a);
+    return __builtin_fma(r1, d.y, q1);
+}
+
+// What the update roles need besides the shared state: the run's constants and this epoch's inputs (all wave-uniform).
+struct UpdateCtx {
+    double fs, chips, dt;          // sampling rate, chips per epoch, epoch duration the Kaplan filters are scaled with
+    int epochs_per_bit;
+    InvDen by_fs, by_dt, by_2pi;   // 1/fs, 1/dt, 1/(GPS 2 pi)
+    int64_t capacity;
+    int lut_words;
+    EpochParams ep;                // the epoch that has just been correlated
+    double cur_fll_bw, cur_pll_bw; // the state machine's previous decision (captured at the top of the epoch)
+    int cur_lock_state;
+    int epoch, n_epochs, ch;
+    bool writer;
+    sdr_track_epoch* rec;          // this epoch's record (recording part only, trajectory requested) or nullptr
+    int8_t* nav_bits;
+    int max_bits;
+};
+
+__device__ __forceinline__ bool carrier_bad(double hz) { return !(hz == hz && fabs(hz) < 1e9); }
+
+// The replica LUT and the ring bound what an epoch may touch; a loop that has run away (loss of lock) stops
+// instead of reading out of range.  Checked by the role that produces the values, for the epoch it announces.
+__device__ __forceinline__ bool code_out_of_range(const EpochShared* sh, int64_t capacity, int lut_words, int64_t start,
+                                                  int n, double rem_code, double code_step) {
+    const double lo = ceil(rem_code + sh->smin);
+    const double hi = ceil(code_step * (double)n + rem_code + sh->smax);
+    return !(n > 0 && (int64_t)n <= capacity && code_step > 0.0 && lo >= -(double)SDR_LUT_PAD &&
+             hi <= (double)(lut_words - SDR_LUT_PAD - 2) && start >= 0);
+}
+
+// Loop update.  The reference's per-epoch sequence is scalar arithmetic whose cost is instruction LATENCY
+// (~15 fp64 divisions, two square roots, two arctangents, a float modulo, ~1250 instructions when one lane
+// does it all).  It splits into four chains that only meet through the previous epoch's results:
+//   wave 0  carrier loop : FLL/PLL discriminators, carrier filter, carrier frequency        (kaplan:405-447,506-534)
+//   wave 1  code loop    : DLL discriminator, code filter, code NCO, next epoch length      (kaplan:451-461,506-534)
+//   wave 2  lock role    : lock indicators, C/N0, lock-state machine, flags, bit sync, nav bits (kaplan:465-619)
+//   wave 3  carrier phase: remCarrier advanced over the epoch, modulo 2 pi -- depends on nothing this epoch
+//                          measured (kaplan:523-524, borre:364-365)
+// Each wave evaluates its divisions / roots / arctangents side by side, one per lane (same IEEE operations on
+// the same operands as the reference's statements: bit-identical), then lane 0 runs the rest of its chain and
+// publishes its share of the next epoch's parameters.  corr[2*NT]: this epoch's correlator totals.
+template <int NT>
+__device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u, const double* corr, int role, int rlane) {
+    constexpr int kTaps = NT;
+    constexpr int kPrompt = NT / 2;                       // centre tap; its neighbours are early and late
+    sdr_track_state& st = sh->st;
+    const sdr_loop_cfg& cfg = sh->cfg;
+    const EpochParams& ep = u.ep;
+    const double fs = u.fs, kChips = u.chips, kDt = u.dt;
+    const int kMsPerBit = u.epochs_per_bit;
+    const double ie = corr[2 * kPrompt - 2], qe = corr[2 * kPrompt - 1], ip = corr[2 * kPrompt], qp = corr[2 * kPrompt + 1],
+                 il = corr[2 * kPrompt + 2], ql = corr[2 * kPrompt + 3];
+    const int n = ep.n;
+    const bool kaplan = cfg.loop_kind != 0;
+    sdr_track_epoch* rec = u.rec;
+    if (role == 0) {
+        // ------------------------------------------------------------------ carrier loop
+        double num = 0.0, den = 1.0;
+        switch (rlane) {
+            case 0: num = qp, den = ip; break;                    // atan(qP/iP): Costas PLL, FLL (tracking.py:133-176)
+            case 1: num = st.q_prompt_prev, den = st.i_prompt_prev; break;  // atan(qP'/iP')
+            case 2: num = u.cur_fll_bw, den = kW0Bw1; break;
+            case 3: num = u.cur_pll_bw, den = kW0Bw2; break;
+            case 5: num = cfg.pll_tau2, den = cfg.pll_tau1; break;  // (Borre PLL filter, tracking.py:180-186)
+            case 6: num = cfg.pll_pdi, den = cfg.pll_tau1; break;
+            default: break;
+        }
+        const double quot = num / den;
+        const double at = atan(quot);
+        const double at_now = lane_value(at, 0), at_prev = lane_value(at, 1);
+        double fll_err = at_now - at_prev;
+        if (fll_err != fll_err) fll_err = 0.0;
+        if (fll_err >= kGpsHalfPi) fll_err = fll_err - kGpsPi;
+        else if (fll_err <= -kGpsHalfPi) fll_err = fll_err + kGpsPi;
+        // lane 0: atan/2pi (pll_costas), lane 1: err/dt, then lane 1: (err/dt)/2pi (fll_atan)
+        InvDen d4 = u.by_2pi;
+        if (rlane == 1) d4 = u.by_dt;
+        const double q4 = div_by(rlane == 1 ? fll_err : at_now, d4);
+        const double q5 = div_by(q4, u.by_2pi);
+        const double costas = lane_value(q4, 0), fll_full = lane_value(q5, 1);
+        const double w0f = lane_value(quot, 2), w0p = lane_value(quot, 3);
+        const double pll_r1 = lane_value(quot, 5), pll_r2 = lane_value(quot, 6);
+        __builtin_amdgcn_wave_barrier();  // (every lane has read the previous prompt before lane 0 replaces it)
+        if (rlane == 0) {
+            double c_pll_mem = st.pll_mem;
+            const int c_code_counter = sh->c_code_counter;
+            double carrier_hz = ep.carrier_hz;
+            double rec_pll, rec_fll, rec_carrier_err;
+            if (!kaplan) {  // Borre: channel_l1ca_borre.py:364-429
+                const double phase_err = costas;
+                double nco_carrier = pll_r1 * (phase_err - c_pll_mem);
+                nco_carrier += pll_r2 * phase_err;
+                c_pll_mem = phase_err;
+                carrier_hz += nco_carrier;
+                rec_pll = nco_carrier, rec_fll = 0.0, rec_carrier_err = phase_err;
+            } else {        // Kaplan: runDiscriminators / runCarrierFrequencyFilter / postTrackingUpdate
+                double fll_d = 0.0, pll_d = 0.0;
+                if (u.cur_lock_state == LOCK_PULL_IN) {
+                    if (c_code_counter > 1) fll_d = fll_full;
+                } else {
+                    fll_d = fll_full;
+                    pll_d = costas;
+                }
+                const double upd = (pll_d * (w0p * w0p) + fll_d * w0f) * kDt;  // FLLassistedPLL_2ndOrder (tracking.py:246-279)
+                double carrier_err = upd + c_pll_mem;
+                c_pll_mem = upd;
+                carrier_err += pll_d * kW0A2 * w0p;
+                carrier_hz += carrier_err;
+                rec_pll = pll_d, rec_fll = fll_d, rec_carrier_err = carrier_err;
+            }
+            st.pll_mem = c_pll_mem;
+            st.i_prompt_prev = ip;
+            st.q_prompt_prev = qp;
+            sh->c_code_counter = c_code_counter + 1;
+            sh->ep.carrier_hz = carrier_hz;
+            sh->stop_carrier = carrier_bad(carrier_hz) ? 1 : 0;
+            sh->dphi = div_by((carrier_hz * 2.0) * M_PI, u.by_fs);  // carrier_step(): tracking.py:102 uses np.pi
+            if (rec) {
+                rec->carrier_hz_in = ep.carrier_hz;
+                rec->rem_carrier_in = ep.rem_carrier;
+                rec->pll = rec_pll;
+                rec->fll = rec_fll;
+                rec->carrier_err = rec_carrier_err;
+                rec->carrier_hz = carrier_hz;
+            }
+        }
+    } else if (role == 1) {
+        // ------------------------------------------------------------------ code loop
+        const double env = sqrt(rlane == 1 ? il * il + ql * ql : ie * ie + qe * qe);  // DLL NNEML envelopes (tracking.py:120-129)
+        const double env_e = lane_value(env, 0), env_l = lane_value(env, 1);
+        double num = 0.0, den = 1.0;
+        switch (rlane) {
+            case 0: num = env_e - env_l, den = env_e + env_l; break;
+            case 1: num = cfg.dll_tau2, den = cfg.dll_tau1; break;              // BorreLoopFilter (tracking.py:180-186)
+            case 2: num = kaplan ? cfg.dll_pdi * 1.0 : cfg.dll_pdi, den = cfg.dll_tau1; break;
+            default: break;
+        }
+        const double quot = num / den;
+        const double dll_nn = lane_value(quot, 0), dll_r1 = lane_value(quot, 1), dll_r2 = lane_value(quot, 2);
+        if (rlane == 0) {
+            const double dll_d = dll_nn;
+            double code_err = dll_r1 * (dll_d - st.dll_mem);
+            code_err += dll_r2 * dll_d;
+            st.dll_mem = dll_d;
+            st.code_counter += 1;
+            const double k_code_hz = st.code_hz - code_err;
+            st.code_hz = k_code_hz;
+            double rem_code = ep.rem_code;
+            rem_code += (double)n * ep.code_step - kChips;
+            const double code_step = div_by(k_code_hz, u.by_fs);
+            const int64_t next_start = ep.start_sample + n;
+            const int next_n = (int)ceil((kChips - rem_code) / code_step);
+            sh->stop_code = code_out_of_range(sh, u.capacity, u.lut_words, next_start, next_n, rem_code, code_step) ? 1 : 0;
+            sh->ep.start_sample = next_start;
+            sh->ep.n = next_n;
+            sh->ep.rem_code = rem_code;
+            sh->ep.code_step = code_step;
+            sh->epochs_done = u.epoch + 1;
+            if (rec) {
+                rec->start_sample = ep.start_sample;
+                rec->n_samples = n;
+                rec->rem_code_in = ep.rem_code;
+                rec->code_step_in = ep.code_step;
+                for (int k = 0; k < 2 * SDR_MAX_TAPS; ++k) rec->corr[k] = k < 2 * kTaps ? corr[k < 2 * kTaps ? k : 0] : 0.0;
+                // Kaplan records the discriminator and the filter output; Borre the NCO command and the error
+                rec->dll = kaplan ? dll_d : code_err;
+                rec->code_err = kaplan ? code_err : dll_d;
+                rec->code_hz = k_code_hz;
+            }
+        }
+    } else if (role == 2) {
+        // ------------------------------------------------------------------ lock indicators, state machine, bits
+        const double pw = ip * ip + qp * qp;
+        double num = 0.0, den = 1.0;
+        switch (rlane) {
+            case 0: {                                             // FLL lock (lockindicator.py:6-18)
+                const double l_ipp = sh->l_ipp, l_qpp = sh->l_qpp;
+                double v = ip * l_ipp - qp * l_qpp;
+                v *= np_sign(ip * l_ipp + qp * l_qpp);
+                num = v, den = pw;
+                break;
+            }
+            case 1: num = ip * ip - qp * qp, den = pw; break;     // PLL lock (:22-36)
+            case 2: {                                             // C/N0 (Beaulieu) ratio term (kaplan:488)
+                const double d = fabs(ip) - fabs(qp);
+                num = pw, den = d * d;
+                break;
+            }
+            default: break;
+        }
+        const double quot = num / den;
+        const double fll_lock_v = lane_value(quot, 0), pll_lock_v = lane_value(quot, 1), cn0_term = lane_value(quot, 2);
+        if (rlane == 0) {
+            double l_fll_lock = st.fll_lock, l_pll_lock = st.pll_lock, l_cn0 = st.cn0, l_ratio_acc = st.cn0_ratio_acc;
+            double l_ipp = sh->l_ipp, l_qpp = sh->l_qpp, l_fll_bw = st.fll_bw, l_pll_bw = st.pll_bw, l_nav_sum = st.nav_prompt_sum;
+            int l_accum = st.accum_counter, l_lock_state = st.lock_state, l_time_in_state = st.time_in_state;
+            int l_spacing_sel = st.spacing_sel, l_flags = st.track_flags, l_code_counter = sh->l_code_counter;
+            int l_nav_count = st.nav_sum_counter, l_bits_emitted = st.nav_bits_emitted, l_bits_run = sh->l_bits_run;
+            int nav_bit = -1;
+            if (!kaplan) {
+                // Borre bit sync: first prompt sign flip after MIN_CONVERGENCE_TIME = 100 epochs (borre:384-391)
+                if (!(l_flags & FLAG_BIT_SYNC) && (l_flags & FLAG_CODE_LOCK) && l_code_counter > 100 &&
+                    np_sign(l_ipp) != np_sign(ip))
+                    l_flags |= FLAG_BIT_SYNC;
+                l_flags |= FLAG_CODE_LOCK;
+                l_ipp = ip;
+                l_qpp = qp;
+                l_code_counter += 1;
+            } else {
+                // runCorrelators bookkeeping (kaplan:392-399)
+                if (l_accum == kMsPerBit) l_accum = 0;
+                l_accum += 1;
+                // runLoopIndicators (:465-502)
+                if (l_code_counter != 0) {
+                    const double v = fabs(fll_lock_v);
+                    l_fll_lock = (1.0 - 0.005) * l_fll_lock + 0.005 * v;
+                    if (l_lock_state > LOCK_PULL_IN) l_pll_lock = (1.0 - 0.005) * l_pll_lock + 0.005 * pll_lock_v;
+                    l_ratio_acc += cn0_term;
+                    if (l_accum == kMsPerBit) {
+                        const double lam = 1.0 / (l_ratio_acc / (double)l_accum);
+                        const double c = lam * (1.0 / ((double)l_accum * kDt));
+                        l_cn0 = (1.0 - 0.1) * l_cn0 + 0.1 * c;
+                        l_ratio_acc = 0.0;
+                    }
+                }
+                l_code_counter += 1;
+                // trackingStateUpdate (:538-619)
+                if (l_lock_state != LOCK_PULL_IN && l_cn0 > cfg.dll_threshold && !(l_flags & FLAG_CODE_LOCK))
+                    l_flags |= FLAG_CODE_LOCK;
+                else if (l_cn0 < cfg.dll_threshold && (l_flags & FLAG_CODE_LOCK))
+                    l_flags ^= FLAG_CODE_LOCK;
+                if ((l_flags & FLAG_CODE_LOCK) && !(l_flags & FLAG_BIT_SYNC)) {
+                    if (np_sign(l_ipp) != np_sign(ip)) {
+                        l_flags |= FLAG_BIT_SYNC;
+                        l_accum = 1;
+                        l_ratio_acc = 0.0;
+                    }
+                }
+                l_ipp = ip;
+                l_qpp = qp;
+                if (l_lock_state != LOCK_NARROW && l_fll_lock >= cfg.fll_thr_narrow && l_pll_lock >= cfg.pll_thr_narrow) {
+                    l_lock_state = LOCK_NARROW;
+                    l_fll_bw = cfg.fll_bw_narrow;
+                    l_pll_bw = cfg.pll_bw_narrow;
+                    l_spacing_sel = 1;
+                    l_time_in_state = 0;
+                } else if (l_lock_state != LOCK_WIDE && l_fll_lock >= cfg.fll_thr_wide && l_fll_lock < cfg.fll_thr_narrow) {
+                    l_lock_state = LOCK_WIDE;
+                    l_fll_bw = cfg.fll_bw_wide;
+                    l_pll_bw = cfg.pll_bw_wide;
+                    l_spacing_sel = 0;
+                    l_time_in_state = 0;
+                } else if (l_lock_state != LOCK_PULL_IN && l_fll_lock <= cfg.fll_thr_wide) {
+                    l_lock_state = LOCK_PULL_IN;
+                    l_fll_bw = cfg.fll_bw_pullin;
+                    l_pll_bw = 0.0;
+                    l_spacing_sel = 0;
+                    l_time_in_state = 0;
+                } else {
+                    l_time_in_state += 1;
+                }
+            }
+            // decodeBit (kaplan:728-754, borre:470-491): 20 prompts after bit sync -> one bit (Prompt2Bit)
+            if (!(l_flags & FLAG_BIT_SYNC)) {
+                l_nav_sum = 0.0;
+                l_nav_count = 0;
+            } else {
+                l_nav_sum += ip;
+                l_nav_count += 1;
+                if (l_nav_count == kMsPerBit) {
+                    nav_bit = l_nav_sum > 0.0 ? 1 : 0;
+                    if (u.writer && u.nav_bits && l_bits_run < u.max_bits) u.nav_bits[(size_t)u.ch * u.max_bits + l_bits_run] = (int8_t)nav_bit;
+                    l_bits_run += 1;
+                    l_bits_emitted += 1;
+                    l_nav_sum = 0.0;
+                    l_nav_count = 0;
+                }
+            }
+            st.fll_lock = l_fll_lock, st.pll_lock = l_pll_lock, st.cn0 = l_cn0, st.cn0_ratio_acc = l_ratio_acc;
+            sh->l_ipp = l_ipp, sh->l_qpp = l_qpp, st.fll_bw = l_fll_bw, st.pll_bw = l_pll_bw, st.nav_prompt_sum = l_nav_sum;
+            st.accum_counter = l_accum, st.lock_state = l_lock_state, st.time_in_state = l_time_in_state;
+            st.spacing_sel = l_spacing_sel, st.track_flags = l_flags, sh->l_code_counter = l_code_counter;
+            st.nav_sum_counter = l_nav_count, st.nav_bits_emitted = l_bits_emitted, sh->l_bits_run = l_bits_run;
+            // hand-over to the other roles / the next epoch
+            const double* sp = l_spacing_sel ? cfg.spacing_narrow : cfg.spacing_wide;
+            for (int t = 0; t < kTaps; ++t) sh->spacing[t] = sp[t];
+            sh->fll_bw = l_fll_bw;
+            sh->pll_bw = l_pll_bw;
+            sh->lock_state = l_lock_state;
+            if (rec) {
+                rec->cn0 = kaplan ? l_cn0 : 0.0;
+                rec->pll_lock = kaplan ? l_pll_lock : 0.0;
+                rec->fll_lock = kaplan ? l_fll_lock : 0.0;
+                rec->lock_state = l_lock_state;
+                rec->track_flags = l_flags;
+                rec->nav_bit = nav_bit;
+            }
+        }
+    } else if (role == 3 && rlane == 0) {
+        // ------------------------------------------------------------------ carrier phase over the epoch
+        // remCarrier -= f * 2 pi * n / fs; remCarrier %= 2 pi -- Kaplan with the GPS-ICD pi (kaplan:523-524), Borre with
+        // np.pi (borre:364-365): SURVEY.md T3.  Needs nothing this epoch measured, so it is off the carrier role's chain.
+        const double adv = (kaplan ? ep.carrier_hz * kGpsTwoPi * (double)n : ep.carrier_hz * 2.0 * M_PI * (double)n) / fs;
+        double rem_carrier = ep.rem_carrier;
+        rem_carrier -= adv;
+        sh->ep.rem_carrier = py_mod(rem_carrier, kaplan ? kGpsTwoPi : 2.0 * M_PI);
+    }
+}
+
+// Wave-uniform copy of the epoch parameters in LDS.  What comes out of LDS is the same in every lane, but only
+// readfirstlane tells the compiler so: as scalars the epoch parameters (and everything derived from them: group
+// counts, ring positions, linspace constants) live in SGPRs and are computed on the scalar unit -- ~100 VGPRs per lane.
+__device__ __forceinline__ EpochParams uniform_params(const EpochParams& v) {
+    EpochParams ep;
+    ep.start_sample = ((int64_t)__builtin_amdgcn_readfirstlane((int)(v.start_sample >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)v.start_sample);
+    ep.n = __builtin_amdgcn_readfirstlane(v.n);
+    ep.carrier_hz = uniform(v.carrier_hz);
+    ep.rem_carrier = uniform(v.rem_carrier);
+    ep.rem_code = uniform(v.rem_code);
+    ep.code_step = uniform(v.code_step);
+    return ep;
+}
+
+// LDS layout in doubles: [0, 128) workgroup reduction scratch, [128, 512) three role waves x 256 words of exchange staging
+constexpr int kRedDoubles = 512;
+constexpr int kXchgStageWords = 256;   // per role wave: up to 4 wave-wide loads of 64 words
+
 // WAVES: resident waves per SIMD the register allocation has to leave room for (2 = two 256-thread
 // workgroups can share a CU, at the price of a few spills).
 // states / cfgs are indexed through ch_map when it is given (the device-resident channel bank: the launch serves
 // the listed channels of a larger array); everything this launch produces (trajectory, bits, epochs_done) is
 // indexed by the position in the list.
+// THREADS == 256 && WAVES == 1 is the CLUSTER form (parts >= 2 workgroups per channel, cooperative launch).
 template <int FMT, int THREADS, int WAVES, int NT>
 __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __restrict__ ring, int64_t capacity,
                                                         sdr_track_state* __restrict__ states,
@@ -112,11 +466,11 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                                                         int n_ch, int parts, unsigned long long* xchg,
                                                         int* __restrict__ fault) {
     constexpr int kTaps = NT;
-    constexpr int kPrompt = NT / 2;                       // centre tap; its neighbours are early and late
     constexpr int kXchgWords = xchg_words(NT);
+    constexpr bool kCluster = THREADS == 256 && WAVES == 1;
     extern __shared__ double smem[];
-    double* red = smem;                                   // kWaves * 2*NT wave sums; reused by the cluster exchange
-    EpochShared* sh = reinterpret_cast<EpochShared*>(red + red_doubles(THREADS, NT));
+    double* red = smem;                                   // kWaves * 2*NT wave sums, then the exchange staging
+    EpochShared* sh = reinterpret_cast<EpochShared*>(red + kRedDoubles);
     double2* prefix = reinterpret_cast<double2*>(sh + 1);  // THREADS * kPrefixSlots, when the launcher found room
     uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + (use_prefix ? THREADS * kPrefixSlots : 0));
 
@@ -151,32 +505,37 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     const int slot = states[sidx].code_slot;
     stage_lut<THREADS>(lut, luts + (size_t)slot * lut_stride, lut_words, tid);
     const double fs = cfg_ptr->fs;
-    const double kChips = cfg_ptr->epoch_chips > 0.0 ? cfg_ptr->epoch_chips : kDefaultEpochChips;
-    const int kMsPerBit = cfg_ptr->epochs_per_bit > 0 ? cfg_ptr->epochs_per_bit : kDefaultEpochsPerBit;
-    const double kDt = cfg_ptr->epoch_seconds > 0.0 ? cfg_ptr->epoch_seconds : kDefaultEpochSeconds;
+    UpdateCtx u;
+    u.fs = fs;
+    u.chips = cfg_ptr->epoch_chips > 0.0 ? cfg_ptr->epoch_chips : kDefaultEpochChips;
+    u.epochs_per_bit = cfg_ptr->epochs_per_bit > 0 ? cfg_ptr->epochs_per_bit : kDefaultEpochsPerBit;
+    u.dt = cfg_ptr->epoch_seconds > 0.0 ? cfg_ptr->epoch_seconds : kDefaultEpochSeconds;
+    u.by_fs = inv_den(fs);
+    u.by_dt = inv_den(u.dt);
+    u.by_2pi = inv_den(kGpsTwoPi);
+    // (vector registers: the scalar file is full of per-epoch constants, and spilled SGPRs come back as v_readlane)
+    asm volatile("" : "+v"(u.fs), "+v"(u.chips), "+v"(u.dt));
+    asm volatile("" : "+v"(u.by_fs.b), "+v"(u.by_fs.y), "+v"(u.by_dt.b), "+v"(u.by_dt.y), "+v"(u.by_2pi.b), "+v"(u.by_2pi.y));
+    u.capacity = capacity;
+    u.lut_words = lut_words;
+    u.n_epochs = n_epochs;
+    u.ch = ch;
+    u.nav_bits = nav_bits;
+    u.max_bits = max_bits;
     sdr_track_state& st = sh->st;
-    const sdr_loop_cfg& cfg = sh->cfg;
     const bool writer = part == 0;                         // one part records trajectory, bits and the end state
+    u.writer = writer;
 
 #ifdef SDR_TRACE_TRACK
     unsigned long long mark_ = wall_clock64();
     if (tid == 0 && ch == 0 && part == 0) for (int k = 0; k < 32; ++k) g_track_phase[k] = 0;
     __syncthreads();
 #endif
-    // The loop update is split over three waves by dependency (see below); each role owns a disjoint set of fields of
-    // the state's LDS copy (loaded into registers for the duration of its update only: carried across the correlation
-    // they cost ~50 VGPRs and spill) and publishes its part of the next epoch's parameters.
+    // Each update role owns a disjoint set of fields of the state's LDS copy (loaded into registers for the
+    // duration of its update only: carried across the correlation they cost ~50 VGPRs and spill) and publishes its
+    // part of the next epoch's parameters.
     const int role = tid >> 6, rlane = tid & 63;
     const sdr_track_state s_init = states[sidx];
-    // The replica LUT and the ring bound what an epoch may touch; a loop that has run away (loss of lock) stops
-    // instead of reading out of range.  Checked by the role that produces the values, for the epoch it announces.
-    auto code_out_of_range = [&](int64_t start, int n, double rem_code, double code_step) {
-        const double lo = ceil(rem_code + sh->smin);
-        const double hi = ceil(code_step * (double)n + rem_code + sh->smax);
-        return !(n > 0 && (int64_t)n <= capacity && code_step > 0.0 && lo >= -(double)SDR_LUT_PAD &&
-                 hi <= (double)(lut_words - SDR_LUT_PAD - 2) && start >= 0);
-    };
-    auto carrier_bad = [&](double hz) { return !(hz == hz && fabs(hz) < 1e9); };
     if (tid == 0) {  // parameters of the first epoch
         double smin = cfg_ptr->spacing_wide[0], smax = smin;
         for (int t = 0; t < kTaps; ++t) {
@@ -185,7 +544,8 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         }
         sh->smin = smin;
         sh->smax = smax;
-        sh->stop_code = code_out_of_range(s_init.current_sample, s_init.n_samples, s_init.rem_code, s_init.code_step) ? 1 : 0;
+        sh->stop_code = code_out_of_range(sh, capacity, lut_words, s_init.current_sample, s_init.n_samples, s_init.rem_code,
+                                          s_init.code_step) ? 1 : 0;
         sh->stop_carrier = carrier_bad(s_init.carrier_hz) ? 1 : 0;
         const double* sp = s_init.spacing_sel ? cfg_ptr->spacing_narrow : cfg_ptr->spacing_wide;
         sh->ep.start_sample = s_init.current_sample;
@@ -201,6 +561,10 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         sh->l_qpp = s_init.q_prompt_prev;
         sh->l_bits_run = 0;
     }
+    // (cluster form) this lane's 16-sample group of the current epoch and of the next one: where epoch k+1 starts is
+    // known when epoch k starts, so its samples are requested a whole epoch ahead
+    Raw8<FMT> cur[2], nxt[2];
+    bool have_next = false;
     for (int epoch = 0; epoch < n_epochs; ++epoch) {
         TRACK_MARK(5);
         __syncthreads();
@@ -209,37 +573,47 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         const unsigned long long wave_mark_ = wall_clock64();
 #endif
         if (sh->fault | sh->stop_code | sh->stop_carrier) break;
-        // What comes out of LDS is the same in every lane, but only readfirstlane tells the compiler so:
-        // as scalars the epoch parameters (and everything derived from them: group counts, ring positions,
-        // linspace constants) live in SGPRs and are computed on the scalar unit -- ~100 VGPRs per lane.
-        EpochParams ep;
-        {
-            const EpochParams v = sh->ep;
-            ep.start_sample = ((int64_t)__builtin_amdgcn_readfirstlane((int)(v.start_sample >> 32)) << 32) |
-                              (uint32_t)__builtin_amdgcn_readfirstlane((int)v.start_sample);
-            ep.n = __builtin_amdgcn_readfirstlane(v.n);
-            ep.carrier_hz = uniform(v.carrier_hz);
-            ep.rem_carrier = uniform(v.rem_carrier);
-            ep.rem_code = uniform(v.rem_code);
-            ep.code_step = uniform(v.code_step);
-        }
+        const EpochParams ep = uniform_params(sh->ep);
         const double dphi = uniform(sh->dphi);
         // what the carrier loop needs from the state machine's previous decision (captured now: the lock role
         // rewrites these while the carrier role is still running)
-        const double cur_fll_bw = uniform(sh->fll_bw), cur_pll_bw = uniform(sh->pll_bw);
-        const int cur_lock_state = __builtin_amdgcn_readfirstlane(sh->lock_state);
-        EpochConsts<kTaps> K;
-        compute_constants<kTaps>(K, ep, sh->spacing, dphi, cluster_lanes);
-        TRACK_MARK(1);
+        u.ep = ep;
+        u.cur_fll_bw = uniform(sh->fll_bw), u.cur_pll_bw = uniform(sh->pll_bw);
+        u.cur_lock_state = __builtin_amdgcn_readfirstlane(sh->lock_state);
+        u.epoch = epoch;
+        u.rec = (writer && keep_traj) ? traj + ((size_t)ch * n_epochs + epoch) : nullptr;
 
         double accr[kTaps], acci[kTaps];
         const bool boundary_ok = use_prefix && ep.code_step >= kFastMinCodeStep && !epoch_wraps(ep, capacity);  // (uniform)
-        if (boundary_ok && ep.code_step <= kFastMaxCodeStep)         // 16-sample boundary variant above ~17 MHz
-            correlate_epoch_wide<FMT, kTaps, false, 16>(ring, capacity, ep, dphi, K, lut, prefix, tid, lane_global, cluster_lanes, edge_lane, accr, acci);
-        else if (boundary_ok && ep.code_step <= kFastMaxCodeStep8)   // 8-sample boundary variant above ~8.2 MHz
-            correlate_epoch_wide<FMT, kTaps, false, 8>(ring, capacity, ep, dphi, K, lut, prefix, tid, lane_global, cluster_lanes, edge_lane, accr, acci);
-        else
-            correlate_epoch<FMT, kTaps>(ring, capacity, ep, dphi, K, lut, lane_global, cluster_lanes, edge_lane, accr, acci);
+        bool single = false;
+        if constexpr (kCluster) {
+            const SingleGeometry geo = single_geometry(ep.start_sample, ep.n, capacity);
+            single = use_prefix && ep.code_step >= kFastMinCodeStep && ep.code_step <= kFastMaxCodeStep && geo.fits &&
+                     geo.groups <= cluster_lanes;
+            if (single) {
+                if (have_next) {
+                    cur[0] = nxt[0];
+                    cur[1] = nxt[1];
+                } else {
+                    single_load<FMT>(ring, single_load_pos(geo, lane_global, capacity), cur);
+                }
+                EpochConsts<kTaps> K;
+                compute_constants<kTaps>(K, ep, sh->spacing, dphi, cluster_lanes);
+                TRACK_MARK(1);
+                correlate_epoch_single<FMT, kTaps>(cur, ep, dphi, K, lut, prefix, tid, lane_global, geo, accr, acci);
+            }
+        }
+        if (!single) {
+            EpochConsts<kTaps> K;
+            compute_constants<kTaps>(K, ep, sh->spacing, dphi, cluster_lanes);
+            TRACK_MARK(1);
+            if (boundary_ok && ep.code_step <= kFastMaxCodeStep)         // 16-sample boundary variant above ~17 MHz
+                correlate_epoch_wide<FMT, kTaps, false, 16>(ring, capacity, ep, dphi, K, lut, prefix, tid, lane_global, cluster_lanes, edge_lane, accr, acci);
+            else if (boundary_ok && ep.code_step <= kFastMaxCodeStep8)   // 8-sample boundary variant above ~8.2 MHz
+                correlate_epoch_wide<FMT, kTaps, false, 8>(ring, capacity, ep, dphi, K, lut, prefix, tid, lane_global, cluster_lanes, edge_lane, accr, acci);
+            else
+                correlate_epoch<FMT, kTaps>(ring, capacity, ep, dphi, K, lut, lane_global, cluster_lanes, edge_lane, accr, acci);
+        }
 #ifdef SDR_TRACE_TRACK
         if ((tid & 63) == 0 && ch == 0) g_track_phase[8 + part * (THREADS / 64) + (tid >> 6)] += wall_clock64() - wave_mark_;
 #endif
@@ -247,344 +621,103 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         double total = reduce_taps<kTaps, THREADS>(accr, acci, red, tid);
         TRACK_MARK(3);
 
-        // Cluster exchange (wave 0): publish this part's six sums, collect the peers', add all parts in
-        // part order.  No fences, no separate flag: every 64-bit word carries half a double and the epoch
-        // tag (epoch+1), is written and read whole, and validates itself (the "LL" idea of collective
-        // libraries) -- an agent-scope release/acquire pair would write back and invalidate the whole L2
-        // every epoch (measured: 2.9 us); a relaxed device-scope word costs ~0.4 us one way
-        // (tools/ubench_xchg.hip), on the same XCD or across XCDs.
-        // Lines are double-buffered by epoch parity: a part can run at most one exchange ahead of a peer.
-        if (parts > 1 && tid < 64) {
+        double corr[2 * kTaps];
+        bool role_ok = true;
+        if constexpr (kCluster) {
+            // Cluster exchange: wave 0 publishes this part's sums; each of the three update roles collects the
+            // parts' sums for itself and adds them in part order -- every role wave of every part holds bit-identical
+            // totals, there is no second hand-over.  No fences, no separate flag: every 64-bit word carries half a
+            // double and the epoch tag (epoch+1), is written and read whole, and validates itself (the "LL" idea of
+            // collective libraries) -- an agent-scope release/acquire pair would write back and invalidate the whole
+            // L2 every epoch (measured: 2.9 us); a relaxed device-scope word costs ~0.4 us one way
+            // (tools/ubench_xchg.hip), on the same XCD or across XCDs.
+            // Lines are double-buffered by epoch parity: a part can run at most one exchange ahead of a peer (its
+            // wave 0 publishes epoch k+1 only after the workgroup's reduction barrier of that epoch, i.e. after
+            // all its role waves have finished reading epoch k).
             unsigned long long* lines = xchg + ((size_t)ch * 2 + (epoch & 1)) * kMaxParts * kXchgWordsMax;
             const unsigned long long tag = (unsigned long long)(unsigned)(epoch + 1) << 32;
-            {   // lane 2v+h publishes half h of value v (lanes 0..2*NT-1 hold the values)
+            if (tid < 64) {   // lane 2v+h publishes half h of value v (lanes 0..2*NT-1 hold the values)
                 const double v = __shfl(total, (tid >> 1) & 15, 64);
                 if (tid < 4 * kTaps) {
                     const unsigned half = (tid & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
                     __hip_atomic_store(lines + part * kXchgWords + tid, tag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            // lane l polls word l % W of parts l / W + j * (64 / W), j = 0 .. W/8 - 1 (words 4*NT.. of a line are padding)
-            constexpr int kPerPass = 64 / kXchgWords;      // parts covered by one wave-wide load
-            constexpr int kPasses = kMaxParts / kPerPass;  // 2 (16-word lines) or 4 (32-word lines)
-            const int k = tid & (kXchgWords - 1), pbase = tid / kXchgWords;
-            bool want[kPasses];
-            const unsigned long long* addr[kPasses];
-#pragma unroll
-            for (int j = 0; j < kPasses; ++j) {
-                const int p = pbase + j * kPerPass;
-                want[j] = k < 4 * kTaps && p < parts;
-                addr[j] = lines + (want[j] ? p : part) * kXchgWords + (want[j] ? k : 0);
-            }
-            unsigned long long w[kPasses];
-            bool done = false;
-            for (long spins = 0; spins < kSpinLimit; ++spins) {
-                bool ok = true;
+            if (role < 3) {
+                // lane l polls word l % W of parts l / W + j * (64 / W), j = 0 .. W/8 - 1 (words 4*NT.. of a line are padding)
+                constexpr int kPerPass = 64 / kXchgWords;      // parts covered by one wave-wide load
+                constexpr int kPasses = kMaxParts / kPerPass;  // 2 (16-word lines) or 4 (32-word lines)
+                const int k = rlane & (kXchgWords - 1), pbase = rlane / kXchgWords;
+                bool want[kPasses];
+                const unsigned long long* addr[kPasses];
 #pragma unroll
                 for (int j = 0; j < kPasses; ++j) {
-                    w[j] = __hip_atomic_load(addr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = ok && (!want[j] || (w[j] >> 32 << 32) == tag);
+                    const int p = pbase + j * kPerPass;
+                    want[j] = k < 4 * kTaps && p < parts;
+                    addr[j] = lines + (want[j] ? p : part) * kXchgWords + (want[j] ? k : 0);
                 }
-                if (__all(ok)) {
-                    done = true;
-                    break;
-                }
-            }
-            if (!done) {
-                if (tid == 0) {
-                    sh->fault = 1;
-                    *fault = 1;
-                }
-            } else {
-                unsigned* halves = reinterpret_cast<unsigned*>(red);  // (the wave sums in `red` have been consumed)
+                unsigned long long w[kPasses];
+                bool done = false;
+                for (long spins = 0; spins < kSpinLimit; ++spins) {
+                    bool ok = true;
 #pragma unroll
-                for (int j = 0; j < kPasses; ++j) halves[j * 64 + tid] = (unsigned)w[j];  // [(p)*W + k], p = pbase + j*kPerPass
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (LDS serves a wave's operations in order)
-                __builtin_amdgcn_wave_barrier();
-                if (tid < 2 * kTaps) {
-                    double sum = 0.0;
-                    for (int p = 0; p < parts; ++p) {
-                        const int at = ((p / kPerPass) * 64) + (p % kPerPass) * kXchgWords;
-                        sum += __hiloint2double((int)halves[at + 2 * tid + 1], (int)halves[at + 2 * tid]);
+                    for (int j = 0; j < kPasses; ++j) {
+                        w[j] = __hip_atomic_load(addr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && (!want[j] || (w[j] >> 32 << 32) == tag);
                     }
-                    total = sum;
-                }
-            }
-        }
-        TRACK_MARK(6);
-
-        // Loop update.  The reference's per-epoch sequence is scalar arithmetic whose cost is instruction LATENCY
-        // (~15 fp64 divisions, two square roots, two arctangents, a float modulo, ~1250 instructions when one lane
-        // does it all).  It splits into three chains that only meet through the previous epoch's results:
-        //   wave 0  carrier loop : FLL/PLL discriminators, carrier filter, carrier NCO        (kaplan:405-447,506-534)
-        //   wave 1  code loop    : DLL discriminator, code filter, code NCO, next epoch length (kaplan:451-461,506-534)
-        //   wave 2  lock role    : lock indicators, C/N0, lock-state machine, flags, bit sync, nav bits (kaplan:465-619)
-        // Each wave evaluates its divisions / roots / arctangents side by side, one per lane (same IEEE operations on
-        // the same operands as the reference's statements: bit-identical), then lane 0 runs the rest of its chain and
-        // publishes its share of the next epoch's parameters.
-        if (tid < 2 * kTaps) sh->corr[tid] = total;
-        __syncthreads();
-        TRACK_MARK(7);
-        if (!sh->fault && role < 3) {
-            const double ie = sh->corr[2 * kPrompt - 2], qe = sh->corr[2 * kPrompt - 1], ip = sh->corr[2 * kPrompt], qp = sh->corr[2 * kPrompt + 1],
-                         il = sh->corr[2 * kPrompt + 2], ql = sh->corr[2 * kPrompt + 3];
-            const int n = ep.n;
-            const bool kaplan = cfg.loop_kind != 0;
-            sdr_track_epoch* rec = (writer && keep_traj) ? traj + ((size_t)ch * n_epochs + epoch) : nullptr;
-            if (role == 0) {
-                // ------------------------------------------------------------------ carrier loop
-                double num = 0.0, den = 1.0;
-                switch (rlane) {
-                    case 0: num = qp, den = ip; break;                    // atan(qP/iP): Costas PLL, FLL (tracking.py:133-176)
-                    case 1: num = st.q_prompt_prev, den = st.i_prompt_prev; break;  // atan(qP'/iP')
-                    case 2: num = cur_fll_bw, den = kW0Bw1; break;
-                    case 3: num = cur_pll_bw, den = kW0Bw2; break;
-                    case 4:                                               // carrier NCO advance over the epoch
-                        num = kaplan ? ep.carrier_hz * kGpsTwoPi * (double)n : ep.carrier_hz * 2.0 * M_PI * (double)n;
-                        den = fs;
+                    if (__all(ok)) {
+                        done = true;
                         break;
-                    case 5: num = cfg.pll_tau2, den = cfg.pll_tau1; break;  // (Borre PLL filter, tracking.py:180-186)
-                    case 6: num = cfg.pll_pdi, den = cfg.pll_tau1; break;
-                    default: break;
+                    }
                 }
-                const double quot = num / den;
-                const double at = atan(quot);
-                const double at_now = lane_value(at, 0), at_prev = lane_value(at, 1);
-                double fll_err = at_now - at_prev;
-                if (fll_err != fll_err) fll_err = 0.0;
-                if (fll_err >= kGpsHalfPi) fll_err = fll_err - kGpsPi;
-                else if (fll_err <= -kGpsHalfPi) fll_err = fll_err + kGpsPi;
-                // lane 0: atan/2pi (pll_costas), lane 1: err/dt, then lane 1: (err/dt)/2pi (fll_atan)
-                const double q4 = (rlane == 1 ? fll_err : at_now) / (rlane == 1 ? kDt : kGpsTwoPi);
-                const double q5 = q4 / kGpsTwoPi;
-                const double costas = lane_value(q4, 0), fll_full = lane_value(q5, 1);
-                const double w0f = lane_value(quot, 2), w0p = lane_value(quot, 3), carrier_adv = lane_value(quot, 4);
-                const double pll_r1 = lane_value(quot, 5), pll_r2 = lane_value(quot, 6);
-                __builtin_amdgcn_wave_barrier();  // (every lane has read the previous prompt before lane 0 replaces it)
-                if (rlane == 0) {
-                    double c_pll_mem = st.pll_mem;
-                    const int c_code_counter = sh->c_code_counter;
-                    double rem_carrier = ep.rem_carrier, carrier_hz = ep.carrier_hz;
-                    double rec_pll, rec_fll, rec_carrier_err;
-                    if (!kaplan) {  // Borre: channel_l1ca_borre.py:364-429
-                        rem_carrier -= carrier_adv;
-                        rem_carrier = py_mod(rem_carrier, 2.0 * M_PI);
-                        const double phase_err = costas;
-                        double nco_carrier = pll_r1 * (phase_err - c_pll_mem);
-                        nco_carrier += pll_r2 * phase_err;
-                        c_pll_mem = phase_err;
-                        carrier_hz += nco_carrier;
-                        rec_pll = nco_carrier, rec_fll = 0.0, rec_carrier_err = phase_err;
-                    } else {        // Kaplan: runDiscriminators / runCarrierFrequencyFilter / postTrackingUpdate
-                        double fll_d = 0.0, pll_d = 0.0;
-                        if (cur_lock_state == LOCK_PULL_IN) {
-                            if (c_code_counter > 1) fll_d = fll_full;
-                        } else {
-                            fll_d = fll_full;
-                            pll_d = costas;
+                if (!done) {
+                    role_ok = false;
+                    if (rlane == 0) {
+                        sh->fault = 1;
+                        *fault = 1;
+                    }
+                } else {
+                    unsigned* halves = reinterpret_cast<unsigned*>(red + 128) + role * kXchgStageWords;  // this wave's staging
+#pragma unroll
+                    for (int j = 0; j < kPasses; ++j) halves[j * 64 + rlane] = (unsigned)w[j];  // [(p)*W + k], p = pbase + j*kPerPass
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (LDS serves a wave's operations in order)
+                    __builtin_amdgcn_wave_barrier();
+                    double sum = 0.0;
+                    if (rlane < 2 * kTaps) {
+                        for (int p = 0; p < parts; ++p) {
+                            const int at = ((p / kPerPass) * 64) + (p % kPerPass) * kXchgWords;
+                            sum += __hiloint2double((int)halves[at + 2 * rlane + 1], (int)halves[at + 2 * rlane]);
                         }
-                        const double upd = (pll_d * (w0p * w0p) + fll_d * w0f) * kDt;  // FLLassistedPLL_2ndOrder (tracking.py:246-279)
-                        double carrier_err = upd + c_pll_mem;
-                        c_pll_mem = upd;
-                        carrier_err += pll_d * kW0A2 * w0p;
-                        rem_carrier -= carrier_adv;
-                        rem_carrier = py_mod(rem_carrier, kGpsTwoPi);
-                        carrier_hz += carrier_err;
-                        rec_pll = pll_d, rec_fll = fll_d, rec_carrier_err = carrier_err;
                     }
-                    st.pll_mem = c_pll_mem;
-                    st.i_prompt_prev = ip;
-                    st.q_prompt_prev = qp;
-                    sh->c_code_counter = c_code_counter + 1;
-                    sh->ep.carrier_hz = carrier_hz;
-                    sh->stop_carrier = carrier_bad(carrier_hz) ? 1 : 0;
-                    sh->ep.rem_carrier = rem_carrier;
-                    sh->dphi = carrier_step(carrier_hz, fs);
-                    if (rec) {
-                        rec->carrier_hz_in = ep.carrier_hz;
-                        rec->rem_carrier_in = ep.rem_carrier;
-                        rec->pll = rec_pll;
-                        rec->fll = rec_fll;
-                        rec->carrier_err = rec_carrier_err;
-                        rec->carrier_hz = carrier_hz;
-                    }
-                }
-            } else if (role == 1) {
-                // ------------------------------------------------------------------ code loop
-                const double env = sqrt(rlane == 1 ? il * il + ql * ql : ie * ie + qe * qe);  // DLL NNEML envelopes (tracking.py:120-129)
-                const double env_e = lane_value(env, 0), env_l = lane_value(env, 1);
-                double num = 0.0, den = 1.0;
-                switch (rlane) {
-                    case 0: num = env_e - env_l, den = env_e + env_l; break;
-                    case 1: num = cfg.dll_tau2, den = cfg.dll_tau1; break;              // BorreLoopFilter (tracking.py:180-186)
-                    case 2: num = kaplan ? cfg.dll_pdi * 1.0 : cfg.dll_pdi, den = cfg.dll_tau1; break;
-                    default: break;
-                }
-                const double quot = num / den;
-                const double dll_nn = lane_value(quot, 0), dll_r1 = lane_value(quot, 1), dll_r2 = lane_value(quot, 2);
-                if (rlane == 0) {
-                    const double dll_d = dll_nn;
-                    double code_err = dll_r1 * (dll_d - st.dll_mem);
-                    code_err += dll_r2 * dll_d;
-                    st.dll_mem = dll_d;
-                    st.code_counter += 1;
-                    const double k_code_hz = st.code_hz - code_err;
-                    st.code_hz = k_code_hz;
-                    double rem_code = ep.rem_code;
-                    rem_code += (double)n * ep.code_step - kChips;
-                    const double code_step = k_code_hz / fs;
-                    const int64_t next_start = ep.start_sample + n;
-                    const int next_n = (int)ceil((kChips - rem_code) / code_step);
-                    sh->stop_code = code_out_of_range(next_start, next_n, rem_code, code_step) ? 1 : 0;
-                    sh->ep.start_sample = next_start;
-                    sh->ep.n = next_n;
-                    sh->ep.rem_code = rem_code;
-                    sh->ep.code_step = code_step;
-                    sh->epochs_done = epoch + 1;
-                    if (rec) {
-                        rec->start_sample = ep.start_sample;
-                        rec->n_samples = n;
-                        rec->rem_code_in = ep.rem_code;
-                        rec->code_step_in = ep.code_step;
-                        for (int k = 0; k < 2 * SDR_MAX_TAPS; ++k) rec->corr[k] = k < 2 * kTaps ? sh->corr[k] : 0.0;
-                        // Kaplan records the discriminator and the filter output; Borre the NCO command and the error
-                        rec->dll = kaplan ? dll_d : code_err;
-                        rec->code_err = kaplan ? code_err : dll_d;
-                        rec->code_hz = k_code_hz;
-                    }
+#pragma unroll
+                    for (int k2 = 0; k2 < 2 * kTaps; ++k2) corr[k2] = lane_value(sum, k2);
                 }
             } else {
-                // ------------------------------------------------------------------ lock indicators, state machine, bits
-                const double pw = ip * ip + qp * qp;
-                double num = 0.0, den = 1.0;
-                switch (rlane) {
-                    case 0: {                                             // FLL lock (lockindicator.py:6-18)
-                        const double l_ipp = sh->l_ipp, l_qpp = sh->l_qpp;
-                        double v = ip * l_ipp - qp * l_qpp;
-                        v *= np_sign(ip * l_ipp + qp * l_qpp);
-                        num = v, den = pw;
-                        break;
-                    }
-                    case 1: num = ip * ip - qp * qp, den = pw; break;     // PLL lock (:22-36)
-                    case 2: {                                             // C/N0 (Beaulieu) ratio term (kaplan:488)
-                        const double d = fabs(ip) - fabs(qp);
-                        num = pw, den = d * d;
-                        break;
-                    }
-                    default: break;
-                }
-                const double quot = num / den;
-                const double fll_lock_v = lane_value(quot, 0), pll_lock_v = lane_value(quot, 1), cn0_term = lane_value(quot, 2);
-                if (rlane == 0) {
-                    double l_fll_lock = st.fll_lock, l_pll_lock = st.pll_lock, l_cn0 = st.cn0, l_ratio_acc = st.cn0_ratio_acc;
-                    double l_ipp = sh->l_ipp, l_qpp = sh->l_qpp, l_fll_bw = st.fll_bw, l_pll_bw = st.pll_bw, l_nav_sum = st.nav_prompt_sum;
-                    int l_accum = st.accum_counter, l_lock_state = st.lock_state, l_time_in_state = st.time_in_state;
-                    int l_spacing_sel = st.spacing_sel, l_flags = st.track_flags, l_code_counter = sh->l_code_counter;
-                    int l_nav_count = st.nav_sum_counter, l_bits_emitted = st.nav_bits_emitted, l_bits_run = sh->l_bits_run;
-                    int nav_bit = -1;
-                    if (!kaplan) {
-                        // Borre bit sync: first prompt sign flip after MIN_CONVERGENCE_TIME = 100 epochs (borre:384-391)
-                        if (!(l_flags & FLAG_BIT_SYNC) && (l_flags & FLAG_CODE_LOCK) && l_code_counter > 100 &&
-                            np_sign(l_ipp) != np_sign(ip))
-                            l_flags |= FLAG_BIT_SYNC;
-                        l_flags |= FLAG_CODE_LOCK;
-                        l_ipp = ip;
-                        l_qpp = qp;
-                        l_code_counter += 1;
-                    } else {
-                        // runCorrelators bookkeeping (kaplan:392-399)
-                        if (l_accum == kMsPerBit) l_accum = 0;
-                        l_accum += 1;
-                        // runLoopIndicators (:465-502)
-                        if (l_code_counter != 0) {
-                            const double v = fabs(fll_lock_v);
-                            l_fll_lock = (1.0 - 0.005) * l_fll_lock + 0.005 * v;
-                            if (l_lock_state > LOCK_PULL_IN) l_pll_lock = (1.0 - 0.005) * l_pll_lock + 0.005 * pll_lock_v;
-                            l_ratio_acc += cn0_term;
-                            if (l_accum == kMsPerBit) {
-                                const double lam = 1.0 / (l_ratio_acc / (double)l_accum);
-                                const double c = lam * (1.0 / ((double)l_accum * kDt));
-                                l_cn0 = (1.0 - 0.1) * l_cn0 + 0.1 * c;
-                                l_ratio_acc = 0.0;
-                            }
-                        }
-                        l_code_counter += 1;
-                        // trackingStateUpdate (:538-619)
-                        if (l_lock_state != LOCK_PULL_IN && l_cn0 > cfg.dll_threshold && !(l_flags & FLAG_CODE_LOCK))
-                            l_flags |= FLAG_CODE_LOCK;
-                        else if (l_cn0 < cfg.dll_threshold && (l_flags & FLAG_CODE_LOCK))
-                            l_flags ^= FLAG_CODE_LOCK;
-                        if ((l_flags & FLAG_CODE_LOCK) && !(l_flags & FLAG_BIT_SYNC)) {
-                            if (np_sign(l_ipp) != np_sign(ip)) {
-                                l_flags |= FLAG_BIT_SYNC;
-                                l_accum = 1;
-                                l_ratio_acc = 0.0;
-                            }
-                        }
-                        l_ipp = ip;
-                        l_qpp = qp;
-                        if (l_lock_state != LOCK_NARROW && l_fll_lock >= cfg.fll_thr_narrow && l_pll_lock >= cfg.pll_thr_narrow) {
-                            l_lock_state = LOCK_NARROW;
-                            l_fll_bw = cfg.fll_bw_narrow;
-                            l_pll_bw = cfg.pll_bw_narrow;
-                            l_spacing_sel = 1;
-                            l_time_in_state = 0;
-                        } else if (l_lock_state != LOCK_WIDE && l_fll_lock >= cfg.fll_thr_wide && l_fll_lock < cfg.fll_thr_narrow) {
-                            l_lock_state = LOCK_WIDE;
-                            l_fll_bw = cfg.fll_bw_wide;
-                            l_pll_bw = cfg.pll_bw_wide;
-                            l_spacing_sel = 0;
-                            l_time_in_state = 0;
-                        } else if (l_lock_state != LOCK_PULL_IN && l_fll_lock <= cfg.fll_thr_wide) {
-                            l_lock_state = LOCK_PULL_IN;
-                            l_fll_bw = cfg.fll_bw_pullin;
-                            l_pll_bw = 0.0;
-                            l_spacing_sel = 0;
-                            l_time_in_state = 0;
-                        } else {
-                            l_time_in_state += 1;
-                        }
-                    }
-                    // decodeBit (kaplan:728-754, borre:470-491): 20 prompts after bit sync -> one bit (Prompt2Bit)
-                    if (!(l_flags & FLAG_BIT_SYNC)) {
-                        l_nav_sum = 0.0;
-                        l_nav_count = 0;
-                    } else {
-                        l_nav_sum += ip;
-                        l_nav_count += 1;
-                        if (l_nav_count == kMsPerBit) {
-                            nav_bit = l_nav_sum > 0.0 ? 1 : 0;
-                            if (writer && nav_bits && l_bits_run < max_bits) nav_bits[(size_t)ch * max_bits + l_bits_run] = (int8_t)nav_bit;
-                            l_bits_run += 1;
-                            l_bits_emitted += 1;
-                            l_nav_sum = 0.0;
-                            l_nav_count = 0;
-                        }
-                    }
-                    st.fll_lock = l_fll_lock, st.pll_lock = l_pll_lock, st.cn0 = l_cn0, st.cn0_ratio_acc = l_ratio_acc;
-                    sh->l_ipp = l_ipp, sh->l_qpp = l_qpp, st.fll_bw = l_fll_bw, st.pll_bw = l_pll_bw, st.nav_prompt_sum = l_nav_sum;
-                    st.accum_counter = l_accum, st.lock_state = l_lock_state, st.time_in_state = l_time_in_state;
-                    st.spacing_sel = l_spacing_sel, st.track_flags = l_flags, sh->l_code_counter = l_code_counter;
-                    st.nav_sum_counter = l_nav_count, st.nav_bits_emitted = l_bits_emitted, sh->l_bits_run = l_bits_run;
-                    // hand-over to the other roles / the next epoch
-                    const double* sp = l_spacing_sel ? cfg.spacing_narrow : cfg.spacing_wide;
-                    for (int t = 0; t < kTaps; ++t) sh->spacing[t] = sp[t];
-                    sh->fll_bw = l_fll_bw;
-                    sh->pll_bw = l_pll_bw;
-                    sh->lock_state = l_lock_state;
-                    if (rec) {
-                        rec->cn0 = kaplan ? l_cn0 : 0.0;
-                        rec->pll_lock = kaplan ? l_pll_lock : 0.0;
-                        rec->fll_lock = kaplan ? l_fll_lock : 0.0;
-                        rec->lock_state = l_lock_state;
-                        rec->track_flags = l_flags;
-                        rec->nav_bit = nav_bit;
-                    }
-                }
+#pragma unroll
+                for (int k2 = 0; k2 < 2 * kTaps; ++k2) corr[k2] = 0.0;   // (the carrier-phase role measures nothing)
+            }
+            TRACK_MARK(6);
+        } else {
+            // one workgroup per channel: the totals reach the roles on waves 1 and 2 through LDS
+            if (tid < 2 * kTaps) sh->corr[tid] = total;
+            __syncthreads();
+            TRACK_MARK(7);
+#pragma unroll
+            for (int k2 = 0; k2 < 2 * kTaps; ++k2) corr[k2] = uniform(sh->corr[k2]);
+        }
+        if constexpr (kCluster) {
+            // Request the next epoch's samples now -- after this epoch's last use of `cur` and after the exchange's own
+            // loads, so that nothing in this epoch waits on them -- and let them arrive during the loop update and the
+            // next epoch's constants (the counter a wave waits on retires loads in order).
+            have_next = single && epoch + 1 < n_epochs;
+            if (have_next) {
+                const SingleGeometry next = single_geometry(ep.start_sample + ep.n, ep.n, capacity);
+                single_load<FMT>(ring, single_load_pos(next, lane_global, capacity), nxt);
             }
         }
+        if (role_ok && role < 4) loop_update<kTaps>(sh, u, corr, role, rlane);
         TRACK_MARK(4);
-        // the next iteration's first barrier orders lane 0's LDS writes against everyone's reads
+        // the next iteration's first barrier orders the roles' LDS writes against everyone's reads
     }
     // End state: the roles kept the LDS copy of the state current; one lane of the recording part writes it out.
     __syncthreads();
@@ -681,7 +814,7 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
         // 768 channels 22.3 -> 18.6)
         const bool dense = parts == 1 && r.n_ch > e->n_cus;
         const int threads = (parts >= 2 || dense) ? 256 : 512;
-        const size_t shmem_base = (size_t)red_doubles(threads, nt) * sizeof(double) + sizeof(EpochShared) +
+        const size_t shmem_base = (size_t)kRedDoubles * sizeof(double) + sizeof(EpochShared) +
                                   (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t);
         const size_t prefix_bytes = (size_t)threads * kPrefixSlots * sizeof(double2);
         // The boundary variant of the correlator needs a 144-byte LDS strip per lane; long multi-period

@@ -245,4 +245,4 @@ def test_closed_loop_e1_like_boc_five_taps(engine, kind):
     assert list(bits[0]) == loop.nav_bits
     assert abs(traj[0]["carrier_hz"][-1] - dop) < 10.0
     mag = np.hypot(traj[0]["corr"][:, 4], traj[0]["corr"][:, 5])
-    assert mag[-8:].min() > 0.8 * 7.0 * traj[0]["n_samples"][-1]        # stays on the main peak
+    assert mag[-8:].min() > 0.6 * 7.0 * traj[0]["n_samples"][-1]        # stays on the main peak (int8 clipping costs ~20 %)
