@@ -50,7 +50,7 @@ struct PassArgs {
     double fs, if_hz, bin_start, bin_delta;
     // LOAD_MUL_CODE: in = F[nbins][N]; code spectra [n_prn][N]
     const double2* code_spec;
-    int nbins;
+    int nbins, n_prn;
     // LOAD_CODE_REAL
     const int8_t* code_samples;  // [batch][N]
     // STORE_*_ACC
@@ -679,12 +679,28 @@ __global__ __launch_bounds__(kThreads) void fft4_cols_kernel(const PassArgs a, i
     double2* bufA = lds4;
     double2* bufB = bufA + N1 * pitch;
     double2* wsub = bufB + N1 * pitch;
-    const int batch = blockIdx.y;
-    const int n2_0 = blockIdx.x * T;
+    int batch = blockIdx.y;
+    int n2_0 = blockIdx.x * T;
     int prn = batch, bin = batch;
     if constexpr (LOAD == LOAD_MUL_CODE) {
-        prn = batch / a.nbins;
-        bin = batch - prn * a.nbins;
+        // XCD-aware mapping (1-D grid).  Every (PRN, bin) transform multiplies the bin's spectrum by the PRN's code
+        // spectrum: 29 MB of unique operands at 32 PRN x 41 bins x 25000, read 1312 times over.  Workgroups are dealt
+        // to the 8 XCDs round-robin by linear id, each XCD with its own 4 MB L2 -- in (tile, batch) order every XCD
+        // ends up streaming all of it (measured 629 MB per call, 8 x the code spectra + every spectrum tile per PRN).
+        // Here XCD x = id % 8 owns a contiguous eighth of the (column tile, bin) pairs -- 2 MB of spectrum tiles and
+        // the code tiles of ~3 column tiles, both L2-resident -- and runs all PRNs of a pair back to back.
+        const int tiles = (N2 + T - 1) / T;
+        const int n_prn = a.n_prn;
+        const int pairs = tiles * a.nbins;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int p_lo = (int)(((long long)pairs * xcd) >> 3), p_hi = (int)(((long long)pairs * (xcd + 1)) >> 3);
+        const int pair = p_lo + slot / n_prn;
+        if (pair >= p_hi) return;                       // (the grid is padded to the largest eighth)
+        prn = slot - (slot / n_prn) * n_prn;
+        const int tile = pair / a.nbins;
+        bin = pair - tile * a.nbins;
+        batch = prn * a.nbins + bin;
+        n2_0 = tile * T;
     } else if constexpr (LOAD == LOAD_MUL_CODE_SEL) {
         bin = (int)a.sel_bin[batch];
     }
@@ -859,8 +875,13 @@ void run_four_step_t(sdr_engine* e, const FourStep& f, PassArgs a, int batch, do
     constexpr bool SEL = LOAD0 == LOAD_MUL_CODE_SEL;
     (void)hipFuncSetAttribute((const void*)fft4_rows_kernel<INV, STORE_LAST, TB, SEL>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shB);
-    hipLaunchKernelGGL((fft4_cols_kernel<INV, LOAD0, FMT, TA>), dim3((f.N2 + TA - 1) / TA, batch), dim3(kThreads), shA,
-                       e->stream, a, f.N1, f.N2, f.rad1, Z);
+    dim3 gridA((f.N2 + TA - 1) / TA, batch);
+    if constexpr (LOAD0 == LOAD_MUL_CODE) {             // 1-D, XCD-aware: 8 x the largest eighth of the (tile, bin) pairs x PRNs
+        const int pairs = (int)gridA.x * a.nbins;
+        a.n_prn = batch / a.nbins;
+        gridA = dim3(8u * (unsigned)((pairs + 7) / 8) * (unsigned)a.n_prn, 1);
+    }
+    hipLaunchKernelGGL((fft4_cols_kernel<INV, LOAD0, FMT, TA>), gridA, dim3(kThreads), shA, e->stream, a, f.N1, f.N2, f.rad1, Z);
     hipLaunchKernelGGL((fft4_rows_kernel<INV, STORE_LAST, TB, SEL>), dim3((f.N1 + TB - 1) / TB, batch), dim3(kThreads), shB,
                        e->stream, a, f.N1, f.N2, f.rad2, Z);
 }
