@@ -380,6 +380,12 @@ def closed_loop_multignss_leg(eng, gps_first, e1_first, fs, taps, n_epochs):
             st.code_slot, st.n_samples, st.current_sample = int(it["code_slot"]), int(it["n_samples"]), int(it["start_sample"])
             st.carrier_hz, st.code_hz = float(it["carrier_hz"]), half * CODE_RATE
             st.rem_carrier, st.rem_code, st.code_step = float(it["rem_carrier"]), float(it["rem_code"]), half * CODE_RATE / fs
+            if half == 2:
+                # the BOC(1,1) main peak is +-1/3 chip wide: the code NCO starts carrier-aided (code Doppler =
+                # Doppler * 1.023e6 / 1575.42e6, up to 2.9 chips/s here) instead of at the nominal rate the reference's
+                # GPS plugin starts from, which a 2 Hz DLL cannot pull in before the replica has left the peak
+                st.code_step = float(it["code_step"])
+                st.code_hz = st.code_step * fs
             st.fll_bw, st.pll_bw, st.lock_state = 20.0, 15.0, 1
             states.append(st)
     n_ch = len(states)

@@ -13,7 +13,7 @@ n_ms, n_ch = 400, 32
 eng = Engine(0)
 total = int(n_ms * 1e-3 * FS) // 8 * 8
 eng.iq_alloc(total, FMT_CI8); eng.code_slots(32)
-sats = bench.satellites(0)[:n_ch]
+sats = bench.satellites()[:n_ch]
 eng.iq_synth(sats, FS, 12.0, 20260003, 0, total)
 raw = eng.iq_download(total, 0)
 rf = RFSignal(dict(filepath="none", sampling_frequency=FS, is_complex="true", intermediate_frequency=0.0, data_size=8))
