@@ -528,6 +528,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
 
 #ifdef SDR_TRACE_TRACK
     unsigned long long mark_ = wall_clock64();
+    const unsigned long long clk0_ = clock64(), wall0_ = wall_clock64();   // shader clock the kernel really runs at
     if (tid == 0 && ch == 0 && part == 0) for (int k = 0; k < 32; ++k) g_track_phase[k] = 0;
     __syncthreads();
 #endif
@@ -719,6 +720,12 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         TRACK_MARK(4);
         // the next iteration's first barrier orders the roles' LDS writes against everyone's reads
     }
+#ifdef SDR_TRACE_TRACK
+    if (tid == 0 && ch == 0 && part == 0) {
+        g_track_phase[30] = clock64() - clk0_;
+        g_track_phase[31] = wall_clock64() - wall0_;
+    }
+#endif
     // End state: the roles kept the LDS copy of the state current; one lane of the recording part writes it out.
     __syncthreads();
     if (tid == 0 && writer) {

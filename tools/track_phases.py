@@ -24,3 +24,5 @@ tot = float(buf[:8].sum())
 for n, v in zip(names, buf[:8]):
     print(f"{n:16s} {float(v)*10/1e3/2000:8.2f} us/epoch  {100.0*float(v)/tot:5.1f} %")
 print("per-wave arrival at the reduction (us after the epoch's first barrier):", " ".join(f"{float(v)*10/1e3/2000:.2f}" for v in buf[8:24]))
+if buf[31]:
+    print(f"shader clock during the kernel: {float(buf[30]) / (float(buf[31]) * 10e-9) / 1e6:.0f} MHz")
