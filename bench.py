@@ -294,7 +294,7 @@ def multignss_workload(args, rank, local_rank, world, torch, dist, eng=None, emi
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=("cpu" if os.environ.get("SYDR_BENCH_REHEARSE") == "1" else "cuda"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     eng.prof_enable(False)
@@ -307,7 +307,7 @@ def multignss_workload(args, rank, local_rank, world, torch, dist, eng=None, emi
     stream_samples = ch_samples / (n_gps + n_e1)
     job = float(ch_samples)
     if world > 1:
-        t = torch.tensor([job], dtype=torch.float64, device="cuda")
+        t = torch.tensor([job], dtype=torch.float64, device=("cpu" if os.environ.get("SYDR_BENCH_REHEARSE") == "1" else "cuda"))
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         job = float(t.item())
     value = job / (n_gps + n_e1) / elapsed / 1e6
@@ -434,10 +434,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the correlator engine has no CPU path")
+    # SYDR_BENCH_REHEARSE=1: every rank on device 0, gloo instead of RCCL -- runs the N > 1 path (one stream, sharded
+    # channels, reductions, JSON) on a one-GPU box; the numbers of such a run mean nothing.
+    rehearse = os.environ.get("SYDR_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     if args.workload == "multignss":
         if args.stream_seconds == 60.0:
@@ -494,10 +502,10 @@ def main():
     job_ch_samples = float(ch_samples)
     if world > 1:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=("cpu" if os.environ.get("SYDR_BENCH_REHEARSE") == "1" else "cuda"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        t = torch.tensor([job_ch_samples], dtype=torch.float64, device="cuda")
+        t = torch.tensor([job_ch_samples], dtype=torch.float64, device=("cpu" if os.environ.get("SYDR_BENCH_REHEARSE") == "1" else "cuda"))
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         job_ch_samples = float(t.item())
     eng.prof_enable(False)
