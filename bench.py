@@ -154,7 +154,6 @@ def cpu_baseline_all_cores(raw, items, prns, n_epochs, budget_s):
 def per_tick_leg(eng):
     """ChannelManager.addNewRFData(1 ms) + run() from Python, 32 channels (tools/per_tick_rate.py)."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
-    sys.path.insert(0, os.path.join(REPO, "tests"))
     import per_tick_rate
     return per_tick_rate.measure(300, N_CH, engine=eng)
 

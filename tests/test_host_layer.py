@@ -21,58 +21,9 @@ from sydr_amd.channel.manager import ChannelManager, shard_channels
 from sydr_amd.signal.iqsource import RFSignal
 from sydr_amd.utils.enumerations import ChannelMessage, ChannelState, LoopLockState, TrackingFlags
 
-KAPLAN_INI = """
-[ACQUISITION]
-method = PCPS
-doppler_range = 5000
-doppler_steps = 250
-coherent_integration = 1
-non_coherent_integration = 1
-threshold = 1.5
-[TRACKING]
-correlator_epl_wide = 0.5
-correlator_epl_narrow = 0.5
-dll_threshold = 10.0
-dll_damping_ratio = 0.7
-dll_noise_bandwidth = 2.0
-dll_loop_gain = 1.0
-dll_pdi = 0.001
-pll_bandwidth_wide = 25.0
-pll_bandwidth_narrow = 15.0
-pll_threshold_wide = 0.5
-pll_threshold_narrow = 0.8
-fll_bandwidth_pullin = 100.0
-fll_bandwidth_wide = 50.0
-fll_bandwidth_narrow = 15.0
-fll_threshold_wide = 0.5
-fll_threshold_narrow = 0.8
-"""
-BORRE_INI = """
-[ACQUISITION]
-method = PCPS
-doppler_range = 5000
-doppler_steps = 250
-coherent_integration = 1
-non_coherent_integration = 1
-threshold = 1.5
-[TRACKING]
-correlator_number = 3
-correlator_early = -0.5
-correlator_prompt = 0
-correlator_late = 0.5
-dll_damping_ratio = 0.7
-dll_noise_bandwidth = 1.0
-dll_loop_gain = 1.0
-dll_pdi = 0.001
-pll_damping_ratio = 0.7
-pll_noise_bandwidth = 8.0
-pll_loop_gain = 0.25
-pll_pdi = 0.001
-fll_damping_ratio = 0.7
-fll_noise_bandwidth = 15.0
-fll_loop_gain = 1.5
-fll_pdi = 0.001
-"""
+_EXAMPLES = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples")
+KAPLAN_INI = open(os.path.join(_EXAMPLES, "channel_GPS_L1CA_kaplan.ini")).read()
+BORRE_INI = open(os.path.join(_EXAMPLES, "channel_GPS_L1CA_borre.ini")).read()
 
 
 def channel_config(text):

@@ -5,9 +5,7 @@ of them pays) and with every packet materialised (what the reference's Receiver 
 import configparser, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import bench
-from test_host_layer import KAPLAN_INI
 from sydr_amd.engine import Engine, FMT_CI8
 from sydr_amd.channel.l1ca_kaplan import ChannelL1CA_Kaplan
 from sydr_amd.channel.manager import ChannelManager
@@ -27,7 +25,7 @@ def measure(n_ms=600, n_ch=32, profile=False, engine=None):
     eng.iq_synth(sats, FS, 12.0, 20260003, 0, total)
     raw = eng.iq_download(total, 0)
     rf = RFSignal(dict(filepath="none", sampling_frequency=FS, is_complex="true", intermediate_frequency=0.0, data_size=8))
-    cfg = configparser.ConfigParser(); cfg.read_string(KAPLAN_INI)
+    cfg = configparser.ConfigParser(); cfg.read(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "channel_GPS_L1CA_kaplan.ini"))
     mgr = ChannelManager(rf, engine=eng, keepCorrelationMap=False)
     mgr.addChannel(ChannelL1CA_Kaplan, cfg, n_ch)
     for s in sats:
