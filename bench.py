@@ -606,12 +606,16 @@ def acquisition_leg(eng, rf):
     slots = np.arange(N_CH)
     eng.pcps(slots, 0, FS, 0.0, 5000.0, 250.0, 1, 1)  # warm (allocations, twiddles)
     reps = 5
-    eng.prof_reset()
-    eng.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(reps):
         pb, pc, pr, _ = eng.pcps(slots, 0, FS, 0.0, 5000.0, 250.0, 1, 1)
-    acq_ms = (time.perf_counter() - t0) / reps * 1e3
+    acq_ms = (time.perf_counter() - t0) / reps * 1e3      # wall time of the call as a receiver makes it
+    # the same calls again with the library's per-stage HIP events switched on (they cost ~10 us of GPU idle time per
+    # stage boundary, which is why the wall time above is taken without them): kernel time for the roofline
+    eng.prof_reset()
+    eng.prof_enable(True)
+    for _ in range(reps):
+        eng.pcps(slots, 0, FS, 0.0, 5000.0, 250.0, 1, 1)
     eng.prof_enable(False)
     kern_ms, _ = eng.prof_read("pcps")
     kern_ms /= reps
