@@ -95,15 +95,23 @@ class ChannelBank:
     # ------------------------------------------------------------------ advancing
     def _absorb(self, channels, records, states, done):
         n_ep = records.shape[1]
-        self.state[channels] = states
-        ran = done > 0
-        self.code_since_tow[channels] += done
-        if ran.any():
-            rows = np.flatnonzero(ran)
-            self.last[channels[rows]] = records[rows, done[rows] - 1]
-        short = done < n_ep
-        if short.any():
-            self.lost[channels[short]] = True
+        lo, n = int(channels[0]), len(channels)
+        if int(channels[-1]) - lo + 1 == n and (n < 3 or bool((np.diff(channels) == 1).all())):
+            sel = slice(lo, lo + n)               # the usual case: a run of channel numbers -- plain slices
+        else:
+            sel = channels
+        self.state[sel] = states
+        self.code_since_tow[sel] += done
+        if n_ep == 1 and int(done.min()) == 1:    # a tick in which every listed channel ran its epoch
+            self.last[sel] = records[:, 0]
+        else:
+            ran = done > 0
+            if ran.any():
+                rows = np.flatnonzero(ran)
+                self.last[channels[rows]] = records[rows, done[rows] - 1]
+            short = done < n_ep
+            if short.any():
+                self.lost[channels[short]] = True
         bits = records["nav_bit"]
         if (bits >= 0).any():
             for r, e in zip(*np.nonzero(bits >= 0)):

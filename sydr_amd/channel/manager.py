@@ -52,6 +52,7 @@ class ChannelManager:
         self.keepCorrelationMap = keepCorrelationMap
         self._slots = 0
         self._pending = None          # slab handed to addNewRFData, uploaded by the next run()
+        self._lists = None            # (state version, active, acquiring, host-side plugins, cids, states) of the last tick
 
     @property
     def bank(self):
@@ -127,11 +128,22 @@ class ChannelManager:
     def run(self):
         """Flat sequence of result packets for this tick (channelManager.py:149-188)."""
         out = TickPackets()
-        active = [ch for ch in self.channels.values() if ch.channelState is not ChannelState.IDLE]
+        # who is active / acquiring only changes when a channel changes state: device-tracked channels bump the ring's
+        # stateVersion when they do, so a tracking receiver does not walk its channel objects every millisecond
+        version = getattr(self.sharedBuffer, "stateVersion", None)
+        if self._lists is not None and self._lists[0] == (version, self.nbChannels):
+            _, active, acquiring, host_plugins, cids_active, states_active = self._lists
+        else:
+            active = [ch for ch in self.channels.values() if ch.channelState is not ChannelState.IDLE]
+            acquiring = [ch for ch in active if ch.channelState is ChannelState.ACQUIRING]
+            host_plugins = [ch for ch in active if not isinstance(ch, DeviceTrackedChannel)]
+            cids_active = np.array([ch.channelID for ch in active], dtype=np.int64)
+            states_active = [ch.channelState for ch in active]
+            cacheable = version is not None and all(isinstance(ch, DeviceTrackedChannel) for ch in self.channels.values())
+            self._lists = ((version, self.nbChannels), active, acquiring, host_plugins, cids_active, states_active) if cacheable else None
         if not active:
             self._flush_pending()
             return out
-        acquiring = [ch for ch in active if ch.channelState is ChannelState.ACQUIRING]
         bank = self.bank
         ready = bank.ready() if bank is not None else np.zeros(0, dtype=np.int32)
         # one device call: ring ingest + one epoch for every ready channel
@@ -143,16 +155,20 @@ class ChannelManager:
             self.engine.iq_upload(staged, offset)
         if acquiring:
             out.add_ready(self._acquire(acquiring))
-        for ch in active:   # plugins that keep their loops on the host (e.g. the reference's class behind the seams mixin)
-            if ch.channelState is ChannelState.TRACKING and not isinstance(ch, DeviceTrackedChannel):
+        for ch in host_plugins:   # plugins that keep their loops on the host (e.g. the reference's class behind the seams mixin)
+            if ch.channelState is ChannelState.TRACKING:
                 out.add_ready(ch._processHandler())
         if len(ready):
             ran = np.flatnonzero(done > 0)
             cids, kinds, rec = ready[ran], bank.cfg["loop_kind"][ready[ran]], rec[ran]
             out.add(len(ran), lambda i: tracking_packet(int(cids[i]), int(kinds[i]), rec[i]))
-        # channel updates: everything they report is captured now, the dicts are made when read
-        cids = np.array([ch.channelID for ch in active], dtype=np.int64)
-        states = [ch.channelState for ch in active]
+        # channel updates: everything they report is captured now, the dicts are made when read (acquisition may have
+        # moved channels to TRACKING during this tick: take the lists again if it did)
+        if getattr(self.sharedBuffer, "stateVersion", None) != version or self._lists is None:
+            cids = np.array([ch.channelID for ch in active], dtype=np.int64)
+            states = [ch.channelState for ch in active]
+        else:
+            cids, states = cids_active, states_active
         if bank is not None:
             unread = bank.unread(cids)
             since = bank.code_since_tow[cids] * 1 + unread / (self.rfSignal.samplingFrequency / 1e3)

@@ -120,6 +120,8 @@ class DeviceTrackedChannel(GpuCorrelatorSeams, Channel, metaclass=_ViewMeta):
     def channelState(self, value):
         self._channel_state = value
         self._bank.tracking[self._row] = value is ChannelState.TRACKING
+        ring = self._bank.ring                                 # (the manager caches its channel lists against this)
+        ring.stateVersion = getattr(ring, "stateVersion", 0) + 1
 
     @property
     def currentSample(self):

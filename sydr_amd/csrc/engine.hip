@@ -234,6 +234,7 @@ void sdr_engine_destroy(sdr_engine* e) {
                       &e->pcps_blu,  &e->pcps_blu_x, &e->pcps_blu_a, &e->pcps_blu_b};
     for (DevBuf* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
+    if (e->slab_pinned) (void)hipHostFree(e->slab_pinned);
     if (e->iq) (void)hipFree(e->iq);
     if (e->codes) (void)hipFree(e->codes);
     if (e->luts) (void)hipFree(e->luts);
@@ -374,6 +375,30 @@ int sdr_iq_download(sdr_engine* e, void* iq, int64_t n_samples, int64_t ring_off
 
 }  // extern "C"
 
+// Asynchronous upload of a caller-owned (pageable) slab: small slabs -- a receiver tick brings 1 ms, 50 KB at 25 MHz --
+// go through a page-locked staging buffer of the engine (one memcpy here, then a DMA the stream does not wait for the
+// host on); the caller's pointer is not kept past return either way.
 int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset) {
-    return iq_copy(e, const_cast<void*>(iq), n_samples, ring_offset, true, false);
+    const size_t bytes = n_samples > 0 ? (size_t)n_samples * sdr_fmt_bytes(e->iq_fmt) : 0;
+    if (!iq || bytes == 0 || bytes > (1u << 20)) return iq_copy(e, const_cast<void*>(iq), n_samples, ring_offset, true, false);
+    if (int rc = sdr_set_device(e)) return rc;
+    if (bytes > e->slab_bytes) {
+        SDR_HIP(hipStreamSynchronize(e->stream));   // (an earlier slab's DMA may still read the old buffer)
+        if (e->slab_pinned) SDR_HIP(hipHostFree(e->slab_pinned));
+        e->slab_pinned = nullptr;
+        e->slab_bytes = 0;
+        const size_t want = bytes < 131072 ? 131072 : bytes * 2;
+        hipError_t err = hipHostMalloc(&e->slab_pinned, 2 * want, hipHostMallocDefault);   // two halves, used alternately
+        if (err != hipSuccess) {
+            e->slab_pinned = nullptr;
+            return sdr_fail(SDR_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", 2 * want, hipGetErrorString(err));
+        }
+        e->slab_bytes = want;
+    }
+    // two halves: the DMA of the previous tick's slab has completed by the time its half is reused (every tick ends
+    // with a synchronisation of this stream, and a bare upload is followed by one before the next)
+    e->slab_flip ^= 1;
+    char* stage = (char*)e->slab_pinned + (e->slab_flip ? e->slab_bytes : 0);
+    memcpy(stage, iq, bytes);
+    return iq_copy(e, stage, n_samples, ring_offset, true, false);
 }

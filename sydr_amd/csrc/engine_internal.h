@@ -81,6 +81,9 @@ struct sdr_engine {
     DevBuf track_state, track_cfg;
     int n_cus = 0;              // compute units of the device (sizes the closed-loop clusters)
     int track_force_parts = 0;  // diagnostics / tests: 0 = choose, else 1, 2, 4 or 8 workgroups per channel
+    void* slab_pinned = nullptr;  // page-locked staging of the slab a receiver tick brings (sdr_bank_tick)
+    size_t slab_bytes = 0;        // bytes of ONE of its two halves
+    int slab_flip = 0;
     int64_t pcps_tw_n = 0;
     // chirp-z (Bluestein) plan for code lengths the mixed-radix planner cannot factor: [chirp N][B_fwd M][B_inv M][tw M]
     DevBuf pcps_blu, pcps_blu_x, pcps_blu_a, pcps_blu_b;

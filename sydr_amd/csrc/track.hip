@@ -449,12 +449,14 @@ constexpr int kXchgStageWords = 256;   // per role wave: up to 4 wave-wide loads
 // WAVES: resident waves per SIMD the register allocation has to leave room for (2 = two 256-thread
 // workgroups can share a CU, at the price of a few spills).
 // states / cfgs are indexed through ch_map when it is given (the device-resident channel bank: the launch serves
-// the listed channels of a larger array); everything this launch produces (trajectory, bits, epochs_done) is
-// indexed by the position in the list.
+// the listed channels of a larger array); everything this launch produces (trajectory, bits, epochs_done, states_copy)
+// is indexed by the position in the list.  Any of these outputs, ch_map and the fault word may live in page-locked
+// host memory (a receiver tick reads its few KB of results without a single copy command).
 // THREADS == 256 && WAVES == 1 is the CLUSTER form (parts >= 2 workgroups per channel, cooperative launch).
 template <int FMT, int THREADS, int WAVES, int NT>
 __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __restrict__ ring, int64_t capacity,
                                                         sdr_track_state* __restrict__ states,
+                                                        sdr_track_state* __restrict__ states_copy,
                                                         const int32_t* __restrict__ ch_map,
                                                         const sdr_loop_cfg* __restrict__ cfgs, int cfg_stride,
                                                         int n_epochs, sdr_track_epoch* __restrict__ traj,
@@ -493,14 +495,19 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     const int edge_lane = edge_wave ? lane_global - (cluster_lanes - 64) : -1;
     const int sidx = ch_map ? ch_map[ch] : ch;             // where this channel's state and configuration live
     const sdr_loop_cfg* __restrict__ cfg_ptr = cfgs + (size_t)sidx * cfg_stride;
+    {   // the channel's state and configuration into LDS, one 64-bit word per lane (a single thread copying the 472
+        // bytes is ~60 loads one after the other: microseconds of a one-epoch receiver tick)
+        constexpr int kStWords = (int)(sizeof(sdr_track_state) / 8), kCfgWords = (int)(sizeof(sdr_loop_cfg) / 8);
+        static_assert(sizeof(sdr_track_state) % 8 == 0 && sizeof(sdr_loop_cfg) % 8 == 0 && kStWords <= 64 && kCfgWords <= 64,
+                      "state / configuration are copied as 64-bit words by the first two waves");
+        if (tid < kStWords)
+            reinterpret_cast<unsigned long long*>(&sh->st)[tid] = reinterpret_cast<const unsigned long long*>(states + sidx)[tid];
+        else if (tid >= 64 && tid < 64 + kCfgWords)
+            reinterpret_cast<unsigned long long*>(&sh->cfg)[tid - 64] = reinterpret_cast<const unsigned long long*>(cfg_ptr)[tid - 64];
+    }
     if (tid == 0) {
-        sh->st = states[sidx];
-        sh->cfg = *cfg_ptr;
         sh->epochs_done = 0;
         sh->fault = 0;
-        sh->fll_bw = states[sidx].fll_bw;
-        sh->pll_bw = states[sidx].pll_bw;
-        sh->lock_state = states[sidx].lock_state;
     }
     const int slot = states[sidx].code_slot;
     stage_lut<THREADS>(lut, luts + (size_t)slot * lut_stride, lut_words, tid);
@@ -557,6 +564,9 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         sh->ep.code_step = s_init.code_step;
         for (int t = 0; t < kTaps; ++t) sh->spacing[t] = sp[t];
         sh->dphi = carrier_step(s_init.carrier_hz, fs);
+        sh->fll_bw = s_init.fll_bw;
+        sh->pll_bw = s_init.pll_bw;
+        sh->lock_state = s_init.lock_state;
         sh->c_code_counter = sh->l_code_counter = s_init.code_counter;
         sh->l_ipp = s_init.i_prompt_prev;
         sh->l_qpp = s_init.q_prompt_prev;
@@ -742,6 +752,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         if (epochs_done < n_epochs && keep_traj)
             for (int k = epochs_done; k < n_epochs; ++k) traj[(size_t)ch * n_epochs + k].n_samples = 0;
         states[sidx] = st;
+        if (states_copy) states_copy[ch] = st;   // (position in the launch's list: what the host reads back)
         if (epochs_done_out) epochs_done_out[ch] = epochs_done;
         if (n_bits) n_bits[ch] = sh->l_bits_run < max_bits ? sh->l_bits_run : max_bits;
     }
@@ -788,6 +799,8 @@ struct TrackRun {
     int max_bits = 0;
     int32_t* d_nbits = nullptr;
     int32_t* d_done = nullptr;            // [n_ch] epochs completed
+    sdr_track_state* d_states_copy = nullptr;  // [n_ch] end states by position in the list (nullable)
+    int* fault_word = nullptr;            // where the launch's fault flag lives (already zero); nullptr: behind the exchange lines
     int force_parts = 0;                  // 0: choose
 };
 
@@ -798,13 +811,14 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
     const size_t xchg_bytes = (size_t)r.n_ch * 2 * kMaxParts * kXchgWordsMax * sizeof(unsigned long long);
     if (int rc = sdr_devbuf_reserve_on(e, ctx->stream, &ctx->xchg, xchg_bytes + 16)) return rc;
     unsigned long long* d_xchg = (unsigned long long*)ctx->xchg.ptr;
-    int* d_fault = (int*)((char*)ctx->xchg.ptr + xchg_bytes);
+    int* d_fault = r.fault_word ? r.fault_word : (int*)((char*)ctx->xchg.ptr + xchg_bytes);
     *d_fault_out = d_fault;
     const void* d_iq = e->iq;
     int64_t cap = e->iq_capacity;
     const uint32_t* d_luts = e->luts;
     int lw = lut_words, ls = e->lut_stride, nch = r.n_ch, n_ep = r.n_epochs, mb = r.max_bits, keep = r.keep;
     sdr_track_state* d_st = r.d_states;
+    sdr_track_state* d_st_copy = r.d_states_copy;
     const int32_t* d_map = r.d_map;
     const sdr_loop_cfg* d_cfgs = r.d_cfgs;
     int cfg_stride = r.cfg_stride;
@@ -832,7 +846,7 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
         if (*too_big) return hipSuccess;
         if (parts > 1)  // tags of a previous launch must not validate this one's polls
             if (hipError_t me = hipMemsetAsync(ctx->xchg.ptr, 0, xchg_bytes + 16, ctx->stream)) return me;
-        void* args[] = {&d_iq, &cap, &d_st, &d_map, &d_cfgs, &cfg_stride, &n_ep, &d_traj, &keep, &d_bits, &mb,
+        void* args[] = {&d_iq, &cap, &d_st, &d_st_copy, &d_map, &d_cfgs, &cfg_stride, &n_ep, &d_traj, &keep, &d_bits, &mb,
                         &d_nbits, &d_done, &d_luts, &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault};
         if (dense) return sdr_track_dense_launch(e->iq_fmt, nt, r.n_ch, shmem, ctx->stream, args);
         hipError_t err = hipSuccess;
@@ -875,7 +889,7 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
     } else if (r.n_epochs > 4) {
         while (parts < kMaxParts && (long)r.n_ch * parts * 2 <= (long)e->n_cus) parts *= 2;
     }
-    SDR_HIP(hipMemsetAsync(d_fault, 0, 16, ctx->stream));
+    if (!r.fault_word) SDR_HIP(hipMemsetAsync(d_fault, 0, 16, ctx->stream));
     hipError_t launch_err = hipSuccess;
     {
         ProfScope ps(e, "track_kernel", ctx->stream);
@@ -1108,53 +1122,77 @@ static int bank_run(sdr_engine* e, sdr_bank* b, StreamCtx* ctx, const int32_t* c
     const size_t st_bytes = (size_t)n_ch * sizeof(sdr_track_state);
     const size_t bits_bytes = nav_bits ? (size_t)n_ch * max_bits : 0;
     const size_t head = ((size_t)3 * n_ch * sizeof(int32_t) + 15) & ~(size_t)15;  // [map][n_bits][epochs_done], then the bits
-    int rc = sdr_devbuf_reserve_on(e, ctx->stream, &ctx->traj, records ? rec_bytes : sizeof(sdr_track_epoch));
-    if (!rc) rc = sdr_devbuf_reserve_on(e, ctx->stream, &ctx->bits, head + bits_bytes + 16);
-    // pinned staging: [fault (4 words)][epochs_done n][n_bits n][channel list n] [states][records][bits]
+    // page-locked block: [fault (4 words)][epochs_done n][n_bits n][channel list n] [states][records][bits]
     const size_t pin_head = ((size_t)(4 + 3 * n_ch) * sizeof(int32_t) + 15) & ~(size_t)15;
     const size_t pin_bytes = pin_head + st_bytes + rec_bytes + bits_bytes;
-    if (!rc) rc = sdr_pinned_reserve(e, ctx, pin_bytes);
+    int rc = sdr_pinned_reserve(e, ctx, pin_bytes);
     if (rc) return rc;
-    int32_t* d_map = (int32_t*)ctx->bits.ptr;
-    TrackRun r;
-    r.d_states = b->d_states;
-    r.d_map = d_map;
-    r.d_cfgs = b->d_cfgs;
-    r.cfg_stride = 1;
-    r.n_ch = n_ch, r.n_epochs = n_epochs, r.n_taps = nt;
-    r.d_traj = (sdr_track_epoch*)ctx->traj.ptr;
-    r.keep = records ? 1 : 0;
-    r.d_nbits = nav_bits ? d_map + n_ch : nullptr;
-    r.d_done = d_map + 2 * n_ch;
-    r.d_bits = nav_bits ? (int8_t*)ctx->bits.ptr + head : nullptr;
-    r.max_bits = max_bits;
     char* pin = (char*)ctx->pinned;
     int32_t* p_head = (int32_t*)pin;
-    SDR_HIP(hipMemsetAsync(ctx->bits.ptr, 0, head + bits_bytes, ctx->stream));
-    memcpy(p_head + 4 + 2 * n_ch, channels, (size_t)n_ch * sizeof(int32_t));  // (the caller's list is not kept past return)
-    SDR_HIP(hipMemcpyAsync(d_map, p_head + 4 + 2 * n_ch, (size_t)n_ch * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    int parts = 1;
-    int* d_fault = nullptr;
-    if (int rc2 = launch_track(e, ctx, r, &parts, &d_fault)) return rc2;
     sdr_track_state* p_states = (sdr_track_state*)(pin + pin_head);
     sdr_track_epoch* p_rec = (sdr_track_epoch*)(pin + pin_head + st_bytes);
     int8_t* p_bits = (int8_t*)(pin + pin_head + st_bytes + rec_bytes);
-    SDR_HIP(hipMemcpyAsync(p_head, d_fault, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SDR_HIP(hipMemcpyAsync(p_head + 4, r.d_done, (size_t)n_ch * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (nav_bits) SDR_HIP(hipMemcpyAsync(p_head + 4 + n_ch, r.d_nbits, (size_t)n_ch * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (states_out) {
-        // contiguous runs of channel indices come back in one copy each
-        int c = 0;
-        while (c < n_ch) {
-            int run = 1;
-            while (c + run < n_ch && channels[c + run] == channels[c] + run) ++run;
-            SDR_HIP(hipMemcpyAsync(p_states + c, b->d_states + channels[c], (size_t)run * sizeof(sdr_track_state),
-                                   hipMemcpyDeviceToHost, ctx->stream));
-            c += run;
-        }
+    // A receiver tick (or any step with a few KB of results) has the kernel read its channel list from, and write its
+    // outputs straight into, the page-locked block -- it is device-accessible -- so the call is one launch and one
+    // synchronisation, with no copy commands around them (each costs the stream several microseconds).  Steps with
+    // long trajectories keep device buffers and copy once at the end.
+    const bool direct = pin_bytes <= 96u * 1024u;
+    if (!direct) {
+        rc = sdr_devbuf_reserve_on(e, ctx->stream, &ctx->traj, records ? rec_bytes : sizeof(sdr_track_epoch));
+        if (!rc) rc = sdr_devbuf_reserve_on(e, ctx->stream, &ctx->bits, head + bits_bytes + 16);
+    } else if (!records) {
+        rc = sdr_devbuf_reserve_on(e, ctx->stream, &ctx->traj, sizeof(sdr_track_epoch));   // (the kernel's scratch record)
     }
-    if (records) SDR_HIP(hipMemcpyAsync(p_rec, ctx->traj.ptr, rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (nav_bits) SDR_HIP(hipMemcpyAsync(p_bits, r.d_bits, bits_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (rc) return rc;
+    memset(p_head, 0, pin_head);
+    memcpy(p_head + 4 + 2 * n_ch, channels, (size_t)n_ch * sizeof(int32_t));  // (the caller's list is not kept past return)
+    TrackRun r;
+    r.d_states = b->d_states;
+    r.d_cfgs = b->d_cfgs;
+    r.cfg_stride = 1;
+    r.n_ch = n_ch, r.n_epochs = n_epochs, r.n_taps = nt;
+    r.keep = records ? 1 : 0;
+    r.max_bits = max_bits;
+    if (direct) {
+        r.d_map = p_head + 4 + 2 * n_ch;
+        r.d_done = p_head + 4;
+        r.d_nbits = nav_bits ? p_head + 4 + n_ch : nullptr;
+        r.d_bits = nav_bits ? p_bits : nullptr;
+        r.d_traj = records ? p_rec : (sdr_track_epoch*)ctx->traj.ptr;
+        r.d_states_copy = states_out ? p_states : nullptr;
+        r.fault_word = p_head;
+        if (nav_bits) memset(p_bits, 0, bits_bytes);
+    } else {
+        int32_t* d_map = (int32_t*)ctx->bits.ptr;
+        r.d_map = d_map;
+        r.d_traj = (sdr_track_epoch*)ctx->traj.ptr;
+        r.d_nbits = nav_bits ? d_map + n_ch : nullptr;
+        r.d_done = d_map + 2 * n_ch;
+        r.d_bits = nav_bits ? (int8_t*)ctx->bits.ptr + head : nullptr;
+        SDR_HIP(hipMemsetAsync(ctx->bits.ptr, 0, head + bits_bytes, ctx->stream));
+        SDR_HIP(hipMemcpyAsync(d_map, p_head + 4 + 2 * n_ch, (size_t)n_ch * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    int parts = 1;
+    int* d_fault = nullptr;
+    if (int rc2 = launch_track(e, ctx, r, &parts, &d_fault)) return rc2;
+    if (!direct) {
+        SDR_HIP(hipMemcpyAsync(p_head, d_fault, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        SDR_HIP(hipMemcpyAsync(p_head + 4, r.d_done, (size_t)n_ch * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (nav_bits) SDR_HIP(hipMemcpyAsync(p_head + 4 + n_ch, r.d_nbits, (size_t)n_ch * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (states_out) {
+            // contiguous runs of channel indices come back in one copy each
+            int c = 0;
+            while (c < n_ch) {
+                int run = 1;
+                while (c + run < n_ch && channels[c + run] == channels[c] + run) ++run;
+                SDR_HIP(hipMemcpyAsync(p_states + c, b->d_states + channels[c], (size_t)run * sizeof(sdr_track_state),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+                c += run;
+            }
+        }
+        if (records) SDR_HIP(hipMemcpyAsync(p_rec, ctx->traj.ptr, rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (nav_bits) SDR_HIP(hipMemcpyAsync(p_bits, r.d_bits, bits_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
     SDR_HIP(hipStreamSynchronize(ctx->stream));
     if (p_head[0])
         return sdr_fail(SDR_ERR_HIP, "closed-loop tracking: a workgroup of a %d-part cluster never published its sums", parts);

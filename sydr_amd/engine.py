@@ -104,8 +104,8 @@ class Bank:
         listed channels run one epoch.  -> (records[n], states[n], epochs_done[n])"""
         channels = np.ascontiguousarray(channels, dtype=np.int32)
         n = len(channels)
-        rec = np.zeros(n, dtype=TRACK_EPOCH_DTYPE)
-        states = np.zeros(n, dtype=TRACK_STATE_DTYPE)
+        rec = np.empty(n, dtype=TRACK_EPOCH_DTYPE)          # (all three are filled by the call)
+        states = np.empty(n, dtype=TRACK_STATE_DTYPE)
         done = np.zeros(n, dtype=np.int32)
         n_samples = 0
         if raw is not None:
