@@ -154,6 +154,36 @@ def tracking_packet(cid: int, kind: int, rec) -> dict:
     return pkt
 
 
+def tracking_packets_builder(cids, kinds, records):
+    """build(i) -> the TRACKING_UPDATE packet of row i, for a whole tick's records at once: the structured array is
+    turned into plain Python tuples in ONE call the first time any packet is read (field access on NumPy records costs
+    more per packet than the dict itself)."""
+    names = records.dtype.names
+    at = {name: k for k, name in enumerate(names)}
+    i_corr, i_chz, i_code, i_cerr, i_coderr = at["corr"], at["carrier_hz"], at["code_hz"], at["carrier_err"], at["code_err"]
+    i_dll, i_pll, i_fll, i_cn0, i_plock, i_flock, i_lock = (at["dll"], at["pll"], at["fll"], at["cn0"], at["pll_lock"],
+                                                            at["fll_lock"], at["lock_state"])
+    rows = []
+
+    def build(i):
+        if not rows:
+            rows.extend(records.tolist())
+        r = rows[i]
+        corr = r[i_corr]
+        pkt = {"cid": int(cids[i]), "type": ChannelMessage.TRACKING_UPDATE,
+               "i_early": corr[0], "q_early": corr[1], "i_prompt": corr[2], "q_prompt": corr[3], "i_late": corr[4],
+               "q_late": corr[5], "carrier_frequency": r[i_chz], "code_frequency": r[i_code],
+               "carrier_frequency_error": r[i_cerr], "code_frequency_error": r[i_coderr],
+               "dll": r[i_dll], "pll": r[i_pll], "fll": r[i_fll]}
+        if kinds[i] == KIND_KAPLAN:
+            pkt["cn0"], pkt["pll_lock"], pkt["fll_lock"] = r[i_cn0], r[i_plock], r[i_flock]
+            pkt["lock_state"] = LoopLockState(r[i_lock])
+        else:
+            pkt["cn0"], pkt["pll_lock"], pkt["fll_lock"], pkt["lock_state"] = np.nan, 0.0, 0.0, 0
+        return pkt
+    return build
+
+
 class TickPackets(Sequence):
     """The flat packet list `ChannelManager.run()` returns (channelManager.py:149-188), built on demand.
 
@@ -212,5 +242,5 @@ def channel_update_builder(cids, states, flags, tows, since_tow_ms, unread, code
     return build
 
 
-__all__ = ["ChannelBank", "TickPackets", "tracking_packet", "channel_update_builder", "KIND_BORRE", "KIND_KAPLAN",
+__all__ = ["ChannelBank", "TickPackets", "tracking_packet", "tracking_packets_builder", "channel_update_builder", "KIND_BORRE", "KIND_KAPLAN",
            "ChannelState"]

@@ -19,7 +19,7 @@ import numpy as np
 from ..engine import FMT_CF64, FMT_CI16, FMT_CI8, Engine
 from ..utils.devicering import CircularBuffer
 from ..utils.enumerations import ChannelState
-from .bank import TickPackets, channel_update_builder, tracking_packet
+from .bank import TickPackets, channel_update_builder, tracking_packet, tracking_packets_builder
 from .tracked import DeviceTrackedChannel
 
 
@@ -161,7 +161,7 @@ class ChannelManager:
         if len(ready):
             ran = np.flatnonzero(done > 0)
             cids, kinds, rec = ready[ran], bank.cfg["loop_kind"][ready[ran]], rec[ran]
-            out.add(len(ran), lambda i: tracking_packet(int(cids[i]), int(kinds[i]), rec[i]))
+            out.add(len(ran), tracking_packets_builder(cids, kinds, rec))
         # channel updates: everything they report is captured now, the dicts are made when read (acquisition may have
         # moved channels to TRACKING during this tick: take the lists again if it did)
         if getattr(self.sharedBuffer, "stateVersion", None) != version or self._lists is None:

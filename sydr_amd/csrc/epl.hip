@@ -30,38 +30,48 @@ namespace {
 
 using namespace sdr;
 
-constexpr int kThreads = 64;  // one wave per channel-epoch: the ~5 us fixed latency of a workgroup is amortised over 4x more work
-constexpr int kWaves = kThreads / 64;
+constexpr int kWaveThreads = 64;  // one wave per channel-epoch: the ~5 us fixed latency of a workgroup is amortised over 4x more work
+constexpr int kLongLutWords = 4096;  // replicas of 16 KB and more (multi-period / BOC half-chip codes): four epochs share a staged copy
 
-// Dynamic LDS: [red: kWaves*2*NT doubles][lut: lut_words uint32]
+// Dynamic LDS: [red: WPW*2*NT doubles][scratch: strips / rotations][lut: lut_words uint32]
 //
-// One workgroup per item.  (A persistent grid-stride variant that keeps the replica in LDS across
-// items was measured slower: holding two items' parameters pushed the kernel from 4 to 2 resident
-// waves per SIMD -- 1.15 ms vs 0.87 ms per 32 000-item launch -- so hardware workgroup dispatch does
-// the scheduling.)
+// One WAVE per item; WPW = 1: one workgroup per item.  (A persistent grid-stride variant that keeps the replica in
+// LDS across items was measured slower: holding two items' parameters pushed the kernel from 4 to 2 resident waves
+// per SIMD -- 1.15 ms vs 0.87 ms per 32 000-item launch -- so hardware workgroup dispatch does the scheduling.)
+// WPW = 4 (long replicas): a 33 KB table per single-wave workgroup leaves 3 waves on a CU; four waves of a workgroup
+// correlate four epochs of the SAME channel -- items i, i+C, i+2C, i+3C of a list whose code slots repeat with
+// period C (the plan checks that) -- against one staged copy, 8 waves per CU.
 // W: samples a lane owns per iteration of the boundary variant (16 or 8), 0 = the per-sample variant.
 #ifndef SDR_EPL_WAVES
 #define SDR_EPL_WAVES 1
 #endif
-template <int FMT, int NT, int W, int KM = 0>
-__global__ __launch_bounds__(kThreads, SDR_EPL_WAVES) void epl_kernel(const void* __restrict__ ring, int64_t capacity,
-                                                       const sdr_epl_item* __restrict__ items,
+template <int FMT, int NT, int W, int KM = 0, int WPW = 1>
+__global__ __launch_bounds__(kWaveThreads * WPW, SDR_EPL_WAVES) void epl_kernel(const void* __restrict__ ring, int64_t capacity,
+                                                       const sdr_epl_item* __restrict__ items, int n_items, int group_stride,
                                                        const uint32_t* __restrict__ luts,
                                                        int lut_words, int lut_stride,
                                                        const double* __restrict__ spacing, double fs,
                                                        int tap0, int n_taps_total,
                                                        double* __restrict__ out) {
+    constexpr int kThreads = kWaveThreads * WPW;
     extern __shared__ double smem[];
     double* red = smem;
-    double2* prefix = reinterpret_cast<double2*>(red + kWaves * 2 * NT);          // boundary variants: kThreads*9 slots; chip variant: strips + rotations
-    constexpr int kScratchSlots = W == kChipMax ? kThreads * chip_strip_slots<NT>() + kWaves * kChipMax : (W ? kThreads * kPrefixSlots : 0);
+    double2* prefix = reinterpret_cast<double2*>(red + WPW * 2 * NT);          // boundary variants: kThreads*9 slots; chip variant: strips + rotations
+    constexpr int kScratchSlots = W == kChipMax ? kThreads * chip_strip_slots<NT>() + WPW * kChipMax : (W ? kThreads * kPrefixSlots : 0);
     uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + kScratchSlots);
 
     const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
 #ifdef SDR_TRACE_WG
     const unsigned long long t_start = wall_clock64();
 #endif
-    const sdr_epl_item it = items[blockIdx.x];
+    int item = blockIdx.x;
+    if (WPW > 1) {
+        const int g = blockIdx.x / group_stride, c = blockIdx.x - g * group_stride;
+        item = (g * WPW + wave) * group_stride + c;
+    }
+    const bool have = item < n_items;
+    const sdr_epl_item it = items[have ? item : (int)(blockIdx.x % group_stride)];   // (a wave without an item still stages its share of the table)
     stage_lut<kThreads>(lut, luts + (size_t)it.code_slot * lut_stride, lut_words, tid);
     const double dphi = carrier_step(it.carrier_hz, fs);
     EpochParams ep;
@@ -72,28 +82,30 @@ __global__ __launch_bounds__(kThreads, SDR_EPL_WAVES) void epl_kernel(const void
     ep.rem_code = it.rem_code;
     ep.code_step = it.code_step;
     EpochConsts<NT> K;
-    compute_constants<NT>(K, ep, spacing + tap0, dphi, kThreads);
+    compute_constants<NT>(K, ep, spacing + tap0, dphi, kWaveThreads);
     __syncthreads();  // replica staged
+    if (WPW > 1 && !have) return;
 
     double accr[NT], acci[NT];
     if constexpr (W == kChipMax && FMT == SDR_FMT_CI8) {
         // chip-aligned blocks (correlator_chip.h); an epoch it does not cover is redone per sample
         const bool done = chip_variant_applies(ep, capacity) &&
-                          correlate_epoch_chip<NT, true, KM>(ring, capacity, ep, dphi, K, lut, prefix, prefix + kThreads * chip_strip_slots<NT>(),
-                                                         tid, tid, kThreads, tid, accr, acci);
+                          correlate_epoch_chip<NT, true, KM>(ring, capacity, ep, dphi, K, lut, prefix,
+                                                         prefix + kThreads * chip_strip_slots<NT>() + wave * kChipMax,
+                                                         tid, lane, kWaveThreads, lane, accr, acci);
         if (!done) {
             // (its own copy of the per-epoch constants: the in-group rotations the per-sample routine wants would
             // otherwise sit in 64 scalar registers across the whole chip-aligned path)
             EpochConsts<NT> K2;
-            compute_constants<NT>(K2, ep, spacing + tap0, dphi, kThreads);
-            correlate_epoch<FMT, NT>(ring, capacity, ep, dphi, K2, lut, tid, kThreads, tid, accr, acci);
+            compute_constants<NT>(K2, ep, spacing + tap0, dphi, kWaveThreads);
+            correlate_epoch<FMT, NT>(ring, capacity, ep, dphi, K2, lut, lane, kWaveThreads, lane, accr, acci);
         }
     } else if (W != 0 && !epoch_wraps(ep, capacity))
-        correlate_epoch_wide<FMT, NT, true, (W ? W : kWide)>(ring, capacity, ep, dphi, K, lut, prefix, tid, tid, kThreads, tid, accr, acci);
+        correlate_epoch_wide<FMT, NT, true, (W ? W : kWide)>(ring, capacity, ep, dphi, K, lut, prefix, tid, lane, kWaveThreads, lane, accr, acci);
     else
-        correlate_epoch<FMT, NT>(ring, capacity, ep, dphi, K, lut, tid, kThreads, tid, accr, acci);
-    const double total = reduce_taps<NT, kThreads>(accr, acci, red, tid);
-    if (tid < 2 * NT) out[(size_t)blockIdx.x * 2 * n_taps_total + 2 * tap0 + tid] = total;
+        correlate_epoch<FMT, NT>(ring, capacity, ep, dphi, K, lut, lane, kWaveThreads, lane, accr, acci);
+    const double total = reduce_taps<NT, kWaveThreads>(accr, acci, red, lane);
+    if (lane < 2 * NT) out[(size_t)item * 2 * n_taps_total + 2 * tap0 + lane] = total;
 #ifdef SDR_TRACE_WG
     if (tid == 0 && blockIdx.x < 65536) {
         unsigned hw;
@@ -109,17 +121,33 @@ __global__ __launch_bounds__(kThreads, SDR_EPL_WAVES) void epl_kernel(const void
 
 template <int FMT, int NT>
 void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
-                int tap0, int n_taps_total, int lut_words, int wide, double* d_out) {
-    const size_t scratch = wide >= kChipMax ? (size_t)kThreads * chip_strip_slots<NT>() + kWaves * kChipMax
-                                            : (wide ? (size_t)kThreads * kPrefixSlots : 0);
-    size_t shmem = (size_t)(kWaves * 2 * NT) * sizeof(double) + (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t) +
+                int tap0, int n_taps_total, int lut_words, int wide, int group_stride, double* d_out) {
+    // long replicas: four waves (four epochs of one channel) per workgroup around one staged table
+    const int wpw = (lut_words >= kLongLutWords && group_stride > 0) ? 4 : 1;
+    const int threads = kWaveThreads * wpw;
+    const size_t scratch = wide >= kChipMax ? (size_t)threads * chip_strip_slots<NT>() + wpw * kChipMax
+                                            : (wide ? (size_t)threads * kPrefixSlots : 0);
+    size_t shmem = (size_t)(wpw * 2 * NT) * sizeof(double) + (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t) +
                    scratch * sizeof(double2);
+    const int stride = wpw > 1 ? group_stride : 1;
+    const int grid = wpw > 1 ? (int)(((int64_t)n_items + (int64_t)wpw * stride - 1) / ((int64_t)wpw * stride)) * stride : n_items;
     auto launch = [&](auto kernel) {
         if (shmem > 64u * 1024u)  // beyond the default dynamic-LDS grant (long multi-period replicas)
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(kernel, dim3(n_items), dim3(kThreads), shmem, stream, e->iq, e->iq_capacity, d_items,
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), shmem, stream, e->iq, e->iq_capacity, d_items, n_items, stride,
                            e->luts, lut_words, e->lut_stride, d_spacing, fs, tap0, n_taps_total, d_out);
     };
+    if (wpw == 4) {
+        if (wide >= kChipMax && FMT == SDR_FMT_CI8)
+            launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 0, 4>);
+        else if (wide == 16)
+            launch(epl_kernel<FMT, NT, 16, 0, 4>);
+        else if (wide == 8)
+            launch(epl_kernel<FMT, NT, 8, 0, 4>);
+        else
+            launch(epl_kernel<FMT, NT, 0, 0, 4>);
+        return;
+    }
     if (wide == kChipMax + 24 && FMT == SDR_FMT_CI8)   // chip-aligned, every epoch with 24 or 25 samples per chip
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24>);
     else if (wide == kChipMax && FMT == SDR_FMT_CI8)
@@ -134,22 +162,22 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
 
 template <int FMT>
 void launch_fmt(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
-                int n_taps, int lut_words, int wide, double* d_out) {
+                int n_taps, int lut_words, int wide, int group_stride, double* d_out) {
     // Taps are served in register-resident chunks of 5/3/2/1.
     int t0 = 0;
     while (t0 < n_taps) {
         int left = n_taps - t0;
         if (left >= 5) {
-            launch_one<FMT, 5>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, d_out);
+            launch_one<FMT, 5>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, d_out);
             t0 += 5;
         } else if (left >= 3) {
-            launch_one<FMT, 3>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, d_out);
+            launch_one<FMT, 3>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, d_out);
             t0 += 3;
         } else if (left == 2) {
-            launch_one<FMT, 2>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, d_out);
+            launch_one<FMT, 2>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, d_out);
             t0 += 2;
         } else {
-            launch_one<FMT, 1>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, d_out);
+            launch_one<FMT, 1>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, d_out);
             t0 += 1;
         }
     }
@@ -165,6 +193,7 @@ struct sdr_epl_plan {
     int n_taps = 0;
     int lut_words = 0;
     int wide = 0;  // 16 / 8: every item has 16 (8) * code_step < 1, the boundary variant with that group width applies
+    int group_stride = 0;  // C > 0: items[i] and items[i + C] use the same code slot for every i (epoch-major lists of C channels)
     double fs = 0.0;
     int64_t code_generation = 0;  // of the engine's code tables the plan was validated against
     int64_t ring_capacity = 0;    // and of the ring
@@ -246,6 +275,14 @@ int sdr_epl_plan_create(sdr_engine* e, const sdr_epl_item* items, int n_items, c
     p->fs = fs;
     p->lut_words = lut_words;
     p->wide = wide;
+    // the period of the code-slot pattern, if the list has one (what lets four epochs of a channel share a staged table)
+    if (lut_words >= kLongLutWords) {
+        int c = 1;
+        while (c < n_items && items[c].code_slot != items[0].code_slot) ++c;
+        bool periodic = c < n_items || n_items == 1;
+        for (int i = 0; periodic && i + c < n_items; ++i) periodic = items[i].code_slot == items[i + c].code_slot;
+        p->group_stride = periodic ? c : 0;
+    }
     p->code_generation = e->code_generation;
     p->ring_capacity = e->iq_capacity;
     hipError_t err = hipMalloc(&p->d_items, (size_t)n_items * sizeof(sdr_epl_item));
@@ -289,10 +326,10 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
         hipStream_t st = ctx->stream;
         ProfScope ps(e, "epl_kernel", st);
         switch (e->iq_fmt) {
-            case SDR_FMT_CI8: launch_fmt<SDR_FMT_CI8>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, out); break;
-            case SDR_FMT_CI16: launch_fmt<SDR_FMT_CI16>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, out); break;
-            case SDR_FMT_CF32: launch_fmt<SDR_FMT_CF32>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, out); break;
-            default: launch_fmt<SDR_FMT_CF64>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, out); break;
+            case SDR_FMT_CI8: launch_fmt<SDR_FMT_CI8>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, out); break;
+            case SDR_FMT_CI16: launch_fmt<SDR_FMT_CI16>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, out); break;
+            case SDR_FMT_CF32: launch_fmt<SDR_FMT_CF32>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, out); break;
+            default: launch_fmt<SDR_FMT_CF64>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, out); break;
         }
     }
     SDR_HIP(hipGetLastError());

@@ -246,3 +246,44 @@ def test_closed_loop_e1_like_boc_five_taps(engine, kind):
     assert abs(traj[0]["carrier_hz"][-1] - dop) < 10.0
     mag = np.hypot(traj[0]["corr"][:, 4], traj[0]["corr"][:, 5])
     assert mag[-8:].min() > 0.6 * 7.0 * traj[0]["n_samples"][-1]        # stays on the main peak (int8 clipping costs ~20 %)
+
+
+def test_long_replicas_four_epochs_per_workgroup(engine):
+    """Replicas of 16 KB and more (multi-period / BOC codes) are staged once per FOUR epochs of a channel: a list whose
+    code slots repeat with a period runs with four waves per workgroup.  Same items in an order without a period
+    (one wave per workgroup) must give the same bits; a few items against the oracle; ragged counts."""
+    fs, n_ch, n_ep = 25e6, 3, 11                       # 33 items: two full groups of 12 and one with missing waves
+    n = 100000                                         # 4 ms = 4 code periods
+    total = (n_ep * n + 4096) // 8 * 8
+    rng = np.random.default_rng(409)
+    raw = rng.integers(-100, 100, 2 * total).astype(np.int8)
+    engine.iq_alloc(total, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(n_ch, 1023, max_periods=5)
+    prns = [3, 17, 29]
+    for s, prn in enumerate(prns):
+        engine.load_gps_code(s, prn)
+    step = np.array([1.023e6 + 2.0, 1.023e6 - 1.5, 1.023e6 + 0.3]) / fs
+    slots = np.tile(np.arange(n_ch), n_ep)
+    starts = np.repeat(np.arange(n_ep) * n, n_ch) + np.tile([5, 1, 12], n_ep)
+    items = make_items(slots, n - 50, starts, np.tile([1200.0, -3300.0, 40.0], n_ep), np.tile([0.3, 1.1, 2.9], n_ep),
+                       np.tile([0.01, 0.2, 0.033], n_ep), np.tile(step, n_ep))
+    got = engine.epl_batch(items, FIVE, fs)                              # periodic slots -> four waves per workgroup
+    perm = rng.permutation(len(items))
+    while len(items) > 3 and all(items["code_slot"][perm][i] == items["code_slot"][perm][i + 3] for i in range(len(items) - 3)):
+        perm = rng.permutation(len(items))                               # (make sure the shuffled list has no period 3)
+    shuffled = engine.epl_batch(items[perm], FIVE, fs)                   # no period -> one wave per workgroup
+    assert np.array_equal(shuffled, got[perm])
+    rf = orc.iq_to_complex(raw)
+    for k in (0, 13, 32):
+        it = items[k]
+        s0 = int(it["start_sample"])
+        ref = orc.epl(rf[s0:s0 + int(it["n_samples"])], orc.pad_code(orc.gold_code(prns[int(it["code_slot"])])), fs,
+                      float(it["carrier_hz"]), float(it["rem_carrier"]), float(it["rem_code"]), float(it["code_step"]), FIVE)
+        assert close(got[k], ref)
+    # a range of the plan that starts inside a group and ends inside another
+    plan = engine.epl_plan(items, FIVE, fs)
+    plan.run(4, 22)
+    part = plan.fetch()[4:26]
+    plan.close()
+    assert np.array_equal(part, got[4:26])
