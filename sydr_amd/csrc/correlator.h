@@ -9,10 +9,15 @@
 // What is reference arithmetic and what is not:
 //   * the chip index is the reference's, operation for operation, in IEEE fp64 with no FMA
 //     (np.linspace + np.ceil) -- it must be bit-exact;
-//   * the carrier replica is evaluated once per 8-sample group in fp64 (exact Cody-Waite
-//     reduction + minimax sin/cos) and advanced inside the group by 8 precomputed fp64
-//     rotations; mix and accumulation use FMAs.  They agree with NumPy to ~1e-13 relative,
-//     the bar being 1e-6.
+//   * the carrier replica is evaluated once per lane in fp64 (exact Cody-Waite reduction +
+//     minimax sin/cos), advanced inside a group by 8 / 16 precomputed fp64 rotations and from
+//     group to group by one more; mix and accumulation use FMAs.  They agree with NumPy to
+//     ~1e-15 relative on the benchmark stream (1.9e-12 worst case in the stress runs), the bar being 1e-6.
+//
+// Contents: the per-sample core (correlate_epoch), the boundary variant (wide_group /
+// correlate_epoch_wide: a lane owns 16 or 8 consecutive samples), its single-round form for the
+// closed-loop clusters (correlate_epoch_single), the wave / workgroup reductions.  The chip-aligned
+// variant of the open-loop kernel lives in correlator_chip.h.
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -1,20 +1,21 @@
 // K1: batched carrier wipe-off + multi-tap PRN correlate-accumulate.
 //
-// One workgroup = one channel-epoch = one call of the reference's EPL
-// (sydr/dsp/tracking.py:92-116).  IQ is streamed from the HBM ring with 16-byte
-// coalesced loads (8 ci8 samples per lane per load), the PRN replica sits in LDS
-// as the high words of +-1.0, accumulators are fp64 and are reduced with
-// wavefront shuffles, then across the 4 waves through LDS in a fixed order (so
-// results do not depend on how channels are sharded over GPUs).
+// One 64-lane WAVE = one channel-epoch = one call of the reference's EPL (sydr/dsp/tracking.py:92-116); a workgroup
+// is one wave (or four waves -- four epochs of one channel -- when the staged replica is 16 KB and more).  IQ is
+// streamed from the HBM ring with 16-byte loads, the PRN replica sits in LDS as the high words of +-1.0, accumulators
+// are fp64 and are reduced inside the wave with DPP moves + v_readlane in a fixed order (so results do not depend on
+// how channels are sharded over GPUs).  Three correlator cores, chosen per launch from the items' code steps:
+//   chip-aligned (correlator_chip.h) : ci8, 16-26 samples per chip -- a lane owns a whole chip of the prompt tap
+//   boundary     (correlator.h)      : a lane owns 16 (8) consecutive samples, < 1 chip; running sums in an LDS strip
+//   per-sample   (correlator.h)      : exact chip index per sample and tap; low rates, epochs that wrap the ring
 //
-// Arithmetic that selects a chip is the reference's, operation for operation
-// (np.linspace + np.ceil), in IEEE fp64 with contraction off:
+// Arithmetic that selects a chip is the reference's, operation for operation (np.linspace + np.ceil),
+// in IEEE fp64 with contraction off:
 //     shift = rem_code + spacing            stop = code_step*n + shift
 //     step  = (stop - shift) / n            idx_i = ceil(i*step + shift)
-// The carrier replica exp(1j*(-(f*2.0*pi*(i/fs)) + rem)) is evaluated once per
-// 8-sample group in fp64 (exact range reduction + libm-grade sincos) and
-// advanced inside the group by 8 precomputed fp64 rotations, which agrees with
-// the reference to ~1e-12 rad (far inside the 1e-6 relative bar on accumulators).
+// The carrier replica exp(1j*(-(f*2.0*pi*(i/fs)) + rem)) is evaluated once per lane in fp64 (exact range reduction +
+// minimax sincos) and advanced by precomputed fp64 rotations inside a block and from block to block, which agrees
+// with the reference to ~1e-15 relative on the accumulators (the bar is 1e-6).
 #include "correlator.h"
 #include "correlator_chip.h"
 
