@@ -1,18 +1,21 @@
 // On-device loop closure: persistent workgroups run
 // correlate -> discriminators -> loop filters -> NCO update for n_epochs without leaving the
-// GPU.  A channel is served by a CLUSTER of `parts` workgroups (1, 2, 4 or 8,
-// chosen so that the launch fills the GPU: 32 channels x 8 parts = 256 CUs): every epoch each part
-// correlates its share of the samples, publishes six partial sums through global memory, waits for
-// its peers' and adds all of them in the same fixed order -- so every part holds bit-identical
-// totals and runs the scalar loop update redundantly; there is no second exchange.  The PRN replica
-// stays in LDS for the whole run; the loop arithmetic is fp64, spread over three waves by dependency
-// (carrier loop / code loop / lock indicators + state machine + bit decisions) and, inside each,
-// over lanes for the divisions, roots and arctangents -- following the two reference plugins
-// statement by statement:
+// GPU.  A channel is served by ONE workgroup (512 threads; or 256 threads capped at
+// 168 registers so that three share a CU when there are more channels than CUs) or by a CLUSTER of 2, 4 or 8
+// workgroups (chosen so that the launch fills the GPU: 32 channels x 8 parts = 256 CUs): every epoch each part
+// correlates its share of the samples, publishes its partial sums through global memory, collects its peers' and
+// adds all of them in the same fixed order -- so every part holds bit-identical totals and runs the scalar loop
+// update redundantly; there is no second exchange.  The PRN replica stays in LDS for the whole run; the loop
+// arithmetic is fp64, spread over four waves by dependency (carrier loop / code loop / lock indicators + state
+// machine + bit decisions / carrier phase over the epoch) and, inside each, over lanes for the divisions, roots
+// and arctangents -- following the two reference plugins statement by statement:
 //   kind 0  Borre  : channel_l1ca_borre.py:333-451  (DLL NNEML + Costas PLL, Borre filters, np.pi NCO)
 //   kind 1  Kaplan : channel_l1ca_kaplan.py:342-619 (FLL-assisted 2nd-order PLL, lock-state machine,
 //                    GPS-ICD pi in the NCO and the discriminators: SURVEY.md T3)
-// built on sydr/dsp/tracking.py:120-186,246-279 and sydr/dsp/lockindicator.py:6-122.
+// built on sydr/dsp/tracking.py:120-186,246-279 and sydr/dsp/lockindicator.py:6-122, generalised by configuration
+// only (taps, chips per epoch, epochs per symbol, epoch duration: BASELINE configs 4-5).  The second half of the
+// file is the host side: launch geometry, the sdr_track_closed_loop* entry points and the device-resident channel
+// bank (sdr_bank_*).
 #include "correlator.h"
 
 #include <cstring>
