@@ -739,6 +739,7 @@ __global__ __launch_bounds__(kThreads) void fft4_cols_kernel(const PassArgs a, i
     // instead of one scattered read per element.
     for (int m = threadIdx.x; m < N1; m += kThreads) wsub[m] = a.tw[(size_t)n2_0 * m];  // n2_0*m < N
     __syncthreads();
+    double2* __restrict__ zt = Z + (size_t)batch * N1 * N2 + n2_0;   // (k1, c) of the tile sits at zt[k1*N2 + c]: 32-bit offsets
     for (int base = 0; base < total; base += kBatchLoads * kThreads) {
         double2 w2[kBatchLoads];
         int k1s[kBatchLoads], cs[kBatchLoads];
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(kThreads) void fft4_cols_kernel(const PassArgs a, i
             if (k1s[u] >= 0) {
                 double2 w = cmul(wsub[k1s[u]], w2[u]);
                 if (INV) w.y = -w.y;
-                Z[((size_t)batch * N1 + k1s[u]) * N2 + n2_0 + cs[u]] = cmul(res[k1s[u] * pitch + cs[u]], w);
+                zt[k1s[u] * N2 + cs[u]] = cmul(res[k1s[u] * pitch + cs[u]], w);
             }
         }
     }
@@ -776,6 +777,10 @@ __global__ __launch_bounds__(kThreads) void fft4_rows_kernel(const PassArgs a, i
     const int k1_0 = blockIdx.x * T;
     const uint32_t n2_magic = div_magic(N2);
     const int total = N2 * T;
+    // the T rows of a tile are ONE contiguous run of Z (row k1 of transform `batch` starts at (batch*N1 + k1)*N2):
+    // element e of the tile sits at tile + e, no per-element 64-bit index arithmetic
+    const double2* __restrict__ tile = Z + ((size_t)batch * N1 + k1_0) * N2;
+    const int exist = (N1 - k1_0 < T ? N1 - k1_0 : T) * N2;    // elements of the tile that belong to the transform
     for (int base = 0; base < total; base += kBatchLoads * kThreads) {
         double2 z[kBatchLoads];
         int slot[kBatchLoads];
@@ -788,10 +793,9 @@ __global__ __launch_bounds__(kThreads) void fft4_rows_kernel(const PassArgs a, i
         for (int u = 0; u < kBatchLoads; ++u) {
             const int e = base + u * kThreads + threadIdx.x;
             const int c = fast_div(e, n2_magic), n2 = e - c * N2;  // n2 fastest: each row of Z is read as one contiguous run
-            const int k1 = k1_0 + c;
             slot[u] = e < total ? n2 * pitch + c : -1;
             z[u] = make_double2(0.0, 0.0);
-            if (e < total && k1 < N1) z[u] = Z[((size_t)batch * N1 + k1) * N2 + n2];
+            if (e < exist) z[u] = tile[e];
         }
         if (wm) wsub[m] = wv;
 #pragma unroll
@@ -826,30 +830,41 @@ __global__ __launch_bounds__(kThreads) void fft4_rows_kernel(const PassArgs a, i
                 b1 = a.N - 1;
             }
         }
+        // A lane walks its elements e = k2*T + c in increasing order, and the map index bin*N + (k1_0 + c) + N1*k2 grows
+        // with e: the first occurrence of a lane's maximum is simply the earliest e, so only the winner's index is ever
+        // formed.  The coarse ordering uses the UNSCALED squared magnitude (the 1/N of the inverse transform is a
+        // positive constant: it moves the ordering by rounding only, far inside the 2^-48 band that goes through the
+        // exact comparison of the scaled hypot, the reference's np.abs).
         double best_sq = -1.0, best_x = 0.0, best_y = 0.0;
-        int best_i = 0x7fffffff;
+        int best_e = -1;
         for (int e = threadIdx.x; e < N2 * T; e += kThreads) {
             const int k2 = e / T, c = e - k2 * T;
-            const int k1 = k1_0 + c;
-            const int col = k1 + N1 * k2;
-            const bool allowed = !LOADSEL || col < a1 || (col >= b0 && col < b1);
-            if (k1 < N1 && allowed) {
+            bool live = k1_0 + c < N1;
+            if (LOADSEL) {
+                const int col = k1_0 + c + N1 * k2;
+                live = live && (col < a1 || (col >= b0 && col < b1));
+            }
+            if (live) {
                 const double2 v = res[k2 * pitch + c];
-                const double x = v.x * a.scale, y = v.y * a.scale;
-                const double sq = x * x + y * y;
-                const int idx = bin * a.N + col;
+                const double sq = v.x * v.x + v.y * v.y;
                 bool take = sq > best_sq;
                 if (__builtin_expect(fabs(sq - best_sq) <= best_sq * 0x1p-48, 0)) {
-                    const double m_new = hypot(x, y), m_old = hypot(best_x, best_y);
-                    take = m_new > m_old || (m_new == m_old && idx < best_i);
+                    const double m_new = hypot(v.x * a.scale, v.y * a.scale), m_old = hypot(best_x * a.scale, best_y * a.scale);
+                    take = m_new > m_old;      // (equal: the earlier element, i.e. the smaller index, stays)
                 }
                 best_sq = take ? sq : best_sq;
-                best_x = take ? x : best_x;
-                best_y = take ? y : best_y;
-                best_i = take ? idx : best_i;
+                best_x = take ? v.x : best_x;
+                best_y = take ? v.y : best_y;
+                best_e = take ? e : best_e;
             }
         }
-        double best_v = best_i != 0x7fffffff ? 0.0 + hypot(best_x, best_y) : -1.0;   // (0.0 + |.|: the map's own rounding)
+        int best_i = 0x7fffffff;
+        double best_v = -1.0;
+        if (best_e >= 0) {
+            const int k2 = best_e / T, c = best_e - k2 * T;
+            best_i = bin * a.N + k1_0 + c + N1 * k2;
+            best_v = 0.0 + hypot(best_x * a.scale, best_y * a.scale);   // (0.0 + |.|: the map's own rounding)
+        }
         wave_best(best_v, best_i);
         if ((threadIdx.x & 63) == 63) {
             Best r = {best_v, (long long)best_i};
