@@ -68,7 +68,8 @@ class DeviceTrackedChannel(GpuCorrelatorSeams, Channel, metaclass=_ViewMeta):
         if not isinstance(sharedBuffer, DeviceRing):
             raise TypeError("a device-tracked channel needs the device ring (sydr_amd.utils.devicering.CircularBuffer); "
                             "to accelerate the reference's own plugin over its host ring, mix GpuCorrelatorSeams into it")
-        self._bank, self._row = sharedBuffer.bankFor(cid), int(cid)
+        sharedBuffer.bankFor(cid)                       # (grows the ring's bank to hold this channel)
+        self._ring, self._row = sharedBuffer, int(cid)
         self._bank.state[self._row] = np.zeros((), dtype=self._bank.state.dtype)
         self._bank.tracking[self._row] = self._bank.lost[self._row] = False
         self._bank.code_since_tow[self._row] = 0
@@ -77,6 +78,12 @@ class DeviceTrackedChannel(GpuCorrelatorSeams, Channel, metaclass=_ViewMeta):
         self.codeOffset = 0
         self.setAcquisition(configuration['ACQUISITION'])
         self.setTracking(configuration['TRACKING'])
+
+    @property
+    def _bank(self):
+        """The ring's channel bank AS IT IS NOW: the bank is re-created when it has to grow (a 33rd channel), and a
+        reference kept from construction would leave this channel on the old, closed one."""
+        return self._ring.channelBank
 
     # ------------------------------------------------------------------ configuration ([ACQUISITION] / [TRACKING])
     def setAcquisition(self, configuration):

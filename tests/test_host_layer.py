@@ -290,3 +290,28 @@ def test_serial_search_plugin_reproduces_reference():
     for p, row in zip(trk, g["ss_epochs"]):
         assert [p["i_early"], p["q_early"], p["i_prompt"], p["q_prompt"], p["i_late"], p["q_late"],
                 p["carrier_frequency"], p["code_frequency"]] == list(row)
+
+
+def test_channels_survive_the_bank_growing_past_32():
+    """The device-resident bank starts with room for 32 channels and is re-created when a 33rd arrives: channels made
+    before that must follow the ring to the new bank (a reference held from construction would leave them on the old,
+    closed one).  Channel 0 acquires and tracks PRN 7 with 39 more channels added in between; the packets are the
+    golden ones."""
+    g, fs, raw = trajectory_iq()
+    spms = int(fs * 1e-3)
+    eng = OracleEngine()
+    mgr = ChannelManager(rf_signal(fs), engine=eng)
+    mgr.addChannel(ChannelL1CA_Kaplan, channel_config(KAPLAN_INI), 2)
+    ch = mgr.requestTracking(7)
+    first = drive(mgr, raw[:2 * spms * 40], spms, 40)                      # acquisition + the first tracking epochs
+    old_bank = mgr.bank
+    mgr.addChannel(ChannelL1CA_Kaplan, channel_config(KAPLAN_INI), 38)      # 40 channels: the bank is re-created
+    assert mgr.bank is not old_bank and mgr.bank.max_channels >= 40
+    assert ch._bank is mgr.bank and mgr.getChannel(39)._bank is mgr.bank
+    rest = drive(mgr, raw[2 * spms * 40:], spms, 510 - 40)
+    trk = [p for t in first + rest for p in t if p["type"] is ChannelMessage.TRACKING_UPDATE]
+    ref = g["kaplan_epochs"]
+    assert len(trk) == len(ref)
+    for k, (p, row) in enumerate(zip(trk, ref)):
+        assert [p["i_prompt"], p["q_prompt"], p["carrier_frequency"], p["code_frequency"]] == [row[8], row[9], row[15], row[16]], k
+    assert ch.channelState is ChannelState.TRACKING and int(ch.trackFlags) == int(ref[-1][23])
