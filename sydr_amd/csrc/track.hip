@@ -48,6 +48,7 @@ constexpr int kMaxParts = 8;
 constexpr int xchg_words(int nt) { return 4 * nt <= 16 ? 16 : 32; }
 constexpr int kXchgWordsMax = 32;
 constexpr long kSpinLimit = 1L << 20;      // peer polls before a part gives up (about a second): never hang the GPU
+constexpr int kXchgSleep = 16;             // x 64 cycles between publishing a part's sums and the first look at the peers'
 
 constexpr double kGpsPi = 3.1415926535898;  // sydr/utils/constants.py:4
 constexpr double kGpsTwoPi = kGpsPi * 2.0;
@@ -672,6 +673,12 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                 }
                 unsigned long long w[kPasses];
                 bool done = false;
+                // The peers' words cannot be there before a store has crossed to the L2 (~0.4 us): a poll issued at
+                // once is wasted -- and 768 waves polling the lines their peers are storing to slow those stores
+                // down (tools/ubench_sload.hip: a store -> load round trip is 1029 cycles alone, 1664 with every
+                // workgroup polling).  Sleeping ~1000 cycles before the first poll: 5.2 -> 4.8 us per epoch at 32
+                // channels (measured 4 / 8 / 12 / 16 / 20 / 28 x 64 cycles: 5.13, 4.97, 4.94, 4.82, 4.87, 5.04).
+                __builtin_amdgcn_s_sleep(kXchgSleep);
                 for (long spins = 0; spins < kSpinLimit; ++spins) {
                     bool ok = true;
 #pragma unroll
