@@ -773,7 +773,9 @@ __device__ __forceinline__ double wave_sum(double x) {
 // Workgroup reduction of 2*NT fp64 accumulators: wave sums, then the waves through LDS in a fixed
 // order.  red needs (THREADS/64)*2*NT doubles.  After the call threads 0..2*NT-1 hold the totals
 // (thread 2t: I_t, thread 2t+1: Q_t) in the return value.
-template <int NT, int THREADS>
+// COLLECTOR: the wave whose lanes 0..2*NT-1 end up with the totals (the closed-loop clusters hand that job, and the
+// publishing that follows, to the one wave that is not on the epoch's critical path).
+template <int NT, int THREADS, int COLLECTOR = 0>
 __device__ __forceinline__ double reduce_taps(const double* accr, const double* acci, double* red, int tid) {
     constexpr int kWaves = THREADS / 64;
     const int lane = tid & 63, wave = tid >> 6;
@@ -787,10 +789,10 @@ __device__ __forceinline__ double reduce_taps(const double* accr, const double* 
     if (lane < 2 * NT) red[wave * 2 * NT + lane] = mine;
     __syncthreads();
     double s = 0.0;
-    if (tid < 2 * NT) {
-        s = red[tid];
+    if (wave == COLLECTOR && lane < 2 * NT) {
+        s = red[lane];
 #pragma unroll
-        for (int wv = 1; wv < kWaves; ++wv) s += red[wv * 2 * NT + tid];
+        for (int wv = 1; wv < kWaves; ++wv) s += red[wv * 2 * NT + lane];
     }
     return s;
 }

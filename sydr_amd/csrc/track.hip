@@ -48,7 +48,10 @@ constexpr int kMaxParts = 8;
 constexpr int xchg_words(int nt) { return 4 * nt <= 16 ? 16 : 32; }
 constexpr int kXchgWordsMax = 32;
 constexpr long kSpinLimit = 1L << 20;      // peer polls before a part gives up (about a second): never hang the GPU
-constexpr int kXchgSleep = 16;             // x 64 cycles between publishing a part's sums and the first look at the peers'
+#ifndef SDR_XCHG_SLEEP
+#define SDR_XCHG_SLEEP 16
+#endif
+constexpr int kXchgSleep = SDR_XCHG_SLEEP;             // x 64 cycles between publishing a part's sums and the first look at the peers'
 
 constexpr double kGpsPi = 3.1415926535898;  // sydr/utils/constants.py:4
 constexpr double kGpsTwoPi = kGpsPi * 2.0;
@@ -633,13 +636,15 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         if ((tid & 63) == 0 && ch == 0) g_track_phase[8 + part * (THREADS / 64) + (tid >> 6)] += wall_clock64() - wave_mark_;
 #endif
         TRACK_MARK(2);
-        double total = reduce_taps<kTaps, THREADS>(accr, acci, red, tid);
+        // (cluster form: the totals go to wave 3, which publishes them while the three measuring roles already wait for
+        // the peers' -- their chains are the epoch's critical path, the carrier-phase role's is short)
+        double total = reduce_taps<kTaps, THREADS, (kCluster ? 3 : 0)>(accr, acci, red, tid);
         TRACK_MARK(3);
 
         double corr[2 * kTaps];
         bool role_ok = true;
         if constexpr (kCluster) {
-            // Cluster exchange: wave 0 publishes this part's sums; each of the three update roles collects the
+            // Cluster exchange: wave 3 publishes this part's sums; each of the three measuring roles collects the
             // parts' sums for itself and adds them in part order -- every role wave of every part holds bit-identical
             // totals, there is no second hand-over.  No fences, no separate flag: every 64-bit word carries half a
             // double and the epoch tag (epoch+1), is written and read whole, and validates itself (the "LL" idea of
@@ -647,16 +652,24 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             // L2 every epoch (measured: 2.9 us); a relaxed device-scope word costs ~0.4 us one way
             // (tools/ubench_xchg.hip), on the same XCD or across XCDs.
             // Lines are double-buffered by epoch parity: a part can run at most one exchange ahead of a peer (its
-            // wave 0 publishes epoch k+1 only after the workgroup's reduction barrier of that epoch, i.e. after
+            // wave 3 publishes epoch k+1 only after the workgroup's reduction barrier of that epoch, i.e. after
             // all its role waves have finished reading epoch k).
             unsigned long long* lines = xchg + ((size_t)ch * 2 + (epoch & 1)) * kMaxParts * kXchgWordsMax;
             const unsigned long long tag = (unsigned long long)(unsigned)(epoch + 1) << 32;
-            if (tid < 64) {   // lane 2v+h publishes half h of value v (lanes 0..2*NT-1 hold the values)
-                const double v = __shfl(total, (tid >> 1) & 15, 64);
-                if (tid < 4 * kTaps) {
-                    const unsigned half = (tid & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
-                    __hip_atomic_store(lines + part * kXchgWords + tid, tag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (role == 3) {   // lane 2v+h publishes half h of value v (lanes 0..2*NT-1 hold the values)
+                const double v = __shfl(total, (rlane >> 1) & 15, 64);
+                if (rlane < 4 * kTaps) {
+                    const unsigned half = (rlane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+                    __hip_atomic_store(lines + part * kXchgWords + rlane, tag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+            }
+            // Request the next epoch's samples now -- after this epoch's last use of `cur`, before the wait for the
+            // peers, so that nothing waits on them: they arrive while this wave sleeps (the counter a wave waits on
+            // retires loads in order, and these are ~0.4 us older than the first poll).
+            have_next = single && epoch + 1 < n_epochs;
+            if (have_next) {
+                const SingleGeometry next = single_geometry(ep.start_sample + ep.n, ep.n, capacity);
+                single_load<FMT>(ring, single_load_pos(next, lane_global, capacity), nxt);
             }
             if (role < 3) {
                 // lane l polls word l % W of parts l / W + j * (64 / W), j = 0 .. W/8 - 1 (words 4*NT.. of a line are padding)
@@ -725,16 +738,6 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             TRACK_MARK(7);
 #pragma unroll
             for (int k2 = 0; k2 < 2 * kTaps; ++k2) corr[k2] = uniform(sh->corr[k2]);
-        }
-        if constexpr (kCluster) {
-            // Request the next epoch's samples now -- after this epoch's last use of `cur` and after the exchange's own
-            // loads, so that nothing in this epoch waits on them -- and let them arrive during the loop update and the
-            // next epoch's constants (the counter a wave waits on retires loads in order).
-            have_next = single && epoch + 1 < n_epochs;
-            if (have_next) {
-                const SingleGeometry next = single_geometry(ep.start_sample + ep.n, ep.n, capacity);
-                single_load<FMT>(ring, single_load_pos(next, lane_global, capacity), nxt);
-            }
         }
         if (role_ok && role < 4) loop_update<kTaps>(sh, u, corr, role, rlane);
         TRACK_MARK(4);
