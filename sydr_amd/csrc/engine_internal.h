@@ -81,6 +81,7 @@ struct sdr_engine {
     DevBuf track_state, track_cfg;
     int n_cus = 0;              // compute units of the device (sizes the closed-loop clusters)
     int track_force_parts = 0;  // diagnostics / tests: 0 = choose, else 1, 2, 4 or 8 workgroups per channel
+    void* pcps_res_direct = nullptr;  // during sdr_pcps: page-locked block the peak kernels write their results into
     void* slab_pinned = nullptr;  // page-locked staging of the slab a receiver tick brings (sdr_bank_tick)
     size_t slab_bytes = 0;        // bytes of ONE of its two halves
     int slab_flip = 0;

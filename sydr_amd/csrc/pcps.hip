@@ -416,8 +416,12 @@ __global__ __launch_bounds__(kThreads) void argmax_records_kernel(const Best* __
 
 // Map-free search, step 4: the second peak of PRN p from the per-wave records of the pass over its winning row
 // (which ran the maximum over the allowed columns only), and the ratio.
+// (dev_bin / dev_code: the first peaks as argmax_records_kernel left them in device memory, where the second sweep
+// read its rows from; out_* may be page-locked host memory -- this is the call's last kernel and hands everything over)
 __global__ __launch_bounds__(64) void ratio_kernel(const Best* __restrict__ seconds, int per_prn,
-                                                   const Best* __restrict__ tops, double* __restrict__ out_ratio) {
+                                                   const Best* __restrict__ tops, const long long* __restrict__ dev_bin,
+                                                   const long long* __restrict__ dev_code, long long* __restrict__ out_bin,
+                                                   long long* __restrict__ out_code, double* __restrict__ out_ratio) {
     const int prn = blockIdx.x;
     Best mine = {-1.0, 0x7fffffffffffffffLL};
     for (int i = threadIdx.x; i < per_prn; i += 64) mine = better(mine, seconds[(size_t)prn * per_prn + i]);
@@ -428,7 +432,13 @@ __global__ __launch_bounds__(64) void ratio_kernel(const Best* __restrict__ seco
         o.i = __shfl_down(mine.i, off, 64);
         mine = better(mine, o);
     }
-    if (threadIdx.x == 0) out_ratio[prn] = mine.v >= 0.0 ? tops[prn].v / mine.v : nan("");
+    if (threadIdx.x == 0) {
+        out_ratio[prn] = mine.v >= 0.0 ? tops[prn].v / mine.v : nan("");
+        if (out_bin != dev_bin) {
+            out_bin[prn] = dev_bin[prn];
+            out_code[prn] = dev_code[prn];
+        }
+    }
 }
 
 /* ------------------------------------------------------------ host driver */
@@ -1132,9 +1142,13 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
 
     // K6
     Best* parts = (Best*)e->pcps_part.ptr;
-    long long* res_bin = (long long*)e->pcps_res.ptr;
+    // (the three result arrays are a few hundred bytes: the peak kernels write them straight into page-locked host
+    // memory when the caller set it up -- one copy command and its stream latency less per acquisition)
+    long long* res_bin = e->pcps_res_direct ? (long long*)e->pcps_res_direct : (long long*)e->pcps_res.ptr;
     long long* res_code = res_bin + n_prn;
     double* res_ratio = (double*)(res_code + n_prn);
+    long long* dev_bin = (long long*)e->pcps_res.ptr;      // device copies of the first peaks (read by the second sweep)
+    long long* dev_code = dev_bin + n_prn;
     if (map_free) {
         // the map was never written: maximum from the per-wave records, then the winning row of every PRN alone
         // (1/nbins of one inverse sweep) for the second peak
@@ -1143,7 +1157,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
         {
             ProfScope ps(e, "pcps_peak");
             hipLaunchKernelGGL(argmax_records_kernel, dim3(n_prn), dim3(kThreads), 0, e->stream, parts, per_prn, N, tops,
-                               res_bin, res_code);
+                               dev_bin, dev_code);
         }
         PassArgs g = {};
         g.tw = tw;
@@ -1152,7 +1166,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
         g.code_spec = C;
         g.nbins = nbins;
         g.scale = 1.0 / (double)N;
-        g.sel_bin = res_bin;
+        g.sel_bin = dev_bin;
         g.tops = tops;
         g.spc = spc;
         Best* seconds = tops + n_prn;      // [n_prn][records_per_transform]
@@ -1161,7 +1175,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
         {
             ProfScope ps(e, "pcps_peak");
             hipLaunchKernelGGL(ratio_kernel, dim3(n_prn), dim3(64), 0, e->stream, seconds, records_per_transform(plan_four_step(N)),
-                               tops, res_ratio);
+                               tops, dev_bin, dev_code, res_bin, res_code, res_ratio);
         }
         SDR_HIP(hipGetLastError());
         return SDR_OK;
@@ -1335,6 +1349,7 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
         memcpy(pin + res_bytes, code_slots, (size_t)n_prn * sizeof(int32_t));
         SDR_HIP(hipMemcpyAsync(d_slots, pin + res_bytes, n_prn * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
     }
+    e->pcps_res_direct = pin;
     const bool hs = code_spectra != nullptr;
 
     // np.arange(-R, R+1, S): element k = start + k*delta with delta = (start+step) - start
@@ -1347,9 +1362,9 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
         case SDR_FMT_CF32: rc = pcps_run<SDR_FMT_CF32>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
         default: rc = pcps_run<SDR_FMT_CF64>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
     }
+    e->pcps_res_direct = nullptr;
     if (rc) return rc;
 
-    SDR_HIP(hipMemcpyAsync(pin, e->pcps_res.ptr, res_bytes, hipMemcpyDeviceToHost, e->stream));
     if (corr_map)
         SDR_HIP(hipMemcpyAsync(corr_map, e->pcps_map.ptr, (size_t)n_prn * nbins * N * sizeof(double),
                                hipMemcpyDeviceToHost, e->stream));
