@@ -770,11 +770,76 @@ __device__ __forceinline__ double wave_sum(double x) {
     return ((lane_value(x, 0) + lane_value(x, 16)) + lane_value(x, 32)) + lane_value(x, 48);
 }
 
+// The same for a workgroup whose totals are wanted by ONE wave only (the closed-loop clusters): the four DPP
+// stages leave every lane of a row of 16 with the row's sum, the row leaders park the 2*NT row sums in LDS, and after
+// the barrier the collector wave adds the 4*waves rows -- G lanes per value, each over its share of the rows, then a
+// DPP butterfly over the G lanes.  No v_readlane at all (the cross-row step of wave_sum is 8 of them per value, and a
+// lone wave pays ~8 cycles per instruction whatever it is).  Fixed order: deterministic.  The sum of value v comes
+// back in lanes v*G .. v*G+G-1 of the collector (collector_group_lanes(NT) = G); red needs 4*waves*2*NT doubles.
+constexpr int collector_group_lanes(int nt) { return 64 / (2 * nt) >= 8 ? 8 : (64 / (2 * nt) >= 4 ? 4 : 2); }
+
+__device__ __forceinline__ double dpp_add_f64(double v, int which) {
+    // which: 0 = lane ^ 1, 1 = lane ^ 2, 2 = the other quad of the 8, 3 = the other half of the 16
+    int lo, hi;
+    switch (which) {
+        case 0:
+            lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xf, 0xf, true);
+            hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xf, 0xf, true);
+            break;
+        case 1:
+            lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x4E, 0xf, 0xf, true);
+            hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x4E, 0xf, 0xf, true);
+            break;
+        case 2:
+            lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x141, 0xf, 0xf, true);
+            hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x141, 0xf, 0xf, true);
+            break;
+        default:
+            lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x140, 0xf, 0xf, true);
+            hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x140, 0xf, 0xf, true);
+            break;
+    }
+    return v + __hiloint2double(hi, lo);
+}
+
+template <int NT, int THREADS, int COLLECTOR>
+__device__ __forceinline__ double reduce_taps_rows(const double* accr, const double* acci, double* red, int tid) {
+    constexpr int kWaves = THREADS / 64, kRows = 4 * kWaves, kVals = 2 * NT, G = collector_group_lanes(NT);
+    static_assert(kRows % G == 0, "every collector lane adds the same number of rows");
+    const int lane = tid & 63, wave = tid >> 6;
+    double rsum[kVals];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        double a = accr[t], b = acci[t];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            a = dpp_add_f64(a, st);
+            b = dpp_add_f64(b, st);
+        }
+        rsum[2 * t] = a;
+        rsum[2 * t + 1] = b;
+    }
+    if ((lane & 15) == 0) {
+        double* mine = red + (wave * 4 + (lane >> 4)) * kVals;
+#pragma unroll
+        for (int k = 0; k < kVals; ++k) mine[k] = rsum[k];
+    }
+    __syncthreads();
+    double s = 0.0;
+    if (wave == COLLECTOR && lane < kVals * G) {
+        const int v = lane / G, g = lane - v * G;
+#pragma unroll
+        for (int r = 0; r < kRows / G; ++r) s += red[(g + r * G) * kVals + v];
+        s = dpp_add_f64(s, 0);
+        if (G >= 4) s = dpp_add_f64(s, 1);
+        if (G >= 8) s = dpp_add_f64(s, 2);
+    }
+    return s;
+}
+
 // Workgroup reduction of 2*NT fp64 accumulators: wave sums, then the waves through LDS in a fixed
 // order.  red needs (THREADS/64)*2*NT doubles.  After the call threads 0..2*NT-1 hold the totals
 // (thread 2t: I_t, thread 2t+1: Q_t) in the return value.
-// COLLECTOR: the wave whose lanes 0..2*NT-1 end up with the totals (the closed-loop clusters hand that job, and the
-// publishing that follows, to the one wave that is not on the epoch's critical path).
 template <int NT, int THREADS, int COLLECTOR = 0>
 __device__ __forceinline__ double reduce_taps(const double* accr, const double* acci, double* red, int tid) {
     constexpr int kWaves = THREADS / 64;

@@ -449,8 +449,8 @@ __device__ __forceinline__ EpochParams uniform_params(const EpochParams& v) {
     return ep;
 }
 
-// LDS layout in doubles: [0, 128) workgroup reduction scratch, [128, 512) three role waves x 256 words of exchange staging
-constexpr int kRedDoubles = 512;
+// LDS layout in doubles: [0, 256) workgroup reduction scratch, [256, 640) three role waves x 256 words of exchange staging
+constexpr int kRedDoubles = 640;
 constexpr int kXchgStageWords = 256;   // per role wave: up to 4 wave-wide loads of 64 words
 
 // WAVES: resident waves per SIMD the register allocation has to leave room for (2 = two 256-thread
@@ -638,7 +638,9 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         TRACK_MARK(2);
         // (cluster form: the totals go to wave 3, which publishes them while the three measuring roles already wait for
         // the peers' -- their chains are the epoch's critical path, the carrier-phase role's is short)
-        double total = reduce_taps<kTaps, THREADS, (kCluster ? 3 : 0)>(accr, acci, red, tid);
+        double total;
+        if constexpr (kCluster) total = reduce_taps_rows<kTaps, THREADS, 3>(accr, acci, red, tid);   // value v in lanes v*G.. of wave 3
+        else total = reduce_taps<kTaps, THREADS, 0>(accr, acci, red, tid);
         TRACK_MARK(3);
 
         double corr[2 * kTaps];
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             unsigned long long* lines = xchg + ((size_t)ch * 2 + (epoch & 1)) * kMaxParts * kXchgWordsMax;
             const unsigned long long tag = (unsigned long long)(unsigned)(epoch + 1) << 32;
             if (role == 3) {   // lane 2v+h publishes half h of value v (lanes 0..2*NT-1 hold the values)
-                const double v = __shfl(total, (rlane >> 1) & 15, 64);
+                const double v = __shfl(total, ((rlane >> 1) & 15) * collector_group_lanes(NT), 64);
                 if (rlane < 4 * kTaps) {
                     const unsigned half = (rlane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
                     __hip_atomic_store(lines + part * kXchgWords + rlane, tag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -711,7 +713,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                         *fault = 1;
                     }
                 } else {
-                    unsigned* halves = reinterpret_cast<unsigned*>(red + 128) + role * kXchgStageWords;  // this wave's staging
+                    unsigned* halves = reinterpret_cast<unsigned*>(red + 256) + role * kXchgStageWords;  // this wave's staging
 #pragma unroll
                     for (int j = 0; j < kPasses; ++j) halves[j * 64 + rlane] = (unsigned)w[j];  // [(p)*W + k], p = pbase + j*kPerPass
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (LDS serves a wave's operations in order)
