@@ -22,7 +22,7 @@
 
 #ifdef SDR_TRACE_TRACK
 // Debug build only (tools/track_phases.py): per-phase clock totals of channel 0's epoch loop.
-__device__ unsigned long long g_track_phase[32];
+__device__ unsigned long long g_track_phase[64];   // [0,8) phases, [8,40) per-wave arrival (8 parts x 4 waves), [48,52) per-role, [62,64) clocks
 extern "C" int sdr_debug_track_phases(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_track_phase), sizeof(g_track_phase));
 }
@@ -94,6 +94,11 @@ struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind 
     int stop_code, stop_carrier;  // the next epoch would leave the staged replica / the ring, or the carrier NCO is not finite
     double smin, smax;         // extreme tap offsets over both tap sets (constant for the run)
     double l_ipp, l_qpp;       // the lock role's copy of the previous prompt (the carrier role owns st.i/q_prompt_prev)
+    // quotients that only change with the configuration or the lock state, kept instead of re-divided every epoch
+    // (same operands => same bits): atan(qP'/iP') of the previous epoch, the Kaplan natural frequencies for the
+    // bandwidths they were computed from, the Borre filter ratios
+    double at_prev, w0f, w0p, w0f_bw, w0p_bw, pll_r1, pll_r2, dll_r1, dll_r2;
+    double pad_sh_;            // (keeps the struct a multiple of 16 bytes)
     sdr_track_state st;        // the loop state; each update role owns a disjoint set of its fields
     sdr_loop_cfg cfg;
 };
@@ -125,6 +130,24 @@ __device__ __forceinline__ double div_by(double a, const InvDen& d) {
     const double r1 = __builtin_fma(-d.b, q1, a);
     return __builtin_fma(r1, d.y, q1);
 }
+
+// The lock role's share of the loop state, held in registers of its lane 0 for the whole run (19 LDS reads and as many
+// writes per epoch otherwise -- and this role is the longest of the four: tools/track_phases.py).  Written back to
+// the LDS copy of the state once, after the last epoch.
+struct LockRegs {
+    double fll_lock, pll_lock, cn0, ratio_acc, ipp, qpp, fll_bw, pll_bw, nav_sum;
+    int accum, lock_state, time_in_state, spacing_sel, flags, code_counter, nav_count, bits_emitted, bits_run;
+};
+__device__ __forceinline__ LockRegs lock_regs_from(const sdr_track_state& s) {
+    LockRegs r;
+    r.fll_lock = s.fll_lock, r.pll_lock = s.pll_lock, r.cn0 = s.cn0, r.ratio_acc = s.cn0_ratio_acc;
+    r.ipp = s.i_prompt_prev, r.qpp = s.q_prompt_prev, r.fll_bw = s.fll_bw, r.pll_bw = s.pll_bw, r.nav_sum = s.nav_prompt_sum;
+    r.accum = s.accum_counter, r.lock_state = s.lock_state, r.time_in_state = s.time_in_state;
+    r.spacing_sel = s.spacing_sel, r.flags = s.track_flags, r.code_counter = s.code_counter;
+    r.nav_count = s.nav_sum_counter, r.bits_emitted = s.nav_bits_emitted, r.bits_run = 0;
+    return r;
+}
+__device__ __forceinline__ void lock_regs_store(const LockRegs& r, EpochShared* sh);
 
 // What the update roles need besides the shared state: the run's constants and this epoch's inputs (all wave-uniform).
 struct UpdateCtx {
@@ -167,7 +190,8 @@ __device__ __forceinline__ bool code_out_of_range(const EpochShared* sh, int64_t
 // the same operands as the reference's statements: bit-identical), then lane 0 runs the rest of its chain and
 // publishes its share of the next epoch's parameters.  corr[2*NT]: this epoch's correlator totals.
 template <int NT>
-__device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u, const double* corr, int role, int rlane) {
+__device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u, const double* corr, int role, int rlane,
+                                            LockRegs& lk) {
     constexpr int kTaps = NT;
     constexpr int kPrompt = NT / 2;                       // centre tap; its neighbours are early and late
     sdr_track_state& st = sh->st;
@@ -182,31 +206,26 @@ __device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u,
     sdr_track_epoch* rec = u.rec;
     if (role == 0) {
         // ------------------------------------------------------------------ carrier loop
-        double num = 0.0, den = 1.0;
-        switch (rlane) {
-            case 0: num = qp, den = ip; break;                    // atan(qP/iP): Costas PLL, FLL (tracking.py:133-176)
-            case 1: num = st.q_prompt_prev, den = st.i_prompt_prev; break;  // atan(qP'/iP')
-            case 2: num = u.cur_fll_bw, den = kW0Bw1; break;
-            case 3: num = u.cur_pll_bw, den = kW0Bw2; break;
-            case 5: num = cfg.pll_tau2, den = cfg.pll_tau1; break;  // (Borre PLL filter, tracking.py:180-186)
-            case 6: num = cfg.pll_pdi, den = cfg.pll_tau1; break;
-            default: break;
-        }
-        const double quot = num / den;
-        const double at = atan(quot);
-        const double at_now = lane_value(at, 0), at_prev = lane_value(at, 1);
+        // (every lane evaluates the same chain on the same wave-uniform operands: no lane specialisation, no
+        // v_readlane -- a lone wave pays per instruction, not per lane)
+        const double at_now = atan(qp / ip);                      // atan(qP/iP): Costas PLL, FLL (tracking.py:133-176)
+        const double at_prev = sh->at_prev;                       // atan(qP'/iP') as the previous epoch computed it
         double fll_err = at_now - at_prev;
         if (fll_err != fll_err) fll_err = 0.0;
         if (fll_err >= kGpsHalfPi) fll_err = fll_err - kGpsPi;
         else if (fll_err <= -kGpsHalfPi) fll_err = fll_err + kGpsPi;
-        // lane 0: atan/2pi (pll_costas), lane 1: err/dt, then lane 1: (err/dt)/2pi (fll_atan)
-        InvDen d4 = u.by_2pi;
-        if (rlane == 1) d4 = u.by_dt;
-        const double q4 = div_by(rlane == 1 ? fll_err : at_now, d4);
-        const double q5 = div_by(q4, u.by_2pi);
-        const double costas = lane_value(q4, 0), fll_full = lane_value(q5, 1);
-        const double w0f = lane_value(quot, 2), w0p = lane_value(quot, 3);
-        const double pll_r1 = lane_value(quot, 5), pll_r2 = lane_value(quot, 6);
+        const double costas = div_by(at_now, u.by_2pi);                          // atan/2pi (pll_costas)
+        const double fll_full = div_by(div_by(fll_err, u.by_dt), u.by_2pi);     // (err/dt)/2pi (fll_atan)
+        double w0f = sh->w0f, w0p = sh->w0p;
+        if (kaplan && (sh->w0f_bw != u.cur_fll_bw || sh->w0p_bw != u.cur_pll_bw)) {   // (the lock state changed the bandwidths)
+            w0f = u.cur_fll_bw / kW0Bw1;
+            w0p = u.cur_pll_bw / kW0Bw2;
+            if (rlane == 0) {
+                sh->w0f = w0f, sh->w0p = w0p;
+                sh->w0f_bw = u.cur_fll_bw, sh->w0p_bw = u.cur_pll_bw;
+            }
+        }
+        const double pll_r1 = sh->pll_r1, pll_r2 = sh->pll_r2;  // Borre PLL filter ratios tau2/tau1, pdi/tau1 (tracking.py:180-186)
         __builtin_amdgcn_wave_barrier();  // (every lane has read the previous prompt before lane 0 replaces it)
         if (rlane == 0) {
             double c_pll_mem = st.pll_mem;
@@ -238,6 +257,7 @@ __device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u,
             st.pll_mem = c_pll_mem;
             st.i_prompt_prev = ip;
             st.q_prompt_prev = qp;
+            sh->at_prev = at_now;
             sh->c_code_counter = c_code_counter + 1;
             sh->ep.carrier_hz = carrier_hz;
             sh->stop_carrier = carrier_bad(carrier_hz) ? 1 : 0;
@@ -253,17 +273,9 @@ __device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u,
         }
     } else if (role == 1) {
         // ------------------------------------------------------------------ code loop
-        const double env = sqrt(rlane == 1 ? il * il + ql * ql : ie * ie + qe * qe);  // DLL NNEML envelopes (tracking.py:120-129)
-        const double env_e = lane_value(env, 0), env_l = lane_value(env, 1);
-        double num = 0.0, den = 1.0;
-        switch (rlane) {
-            case 0: num = env_e - env_l, den = env_e + env_l; break;
-            case 1: num = cfg.dll_tau2, den = cfg.dll_tau1; break;              // BorreLoopFilter (tracking.py:180-186)
-            case 2: num = kaplan ? cfg.dll_pdi * 1.0 : cfg.dll_pdi, den = cfg.dll_tau1; break;
-            default: break;
-        }
-        const double quot = num / den;
-        const double dll_nn = lane_value(quot, 0), dll_r1 = lane_value(quot, 1), dll_r2 = lane_value(quot, 2);
+        const double env_e = sqrt(ie * ie + qe * qe), env_l = sqrt(il * il + ql * ql);  // DLL NNEML envelopes (tracking.py:120-129)
+        const double dll_nn = (env_e - env_l) / (env_e + env_l);
+        const double dll_r1 = sh->dll_r1, dll_r2 = sh->dll_r2;   // BorreLoopFilter ratios tau2/tau1, pdi/tau1 (tracking.py:180-186)
         if (rlane == 0) {
             const double dll_d = dll_nn;
             double code_err = dll_r1 * (dll_d - st.dll_mem);
@@ -301,7 +313,7 @@ __device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u,
         double num = 0.0, den = 1.0;
         switch (rlane) {
             case 0: {                                             // FLL lock (lockindicator.py:6-18)
-                const double l_ipp = sh->l_ipp, l_qpp = sh->l_qpp;
+                const double l_ipp = lk.ipp, l_qpp = lk.qpp;
                 double v = ip * l_ipp - qp * l_qpp;
                 v *= np_sign(ip * l_ipp + qp * l_qpp);
                 num = v, den = pw;
@@ -318,11 +330,11 @@ __device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u,
         const double quot = num / den;
         const double fll_lock_v = lane_value(quot, 0), pll_lock_v = lane_value(quot, 1), cn0_term = lane_value(quot, 2);
         if (rlane == 0) {
-            double l_fll_lock = st.fll_lock, l_pll_lock = st.pll_lock, l_cn0 = st.cn0, l_ratio_acc = st.cn0_ratio_acc;
-            double l_ipp = sh->l_ipp, l_qpp = sh->l_qpp, l_fll_bw = st.fll_bw, l_pll_bw = st.pll_bw, l_nav_sum = st.nav_prompt_sum;
-            int l_accum = st.accum_counter, l_lock_state = st.lock_state, l_time_in_state = st.time_in_state;
-            int l_spacing_sel = st.spacing_sel, l_flags = st.track_flags, l_code_counter = sh->l_code_counter;
-            int l_nav_count = st.nav_sum_counter, l_bits_emitted = st.nav_bits_emitted, l_bits_run = sh->l_bits_run;
+            double l_fll_lock = lk.fll_lock, l_pll_lock = lk.pll_lock, l_cn0 = lk.cn0, l_ratio_acc = lk.ratio_acc;
+            double l_ipp = lk.ipp, l_qpp = lk.qpp, l_fll_bw = lk.fll_bw, l_pll_bw = lk.pll_bw, l_nav_sum = lk.nav_sum;
+            int l_accum = lk.accum, l_lock_state = lk.lock_state, l_time_in_state = lk.time_in_state;
+            int l_spacing_sel = lk.spacing_sel, l_flags = lk.flags, l_code_counter = lk.code_counter;
+            int l_nav_count = lk.nav_count, l_bits_emitted = lk.bits_emitted, l_bits_run = lk.bits_run;
             int nav_bit = -1;
             if (!kaplan) {
                 // Borre bit sync: first prompt sign flip after MIN_CONVERGENCE_TIME = 100 epochs (borre:384-391)
@@ -403,17 +415,21 @@ __device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u,
                     l_nav_count = 0;
                 }
             }
-            st.fll_lock = l_fll_lock, st.pll_lock = l_pll_lock, st.cn0 = l_cn0, st.cn0_ratio_acc = l_ratio_acc;
-            sh->l_ipp = l_ipp, sh->l_qpp = l_qpp, st.fll_bw = l_fll_bw, st.pll_bw = l_pll_bw, st.nav_prompt_sum = l_nav_sum;
-            st.accum_counter = l_accum, st.lock_state = l_lock_state, st.time_in_state = l_time_in_state;
-            st.spacing_sel = l_spacing_sel, st.track_flags = l_flags, sh->l_code_counter = l_code_counter;
-            st.nav_sum_counter = l_nav_count, st.nav_bits_emitted = l_bits_emitted, sh->l_bits_run = l_bits_run;
-            // hand-over to the other roles / the next epoch
-            const double* sp = l_spacing_sel ? cfg.spacing_narrow : cfg.spacing_wide;
-            for (int t = 0; t < kTaps; ++t) sh->spacing[t] = sp[t];
-            sh->fll_bw = l_fll_bw;
-            sh->pll_bw = l_pll_bw;
-            sh->lock_state = l_lock_state;
+            // hand-over to the other roles / the next epoch: only what changed (taps and bandwidths move with the lock state)
+            if (l_spacing_sel != lk.spacing_sel) {
+                const double* sp = l_spacing_sel ? cfg.spacing_narrow : cfg.spacing_wide;
+                for (int t = 0; t < kTaps; ++t) sh->spacing[t] = sp[t];
+            }
+            if (l_lock_state != lk.lock_state || l_fll_bw != lk.fll_bw || l_pll_bw != lk.pll_bw) {
+                sh->fll_bw = l_fll_bw;
+                sh->pll_bw = l_pll_bw;
+                sh->lock_state = l_lock_state;
+            }
+            lk.fll_lock = l_fll_lock, lk.pll_lock = l_pll_lock, lk.cn0 = l_cn0, lk.ratio_acc = l_ratio_acc;
+            lk.ipp = l_ipp, lk.qpp = l_qpp, lk.fll_bw = l_fll_bw, lk.pll_bw = l_pll_bw, lk.nav_sum = l_nav_sum;
+            lk.accum = l_accum, lk.lock_state = l_lock_state, lk.time_in_state = l_time_in_state;
+            lk.spacing_sel = l_spacing_sel, lk.flags = l_flags, lk.code_counter = l_code_counter;
+            lk.nav_count = l_nav_count, lk.bits_emitted = l_bits_emitted, lk.bits_run = l_bits_run;
             if (rec) {
                 rec->cn0 = kaplan ? l_cn0 : 0.0;
                 rec->pll_lock = kaplan ? l_pll_lock : 0.0;
@@ -432,6 +448,16 @@ __device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u,
         rem_carrier -= adv;
         sh->ep.rem_carrier = py_mod(rem_carrier, kaplan ? kGpsTwoPi : 2.0 * M_PI);
     }
+}
+
+__device__ __forceinline__ void lock_regs_store(const LockRegs& r, EpochShared* sh) {
+    sdr_track_state& st = sh->st;
+    st.fll_lock = r.fll_lock, st.pll_lock = r.pll_lock, st.cn0 = r.cn0, st.cn0_ratio_acc = r.ratio_acc;
+    st.fll_bw = r.fll_bw, st.pll_bw = r.pll_bw, st.nav_prompt_sum = r.nav_sum;
+    st.accum_counter = r.accum, st.lock_state = r.lock_state, st.time_in_state = r.time_in_state;
+    st.spacing_sel = r.spacing_sel, st.track_flags = r.flags;
+    st.nav_sum_counter = r.nav_count, st.nav_bits_emitted = r.bits_emitted;
+    sh->l_bits_run = r.bits_run;
 }
 
 // Wave-uniform copy of the epoch parameters in LDS.  What comes out of LDS is the same in every lane, but only
@@ -543,7 +569,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
 #ifdef SDR_TRACE_TRACK
     unsigned long long mark_ = wall_clock64();
     const unsigned long long clk0_ = clock64(), wall0_ = wall_clock64();   // shader clock the kernel really runs at
-    if (tid == 0 && ch == 0 && part == 0) for (int k = 0; k < 32; ++k) g_track_phase[k] = 0;
+    if (tid == 0 && ch == 0 && part == 0) for (int k = 0; k < 64; ++k) g_track_phase[k] = 0;
     __syncthreads();
 #endif
     // Each update role owns a disjoint set of fields of the state's LDS copy (loaded into registers for the
@@ -578,11 +604,19 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         sh->l_ipp = s_init.i_prompt_prev;
         sh->l_qpp = s_init.q_prompt_prev;
         sh->l_bits_run = 0;
+        // the quotients the roles keep instead of re-dividing (see EpochShared)
+        sh->at_prev = atan(s_init.q_prompt_prev / s_init.i_prompt_prev);
+        sh->w0f_bw = s_init.fll_bw, sh->w0p_bw = s_init.pll_bw;
+        sh->w0f = s_init.fll_bw / kW0Bw1, sh->w0p = s_init.pll_bw / kW0Bw2;
+        sh->pll_r1 = cfg_ptr->pll_tau2 / cfg_ptr->pll_tau1, sh->pll_r2 = cfg_ptr->pll_pdi / cfg_ptr->pll_tau1;
+        sh->dll_r1 = cfg_ptr->dll_tau2 / cfg_ptr->dll_tau1;
+        sh->dll_r2 = (cfg_ptr->loop_kind != 0 ? cfg_ptr->dll_pdi * 1.0 : cfg_ptr->dll_pdi) / cfg_ptr->dll_tau1;
     }
     // (cluster form) this lane's 16-sample group of the current epoch and of the next one: where epoch k+1 starts is
     // known when epoch k starts, so its samples are requested a whole epoch ahead
     Raw8<FMT> cur[2], nxt[2];
     bool have_next = false;
+    LockRegs lk = lock_regs_from(s_init);                  // (meaningful in lane 0 of the lock role's wave only)
     for (int epoch = 0; epoch < n_epochs; ++epoch) {
         TRACK_MARK(5);
         __syncthreads();
@@ -639,9 +673,15 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         // (cluster form: the totals go to wave 3, which publishes them while the three measuring roles already wait for
         // the peers' -- their chains are the epoch's critical path, the carrier-phase role's is short)
         double total;
+#ifdef SDR_TRACE_TRACK
+        unsigned long long role_mark_ = 0;
+#endif
         if constexpr (kCluster) total = reduce_taps_rows<kTaps, THREADS, 3>(accr, acci, red, tid);   // value v in lanes v*G.. of wave 3
         else total = reduce_taps<kTaps, THREADS, 0>(accr, acci, red, tid);
         TRACK_MARK(3);
+#ifdef SDR_TRACE_TRACK
+        role_mark_ = wall_clock64();   // (all waves leave the reduction barrier together: per-role time from here to the end of its update)
+#endif
 
         double corr[2 * kTaps];
         bool role_ok = true;
@@ -741,17 +781,22 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
 #pragma unroll
             for (int k2 = 0; k2 < 2 * kTaps; ++k2) corr[k2] = uniform(sh->corr[k2]);
         }
-        if (role_ok && role < 4) loop_update<kTaps>(sh, u, corr, role, rlane);
+        if (role_ok && role < 4) loop_update<kTaps>(sh, u, corr, role, rlane, lk);
+#ifdef SDR_TRACE_TRACK
+        if (rlane == 0 && role < 4 && ch == 0 && part == 0) g_track_phase[48 + role] += wall_clock64() - role_mark_;
+#endif
         TRACK_MARK(4);
         // the next iteration's first barrier orders the roles' LDS writes against everyone's reads
     }
 #ifdef SDR_TRACE_TRACK
     if (tid == 0 && ch == 0 && part == 0) {
-        g_track_phase[30] = clock64() - clk0_;
-        g_track_phase[31] = wall_clock64() - wall0_;
+        g_track_phase[62] = clock64() - clk0_;
+        g_track_phase[63] = wall_clock64() - wall0_;
     }
 #endif
-    // End state: the roles kept the LDS copy of the state current; one lane of the recording part writes it out.
+    // End state: the roles kept the LDS copy of the state current (the lock role hands its registers back now); one lane
+    // of the recording part writes it out.
+    if (role == 2 && rlane == 0) lock_regs_store(lk, sh);
     __syncthreads();
     if (tid == 0 && writer) {
         const int epochs_done = sh->epochs_done;

@@ -15,7 +15,7 @@ for s, sat in enumerate(sats):
 eng.iq_synth(sats, bench.FS, 12.0, 20260003, 0, total)
 items, n_epochs = bench.truth_items(sats, bench.FS, total)
 print(bench.closed_loop_leg(eng, items, 2000))
-buf = np.zeros(32, dtype=np.uint64)
+buf = np.zeros(64, dtype=np.uint64)
 lib = L.load()
 lib.sdr_debug_track_phases.argtypes = [ctypes.c_void_p]
 assert lib.sdr_debug_track_phases(buf.ctypes.data) == 0
@@ -24,5 +24,6 @@ tot = float(buf[:8].sum())
 for n, v in zip(names, buf[:8]):
     print(f"{n:16s} {float(v)*10/1e3/2000:8.2f} us/epoch  {100.0*float(v)/tot:5.1f} %")
 print("per-wave arrival at the reduction (us after the epoch's first barrier):", " ".join(f"{float(v)*10/1e3/2000:.2f}" for v in buf[8:24]))
-if buf[31]:
-    print(f"shader clock during the kernel: {float(buf[30]) / (float(buf[31]) * 10e-9) / 1e6:.0f} MHz")
+print("reduction barrier -> end of the role's update (us): carrier %.2f  code %.2f  lock %.2f  carrier-phase/publisher %.2f" % tuple(float(v) * 10 / 1e3 / 2000 for v in buf[48:52]))
+if buf[63]:
+    print(f"shader clock during the kernel: {float(buf[62]) / (float(buf[63]) * 10e-9) / 1e6:.0f} MHz")
