@@ -461,11 +461,14 @@ __device__ __forceinline__ bool epoch_wraps(const EpochParams& ep, int64_t capac
 // belong to the epoch -- its last group in the single-round form of the closed-loop kernel, which has no separate
 // edge-sample pass: the running sums are there anyway, so the group's share is c(p0+1)*P_v + (c(p0)-c(p0+1))*P_min(nlead,v)
 // and what lies behind sample v is never read.  strip: this lane's kPrefixSlots double2 slots of LDS, slot 0 holding zero.
-template <int FMT, int NT, int W, bool TAIL>
+// ROT8 (16-sample groups only): rc / rs hold the rotations of samples 0..7 alone; the second half is mixed with the
+// same eight and its running sums are turned by (c8, s8) = exp(-1j*8*dphi) where they are read -- 16 FMAs per group
+// instead of eight more rotations per epoch, which cost the closed-loop kernel 28 v_readlane and 32 v_mov.
+template <int FMT, int NT, int W, bool TAIL, bool ROT8 = false>
 __device__ __forceinline__ void wide_group(const Raw8<FMT>* raw, int i0, int v, const double* rc, const double* rs,
                                            const double* shift, const double* step, const double* inv_step,
                                            const uint32_t* lut, double2* strip, double sb, double cb, double* accr,
-                                           double* acci) {
+                                           double* acci, double c8 = 1.0, double s8 = 0.0) {
     constexpr int kHalves = W / kGroup;
     const double di0 = (double)i0;
 
@@ -542,26 +545,32 @@ __device__ __forceinline__ void wide_group(const Raw8<FMT>* raw, int i0, int v, 
     for (int t = 0; t < NT; ++t) pa[t] = strip[nlead[t] < kGroup ? nlead[t] : kGroup];
     double2 pva = make_double2(0.0, 0.0);
     if (TAIL) pva = strip[v < kGroup ? v : kGroup];
+    constexpr int kOff = ROT8 ? 0 : (kHalves - 1) * kGroup;   // which rotations the second half is mixed with
     double qr = 0.0, qi = 0.0;
 #pragma unroll
     for (int j = 0; j < kGroup; ++j) {
         double ar, ai;
         raw[kHalves - 1].get(j, ar, ai);
-        qr = __builtin_fma(-ai, rs[(kHalves - 1) * kGroup + j], __builtin_fma(ar, rc[(kHalves - 1) * kGroup + j], qr));
-        qi = __builtin_fma(ai, rc[(kHalves - 1) * kGroup + j], __builtin_fma(ar, rs[(kHalves - 1) * kGroup + j], qi));
+        qr = __builtin_fma(-ai, rs[kOff + j], __builtin_fma(ar, rc[kOff + j], qr));
+        qi = __builtin_fma(ai, rc[kOff + j], __builtin_fma(ar, rs[kOff + j], qi));
         strip[1 + j] = make_double2(qr, qi);
     }
+    auto turn = [&](double2 q) {   // a running sum of the second half as mixed with the full rotations
+        if (!ROT8) return q;
+        return make_double2(__builtin_fma(-q.y, s8, q.x * c8), __builtin_fma(q.y, c8, q.x * s8));
+    };
     if (TAIL) {
-        const double2 pvb = strip[(v > kGroup ? v : kGroup) - kGroup];
+        const double2 pvb = turn(strip[(v > kGroup ? v : kGroup) - kGroup]);
         pr = pva.x + pvb.x;
         pi = pva.y + pvb.y;
     } else {
-        pr += qr;
-        pi += qi;
+        const double2 qt = turn(make_double2(qr, qi));
+        pr += qt.x;
+        pi += qt.y;
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const double2 qb = strip[(nlead[t] > kGroup ? nlead[t] : kGroup) - kGroup];
+        const double2 qb = turn(strip[(nlead[t] > kGroup ? nlead[t] : kGroup) - kGroup]);
         const double gr = __builtin_fma(sign_diff[t], pa[t].x + qb.x, sign_b[t] * pr);
         const double gi = __builtin_fma(sign_diff[t], pa[t].y + qb.y, sign_b[t] * pi);
         accr[t] = __builtin_fma(-sb, gi, __builtin_fma(cb, gr, accr[t]));
@@ -724,16 +733,10 @@ __device__ __forceinline__ void correlate_epoch_single(const Raw8<FMT>* raw, con
                                                        double* accr, double* acci) {
     double2* strip = prefix_lds + tid * kPrefixSlots;
     strip[0] = make_double2(0.0, 0.0);
-    double rc[kWide], rs[kWide];
-#pragma unroll
-    for (int j = 0; j < kWide; ++j) {
-        rc[j] = K.rc[j];
-        rs[j] = K.rs[j];
-        if (j >= kGroup) {  // (second half in vector registers: see correlate_epoch_wide)
-            asm volatile("" : "+v"(rc[j]));
-            asm volatile("" : "+v"(rs[j]));
-        }
-    }
+    const double* rc = K.rc;       // rotations 0..7 (scalar registers) and exp(-1j*8*dphi) for the second half
+    const double* rs = K.rs;
+    const double c8 = K.rc[kGroup], s8 = K.rs[kGroup];
+    constexpr bool kRot8 = true;
 #pragma unroll
     for (int t = 0; t < NT; ++t) accr[t] = acci[t] = 0.0;
     const bool alive = g < geo.groups;
@@ -744,9 +747,9 @@ __device__ __forceinline__ void correlate_epoch_single(const Raw8<FMT>* raw, con
     sincos_reduced(__builtin_fma(-(double)i0, uniform(dphi), uniform(ep.rem_carrier)), &sb, &cb);
     const int v = ep.n - i0 < kWide ? ep.n - i0 : kWide;         // samples of the group that belong to the epoch
     if (__any(v < kWide))
-        wide_group<FMT, NT, kWide, true>(raw, i0, v, rc, rs, K.shift, K.step, K.inv_step, lut, strip, sb, cb, accr, acci);
+        wide_group<FMT, NT, kWide, true, kRot8>(raw, i0, v, rc, rs, K.shift, K.step, K.inv_step, lut, strip, sb, cb, accr, acci, c8, s8);
     else
-        wide_group<FMT, NT, kWide, false>(raw, i0, v, rc, rs, K.shift, K.step, K.inv_step, lut, strip, sb, cb, accr, acci);
+        wide_group<FMT, NT, kWide, false, kRot8>(raw, i0, v, rc, rs, K.shift, K.step, K.inv_step, lut, strip, sb, cb, accr, acci, c8, s8);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {                               // (not a zero phasor: float rings may hold NaNs out there)
         accr[t] = alive ? accr[t] : 0.0;
