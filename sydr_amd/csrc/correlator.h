@@ -705,9 +705,11 @@ struct SingleGeometry {
     bool fits;     // every group lies inside the ring (an epoch that wraps goes through the per-sample variant)
 };
 
-__device__ __forceinline__ SingleGeometry single_geometry(int64_t start_sample, int n, int64_t capacity) {
+// pos0 = start_sample % capacity, kept by the caller from epoch to epoch (+n, minus the capacity when it passes it):
+// a 64-bit modulo is ~60 instructions, and a lone wave pays for every one of them.
+__device__ __forceinline__ SingleGeometry single_geometry(int64_t pos0, int n, int64_t capacity) {
     SingleGeometry s;
-    s.pos0 = start_sample % capacity;
+    s.pos0 = pos0;
     s.groups = (n + kWide - 1) / kWide;
     s.fits = s.pos0 + (int64_t)s.groups * kWide <= capacity;
     return s;

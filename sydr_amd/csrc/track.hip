@@ -617,6 +617,13 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     Raw8<FMT> cur[2], nxt[2];
     bool have_next = false;
     LockRegs lk = lock_regs_from(s_init);                  // (meaningful in lane 0 of the lock role's wave only)
+    // ring position of the current epoch's first sample: start % capacity once, then += n (minus the capacity when it
+    // passes it) -- the 64-bit modulo is not paid three times per epoch
+    int64_t ring_pos;
+    {
+        const int64_t p0 = s_init.current_sample % capacity;
+        ring_pos = ((int64_t)__builtin_amdgcn_readfirstlane((int)(p0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
+    }
     for (int epoch = 0; epoch < n_epochs; ++epoch) {
         TRACK_MARK(5);
         __syncthreads();
@@ -636,10 +643,11 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         u.rec = (writer && keep_traj) ? traj + ((size_t)ch * n_epochs + epoch) : nullptr;
 
         double accr[kTaps], acci[kTaps];
-        const bool boundary_ok = use_prefix && ep.code_step >= kFastMinCodeStep && !epoch_wraps(ep, capacity);  // (uniform)
         bool single = false;
+        int64_t ring_pos_next = ring_pos + ep.n;               // (n <= capacity: checked by the role that announced it)
+        if (ring_pos_next >= capacity) ring_pos_next -= capacity;
         if constexpr (kCluster) {
-            const SingleGeometry geo = single_geometry(ep.start_sample, ep.n, capacity);
+            const SingleGeometry geo = single_geometry(ring_pos, ep.n, capacity);
             single = use_prefix && ep.code_step >= kFastMinCodeStep && ep.code_step <= kFastMaxCodeStep && geo.fits &&
                      geo.groups <= cluster_lanes;
             if (single) {
@@ -656,6 +664,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             }
         }
         if (!single) {
+            const bool boundary_ok = use_prefix && ep.code_step >= kFastMinCodeStep && !epoch_wraps(ep, capacity);  // (uniform)
             EpochConsts<kTaps> K;
             compute_constants<kTaps>(K, ep, sh->spacing, dphi, cluster_lanes);
             TRACK_MARK(1);
@@ -710,7 +719,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             // retires loads in order, and these are ~0.4 us older than the first poll).
             have_next = single && epoch + 1 < n_epochs;
             if (have_next) {
-                const SingleGeometry next = single_geometry(ep.start_sample + ep.n, ep.n, capacity);
+                const SingleGeometry next = single_geometry(ring_pos_next, ep.n, capacity);
                 single_load<FMT>(ring, single_load_pos(next, lane_global, capacity), nxt);
             }
             if (role < 3) {
@@ -781,6 +790,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
 #pragma unroll
             for (int k2 = 0; k2 < 2 * kTaps; ++k2) corr[k2] = uniform(sh->corr[k2]);
         }
+        ring_pos = ring_pos_next;
         if (role_ok && role < 4) loop_update<kTaps>(sh, u, corr, role, rlane, lk);
 #ifdef SDR_TRACE_TRACK
         if (rlane == 0 && role < 4 && ch == 0 && part == 0) g_track_phase[48 + role] += wall_clock64() - role_mark_;
