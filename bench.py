@@ -273,9 +273,10 @@ def multignss_workload(args, rank, local_rank, world, torch, dist, eng=None, emi
     per_step = 250                                                   # epochs per step = 1 s of stream
     n_avail = max(1, min(e_gps, e_e1) // per_step)
 
-    def run_step(k):
-        for plan, n_ch, _, _ in plans:
-            plan.run((k % n_avail) * per_step * n_ch, per_step * n_ch)
+    def run_step(k):                                                 # one pass over the whole stream, a second per launch pair
+        for j in range(n_avail):
+            for plan, n_ch, _, _ in plans:
+                plan.run(j * per_step * n_ch, per_step * n_ch)
 
     for k in range(args.warmup):
         run_step(k)
@@ -299,10 +300,8 @@ def multignss_workload(args, rank, local_rank, world, torch, dist, eng=None, emi
     eng.prof_enable(False)
     kern_ms, launches = eng.prof_read("epl_kernel")
     ch_samples = 0
-    for k in range(args.steps):
-        for _, n_ch, _, items in plans:
-            lo = (k % n_avail) * per_step * n_ch
-            ch_samples += int(items["n_samples"][lo:lo + per_step * n_ch].sum())
+    for _, n_ch, _, items in plans:
+        ch_samples += int(items["n_samples"][:n_avail * per_step * n_ch].sum()) * args.steps
     stream_samples = ch_samples / (n_gps + n_e1)
     job = float(ch_samples)
     if world > 1:
@@ -316,7 +315,8 @@ def multignss_workload(args, rank, local_rank, world, torch, dist, eng=None, emi
               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
               "dtype": "f64", "data": "synthetic",
               "config": {"workload": "GPS L1 C/A (32 ch) + E1-like BOC(1,1) with seeded 4092-chip codes (32 ch) per GPU, "
-                                     f"5 taps, fs=50 MHz, 4 ms epochs, {args.stream_seconds:g} s ci8 stream, 1 step = 1 s",
+                                     f"5 taps, fs=50 MHz, 4 ms epochs, {args.stream_seconds:g} s ci8 stream, 1 step = one pass over the "
+                                     f"whole stream = {n_avail} launches of 1 s per signal",
                          "channels_per_gpu": n_gps + n_e1, "fs_hz": fs, "taps": 5, "iq_format": "ci8",
                          "note": "no reference implementation exists for this configuration (SURVEY.md section 0); "
                                  "parity is against the oracle's generalised restatement"},
@@ -411,8 +411,8 @@ def main():
     ap.add_argument("--workload", choices=["l1ca32", "multignss"], default="l1ca32",
                     help="l1ca32 = BASELINE configs[2] (headline); multignss = configs[3]/[4] geometry")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--stream-seconds", type=float, default=60.0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-acquisition", action="store_true")
@@ -476,8 +476,13 @@ def main():
     step_samples = [int(items["n_samples"][k * per_step:(k + 1) * per_step].sum()) for k in range(n_steps_avail)]
     batch_stream = eng.stream_create()                      # one HIP stream per channel batch (north_star)
 
+    # One step = one pass of the correlators over the WHOLE stream (configs[2]: 60 s), as n_steps_avail launches of one
+    # second each (32 000 channel-epochs per launch).  A step of one launch (0.3 ms) would put the driver's whole timed
+    # region inside the ~40 ms the chip takes to settle its clocks under this kernel (tools/epl_ramp.py: 0.37 ms per
+    # launch falling to 0.31 over the first ~100 launches, whatever ran before).
     def run_step(k):
-        plan.run((k % n_steps_avail) * per_step, per_step, stream=batch_stream)
+        for j in range(n_steps_avail):
+            plan.run(j * per_step, per_step, stream=batch_stream)
 
     def barrier():
         eng.stream_sync(batch_stream)
@@ -497,7 +502,8 @@ def main():
     eng.stream_sync(batch_stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ch_samples = sum(step_samples[k % n_steps_avail] for k in range(args.steps))  # channel-samples, this rank
+    ch_samples = sum(step_samples) * args.steps              # channel-samples, this rank
+    n_launches = n_steps_avail * args.steps
     job_ch_samples = float(ch_samples)
     if world > 1:
         dist.barrier()
@@ -514,9 +520,9 @@ def main():
     stream_samples = ch_samples / N_CH                       # samples of THE stream consumed per rank (same on all)
     value = job_ch_samples / N_CH / elapsed / 1e6            # the job's channel-samples, in units of 32-channel batches
     avg_kernel_s = kern_ms / max(1, launches) * 1e-3
-    algo_bytes_per_launch = 2.0 * ch_samples / max(1, args.steps)  # 2 B per channel-sample (ci8)
+    algo_bytes_per_launch = 2.0 * ch_samples / max(1, n_launches)  # 2 B per channel-sample (ci8)
     achieved = algo_bytes_per_launch / avg_kernel_s / 1e9 if launches else 0.0
-    flops = (6 + 4 * len(SPACING)) * ch_samples / max(1, args.steps)
+    flops = (6 + 4 * len(SPACING)) * ch_samples / max(1, n_launches)
 
     result = {
         "metric": "IQ Msamples/s through 32-ch E/P/L correlators @25 MHz fs",
@@ -524,7 +530,8 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "GPS L1 C/A tracking, 32 channels/GPU, E/P/L (3 taps), fs=25 MHz, 1 ms integration, "
-                               f"{args.stream_seconds:g} s synthetic ci8 IQ stream, 1 step = 1 s of stream",
+                               f"{args.stream_seconds:g} s synthetic ci8 IQ stream, 1 step = one pass over the whole "
+                               f"stream = {n_steps_avail} launches of 1 s (32 000 channel-epochs) each",
                    "channels_per_gpu": N_CH, "channels_total": n_total, "fs_hz": FS, "taps": len(SPACING), "iq_format": "ci8",
                    "mode": "open-loop batched (true NCO trajectory, 32000 channel-epochs per launch)",
                    "sharding": f"one stream of {n_total} satellites replicated on {world} GPU(s) (same seed), channels "
@@ -590,7 +597,7 @@ def main():
     eng.close()
     if rank == 0 and world == 1 and not args.no_multignss:
         margs = argparse.Namespace(**vars(args))
-        margs.stream_seconds, margs.steps, margs.warmup = 10.0, 9, 1
+        margs.stream_seconds, margs.steps, margs.warmup = 10.0, 4, 2
         m = multignss_workload(margs, rank, local_rank, world, torch, dist, emit=False)
         result["multignss"] = {k: m[k] for k in ("metric", "value", "unit", "ms_per_step", "x_realtime", "config", "roofline",
                                                   "cpu_baseline", "closed_loop") if k in m}
@@ -604,8 +611,9 @@ def acquisition_leg(eng, rf):
     """BASELINE configs[1]: PCPS, all 32 PRNs, +-5 kHz @ 250 Hz, 1 ms coherent, indices + ratio only."""
     from oracle import sydr_oracle as orc
     slots = np.arange(N_CH)
-    eng.pcps(slots, 0, FS, 0.0, 5000.0, 250.0, 1, 1)  # warm (allocations, twiddles)
-    reps = 5
+    for _ in range(60):                               # warm: allocations, twiddles, and ~35 ms for the clocks to settle
+        eng.pcps(slots, 0, FS, 0.0, 5000.0, 250.0, 1, 1)
+    reps = 20
     t0 = time.perf_counter()
     for _ in range(reps):
         pb, pc, pr, _ = eng.pcps(slots, 0, FS, 0.0, 5000.0, 250.0, 1, 1)

@@ -148,6 +148,7 @@ _PROTOTYPES = {
     "sdr_stream_create": (C.c_int, [_VP, C.POINTER(C.c_int)]),
     "sdr_stream_sync": (C.c_int, [_VP, C.c_int]),
     "sdr_epl_plan_run_range_on": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int]),
+    "sdr_epl_plan_variant": (C.c_int, [_VP]),
 }
 ABI_VERSION = 3
 

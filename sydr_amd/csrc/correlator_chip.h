@@ -103,7 +103,12 @@ struct ChipBlock {
 // of P_M and P_(M+1) are unconditional -- two scalar instructions per sample (bit test + branch for a tap position)
 // instead of six with two branches (measured: 0.436 -> 0.40 ms per launch; testing two samples per branch with
 // both bodies duplicated was slower again: 0.415).
-template <int NT, bool SINGLE_WAVE, int KM = 0>
+// KS > 0 (with KM > 0): every other tap's switch position m_t is known too (KS = 12: taps half a chip either side of
+// the anchor at 24.4 samples per chip -- the reference's default correlator spacing at 25 MHz; the host checked it for
+// every epoch of the launch, and an epoch that disagrees is flagged and redone per sample).  All four positions
+// somebody reads -- P_KS, P_(KS+1), P_KM, P_(KM+1) -- are then compile-time: they stay in registers, the sample loop
+// is one straight line (no strip stores, no bit tests, no branches) and a lane picks its pair member with selects.
+template <int NT, bool SINGLE_WAVE, int KM = 0, int KS = 0>
 __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ring, int64_t capacity,
                                                      const EpochParams& ep, double dphi, const EpochConsts<NT>& K,
                                                      const uint32_t* lut, double2* strip_lds, double2* rot, int tid,
@@ -139,10 +144,20 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
     const char* ring_base = static_cast<const char*>(ring) + base * 2;
 
     // in-block rotations exp(-1j*k*dphi), k = 0..25: one per lane, parked in LDS, read back as broadcasts
-    if (wlane < kChipMax) {
-        double sn, cs;
-        sincos_reduced(-(double)wlane * dphi_u, &sn, &cs);
-        rot[wlane] = make_double2(cs, sn);
+    // (KS: the block is summed in two halves of KS + 1 and KM - KS samples that both start at rotation 0, so only
+    // k = 1 .. KS + 1 are needed and they fit in scalar registers -- no LDS reads in the sample loop at all)
+    constexpr bool kStatic = KM != 0 && KS != 0;
+    constexpr int kHalf = KS + 1;
+    double urc[kStatic ? kHalf + 1 : 1], urs[kStatic ? kHalf + 1 : 1];
+    {
+        double sn = 0.0, cs = 0.0;
+        if (wlane < kChipMax) sincos_reduced(-(double)wlane * dphi_u, &sn, &cs);
+        if constexpr (kStatic) {
+#pragma unroll
+            for (int k = 1; k <= kHalf; ++k) urc[k] = lane_value(cs, k), urs[k] = lane_value(sn, k);
+        } else if (wlane < kChipMax) {
+            rot[wlane] = make_double2(cs, sn);
+        }
     }
 
     bool bad = false;
@@ -177,6 +192,7 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
             J[t] = j;
             delta[t] = (uint64_t)d;
             m[t] = (int)(d >> 32);
+            bad = bad || (KS != 0 && m[t] != KS);
             evmask |= (1u << m[t]) | (2u << m[t]);
         }
         const int k_last = M + 1;                       // no prefix beyond P_(M+1) is ever read
@@ -275,13 +291,15 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
             // bit tests out of the round loop as 27 lane masks and spills them through v_writelane / v_readlane
             unsigned evm = evmask;
             int klast = k_last;
-            asm volatile("" : "+s"(evm), "+s"(klast));
+            if constexpr (!kStatic) asm volatile("" : "+s"(evm), "+s"(klast));
             // the in-block rotations come from LDS as broadcasts, fetched a few samples ahead of their use (the
             // uniform branches below end a basic block: nothing is hoisted across them for us)
             constexpr int kAhead = 4;
             double2 rr[kChipMax + kAhead];
+            if constexpr (!kStatic) {
 #pragma unroll
-            for (int k = 0; k < kAhead; ++k) rr[k] = rot[k];
+                for (int k = 0; k < kAhead; ++k) rr[k] = rot[k];
+            }
             auto park = [&]() {                         // P_k -> the lane's next strip slot
                 *wp = make_double2(pr, pi);
                 ++wp;
@@ -297,7 +315,28 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                 pr = __builtin_fma(-ai, r.y, __builtin_fma(ar, r.x, pr));
                 pi = __builtin_fma(ai, r.x, __builtin_fma(ar, r.y, pi));
             };
-            if constexpr (KM != 0) {
+            double capr[3] = {0.0, 0.0, 0.0}, capi[3] = {0.0, 0.0, 0.0};   // KS: P_KS, second half before its last sample, second half
+            if constexpr (kStatic) {
+                static_assert(2 * kHalf >= KM + 1 && kHalf < KM, "two halves of at most KS + 1 samples cover the block");
+                // first half: samples 0 .. KS (P_KS is its running sum before the last one, P_(KS+1) its total);
+                // second half: samples KS+1 .. KM summed from rotation 0 again, turned by exp(-1j*(KS+1)*dphi) where read
+                static_for<0, KM + 1>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    constexpr int j = k < kHalf ? k : k - kHalf;
+                    const int w = (int)b.raw[k >> 1];
+                    const double ar = (k & 1) ? (double)(int)(int8_t)(w >> 16) : (double)(int)(int8_t)w;
+                    const double ai = (k & 1) ? (double)(w >> 24) : (double)(int)(int8_t)(w >> 8);
+                    if constexpr (k == KS) capr[0] = pr, capi[0] = pi;
+                    if constexpr (k == KM) capr[1] = pr, capi[1] = pi;
+                    if constexpr (k == kHalf) capr[2] = pr, capi[2] = pi;          // first half's total
+                    if constexpr (j == 0) {
+                        pr = ar, pi = ai;
+                    } else {
+                        pr = __builtin_fma(-ai, urs[j], __builtin_fma(ar, urc[j], pr));
+                        pi = __builtin_fma(ai, urc[j], __builtin_fma(ar, urs[j], pi));
+                    }
+                });
+            } else if constexpr (KM != 0) {
                 // positions KM and KM + 1 are always events; the others (the taps' m_t, m_t + 1 < KM) are looked for
                 // two samples at a time
                 static_for<0, KM>([&](auto kc) {         // samples below KM: a tap's position may sit in front of any of them
@@ -326,7 +365,14 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                     }
                 }
             }
-            const double2 ptot = strip[rank[A] + b.dn];
+            double2 ptot;
+            if constexpr (kStatic) {
+                const double qr = b.dn ? pr : capr[1], qi = b.dn ? pi : capi[1];   // second half up to M or M + 1 samples
+                ptot.x = __builtin_fma(-qi, urs[kHalf], __builtin_fma(qr, urc[kHalf], capr[2]));
+                ptot.y = __builtin_fma(qi, urc[kHalf], __builtin_fma(qr, urs[kHalf], capi[2]));
+            } else {
+                ptot = strip[rank[A] + b.dn];
+            }
             const int first = round * stride;           // (a lane beyond the last whole chip re-does the last one)
             const uint32_t* lq = lut + q_lane + (first + lane <= last_idx ? first : last_idx - lane);   // replica entry of the block's anchor chip
 #pragma unroll
@@ -337,7 +383,11 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                     gr = c * ptot.x;
                     gi = c * ptot.y;
                 } else {
-                    const double2 ps = strip[rank[t] + b.ds[t]];
+                    double2 ps;
+                    if constexpr (kStatic)
+                        ps = b.ds[t] ? make_double2(capr[2], capi[2]) : make_double2(capr[0], capi[0]);
+                    else
+                        ps = strip[rank[t] + b.ds[t]];
                     const double ca = __hiloint2double((int)lq[J[t]], 0);
                     const double cbn = __hiloint2double((int)lq[J[t] + 1], 0);
                     const double diff = ca - cbn;

@@ -90,6 +90,7 @@ struct sdr_engine {
     DevBuf pcps_blu, pcps_blu_x, pcps_blu_a, pcps_blu_b;
     int64_t pcps_blu_n = 0;
     bool epl_no_chip = false;        // diagnostics: keep the 16-sample boundary variant where the chip-aligned one would run
+    bool epl_no_split = false;       // diagnostics: keep the run-time switch positions where the KS = 12 kernel would run
     int pcps_prn_chunk = 0;          // diagnostics: PRNs per inverse sweep (0 = as many as the work buffers hold)
     bool pcps_force_map = false;     // diagnostics / tests: materialise the map even when the caller does not ask for it
     bool pcps_force_passes = false;  // diagnostics: use the one-kernel-per-radix-pass transform instead of the four-step one

@@ -46,7 +46,7 @@ constexpr int kLongLutWords = 4096;  // replicas of 16 KB and more (multi-period
 #ifndef SDR_EPL_WAVES
 #define SDR_EPL_WAVES 1
 #endif
-template <int FMT, int NT, int W, int KM = 0, int WPW = 1>
+template <int FMT, int NT, int W, int KM = 0, int WPW = 1, int KS = 0>
 __global__ __launch_bounds__(kWaveThreads * WPW, SDR_EPL_WAVES) void epl_kernel(const void* __restrict__ ring, int64_t capacity,
                                                        const sdr_epl_item* __restrict__ items, int n_items, int group_stride,
                                                        const uint32_t* __restrict__ luts,
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kWaveThreads * WPW, SDR_EPL_WAVES) void epl_kernel(
     if constexpr (W == kChipMax && FMT == SDR_FMT_CI8) {
         // chip-aligned blocks (correlator_chip.h); an epoch it does not cover is redone per sample
         const bool done = chip_variant_applies(ep, capacity) &&
-                          correlate_epoch_chip<NT, true, KM>(ring, capacity, ep, dphi, K, lut, prefix,
+                          correlate_epoch_chip<NT, true, KM, KS>(ring, capacity, ep, dphi, K, lut, prefix,
                                                          prefix + kThreads * chip_strip_slots<NT>() + wave * kChipMax,
                                                          tid, lane, kWaveThreads, lane, accr, acci);
         if (!done) {
@@ -149,7 +149,9 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
             launch(epl_kernel<FMT, NT, 0, 0, 4>);
         return;
     }
-    if (wide == kChipMax + 24 && FMT == SDR_FMT_CI8)   // chip-aligned, every epoch with 24 or 25 samples per chip
+    if (wide == kChipMax + 24 + 256 * 12 && FMT == SDR_FMT_CI8 && NT == 3)   // ... and both outer taps switching at sample 12 or 13
+        launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 1, (NT == 3 ? 12 : 0)>);
+    else if (wide >= kChipMax + 24 && FMT == SDR_FMT_CI8)   // chip-aligned, every epoch with 24 or 25 samples per chip
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24>);
     else if (wide == kChipMax && FMT == SDR_FMT_CI8)
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16)>);
@@ -212,16 +214,34 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
     double max_step = 0.0, min_step = 1e300;
     const double s_anchor = spacing[n_taps < 5 ? n_taps / 2 : 2];   // centre tap of the first chunk of taps the kernels serve together
     bool all_m24 = true;
+    bool all_s12 = n_taps == 3;   // both outer taps switch chips 12.x samples into the anchor's block (KS = 12 kernel)
     for (int i = 0; i < n_items; ++i) {
         const sdr_epl_item& it = items[i];
         {   // samples per chip of the anchor tap's np.linspace step, exactly as the kernel derives it (correlator_chip.h)
+            const double two32 = 4294967296.0;
             const double nd = (double)it.n_samples;
-            const double sh = it.rem_code + s_anchor;
-            double stop = it.code_step * nd;
-            stop = stop + sh;
-            const double st = (stop - sh) / nd;
-            const double inv = 1.0 / st;
-            all_m24 = all_m24 && (int)((int64_t)std::rint(inv * 4294967296.0) >> 32) == 24;
+            auto line = [&](double spc, double& sh, double& inv) {
+                sh = it.rem_code + spc;
+                double stop = it.code_step * nd;
+                stop = stop + sh;
+                inv = 1.0 / ((stop - sh) / nd);
+            };
+            double sh, inv;
+            line(s_anchor, sh, inv);
+            const int64_t tfx = (int64_t)std::rint(inv * two32);
+            all_m24 = all_m24 && (int)(tfx >> 32) == 24;
+            for (int t = 0; all_s12 && all_m24 && t < 3; t += 2) {
+                // the kernel's own derivation of the switch offset (a Q32.32 sample count); its reciprocal is a Newton
+                // step, not a division, so a margin of 2^-10 sample keeps the two from disagreeing about the integer part
+                double sht, invt;
+                line(spacing[t], sht, invt);
+                const int64_t ufx = (int64_t)std::floor(-sh * inv * two32), ut = (int64_t)std::floor(-sht * invt * two32);
+                const int j = (int)std::ceil(sht - sh) - 1;
+                int64_t d = (ut - ufx) + (int64_t)(1 + j) * tfx;
+                if (d < 0) d += tfx; else if (d >= tfx) d -= tfx;
+                const int64_t margin = (int64_t)1 << 22;
+                all_s12 = d >= ((int64_t)12 << 32) + margin && d < ((int64_t)13 << 32) - margin;
+            }
         }
         if (it.code_step > max_step) max_step = it.code_step;
         if (it.code_step < min_step) min_step = it.code_step;
@@ -248,7 +268,8 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
     // every item inside the chip-aligned variant's range (ci8 ring): lanes own whole chips instead of 16 samples
     if (boundary_ok && e->iq_fmt == SDR_FMT_CI8 && min_step >= sdr::kChipMinCodeStep && max_step <= sdr::kChipMaxCodeStep &&
         !e->epl_no_chip)
-        *wide = sdr::kChipMax + ((all_m24 && (n_taps == 3 || n_taps == 1 || n_taps == 2)) ? 24 : 0);
+        *wide = sdr::kChipMax + ((all_m24 && (n_taps == 3 || n_taps == 1 || n_taps == 2)) ? 24 : 0) +
+                ((all_m24 && all_s12 && !e->epl_no_split) ? 256 * 12 : 0);
     return SDR_OK;
 }
 
@@ -336,6 +357,8 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
     SDR_HIP(hipGetLastError());
     return SDR_OK;
 }
+
+int sdr_epl_plan_variant(const sdr_epl_plan* p) { return p ? p->wide : -1; }
 
 int sdr_epl_plan_run(sdr_engine* e, sdr_epl_plan* p) {
     if (!p) return sdr_fail(SDR_ERR_INVALID, "plan is NULL");

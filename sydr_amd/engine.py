@@ -44,6 +44,11 @@ class EplPlan:
             first, count = 0, self.n_items
         check(self._lib.sdr_epl_plan_run_range_on(self._e._h, self._h, int(first), int(count), int(stream)))
 
+    @property
+    def variant(self) -> int:
+        """Which correlator variant the items selected (sdr_epl_plan_variant: diagnostics)."""
+        return int(self._lib.sdr_epl_plan_variant(self._h))
+
     def fetch(self) -> np.ndarray:
         out = np.empty((self.n_items, 2 * self.n_taps), dtype=np.float64)
         check(self._lib.sdr_epl_plan_fetch(self._e._h, self._h, ptr(out)))

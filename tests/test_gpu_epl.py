@@ -331,3 +331,68 @@ def test_chip_aligned_variant_over_its_whole_range(engine, spacing):
             scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 50.0), 2)
             assert np.max(np.abs(got[k] - ref) / scale) < 1e-9, (group, k, step[k], n[k])
             assert np.max(np.abs(other[k] - ref) / scale) < 1e-9, (group, k)
+
+
+def test_compile_time_tap_switch_variant(engine):
+    """At 25 MHz with the reference's default spacing (+-0.5 chip) both outer taps switch chips 12.2 samples into the
+    prompt tap's chip in EVERY block: the plan then selects the kernel that has those positions compiled in (running
+    sums kept in registers, rotations in scalar registers, two half-block sums).  Checked against the oracle and against
+    the run-time-position kernel of the same library; a spacing whose switch falls within the host's margin of a
+    sample (12.00002 samples) must NOT select it, and epochs the kernel cannot cover (too short, block length 25)
+    fall back inside the launch."""
+    rng = np.random.default_rng(20261005)
+    cap = 8 * 60000
+    raw = rng.integers(-100, 100, 2 * cap).astype(np.int8)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(8, 1023, 3)
+    for s in range(8):
+        engine.load_gps_code(s, 3 * s + 2)
+    rf = orc.iq_to_complex(raw)
+    n_items = 96
+    step = (1.023e6 + rng.uniform(-4, 4, n_items)) / 25e6
+    rem_code = rng.uniform(0, step)
+    rem_code[:6] = [0.0, 0.5, 0.25, 1e-9, step[4] / 2, step[5] * (1 - 1e-12)]
+    periods = rng.integers(1, 3, n_items)
+    n = np.ceil((1023 * periods - rem_code) / step).astype(np.int64) + rng.integers(-1, 2, n_items)
+    n[6:10] = [3, 40, 70, 26]
+    start = rng.integers(0, cap - 60000, n_items)
+    start[10:13] = [0, 1, cap - int(n[12]) - 1]
+    slot = rng.integers(0, 8, n_items)
+    f = rng.uniform(-6000, 6000, n_items)
+    f[13:16] = [0.0, 4.092e6, -4.092e6]                  # no carrier at all; an intermediate frequency
+    rem_carrier = rng.uniform(0, 2 * np.pi, n_items)
+    items = make_items(slot, n, start, f, rem_carrier, rem_code, step)
+
+    def run(spacing, no_split):
+        engine.set_option("epl_no_split_variant", int(no_split))
+        try:
+            plan = engine.epl_plan(items, spacing, 25e6)
+            plan.run()
+            return plan.variant, plan.fetch()
+        finally:
+            engine.set_option("epl_no_split_variant", 0)
+
+    def check(got, spacing):
+        for k in range(n_items):
+            x = orc.ring_slice(rf, int(start[k]), int(n[k]))
+            ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(3 * int(slot[k]) + 2)), 25e6, f[k], rem_carrier[k],
+                                   rem_code[k], step[k], spacing))
+            scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 50.0), 2)
+            assert np.max(np.abs(got[k] - ref) / scale) < 1e-9, (k, step[k], n[k])
+
+    half = (-0.5, 0.0, 0.5)
+    v_split, got = run(half, False)
+    v_dyn, other = run(half, True)
+    assert v_split == 26 + 24 + 256 * 12 and v_dyn == 26 + 24
+    check(got, half)
+    check(other, half)
+    # a switch 12.00002 samples into the block is too close to a sample for a compile-time position
+    near = 12.00002 * 1.023e6 / 25e6
+    v_near, got_near = run((-near, 0.0, near), False)
+    assert v_near == 26 + 24
+    check(got_near, (-near, 0.0, near))
+    # asymmetric spacings: one tap at 12.x, the other not
+    v_asym, got_asym = run((-0.5, 0.0, 0.3), False)
+    assert v_asym == 26 + 24
+    check(got_asym, (-0.5, 0.0, 0.3))
