@@ -1,5 +1,7 @@
+"""Same-process A/B of the two headline E/P/L kernels (tap switch positions compiled in / found at run time) on one box:
+alternating groups of 20 launches, and the difference of their outputs.      python tools/epl_ab.py"""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
 from sydr_amd.engine import FMT_CI8, Engine

@@ -1,5 +1,8 @@
+"""Launch-time trajectory of the headline E/P/L launch from a cold start: the chip settles its clocks under this kernel
+over the first ~100 launches (~35 ms), whatever ran before (a copy kernel does not do it).  Prints kernel ms / wall ms per
+launch for consecutive groups of 20 launches.      python tools/epl_ramp.py [seconds idle before the first launch]"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
 from sydr_amd.engine import FMT_CI8, Engine
