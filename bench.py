@@ -273,10 +273,9 @@ def multignss_workload(args, rank, local_rank, world, torch, dist, eng=None, emi
     per_step = 250                                                   # epochs per step = 1 s of stream
     n_avail = max(1, min(e_gps, e_e1) // per_step)
 
-    def run_step(k):                                                 # one pass over the whole stream, a second per launch pair
-        for j in range(n_avail):
-            for plan, n_ch, _, _ in plans:
-                plan.run(j * per_step * n_ch, per_step * n_ch)
+    def run_step(k):                                                 # one pass over the whole stream: one launch per signal
+        for plan, n_ch, _, _ in plans:
+            plan.run(0, n_avail * per_step * n_ch)
 
     for k in range(args.warmup):
         run_step(k)
@@ -316,7 +315,7 @@ def multignss_workload(args, rank, local_rank, world, torch, dist, eng=None, emi
               "dtype": "f64", "data": "synthetic",
               "config": {"workload": "GPS L1 C/A (32 ch) + E1-like BOC(1,1) with seeded 4092-chip codes (32 ch) per GPU, "
                                      f"5 taps, fs=50 MHz, 4 ms epochs, {args.stream_seconds:g} s ci8 stream, 1 step = one pass over the "
-                                     f"whole stream = {n_avail} launches of 1 s per signal",
+                                     f"whole stream = one launch of {n_avail} s per signal",
                          "channels_per_gpu": n_gps + n_e1, "fs_hz": fs, "taps": 5, "iq_format": "ci8",
                          "note": "no reference implementation exists for this configuration (SURVEY.md section 0); "
                                  "parity is against the oracle's generalised restatement"},
@@ -414,6 +413,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--stream-seconds", type=float, default=60.0)
+    ap.add_argument("--launch-seconds", type=float, default=0.0,
+                    help="seconds of stream per E/P/L launch (0 = the whole stream in one launch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-acquisition", action="store_true")
     ap.add_argument("--no-closed-loop", action="store_true")
@@ -480,9 +481,15 @@ def main():
     # second each (32 000 channel-epochs per launch).  A step of one launch (0.3 ms) would put the driver's whole timed
     # region inside the ~40 ms the chip takes to settle its clocks under this kernel (tools/epl_ramp.py: 0.37 ms per
     # launch falling to 0.31 over the first ~100 launches, whatever ran before).
+    # The pass is ONE launch by default (1.9 M single-wave workgroups at 60 s): every launch ends with a partial round
+    # of workgroups on the 3072 resident slots, and launches of one second each cost 4 % more per second of stream
+    # (tools/epl_launch_size.py); --launch-seconds picks smaller launches.
+    secs_per_launch = n_steps_avail if args.launch_seconds <= 0 else max(1, min(n_steps_avail, int(args.launch_seconds)))
+    launch_starts = list(range(0, n_steps_avail, secs_per_launch))
+
     def run_step(k):
-        for j in range(n_steps_avail):
-            plan.run(j * per_step, per_step, stream=batch_stream)
+        for j in launch_starts:
+            plan.run(j * per_step, min(secs_per_launch, n_steps_avail - j) * per_step, stream=batch_stream)
 
     def barrier():
         eng.stream_sync(batch_stream)
@@ -503,7 +510,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ch_samples = sum(step_samples) * args.steps              # channel-samples, this rank
-    n_launches = n_steps_avail * args.steps
+    n_launches = len(launch_starts) * args.steps
     job_ch_samples = float(ch_samples)
     if world > 1:
         dist.barrier()
@@ -531,9 +538,10 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "GPS L1 C/A tracking, 32 channels/GPU, E/P/L (3 taps), fs=25 MHz, 1 ms integration, "
                                f"{args.stream_seconds:g} s synthetic ci8 IQ stream, 1 step = one pass over the whole "
-                               f"stream = {n_steps_avail} launches of 1 s (32 000 channel-epochs) each",
+                               f"stream = {len(launch_starts)} launch(es) of {secs_per_launch} s "
+                               f"({secs_per_launch * 32000} channel-epochs) each",
                    "channels_per_gpu": N_CH, "channels_total": n_total, "fs_hz": FS, "taps": len(SPACING), "iq_format": "ci8",
-                   "mode": "open-loop batched (true NCO trajectory, 32000 channel-epochs per launch)",
+                   "mode": f"open-loop batched (true NCO trajectory, {secs_per_launch * 32000} channel-epochs per launch)",
                    "sharding": f"one stream of {n_total} satellites replicated on {world} GPU(s) (same seed), channels "
                                f"sharded {N_CH} per GPU, one HIP stream per channel batch, no collective"},
         "x_realtime": stream_samples / elapsed / FS,          # seconds of THE stream (all channels tracked) per second
@@ -551,11 +559,13 @@ def main():
     if os.path.exists(pmc):
         try:
             info = json.load(open(pmc))
-            result["roofline"]["traffic"] = info.get("epl_kernel_hbm_bytes_per_launch")
-            if info.get("epl_kernel_valu_insts_per_launch"):
+            epochs_per_launch = ch_samples / max(1, n_launches) * len(items) / max(1.0, float(items["n_samples"].sum()))
+            if info.get("epl_kernel_hbm_bytes_per_epoch"):   # counters are per channel-epoch (one workgroup each), scaled to this launch size
+                result["roofline"]["traffic"] = info["epl_kernel_hbm_bytes_per_epoch"] * epochs_per_launch
+            if info.get("epl_kernel_valu_insts_per_epoch"):
                 # VALU issue roof from the SQ counter pass (tools/summarize_pmc.py): wave-instructions x 4 cycles
                 # over 1024 SIMDs at 2.4 GHz against THIS run's launch duration
-                insts = float(info["epl_kernel_valu_insts_per_launch"])
+                insts = float(info["epl_kernel_valu_insts_per_epoch"]) * epochs_per_launch
                 result["roofline"]["valu_issue"] = {"insts_per_launch": insts,
                                                     "busy_frac": insts * 4.0 / 1024.0 / 2.4e9 / avg_kernel_s if launches else None,
                                                     "source": info.get("source")}

@@ -913,10 +913,16 @@ void run_four_step_t(sdr_engine* e, const FourStep& f, PassArgs a, int batch, do
 
 // Tile widths: 8 columns for kernel A (128-byte runs), 4 rows for kernel B -- its LDS footprint is the larger
 // one (N2 >= N1) and halving it (5 instead of 2 workgroups per CU at N = 25000) measured 9 % faster than 8.
-constexpr int kRowTile = 4;
+#ifndef SDR_PCPS_ROW_TILE
+#define SDR_PCPS_ROW_TILE 4
+#endif
+#ifndef SDR_PCPS_COL_TILE
+#define SDR_PCPS_COL_TILE 8
+#endif
+constexpr int kRowTile = SDR_PCPS_ROW_TILE;
 template <bool INV, int LOAD0, int STORE_LAST, int FMT>
 void run_four_step(sdr_engine* e, const FourStep& f, PassArgs a, int batch, double2* Z, double2* final_out) {
-    run_four_step_t<INV, LOAD0, STORE_LAST, FMT, 8, kRowTile>(e, f, a, batch, Z, final_out);
+    run_four_step_t<INV, LOAD0, STORE_LAST, FMT, SDR_PCPS_COL_TILE, kRowTile>(e, f, a, batch, Z, final_out);
 }
 // per-wave records one map-free inverse sweep leaves per transform
 inline int records_per_transform(const FourStep& f) { return ((f.N1 + kRowTile - 1) / kRowTile) * (kThreads / 64); }

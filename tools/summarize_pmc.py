@@ -69,11 +69,19 @@ if head:
         fetch, write = full("FETCH_SIZE") * 1024, full("WRITE_SIZE") * 1024
         info.update({"epl_kernel": k, "epl_kernel_hbm_bytes_per_launch": 2 * fetch + write,
                      "epl_fetch_size_bytes_raw": fetch, "epl_write_size_bytes": write,
-                     "epl_workload": "bench.py step: 32 ch x 1000 epochs x ~25000 samples ci8 (1.6e9 algorithmic bytes)"})
+                     "epl_workload": "bench.py launch of the PMC passes: 32 ch x ~25000 samples ci8 per epoch (50 KB algorithmic bytes per channel-epoch)"})
     for counter, key in (("SQ_INSTS_VALU", "epl_kernel_valu_insts_per_launch"), ("SQ_INSTS_SALU", "epl_kernel_salu_insts_per_launch"),
                          ("SQ_INSTS_LDS", "epl_kernel_lds_insts_per_launch")):
         if full(counter) is not None:
             info[key] = full(counter)
+    # one single-wave workgroup per channel-epoch: SQ_WAVES of the profiled launch = its channel-epochs; bench.py scales
+    # the per-epoch figures to whatever launch size it runs
+    if full("SQ_WAVES"):
+        epochs = full("SQ_WAVES")
+        info["epl_kernel_epochs_per_profiled_launch"] = epochs
+        for key in ("hbm_bytes", "valu_insts", "salu_insts", "lds_insts"):
+            if f"epl_kernel_{key}_per_launch" in info:
+                info[f"epl_kernel_{key}_per_epoch"] = info[f"epl_kernel_{key}_per_launch"] / epochs
 calls = len(agg.get("ratio_kernel", {}).get("FETCH_SIZE", []))
 if calls:
     fetch = write = 0.0
