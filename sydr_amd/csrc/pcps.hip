@@ -889,6 +889,8 @@ __global__ __launch_bounds__(kThreads) void fft4_rows_kernel(const PassArgs a, i
     }
 }
 
+#include "pcps_fast.h"   // register-resident kernels for N = 125 x 200 (needs Butterfly, PassArgs, Best, wave_best)
+
 template <bool INV, int LOAD0, int STORE_LAST, int FMT, int TA, int TB>
 void run_four_step_t(sdr_engine* e, const FourStep& f, PassArgs a, int batch, double2* Z, double2* final_out) {
     a.out = final_out;
@@ -920,12 +922,25 @@ void run_four_step_t(sdr_engine* e, const FourStep& f, PassArgs a, int batch, do
 #define SDR_PCPS_COL_TILE 8
 #endif
 constexpr int kRowTile = SDR_PCPS_ROW_TILE;
+inline bool fast25k_applies(const sdr_engine* e, const FourStep& f) {
+    return f.ok && f.N1 == fast25k::N1 && f.N2 == fast25k::N2 && !e->pcps_no_fast;
+}
 template <bool INV, int LOAD0, int STORE_LAST, int FMT>
 void run_four_step(sdr_engine* e, const FourStep& f, PassArgs a, int batch, double2* Z, double2* final_out) {
+    if constexpr (INV && LOAD0 == LOAD_MUL_CODE && STORE_LAST == STORE_MAG_MAX) {
+        if (fast25k_applies(e, f)) {      // the 1312 transforms of a map-free search at 25 MHz
+            fast25k::run(e, a, batch, Z);
+            return;
+        }
+    }
     run_four_step_t<INV, LOAD0, STORE_LAST, FMT, SDR_PCPS_COL_TILE, kRowTile>(e, f, a, batch, Z, final_out);
 }
 // per-wave records one map-free inverse sweep leaves per transform
 inline int records_per_transform(const FourStep& f) { return ((f.N1 + kRowTile - 1) / kRowTile) * (kThreads / 64); }
+// ... and of the main sweep, which may run the register-resident kernels
+inline int records_main_sweep(const sdr_engine* e, const FourStep& f) {
+    return fast25k_applies(e, f) ? fast25k::kRecordsPerTransform : records_per_transform(f);
+}
 
 /* ------------------------------------------------------------------------------------------------
  * Chirp-z (Bluestein) transform for a length N the planner cannot factor (a prime factor above 64):
@@ -1127,7 +1142,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
                 g.map = map + (size_t)p0 * nbins * N;
                 g.csum = csum ? csum + (size_t)p0 * nbins * N : nullptr;
                 if (map_free) {
-                    g.partials = (Best*)e->pcps_part.ptr + (size_t)p0 * nbins * records_per_transform(plan_four_step(N));
+                    g.partials = (Best*)e->pcps_part.ptr + (size_t)p0 * nbins * records_main_sweep(e, plan_four_step(N));
                     run_fft<true, LOAD_MUL_CODE, STORE_MAG_MAX, FMT>(e, radices, g, pc * nbins, A, B, nullptr, "pcps_inv_fft", blu);
                 } else if (coh == 1) {
                     g.first_block = inc == 0;
@@ -1158,7 +1173,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
     if (map_free) {
         // the map was never written: maximum from the per-wave records, then the winning row of every PRN alone
         // (1/nbins of one inverse sweep) for the second peak
-        const int per_prn = nbins * records_per_transform(plan_four_step(N));
+        const int per_prn = nbins * records_main_sweep(e, plan_four_step(N));
         Best* tops = parts + (size_t)n_prn * per_prn;
         {
             ProfScope ps(e, "pcps_peak");
