@@ -40,7 +40,10 @@ def test_pcps_golden(engine, tag):
         assert pr[k] == pytest.approx(float(g[f"{tag}_ratio"][k]), rel=1e-9)
     # indices-only call (no map transfer) returns the same answer
     pb2, pc2, pr2, none = engine.pcps(np.arange(len(prns)), 0, fs, if_hz, rng_hz, step, int(coh), int(noncoh))
-    assert none is None and np.array_equal(pb, pb2) and np.array_equal(pc, pc2) and np.array_equal(pr, pr2)
+    # (same indices; the ratio to rounding -- at 25 MHz the map-free sweep runs the register-resident 125 x 200 kernels,
+    # whose transforms are ordered differently from the general ones behind the map)
+    assert none is None and np.array_equal(pb, pb2) and np.array_equal(pc, pc2)
+    np.testing.assert_allclose(pr2, pr, rtol=1e-12, atol=0)
 
 
 def test_two_peak_compare_edge_cases(engine):
@@ -214,6 +217,17 @@ def test_map_free_search_equals_the_materialised_one(engine):
         finally:
             engine.set_option("pcps_materialise_map", 0)
         mb, mc, mr, cmap = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1, want_map=True)
+        if fs == 25e6:
+            # N = 125 x 200: the map-free sweep runs the register-resident kernels, whose transforms are ordered
+            # differently from the general ones behind the map -- same indices, ratio to rounding; with the general
+            # kernels forced the two searches are bit for bit the same again
+            assert np.array_equal(pb, qb) and np.array_equal(pc, qc)
+            np.testing.assert_allclose(pr, qr, rtol=1e-12, atol=0)
+            engine.set_option("pcps_general_kernels", 1)
+            try:
+                pb, pc, pr, _ = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1)
+            finally:
+                engine.set_option("pcps_general_kernels", 0)
         assert np.array_equal(pb, qb) and np.array_equal(pc, qc) and pr.tobytes() == qr.tobytes()
         assert np.array_equal(pb, mb) and np.array_equal(pc, mc) and pr.tobytes() == mr.tobytes()
         for p in range(32):                                   # and against NumPy's own argmax of the returned map
