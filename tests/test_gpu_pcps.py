@@ -261,3 +261,41 @@ def test_cached_code_spectra_follow_the_staged_codes(engine):
     cmap = orc.pcps_map(rf.reshape(1, -1), 0.0, fs, orc.code_spectrum(orc.gold_code(9), fs), 5000.0, 250.0, n)
     peak, ratio = orc.two_peak_compare(cmap, n, round(fs / orc.CODE_RATE))
     assert [int(restaged[0][2]), int(restaged[1][2])] == peak and restaged[2][2] == pytest.approx(ratio, rel=1e-9)
+
+
+def test_register_resident_kernels_at_25_mhz_vs_oracle(engine):
+    """The map-free search at N = 25 000 runs its 1312 inverse transforms through the register-resident 125 x 200
+    kernels (pcps_fast.h): peaks and ratio against the oracle's map for present and absent satellites, an intermediate
+    frequency, other Doppler grids (21 / 41 / 81 / 101 bins: other workgroup-to-XCD mappings) and PRN counts that do
+    not fill a group, from a ring offset -- and the general kernels on the same inputs."""
+    rng = np.random.default_rng(250001)
+    fs, n = 25e6, 25000
+    for case, (if_hz, drange, dstep, n_prn) in enumerate(((0.0, 5000.0, 250.0, 6), (1250.0, 5000.0, 500.0, 5),
+                                                          (0.0, 4000.0, 100.0, 3), (-2000.0, 5000.0, 100.0, 1))):
+        prns = [int(p) for p in rng.choice(np.arange(1, 33), n_prn, replace=False)]
+        present = prns[:max(1, n_prn // 2)]
+        sats = [dict(prn=p, doppler=float(rng.uniform(-3500, 3500)), code_phase=float(rng.uniform(0, 1023)),
+                     phase=float(rng.random()), amp=float(rng.uniform(5, 10))) for p in present]
+        start = int(rng.integers(0, 64))
+        cap = (n + start + 7) // 8 * 8
+        engine.iq_alloc(cap, FMT_CI8)
+        engine.code_slots(n_prn)
+        for s, p in enumerate(prns):
+            engine.load_gps_code(s, p)
+        engine.iq_synth(sats, fs, 12.0, 1000 + case, 0, cap)
+        rf = orc.iq_to_complex(engine.iq_download(cap, 0))
+        pb, pc, pr, none = engine.pcps(np.arange(n_prn), start, fs, if_hz, drange, dstep, 1, 1)
+        assert none is None
+        engine.set_option("pcps_general_kernels", 1)
+        try:
+            gb, gc, gr, _ = engine.pcps(np.arange(n_prn), start, fs, if_hz, drange, dstep, 1, 1)
+        finally:
+            engine.set_option("pcps_general_kernels", 0)
+        assert np.array_equal(pb, gb) and np.array_equal(pc, gc)
+        np.testing.assert_allclose(pr, gr, rtol=1e-12, atol=0)
+        x = rf[start:start + n].reshape(1, -1)
+        for s, p in enumerate(prns):
+            m = orc.pcps_map(x, if_hz, fs, orc.code_spectrum(orc.gold_code(p), fs), drange, dstep, n)
+            peak, ratio = orc.two_peak_compare(m, n, round(fs / orc.CODE_RATE))
+            assert peak == [int(pb[s]), int(pc[s])], (case, p)
+            assert pr[s] == pytest.approx(ratio, rel=1e-9)
