@@ -149,13 +149,25 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
     constexpr bool kStatic = KM != 0 && KS != 0;
     constexpr int kHalf = KS + 1;
     double urc[kStatic ? kHalf + 1 : 1], urs[kStatic ? kHalf + 1 : 1];
+    // samples per chip as Q32.32, and the distance to a lane's next block: D or D + 1 samples
+    const double two32 = 4294967296.0;
+    const int64_t Tfx = (int64_t)rint(inv_step[A] * two32);
+    const int64_t stride_fx = (int64_t)stride * Tfx;
+    const int Dmin = (int)(stride_fx >> 32);
+    double rd0c = 1.0, rd0s = 0.0, rd1c = 1.0, rd1s = 0.0;  // the carrier rotations over D and D + 1 samples
     {
         double sn = 0.0, cs = 0.0;
-        if (wlane < kChipMax) sincos_reduced(-(double)wlane * dphi_u, &sn, &cs);
         if constexpr (kStatic) {
+            // one evaluation per epoch serves both: lanes 0 .. 25 the in-block rotations, lanes 32 / 33 the two
+            // block-to-block ones
+            const double mult = wlane < 32 ? (double)wlane : (double)(Dmin + (wlane & 1));
+            sincos_reduced(-mult * dphi_u, &sn, &cs);
 #pragma unroll
             for (int k = 1; k <= kHalf; ++k) urc[k] = lane_value(cs, k), urs[k] = lane_value(sn, k);
+            rd0c = lane_value(cs, 32), rd0s = lane_value(sn, 32);
+            rd1c = lane_value(cs, 33), rd1s = lane_value(sn, 33);
         } else if (wlane < kChipMax) {
+            sincos_reduced(-(double)wlane * dphi_u, &sn, &cs);
             rot[wlane] = make_double2(cs, sn);
         }
     }
@@ -164,8 +176,6 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
     const int rounds = F > 0 ? (F + stride - 1) / stride : 0;
     if (rounds > 0) {
         // ---- the fixed-point line of the anchor tap, and each tap's constant offset on it
-        const double two32 = 4294967296.0;
-        const int64_t Tfx = (int64_t)rint(inv_step[A] * two32);
         const int64_t Ufx = (int64_t)floor(-shift[A] * inv_step[A] * two32);
         const int M = (int)(Tfx >> 32);                                   // block length M or M + 1
         bad = bad || M < 1 || M + 1 > kChipMax || F > 16384 || (KM != 0 && M != KM);
@@ -192,24 +202,20 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
             J[t] = j;
             delta[t] = (uint64_t)d;
             m[t] = (int)(d >> 32);
-            bad = bad || (KS != 0 && m[t] != KS);
+            bad = bad || (KS != 0 && (m[t] != KS || j != (t < A ? -1 : 0)));   // (KS: the tap sits on chip q - 1 / q at the block start)
             evmask |= (1u << m[t]) | (2u << m[t]);
         }
         const int k_last = M + 1;                       // no prefix beyond P_(M+1) is ever read
         int rank[NT];                                   // strip slot of position m_t (m_t + 1 sits in the next one)
 #pragma unroll
         for (int t = 0; t < NT; ++t) rank[t] = __builtin_popcount(evmask & ((1u << m[t]) - 1u));
-        // distance to a lane's next block: D or D + 1 samples; the two carrier rotations over it
-        const int64_t stride_fx = (int64_t)stride * Tfx;
-        const int Dmin = (int)(stride_fx >> 32);
-        double rd0c, rd0s, rd1c, rd1s;
-        {
+        if constexpr (!kStatic) {
             double sn, cs;
             sincos_reduced(-(double)(Dmin + (wlane & 1)) * dphi_u, &sn, &cs);   // lane 0: Dmin, lane 1: Dmin + 1
             rd0c = lane_value(cs, 0), rd0s = lane_value(sn, 0);
             rd1c = lane_value(cs, 1), rd1s = lane_value(sn, 1);
-            asm volatile("" : "+v"(rd0c), "+v"(rd0s), "+v"(rd1c), "+v"(rd1s));   // (selected per lane: keep them in vector registers)
         }
+        asm volatile("" : "+v"(rd0c), "+v"(rd0s), "+v"(rd1c), "+v"(rd1s));   // (selected per lane: keep them in vector registers)
         const uint64_t lane_fx = (uint64_t)((int64_t)lane * Tfx);
         // u of the lane's block start in round 0, "+1 sample" folded in: S = u >> 32
         uint64_t u_cur = (uint64_t)(Ufx + (int64_t)q0 * Tfx + (int64_t)two32) + lane_fx;
@@ -279,10 +285,16 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
         // carrier phase at the lane's first block: one exact evaluation; later blocks by a fixed rotation
         double sb, cb;
         sincos_reduced(__builtin_fma(-(double)blk_a.S, dphi_u, rem_carrier_u), &sb, &cb);
-        sb = lane <= last_idx ? sb : 0.0;
-        cb = lane <= last_idx ? cb : 0.0;
+        if constexpr (!kStatic) {
+            sb = lane <= last_idx ? sb : 0.0;
+            cb = lane <= last_idx ? cb : 0.0;
+        }
         // per-lane LDS addresses: the strip slots of each tap's position m_t, and the lane's replica entry
         const int q_lane = q0 + 1 + lane + SDR_LUT_PAD;
+        // (KS) the lane's own strip slot is not used for running sums: four zero words stand in for the replica of a
+        // lane that has no block in a round (the last one)
+        const uint32_t* zero_lq = reinterpret_cast<const uint32_t*>(strip) + 1;
+        if constexpr (kStatic) *strip = make_double2(0.0, 0.0);
 
         auto process = [&](const ChipBlock<NT>& b, int round, double sbk, double cbk) {
             double pr = 0.0, pi = 0.0;
@@ -374,7 +386,11 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                 ptot = strip[rank[A] + b.dn];
             }
             const int first = round * stride;           // (a lane beyond the last whole chip re-does the last one)
-            const uint32_t* lq = lut + q_lane + (first + lane <= last_idx ? first : last_idx - lane);   // replica entry of the block's anchor chip
+            const uint32_t* lq;                         // replica entry of the block's anchor chip
+            if constexpr (kStatic)                      // (... against three zero words: it adds nothing, whatever its phasor)
+                lq = first + lane <= last_idx ? lut + q_lane + first : zero_lq;
+            else
+                lq = lut + q_lane + (first + lane <= last_idx ? first : last_idx - lane);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 double gr, gi;
@@ -388,8 +404,9 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                         ps = b.ds[t] ? make_double2(capr[2], capi[2]) : make_double2(capr[0], capi[0]);
                     else
                         ps = strip[rank[t] + b.ds[t]];
-                    const double ca = __hiloint2double((int)lq[J[t]], 0);
-                    const double cbn = __hiloint2double((int)lq[J[t] + 1], 0);
+                    const int jt = kStatic ? (t < A ? -1 : 0) : J[t];      // (KS: checked when the epoch was set up)
+                    const double ca = __hiloint2double((int)lq[jt], 0);
+                    const double cbn = __hiloint2double((int)lq[jt + 1], 0);
                     const double diff = ca - cbn;
                     gr = __builtin_fma(diff, ps.x, cbn * ptot.x);
                     gi = __builtin_fma(diff, ps.y, cbn * ptot.y);
@@ -408,8 +425,12 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
             const double rc_ = dd ? rd1c : rd0c, rs_ = dd ? rd1s : rd0s;
             const double cbn = __builtin_fma(cb, rc_, -sb * rs_);
             const double sbn = __builtin_fma(sb, rc_, cb * rs_);
-            cb = alive ? cbn : 0.0;
-            sb = alive ? sbn : 0.0;
+            if constexpr (kStatic) {
+                cb = cbn, sb = sbn;                     // (a lane without a block correlates against zero replica words)
+            } else {
+                cb = alive ? cbn : 0.0;
+                sb = alive ? sbn : 0.0;
+            }
         };
 
         for (int it = 0; it < rounds / 2; ++it) {
