@@ -139,7 +139,9 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
                            e->luts, lut_words, e->lut_stride, d_spacing, fs, tap0, n_taps_total, d_out);
     };
     if (wpw == 4) {
-        if (wide >= kChipMax && FMT == SDR_FMT_CI8)
+        if (wide >= kChipMax + 24 && FMT == SDR_FMT_CI8)     // (every epoch with 24 or 25 samples per chip: BOC(1,1) half-chips at 50 MHz)
+            launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 4>);
+        else if (wide >= kChipMax && FMT == SDR_FMT_CI8)
             launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 0, 4>);
         else if (wide == 16)
             launch(epl_kernel<FMT, NT, 16, 0, 4>);
@@ -268,7 +270,7 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
     // every item inside the chip-aligned variant's range (ci8 ring): lanes own whole chips instead of 16 samples
     if (boundary_ok && e->iq_fmt == SDR_FMT_CI8 && min_step >= sdr::kChipMinCodeStep && max_step <= sdr::kChipMaxCodeStep &&
         !e->epl_no_chip)
-        *wide = sdr::kChipMax + ((all_m24 && (n_taps == 3 || n_taps == 1 || n_taps == 2)) ? 24 : 0) +
+        *wide = sdr::kChipMax + (all_m24 ? 24 : 0) +
                 ((all_m24 && all_s12 && !e->epl_no_split) ? 256 * 12 : 0);
     return SDR_OK;
 }
