@@ -176,6 +176,9 @@ int sdr_code_slots_ex(sdr_engine* e, int n_slots, int max_chips, int max_periods
     if (e->codes) SDR_HIP(hipFree(e->codes));
     if (e->luts) SDR_HIP(hipFree(e->luts));
     e->luts = nullptr;
+    if (e->luts2) SDR_HIP(hipFree(e->luts2));
+    e->luts2 = nullptr;
+    e->luts2_generation = -1;
     if (e->code_len) SDR_HIP(hipFree(e->code_len));
     e->codes = nullptr;
     e->code_len = nullptr;

@@ -125,6 +125,7 @@ int sdr_set_option(sdr_engine* e, const char* name, int value) {
     else if (!strcmp(name, "pcps_prn_chunk")) e->pcps_prn_chunk = value;
     else if (!strcmp(name, "epl_no_chip_variant")) e->epl_no_chip = value != 0;
     else if (!strcmp(name, "epl_no_split_variant")) e->epl_no_split = value != 0;
+    else if (!strcmp(name, "epl_no_half_chip_view")) e->epl_no_double = value != 0;
     else return sdr_fail(SDR_ERR_INVALID, "unknown option '%s'", name);
     return SDR_OK;
 }
@@ -240,6 +241,7 @@ void sdr_engine_destroy(sdr_engine* e) {
     if (e->iq) (void)hipFree(e->iq);
     if (e->codes) (void)hipFree(e->codes);
     if (e->luts) (void)hipFree(e->luts);
+    if (e->luts2) (void)hipFree(e->luts2);
     if (e->code_len) (void)hipFree(e->code_len);
     (void)hipStreamDestroy(e->stream);
     delete e;

@@ -74,6 +74,11 @@ struct sdr_engine {
     // padding already applied (lut[q] = chip[(q - SDR_LUT_PAD - 1) mod L]); copied with 16-byte loads
     uint32_t* luts = nullptr;  // [n_slots][lut_stride]
     int lut_stride = 0;
+    // the same replicas with every chip twice (lut2[h + PAD] = lut[ceil(h / 2) + PAD]): the "half-chip view" E/P/L
+    // plans of 32-52 samples per chip run on (epl.hip); built on demand, rebuilt when a slot is re-staged
+    uint32_t* luts2 = nullptr;  // [n_slots][lut2_stride]
+    int lut2_stride = 0;
+    int64_t luts2_generation = -1, luts2_stamp = -1;
 
     // workspaces
     DevBuf ws_items, ws_out, ws_spacing;
@@ -90,6 +95,7 @@ struct sdr_engine {
     DevBuf pcps_blu, pcps_blu_x, pcps_blu_a, pcps_blu_b;
     int64_t pcps_blu_n = 0;
     bool epl_no_chip = false;        // diagnostics: keep the 16-sample boundary variant where the chip-aligned one would run
+    bool epl_no_double = false;      // diagnostics: keep the boundary variant where the half-chip view would run
     bool epl_no_split = false;       // diagnostics: keep the run-time switch positions where the KS = 12 kernel would run
     int pcps_prn_chunk = 0;          // diagnostics: PRNs per inverse sweep (0 = as many as the work buffers hold)
     bool pcps_force_map = false;     // diagnostics / tests: materialise the map even when the caller does not ask for it

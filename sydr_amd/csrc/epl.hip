@@ -120,9 +120,43 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? 3 : SDR_EPL_WAVES)) 
 #endif
 }
 
+// Half-chip view of the staged replicas: every chip twice.  A code of 32-52 samples per chip (GPS L1 C/A at 50 MHz)
+// presented as a code of twice the chips at twice the rate has 16-26 samples per (half-)chip and runs on the
+// chip-aligned correlator.  Exact: the kernel is handed 2*rem_code, 2*code_step and 2*spacing -- scaling by two
+// commutes with every fp64 rounding of the reference's index expression, so its half-chip index is ceil(2y) for the
+// reference's own y, and ceil(ceil(2y) / 2) = ceil(y) is the chip:  lut2[h + PAD] = lut[((h + 1) >> 1) + PAD].
+__global__ __launch_bounds__(256) void double_lut_kernel(const uint32_t* __restrict__ luts, int stride, uint32_t* __restrict__ luts2,
+                                                         int stride2) {
+    const int slot = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= stride2) return;
+    int src = ((j - SDR_LUT_PAD + 1) >> 1) + SDR_LUT_PAD;
+    src = src < stride - 1 ? src : stride - 1;
+    luts2[(size_t)slot * stride2 + j] = luts[(size_t)slot * stride + src];
+}
+
+int ensure_doubled_luts(sdr_engine* e, hipStream_t stream) {
+    if (e->luts2 && e->luts2_generation == e->code_generation && e->luts2_stamp == e->code_stamp_counter) return SDR_OK;
+    if (!e->luts2 || e->luts2_generation != e->code_generation) {
+        if (e->luts2) SDR_HIP(hipFree(e->luts2));
+        e->luts2 = nullptr;
+        e->lut2_stride = (2 * e->lut_stride + 3) & ~3;
+        if (hipMalloc(&e->luts2, (size_t)e->n_slots * e->lut2_stride * sizeof(uint32_t)) != hipSuccess)
+            return sdr_fail(SDR_ERR_NOMEM, "hipMalloc for the half-chip replica tables failed");
+    }
+    // (on the stream the staging kernels use -- they are ordered before this -- and complete before any batch stream reads it)
+    hipLaunchKernelGGL(double_lut_kernel, dim3((e->lut2_stride + 255) / 256, e->n_slots), dim3(256), 0, e->stream, e->luts,
+                       e->lut_stride, e->luts2, e->lut2_stride);
+    SDR_HIP(hipGetLastError());
+    if (stream != e->stream) SDR_HIP(hipStreamSynchronize(e->stream));
+    e->luts2_generation = e->code_generation;
+    e->luts2_stamp = e->code_stamp_counter;
+    return SDR_OK;
+}
+
 template <int FMT, int NT>
 void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
-                int tap0, int n_taps_total, int lut_words, int wide, int group_stride, double* d_out) {
+                int tap0, int n_taps_total, int lut_words, int wide, int group_stride, bool doubled, double* d_out) {
     // long replicas: four waves (four epochs of one channel) per workgroup around one staged table
     const int wpw = (lut_words >= kLongLutWords && group_stride > 0) ? 4 : 1;
     const int threads = kWaveThreads * wpw;
@@ -136,7 +170,8 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
         if (shmem > 64u * 1024u)  // beyond the default dynamic-LDS grant (long multi-period replicas)
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), shmem, stream, e->iq, e->iq_capacity, d_items, n_items, stride,
-                           e->luts, lut_words, e->lut_stride, d_spacing, fs, tap0, n_taps_total, d_out);
+                           doubled ? e->luts2 : e->luts, lut_words, doubled ? e->lut2_stride : e->lut_stride, d_spacing, fs, tap0,
+                           n_taps_total, d_out);
     };
     if (wpw == 4) {
         if (wide >= kChipMax + 24 && FMT == SDR_FMT_CI8)     // (every epoch with 24 or 25 samples per chip: BOC(1,1) half-chips at 50 MHz)
@@ -167,22 +202,22 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
 
 template <int FMT>
 void launch_fmt(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
-                int n_taps, int lut_words, int wide, int group_stride, double* d_out) {
+                int n_taps, int lut_words, int wide, int group_stride, bool doubled, double* d_out) {
     // Taps are served in register-resident chunks of 5/3/2/1.
     int t0 = 0;
     while (t0 < n_taps) {
         int left = n_taps - t0;
         if (left >= 5) {
-            launch_one<FMT, 5>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, d_out);
+            launch_one<FMT, 5>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, doubled, d_out);
             t0 += 5;
         } else if (left >= 3) {
-            launch_one<FMT, 3>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, d_out);
+            launch_one<FMT, 3>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, doubled, d_out);
             t0 += 3;
         } else if (left == 2) {
-            launch_one<FMT, 2>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, d_out);
+            launch_one<FMT, 2>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, doubled, d_out);
             t0 += 2;
         } else {
-            launch_one<FMT, 1>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, d_out);
+            launch_one<FMT, 1>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, doubled, d_out);
             t0 += 1;
         }
     }
@@ -199,14 +234,16 @@ struct sdr_epl_plan {
     int lut_words = 0;
     int wide = 0;  // 16 / 8: every item has 16 (8) * code_step < 1, the boundary variant with that group width applies
     int group_stride = 0;  // C > 0: items[i] and items[i + C] use the same code slot for every i (epoch-major lists of C channels)
+    bool doubled = false;  // the plan runs on the half-chip view: its device items / spacings carry 2*rem_code, 2*code_step, 2*spacing
     double fs = 0.0;
     int64_t code_generation = 0;  // of the engine's code tables the plan was validated against
     int64_t ring_capacity = 0;    // and of the ring
 };
 
 // Host-side check that no item can index outside the ring or the staged LUT.
+// scale = 2: the variant is chosen for the half-chip view (2*rem_code, 2*code_step, 2*spacing against tables of twice the length).
 static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items, const double* spacing,
-                          int n_taps, int* lut_words, int* wide) {
+                          int n_taps, double scale, int* lut_words, int* wide) {
     double smin = spacing[0], smax = spacing[0];
     for (int t = 1; t < n_taps; ++t) {
         smin = spacing[t] < smin ? spacing[t] : smin;
@@ -214,7 +251,7 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
     }
     int maxlen = 0;
     double max_step = 0.0, min_step = 1e300;
-    const double s_anchor = spacing[n_taps < 5 ? n_taps / 2 : 2];   // centre tap of the first chunk of taps the kernels serve together
+    const double s_anchor = scale * spacing[n_taps < 5 ? n_taps / 2 : 2];   // centre tap of the first chunk of taps the kernels serve together
     bool all_m24 = true;
     bool all_s12 = n_taps == 3;   // both outer taps switch chips 12.x samples into the anchor's block (KS = 12 kernel)
     for (int i = 0; i < n_items; ++i) {
@@ -223,8 +260,8 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
             const double two32 = 4294967296.0;
             const double nd = (double)it.n_samples;
             auto line = [&](double spc, double& sh, double& inv) {
-                sh = it.rem_code + spc;
-                double stop = it.code_step * nd;
+                sh = scale * it.rem_code + spc;
+                double stop = (scale * it.code_step) * nd;
                 stop = stop + sh;
                 inv = 1.0 / ((stop - sh) / nd);
             };
@@ -236,7 +273,7 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
                 // the kernel's own derivation of the switch offset (a Q32.32 sample count); its reciprocal is a Newton
                 // step, not a division, so a margin of 2^-10 sample keeps the two from disagreeing about the integer part
                 double sht, invt;
-                line(spacing[t], sht, invt);
+                line(scale * spacing[t], sht, invt);
                 const int64_t ufx = (int64_t)std::floor(-sh * inv * two32), ut = (int64_t)std::floor(-sht * invt * two32);
                 const int j = (int)std::ceil(sht - sh) - 1;
                 int64_t d = (ut - ufx) + (int64_t)(1 + j) * tfx;
@@ -245,8 +282,8 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
                 all_s12 = d >= ((int64_t)12 << 32) + margin && d < ((int64_t)13 << 32) - margin;
             }
         }
-        if (it.code_step > max_step) max_step = it.code_step;
-        if (it.code_step < min_step) min_step = it.code_step;
+        if (scale * it.code_step > max_step) max_step = scale * it.code_step;
+        if (scale * it.code_step < min_step) min_step = scale * it.code_step;
         if (it.code_slot < 0 || it.code_slot >= e->n_slots || e->code_len_host[it.code_slot] <= 0)
             return sdr_fail(SDR_ERR_INVALID, "item %d: code slot %d is not staged", i, it.code_slot);
         if (it.n_samples <= 0 || it.n_samples > e->iq_capacity)
@@ -265,7 +302,7 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
         if ((int)hi > maxlen) maxlen = (int)hi;
     }
     *lut_words = maxlen + SDR_LUT_PAD + 2;
-    const bool boundary_ok = min_step >= sdr::kFastMinCodeStep && e->lut_stride < sdr::kFastMaxLutWords;
+    const bool boundary_ok = min_step >= sdr::kFastMinCodeStep && scale * e->lut_stride < sdr::kFastMaxLutWords;
     *wide = !boundary_ok ? 0 : (max_step <= sdr::kFastMaxCodeStep ? 16 : (max_step <= sdr::kFastMaxCodeStep8 ? 8 : 0));
     // every item inside the chip-aligned variant's range (ci8 ring): lanes own whole chips instead of 16 samples
     if (boundary_ok && e->iq_fmt == SDR_FMT_CI8 && min_step >= sdr::kChipMinCodeStep && max_step <= sdr::kChipMaxCodeStep &&
@@ -290,7 +327,19 @@ int sdr_epl_plan_create(sdr_engine* e, const sdr_epl_item* items, int n_items, c
     if (!(fs > 0.0)) return sdr_fail(SDR_ERR_INVALID, "fs must be positive");
     int lut_words = 0;
     int wide = 0;
-    if (int rc = validate_items(e, items, n_items, spacing, n_taps, &lut_words, &wide)) return rc;
+    if (int rc = validate_items(e, items, n_items, spacing, n_taps, 1.0, &lut_words, &wide)) return rc;
+    // a list that misses the chip-aligned correlator only because a chip holds too many samples (32-52: GPS L1 C/A at
+    // 50 MHz) runs on the half-chip view of its replicas
+    bool doubled = false;
+    if (wide < sdr::kChipMax && e->iq_fmt == SDR_FMT_CI8 && !e->epl_no_chip && !e->epl_no_double) {
+        int lw2 = 0, wide2 = 0;
+        if (validate_items(e, items, n_items, spacing, n_taps, 2.0, &lw2, &wide2) == SDR_OK && wide2 >= sdr::kChipMax) {
+            if (int rc = ensure_doubled_luts(e, e->stream)) return rc;
+            doubled = true;
+            wide = wide2;
+            lut_words = 2 * lut_words < e->lut2_stride ? 2 * lut_words : e->lut2_stride;
+        }
+    }
 
     sdr_epl_plan* p = new (std::nothrow) sdr_epl_plan();
     if (!p) return sdr_fail(SDR_ERR_NOMEM, "host allocation failed");
@@ -299,6 +348,7 @@ int sdr_epl_plan_create(sdr_engine* e, const sdr_epl_item* items, int n_items, c
     p->fs = fs;
     p->lut_words = lut_words;
     p->wide = wide;
+    p->doubled = doubled;
     // the period of the code-slot pattern, if the list has one (what lets four epochs of a channel share a staged table)
     if (lut_words >= kLongLutWords) {
         int c = 1;
@@ -312,11 +362,18 @@ int sdr_epl_plan_create(sdr_engine* e, const sdr_epl_item* items, int n_items, c
     hipError_t err = hipMalloc(&p->d_items, (size_t)n_items * sizeof(sdr_epl_item));
     if (err == hipSuccess) err = hipMalloc(&p->d_out, (size_t)n_items * 2 * n_taps * sizeof(double));
     if (err == hipSuccess) err = hipMalloc(&p->d_spacing, SDR_MAX_TAPS * sizeof(double));
+    std::vector<sdr_epl_item> items2;
+    double spacing2[SDR_MAX_TAPS];
+    if (doubled) {
+        items2.assign(items, items + n_items);
+        for (sdr_epl_item& it : items2) it.rem_code *= 2.0, it.code_step *= 2.0;
+        for (int t = 0; t < n_taps; ++t) spacing2[t] = 2.0 * spacing[t];
+    }
     if (err == hipSuccess)
-        err = hipMemcpyAsync(p->d_items, items, (size_t)n_items * sizeof(sdr_epl_item), hipMemcpyHostToDevice,
-                             e->stream);
+        err = hipMemcpyAsync(p->d_items, doubled ? items2.data() : items, (size_t)n_items * sizeof(sdr_epl_item),
+                             hipMemcpyHostToDevice, e->stream);
     if (err == hipSuccess)
-        err = hipMemcpyAsync(p->d_spacing, spacing, n_taps * sizeof(double), hipMemcpyHostToDevice, e->stream);
+        err = hipMemcpyAsync(p->d_spacing, doubled ? spacing2 : spacing, n_taps * sizeof(double), hipMemcpyHostToDevice, e->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
     if (err != hipSuccess) {
         sdr_epl_plan_destroy(e, p);
@@ -338,11 +395,14 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
     if (!ctx) return sdr_fail(SDR_ERR_INVALID, "stream id %d does not exist", stream_id);
     // A plan is validated against the code tables and the ring as they were at sdr_epl_plan_create; after
     // sdr_code_slots(_ex) / sdr_iq_alloc its slot indices, LUT length and ring bounds mean something else.
-    if (p->code_generation != e->code_generation || p->ring_capacity != e->iq_capacity || p->lut_words > e->lut_stride)
+    if (p->code_generation != e->code_generation || p->ring_capacity != e->iq_capacity ||
+        p->lut_words > (p->doubled ? 2 * e->lut_stride + 3 : e->lut_stride))
         return sdr_fail(SDR_ERR_STATE, "plan is stale: the code slots or the IQ ring were re-allocated after it was created");
     if (first < 0 || count <= 0 || first + count > p->n_items)
         return sdr_fail(SDR_ERR_RANGE, "item range [%lld, %lld) outside the plan's %d items", (long long)first,
                         (long long)(first + count), p->n_items);
+    if (p->doubled)
+        if (int rc = ensure_doubled_luts(e, ctx->stream)) return rc;   // (a slot may have been re-staged since the plan was made)
     const sdr_epl_item* items = p->d_items + first;
     double* out = p->d_out + (size_t)first * 2 * p->n_taps;
     const int n = (int)count;
@@ -350,17 +410,17 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
         hipStream_t st = ctx->stream;
         ProfScope ps(e, "epl_kernel", st);
         switch (e->iq_fmt) {
-            case SDR_FMT_CI8: launch_fmt<SDR_FMT_CI8>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, out); break;
-            case SDR_FMT_CI16: launch_fmt<SDR_FMT_CI16>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, out); break;
-            case SDR_FMT_CF32: launch_fmt<SDR_FMT_CF32>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, out); break;
-            default: launch_fmt<SDR_FMT_CF64>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, out); break;
+            case SDR_FMT_CI8: launch_fmt<SDR_FMT_CI8>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, p->doubled, out); break;
+            case SDR_FMT_CI16: launch_fmt<SDR_FMT_CI16>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, p->doubled, out); break;
+            case SDR_FMT_CF32: launch_fmt<SDR_FMT_CF32>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, p->doubled, out); break;
+            default: launch_fmt<SDR_FMT_CF64>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, p->doubled, out); break;
         }
     }
     SDR_HIP(hipGetLastError());
     return SDR_OK;
 }
 
-int sdr_epl_plan_variant(const sdr_epl_plan* p) { return p ? p->wide : -1; }
+int sdr_epl_plan_variant(const sdr_epl_plan* p) { return p ? p->wide + (p->doubled ? 65536 : 0) : -1; }
 
 int sdr_epl_plan_run(sdr_engine* e, sdr_epl_plan* p) {
     if (!p) return sdr_fail(SDR_ERR_INVALID, "plan is NULL");

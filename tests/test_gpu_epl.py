@@ -396,3 +396,62 @@ def test_compile_time_tap_switch_variant(engine):
     v_asym, got_asym = run((-0.5, 0.0, 0.3), False)
     assert v_asym == 26 + 24
     check(got_asym, (-0.5, 0.0, 0.3))
+
+
+def test_half_chip_view_for_32_to_52_samples_per_chip(engine):
+    """A BPSK code at 32-52 samples per chip (GPS L1 C/A at 40 / 50 MHz) runs on the chip-aligned correlator through
+    the half-chip view of its replica (every chip twice; 2*rem_code, 2*code_step, 2*spacing -- exact scalings):
+    selected by the plan, equal to the oracle and to the boundary variant, for 3 and 5 taps, one and several
+    periods per epoch, n = N +- 1, switches exactly on samples, and after a slot has been re-staged."""
+    rng = np.random.default_rng(20261007)
+    cap = 8 * 120000
+    raw = rng.integers(-100, 100, 2 * cap).astype(np.int8)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(6, 1023, 4)
+    prn_of = [3 * s + 2 for s in range(6)]
+    for s in range(6):
+        engine.load_gps_code(s, prn_of[s])
+    rf = orc.iq_to_complex(raw)
+
+    def check(fs, spacing, periods_hi, restage=False):
+        n_items = 40
+        step = (1.023e6 + rng.uniform(-5, 5, n_items)) / fs
+        step[:3] = [1 / 40, 1 / 48, 1 / 50][: 3]                       # chip switches exactly on samples
+        step = np.clip(step, 1 / 51.5, 1 / 32.5)
+        rem_code = rng.uniform(0, step)
+        rem_code[3:6] = [0.0, 0.5, 1e-9]
+        periods = rng.integers(1, periods_hi + 1, n_items)
+        n = np.ceil((1023 * periods - rem_code) / step).astype(np.int64) + rng.integers(-1, 2, n_items)
+        n[6:8] = [5, 90]
+        start = rng.integers(0, cap - 4 * 60000, n_items)
+        slot = rng.integers(0, 6, n_items)
+        f = rng.uniform(-6000, 6000, n_items)
+        rem_carrier = rng.uniform(0, 2 * np.pi, n_items)
+        items = make_items(slot, n, start, f, rem_carrier, rem_code, step)
+        plan = engine.epl_plan(items, spacing, fs)
+        assert plan.variant >= 65536 + 26, plan.variant
+        if restage:                                                    # the doubled tables follow the staged codes
+            prn_of[2] = 29
+            engine.load_gps_code(2, 29)
+        plan.run()
+        got = plan.fetch()
+        engine.set_option("epl_no_half_chip_view", 1)
+        try:
+            other_plan = engine.epl_plan(items, spacing, fs)
+            assert other_plan.variant in (8, 16)
+            other_plan.run()
+            other = other_plan.fetch()
+        finally:
+            engine.set_option("epl_no_half_chip_view", 0)
+        for k in range(n_items):
+            x = orc.ring_slice(rf, int(start[k]), int(n[k]))
+            ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(prn_of[int(slot[k])])), fs, f[k], rem_carrier[k],
+                                   rem_code[k], step[k], spacing))
+            scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 50.0), 2)
+            assert np.max(np.abs(got[k] - ref) / scale) < 1e-9, (fs, k, step[k], n[k])
+            assert np.max(np.abs(other[k] - ref) / scale) < 1e-9, (fs, k)
+
+    check(50e6, (-0.5, 0.0, 0.5), 1)
+    check(50e6, (-1.0, -0.5, 0.0, 0.5, 1.0), 4)
+    check(40e6, (-0.25, 0.0, 0.25), 2, restage=True)
