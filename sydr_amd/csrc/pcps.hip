@@ -1300,6 +1300,23 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     const size_t mbytes = (size_t)M * sizeof(double2);  // (0 without the chirp-z path)
     int prn_chunk = (int)std::min<int64_t>(n_prn, std::max<int64_t>(1, (int64_t)((8ull << 30) / (std::max(tbytes, mbytes) * nbins))));
     if ((int64_t)prn_chunk * nbins > 65535) prn_chunk = std::max(1, 65535 / nbins);
+    // Indices and ratio only, one block, four-step transform available: the map is never materialised.
+    const FourStep four = plan_four_step(N);
+    const bool map_free = !corr_map && coh == 1 && noncoh == 1 && !use_blu && four.ok && !e->pcps_force_passes &&
+                          !e->pcps_force_map;
+    // The column kernel of an inverse sweep writes 16 N bytes per (PRN, bin) and the row kernel reads them back: as
+    // many PRNs per sweep as keep that intermediate inside the 256 MB Infinity Cache (a 200 MB budget), in sweeps of
+    // equal size -- 32 PRNs x 41 bins x 25 000: three sweeps of 11 / 11 / 10 PRNs instead of one of 525 MB, measured
+    // 0.40 -> 0.34 ms per acquisition (tools/pcps_breakdown.py <chunk>: 12: 0.341, 11: 0.339, 10: 0.348, 8: 0.357,
+    // 16: 0.379, 6: 0.392 -- the smaller the sweep, the larger the share of its partial last round of workgroups).
+    if (map_free && e->pcps_prn_chunk == 0) {
+        const int64_t per_prn = (int64_t)tbytes * nbins;
+        const int fit = (int)std::max<int64_t>(1, (200ll << 20) / per_prn);
+        if (fit < prn_chunk) {
+            const int sweeps = (n_prn + fit - 1) / fit;
+            prn_chunk = (n_prn + sweeps - 1) / sweeps;
+        }
+    }
     if (e->pcps_prn_chunk > 0) prn_chunk = std::min(prn_chunk, e->pcps_prn_chunk);
     if (nbins > 65535 || n_prn > 65535) return sdr_fail(SDR_ERR_UNSUPPORTED, "grid too large");
     const size_t work = tbytes * (size_t)std::max(prn_chunk * nbins, std::max(n_prn, nbins));
@@ -1307,10 +1324,6 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_a, work);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_b, work);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_code, tbytes * n_prn);
-    // Indices and ratio only, one block, four-step transform available: the map is never materialised.
-    const FourStep four = plan_four_step(N);
-    const bool map_free = !corr_map && coh == 1 && noncoh == 1 && !use_blu && four.ok && !e->pcps_force_passes &&
-                          !e->pcps_force_map;
     const size_t n_records = map_free ? (size_t)n_prn * (nbins + 1) * records_per_transform(four) + n_prn : 0;
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_map, (size_t)n_prn * (map_free ? 1 : nbins) * N * sizeof(double));
     if (!rc && coh > 1) rc = sdr_devbuf_reserve(e, &e->pcps_csum, (size_t)n_prn * nbins * tbytes);
