@@ -19,13 +19,13 @@ import sys
 
 src, tag = sys.argv[1], sys.argv[2]
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PCPS = ("fft4_rows_kernel", "fft4_cols_kernel", "fft_pass_kernel", "argmax", "ratio_kernel", "peak_", "second_peak",
+PCPS = ("fft4_rows_kernel", "fft4_cols_kernel", "fast25k", "fft_pass_kernel", "argmax", "ratio_kernel", "peak_", "second_peak",
         "chirp", "upsample_batch_kernel", "mix_", "twiddle_kernel")
 
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"([A-Za-z0-9_]+)(<[^>]*>)?", name)
+    m = re.match(r"((?:fast25k::)?[A-Za-z0-9_]+)(<[^>]*>)?", name)
     base, targs = m.group(1), m.group(2) or ""
     if base in ("epl_kernel", "track_kernel", "fft4_rows_kernel", "fft4_cols_kernel", "fft_pass_kernel"):
         return base + targs.replace(", ", ",")
