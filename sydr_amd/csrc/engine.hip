@@ -122,6 +122,7 @@ int sdr_set_option(sdr_engine* e, const char* name, int value) {
     if (!strcmp(name, "pcps_materialise_map")) e->pcps_force_map = value != 0;
     else if (!strcmp(name, "pcps_radix_passes")) e->pcps_force_passes = value != 0;
     else if (!strcmp(name, "pcps_general_kernels")) e->pcps_no_fast = value != 0;
+    else if (!strcmp(name, "pcps_one_stream")) e->pcps_no_overlap = value != 0;
     else if (!strcmp(name, "pcps_prn_chunk")) e->pcps_prn_chunk = value;
     else if (!strcmp(name, "epl_no_chip_variant")) e->epl_no_chip = value != 0;
     else if (!strcmp(name, "epl_no_split_variant")) e->epl_no_split = value != 0;
@@ -242,6 +243,9 @@ void sdr_engine_destroy(sdr_engine* e) {
     if (e->codes) (void)hipFree(e->codes);
     if (e->luts) (void)hipFree(e->luts);
     if (e->luts2) (void)hipFree(e->luts2);
+    if (e->pcps_aux) (void)hipStreamDestroy(e->pcps_aux);
+    for (hipEvent_t ev : e->pcps_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (e->code_len) (void)hipFree(e->code_len);
     (void)hipStreamDestroy(e->stream);
     delete e;

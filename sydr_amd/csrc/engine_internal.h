@@ -99,6 +99,9 @@ struct sdr_engine {
     bool epl_no_split = false;       // diagnostics: keep the run-time switch positions where the KS = 12 kernel would run
     int pcps_prn_chunk = 0;          // diagnostics: PRNs per inverse sweep (0 = as many as the work buffers hold)
     bool pcps_force_map = false;     // diagnostics / tests: materialise the map even when the caller does not ask for it
+    bool pcps_no_overlap = false;    // diagnostics: one stream for the inverse sweeps of a map-free search
+    hipStream_t pcps_aux = nullptr;  // second stream of the map-free search (odd sweeps), its two ordering events
+    hipEvent_t pcps_ev[2] = {nullptr, nullptr};
     bool pcps_no_fast = false;       // diagnostics: keep the general four-step kernels where the N = 125 x 200 ones would run
     bool pcps_force_passes = false;  // diagnostics: use the one-kernel-per-radix-pass transform instead of the four-step one
 

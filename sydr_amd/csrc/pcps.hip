@@ -889,6 +889,9 @@ __global__ __launch_bounds__(kThreads) void fft4_rows_kernel(const PassArgs a, i
     }
 }
 
+#ifndef SDR_PCPS_OVERLAP_MB
+#define SDR_PCPS_OVERLAP_MB 100ll
+#endif
 #include "pcps_fast.h"   // register-resident kernels for N = 125 x 200 (needs Butterfly, PassArgs, Best, wave_best)
 
 template <bool INV, int LOAD0, int STORE_LAST, int FMT, int TA, int TB>
@@ -929,7 +932,7 @@ template <bool INV, int LOAD0, int STORE_LAST, int FMT>
 void run_four_step(sdr_engine* e, const FourStep& f, PassArgs a, int batch, double2* Z, double2* final_out) {
     if constexpr (INV && LOAD0 == LOAD_MUL_CODE && STORE_LAST == STORE_MAG_MAX) {
         if (fast25k_applies(e, f)) {      // the 1312 transforms of a map-free search at 25 MHz
-            fast25k::run(e, a, batch, Z);
+            fast25k::run(e, a, batch, Z, e->stream);
             return;
         }
     }
@@ -1130,8 +1133,36 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
             f.bin_delta = bin_delta;
             run_fft<false, LOAD_IQ_MIX, STORE_PLAIN, FMT>(e, radices, f, nbins, A, B, F, "pcps_fwd_fft", blu);
 
-            for (int p0 = 0; p0 < n_prn; p0 += prn_chunk) {
+            // Register-resident kernels, several sweeps, nobody timing the stages: the sweeps alternate between two
+            // streams and two intermediates, so that one sweep's partial last rounds of workgroups (and its launch
+            // ramps) are filled by the other's -- ordered behind the forward transforms and in front of the peak
+            // kernels by two events.
+            const bool overlap = map_free && fast25k_applies(e, plan_four_step(N)) && n_prn > prn_chunk && !e->prof &&
+                                 !e->pcps_no_overlap;
+            if (overlap) {
+                if (!e->pcps_aux) {
+                    SDR_HIP(hipStreamCreateWithFlags(&e->pcps_aux, hipStreamNonBlocking));
+                    SDR_HIP(hipEventCreateWithFlags(&e->pcps_ev[0], hipEventDisableTiming));
+                    SDR_HIP(hipEventCreateWithFlags(&e->pcps_ev[1], hipEventDisableTiming));
+                }
+                SDR_HIP(hipEventRecord(e->pcps_ev[0], e->stream));
+                SDR_HIP(hipStreamWaitEvent(e->pcps_aux, e->pcps_ev[0], 0));
+            }
+            int sweep = 0;
+            for (int p0 = 0; p0 < n_prn; p0 += prn_chunk, ++sweep) {
                 const int pc = n_prn - p0 < prn_chunk ? n_prn - p0 : prn_chunk;
+                if (overlap) {
+                    PassArgs g = {};
+                    g.tw = tw;
+                    g.N = N;
+                    g.in = F;
+                    g.code_spec = C + (size_t)p0 * N;
+                    g.nbins = nbins;
+                    g.scale = 1.0 / (double)N;
+                    g.partials = (Best*)e->pcps_part.ptr + (size_t)p0 * nbins * records_main_sweep(e, plan_four_step(N));
+                    fast25k::run(e, g, pc * nbins, (sweep & 1) ? B : A, (sweep & 1) ? e->pcps_aux : e->stream);
+                    continue;
+                }
                 PassArgs g = {};
                 g.tw = tw;
                 g.N = N;
@@ -1151,6 +1182,10 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
                     g.first_block = ic == 0;
                     run_fft<true, LOAD_MUL_CODE, STORE_CPLX_ACC, FMT>(e, radices, g, pc * nbins, A, B, nullptr, "pcps_inv_fft", blu);
                 }
+            }
+            if (overlap) {
+                SDR_HIP(hipEventRecord(e->pcps_ev[1], e->pcps_aux));
+                SDR_HIP(hipStreamWaitEvent(e->stream, e->pcps_ev[1], 0));
             }
         }
         if (coh > 1) {
@@ -1311,7 +1346,9 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     // 16: 0.379, 6: 0.392 -- the smaller the sweep, the larger the share of its partial last round of workgroups).
     if (map_free && e->pcps_prn_chunk == 0) {
         const int64_t per_prn = (int64_t)tbytes * nbins;
-        const int fit = (int)std::max<int64_t>(1, (200ll << 20) / per_prn);
+        // (two sweeps alive at a time where they alternate between two streams: pcps_run)
+        const bool two_alive = fast25k_applies(e, four) && !e->prof && !e->pcps_no_overlap;
+        const int fit = (int)std::max<int64_t>(1, ((two_alive ? SDR_PCPS_OVERLAP_MB : 200ll) << 20) / per_prn);
         if (fit < prn_chunk) {
             const int sweeps = (n_prn + fit - 1) / fit;
             prn_chunk = (n_prn + sweeps - 1) / sweeps;

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, con
     }
 }
 
-inline void run(sdr_engine* e, PassArgs a, int batch, double2* Z) {
+inline void run(sdr_engine* e, PassArgs a, int batch, double2* Z, hipStream_t stream) {
     const size_t shA = (size_t)(N1 * kColT + N1) * sizeof(double2);
     const size_t shB = (size_t)(20 * kRowPitch + N2) * sizeof(double2);
     (void)hipFuncSetAttribute((const void*)cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shA);
@@ -315,8 +315,8 @@ inline void run(sdr_engine* e, PassArgs a, int batch, double2* Z) {
     a.n_prn = batch / a.nbins;
     const int pairs = (N2 / kColT) * a.nbins;
     const unsigned gridA = 8u * (unsigned)((pairs + 7) / 8) * (unsigned)a.n_prn;
-    hipLaunchKernelGGL(cols_kernel, dim3(gridA), dim3(kColThreads), shA, e->stream, a, Z);
-    hipLaunchKernelGGL(rows_kernel, dim3(kRowTiles, batch), dim3(kRowThreads), shB, e->stream, a, Z);
+    hipLaunchKernelGGL(cols_kernel, dim3(gridA), dim3(kColThreads), shA, stream, a, Z);
+    hipLaunchKernelGGL(rows_kernel, dim3(kRowTiles, batch), dim3(kRowThreads), shB, stream, a, Z);
 }
 
 }  // namespace fast25k
