@@ -5,7 +5,10 @@
 // streamed from the HBM ring with 16-byte loads, the PRN replica sits in LDS as the high words of +-1.0, accumulators
 // are fp64 and are reduced inside the wave with DPP moves + v_readlane in a fixed order (so results do not depend on
 // how channels are sharded over GPUs).  Three correlator cores, chosen per launch from the items' code steps:
-//   chip-aligned (correlator_chip.h) : ci8, 16-26 samples per chip -- a lane owns a whole chip of the prompt tap
+//   chip-aligned (correlator_chip.h) : ci8, 16-26 samples per chip -- a lane owns a whole chip of the prompt tap; with the
+//                                      block length (24/25 samples) and the outer taps' switch position (12/13) compiled
+//                                      in when every epoch of the launch has them; 32-52 samples per chip through the
+//                                      half-chip view of the replicas (every chip twice, doubled NCO parameters)
 //   boundary     (correlator.h)      : a lane owns 16 (8) consecutive samples, < 1 chip; running sums in an LDS strip
 //   per-sample   (correlator.h)      : exact chip index per sample and tap; low rates, epochs that wrap the ring
 //
