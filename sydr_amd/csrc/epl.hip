@@ -50,7 +50,10 @@ constexpr int kLongLutWords = 4096;  // replicas of 16 KB and more (multi-period
 #define SDR_EPL_WAVES 1
 #endif
 template <int FMT, int NT, int W, int KM = 0, int WPW = 1, int KS = 0>
-__global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? 3 : SDR_EPL_WAVES)) void epl_kernel(const void* __restrict__ ring, int64_t capacity,
+#ifndef SDR_EPL_KS_WAVES
+#define SDR_EPL_KS_WAVES 3   // (the KS kernel sits at the 168-register cap of three waves per SIMD; two waves: 0.306 instead of 0.286 ms per stream-second)
+#endif
+__global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : SDR_EPL_WAVES)) void epl_kernel(const void* __restrict__ ring, int64_t capacity,
                                                        const sdr_epl_item* __restrict__ items, int n_items, int group_stride,
                                                        const uint32_t* __restrict__ luts,
                                                        int lut_words, int lut_stride,
