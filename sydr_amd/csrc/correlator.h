@@ -191,11 +191,13 @@ template <int FMT, int NT>
 __device__ __forceinline__ void edge_samples(const void* __restrict__ ring, int64_t capacity,
                                              const EpochParams& ep, double dphi, const double* shift,
                                              const double* step, const uint32_t* lut, int lane, int head_end,
-                                             int tail_start, double* accr, double* acci) {
+                                             int tail_start, double* accr, double* acci, int64_t base = -1) {
     const int count = head_end + (ep.n - tail_start);
     if (lane >= count) return;
     const int i = lane < head_end ? lane : tail_start + (lane - head_end);
-    int64_t pos = (ep.start_sample + i) % capacity;
+    // base >= 0: the ring position of the epoch's first sample, from a caller whose epoch does not wrap (a 64-bit
+    // modulo is ~60 instructions)
+    int64_t pos = base >= 0 ? base + i : (ep.start_sample + i) % capacity;
     double xr, xi;
     load_one<FMT>(ring, pos, xr, xi);
     double sn, cs;

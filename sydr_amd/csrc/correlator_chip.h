@@ -454,9 +454,9 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
     if (edge_lane >= 0) {
         if (head_end + (n - tail_start) > 64) {
             for (int off = 0; off < head_end + (n - tail_start); off += 64)
-                edge_samples<SDR_FMT_CI8, NT>(ring, capacity, ep, dphi, shift, step, lut, edge_lane + off, head_end, tail_start, accr, acci);
+                edge_samples<SDR_FMT_CI8, NT>(ring, capacity, ep, dphi, shift, step, lut, edge_lane + off, head_end, tail_start, accr, acci, base);
         } else {
-            edge_samples<SDR_FMT_CI8, NT>(ring, capacity, ep, dphi, shift, step, lut, edge_lane, head_end, tail_start, accr, acci);
+            edge_samples<SDR_FMT_CI8, NT>(ring, capacity, ep, dphi, shift, step, lut, edge_lane, head_end, tail_start, accr, acci, base);
         }
     }
     return true;
