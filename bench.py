@@ -562,6 +562,11 @@ def main():
             epochs_per_launch = ch_samples / max(1, n_launches) * len(items) / max(1.0, float(items["n_samples"].sum()))
             if info.get("epl_kernel_hbm_bytes_per_epoch"):   # counters are per channel-epoch (one workgroup each), scaled to this launch size
                 result["roofline"]["traffic"] = info["epl_kernel_hbm_bytes_per_epoch"] * epochs_per_launch
+                # the same bytes as a rate: what the memory system actually moves (the 32 channels share the stream
+                # through the caches: 0.26 x the algorithmic bytes) -- beside `achieved`, which prices every channel's read
+                if launches:
+                    result["roofline"]["traffic_GBps"] = result["roofline"]["traffic"] / avg_kernel_s / 1e9
+                    result["roofline"]["traffic_frac_of_peak"] = result["roofline"]["traffic_GBps"] / HBM_PEAK_GBS
             if info.get("epl_kernel_valu_insts_per_epoch"):
                 # VALU issue roof from the SQ counter pass (tools/summarize_pmc.py): wave-instructions x 4 cycles
                 # over 1024 SIMDs at 2.4 GHz against THIS run's launch duration
