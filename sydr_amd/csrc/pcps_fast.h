@@ -29,9 +29,12 @@ namespace fast25k {
 constexpr int N1 = 125, N2 = 200, N = 25000;
 constexpr int kColT = 25;            // columns per workgroup: 125 of 128 threads hold 25 points each
 constexpr int kColThreads = 128;
-constexpr int kRowT = 12;            // rows per workgroup: 120 of 128 threads hold 20 points each
-constexpr int kRowThreads = 128;
-constexpr int kRowPitch = 121;       // 16-byte slots per exchanged register (odd: ten-strided reads hit sixteen different slots)
+#ifndef SDR_PCPS_FAST_ROWT
+#define SDR_PCPS_FAST_ROWT 12
+#endif
+constexpr int kRowT = SDR_PCPS_FAST_ROWT;                 // rows per workgroup: 120 of 128 threads hold 20 points each
+constexpr int kRowThreads = (10 * kRowT + 63) / 64 * 64;
+constexpr int kRowPitch = 10 * kRowT + 1;                 // 16-byte slots per exchanged register (odd: ten-strided reads hit sixteen different slots)
 constexpr int kRowTiles = (N1 + kRowT - 1) / kRowT;
 constexpr int kRecordsPerTransform = kRowTiles * (kRowThreads / 64);
 
@@ -235,15 +238,19 @@ __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, con
     const bool live = tid < 10 * T && k1_0 + i < N1;
     const double2* __restrict__ tw = a.tw;
     double2* w200 = lds4 + 20 * kRowPitch;                   // w200^e, e < 200
-    const double2 wa = tw[(N / 200) * tid], wb = tw[(N / 200) * (tid + kRowThreads < N2 ? tid + kRowThreads : 0)];
+    constexpr int kTabPerThread = (N2 + kRowThreads - 1) / kRowThreads;
+    double2 wt[kTabPerThread];
+#pragma unroll
+    for (int q = 0; q < kTabPerThread; ++q) wt[q] = tw[(N / 200) * (tid + q * kRowThreads < N2 ? tid + q * kRowThreads : 0)];
     double2 v[20];
     if (live) {
         const double2* __restrict__ row = Z + ((size_t)batch * N1 + k1_0 + i) * N2 + r;
 #pragma unroll
         for (int m = 0; m < 20; ++m) v[m] = row[10 * m];
     }
-    w200[tid] = wa;
-    if (tid + kRowThreads < N2) w200[tid + kRowThreads] = wb;
+#pragma unroll
+    for (int q = 0; q < kTabPerThread; ++q)
+        if (tid + q * kRowThreads < N2) w200[tid + q * kRowThreads] = wt[q];
     if (live) idft20(v, tw);
     __syncthreads();                                         // the table
     if (live) {
