@@ -240,6 +240,7 @@ struct sdr_epl_plan {
     int lut_words = 0;
     int wide = 0;  // 16 / 8: every item has 16 (8) * code_step < 1, the boundary variant with that group width applies
     int group_stride = 0;  // C > 0: items[i] and items[i + C] use the same code slot for every i (epoch-major lists of C channels)
+    bool borrowed = false;  // device buffers are the engine's workspaces (sdr_epl_batch): not freed with the plan
     bool doubled = false;  // the plan runs on the half-chip view: its device items / spacings carry 2*rem_code, 2*code_step, 2*spacing
     double fs = 0.0;
     int64_t code_generation = 0;  // of the engine's code tables the plan was validated against
@@ -320,8 +321,18 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
 
 extern "C" {
 
+static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_items, const double* spacing,
+                            int n_taps, double fs, bool use_workspaces, sdr_epl_plan** out);
+
 int sdr_epl_plan_create(sdr_engine* e, const sdr_epl_item* items, int n_items, const double* spacing,
                         int n_taps, double fs, sdr_epl_plan** out) {
+    return plan_create_impl(e, items, n_items, spacing, n_taps, fs, false, out);
+}
+
+// use_workspaces: the one-shot sdr_epl_batch (the function-level drop-in calls it once per EPL()) keeps its three device
+// buffers in the engine between calls instead of allocating and freeing them every time.
+static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_items, const double* spacing,
+                            int n_taps, double fs, bool use_workspaces, sdr_epl_plan** out) {
     if (int rc = sdr_set_device(e)) return rc;
     if (!out) return sdr_fail(SDR_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -365,9 +376,24 @@ int sdr_epl_plan_create(sdr_engine* e, const sdr_epl_item* items, int n_items, c
     }
     p->code_generation = e->code_generation;
     p->ring_capacity = e->iq_capacity;
-    hipError_t err = hipMalloc(&p->d_items, (size_t)n_items * sizeof(sdr_epl_item));
-    if (err == hipSuccess) err = hipMalloc(&p->d_out, (size_t)n_items * 2 * n_taps * sizeof(double));
-    if (err == hipSuccess) err = hipMalloc(&p->d_spacing, SDR_MAX_TAPS * sizeof(double));
+    hipError_t err = hipSuccess;
+    if (use_workspaces) {
+        int rc = sdr_devbuf_reserve(e, &e->ws_items, (size_t)n_items * sizeof(sdr_epl_item));
+        if (!rc) rc = sdr_devbuf_reserve(e, &e->ws_out, (size_t)n_items * 2 * n_taps * sizeof(double));
+        if (!rc) rc = sdr_devbuf_reserve(e, &e->ws_spacing, SDR_MAX_TAPS * sizeof(double));
+        if (rc) {
+            delete p;
+            return rc;
+        }
+        p->borrowed = true;
+        p->d_items = (sdr_epl_item*)e->ws_items.ptr;
+        p->d_out = (double*)e->ws_out.ptr;
+        p->d_spacing = (double*)e->ws_spacing.ptr;
+    } else {
+        err = hipMalloc(&p->d_items, (size_t)n_items * sizeof(sdr_epl_item));
+        if (err == hipSuccess) err = hipMalloc(&p->d_out, (size_t)n_items * 2 * n_taps * sizeof(double));
+        if (err == hipSuccess) err = hipMalloc(&p->d_spacing, SDR_MAX_TAPS * sizeof(double));
+    }
     std::vector<sdr_epl_item> items2;
     double spacing2[SDR_MAX_TAPS];
     if (doubled) {
@@ -449,9 +475,11 @@ void sdr_epl_plan_destroy(sdr_engine* e, sdr_epl_plan* p) {
         (void)hipSetDevice(e->device);
         (void)hipStreamSynchronize(e->stream);
     }
-    if (p->d_items) (void)hipFree(p->d_items);
-    if (p->d_out) (void)hipFree(p->d_out);
-    if (p->d_spacing) (void)hipFree(p->d_spacing);
+    if (!p->borrowed) {
+        if (p->d_items) (void)hipFree(p->d_items);
+        if (p->d_out) (void)hipFree(p->d_out);
+        if (p->d_spacing) (void)hipFree(p->d_spacing);
+    }
     delete p;
 }
 
@@ -459,7 +487,7 @@ int sdr_epl_batch(sdr_engine* e, const sdr_epl_item* items, int n_items, const d
                   double fs, double* out) {
     if (!out) return sdr_fail(SDR_ERR_INVALID, "out is NULL");
     sdr_epl_plan* p = nullptr;
-    if (int rc = sdr_epl_plan_create(e, items, n_items, spacing, n_taps, fs, &p)) return rc;
+    if (int rc = plan_create_impl(e, items, n_items, spacing, n_taps, fs, true, &p)) return rc;
     int rc = sdr_epl_plan_run(e, p);
     if (!rc) rc = sdr_epl_plan_fetch(e, p, out);
     sdr_epl_plan_destroy(e, p);
