@@ -455,3 +455,38 @@ def test_half_chip_view_for_32_to_52_samples_per_chip(engine):
     check(50e6, (-0.5, 0.0, 0.5), 1)
     check(50e6, (-1.0, -0.5, 0.0, 0.5, 1.0), 4)
     check(40e6, (-0.25, 0.0, 0.25), 2, restage=True)
+
+
+def test_compile_time_tap_switch_variant_randomised(engine):
+    """1200 random channel-epochs through the kernel with the tap switch positions compiled in: code Doppler of +-12 Hz,
+    code phases at and next to zero, one and two periods, n = N - 2 .. N + 2, carriers from 0 to +-4 MHz, phases of
+    +-10 rad, full-scale int8 samples -- against the oracle."""
+    rng = np.random.default_rng(99)
+    cap = 8 * 200000
+    raw = rng.integers(-128, 128, 2 * cap).astype(np.int8)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(8, 1023, 2)
+    for s in range(8):
+        engine.load_gps_code(s, 4 * s + 1)
+    rf = orc.iq_to_complex(raw)
+    half = (-0.5, 0.0, 0.5)
+    for rnd in range(3):
+        n_items = 400
+        step = (1.023e6 + rng.uniform(-12, 12, n_items)) / 25e6
+        rem = rng.uniform(0, step) * rng.choice([1.0, 1.0, 1e-6, 0.999999], n_items)
+        per = rng.integers(1, 3, n_items)
+        n = np.ceil((1023 * per - rem) / step).astype(np.int64) + rng.integers(-2, 3, n_items)
+        start = rng.integers(0, cap - 60000, n_items)
+        slot = rng.integers(0, 8, n_items)
+        f = rng.uniform(-20000, 20000, n_items) * rng.choice([1.0, 0.0, 200.0], n_items)
+        ph = rng.uniform(-10, 10, n_items)
+        plan = engine.epl_plan(make_items(slot, n, start, f, ph, rem, step), half, 25e6)
+        assert plan.variant == 26 + 24 + 256 * 12
+        plan.run()
+        got = plan.fetch()
+        for k in range(n_items):
+            x = orc.ring_slice(rf, int(start[k]), int(n[k]))
+            ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(4 * int(slot[k]) + 1)), 25e6, f[k], ph[k], rem[k], step[k], half))
+            scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 60.0), 2)
+            assert np.max(np.abs(got[k] - ref) / scale) < 1e-9, (rnd, k, step[k], n[k], rem[k], f[k])
