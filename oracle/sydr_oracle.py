@@ -575,7 +575,10 @@ def synth_iq(fs, n_samples, sats, noise_sigma, seed, dtype=np.int8):
         chips = s["code_phase"] + n * cstep
         idx = np.floor(chips).astype(np.int64) % CODE_CHIPS
         period = np.floor(chips / CODE_CHIPS).astype(np.int64)
-        bits = rng.integers(0, 2, size=int(period.max() // MS_PER_BIT) + 2) * 2 - 1
+        if "data" in s:     # caller-supplied navigation symbols (+-1 per 20 code periods), e.g. encoded LNAV subframes
+            bits = np.asarray(s["data"])
+        else:
+            bits = rng.integers(0, 2, size=int(period.max() // MS_PER_BIT) + 2) * 2 - 1
         data = bits[period // MS_PER_BIT]
         carrier = np.exp(2j * np.pi * (s["doppler"] / fs * n + s.get("phase", 0.0)))
         x += s["amp"] * code[idx] * data * carrier
@@ -587,6 +590,32 @@ def synth_iq(fs, n_samples, sats, noise_sigma, seed, dtype=np.int8):
     out = np.empty(2 * n_samples, dtype=dtype)
     out[0::2] = re
     out[1::2] = im
+    return out
+
+
+def synth_iq_stream(fs, n_samples, sats, noise_sigma, seed, chunk=1 << 22, dtype=np.int8):
+    """`synth_iq` for streams of many seconds, made in chunks of `chunk` samples (bounded memory): the same signal
+    model on absolute sample numbers; every satellite needs its `data` symbols (+-1 per 20 code periods, counted
+    from the code period in which sample 0 lies); the noise of chunk k is drawn from default_rng([seed, k])."""
+    out = np.empty(2 * n_samples, dtype=dtype)
+    info = np.iinfo(dtype)
+    lim = min(info.max, 127 if dtype == np.int8 else 32767)
+    codes = [gold_code(s["prn"]) for s in sats]
+    for k, first in enumerate(range(0, n_samples, chunk)):
+        m = min(chunk, n_samples - first)
+        n = first + np.arange(m, dtype=np.float64)
+        x = np.zeros(m, dtype=np.complex128)
+        for s, code in zip(sats, codes):
+            cstep = CODE_RATE * (1.0 + s["doppler"] / 1575.42e6) / fs
+            chips = s["code_phase"] + n * cstep
+            period = np.floor(chips / CODE_CHIPS).astype(np.int64)
+            idx = np.floor(chips).astype(np.int64) - period * CODE_CHIPS
+            data = np.asarray(s["data"])[period // MS_PER_BIT]
+            x += s["amp"] * code[idx] * data * np.exp(2j * np.pi * (s["doppler"] / fs * n + s.get("phase", 0.0)))
+        rng = np.random.default_rng([seed, k])
+        x += noise_sigma * (rng.standard_normal(m) + 1j * rng.standard_normal(m))
+        out[2 * first:2 * (first + m):2] = np.clip(np.rint(x.real), -lim, lim).astype(dtype)
+        out[2 * first + 1:2 * (first + m):2] = np.clip(np.rint(x.imag), -lim, lim).astype(dtype)
     return out
 
 

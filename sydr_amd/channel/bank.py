@@ -18,6 +18,7 @@ import numpy as np
 
 from .._lib import LOOP_CFG_DTYPE, TRACK_EPOCH_DTYPE, TRACK_STATE_DTYPE
 from ..utils.enumerations import ChannelMessage, ChannelState, LoopLockState, TrackingFlags
+from .navdecoder import HOST_FLAGS
 
 KIND_BORRE, KIND_KAPLAN = 0, 1
 
@@ -44,7 +45,11 @@ class ChannelBank:
         self.last = np.zeros(self.max_channels, dtype=TRACK_EPOCH_DTYPE)   # most recent epoch record per channel
         self.last["nav_bit"] = -1
         self.code_since_tow = np.zeros(self.max_channels, dtype=np.int64)
-        self.tow = np.zeros(self.max_channels, dtype=np.int64)
+        self.tow = np.zeros(self.max_channels, dtype=np.float64)           # Channel.tow once a subframe was decoded ...
+        self.tow_decoded = np.zeros(self.max_channels, dtype=bool)         # ... (the plain int 0 of channel.py:93 before)
+        self.host_flags = np.zeros(self.max_channels, dtype=np.int64)      # TrackingFlags owned by the decoder (HOST_FLAGS)
+        self.decoders = [None] * self.max_channels                         # NavDecoder per channel (navdecoder.py)
+        self.decoded = []                                                  # DECODING_UPDATE packets of the last step
         self.tracking = np.zeros(self.max_channels, dtype=bool)            # channels in ChannelState.TRACKING
         self.lost = np.zeros(self.max_channels, dtype=bool)                # NCO ran away on the device: channel parked
         self._dirty = np.zeros(self.max_channels, dtype=bool)
@@ -54,9 +59,10 @@ class ChannelBank:
         """A larger bank holding this one's channels (the mirror is complete, so the rows are simply re-uploaded)."""
         big = ChannelBank(self.engine, max_channels, self.ring)
         n = self.max_channels
-        for name in ("state", "cfg", "last", "code_since_tow", "tow", "tracking", "lost"):
+        for name in ("state", "cfg", "last", "code_since_tow", "tow", "tow_decoded", "host_flags", "tracking", "lost"):
             getattr(big, name)[:n] = getattr(self, name)
         big.nav_bits[:n] = self.nav_bits
+        big.decoders[:n] = self.decoders
         big._dirty[:n] = self.cfg["n_taps"] != 0
         self.close()
         return big
@@ -114,9 +120,38 @@ class ChannelBank:
                 self.lost[channels[short]] = True
         bits = records["nav_bit"]
         if (bits >= 0).any():
-            for r, e in zip(*np.nonzero(bits >= 0)):
+            for r, e in zip(*np.nonzero(bits >= 0)):      # (row-major: a channel's bits arrive in epoch order)
                 if e < done[r]:
-                    self.nav_bits[int(channels[r])].append(int(bits[r, e]))
+                    self._new_bit(int(channels[r]), int(bits[r, e]), int(records["track_flags"][r, e]),
+                                  int(e), int(done[r]))
+
+    def _new_bit(self, ch: int, bit: int, device_flags: int, epoch: int, epochs_run: int):
+        """One navigation bit left the device: keep it, and let the channel's decoder look at it -- the `runDecoding`
+        that follows `runTracking` in the reference's tick (kaplan:71-73).  A completed subframe becomes a
+        DECODING_UPDATE packet (kaplan:858-868), `tow`, and restarts the code count (kaplan:833) from this epoch."""
+        self.nav_bits[ch].append(bit)
+        decoder = self.decoders[ch]
+        if decoder is None:
+            return
+        flags, event = decoder.push(bit, device_flags | int(self.host_flags[ch]))
+        self.host_flags[ch] = flags & HOST_FLAGS
+        if event is not None:
+            self.tow[ch], self.tow_decoded[ch] = event.channel_tow, True
+            self.code_since_tow[ch] = epochs_run - 1 - epoch
+            self.decoded.append((ch, epoch, {"cid": ch, "type": ChannelMessage.DECODING_UPDATE,
+                                             "subframe_id": event.subframe_id, "tow": event.tow, "bits": event.bits}))
+
+    def take_decoded(self):
+        """[(channel, epoch within the step, DECODING_UPDATE packet)] produced by the last step, handed over once."""
+        out, self.decoded = self.decoded, []
+        return out
+
+    def flags(self, channels):
+        """TrackingFlags of `channels`: the device's bits (code lock, bit sync) and the decoder's."""
+        return self.state["track_flags"][channels] | self.host_flags[channels]
+
+    def channel_tow(self, ch: int):
+        return float(self.tow[ch]) if self.tow_decoded[ch] else 0
 
     def tick(self, raw, ring_offset, channels):
         """Ring ingest + one epoch for `channels` in one device call; returns the records [n]."""
@@ -233,11 +268,13 @@ class TickPackets(Sequence):
         return f"TickPackets({list(self)!r})"
 
 
-def channel_update_builder(cids, states, flags, tows, since_tow_ms, unread, code_since_tow):
-    """CHANNEL_UPDATE packets (channel.py:205-228) from values captured at the end of the tick."""
+def channel_update_builder(cids, states, flags, tows, tow_decoded, since_tow_ms, unread, code_since_tow):
+    """CHANNEL_UPDATE packets (channel.py:205-228) from values captured at the end of the tick.  `tow` is what the
+    reference's `Channel.tow` holds: the int 0 until a subframe was decoded, then HOW TOW + 1.24 s (kaplan:810-822)."""
     def build(i):
         return {"cid": int(cids[i]), "type": ChannelMessage.CHANNEL_UPDATE, "state": states[i],
-                "tracking_flags": _flags(int(flags[i])), "tow": int(tows[i]), "time_since_tow": float(since_tow_ms[i]),
+                "tracking_flags": _flags(int(flags[i])), "tow": float(tows[i]) if tow_decoded[i] else 0,
+                "time_since_tow": float(since_tow_ms[i]),
                 "unprocessed_samples": int(unread[i]), "code_since_tow": int(code_since_tow[i])}
     return build
 

@@ -13,6 +13,7 @@ from .tracked import DeviceTrackedChannel
 
 class ChannelL1CA(DeviceTrackedChannel):
     LOOP_KIND = KIND_BORRE
+    DECODER_PLUGIN = "borre"          # the default decoder drives borre:455-579 (packet `tow` = the HOW's value)
     MIN_CONVERGENCE_TIME = 100        # epochs before bit sync is looked for (borre:384-391); fixed in the kernel
 
     CFG_KEYS = {"dll_pdi": "dll_pdi", "pll_pdi": "pll_pdi"}

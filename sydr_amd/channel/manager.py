@@ -162,6 +162,8 @@ class ChannelManager:
             ran = np.flatnonzero(done > 0)
             cids, kinds, rec = ready[ran], bank.cfg["loop_kind"][ready[ran]], rec[ran]
             out.add(len(ran), tracking_packets_builder(cids, kinds, rec))
+            if bank.decoded:                                  # subframes completed by this tick's bits (kaplan:71-73)
+                out.add_ready(pkt for _, _, pkt in bank.take_decoded())
         # channel updates: everything they report is captured now, the dicts are made when read (acquisition may have
         # moved channels to TRACKING during this tick: take the lists again if it did)
         if getattr(self.sharedBuffer, "stateVersion", None) != version or self._lists is None:
@@ -172,8 +174,8 @@ class ChannelManager:
         if bank is not None:
             unread = bank.unread(cids)
             since = bank.code_since_tow[cids] * 1 + unread / (self.rfSignal.samplingFrequency / 1e3)
-            out.add(len(active), channel_update_builder(cids, states, bank.state["track_flags"][cids].copy(),
-                                                        bank.tow[cids].copy(), since, unread,
+            out.add(len(active), channel_update_builder(cids, states, bank.flags(cids), bank.tow[cids].copy(),
+                                                        bank.tow_decoded[cids].copy(), since, unread,
                                                         bank.code_since_tow[cids].copy()))
         else:
             out.add_ready(ch.prepareChannelUpdate() for ch in active)
@@ -226,8 +228,14 @@ class ChannelManager:
             members = np.array(members, dtype=np.int32)
             rec, done = bank.step(members, n)
             kinds = bank.cfg["loop_kind"][members]
-            flat = [(int(c), int(k), rec[r, e]) for r, (c, k) in enumerate(zip(members, kinds)) for e in range(done[r])]
-            out.add(len(flat), lambda i, flat=flat: tracking_packet(*flat[i]))
+            decoded = {(c, e): pkt for c, e, pkt in bank.take_decoded()}
+            flat = []
+            for r, (c, k) in enumerate(zip(members, kinds)):
+                for e in range(done[r]):
+                    flat.append((int(c), int(k), rec[r, e]))
+                    if decoded and (int(c), e) in decoded:    # a subframe completed by this epoch's bit follows it
+                        flat.append(decoded[(int(c), e)])
+            out.add(len(flat), lambda i, flat=flat: flat[i] if isinstance(flat[i], dict) else tracking_packet(*flat[i]))
         out.add_ready(ch.prepareChannelUpdate() for ch in chans)
         return out
 

@@ -21,6 +21,7 @@ from ..utils.constants import GPS_L1CA_CODE_FREQ, GPS_L1CA_CODE_MS, GPS_L1CA_COD
 from ..utils.devicering import CircularBuffer as DeviceRing
 from ..utils.enumerations import ChannelMessage, ChannelState, GNSSSignalType, GNSSSystems, TrackingFlags
 from .bank import tracking_packet
+from .navdecoder import HOST_FLAGS, default_decoder
 from .base import Channel
 from .seams import GpuCorrelatorSeams
 
@@ -73,8 +74,10 @@ class DeviceTrackedChannel(GpuCorrelatorSeams, Channel, metaclass=_ViewMeta):
         self._bank.state[self._row] = np.zeros((), dtype=self._bank.state.dtype)
         self._bank.tracking[self._row] = self._bank.lost[self._row] = False
         self._bank.code_since_tow[self._row] = 0
+        self._bank.tow[self._row], self._bank.tow_decoded[self._row], self._bank.host_flags[self._row] = 0.0, False, 0
         del self._bank.nav_bits[self._row][:]
         super().__init__(cid, sharedBuffer, resultQueue, rfSignal, configuration)
+        self.setDecoding()
         self.codeOffset = 0
         self.setAcquisition(configuration['ACQUISITION'])
         self.setTracking(configuration['TRACKING'])
@@ -141,13 +144,25 @@ class DeviceTrackedChannel(GpuCorrelatorSeams, Channel, metaclass=_ViewMeta):
 
     @property
     def trackFlags(self):
-        v = int(self._bank.state["track_flags"][self._row])
+        v = int(self._bank.state["track_flags"][self._row]) | int(self._bank.host_flags[self._row])
         return TrackingFlags(v) if v in TrackingFlags._value2member_map_ else v
 
     @trackFlags.setter
     def trackFlags(self, value):
-        self._bank.state["track_flags"][self._row] = int(value)
-        self._bank.touch(self._row)
+        """The tracking loop's bits live on the device, the decoder's (HOST_FLAGS) on the host."""
+        device_bits = int(value) & ~HOST_FLAGS
+        self._bank.host_flags[self._row] = int(value) & HOST_FLAGS
+        if device_bits != int(self._bank.state["track_flags"][self._row]):
+            self._bank.state["track_flags"][self._row] = device_bits
+            self._bank.touch(self._row)
+
+    @property
+    def tow(self):
+        return self._bank.channel_tow(self._row)
+
+    @tow.setter
+    def tow(self, value):
+        self._bank.tow[self._row], self._bank.tow_decoded[self._row] = float(value), bool(value)
 
     @property
     def codeSinceTOW(self):
@@ -180,6 +195,33 @@ class DeviceTrackedChannel(GpuCorrelatorSeams, Channel, metaclass=_ViewMeta):
         chips = eng.read_code(self.codeSlot).astype(np.float64)
         self.code = np.r_[chips[-1], chips, chips[0]]   # padded table of kaplan:104-107, kept for API compatibility
 
+    # ------------------------------------------------------------------ decoding seam (navdecoder.py)
+    DECODER_PLUGIN = "kaplan"      # whose subframe logic the default (reference-backed) decoder drives
+
+    def setDecoding(self, decoder="default"):
+        """Choose what turns this channel's navigation bits into DECODING_UPDATE packets / `tow` / the TOW and EPH
+        flags (kaplan:680-698 sets up the reference's own buffers at this point).  "default": the reference's own
+        subframe logic when `sydr` is importable on this host, else None (bits only); None; or any NavDecoder."""
+        if isinstance(decoder, str):
+            decoder = default_decoder(self.channelID, self.DECODER_PLUGIN)
+        self._bank.decoders[self._row] = decoder
+        if decoder is not None:
+            decoder.reset()
+
+    @property
+    def navDecoder(self):
+        return self._bank.decoders[self._row]
+
+    def runDecoding(self):
+        """The seam of kaplan:702-726 / borre:455: the DECODING_UPDATE packet completed by the epoch `runTracking` just
+        ran, or None.  (The bits are decided on the device and pushed through the decoder as they arrive -- bank.py
+        `_new_bit`; a ChannelManager collects the packets of all channels itself.)"""
+        mine = [item for item in self._bank.decoded if item[0] == self._row]
+        if not mine:
+            return None
+        self._bank.decoded.remove(mine[0])
+        return mine[0][2]
+
     def getTimeSinceTOW(self):
         ms = self.codeSinceTOW * GPS_L1CA_CODE_MS
         return ms + self.rfBuffer.getNbUnreadSamples(self.currentSample) / (self.rfSignal.samplingFrequency / 1e3)
@@ -192,7 +234,7 @@ class DeviceTrackedChannel(GpuCorrelatorSeams, Channel, metaclass=_ViewMeta):
         if self.channelState == ChannelState.ACQUIRING:
             packet = self.runAcquisition()
         elif self.channelState == ChannelState.TRACKING:
-            packet = self.runTracking()
+            return [p for p in (self.runTracking(), self.runDecoding()) if p is not None]
         else:
             raise ValueError(f"Channel state {self.channelState} is not valid.")
         return [] if packet is None else [packet]

@@ -296,6 +296,88 @@ def make_trajectories(fname="g6_trajectories.npz", ms=510, amp=8.0, sigma=20.0, 
     save(fname, **out)
 
 
+# ---------------------------------------------------------------------------------------------- G10
+def make_decoding(fname="g10_decoding.npz", seconds=20.6, lead_bits=30, fs=4e6):
+    """The Kaplan plugin over a stream that carries valid LNAV subframes (oracle/lnav.py encodes them): the
+    reference's own DECODING_UPDATE packets (kaplan:702-868), the `tow` / `time_since_tow` / `tracking_flags`
+    / `code_since_tow` of every CHANNEL_UPDATE (channel.py:205-228) and the bit decided in every epoch.
+    The stream starts `lead_bits` navigation bits before a subframe boundary; three whole subframes (IDs 1, 2, 3)
+    follow, so the plugin passes SUBFRAME_SYNC, TOW_DECODED and EPH_DECODED.  IQ is not stored (seed + sha256)."""
+    from sydr.channel.channel_l1ca_kaplan import ChannelL1CA_Kaplan as RefKaplan
+    from sydr.utils.enumerations import ChannelMessage
+    from oracle import lnav
+
+    spms = int(fs * 1e-3)
+    ms = int(round(seconds * 1000))
+    first_tow, lnav_seed, n_sub = 57600, 20261000, 6
+    frames = lnav.lnav_stream(first_tow, 5, n_sub, lnav_seed)          # subframe 5, then 1, 2, 3, 4, 5
+    symbols = (2 * frames.astype(np.int64) - 1)[300 - lead_bits:]
+    prn, doppler, code_phase, phase, amp, sigma, seed = 7, 1750.0, 300.25, 0.1, 30.0, 10.0, 20261001
+    # code_phase chips into a period at sample 0; the bit edges fall on code-period boundaries
+    sats = [dict(prn=prn, doppler=doppler, code_phase=code_phase, phase=phase, amp=amp, data=symbols)]
+    raw = orc.synth_iq_stream(fs, ms * spms, sats, sigma, seed)
+    track_over = dict(fll_threshold_wide=0.3, fll_threshold_narrow=0.7, pll_threshold_narrow=0.7, dll_threshold=3.0,
+                      correlator_epl_narrow=0.25)
+    cfg = _channel_config(os.path.join(REF, "config/channels/channel_GPS_L1CA_kaplan.ini"),
+                          {"ACQUISITION": dict(doppler_steps=250, coherent_integration=1, non_coherent_integration=1),
+                           "TRACKING": track_over})
+    rfs = RFSignal(dict(filepath="none", sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0,
+                        data_size=8))
+    buf = CircularBuffer(100 * spms, complex)
+    ch = RefKaplan(0, buf, None, rfs, cfg)
+    ch.setSatellite(prn)
+    acq, ints, floats, dec_tick, dec_epoch, dec_meta, dec_bits = None, [], [], [], [], [], []
+    updates = []
+    for k in range(ms):
+        slab = raw[2 * k * spms:2 * (k + 1) * spms].astype(np.float64)
+        buf.shift(slab[0::2] + 1j * slab[1::2])
+        pre = [ch.currentSample, ch.track_requiredSamples] if ch.channelState == ChannelState.TRACKING else None
+        bits_before = ch.navBitsCounter
+        results = ch._processHandler()
+        nav_bit = -1
+        for r in results:
+            if r["type"] == ChannelMessage.ACQUISITION_UPDATE:
+                acq = [r["frequency_idx"], r["code_idx"], r["peak_ratio"], r["carrierFrequency"], r["codeOffset"],
+                       ch.currentSample, ch.track_requiredSamples]
+            elif r["type"] == ChannelMessage.TRACKING_UPDATE:
+                ints.append(pre + [int(ch.trackFlags), int(r["lock_state"]), -1])
+                floats.append([r["i_prompt"], r["q_prompt"], r["carrier_frequency"], r["code_frequency"], r["cn0"]])
+            elif r["type"] == ChannelMessage.DECODING_UPDATE:
+                assert sorted(r) == ["bits", "cid", "subframe_id", "tow", "type"]
+                dec_tick.append(k)
+                dec_epoch.append(len(ints) - 1)
+                dec_meta.append([r["subframe_id"], r["tow"]])
+                dec_bits.append(np.frombuffer(r["bits"].encode(), dtype=np.uint8) - ord("0"))
+        if ints and ch.navPromptSumCounter == 0 and (int(ch.trackFlags) & 2) and any("i_prompt" in r for r in results) \
+                and getattr(ch, "_g10_last_bit_epoch", None) != len(ints):
+            # a bit was decided in this epoch: it is the newest entry of the plugin's buffer, unless the buffer was
+            # just re-packed by decodeSubframe (then it sits at the end of what was kept)
+            nav_bit = int(ch.navBitsBuffer[ch.navBitsCounter - 1])
+            ints[-1][-1] = nav_bit
+            ch._g10_last_bit_epoch = len(ints)
+        u = ch.prepareChannelUpdate()
+        updates.append([k, int(u["state"].value), int(u["tracking_flags"]), float(u["tow"]), float(u["time_since_tow"]),
+                        int(u["unprocessed_samples"]), int(u["code_since_tow"])])
+    ints = np.array(ints, dtype=np.int64)
+    print("g10: acq", acq, "epochs", len(ints), "bits", int((ints[:, 4] >= 0).sum()), "decoding packets", dec_meta,
+          "at ticks", dec_tick, "final flags", int(ch.trackFlags), "tow", ch.tow)
+    save(fname, iq_sha256=iq_hash(raw),
+         synth=np.array([fs, ms * spms, prn, doppler, code_phase, phase, amp, sigma, seed]),
+         lnav=np.array([first_tow, 5, n_sub, lnav_seed, lead_bits]),
+         stand_ins=np.array(["gps_time (import only; never called on this path)"]),
+         track_override_keys=np.array(sorted(track_over)),
+         track_override_vals=np.array([float(track_over[k]) for k in sorted(track_over)]),
+         acq=np.array(acq, dtype=np.float64), epoch_ints=ints.astype(np.int32),
+         epoch_int_columns=np.array(["currentSample", "n", "flags", "lock_state", "nav_bit"]),
+         epoch_floats=np.array(floats)[::50], epoch_float_stride=np.array(50),
+         epoch_float_columns=np.array(["i_prompt", "q_prompt", "carrier_hz", "code_hz", "cn0"]),
+         updates=np.array(updates, dtype=np.float64),
+         update_columns=np.array(["tick", "state", "tracking_flags", "tow", "time_since_tow", "unprocessed_samples",
+                                  "code_since_tow"]),
+         dec_tick=np.array(dec_tick), dec_epoch=np.array(dec_epoch), dec_meta=np.array(dec_meta, dtype=np.int64),
+         dec_bits=np.array(dec_bits, dtype=np.uint8))
+
+
 # ---------------------------------------------------------------------------------------------- G9
 def make_serial():
     """SerialSearch + TwoCorrelationPeakComparison_SS (acquisition.py:119-193), reduced Doppler grid."""
@@ -372,7 +454,7 @@ def make_loopmath():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["codes", "pcps", "peaks", "epl", "traj", "loop", "serial"]
+    which = sys.argv[1:] or ["codes", "pcps", "peaks", "epl", "traj", "loop", "serial", "decoding"]
     if "serial" in which:
         make_serial()
     if "codes" in which:
@@ -394,3 +476,5 @@ if __name__ == "__main__":
         make_trajectories("g6c_25mhz.npz", ms=310, amp=8.0, sigma=20.0, seed=20260625, fs=25e6)
     if "loop" in which:
         make_loopmath()
+    if "decoding" in which:
+        make_decoding()
