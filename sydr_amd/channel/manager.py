@@ -35,6 +35,7 @@ def shard_channels(n_items: int, rank: int, world_size: int) -> list[int]:
 
 class ChannelManager:
     TIMEOUT = 1
+    DEFER_BYTES = 1 << 20         # slabs up to this size ride in the next run()'s device call; longer ones upload at once
 
     def __init__(self, rfSignal, engine: Engine | None = None, device_id: int = 0, keepCorrelationMap: bool = True,
                  ring_ms: int = 100):
@@ -51,7 +52,8 @@ class ChannelManager:
         self.resultQueue = None
         self.keepCorrelationMap = keepCorrelationMap
         self._slots = 0
-        self._pending = None          # slab handed to addNewRFData, uploaded by the next run()
+        self._pending = None          # (owned copy of the slab handed to addNewRFData, ring offset): uploaded by the next run()
+        self._stage_buf = None        # the host buffer those copies live in (re-used from tick to tick)
         self._lists = None            # (state version, active, acquiring, host-side plugins, cids, states) of the last tick
 
     @property
@@ -90,7 +92,16 @@ class ChannelManager:
         self._flush_pending()
         staged, offset, count = self.sharedBuffer.stage(data)
         self._guard_unread(count)
-        self._pending = (staged, offset)
+        if staged.nbytes > self.DEFER_BYTES:
+            self.engine.iq_upload(staged, offset)         # a long slab gains nothing from riding in the tick's call
+        else:
+            # the reference copies at this point (circularbuffer.py:54-82): keep an OWNED copy, so that a caller who
+            # reuses its buffer before run() cannot change what enters the ring
+            if self._stage_buf is None or self._stage_buf.dtype != staged.dtype or self._stage_buf.size < staged.size:
+                self._stage_buf = np.empty(max(staged.size, 1), dtype=staged.dtype)
+            own = self._stage_buf[:staged.size]
+            np.copyto(own, staged.reshape(-1))
+            self._pending = (own, offset)
         self.sharedBuffer.shiftIdxWrite(count)
 
     def _guard_unread(self, count: int):
@@ -148,11 +159,20 @@ class ChannelManager:
         ready = bank.ready() if bank is not None else np.zeros(0, dtype=np.int32)
         # one device call: ring ingest + one epoch for every ready channel
         staged, offset = self._pending if self._pending is not None else (None, 0)
-        self._pending = None
-        if bank is not None:
-            rec, done = bank.tick(staged, offset, ready)
-        elif staged is not None:
-            self.engine.iq_upload(staged, offset)
+        try:
+            if bank is not None:
+                rec, done = bank.tick(staged, offset, ready)
+            elif staged is not None:
+                self.engine.iq_upload(staged, offset)
+            self._pending = None
+        except Exception:
+            # the write index already counts this slab: whatever stopped the tick, its samples must still reach the ring
+            # (uploading them twice is harmless) before anybody reads it again
+            try:
+                self._flush_pending()
+            finally:
+                self._pending = None
+            raise
         if acquiring:
             out.add_ready(self._acquire(acquiring))
         for ch in host_plugins:   # plugins that keep their loops on the host (e.g. the reference's class behind the seams mixin)

@@ -78,7 +78,10 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : S
         item = (g * WPW + wave) * group_stride + c;
     }
     const bool have = item < n_items;
-    const sdr_epl_item it = items[have ? item : (int)(blockIdx.x % group_stride)];   // (a wave without an item still stages its share of the table)
+    // (a wave without an item still stages its share of the table: the slot of its group's column c = item c of the
+    // range -- clamped, because a range shorter than the stride launches columns that hold no item at all)
+    const int column = (int)(blockIdx.x % group_stride);
+    const sdr_epl_item it = items[have ? item : (column < n_items ? column : n_items - 1)];
     stage_lut<kThreads>(lut, luts + (size_t)it.code_slot * lut_stride, lut_words, tid);
     const double dphi = carrier_step(it.carrier_hz, fs);
     EpochParams ep;
@@ -245,6 +248,9 @@ struct sdr_epl_plan {
     double fs = 0.0;
     int64_t code_generation = 0;  // of the engine's code tables the plan was validated against
     int64_t ring_capacity = 0;    // and of the ring
+    // one event per stream a range of the plan was launched on, re-recorded behind every launch: fetch waits for
+    // exactly these instead of the whole device
+    std::vector<std::pair<hipStream_t, hipEvent_t>> ran_on;
 };
 
 // Host-side check that no item can index outside the ring or the staged LUT.
@@ -263,6 +269,15 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
     bool all_s12 = n_taps == 3;   // both outer taps switch chips 12.x samples into the anchor's block (KS = 12 kernel)
     for (int i = 0; i < n_items; ++i) {
         const sdr_epl_item& it = items[i];
+        // (before anything is derived from them: a zero n_samples or a NaN code_step would be cast to an integer below)
+        if (it.code_slot < 0 || it.code_slot >= e->n_slots || e->code_len_host[it.code_slot] <= 0)
+            return sdr_fail(SDR_ERR_INVALID, "item %d: code slot %d is not staged", i, it.code_slot);
+        if (it.n_samples <= 0 || it.n_samples > e->iq_capacity)
+            return sdr_fail(SDR_ERR_RANGE, "item %d: n_samples %d outside (0, ring capacity]", i, it.n_samples);
+        if (it.start_sample < 0) return sdr_fail(SDR_ERR_RANGE, "item %d: negative start_sample", i);
+        if (!(it.code_step > 0.0) || !std::isfinite(it.code_step) || !std::isfinite(it.rem_code) ||
+            !std::isfinite(it.rem_carrier) || !std::isfinite(it.carrier_hz))
+            return sdr_fail(SDR_ERR_INVALID, "item %d: non-finite or non-positive NCO parameter", i);
         {   // samples per chip of the anchor tap's np.linspace step, exactly as the kernel derives it (correlator_chip.h)
             const double two32 = 4294967296.0;
             const double nd = (double)it.n_samples;
@@ -274,7 +289,8 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
             };
             double sh, inv;
             line(s_anchor, sh, inv);
-            const int64_t tfx = (int64_t)std::rint(inv * two32);
+            const bool in_range = inv >= 1.0 && inv < 1024.0;   // (samples per chip; false for NaN / Inf as well)
+            const int64_t tfx = in_range ? (int64_t)std::rint(inv * two32) : 0;
             all_m24 = all_m24 && (int)(tfx >> 32) == 24;
             for (int t = 0; all_s12 && all_m24 && t < 3; t += 2) {
                 // the kernel's own derivation of the switch offset (a Q32.32 sample count); its reciprocal is a Newton
@@ -291,14 +307,6 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
         }
         if (scale * it.code_step > max_step) max_step = scale * it.code_step;
         if (scale * it.code_step < min_step) min_step = scale * it.code_step;
-        if (it.code_slot < 0 || it.code_slot >= e->n_slots || e->code_len_host[it.code_slot] <= 0)
-            return sdr_fail(SDR_ERR_INVALID, "item %d: code slot %d is not staged", i, it.code_slot);
-        if (it.n_samples <= 0 || it.n_samples > e->iq_capacity)
-            return sdr_fail(SDR_ERR_RANGE, "item %d: n_samples %d outside (0, ring capacity]", i, it.n_samples);
-        if (it.start_sample < 0) return sdr_fail(SDR_ERR_RANGE, "item %d: negative start_sample", i);
-        if (!(it.code_step > 0.0) || !std::isfinite(it.rem_code) || !std::isfinite(it.rem_carrier) ||
-            !std::isfinite(it.carrier_hz))
-            return sdr_fail(SDR_ERR_INVALID, "item %d: non-finite or non-positive NCO parameter", i);
         const double lo = std::ceil(it.rem_code + smin);
         const double hi = std::ceil(it.code_step * (double)it.n_samples + it.rem_code + smax);
         const int reach = e->lut_stride - SDR_LUT_PAD - 2;  // largest padded index the staged row serves
@@ -449,6 +457,16 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
         }
     }
     SDR_HIP(hipGetLastError());
+    if (ctx->stream != e->stream) {   // (fetch copies on e->stream, which is ordered behind its own launches anyway)
+        hipEvent_t ev = nullptr;
+        for (auto& se : p->ran_on)
+            if (se.first == ctx->stream) ev = se.second;
+        if (!ev) {
+            SDR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            p->ran_on.emplace_back(ctx->stream, ev);
+        }
+        SDR_HIP(hipEventRecord(ev, ctx->stream));
+    }
     return SDR_OK;
 }
 
@@ -462,7 +480,7 @@ int sdr_epl_plan_run(sdr_engine* e, sdr_epl_plan* p) {
 int sdr_epl_plan_fetch(sdr_engine* e, sdr_epl_plan* p, double* out) {
     if (int rc = sdr_set_device(e)) return rc;
     if (!p || !out) return sdr_fail(SDR_ERR_INVALID, "NULL plan or output");
-    SDR_HIP(hipDeviceSynchronize());   // ranges of the plan may have been launched on several streams
+    for (auto& se : p->ran_on) SDR_HIP(hipStreamWaitEvent(e->stream, se.second, 0));   // the streams its ranges ran on, no others
     SDR_HIP(hipMemcpyAsync(out, p->d_out, (size_t)p->n_items * 2 * p->n_taps * sizeof(double),
                            hipMemcpyDeviceToHost, e->stream));
     SDR_HIP(hipStreamSynchronize(e->stream));
@@ -474,6 +492,10 @@ void sdr_epl_plan_destroy(sdr_engine* e, sdr_epl_plan* p) {
     if (e) {
         (void)hipSetDevice(e->device);
         (void)hipStreamSynchronize(e->stream);
+    }
+    for (auto& se : p->ran_on) {
+        (void)hipEventSynchronize(se.second);
+        (void)hipEventDestroy(se.second);
     }
     if (!p->borrowed) {
         if (p->d_items) (void)hipFree(p->d_items);

@@ -1102,7 +1102,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
     const bool spectra_cached = !have_spectra && key == e->pcps_spec_key;
     if (have_spectra) e->pcps_spec_key.clear();
     if (!have_spectra && !spectra_cached) {
-        e->pcps_spec_key = key;
+        e->pcps_spec_key.clear();   // (valid again only once the new spectra are queued without error, below)
         int8_t* up = (int8_t*)B;  // scratch: n_prn*N bytes fits easily in a work buffer
         {
             ProfScope ps(e, "pcps_upsample");
@@ -1115,6 +1115,8 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
         a.code_samples = up;
         // ping-pong inside A (two halves are not needed: code batch is small) -> use A and F as scratch
         run_fft<false, LOAD_CODE_REAL, STORE_CONJ, FMT>(e, radices, a, n_prn, A, F, C, "pcps_code_fft", blu);
+        SDR_HIP(hipGetLastError());
+        e->pcps_spec_key = key;
     }
 
     for (int inc = 0; inc < noncoh; ++inc) {
@@ -1434,7 +1436,13 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
         default: rc = pcps_run<SDR_FMT_CF64>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
     }
     e->pcps_res_direct = nullptr;
-    if (rc) return rc;
+    if (rc) {
+        // a search that stopped half way: what the code-spectra buffer holds is unknown, and a sweep may still be
+        // running on the second stream -- join it before anybody re-uses the work buffers
+        e->pcps_spec_key.clear();
+        if (e->pcps_aux) (void)hipStreamSynchronize(e->pcps_aux);
+        return rc;
+    }
 
     if (corr_map)
         SDR_HIP(hipMemcpyAsync(corr_map, e->pcps_map.ptr, (size_t)n_prn * nbins * N * sizeof(double),

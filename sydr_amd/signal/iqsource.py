@@ -6,7 +6,8 @@ the GPU wants it: the recording is memory-mapped and a slab is a zero-copy view 
 integers (int8 / int16 I,Q -- 2 or 4 bytes per sample), which is byte for byte what the device ring stores.
 The reference instead reads 120 ms chunks and inflates every sample to complex128 (16 bytes) before anything
 else touches it (rfsignal.py:58-132).  Only what the hot path's callers use is kept of that class's surface:
-the front-end attributes and `getMilliseconds`.
+the front-end attributes, `getMilliseconds`, and `readFile` / `readFileBySamples` / `closeFile` /
+`getCurrentSampleIndex` (rfsignal.py:92-204) as views of the mapped file with the reference's cursor semantics.
 """
 from __future__ import annotations
 
@@ -14,24 +15,13 @@ import os
 
 import numpy as np
 
-_TRUE, _FALSE = {"1", "true", "yes", "on"}, {"0", "false", "no", "off"}
-
-
-def _as_bool(value) -> bool:
-    text = str(value).strip().lower()
-    if text in _TRUE:
-        return True
-    if text in _FALSE:
-        return False
-    raise ValueError(f"is_complex = {value!r} is not a boolean")
-
-
 class RFSignal:
     def __init__(self, configuration):
         self.filepath = str(configuration["filepath"])
         self.samplingFrequency = float(configuration["sampling_frequency"])
         self.interFrequency = float(configuration["intermediate_frequency"])
-        self.isComplex = _as_bool(configuration["is_complex"])
+        # rfsignal.py:35: bool(<ini string>) -- ANY non-empty string is True there ("false" included); mirrored as is
+        self.isComplex = bool(configuration["is_complex"])
         bits = int(configuration["data_size"])
         if bits not in (8, 16):
             raise ValueError(f"Data type of {bits} bit(s) is not valid.")
@@ -42,6 +32,7 @@ class RFSignal:
         self.samplesPerMs = int(self.samplingFrequency * 1e-3)
         self._map = None
         self._next = 0                                  # samples handed out so far
+        self._open = False                              # the reference's `file_id is not None` (readFile keep_open)
 
     # ------------------------------------------------------------------ the recording
     def _recording(self) -> np.ndarray:
@@ -83,3 +74,36 @@ class RFSignal:
         if raw:
             return block
         return block[0::2].astype(np.float64) + 1j * block[1::2].astype(np.float64)
+
+    # ------------------------------------------------------------------ the reference's file readers (rfsignal.py:92-204)
+    def _read(self, n_samples: int, skip: int, keep_open: bool, raw: bool):
+        """`skip` counts from the cursor while the file is "open" (np.fromfile(fid, offset=...) on a kept descriptor),
+        from the start of the recording otherwise; a short read at the end of the file returns what is there."""
+        rec = self._recording()
+        first = (self._next if self._open else 0) + int(skip)
+        stop = min(first + int(n_samples), rec.size // 2)
+        block = rec[2 * first:2 * max(stop, first)]
+        if keep_open:
+            self._open, self._next = True, max(stop, first)
+        elif self._open:              # the kept descriptor is closed by a read without keep_open (rfsignal.py:118-121)
+            self._open = False
+        if raw:
+            return block
+        return block[0::2].astype(np.float64) + 1j * block[1::2].astype(np.float64)
+
+    def readFile(self, timeLength, skip=0, keep_open=False, raw=False):
+        """`timeLength` milliseconds of signal (complex128 like the reference; raw=True: the interleaved integers)."""
+        return self._read(int((timeLength * 1e-3) * self.samplingFrequency), skip, keep_open, raw)
+
+    def readFileBySamples(self, nb_values, skip=0, keep_open=False, raw=False):
+        return self._read(int(nb_values), skip, keep_open, raw)
+
+    def closeFile(self):
+        if not self._open:
+            raise Warning("File was already close.")
+        self._open = False
+
+    def getCurrentSampleIndex(self):
+        if not self._open:
+            raise Warning("Signal file not open, cannot return current cursor position.")
+        return int(self._next)

@@ -159,6 +159,41 @@ def test_ring_bookkeeping_matches_reference_semantics():
         ring.shift(np.array([0.5 + 1j] * 1000))            # non-integer samples into an int8 ring
 
 
+def test_pending_slab_is_owned_and_survives_a_failed_tick():
+    """addNewRFData defers the ring write to the next run(): the reference copies at addNewRFData time
+    (circularbuffer.py:54-82), so what reaches the ring must be what the caller held THEN, and a tick that fails
+    must not lose the slab the write index already counts."""
+    fs, spms = 4e6, 4000
+    eng = OracleEngine()
+    mgr = ChannelManager(rf_signal(fs), engine=eng)
+    mgr.addChannel(ChannelL1CA_Kaplan, channel_config(KAPLAN_INI), 1)
+    mgr.requestTracking(7)
+    rng = np.random.default_rng(3)
+    slab = rng.integers(-100, 100, 2 * spms).astype(np.int8)
+    want = slab.copy()
+    mgr.addNewRFData(slab)
+    slab[:] = 0                                     # the caller re-uses its buffer before run()
+    mgr.run()
+    assert np.array_equal(eng.iq_download(spms, 0), want)
+    # a device call that raises: the slab still enters the ring, the exception still surfaces
+    second = rng.integers(-100, 100, 2 * spms).astype(np.int8)
+    mgr.addNewRFData(second)
+    bank, boom = mgr.bank, RuntimeError("tick failed")
+
+    def failing_tick(raw, offset, channels):
+        raise boom
+    real_tick, bank.tick = bank.tick, failing_tick
+    with pytest.raises(RuntimeError):
+        mgr.run()
+    bank.tick = real_tick
+    assert mgr._pending is None and np.array_equal(eng.iq_download(spms, spms), second)
+    # slabs beyond DEFER_BYTES go to the ring at once
+    long = rng.integers(-100, 100, 2 * spms * 20).astype(np.int8)
+    mgr.DEFER_BYTES = 1 << 10
+    mgr.addNewRFData(long)
+    assert mgr._pending is None and np.array_equal(eng.iq_download(20 * spms, 2 * spms), long)
+
+
 def test_rfsignal_serves_the_recording_as_raw_integer_slabs(tmp_path):
     rng = np.random.default_rng(2)
     raw = rng.integers(-128, 127, 2 * 4000 * 130).astype(np.int8)
@@ -181,8 +216,28 @@ def test_rfsignal_serves_the_recording_as_raw_integer_slabs(tmp_path):
         sig.getMilliseconds(1)
     with pytest.raises(ValueError):
         RFSignal(dict(filepath="x", sampling_frequency=4e6, is_complex="true", intermediate_frequency=0, data_size=12))
+    # rfsignal.py:35 reads the key with bool(<string>): "false" is True there, and here; only an empty value is real-valued
+    assert RFSignal(dict(filepath="x", sampling_frequency=4e6, is_complex="false", intermediate_frequency=0,
+                         data_size=8)).isComplex
     with pytest.raises(ValueError):
-        RFSignal(dict(filepath="x", sampling_frequency=4e6, is_complex="false", intermediate_frequency=0, data_size=8))
+        RFSignal(dict(filepath="x", sampling_frequency=4e6, is_complex="", intermediate_frequency=0, data_size=8))
+    # the reference's file readers (rfsignal.py:92-204): cursor kept while "open", complex128 out
+    rd = RFSignal(dict(filepath=str(path), sampling_frequency=4e6, is_complex="true", intermediate_frequency=0.0,
+                       data_size=8))
+    with pytest.raises(Warning):
+        rd.getCurrentSampleIndex()
+    a = rd.readFile(timeLength=2, keep_open=True)
+    assert a.dtype == np.complex128 and np.array_equal(a, raw[0:16000:2] + 1j * raw[1:16000:2])
+    assert rd.getCurrentSampleIndex() == 8000
+    b = rd.readFileBySamples(100, skip=50, keep_open=True)             # skip counts from the kept cursor
+    assert np.array_equal(b, raw[2 * 8050:2 * 8150:2] + 1j * raw[2 * 8050 + 1:2 * 8150:2])
+    assert rd.getCurrentSampleIndex() == 8150
+    rd.closeFile()
+    with pytest.raises(Warning):
+        rd.closeFile()
+    c = rd.readFileBySamples(10, skip=3, raw=True)                     # closed: from the start of the file
+    assert np.array_equal(c, raw[6:26]) and np.shares_memory(c, rd._recording())
+    assert rd.readFile(timeLength=1, skip=4000 * 130 - 10).size == 10  # a short read at the end of the file
     raw16 = rng.integers(-3000, 3000, 2 * 1000).astype(np.int16)
     raw16.tofile(tmp_path / "iq16.bin")
     sig16 = RFSignal(dict(filepath=str(tmp_path / "iq16.bin"), sampling_frequency=1e6, is_complex="True",

@@ -139,6 +139,44 @@ def test_scalar_loop_math():
         assert list(orc.loop_coefficients(b, z, gain)) == list(g["coeff"][k])
 
 
+def test_host_loop_math_drop_ins_match_the_reference():
+    """sydr_amd.dsp.tracking / lockindicator host functions (the reference's names and signatures) against the same
+    captured values, bit for bit -- including the atan(+-inf) and 0/0 rows."""
+    from sydr_amd.dsp import lockindicator as li
+    from sydr_amd.dsp import tracking as trk
+    g = load_golden("g7_loopmath.npz")
+    with np.errstate(all="ignore"):
+        for k, r in enumerate(g["inputs"]):
+            assert trk.DLL_NNEML(r[0], r[1], r[4], r[5]) == g["dll"][k]
+            np.testing.assert_equal(trk.PLL_costa(r[2], r[3]), g["pll"][k])
+            np.testing.assert_equal(trk.FLL_ATAN(r[2], r[3], r[6], r[7], 1e-3), g["fll"][k])
+            np.testing.assert_equal(li.FLL_Lock_Borre(r[2], r[6], r[3], r[7], 0.3, alpha=0.005), g["fll_lock"][k])
+            np.testing.assert_equal(li.PLL_Lock_Borre(r[2], r[3], 0.4, alpha=0.005), g["pll_lock"][k])
+            assert li.CN0_Beaulieu(abs(r[0]) * 1e-3 + 1.0, 20, 20e-3, abs(r[1]) * 1e-3) == g["cn0"][k]
+            assert trk.BorreLoopFilter(r[0] * 1e-5, r[1] * 1e-5, g["coeff"][0, 0], g["coeff"][0, 1], 0.001) == \
+                g["borre_filter"][k]
+            assert list(trk.FLLassistedPLL_2ndOrder(r[0] * 1e-6, r[1] * 1e-3, 100.0 / 0.25, 25.0 / 0.53, 1.414, 1e-3,
+                                                    r[2] * 1e-4)) == list(g["fll_pll"][k])
+    for k, (b, z, gain) in enumerate(((2.0, 0.7, 1.0), (1.0, 0.7, 1.0), (8.0, 0.7, 0.25), (15.0, 0.7, 1.5))):
+        assert list(trk.LoopFiltersCoefficients(b, z, gain)) == list(g["coeff"][k])
+    # legacy pieces: the replica known answers captured from the reference's generateReplica (g5), and one tap of
+    # getCorrelator against the oracle's index rule
+    g5 = load_golden("g5_epl.npz")
+    rep, rem = trk.generateReplica(np.arange(0, 6) / 1e7, 5, -1500.0, 0.0)
+    assert np.array_equal(rep, g5["replica_known"]) and rem == float(g5["replica_rem"])
+    rng = np.random.default_rng(5)
+    i_sig, q_sig = rng.normal(size=4001), rng.normal(size=4001)
+    code = orc.pad_code(orc.gold_code(9))
+    idx = orc.epl_indices(4001, 0.1, 0.25575, 0.5)
+    assert trk.getCorrelator(i_sig, q_sig, 0.5, code, 0.1, 0.25575, 4001) == (np.sum(code[idx] * i_sig),
+                                                                            np.sum(code[idx] * q_sig))
+    # third order: collapses onto the second-order arithmetic when the extra terms vanish
+    out3, vel3, acc3 = trk.FLLassistedPLL_3rdOrder(0.01, 0.5, 0.0, 10.0, 1.414, 0.0, 1.414, 1e-3, 0.25, 0.0)
+    assert acc3 == (0.01 * 10.0**3) * 1e-3 and vel3 == (acc3 + 0.0) * 1e-3 and out3 == vel3 + 0.25 + 0.01 * 1.414 * 10.0
+    assert li.CN0_NWPR(30.0, 4.0, 60.0, 2.0) == 10 * np.log10(1e3 * ((900.0 + 16.0) / 62.0 - 1) / (20 - (900.0 + 16.0) / 62.0))
+    assert li.lowPassFilter(2.0, 1.0, 0.25) == 1.25
+
+
 # ------------------------------------------------------------------------------------------------ G6
 BORRE_CFG = dict(correlator_early=-0.5, correlator_prompt=0.0, correlator_late=0.5, dll_damping_ratio=0.7,
                  dll_noise_bandwidth=1.0, dll_loop_gain=1.0, dll_pdi=0.001, pll_damping_ratio=0.7,
