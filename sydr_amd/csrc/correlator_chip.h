@@ -108,7 +108,15 @@ struct ChipBlock {
 // every epoch of the launch, and an epoch that disagrees is flagged and redone per sample).  All four positions
 // somebody reads -- P_KS, P_(KS+1), P_KM, P_(KM+1) -- are then compile-time: they stay in registers, the sample loop
 // is one straight line (no strip stores, no bit tests, no branches) and a lane picks its pair member with selects.
-template <int NT, bool SINGLE_WAVE, int KM = 0, int KS = 0>
+// KI = 1 (with KM > 0): the taps sit whole chips apart -- tap t on chip q + (t - A) for ALL of the anchor's block of
+// chip q (the five taps VE/E/P/L/VL at -1, -0.5, 0, +0.5, +1 chip of BASELINE configs 4-5 on the half-chip view of
+// their replicas: -2 .. +2 half-chips at 24.4 samples per half-chip).  No tap switches inside a block, so the block
+// needs ONE sum (P_M or P_(M+1)), turned by the block-start phasor once and added into every tap with that tap's
+// replica value: two FMAs per tap and block, no strip, no per-tap fixed-point arithmetic.  The host checks the spacing;
+// a block in which the reference's rounding lets a tap switch a sample early or late (only possible within 2^-16 of
+// a sample, where the wave evaluates the reference expression exactly anyway) flags the epoch, which is redone per
+// sample.
+template <int NT, bool SINGLE_WAVE, int KM = 0, int KS = 0, int KI = 0>
 __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ring, int64_t capacity,
                                                      const EpochParams& ep, double dphi, const EpochConsts<NT>& K,
                                                      const uint32_t* lut, double2* strip_lds, double2* rot, int tid,
@@ -146,8 +154,9 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
     // in-block rotations exp(-1j*k*dphi), k = 0..25: one per lane, parked in LDS, read back as broadcasts
     // (KS: the block is summed in two halves of KS + 1 and KM - KS samples that both start at rotation 0, so only
     // k = 1 .. KS + 1 are needed and they fit in scalar registers -- no LDS reads in the sample loop at all)
-    constexpr bool kStatic = KM != 0 && KS != 0;
-    constexpr int kHalf = KS + 1;
+    static_assert(!(KS != 0 && KI != 0), "either the taps switch inside the block (KS) or with it (KI)");
+    constexpr bool kStatic = KM != 0 && (KS != 0 || KI != 0);
+    constexpr int kHalf = KI != 0 ? (KM + 2) / 2 : KS + 1;
     double urc[kStatic ? kHalf + 1 : 1], urs[kStatic ? kHalf + 1 : 1];
     // samples per chip as Q32.32, and the distance to a lane's next block: D or D + 1 samples
     const double two32 = 4294967296.0;
@@ -203,6 +212,8 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
             delta[t] = (uint64_t)d;
             m[t] = (int)(d >> 32);
             bad = bad || (KS != 0 && (m[t] != KS || j != (t < A ? -1 : 0)));   // (KS: the tap sits on chip q - 1 / q at the block start)
+            // (KI: on chip q + (t - A) - 1 and switching at the block's first sample, or on q + (t - A) until its end)
+            bad = bad || (KI != 0 && !((j == (t - A) * KI - 1 && m[t] == 0) || (j == (t - A) * KI && m[t] >= M)));
             evmask |= (1u << m[t]) | (2u << m[t]);
         }
         const int k_last = M + 1;                       // no prefix beyond P_(M+1) is ever read
@@ -235,6 +246,12 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
             for (int t = 0; t < NT; ++t) {
                 split[t] = 0;
                 if (t == A) continue;
+                if constexpr (KI != 0) {
+                    // (the tap's switch IS the block's boundary up to a few units of 2^-32 sample: away from `near` it
+                    // falls on the same sample, so there is nothing to compute)
+                    split[t] = J[t] == (t - A) * KI ? E - S : 0;
+                    continue;
+                }
                 const uint64_t uT = uS + delta[t];
                 near = near || (uint32_t)uT + 0x10000u < 0x20000u;
                 split[t] = (int)(uT >> 32) - S;
@@ -265,6 +282,10 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                 b.ds[t] = 0;
                 if (t == A) continue;
                 const int sp = split[t] > nn ? nn : split[t];
+                if constexpr (KI != 0) {
+                    bad = bad || !(J[t] == (t - A) * KI ? sp == nn : sp == 0);   // on chip q + (t - A) for the whole block
+                    continue;
+                }
                 b.ds[t] = sp - m[t];
                 bad = bad || (unsigned)b.ds[t] > 1u;
             }
@@ -291,10 +312,10 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
         }
         // per-lane LDS addresses: the strip slots of each tap's position m_t, and the lane's replica entry
         const int q_lane = q0 + 1 + lane + SDR_LUT_PAD;
-        // (KS) the lane's own strip slot is not used for running sums: four zero words stand in for the replica of a
+        // (KS / KI) the lane's own strip slots are not used for running sums: eight zero words stand in for the replica of a
         // lane that has no block in a round (the last one)
-        const uint32_t* zero_lq = reinterpret_cast<const uint32_t*>(strip) + 1;
-        if constexpr (kStatic) *strip = make_double2(0.0, 0.0);
+        const uint32_t* zero_lq = reinterpret_cast<const uint32_t*>(strip) + 3;   // (words 1 .. 5 serve entries -2 .. +2)
+        if constexpr (kStatic) strip[0] = strip[1] = make_double2(0.0, 0.0);
 
         auto process = [&](const ChipBlock<NT>& b, int round, double sbk, double cbk) {
             double pr = 0.0, pi = 0.0;
@@ -338,7 +359,7 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                     const int w = (int)b.raw[k >> 1];
                     const double ar = (k & 1) ? (double)(int)(int8_t)(w >> 16) : (double)(int)(int8_t)w;
                     const double ai = (k & 1) ? (double)(w >> 24) : (double)(int)(int8_t)(w >> 8);
-                    if constexpr (k == KS) capr[0] = pr, capi[0] = pi;
+                    if constexpr (KS != 0 && k == KS) capr[0] = pr, capi[0] = pi;
                     if constexpr (k == KM) capr[1] = pr, capi[1] = pi;
                     if constexpr (k == kHalf) capr[2] = pr, capi[2] = pi;          // first half's total
                     if constexpr (j == 0) {
@@ -391,6 +412,18 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                 lq = first + lane <= last_idx ? lut + q_lane + first : zero_lq;
             else
                 lq = lut + q_lane + (first + lane <= last_idx ? first : last_idx - lane);
+            if constexpr (KI != 0) {
+                // every tap sees the whole block on one chip: turn the block's sum once, add it per tap
+                const double xr = __builtin_fma(-sbk, ptot.y, cbk * ptot.x);
+                const double xi = __builtin_fma(sbk, ptot.x, cbk * ptot.y);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const double c = __hiloint2double((int)lq[(t - A) * KI], 0);
+                    accr[t] = __builtin_fma(c, xr, accr[t]);
+                    acci[t] = __builtin_fma(c, xi, acci[t]);
+                }
+                return;
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 double gr, gi;

@@ -35,6 +35,10 @@ namespace {
 using namespace sdr;
 
 constexpr int kWaveThreads = 64;  // one wave per channel-epoch: the ~5 us fixed latency of a workgroup is amortised over 4x more work
+// plan variant word (sdr_epl_plan_variant): low byte = samples a lane owns (0 / 8 / 16 / 26, + 24 when the block length is
+// compiled in), then the compile-time tap geometry
+constexpr int kVariantKS12 = 256 * 12;   // three taps, the outer ones switching 12.x samples into the anchor's block
+constexpr int kVariantKI = 4096;         // taps whole (half-)chips apart: no switch inside a block
 constexpr int kLongLutWords = 4096;  // replicas of 16 KB and more (multi-period / BOC half-chip codes): four epochs share a staged copy
 
 // Dynamic LDS: [red: WPW*2*NT doubles][scratch: strips / rotations][lut: lut_words uint32]
@@ -49,11 +53,14 @@ constexpr int kLongLutWords = 4096;  // replicas of 16 KB and more (multi-period
 #ifndef SDR_EPL_WAVES
 #define SDR_EPL_WAVES 1
 #endif
-template <int FMT, int NT, int W, int KM = 0, int WPW = 1, int KS = 0>
+template <int FMT, int NT, int W, int KM = 0, int WPW = 1, int KS = 0, int KI = 0>
 #ifndef SDR_EPL_KS_WAVES
 #define SDR_EPL_KS_WAVES 3   // (the KS kernel sits at the 168-register cap of three waves per SIMD; two waves: 0.306 instead of 0.286 ms per stream-second)
 #endif
-__global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : SDR_EPL_WAVES)) void epl_kernel(const void* __restrict__ ring, int64_t capacity,
+#ifndef SDR_EPL_KI_WAVES
+#define SDR_EPL_KI_WAVES 1
+#endif
+__global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (KI != 0 ? SDR_EPL_KI_WAVES : SDR_EPL_WAVES))) void epl_kernel(const void* __restrict__ ring, int64_t capacity,
                                                        const sdr_epl_item* __restrict__ items, int n_items, int group_stride,
                                                        const uint32_t* __restrict__ luts,
                                                        int lut_words, int lut_stride,
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : S
     if constexpr (W == kChipMax && FMT == SDR_FMT_CI8) {
         // chip-aligned blocks (correlator_chip.h); an epoch it does not cover is redone per sample
         const bool done = chip_variant_applies(ep, capacity) &&
-                          correlate_epoch_chip<NT, true, KM, KS>(ring, capacity, ep, dphi, K, lut, prefix,
+                          correlate_epoch_chip<NT, true, KM, KS, KI>(ring, capacity, ep, dphi, K, lut, prefix,
                                                          prefix + kThreads * chip_strip_slots<NT>() + wave * kChipMax,
                                                          tid, lane, kWaveThreads, lane, accr, acci);
         if (!done) {
@@ -182,8 +189,14 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
                            doubled ? e->luts2 : e->luts, lut_words, doubled ? e->lut2_stride : e->lut_stride, d_spacing, fs, tap0,
                            n_taps_total, d_out);
     };
+    constexpr bool kOdd = NT == 3 || NT == 5;               // (the compile-time tap geometries exist for these)
+    const bool ki = (wide & kVariantKI) != 0 && FMT == SDR_FMT_CI8 && kOdd;
+    const bool ks = (wide & kVariantKS12) != 0 && FMT == SDR_FMT_CI8 && NT == 3;
+    wide &= 255;
     if (wpw == 4) {
-        if (wide >= kChipMax + 24 && FMT == SDR_FMT_CI8)     // (every epoch with 24 or 25 samples per chip: BOC(1,1) half-chips at 50 MHz)
+        if (ki)                                              // taps whole (half-)chips apart: configs 4-5
+            launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 4, 0, (kOdd ? 1 : 0)>);
+        else if (wide >= kChipMax + 24 && FMT == SDR_FMT_CI8)     // (every epoch with 24 or 25 samples per chip: BOC(1,1) half-chips at 50 MHz)
             launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 4>);
         else if (wide >= kChipMax && FMT == SDR_FMT_CI8)
             launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 0, 4>);
@@ -195,8 +208,10 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
             launch(epl_kernel<FMT, NT, 0, 0, 4>);
         return;
     }
-    if (wide == kChipMax + 24 + 256 * 12 && FMT == SDR_FMT_CI8 && NT == 3)   // ... and both outer taps switching at sample 12 or 13
+    if (ks)                                                  // ... and both outer taps switching at sample 12 or 13
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 1, (NT == 3 ? 12 : 0)>);
+    else if (ki)
+        launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 1, 0, (kOdd ? 1 : 0)>);
     else if (wide >= kChipMax + 24 && FMT == SDR_FMT_CI8)   // chip-aligned, every epoch with 24 or 25 samples per chip
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24>);
     else if (wide == kChipMax && FMT == SDR_FMT_CI8)
@@ -267,6 +282,8 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
     const double s_anchor = scale * spacing[n_taps < 5 ? n_taps / 2 : 2];   // centre tap of the first chunk of taps the kernels serve together
     bool all_m24 = true;
     bool all_s12 = n_taps == 3;   // both outer taps switch chips 12.x samples into the anchor's block (KS = 12 kernel)
+    bool all_ki = n_taps == 3 || n_taps == 5;   // tap t exactly (t - A) chips from the anchor (KI kernel)
+    for (int t = 0; all_ki && t < n_taps; ++t) all_ki = scale * spacing[t] - s_anchor == (double)(t - n_taps / 2);
     for (int i = 0; i < n_items; ++i) {
         const sdr_epl_item& it = items[i];
         // (before anything is derived from them: a zero n_samples or a NaN code_step would be cast to an integer below)
@@ -323,7 +340,8 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
     if (boundary_ok && e->iq_fmt == SDR_FMT_CI8 && min_step >= sdr::kChipMinCodeStep && max_step <= sdr::kChipMaxCodeStep &&
         !e->epl_no_chip)
         *wide = sdr::kChipMax + (all_m24 ? 24 : 0) +
-                ((all_m24 && all_s12 && !e->epl_no_split) ? 256 * 12 : 0);
+                ((all_m24 && all_s12 && !e->epl_no_split) ? kVariantKS12 : 0) +
+                ((all_m24 && all_ki && !e->epl_no_split) ? kVariantKI : 0);
     return SDR_OK;
 }
 

@@ -490,3 +490,59 @@ def test_compile_time_tap_switch_variant_randomised(engine):
             ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(4 * int(slot[k]) + 1)), 25e6, f[k], ph[k], rem[k], step[k], half))
             scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 60.0), 2)
             assert np.max(np.abs(got[k] - ref) / scale) < 1e-9, (rnd, k, step[k], n[k], rem[k], f[k])
+
+
+def test_whole_chip_tap_variant(engine):
+    """Taps whole (half-)chips apart -- the VE/E/P/L/VL set of BASELINE configs 4-5 on the half-chip view of a replica
+    at 50 MHz, or three taps one chip apart at 25 MHz: no tap switches inside the anchor's block, and the plan selects
+    the kernel that has that compiled in (one running sum per block, turned once, two FMAs per tap).  Against the
+    oracle and against the run-time-position kernel: random code Doppler, phases at and next to zero, one to four
+    periods, n = N - 2 .. N + 2, chip switches exactly on samples, short epochs."""
+    rng = np.random.default_rng(20261011)
+    cap = 8 * 240000
+    raw = rng.integers(-128, 128, 2 * cap).astype(np.int8)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(8, 1023, 5)
+    for s in range(8):
+        engine.load_gps_code(s, 4 * s + 1)
+    rf = orc.iq_to_complex(raw)
+    five, three = (-1.0, -0.5, 0.0, 0.5, 1.0), (-1.0, 0.0, 1.0)
+
+    def run(items, spacing, fs, no_split):
+        engine.set_option("epl_no_split_variant", int(no_split))
+        try:
+            plan = engine.epl_plan(items, spacing, fs)
+            plan.run()
+            return plan.variant, plan.fetch()
+        finally:
+            engine.set_option("epl_no_split_variant", 0)
+
+    for fs, spacing, per_hi, want in ((50e6, five, 4, 65536 + 26 + 24 + 4096), (25e6, three, 2, 26 + 24 + 4096),
+                                      (50e6, (-0.5, 0.0, 0.5), 1, 65536 + 26 + 24 + 4096)):
+        n_items = 120
+        step = (1.023e6 + rng.uniform(-12, 12, n_items)) / fs
+        rem = rng.uniform(0, step) * rng.choice([1.0, 1.0, 1e-6, 0.999999], n_items)
+        rem[:2] = [0.5 * step[0], 1e-12]
+        per = rng.integers(1, per_hi + 1, n_items)
+        n = np.ceil((1023 * per - rem) / step).astype(np.int64) + rng.integers(-2, 3, n_items)
+        n[2:6] = [3, 60, 130, 26]
+        start = rng.integers(0, cap - 4 * 60000, n_items)
+        slot = rng.integers(0, 8, n_items)
+        f = rng.uniform(-20000, 20000, n_items) * rng.choice([1.0, 0.0, 200.0], n_items)
+        ph = rng.uniform(-10, 10, n_items)
+        items = make_items(slot, n, start, f, ph, rem, step)
+        v_ki, got = run(items, spacing, fs, False)
+        v_dyn, other = run(items, spacing, fs, True)
+        assert v_ki == want and v_dyn == want - 4096, (v_ki, v_dyn)
+        for k in range(n_items):
+            x = orc.ring_slice(rf, int(start[k]), int(n[k]))
+            ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(4 * int(slot[k]) + 1)), fs, f[k], ph[k], rem[k], step[k],
+                                   spacing))
+            scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 60.0), 2)
+            assert np.max(np.abs(got[k] - ref) / scale) < 1e-9, (fs, k, step[k], n[k], rem[k], f[k])
+            assert np.max(np.abs(other[k] - ref) / scale) < 1e-9, (fs, k)
+    # a spacing that is not a whole number of (half-)chips keeps the run-time-position kernel
+    items = make_items(0, 50000, 100, 1000.0, 0.3, 0.01, 1.023e6 / 50e6)
+    v, _ = run(items, (-1.0, -0.4, 0.0, 0.4, 1.0), 50e6, False)
+    assert v == 65536 + 26 + 24
