@@ -276,6 +276,29 @@ __device__ __forceinline__ void compute_constants(EpochConsts<NT>& k, const Epoc
     }
 }
 
+// Only the np.linspace constants of the taps (what the chip-aligned core reads of EpochConsts): no rotations, no
+// sincos -- the per-sample rotations are evaluated where an epoch actually falls back to the per-sample core.
+template <int NT>
+__device__ __forceinline__ void compute_tap_constants(EpochConsts<NT>& k, const EpochParams& ep,
+                                                      const double* __restrict__ spacing) {
+    const int lane = threadIdx.x & 63;
+    const int t = lane < NT ? lane : NT - 1;
+    const double nd = (double)ep.n;
+    const double shift = ep.rem_code + spacing[t];  // reference arithmetic, operation for operation
+    double stop = ep.code_step * nd;
+    stop = stop + shift;
+    const double delta = stop - shift;
+    const double step = delta / nd;
+    const double r0 = __builtin_amdgcn_rcp(step);
+    const double inv = __builtin_fma(__builtin_fma(-step, r0, 1.0), r0, r0);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        k.shift[q] = lane_value(shift, q);
+        k.step[q] = lane_value(step, q);
+        k.inv_step[q] = lane_value(inv, q);
+    }
+}
+
 // Correlate this lane's share (groups lane, lane+stride, ...) of one epoch; `lane` is the index among
 // the `stride` lanes that share the epoch.  edge_lane = 0..63 in the ONE wave that also takes the
 // epoch's edge samples, -1 elsewhere.  accr/acci[NT] receive the lane-partial fp64 accumulators.

@@ -78,6 +78,27 @@ __device__ __forceinline__ int wave_min_i32(int x) {
     return __builtin_amdgcn_readfirstlane(x);
 }
 
+// int8 -> fp64 in ONE instruction, with a known offset.  v_perm_b32 drops a sample byte (sign bit flipped: u = x + 128)
+// into bits 8..15 of the high word 0x40B0_0000 of a double whose low word is zero: that double is 4096 + u = 4224 + x,
+// exactly.  The straight-line kernels mix THESE into their running sums (against 2 instructions for
+// v_bfe_i32 + v_cvt_f64_i32: the conversion was half of the 8-instruction floor per sample) and take the offset's share
+// 4224 * (1 + 1j) * sum_k r_k out where a sum is read: the in-block rotations r_k are per-epoch constants, so that share
+// is three complex scalars per epoch.  The running sums carry ~2^16 instead of ~2^9 while a half block is summed, i.e. their
+// roundings are ~2^7 larger: ~1e-13 relative on an epoch's accumulators (measured; the bar is 1e-6).
+#ifndef SDR_BIASED_CVT
+#define SDR_BIASED_CVT 1
+#endif
+constexpr double kCvtBias = 4224.0;
+// The double lives in a register PAIR whose low word stays zero for the whole epoch: only the high word is rewritten
+// (built from a fresh zero each time, the compiler spends a v_mov on every low word and nothing is gained).
+typedef uint32_t sdr_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double biased_sample(sdr_u32x2& pair, uint32_t w_flipped, uint32_t selector, uint32_t hi_const) {
+    pair.y = __builtin_amdgcn_perm(w_flipped, hi_const, selector);
+    return __builtin_bit_cast(double, pair);
+}
+// selector of v_perm_b32 for byte `byte` of the sample dword: result = [0x40][0xB0][that byte][0x00]
+constexpr uint32_t cvt_selector(int byte) { return 0x03020000u | ((uint32_t)(4 + byte) << 8) | 0x0Cu; }
+
 // One lane's block, prepared one round ahead of its use (its loads are in flight while the previous block computes).
 template <int NT>
 struct ChipBlock {
@@ -158,6 +179,7 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
     constexpr bool kStatic = KM != 0 && (KS != 0 || KI != 0);
     constexpr int kHalf = KI != 0 ? (KM + 2) / 2 : KS + 1;
     double urc[kStatic ? kHalf + 1 : 1], urs[kStatic ? kHalf + 1 : 1];
+    double biasc[3] = {0.0, 0.0, 0.0}, biass[3] = {0.0, 0.0, 0.0};   // (biased conversion) the offset's share of a sum of kHalf - 2 / - 1 / - 0 samples
     // samples per chip as Q32.32, and the distance to a lane's next block: D or D + 1 samples
     const double two32 = 4294967296.0;
     const int64_t Tfx = (int64_t)rint(inv_step[A] * two32);
@@ -175,6 +197,28 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
             for (int k = 1; k <= kHalf; ++k) urc[k] = lane_value(cs, k), urs[k] = lane_value(sn, k);
             rd0c = lane_value(cs, 32), rd0s = lane_value(sn, 32);
             rd1c = lane_value(cs, 33), rd1s = lane_value(sn, 33);
+            if constexpr (SDR_BIASED_CVT) {
+                // B_n = 4224 * (1 + 1j) * sum_{k < n} exp(-1j*k*dphi): inclusive prefix sums over lanes 0 .. 15 (one DPP row)
+                double pc = cs, psn = sn;
+                auto shifted = [](double v, auto ctrl) {      // the value `ctrl` lanes to the left in the row of 16, 0.0 beyond its start
+                    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), decltype(ctrl)::value, 0xf, 0xf, false);
+                    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), decltype(ctrl)::value, 0xf, 0xf, false);
+                    return __hiloint2double(hi, lo);
+                };
+                static_for<0, 4>([&](auto st) {               // row_shr:1, 2, 4, 8
+                    constexpr int ctrl = 0x110 + (1 << decltype(st)::value);
+                    pc += shifted(pc, std::integral_constant<int, ctrl>{});
+                    psn += shifted(psn, std::integral_constant<int, ctrl>{});
+                });
+                // (both components of a sample carry the offset: its share of a sum is 4224 * (1 + 1j) * sum r_k)
+                {
+                    const double re = pc - psn, im = pc + psn;
+                    pc = re * kCvtBias, psn = im * kCvtBias;
+                }
+                biasc[0] = lane_value(pc, kHalf - 3), biass[0] = lane_value(psn, kHalf - 3);   // n = kHalf - 2
+                biasc[1] = lane_value(pc, kHalf - 2), biass[1] = lane_value(psn, kHalf - 2);   // n = kHalf - 1
+                biasc[2] = lane_value(pc, kHalf - 1), biass[2] = lane_value(psn, kHalf - 1);   // n = kHalf
+            }
         } else if (wlane < kChipMax) {
             sincos_reduced(-(double)wlane * dphi_u, &sn, &cs);
             rot[wlane] = make_double2(cs, sn);
@@ -317,6 +361,9 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
         const uint32_t* zero_lq = reinterpret_cast<const uint32_t*>(strip) + 3;   // (words 1 .. 5 serve entries -2 .. +2)
         if constexpr (kStatic) strip[0] = strip[1] = make_double2(0.0, 0.0);
 
+        sdr_u32x2 zI = {0u, 0u}, zQ = {0u, 0u};     // (biased conversion) the two register pairs the samples are built in
+        asm volatile("" : "+v"(zI), "+v"(zQ));
+
         auto process = [&](const ChipBlock<NT>& b, int round, double sbk, double cbk) {
             double pr = 0.0, pi = 0.0;
             double2* wp = strip;
@@ -353,12 +400,27 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                 static_assert(2 * kHalf >= KM + 1 && kHalf < KM, "two halves of at most KS + 1 samples cover the block");
                 // first half: samples 0 .. KS (P_KS is its running sum before the last one, P_(KS+1) its total);
                 // second half: samples KS+1 .. KM summed from rotation 0 again, turned by exp(-1j*(KS+1)*dphi) where read
+                static_assert(!SDR_BIASED_CVT || (KM - kHalf == kHalf - 2 && (KS == 0 || KS == kHalf - 1)),
+                              "the offset's shares are kept for sums of kHalf - 2, kHalf - 1 and kHalf samples");
+                uint32_t flipped[kChipRawDwords];
+                uint32_t hi_const = 0x40B00000u;
+                if constexpr (SDR_BIASED_CVT) {
+                    asm volatile("" : "+v"(hi_const));             // (v_perm_b32 takes one scalar operand: the selector)
+#pragma unroll
+                    for (int i = 0; i < kChipRawDwords; ++i) flipped[i] = b.raw[i] ^ 0x80808080u;
+                }
                 static_for<0, KM + 1>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     constexpr int j = k < kHalf ? k : k - kHalf;
                     const int w = (int)b.raw[k >> 1];
-                    const double ar = (k & 1) ? (double)(int)(int8_t)(w >> 16) : (double)(int)(int8_t)w;
-                    const double ai = (k & 1) ? (double)(w >> 24) : (double)(int)(int8_t)(w >> 8);
+                    double ar, ai;
+                    if constexpr (SDR_BIASED_CVT) {
+                        ar = biased_sample(zI, flipped[k >> 1], cvt_selector((k & 1) ? 2 : 0), hi_const);
+                        ai = biased_sample(zQ, flipped[k >> 1], cvt_selector((k & 1) ? 3 : 1), hi_const);
+                    } else {
+                        ar = (k & 1) ? (double)(int)(int8_t)(w >> 16) : (double)(int)(int8_t)w;
+                        ai = (k & 1) ? (double)(w >> 24) : (double)(int)(int8_t)(w >> 8);
+                    }
                     if constexpr (KS != 0 && k == KS) capr[0] = pr, capi[0] = pi;
                     if constexpr (k == KM) capr[1] = pr, capi[1] = pi;
                     if constexpr (k == kHalf) capr[2] = pr, capi[2] = pi;          // first half's total
@@ -368,6 +430,10 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                         pr = __builtin_fma(-ai, urs[j], __builtin_fma(ar, urc[j], pr));
                         pi = __builtin_fma(ai, urc[j], __builtin_fma(ar, urs[j], pi));
                     }
+                    // (an opaque point per sample: the sums must have read the pairs before their high words are written
+                    // again, and the next sample must be built on THESE registers -- seen through, every sample would be
+                    // rebuilt from the original pair, i.e. from a copy of its low word)
+                    if constexpr (SDR_BIASED_CVT) asm volatile("" : "+v"(pr), "+v"(pi), "+v"(zI), "+v"(zQ));
                 });
             } else if constexpr (KM != 0) {
                 // positions KM and KM + 1 are always events; the others (the taps' m_t, m_t + 1 < KM) are looked for
@@ -399,6 +465,14 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                 }
             }
             double2 ptot;
+            if constexpr (kStatic && SDR_BIASED_CVT) {
+                // what the offset of 4224 per sample put into each sum that is read (its first sample has rotation 1:
+                // the sums start from the biased sample itself, and sum_{k<n} r_k includes that r_0 = 1)
+                pr -= biasc[1], pi -= biass[1];                    // second half, KM + 1 - kHalf = kHalf - 1 samples
+                capr[1] -= biasc[0], capi[1] -= biass[0];          // ... before its last sample
+                capr[2] -= biasc[2], capi[2] -= biass[2];          // first half: kHalf samples
+                if constexpr (KS != 0) capr[0] -= biasc[1], capi[0] -= biass[1];   // P_KS: kHalf - 1 samples
+            }
             if constexpr (kStatic) {
                 const double qr = b.dn ? pr : capr[1], qi = b.dn ? pi : capi[1];   // second half up to M or M + 1 samples
                 ptot.x = __builtin_fma(-qi, urs[kHalf], __builtin_fma(qr, urc[kHalf], capr[2]));

@@ -99,7 +99,10 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (
     ep.rem_code = it.rem_code;
     ep.code_step = it.code_step;
     EpochConsts<NT> K;
-    compute_constants<NT>(K, ep, spacing + tap0, dphi, kWaveThreads);
+    if constexpr (W == kChipMax && FMT == SDR_FMT_CI8)
+        compute_tap_constants<NT>(K, ep, spacing + tap0);   // (the chip-aligned core evaluates its own rotations)
+    else
+        compute_constants<NT>(K, ep, spacing + tap0, dphi, kWaveThreads);
     __syncthreads();  // replica staged
     if (WPW > 1 && !have) return;
 
