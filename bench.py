@@ -38,6 +38,7 @@ SPACING = (-0.5, 0.0, 0.5)
 CODE_RATE = 1.023e6
 L1 = 1575.42e6
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VERIFY_PER_RANK = 4     # N > 1: channels of every other rank that rank 0 recomputes on its own GPU and compares bitwise
 
 
 def satellites(n_total=N_CH, seed=20260003):
@@ -151,11 +152,209 @@ def cpu_baseline_all_cores(raw, items, prns, n_epochs, budget_s):
     return ch_samples / N_CH / dt / 1e6, procs, dt, epochs
 
 
-def per_tick_leg(eng):
-    """ChannelManager.addNewRFData(1 ms) + run() from Python, 32 channels (tools/per_tick_rate.py)."""
+def kernel_of_variant(variant, n_taps, waves_per_group=1):
+    """Name of the epl_kernel instantiation a plan of this variant launches on a ci8 ring, as tools/summarize_pmc.py
+    spells it -- the key that ties committed counters (profiles/pmc_traffic.json) to the kernel a run actually used."""
+    w = variant & 255
+    km = 24 if w >= 50 else 0
+    ks = 12 if (variant & 0xF00) == 0xC00 else 0
+    ki = 1 if variant & 4096 else 0
+    base = 26 if w >= 26 else w
+    return f"epl_kernel<0,{n_taps},{base},{km},{waves_per_group},{ks},{ki}>"
+
+
+def device_identity(torch, local_rank):
+    """What tells two GPUs apart: PCI location and UUID of this rank's device, plus host and process."""
+    import socket
+    p = torch.cuda.get_device_properties(local_rank)
+    ident = {"host": socket.gethostname(), "pid": os.getpid(), "local_rank": int(local_rank), "name": p.name}
+    for key in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+        if hasattr(p, key):
+            ident[key] = str(getattr(p, key))
+    return ident
+
+
+def channel_digests(got, n_ch):
+    """sha256 of every channel's accumulators over the whole pass (epoch-major list: channel c = rows c, c + n_ch, ...)."""
+    import hashlib
+    return [hashlib.sha256(np.ascontiguousarray(got[c::n_ch]).tobytes()).hexdigest() for c in range(n_ch)]
+
+
+def verify_across_ranks(eng, dist, torch, rank, local_rank, world, all_sats, mine, got, total, elapsed_own, ch_samples):
+    """"per-channel outputs at 2/4/8 GPUs must be bitwise identical to 1 GPU".  Every rank hashes what its
+    kernel wrote for each of its channels; rank 0 tracks VERIFY_PER_RANK channels of every OTHER rank again on its own
+    GPU (same stream, same items) and compares the hashes.  Returns the `multi_gpu` record; any mismatch ends the job
+    with a non-zero exit on every rank."""
+    from sydr_amd.channel.manager import shard_channels
+    mine_digests = channel_digests(got, N_CH)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, {"rank": rank, "device": device_identity(torch, local_rank), "channels": list(mine),
+                                      "digests": mine_digests, "ms_per_pass": elapsed_own,
+                                      "Msamples_per_s": ch_samples / N_CH / max(elapsed_own, 1e-12) / 1e6})
+    verdict = {"ok": True, "mismatches": []}
+    record = None
+    if rank == 0:
+        checked = []
+        for info in gathered:
+            r = info["rank"]
+            if r == 0:
+                continue
+            theirs = shard_channels(len(all_sats), r, world)
+            assert theirs == info["channels"], "ranks disagree about the sharding"
+            pick = sorted(set(int(round(x)) for x in np.linspace(0, len(theirs) - 1, VERIFY_PER_RANK)))
+            sats = [all_sats[theirs[i]] for i in pick]
+            for k, sat in enumerate(sats):
+                eng.load_gps_code(N_CH + k, sat["prn"])
+            items, _ = truth_items(sats, FS, total)
+            items["code_slot"] += N_CH                     # (truth_items numbers its slots from 0: these live in the spare ones)
+            plan = eng.epl_plan(items, SPACING, FS)
+            plan.run()
+            again = channel_digests(plan.fetch(), len(sats))
+            plan.close()
+            for k, i in enumerate(pick):
+                same = again[k] == info["digests"][i]
+                checked.append([r, theirs[i], bool(same)])
+                if not same:
+                    verdict["ok"] = False
+                    verdict["mismatches"].append({"rank": r, "channel": theirs[i]})
+        devices = [g["device"] for g in gathered]
+        distinct = len({(d["host"], d.get("uuid"), d.get("pci_bus_id"), d.get("pci_domain_id")) for d in devices})
+        record = {"ranks_seen": len(gathered), "distinct_devices": distinct, "devices": devices,
+                  "per_rank_ms_per_step": [g["ms_per_pass"] * 1e3 for g in gathered],
+                  "per_rank_Msamples_per_s": [g["Msamples_per_s"] for g in gathered],
+                  "channels_recomputed_on_rank0": checked, "bitwise_identical": verdict["ok"],
+                  "check": f"rank 0 re-tracked {VERIFY_PER_RANK} channels of every other rank over the whole stream on its "
+                           "own GPU; sha256 of the fp64 accumulators equal"}
+    box = [verdict]
+    dist.broadcast_object_list(box, src=0)
+    if not box[0]["ok"]:
+        if rank == 0:
+            print(json.dumps({"error": "per-channel outputs differ between ranks", "mismatches": box[0]["mismatches"]}),
+                  file=sys.stderr)
+        dist.destroy_process_group()
+        raise SystemExit(3)
+    return record
+
+
+def ref_config_leg(eng, cpu_seconds=4.0):
+    """The reference's own shipped configuration (config/receiver.ini:18-20: 10 MHz, 8-bit I/Q;
+    config/channels/channel_GPS_L1CA_kaplan.ini:6-10: PCPS with a 300 Hz grid, 1 x 10 ms non-coherent; taps +-0.5 chip),
+    32 channels: tracking throughput (the 8-sample boundary variant of the correlator serves this rate) and
+    acquisition time, each with its roofline by algorithmic bytes, the oracle timed beside it and checked against it."""
+    from oracle import sydr_oracle as orc
+    from sydr_amd.engine import FMT_CI8
+    fs, seconds = 10e6, 20.0
+    total = int(seconds * fs) // 8 * 8
+    eng.iq_alloc(total, FMT_CI8)
+    eng.code_slots(N_CH)
+    sats = satellites(N_CH, seed=20260010)
+    for k, sat in enumerate(sats):
+        eng.load_gps_code(k, sat["prn"])
+    eng.iq_synth(sats, fs, 12.0, 20260010, 0, total)
+    items, n_epochs = truth_items(sats, fs, total)
+    plan = eng.epl_plan(items, SPACING, fs)
+    n_run = n_epochs * N_CH
+    for _ in range(3):
+        plan.run(0, n_run)
+    eng.sync()
+    eng.prof_reset()
+    eng.prof_enable(True)
+    steps = 10
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.run(0, n_run)
+    eng.sync()
+    wall = time.perf_counter() - t0
+    eng.prof_enable(False)
+    kern_ms, launches = eng.prof_read("epl_kernel")
+    eng.prof_reset()
+    ch_samples = float(items["n_samples"][:n_run].sum())
+    avg_s = kern_ms / max(1, launches) * 1e-3
+    got = plan.fetch()
+    variant = plan.variant
+    plan.close()
+    # oracle: check + CPU baseline on the first epochs of the same stream
+    n_chk = N_CH * 4
+    hi = int((items["start_sample"][:n_chk] + items["n_samples"][:n_chk]).max())
+    rf = orc.iq_to_complex(eng.iq_download(max(hi, int(10 * fs * 1e-3)), 0))
+    codes = [orc.pad_code(orc.gold_code(s["prn"])) for s in sats]
+    done, t0 = 0, time.perf_counter()
+    err = 0.0
+    for k in range(len(items)):
+        it = items[k]
+        a, n = int(it["start_sample"]), int(it["n_samples"])
+        if a + n > len(rf):
+            break
+        ref = np.array(orc.epl(rf[a:a + n], codes[int(it["code_slot"])], fs, float(it["carrier_hz"]), float(it["rem_carrier"]),
+                               float(it["rem_code"]), float(it["code_step"]), SPACING))
+        scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), 1.0), 2)
+        err = max(err, float(np.max(np.abs(got[k] - ref) / scale)))
+        done = k + 1
+        if done >= n_chk and (time.perf_counter() - t0 > cpu_seconds or done >= N_CH * 200):
+            break
+    cpu_dt = time.perf_counter() - t0
+    if err > 1e-6:
+        raise SystemExit(f"GPU/oracle mismatch in the ref_config tracking leg: {err:.3e}")
+    tracking = {"metric": "IQ Msamples/s through 32-ch E/P/L correlators @10 MHz fs", "value": ch_samples * steps / N_CH / wall / 1e6,
+                "unit": "Msamples/s", "x_realtime": ch_samples * steps / N_CH / wall / fs, "ms_per_pass": wall / steps * 1e3,
+                "kernel_variant": kernel_of_variant(variant, len(SPACING)),
+                "roofline": {"bound": "hbm", "achieved": 2.0 * ch_samples / avg_s / 1e9 if launches else 0.0, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": 2.0 * ch_samples / avg_s / 1e9 / HBM_PEAK_GBS if launches else 0.0,
+                             "traffic": None, "kernel": "epl_kernel", "avg_launch_ms": avg_s * 1e3, "launches": int(launches),
+                             "algorithmic_bytes_per_launch": 2.0 * ch_samples},
+                "cpu_baseline": {"value": float(items["n_samples"][:done].sum()) / N_CH / cpu_dt / 1e6, "unit": "Msamples/s",
+                                 "cores": 1, "kind": "port", "sample": f"first {done} channel-epochs of the same stream "
+                                 f"through oracle/sydr_oracle.py:epl, {cpu_dt:.1f} s", "max_rel_err_gpu_vs_oracle": err}}
+    # acquisition as the shipped ini asks for it: +-5 kHz @ 300 Hz (34 bins), 1 ms coherent x 10 non-coherent
+    slots = np.arange(N_CH)
+    rng_hz, step_hz, coh, noncoh = 5000.0, 300.0, 1, 10
+    for _ in range(10):
+        eng.pcps(slots, 0, fs, 0.0, rng_hz, step_hz, coh, noncoh)
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pb, pc, pr, _ = eng.pcps(slots, 0, fs, 0.0, rng_hz, step_hz, coh, noncoh)
+    acq_ms = (time.perf_counter() - t0) / reps * 1e3
+    eng.prof_reset()
+    eng.prof_enable(True)
+    for _ in range(reps):
+        eng.pcps(slots, 0, fs, 0.0, rng_hz, step_hz, coh, noncoh)
+    eng.prof_enable(False)
+    pk_ms, _ = eng.prof_read("pcps")
+    pk_ms /= reps
+    eng.prof_reset()
+    n_code, bins = 10000, len(orc.doppler_bins(rng_hz, step_hz))
+    t0 = time.perf_counter()
+    ok = True
+    for k in range(2):
+        cmap = orc.pcps_map(rf[:n_code * coh * noncoh].reshape(1, -1), 0.0, fs, orc.code_spectrum(orc.gold_code(sats[k]["prn"]), fs),
+                            rng_hz, step_hz, n_code, coh, noncoh)
+        peak, ratio = orc.two_peak_compare(cmap, n_code, round(fs / CODE_RATE))
+        ok &= peak == [int(pb[k]), int(pc[k])] and abs(ratio - pr[k]) <= 1e-6 * ratio
+    cpu_ms = (time.perf_counter() - t0) / 2 * 1e3
+    if not ok:
+        raise SystemExit("PCPS peak mismatch vs oracle in the ref_config leg")
+    # SURVEY 8d per (PRN, bin) and millisecond block: 16 spectrum + 16 code spectrum + 8 of the map that accumulates the blocks
+    algo = N_CH * bins * noncoh * 40.0 * n_code
+    acquisition = {"metric": "acquisition ms/PRN", "value": acq_ms / N_CH, "unit": "ms/PRN", "ms_total_32_prn": acq_ms,
+                   "kernel_ms_32_prn": pk_ms, "cpu_ms_per_prn_1core": cpu_ms, "peaks_match_oracle": bool(ok),
+                   "roofline": {"bound": "hbm", "achieved": algo / (pk_ms * 1e-3) / 1e9 if pk_ms else 0.0, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": algo / (pk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pk_ms else 0.0, "traffic": None,
+                                "kernel": "pcps_* (all kernels of one sdr_pcps call)", "algorithmic_bytes_per_call": algo},
+                   "cpu_baseline": {"value": cpu_ms, "unit": "ms/PRN", "cores": 1, "kind": "port",
+                                    "sample": "2 PRNs x 34 bins x 10 blocks through oracle/sydr_oracle.py:pcps_map"}}
+    return {"config": {"workload": "the reference's shipped configuration: fs=10 MHz ci8 (config/receiver.ini:18-20), 32 channels, "
+                                   "E/P/L +-0.5 chip, 20 s stream in one launch per pass; PCPS +-5 kHz @ 300 Hz (34 bins), "
+                                   "1 ms x 10 non-coherent (channel_GPS_L1CA_kaplan.ini:6-10), code spectra cached between calls"},
+            "tracking": tracking, "acquisition": acquisition}
+
+
+def per_tick_leg(eng, read_ahead=0):
+    """ChannelManager.addNewRFData(1 ms) + run() from Python, 32 channels (tools/per_tick_rate.py); read_ahead: the same
+    calls with ChannelManager.enableReadAhead (blocks of epochs computed ahead and handed out tick by tick)."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import per_tick_rate
-    return per_tick_rate.measure(300, N_CH, engine=eng)
+    return per_tick_rate.measure(600 if read_ahead else 300, N_CH, engine=eng, read_ahead=read_ahead)
 
 
 def closed_loop_leg(eng, items, n_epochs, n_ch=N_CH):
@@ -323,6 +522,22 @@ def multignss_workload(args, rank, local_rank, world, torch, dist, eng=None, emi
               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "epl_kernel",
                            "avg_launch_ms": kern_ms / max(1, launches), "launches": int(launches)}}
+    pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc) and launches:
+        try:
+            info = json.load(open(pmc))
+            ran = [kernel_of_variant(pl.variant, 5, 4) for pl, *_ in plans]
+            result["roofline"]["kernel_variant"] = ran[0] if len(set(ran)) == 1 else ran
+            if info.get("multignss_hbm_bytes_per_wave") and all(r == info.get("multignss_kernel", "").replace(" ", "") for r in ran):
+                waves_per_launch = sum(n_avail * per_step * n_ch for _, n_ch, _, _ in plans) / len(plans)
+                traffic = info["multignss_hbm_bytes_per_wave"] * waves_per_launch
+                result["roofline"].update({"traffic": traffic, "traffic_GBps": traffic / (kern_ms / launches * 1e-3) / 1e9,
+                                           "traffic_source": {"file": info.get("source"), "git_head": info.get("git_head")}})
+            elif info.get("multignss_kernel"):
+                result["roofline"]["traffic_note"] = (f"profiles/pmc_traffic.json holds counters of {info['multignss_kernel']!r}, "
+                                                      f"this run launched {ran!r}: no traffic figure")
+        except Exception:
+            pass
     if rank == 0 and world == 1:
         from oracle import sydr_oracle as orc
         got = plans[1][0].fetch()
@@ -410,8 +625,8 @@ def main():
     ap.add_argument("--workload", choices=["l1ca32", "multignss"], default="l1ca32",
                     help="l1ca32 = BASELINE configs[2] (headline); multignss = configs[3]/[4] geometry")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=120)        # (~2 s of timed region at 16.6 ms per pass: the GPU shows up in smi samples)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--stream-seconds", type=float, default=60.0)
     ap.add_argument("--launch-seconds", type=float, default=0.0,
                     help="seconds of stream per E/P/L launch (0 = the whole stream in one launch)")
@@ -420,6 +635,7 @@ def main():
     ap.add_argument("--no-closed-loop", action="store_true")
     ap.add_argument("--no-per-tick", action="store_true")
     ap.add_argument("--no-multignss", action="store_true")
+    ap.add_argument("--no-ref-config", action="store_true")
     ap.add_argument("--cpu-mp-seconds", type=float, default=10.0, help="budget of the all-cores CPU baseline (0: skip)")
     ap.add_argument("--closed-loop-epochs", type=int, default=2000)
     args = ap.parse_args()
@@ -461,7 +677,7 @@ def main():
     eng = Engine(local_rank)
     total = int(args.stream_seconds * FS) // 8 * 8
     eng.iq_alloc(total, FMT_CI8)
-    eng.code_slots(N_CH)
+    eng.code_slots(N_CH + VERIFY_PER_RANK)                  # (+ spare slots: rank 0 re-tracks other ranks' channels)
     n_total = N_CH * world
     all_sats = satellites(n_total)                          # the same stream on every rank ...
     mine = shard_channels(n_total, rank, world)             # ... of which this rank tracks its 32 channels
@@ -470,26 +686,24 @@ def main():
         eng.load_gps_code(s, sat["prn"])
     eng.iq_synth(all_sats, FS, 12.0, 20260003, 0, total)
     items, n_epochs = truth_items(sats, FS, total)
-    epochs_per_step = 1000
-    n_steps_avail = max(1, n_epochs // epochs_per_step)
-    per_step = epochs_per_step * N_CH if n_epochs >= epochs_per_step else n_epochs * N_CH
     plan = eng.epl_plan(items, SPACING, FS)
-    step_samples = [int(items["n_samples"][k * per_step:(k + 1) * per_step].sum()) for k in range(n_steps_avail)]
+    n_run = n_epochs * N_CH                                 # every whole code period of the stream, every channel
+    pass_samples = int(items["n_samples"][:n_run].sum())
     batch_stream = eng.stream_create()                      # one HIP stream per channel batch (north_star)
 
-    # One step = one pass of the correlators over the WHOLE stream (configs[2]: 60 s), as n_steps_avail launches of one
-    # second each (32 000 channel-epochs per launch).  A step of one launch (0.3 ms) would put the driver's whole timed
-    # region inside the ~40 ms the chip takes to settle its clocks under this kernel (tools/epl_ramp.py: 0.37 ms per
-    # launch falling to 0.31 over the first ~100 launches, whatever ran before).
-    # The pass is ONE launch by default (1.9 M single-wave workgroups at 60 s): every launch ends with a partial round
-    # of workgroups on the 3072 resident slots, and launches of one second each cost 4 % more per second of stream
-    # (tools/epl_launch_size.py); --launch-seconds picks smaller launches.
-    secs_per_launch = n_steps_avail if args.launch_seconds <= 0 else max(1, min(n_steps_avail, int(args.launch_seconds)))
-    launch_starts = list(range(0, n_steps_avail, secs_per_launch))
+    # One step = one pass of the correlators over the WHOLE stream (configs[2]: 60 s): every whole code period of every
+    # channel (59 998 epochs x 32 at 60 s).  A step of one second (0.3 ms) would put the driver's whole timed region inside
+    # the ~40 ms the chip takes to settle its clocks under this kernel (tools/epl_ramp.py: 0.37 ms per launch falling to
+    # 0.31 over the first ~100 launches, whatever ran before).  The pass is ONE launch by default (1.9 M single-wave
+    # workgroups): every launch ends with a partial round of workgroups on the 3072 resident slots, and launches of one
+    # second each cost 4 % more per second of stream (tools/epl_launch_size.py); --launch-seconds picks smaller launches.
+    per_launch = n_run if args.launch_seconds <= 0 else max(N_CH, int(args.launch_seconds * 1000) * N_CH)
+    launch_starts = list(range(0, n_run, per_launch))
+    secs_per_launch = per_launch / N_CH / 1000.0
 
     def run_step(k):
         for j in launch_starts:
-            plan.run(j * per_step, min(secs_per_launch, n_steps_avail - j) * per_step, stream=batch_stream)
+            plan.run(j, min(per_launch, n_run - j), stream=batch_stream)
 
     def barrier():
         eng.stream_sync(batch_stream)
@@ -508,8 +722,8 @@ def main():
         run_step(k)
     eng.stream_sync(batch_stream)
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ch_samples = sum(step_samples) * args.steps              # channel-samples, this rank
+    elapsed = elapsed_own = time.perf_counter() - t0
+    ch_samples = pass_samples * args.steps                   # channel-samples, this rank
     n_launches = len(launch_starts) * args.steps
     job_ch_samples = float(ch_samples)
     if world > 1:
@@ -523,6 +737,10 @@ def main():
     eng.prof_enable(False)
     kern_ms, launches = eng.prof_read("epl_kernel")
     eng.prof_reset()
+    multi_gpu = None
+    if world > 1:
+        multi_gpu = verify_across_ranks(eng, dist, torch, rank, local_rank, world, all_sats, mine, plan.fetch()[:n_run], total,
+                                        elapsed_own / args.steps, ch_samples / args.steps)
 
     stream_samples = ch_samples / N_CH                       # samples of THE stream consumed per rank (same on all)
     value = job_ch_samples / N_CH / elapsed / 1e6            # the job's channel-samples, in units of 32-channel batches
@@ -538,14 +756,15 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "GPS L1 C/A tracking, 32 channels/GPU, E/P/L (3 taps), fs=25 MHz, 1 ms integration, "
                                f"{args.stream_seconds:g} s synthetic ci8 IQ stream, 1 step = one pass over the whole "
-                               f"stream = {len(launch_starts)} launch(es) of {secs_per_launch} s "
-                               f"({secs_per_launch * 32000} channel-epochs) each",
+                               f"stream ({n_epochs} epochs x {N_CH} channels) = {len(launch_starts)} launch(es) of "
+                               f"{min(per_launch, n_run)} channel-epochs",
                    "channels_per_gpu": N_CH, "channels_total": n_total, "fs_hz": FS, "taps": len(SPACING), "iq_format": "ci8",
-                   "mode": f"open-loop batched (true NCO trajectory, {secs_per_launch * 32000} channel-epochs per launch)",
+                   "mode": f"open-loop batched (true NCO trajectory, {min(per_launch, n_run)} channel-epochs per launch)",
                    "sharding": f"one stream of {n_total} satellites replicated on {world} GPU(s) (same seed), channels "
                                f"sharded {N_CH} per GPU, one HIP stream per channel batch, no collective"},
         "x_realtime": stream_samples / elapsed / FS,          # seconds of THE stream (all channels tracked) per second
         "channel_Msamples_per_s": job_ch_samples / elapsed / 1e6,
+        "multi_gpu": multi_gpu,                               # N > 1: who took part, per-rank rates, cross-rank bitwise check
     }
     result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "epl_kernel",
@@ -560,6 +779,15 @@ def main():
         try:
             info = json.load(open(pmc))
             epochs_per_launch = ch_samples / max(1, n_launches) * len(items) / max(1.0, float(items["n_samples"].sum()))
+            ran = kernel_of_variant(plan.variant, len(SPACING))
+            result["roofline"]["kernel_variant"] = ran
+            if info.get("epl_kernel", "").replace(" ", "") != ran:
+                # the committed counters were taken on another instantiation: they say nothing about this run
+                result["roofline"]["traffic_note"] = (f"profiles/pmc_traffic.json holds counters of {info.get('epl_kernel')!r}, "
+                                                      f"this run launched {ran!r}: no traffic figure")
+                info = {}
+            else:
+                result["roofline"]["traffic_source"] = {"file": info.get("source"), "git_head": info.get("git_head")}
             if info.get("epl_kernel_hbm_bytes_per_epoch"):   # counters are per channel-epoch (one workgroup each), scaled to this launch size
                 result["roofline"]["traffic"] = info["epl_kernel_hbm_bytes_per_epoch"] * epochs_per_launch
                 # the same bytes as a rate: what the memory system actually moves (the 32 channels share the stream
@@ -609,6 +837,9 @@ def main():
     plan.close()
     if rank == 0 and world == 1 and not args.no_per_tick:
         result["per_tick"] = per_tick_leg(eng)
+        result["per_tick_readahead"] = per_tick_leg(eng, read_ahead=50)
+    if rank == 0 and world == 1 and not args.no_ref_config:
+        result["ref_config"] = ref_config_leg(eng)
     eng.close()
     if rank == 0 and world == 1 and not args.no_multignss:
         margs = argparse.Namespace(**vars(args))
@@ -659,7 +890,9 @@ def acquisition_leg(eng, rf):
     # map not requested: SURVEY 8d charges 32*N bytes per (PRN, bin) -- 16 spectrum + 16 code spectrum
     algo = N_CH * bins * 32.0 * n_code
     out = {"metric": "acquisition ms/PRN", "value": acq_ms / N_CH, "unit": "ms/PRN",
-           "config": "PCPS, 32 PRNs, fs=25 MHz, +-5 kHz @250 Hz (41 bins), 1 ms coherent, indices + ratio (no map)",
+           "config": "PCPS, 32 PRNs, fs=25 MHz, +-5 kHz @250 Hz (41 bins), 1 ms coherent, indices + ratio (no map); the code "
+                     "spectra of the staged PRNs are cached between calls (the reference recomputes conj(fft(code)) per acquisition)",
+           "code_spectra_cached": True,
            "ms_total_32_prn": acq_ms, "kernel_ms_32_prn": kern_ms, "cpu_ms_per_prn_1core": cpu_ms,
            "peaks_match_oracle": bool(ok),
            "roofline": {"bound": "hbm", "achieved": algo / (kern_ms * 1e-3) / 1e9 if kern_ms else 0.0, "peak": HBM_PEAK_GBS,

@@ -52,6 +52,8 @@ class ChannelManager:
         self.resultQueue = None
         self.keepCorrelationMap = keepCorrelationMap
         self._slots = 0
+        self._readahead = None        # EpochSchedule once enableReadAhead() was called (readahead.py)
+        self._ra_ms = 0
         self._pending = None          # (owned copy of the slab handed to addNewRFData, ring offset): uploaded by the next run()
         self._stage_buf = None        # the host buffer those copies live in (re-used from tick to tick)
         self._lists = None            # (state version, active, acquiring, host-side plugins, cids, states) of the last tick
@@ -86,9 +88,125 @@ class ChannelManager:
                 return channel
         raise Warning(f"Could not find an IDLE channel for tracking satellite [G{satelliteID}].")
 
+    def enableReadAhead(self, nbMilliseconds: int = 50):
+        """Serve the per-millisecond loop from blocks computed ahead (readahead.py): whenever every active channel is
+        tracking and `rfSignal` is this package's file reader, the next `nbMilliseconds` of the recording are uploaded
+        and tracked in one launch, and the following ticks hand out what they would have computed.  The reference's
+        calls (`addNewRFData(rfSignal.getMilliseconds(1)); run()`) stay as they are; a slab that is not the
+        recording's next millisecond is refused while a block is being replayed.  0 switches it off (once the
+        epochs already computed have been handed out)."""
+        from .readahead import EpochSchedule
+        self._ra_ms = max(0, int(nbMilliseconds))
+        self._EpochSchedule = EpochSchedule
+
+    def _recording_position(self, data):
+        """Sample index of `data` inside the recording when it is the slab `rfSignal` handed out last (or equals it
+        byte for byte), else None."""
+        rec_of = getattr(self.rfSignal, "_recording", None)
+        if rec_of is None or not getattr(self.rfSignal, "filepath", None) or not isinstance(data, np.ndarray):
+            return None
+        try:
+            rec = rec_of()
+        except OSError:
+            return None
+        n = data.size // 2
+        first = int(self.rfSignal.position) - n
+        if first < 0 or data.dtype != rec.dtype or data.ndim != 1:
+            return None
+        there = rec[2 * first:2 * (first + n)]
+        same = data.__array_interface__["data"][0] == there.__array_interface__["data"][0] or np.array_equal(data, there)
+        return first if same else None
+
+    def _open_window(self, data) -> bool:
+        """Prefetch and track the next block if everything allows it; True when `data` was consumed that way."""
+        ra, bank, ring = self._readahead, self.bank, self.sharedBuffer
+        spt = ra.spt
+        if data.size != 2 * spt or self.nbChannels == 0:
+            return False
+        chans = [ch for ch in self.channels.values() if ch.channelState is not ChannelState.IDLE]
+        if not chans or any(not isinstance(ch, DeviceTrackedChannel) or ch.channelState is not ChannelState.TRACKING
+                            or ch.lostLock for ch in chans):
+            return False
+        first = self._recording_position(data)
+        if first is None:
+            return False
+        rec = self.rfSignal._recording()
+        cids = np.array([ch.channelID for ch in chans], dtype=np.int32)
+        unread = bank.unread(cids)
+        room = (ring.maxSize - int(unread.max())) // spt - 1          # milliseconds the ring can take without overwriting
+        k = min(self._ra_ms, (rec.size // 2 - first) // spt, room)
+        if k < 4:
+            return False
+        self._flush_pending()
+        block = rec[2 * first:2 * (first + k * spt)]
+        self.engine.iq_upload(block, ring.idxWrite)
+        # every epoch that is complete inside the block, one persistent launch per group of equal epoch counts (and one
+        # more single-epoch launch for a channel whose last epoch just fits)
+        bank.flush()
+        avail = unread + k * spt
+        width = k + 2
+        records = np.zeros((len(cids), width), dtype=bank.last.dtype)
+        done = np.zeros(len(cids), dtype=np.int64)
+        used = np.zeros(len(cids), dtype=np.int64)               # samples of the epochs run so far
+        states = bank.state[cids].copy()
+        pending = np.ones(len(cids), dtype=bool)
+        while pending.any():
+            rows = np.flatnonzero(pending)
+            left = avail[rows] - used[rows]
+            n_next = states["n_samples"][rows].astype(np.int64)
+            budget = np.minimum(left // (n_next + 1), width - done[rows])
+            budget = np.where((budget == 0) & (left >= n_next) & (done[rows] < width), 1, budget)   # the last epoch just fits
+            pending[rows[budget <= 0]] = False
+            for n_ep in np.unique(budget[budget > 0]):
+                grp = rows[budget == n_ep]
+                n_ep = int(n_ep)
+                rec_g, st_g, done_g, _ = bank.device.step(cids[grp], n_ep, want_records=True, want_bits=False)
+                if (done_g == n_ep).all() and (done[grp] == done[grp[0]]).all():
+                    records[grp, done[grp[0]]:done[grp[0]] + n_ep] = rec_g      # (the usual case: one slice assignment)
+                    done[grp] += n_ep
+                else:
+                    for i, r in enumerate(grp):
+                        records[r, done[r]:done[r] + done_g[i]] = rec_g[i, :done_g[i]]
+                        done[r] += done_g[i]
+                        if done_g[i] < n_ep:                  # the device parked the channel (NCO ran away)
+                            bank.lost[cids[r]] = True
+                            pending[r] = False
+                used[grp] += np.where(np.arange(n_ep)[None, :] < done_g[:, None], rec_g["n_samples"], 0).sum(axis=1)
+                states[grp] = st_g
+        ra.load(cids, records, done, states, unread)
+        ra.raw, ra.first, ra.slabs_left, ra.slab_no = block, first, k, 0
+        ra.raw_address = block.__array_interface__["data"][0]
+        ra.version = getattr(ring, "stateVersion", None)       # (while it stands, the scheduled channels are all there is)
+        lists = self._lists
+        ra.covers_active = lists is not None and np.array_equal(lists[4], ra.cids64)
+        self._accept_prefetched(data)
+        return True
+
+    def _accept_prefetched(self, data):
+        ra = self._readahead
+        spt = ra.spt
+        # (the usual case costs one address comparison: the slab IS the recording's next millisecond)
+        ok = isinstance(data, np.ndarray) and data.size == 2 * spt and (
+            data.__array_interface__["data"][0] == ra.raw_address + 2 * ra.slab_no * spt * ra.raw.itemsize
+            or np.array_equal(data, ra.raw[2 * ra.slab_no * spt:2 * (ra.slab_no + 1) * spt]))
+        if not ok:
+            raise ValueError("addNewRFData: while a read-ahead block is replayed the slab must be the recording's next "
+                             f"millisecond (sample {ra.first + ra.slab_no * spt}); call enableReadAhead(0) to feed other data")
+        ra.slab_no += 1
+        ra.slabs_left -= 1
+        self.sharedBuffer.shiftIdxWrite(spt)
+
     def addNewRFData(self, data):
         """Queue one slab for the ring.  The copy itself rides in the next run()'s device call (one call per tick);
         anything that looks at the ring before that (another addNewRFData, getSlice, runBlock) flushes it first."""
+        ra = self._readahead
+        if self._ra_ms and self.bank is not None and (ra is None or (ra.bank is not self.bank and ra.empty)):
+            ra = self._readahead = self._EpochSchedule(self.bank, int(self.rfSignal.samplingFrequency * 1e-3))
+        if ra is not None:
+            if ra.slabs_left:
+                return self._accept_prefetched(data)
+            if self._ra_ms and ra.empty and self._open_window(data):
+                return None
         self._flush_pending()
         staged, offset, count = self.sharedBuffer.stage(data)
         self._guard_unread(count)
@@ -156,11 +274,34 @@ class ChannelManager:
             self._flush_pending()
             return out
         bank = self.bank
+        ra = self._readahead
+        if (ra is not None and not ra.empty and self._pending is None and self._lists is not None and not acquiring
+                and not host_plugins and ra.version == version and ra.covers_active):
+            # replaying a read-ahead block and nothing else is going on: everything this tick reports was worked out
+            # when the block was computed (readahead.py)
+            k = ra.tick
+            entry, decoded = ra.release()
+            if entry is not None:
+                out.add(len(entry[0]), tracking_packets_builder(entry[0], bank.cfg["loop_kind"][entry[0]], entry[1]))
+            if decoded:
+                out.add_ready(decoded)
+            unread, flags, code, tow, tow_dec = ra.updates(k)
+            since = code + unread / (self.rfSignal.samplingFrequency / 1e3)
+            out.add(len(active), channel_update_builder(cids_active, states_active, flags, tow, tow_dec, since, unread, code))
+            return out
         ready = bank.ready() if bank is not None else np.zeros(0, dtype=np.int32)
+        released, ra_tick = None, None
+        if ra is not None and not ra.empty:
+            if len(ready):
+                ready = ready[~ra.busy[ready]]               # (their next epochs are computed already: not to be run again)
+            ra_tick = ra.tick
+            released = ra.release()                          # epochs (and subframes) a block run computed for this tick
         # one device call: ring ingest + one epoch for every ready channel
         staged, offset = self._pending if self._pending is not None else (None, 0)
         try:
-            if bank is not None:
+            if bank is not None and staged is None and not len(ready):
+                rec, done = None, None                       # (nothing for the device to do in this tick)
+            elif bank is not None:
                 rec, done = bank.tick(staged, offset, ready)
             elif staged is not None:
                 self.engine.iq_upload(staged, offset)
@@ -178,6 +319,12 @@ class ChannelManager:
         for ch in host_plugins:   # plugins that keep their loops on the host (e.g. the reference's class behind the seams mixin)
             if ch.channelState is ChannelState.TRACKING:
                 out.add_ready(ch._processHandler())
+        if released is not None:
+            entry, decoded = released
+            if entry is not None:
+                out.add(len(entry[0]), tracking_packets_builder(entry[0], bank.cfg["loop_kind"][entry[0]], entry[1]))
+            if decoded:
+                out.add_ready(decoded)
         if len(ready):
             ran = np.flatnonzero(done > 0)
             cids, kinds, rec = ready[ran], bank.cfg["loop_kind"][ready[ran]], rec[ran]
@@ -192,11 +339,16 @@ class ChannelManager:
         else:
             cids, states = cids_active, states_active
         if bank is not None:
-            unread = bank.unread(cids)
-            since = bank.code_since_tow[cids] * 1 + unread / (self.rfSignal.samplingFrequency / 1e3)
-            out.add(len(active), channel_update_builder(cids, states, bank.flags(cids), bank.tow[cids].copy(),
-                                                        bank.tow_decoded[cids].copy(), since, unread,
-                                                        bank.code_since_tow[cids].copy()))
+            unread, flags, code = bank.unread(cids), bank.flags(cids), bank.code_since_tow[cids].copy()
+            tow, tow_dec = bank.tow[cids].copy(), bank.tow_decoded[cids].copy()
+            if ra_tick is not None:                          # channels of a replayed block report the TICK's state, not the mirror's
+                rows = ra.row_of[cids]
+                sel = rows >= 0
+                if sel.any():
+                    for dst, src in zip((unread, flags, code, tow, tow_dec), ra.updates(ra_tick)):
+                        dst[sel] = src[rows[sel]]
+            since = code + unread / (self.rfSignal.samplingFrequency / 1e3)
+            out.add(len(active), channel_update_builder(cids, states, flags, tow, tow_dec, since, unread, code))
         else:
             out.add_ready(ch.prepareChannelUpdate() for ch in active)
         return out
@@ -232,6 +384,8 @@ class ChannelManager:
         read that has not been written.  Returns the per-epoch TRACKING_UPDATE packets, channel by channel, epoch
         by epoch, followed by one CHANNEL_UPDATE per tracking channel."""
         self._flush_pending()
+        if self._readahead is not None and (self._readahead.slabs_left or not self._readahead.empty):
+            raise RuntimeError("runBlock while a read-ahead block is being replayed: finish its ticks first")
         out = TickPackets()
         bank = self.bank
         chans = [ch for ch in self.channels.values() if ch.channelState is ChannelState.TRACKING and not ch.lostLock]

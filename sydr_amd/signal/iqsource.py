@@ -39,7 +39,9 @@ class RFSignal:
         if self._map is None:
             if not os.path.isfile(self.filepath):
                 raise FileNotFoundError(f"IQ recording {self.filepath!r} does not exist")
-            self._map = np.memmap(self.filepath, dtype=self.fileDataType, mode="r")
+            self._mapping = np.memmap(self.filepath, dtype=self.fileDataType, mode="r")
+            # (a plain ndarray over the mapping: slicing an np.memmap costs ~10 us per slab in subclass bookkeeping)
+            self._map = np.asarray(self._mapping) if self._mapping.size else self._mapping
         return self._map
 
     @property

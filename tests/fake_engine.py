@@ -206,7 +206,13 @@ class OracleBank:
         return rec[:, 0], states, done
 
 
-OracleEngine.bank = lambda self, max_channels: OracleBank(self, max_channels)
+def _make_bank(self, max_channels):
+    bank = OracleBank(self, max_channels)
+    self.bank_calls = bank.calls          # (what the host layer asked of the device: ticks / block steps)
+    return bank
+
+
+OracleEngine.bank = _make_bank
 OracleEngine._ring_samples = lambda self, raw: np.asarray(raw)
 
 

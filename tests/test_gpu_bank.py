@@ -237,3 +237,70 @@ def test_manager_with_more_than_32_channels(engine):
     assert sum(abs(ch.carrierFrequency - sats[ch.satelliteID - 1]["doppler"]) < 40.0 for ch in chans) >= 30
     assert tracked > 8 * 250 + 28 * 180
     mgr.close()
+
+
+def test_read_ahead_on_the_device_equals_plain_ticks(engine, tmp_path):
+    """The per-millisecond loop with ChannelManager.enableReadAhead (blocks of epochs tracked ahead in one launch and
+    handed out tick by tick) against the plain one-device-call-per-tick loop: 12 channels at 10 MHz with late joiners
+    (acquisition in the middle of a replay), every packet of every tick bitwise equal."""
+    import configparser
+    import os
+    from conftest import REPO
+    from sydr_amd.channel.l1ca_kaplan import ChannelL1CA_Kaplan
+    from sydr_amd.channel.manager import ChannelManager
+    from sydr_amd.signal.iqsource import RFSignal
+    fs, n_ms = 10e6, 400
+    spms = int(fs * 1e-3)
+    rng = np.random.default_rng(5050)
+    sats = [dict(prn=1 + c, doppler=float(250.0 * rng.integers(-15, 16) + rng.uniform(-40, 40)),
+                 code_phase=float(rng.uniform(0, 1023)), phase=float(rng.uniform(0, 1)), amp=5.0) for c in range(12)]
+    total = n_ms * spms
+    engine.iq_alloc(total, FMT_CI8)
+    engine.code_slots(32)
+    engine.iq_synth(sats, fs, 10.0, 5051, 0, total)
+    path = tmp_path / "iq.bin"
+    engine.iq_download(total, 0).tofile(path)
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(REPO, "examples", "channel_GPS_L1CA_kaplan.ini"))
+
+    def receiver(read_ahead):
+        rf = RFSignal(dict(filepath=str(path), sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0, data_size=8))
+        mgr = ChannelManager(rf, engine=engine, keepCorrelationMap=False)
+        mgr.addChannel(ChannelL1CA_Kaplan, cfg, 12)
+        for s in sats[:8]:
+            mgr.requestTracking(s["prn"])
+        if read_ahead:
+            mgr.enableReadAhead(read_ahead)
+        ticks = []
+        for k in range(n_ms):
+            if k == 150:                                # four more satellites while blocks are being replayed
+                for s in sats[8:]:
+                    mgr.requestTracking(s["prn"])
+            mgr.addNewRFData(rf.getMilliseconds(1))
+            ticks.append([dict(p) for p in mgr.run()])
+        opened = 0 if mgr._readahead is None else mgr._readahead.tick
+        mgr.close()
+        return ticks, opened
+
+    plain, _ = receiver(0)
+    ahead, _ = receiver(40)
+    # a block launch spreads a channel over several workgroups, the one-epoch tick kernel does not: the partial sums are
+    # added in another order, so floating fields agree to rounding (1e-9 of the prompt magnitude), everything else exactly
+    n_trk, worst = 0, 0.0
+    for k, (a, b) in enumerate(zip(plain, ahead)):
+        key = lambda p: (p["cid"], p["type"].value)
+        a, b = sorted(a, key=key), sorted(b, key=key)
+        assert [key(p) for p in a] == [key(p) for p in b], k
+        for p, q in zip(a, b):
+            assert p.keys() == q.keys()
+            scale = max(1.0, float(np.hypot(p.get("i_prompt", 0.0), p.get("q_prompt", 0.0))))
+            for name in p:
+                if isinstance(p[name], float) and name not in ("peak_ratio",):
+                    ref = scale if name[:2] in ("i_", "q_") else max(1.0, abs(p[name]))
+                    if not (np.isnan(p[name]) and np.isnan(q[name])):
+                        worst = max(worst, abs(p[name] - q[name]) / ref)
+                else:
+                    assert p[name] == q[name] or name == "peak_ratio", (k, name, p[name], q[name])
+        n_trk += sum(1 for p in b if "i_prompt" in p)
+    assert worst < 1e-9, worst
+    assert n_trk > 8 * 350 + 4 * 200

@@ -1,4 +1,4 @@
-"""bench.py's N > 1 path rehearsed on one GPU: two ranks (gloo, both on device 0) generate the SAME 64-satellite
+"""bench.py's N > 1 path rehearsed on one GPU: two / four ranks (gloo, all on device 0) generate the SAME 32*N-satellite
 stream, each tracks its shard of 32 channels, and rank 0 reports the job.  The driver's own 8-GPU run uses RCCL and
 one device per rank; what is checked here is everything else -- the sharding, the reductions and the JSON contract."""
 import json
@@ -13,18 +13,27 @@ from conftest import REPO
 pytestmark = pytest.mark.gpu
 
 
-def test_two_rank_rehearsal_reports_one_job():
+@pytest.mark.parametrize("world", [2, 4])     # (a GPU box admits six processes on its card: eight ranks cannot be rehearsed here)
+def test_rank_rehearsal_reports_one_self_verified_job(world):
     env = dict(os.environ, SYDR_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29533 + world), os.path.join(REPO, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
            "--stream-seconds", "2.5"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)   # (the first `import torch` on a fresh box pages the image in: minutes)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1                                  # rank 0 alone prints
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak"
-    assert r["config"]["channels_total"] == 64 and r["config"]["channels_per_gpu"] == 32
+    assert r["n_gpus"] == world and r["steps"] == 3 and r["scaling"] == "weak"
+    assert r["config"]["channels_total"] == 32 * world and r["config"]["channels_per_gpu"] == 32
     assert r["value"] > 0 and r["ms_per_step"] > 0 and r["roofline"]["launches"] == 3   # (one launch per pass over the stream)
-    # the job's value counts both ranks' channel-samples: twice what one rank's stream rate alone would give
-    assert r["value"] == pytest.approx(2.0 * r["x_realtime"] * 25.0, rel=2e-3)
+    # the job's value counts every rank's channel-samples: `world` times what one rank's stream rate alone would give
+    assert r["value"] == pytest.approx(world * r["x_realtime"] * 25.0, rel=2e-3)
+    # the run verifies itself: every rank took part, and rank 0 re-tracked four channels of every other rank
+    # on its own GPU with bitwise equal accumulators
+    m = r["multi_gpu"]
+    assert m["ranks_seen"] == world and m["bitwise_identical"] is True
+    assert len(m["channels_recomputed_on_rank0"]) == 4 * (world - 1) and all(ok for _, _, ok in m["channels_recomputed_on_rank0"])
+    assert sorted({c[0] for c in m["channels_recomputed_on_rank0"]}) == list(range(1, world))
+    assert len(m["per_rank_ms_per_step"]) == world and min(m["per_rank_Msamples_per_s"]) > 0
+    assert m["distinct_devices"] == 1 and len({d["pid"] for d in m["devices"]}) == world     # (a rehearsal: one card, `world` processes)

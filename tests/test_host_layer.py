@@ -194,6 +194,61 @@ def test_pending_slab_is_owned_and_survives_a_failed_tick():
     assert mgr._pending is None and np.array_equal(eng.iq_download(20 * spms, 2 * spms), long)
 
 
+@pytest.mark.parametrize("block_ms", [50, 7])
+def test_read_ahead_ticks_equal_plain_ticks(tmp_path, block_ms):
+    """enableReadAhead: blocks of epochs computed ahead, handed out tick by tick -- every packet of every tick equal
+    to the plain per-tick manager's (g6b: PULL_IN -> WIDE -> NARROW, code lock, bit sync, navigation bits through a
+    stub decoder), the reference's calls unchanged, and a foreign slab refused while a block is replayed."""
+    from test_decoding import RecordingDecoder
+    g, fs, raw = trajectory_iq("g6b_kaplan_strong.npz")
+    path = tmp_path / "iq.bin"
+    raw.tofile(path)
+    cfg = channel_config(KAPLAN_INI)
+    for k, v in zip(g["track_override_keys"], g["track_override_vals"]):
+        cfg["TRACKING"][str(k)] = repr(float(v))
+
+    def receiver(read_ahead):
+        sig = RFSignal(dict(filepath=str(path), sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0,
+                            data_size=8))
+        eng = OracleEngine()
+        mgr = ChannelManager(sig, engine=eng)
+        mgr.addChannel(ChannelL1CA_Kaplan, cfg, 1)
+        ch = mgr.requestTracking(7)
+        ch.setDecoding(RecordingDecoder(every=10))
+        if read_ahead:
+            mgr.enableReadAhead(read_ahead)
+        ticks = []
+        for _ in range(1200):
+            mgr.addNewRFData(sig.getMilliseconds(1))          # the reference's loop, receiver.py:120-131
+            ticks.append([dict(p) for p in mgr.run()])
+        return mgr, ch, eng, ticks
+
+    plain_mgr, plain_ch, plain_eng, plain = receiver(0)
+    ra_mgr, ra_ch, ra_eng, ahead = receiver(block_ms)
+    for k, (a, b) in enumerate(zip(plain, ahead)):
+        for p in a + b:
+            p.pop("correlation_map", None)
+        assert a == b, k
+    assert ra_eng.bank_calls["step"] >= 1100 // block_ms and ra_eng.bank_calls["tick"] < 200       # blocks did the tracking
+    assert plain_eng.bank_calls["tick"] >= 1190
+    assert ra_ch.navBits == plain_ch.navBits and len(ra_ch.navBits) >= 40
+    assert ra_ch.carrierFrequency == plain_ch.carrierFrequency and ra_ch.currentSample == plain_ch.currentSample
+    assert ra_ch.tow == plain_ch.tow and int(ra_ch.trackFlags) == int(plain_ch.trackFlags)
+    # a slab that is not the recording's next millisecond cannot be replayed
+    sig = ra_mgr.rfSignal
+    sig.seek(0)
+    mgr2 = ChannelManager(sig, engine=OracleEngine())
+    mgr2.addChannel(ChannelL1CA_Kaplan, cfg, 1)
+    mgr2.requestTracking(7)
+    mgr2.enableReadAhead(20)
+    for _ in range(30):
+        mgr2.addNewRFData(sig.getMilliseconds(1))
+        mgr2.run()
+    assert mgr2._readahead is not None and mgr2._readahead.slabs_left > 0
+    with pytest.raises(ValueError, match="next millisecond"):
+        mgr2.addNewRFData(np.zeros(2 * int(fs * 1e-3), dtype=np.int8))
+
+
 def test_rfsignal_serves_the_recording_as_raw_integer_slabs(tmp_path):
     rng = np.random.default_rng(2)
     raw = rng.integers(-128, 127, 2 * 4000 * 130).astype(np.int8)

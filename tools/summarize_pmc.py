@@ -52,7 +52,16 @@ def mean(v):
     return sum(v) / len(v)
 
 
-info = {"correction": "FETCH_SIZE doubled (gfx950, 16-B/lane streaming reads)", "source": f"profiles/{tag}_pmc_summary.csv"}
+import subprocess
+try:
+    head = subprocess.run(["git", "-C", repo, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = bool(subprocess.run(["git", "-C", repo, "status", "--porcelain", "--", "sydr_amd", "bench.py"], capture_output=True,
+                                text=True).stdout.strip())
+except OSError:
+    head, dirty = "", False
+info = {"correction": "FETCH_SIZE doubled (gfx950, 16-B/lane streaming reads)", "source": f"profiles/{tag}_pmc_summary.csv",
+        "git_head": head + ("+uncommitted" if dirty else ""),
+        "note": "counters belong to the kernel VARIANT named here; bench.py prints them only for a run of that variant"}
 # the headline launch: ci8, 3 taps; the full 32000-epoch launches are the dispatches with the most waves
 head = [k for k in agg if k.startswith("epl_kernel<0,3,")]
 if head:
@@ -82,6 +91,20 @@ if head:
         for key in ("hbm_bytes", "valu_insts", "salu_insts", "lds_insts"):
             if f"epl_kernel_{key}_per_launch" in info:
                 info[f"epl_kernel_{key}_per_epoch"] = info[f"epl_kernel_{key}_per_launch"] / epochs
+# the multi-GNSS launches (configs 4-5: five taps, four epochs of a channel per workgroup)
+multi = [k for k in agg if k.startswith("epl_kernel<0,5,") and agg[k].get("FETCH_SIZE") and agg[k].get("WRITE_SIZE")]
+if multi:
+    k = max(multi, key=lambda k: mean(agg[k]["FETCH_SIZE"]))
+    m = agg[k]
+    big = lambda v: mean([x for x in v if x >= 0.5 * max(v)])
+    info.update({"multignss_kernel": k,
+                 "multignss_hbm_bytes_per_launch": 2 * big(m["FETCH_SIZE"]) * 1024 + big(m["WRITE_SIZE"]) * 1024})
+    if m.get("SQ_WAVES"):
+        info["multignss_waves_per_profiled_launch"] = big(m["SQ_WAVES"])
+        info["multignss_hbm_bytes_per_wave"] = info["multignss_hbm_bytes_per_launch"] / big(m["SQ_WAVES"])
+        for counter, key in (("SQ_INSTS_VALU", "valu"), ("SQ_INSTS_LDS", "lds")):
+            if m.get(counter):
+                info[f"multignss_{key}_insts_per_wave"] = big(m[counter]) / big(m["SQ_WAVES"])
 calls = len(agg.get("ratio_kernel", {}).get("FETCH_SIZE", []))
 if calls:
     fetch = write = 0.0
