@@ -5,7 +5,6 @@ from __future__ import annotations
 import numpy as np
 
 from ..utils.constants import GPS_L1CA_CODE_FREQ
-from ..utils.enumerations import ChannelState
 from .l1ca_kaplan import ChannelL1CA_Kaplan
 
 
@@ -26,11 +25,8 @@ class ChannelL1CA_Kaplan_SS(ChannelL1CA_Kaplan):
         return self._engine().two_peak_compare_ss(np.asarray(correlationMap))
 
     def postAcquisitionUpdate(self, acqIndices):
-        dopplerShift = ((-self.acq_dopplerRange) + self.acq_dopplerSteps * acqIndices[0])
-        self.carrierFrequency = -(self.rfSignal.interFrequency + dopplerShift)
-        samplesPerCodeChip = self.rfSignal.samplingFrequency / GPS_L1CA_CODE_FREQ
-        self.codeOffset = int(np.round(acqIndices[1] * samplesPerCodeChip))
-        self.currentSample = self.currentSample + self.acq_requiredSamples
-        self.currentSample -= self.track_requiredSamples
-        self.currentSample += self.codeOffset + 1
-        self.channelState = ChannelState.TRACKING
+        """SerialSearch peak [bin, code CHIP] -> NCO start values: the search runs in chips (scaled to samples here) and
+        mixes with the opposite sign (channel_l1ca_kaplan_ss.py:38-52)."""
+        samples_per_chip = self.rfSignal.samplingFrequency / GPS_L1CA_CODE_FREQ
+        self.enterTracking(-(self.rfSignal.interFrequency + self.searchedFrequency(acqIndices[0])),
+                           acqIndices[1] * samples_per_chip)

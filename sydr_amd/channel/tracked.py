@@ -248,15 +248,23 @@ class DeviceTrackedChannel(GpuCorrelatorSeams, Channel, metaclass=_ViewMeta):
         self.postAcquisitionUpdate(indices)
         return self.prepareResultsAcquisition(correlationMap, indices, ratio)
 
-    def postAcquisitionUpdate(self, acqIndices):
-        """Peak -> NCO start values (kaplan:217-235 / borre:301-316; SURVEY T10: note the +1)."""
-        bin_idx, code_idx = acqIndices
-        searched_hz = -self.acq_dopplerRange + self.acq_dopplerSteps * bin_idx
-        self.codeOffset = int(np.round(code_idx))
-        self.carrierFrequency = self.rfSignal.interFrequency - searched_hz
+    def searchedFrequency(self, bin_idx):
+        """Frequency of Doppler bin `bin_idx` of this channel's search grid (np.arange(-range, range + 1, step))."""
+        return -self.acq_dopplerRange + self.acq_dopplerSteps * bin_idx
+
+    def enterTracking(self, carrier_hz: float, code_offset_samples: float):
+        """From an acquisition result to the first tracking epoch: NCO carrier, and the sample at which the code period
+        found at `code_offset_samples` into the searched slab begins (the searched samples are skipped,
+        the first epoch is taken back, + offset + 1)."""
+        self.codeOffset = int(np.round(code_offset_samples))
+        self.carrierFrequency = carrier_hz
         first_epoch = int(self._bank.state["n_samples"][self._row])
         self.currentSample = self.currentSample + self.acq_requiredSamples - first_epoch + self.codeOffset + 1
         self.channelState = ChannelState.TRACKING
+
+    def postAcquisitionUpdate(self, acqIndices):
+        """PCPS peak [bin, code sample] -> NCO start values (kaplan:217-235 / borre:301-316)."""
+        self.enterTracking(self.rfSignal.interFrequency - self.searchedFrequency(acqIndices[0]), acqIndices[1])
 
     def prepareResultsAcquisition(self, correlationMap, acqIndices, acqPeakRatio):
         packet = self.prepareResults()

@@ -57,8 +57,13 @@ from oracle import sydr_oracle as orc  # noqa: E402  (only its seeded IQ synthes
 META = dict(numpy_version=np.__version__, reference="aproposorg/sydr@/root/reference")
 
 
+STAND_INS = np.array(["gps_time: third-party calendar module the reference imports (sydr/utils/time.py:4), absent from this "
+                      "image; replaced by a stub so that the import succeeds -- never called on this path"])
+
+
 def save(name, **arrays):
     path = os.path.join(HERE, name)
+    arrays.setdefault("stand_ins", STAND_INS)     # what was NOT the reference's own code when this file was produced
     np.savez_compressed(path, numpy_version=np.array(np.__version__), **arrays)
     print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
 
@@ -364,7 +369,6 @@ def make_decoding(fname="g10_decoding.npz", seconds=20.6, lead_bits=30, fs=4e6):
     save(fname, iq_sha256=iq_hash(raw),
          synth=np.array([fs, ms * spms, prn, doppler, code_phase, phase, amp, sigma, seed]),
          lnav=np.array([first_tow, 5, n_sub, lnav_seed, lead_bits]),
-         stand_ins=np.array(["gps_time (import only; never called on this path)"]),
          track_override_keys=np.array(sorted(track_over)),
          track_override_vals=np.array([float(track_over[k]) for k in sorted(track_over)]),
          acq=np.array(acq, dtype=np.float64), epoch_ints=ints.astype(np.int32),

@@ -490,3 +490,62 @@ gps_l1ca = ./channel.ini
     assert abs(carriers[4] - 2100.0) < 30.0 and abs(carriers[9] + 3300.0) < 30.0, out
     rows = np.loadtxt(tmp_path / "out.csv", delimiter=",", skiprows=1)
     assert rows.shape[0] > 2 * 2400                 # both channels, nearly all of the 2600 ms
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_discriminator_corner_inputs_on_the_device(engine, kind):
+    """The corner rows of the scalar loop math (g7: iPrompt = 0 -> atan(+-inf); 0/0 -> the NaN branch of FLL_ATAN) met
+    by the DEVICE's discriminators.  A stream whose in-phase component is identically zero and whose quadrature
+    component is the code itself correlates, with a zero carrier NCO, to iPrompt = 0 exactly and qPrompt = A*n; after two
+    milliseconds of that the stream falls silent, so the third epoch has every correlator at exactly 0.  Epochs 1-2
+    against the oracle's loops (pinned bit for bit by g6 / g7), epoch 3 against the oracle's scalar functions; the code
+    loop's 0/0 leaves no next epoch length, and the device parks the channel instead of reading anywhere."""
+    fs, prn, amp = 4e6, 13, 9
+    n_code = orc.samples_per_code(fs)
+    n = 8 * n_code
+    code = orc.gold_code(prn)
+    raw = np.zeros(2 * n, dtype=np.int8)
+    live = 2 * n_code + 2
+    idx = np.ceil(np.arange(live) * (orc.CODE_RATE / fs)).astype(int) % 1023 + 0     # chip per sample at zero code phase
+    raw[1:2 * live:2] = (amp * orc.pad_code(code)[np.where(idx == 0, 1023, idx)]).astype(np.int8)   # Q = A * code, I = 0
+    engine.iq_alloc(n, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(1)
+    engine.load_gps_code(0, prn)
+    rf = orc.iq_to_complex(raw)
+    c = KAPLAN_CFG if kind == 1 else BORRE_CFG
+    loop = (orc.KaplanLoop if kind == 1 else orc.BorreLoop)(fs, code, c, 0.0, 0)
+    with np.errstate(all="ignore"):
+        ref = [loop.step(rf[loop.current_sample:loop.current_sample + loop.n]) for _ in range(2)]
+    assert ref[0]["corr"][2] == 0.0 and ref[0]["corr"][3] > 0.9 * amp * ref[0]["n"]     # iPrompt = 0 exactly: atan(+inf)
+    if kind == 0:
+        assert ref[0]["carrier_err"] == orc.pll_costas(0.0, ref[0]["corr"][3]) and abs(ref[0]["carrier_err"] - 0.25) < 1e-12
+    states, traj, _, done = engine.track_closed_loop_ex([initial_state(kind, fs, 0.0, 0, c)], [loop_cfg(kind, fs, c)], 5)
+    tr = traj[0]
+
+    def same(got, want):
+        got, want = float(got), float(want)
+        return (np.isnan(got) and np.isnan(want)) or abs(got - want) <= RTOL * max(1.0, abs(want))
+    for k, r in enumerate(ref):
+        assert tr["start_sample"][k] == r["start"] and tr["n_samples"][k] == r["n"]
+        assert np.all(np.abs(tr["corr"][k][:6] - np.array(r["corr"])) <= RTOL * amp * r["n"]), k
+        if k == 0:
+            assert tr["corr"][k][2] == 0.0                                             # exactly zero on the device too
+        for field in ("dll", "pll", "carrier_err", "code_err", "carrier_hz", "code_hz"):
+            assert same(tr[field][k], r[field]), (k, field, tr[field][k], r[field])
+        if kind == 1:
+            assert same(tr["fll"][k], r["fll"])
+    # epoch 3: silence.  Every correlator is exactly 0; the carrier loop meets 0/0
+    e3 = tr[2]
+    assert np.all(e3["corr"][:6] == 0.0) and e3["n_samples"] > 0
+    ip2, qp2 = ref[1]["corr"][2], ref[1]["corr"][3]
+    with np.errstate(all="ignore"):
+        assert np.isnan(orc.dll_nneml(0.0, 0.0, 0.0, 0.0)) and np.isnan(e3["dll"])
+        if kind == 1:
+            # Kaplan, PULL_IN, third epoch: the FLL discriminator runs; atan(0/0) - atan(q'/i') is NaN and reads as no error
+            assert orc.fll_atan(0.0, 0.0, ip2, qp2, 1e-3) == 0.0 and e3["fll"] == 0.0 and e3["pll"] == 0.0
+            assert e3["carrier_hz"] == ref[1]["carrier_hz"] + (e3["carrier_err"]) and np.isfinite(e3["carrier_hz"])
+        else:
+            assert np.isnan(orc.pll_costas(0.0, 0.0)) and np.isnan(e3["carrier_err"])
+    # the code NCO is NaN now: the device stops this channel after the third epoch instead of reading anywhere
+    assert int(done[0]) == 3
