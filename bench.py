@@ -316,11 +316,11 @@ def ref_config_leg(eng, cpu_seconds=4.0):
         pb, pc, pr, _ = eng.pcps(slots, 0, fs, 0.0, rng_hz, step_hz, coh, noncoh)
     acq_ms = (time.perf_counter() - t0) / reps * 1e3
     eng.prof_reset()
-    eng.prof_enable(True)
+    eng.prof_enable(True, calls_only=True)
     for _ in range(reps):
         eng.pcps(slots, 0, fs, 0.0, rng_hz, step_hz, coh, noncoh)
     eng.prof_enable(False)
-    pk_ms, _ = eng.prof_read("pcps")
+    pk_ms, _ = eng.prof_read("call_pcps")
     pk_ms /= reps
     eng.prof_reset()
     n_code, bins = 10000, len(orc.doppler_bins(rng_hz, step_hz))
@@ -864,14 +864,15 @@ def acquisition_leg(eng, rf):
     for _ in range(reps):
         pb, pc, pr, _ = eng.pcps(slots, 0, FS, 0.0, 5000.0, 250.0, 1, 1)
     acq_ms = (time.perf_counter() - t0) / reps * 1e3      # wall time of the call as a receiver makes it
-    # the same calls again with the library's per-stage HIP events switched on (they cost ~10 us of GPU idle time per
-    # stage boundary, which is why the wall time above is taken without them): kernel time for the roofline
+    # the same calls again on ONE stream with one HIP-event pair around the kernels of each call: the in-stream time of
+    # a call, the figure the roofline is priced on (profiles/rNN_pcps_one_stream.json: the summed kernel durations of a
+    # rocprofv3 trace of such calls reproduce it)
     eng.prof_reset()
-    eng.prof_enable(True)
+    eng.prof_enable(True, calls_only=True)                 # one event pair around the kernels of each call (one stream)
     for _ in range(reps):
         eng.pcps(slots, 0, FS, 0.0, 5000.0, 250.0, 1, 1)
     eng.prof_enable(False)
-    kern_ms, _ = eng.prof_read("pcps")
+    kern_ms, _ = eng.prof_read("call_pcps")
     kern_ms /= reps
     eng.prof_reset()
     n_code = 25000

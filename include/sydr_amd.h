@@ -69,8 +69,10 @@ int sdr_engine_create(int device_id, sdr_engine** out);
 void sdr_engine_destroy(sdr_engine* e);
 /* Wait for everything queued on the engine's stream. */
 int sdr_engine_sync(sdr_engine* e);
-/* Per-kernel HIP-event timing.  enable=1 brackets every kernel launch with
- * hipEvents on the launch stream; sdr_prof_read drains them (it syncs). */
+/* HIP-event timing.  enable=1 brackets every stage of a call (named scopes: "epl_kernel", "pcps_fwd_fft", ...) with
+ * hipEvents on the launch stream; enable=2 brackets each whole call instead ("call_pcps": one event pair around
+ * everything sdr_pcps launches -- the per-stage pairs each cost the stream a few microseconds); sdr_prof_read drains
+ * them (it syncs).  While either is on, sdr_pcps keeps to one stream. */
 int sdr_prof_enable(sdr_engine* e, int enable);
 /* Sum/count of launch durations of kernels whose name starts with `prefix`
  * ("" = all) since the last sdr_prof_reset. */

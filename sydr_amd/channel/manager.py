@@ -343,7 +343,9 @@ class ChannelManager:
             tow, tow_dec = bank.tow[cids].copy(), bank.tow_decoded[cids].copy()
             if ra_tick is not None:                          # channels of a replayed block report the TICK's state, not the mirror's
                 rows = ra.row_of[cids]
-                sel = rows >= 0
+                # (... up to the tick of their last computed epoch: from then on the mirror is their state again, and the
+                # device may already have run them further)
+                sel = (rows >= 0) & (ra.last_tick[cids] >= ra_tick)
                 if sel.any():
                     for dst, src in zip((unread, flags, code, tow, tow_dec), ra.updates(ra_tick)):
                         dst[sel] = src[rows[sel]]

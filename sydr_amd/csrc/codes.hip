@@ -355,6 +355,7 @@ int sdr_iq_synth(sdr_engine* e, const sdr_synth_sat* sats, int n_sats, double fs
             const SynthSatDev* ds = (const SynthSatDev*)dsat.ptr;
             const int8_t* dc = (const int8_t*)dcode.ptr;
             float sg = (float)noise_sigma;
+            sdr_iq_mark_written(e, first_sample, n_samples);
             switch (e->iq_fmt) {
                 case SDR_FMT_CI8:
                     hipLaunchKernelGGL(synth_kernel<int8_t>, grid, dim3(256), 0, e->stream, (int8_t*)e->iq,

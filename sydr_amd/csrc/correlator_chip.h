@@ -78,7 +78,8 @@ __device__ __forceinline__ int wave_min_i32(int x) {
     return __builtin_amdgcn_readfirstlane(x);
 }
 
-// int8 -> fp64 in ONE instruction, with a known offset.  v_perm_b32 drops a sample byte (sign bit flipped: u = x + 128)
+// int8 -> fp64 in ONE instruction, with a known offset.  v_perm_b32 drops a sample byte (sign bit flipped: u = x + 128;
+// the engine keeps an image of a ci8 ring with the bits already flipped, engine_internal.h iq_flip)
 // into bits 8..15 of the high word 0x40B0_0000 of a double whose low word is zero: that double is 4096 + u = 4224 + x,
 // exactly.  The straight-line kernels mix THESE into their running sums (against 2 instructions for
 // v_bfe_i32 + v_cvt_f64_i32: the conversion was half of the 8-instruction floor per sample) and take the offset's share
@@ -138,7 +139,7 @@ struct ChipBlock {
 // a sample, where the wave evaluates the reference expression exactly anyway) flags the epoch, which is redone per
 // sample.
 template <int NT, bool SINGLE_WAVE, int KM = 0, int KS = 0, int KI = 0>
-__device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ring, int64_t capacity,
+__device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ring, const void* __restrict__ ring_flipped, int64_t capacity,
                                                      const EpochParams& ep, double dphi, const EpochConsts<NT>& K,
                                                      const uint32_t* lut, double2* strip_lds, double2* rot, int tid,
                                                      int lane, int stride, int edge_lane, double* accr, double* acci) {
@@ -170,7 +171,8 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
         tail_start = __builtin_amdgcn_readfirstlane(tail_start);
     }
     const int64_t base = ep.start_sample % capacity;   // (the caller guarantees base + n + 32 <= capacity)
-    const char* ring_base = static_cast<const char*>(ring) + base * 2;
+    // (the straight-line forms build their samples from the sign-flipped image of the ring: see biased_sample())
+    const char* ring_base = static_cast<const char*>(KM != 0 && (KS != 0 || KI != 0) && SDR_BIASED_CVT ? ring_flipped : ring) + base * 2;
 
     // in-block rotations exp(-1j*k*dphi), k = 0..25: one per lane, parked in LDS, read back as broadcasts
     // (KS: the block is summed in two halves of KS + 1 and KM - KS samples that both start at rotation 0, so only
@@ -407,7 +409,7 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                 if constexpr (SDR_BIASED_CVT) {
                     asm volatile("" : "+v"(hi_const));             // (v_perm_b32 takes one scalar operand: the selector)
 #pragma unroll
-                    for (int i = 0; i < kChipRawDwords; ++i) flipped[i] = b.raw[i] ^ 0x80808080u;
+                    for (int i = 0; i < kChipRawDwords; ++i) flipped[i] = b.raw[i];   // (loaded from the flipped image of the ring)
                 }
                 static_for<0, KM + 1>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;

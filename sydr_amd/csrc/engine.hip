@@ -80,6 +80,9 @@ ProfScope::ProfScope(sdr_engine* eng, const char* name, hipStream_t on)
     : e(eng), active(eng->prof), stream(on ? on : eng->stream) {
     rec.name = name;
     rec.start = rec.stop = nullptr;
+    // sdr_prof_enable(e, 2): whole calls only ("call_*" scopes: one event pair around everything a call launches) -- the
+    // per-stage scopes inside a call each cost the stream a few microseconds, which a sum over them would count as kernel time
+    if (active && e->prof_calls_only != (strncmp(name, "call_", 5) == 0)) active = false;
     if (!active) return;
     for (int i = 0; i < 2; ++i) {
         hipEvent_t ev = nullptr;
@@ -114,6 +117,60 @@ __global__ __launch_bounds__(256) void hbm_copy_kernel(const uint4* __restrict__
     }
     for (; i < n16; i += stride) dst[i] = src[i];
 }
+
+void sdr_iq_mark_written(sdr_engine* e, int64_t ring_offset, int64_t n_samples) {
+    if (n_samples <= 0 || e->iq_capacity <= 0) return;
+    const int64_t cap = e->iq_capacity;
+    int64_t lo = ring_offset % cap, hi = lo + n_samples;
+    if (hi > cap || n_samples >= cap) lo = 0, hi = cap;           // (a write that wraps: the whole ring, for simplicity)
+    if (e->iq_dirty_hi <= e->iq_dirty_lo) {
+        e->iq_dirty_lo = lo, e->iq_dirty_hi = hi;
+    } else {
+        e->iq_dirty_lo = lo < e->iq_dirty_lo ? lo : e->iq_dirty_lo;
+        e->iq_dirty_hi = hi > e->iq_dirty_hi ? hi : e->iq_dirty_hi;
+    }
+}
+
+__global__ __launch_bounds__(256) void flip_sign_bits_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        uint4 v = src[i];
+        v.x ^= 0x80808080u, v.y ^= 0x80808080u, v.z ^= 0x80808080u, v.w ^= 0x80808080u;
+        dst[i] = v;
+    }
+}
+
+int sdr_iq_flipped(sdr_engine* e, hipStream_t stream, const void** out) {
+    if (e->iq_fmt != SDR_FMT_CI8 || !e->iq) return sdr_fail(SDR_ERR_STATE, "the flipped ring image exists for ci8 rings only");
+    const size_t bytes = (size_t)e->iq_capacity * 2 + 256;        // (the same slack as the ring itself)
+    if (!e->iq_flip || e->iq_flip_capacity != e->iq_capacity) {
+        if (e->iq_flip) SDR_HIP(hipFree(e->iq_flip));
+        e->iq_flip = nullptr;
+        if (hipMalloc(&e->iq_flip, bytes) != hipSuccess) {
+            e->iq_flip = nullptr;
+            return sdr_fail(SDR_ERR_NOMEM, "hipMalloc(%zu) for the flipped image of the IQ ring failed", bytes);
+        }
+        e->iq_flip_capacity = e->iq_capacity;
+        e->iq_dirty_lo = 0, e->iq_dirty_hi = e->iq_capacity;
+        if (!e->iq_flip_done) SDR_HIP(hipEventCreateWithFlags(&e->iq_flip_done, hipEventDisableTiming));
+    }
+    if (e->iq_dirty_hi > e->iq_dirty_lo) {
+        // 16-byte granules around the dirty samples (2 bytes each); the whole ring takes its slack along
+        size_t lo = (size_t)e->iq_dirty_lo * 2 / 16, hi = ((size_t)e->iq_dirty_hi * 2 + 15) / 16;
+        if (e->iq_dirty_lo == 0 && e->iq_dirty_hi >= e->iq_capacity) hi = bytes / 16;
+        const size_t n16 = hi - lo;
+        const unsigned blocks = (unsigned)(n16 / 256 / 4 + 1 < 8192 ? n16 / 256 / 4 + 1 : 8192);
+        hipLaunchKernelGGL(flip_sign_bits_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)e->iq + lo,
+                           (uint4*)e->iq_flip + lo, n16);
+        SDR_HIP(hipGetLastError());
+        SDR_HIP(hipEventRecord(e->iq_flip_done, e->stream));
+        e->iq_dirty_lo = e->iq_dirty_hi = 0;
+    }
+    if (stream != e->stream && e->iq_flip_done) SDR_HIP(hipStreamWaitEvent(stream, e->iq_flip_done, 0));
+    *out = e->iq_flip;
+    return SDR_OK;
+}
+
 
 extern "C" {
 
@@ -240,6 +297,8 @@ void sdr_engine_destroy(sdr_engine* e) {
         if (b->ptr) (void)hipFree(b->ptr);
     if (e->slab_pinned) (void)hipHostFree(e->slab_pinned);
     if (e->iq) (void)hipFree(e->iq);
+    if (e->iq_flip) (void)hipFree(e->iq_flip);
+    if (e->iq_flip_done) (void)hipEventDestroy(e->iq_flip_done);
     if (e->codes) (void)hipFree(e->codes);
     if (e->luts) (void)hipFree(e->luts);
     if (e->luts2) (void)hipFree(e->luts2);
@@ -283,6 +342,7 @@ int sdr_stream_sync(sdr_engine* e, int stream_id) {
 int sdr_prof_enable(sdr_engine* e, int enable) {
     if (!e) return sdr_fail(SDR_ERR_INVALID, "engine is NULL");
     e->prof = enable != 0;
+    e->prof_calls_only = enable == 2;
     return SDR_OK;
 }
 
@@ -342,6 +402,12 @@ int sdr_iq_alloc(sdr_engine* e, int64_t capacity_samples, int fmt) {
     SDR_HIP(hipMemsetAsync(e->iq, 0, bytes, e->stream));
     e->iq_capacity = capacity_samples;
     e->iq_fmt = fmt;
+    if (e->iq_flip) {               // (the image of another ring: rebuilt when a kernel next asks for it)
+        SDR_HIP(hipFree(e->iq_flip));
+        e->iq_flip = nullptr;
+        e->iq_flip_capacity = 0;
+    }
+    e->iq_dirty_lo = 0, e->iq_dirty_hi = capacity_samples;
     return SDR_OK;
 }
 
@@ -359,6 +425,7 @@ static int iq_copy(sdr_engine* e, void* host, int64_t n, int64_t off, bool uploa
     char* dev = (char*)e->iq;
     char* h = (char*)host;
     if (upload) {
+        sdr_iq_mark_written(e, off, n);
         if (first) SDR_HIP(hipMemcpyAsync(dev + off * sb, h, first * sb, hipMemcpyHostToDevice, e->stream));
         if (n > first)
             SDR_HIP(hipMemcpyAsync(dev, h + first * sb, (n - first) * sb, hipMemcpyHostToDevice, e->stream));

@@ -59,6 +59,13 @@ struct sdr_engine {
     // IQ ring
     void* iq = nullptr;
     int64_t iq_capacity = 0;  // samples
+    // ci8 rings: a second image of the ring with the sign bit of every byte flipped (x + 128 as an unsigned byte) -- what
+    // the straight-line E/P/L kernels build their doubles from (correlator_chip.h: one v_perm_b32 per component, no
+    // v_xor per dword).  Allocated when such a kernel first runs; brought up to date from the ring's dirty range.
+    void* iq_flip = nullptr;
+    int64_t iq_flip_capacity = 0;
+    int64_t iq_dirty_lo = 0, iq_dirty_hi = 0;   // ring samples [lo, hi) written since the flipped image was refreshed (hi - lo >= capacity: all of it)
+    hipEvent_t iq_flip_done = nullptr;
     int iq_fmt = SDR_FMT_CI8;
 
     // code slots: int8 chips, row stride = code_stride bytes, plus per-slot length
@@ -96,6 +103,7 @@ struct sdr_engine {
     int64_t pcps_blu_n = 0;
     bool epl_no_chip = false;        // diagnostics: keep the 16-sample boundary variant where the chip-aligned one would run
     bool epl_no_double = false;      // diagnostics: keep the boundary variant where the half-chip view would run
+    bool prof_calls_only = false;    // sdr_prof_enable(e, 2): only the "call_*" scopes record
     bool epl_no_split = false;       // diagnostics: keep the run-time switch positions where the KS = 12 kernel would run
     int pcps_prn_chunk = 0;          // diagnostics: PRNs per inverse sweep (0 = as many as the work buffers hold)
     bool pcps_force_map = false;     // diagnostics / tests: materialise the map even when the caller does not ask for it
@@ -118,6 +126,10 @@ int sdr_pinned_reserve(sdr_engine* e, StreamCtx* ctx, size_t bytes);
 StreamCtx* sdr_stream_ctx(sdr_engine* e, int stream_id);   // nullptr when the id does not exist
 // Queue the ring write of sdr_iq_upload on the engine's stream without waiting for it.
 int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset);
+// Ring samples [offset, offset + n) (modulo capacity) are being written on e->stream: the flipped image is stale there.
+void sdr_iq_mark_written(sdr_engine* e, int64_t ring_offset, int64_t n_samples);
+// The flipped image of a ci8 ring, up to date with everything queued on e->stream, usable from `stream`.
+int sdr_iq_flipped(sdr_engine* e, hipStream_t stream, const void** out);
 
 static inline size_t sdr_fmt_bytes(int fmt) {
     switch (fmt) {

@@ -60,7 +60,7 @@ template <int FMT, int NT, int W, int KM = 0, int WPW = 1, int KS = 0, int KI = 
 #ifndef SDR_EPL_KI_WAVES
 #define SDR_EPL_KI_WAVES 1
 #endif
-__global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (KI != 0 ? SDR_EPL_KI_WAVES : SDR_EPL_WAVES))) void epl_kernel(const void* __restrict__ ring, int64_t capacity,
+__global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (KI != 0 ? SDR_EPL_KI_WAVES : SDR_EPL_WAVES))) void epl_kernel(const void* __restrict__ ring, const void* __restrict__ ring_flipped, int64_t capacity,
                                                        const sdr_epl_item* __restrict__ items, int n_items, int group_stride,
                                                        const uint32_t* __restrict__ luts,
                                                        int lut_words, int lut_stride,
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (
     if constexpr (W == kChipMax && FMT == SDR_FMT_CI8) {
         // chip-aligned blocks (correlator_chip.h); an epoch it does not cover is redone per sample
         const bool done = chip_variant_applies(ep, capacity) &&
-                          correlate_epoch_chip<NT, true, KM, KS, KI>(ring, capacity, ep, dphi, K, lut, prefix,
+                          correlate_epoch_chip<NT, true, KM, KS, KI>(ring, ring_flipped, capacity, ep, dphi, K, lut, prefix,
                                                          prefix + kThreads * chip_strip_slots<NT>() + wave * kChipMax,
                                                          tid, lane, kWaveThreads, lane, accr, acci);
         if (!done) {
@@ -188,7 +188,7 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
     auto launch = [&](auto kernel) {
         if (shmem > 64u * 1024u)  // beyond the default dynamic-LDS grant (long multi-period replicas)
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), shmem, stream, e->iq, e->iq_capacity, d_items, n_items, stride,
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), shmem, stream, e->iq, (const void*)e->iq_flip, e->iq_capacity, d_items, n_items, stride,
                            doubled ? e->luts2 : e->luts, lut_words, doubled ? e->lut2_stride : e->lut_stride, d_spacing, fs, tap0,
                            n_taps_total, d_out);
     };
@@ -464,6 +464,10 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
                         (long long)(first + count), p->n_items);
     if (p->doubled)
         if (int rc = ensure_doubled_luts(e, ctx->stream)) return rc;   // (a slot may have been re-staged since the plan was made)
+    if (e->iq_fmt == SDR_FMT_CI8 && (p->wide & (kVariantKS12 | kVariantKI))) {
+        const void* flipped = nullptr;                                   // (the straight-line kernels read the flipped ring image)
+        if (int rc = sdr_iq_flipped(e, ctx->stream, &flipped)) return rc;
+    }
     const sdr_epl_item* items = p->d_items + first;
     double* out = p->d_out + (size_t)first * 2 * p->n_taps;
     const int n = (int)count;

@@ -1429,11 +1429,15 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     const double bin_start = -doppler_range;
     const double bin_delta = (bin_start + doppler_step) - bin_start;
 
+    {
+    // (one event pair around every kernel of the search: its in-stream time; while it records, the search stays on one stream)
+    ProfScope whole(e, "call_pcps");
     switch (e->iq_fmt) {
         case SDR_FMT_CI8: rc = pcps_run<SDR_FMT_CI8>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
         case SDR_FMT_CI16: rc = pcps_run<SDR_FMT_CI16>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
         case SDR_FMT_CF32: rc = pcps_run<SDR_FMT_CF32>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
         default: rc = pcps_run<SDR_FMT_CF64>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
+    }
     }
     e->pcps_res_direct = nullptr;
     if (rc) {

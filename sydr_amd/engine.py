@@ -157,8 +157,10 @@ class Engine:
     def sync(self):
         check(self._lib.sdr_engine_sync(self._h))
 
-    def prof_enable(self, on=True):
-        check(self._lib.sdr_prof_enable(self._h, 1 if on else 0))
+    def prof_enable(self, on=True, calls_only=False):
+        """Per-stage HIP-event timing (`prof_read`); calls_only: one event pair around each whole call instead
+        (scopes named "call_*": the in-stream time of everything the call launched)."""
+        check(self._lib.sdr_prof_enable(self._h, (2 if calls_only else 1) if on else 0))
 
     def prof_reset(self):
         check(self._lib.sdr_prof_reset(self._h))

@@ -508,15 +508,20 @@ def test_discriminator_corner_inputs_on_the_device(engine, kind):
     live = 2 * n_code + 2
     idx = np.ceil(np.arange(live) * (orc.CODE_RATE / fs)).astype(int) % 1023 + 0     # chip per sample at zero code phase
     raw[1:2 * live:2] = (amp * orc.pad_code(code)[np.where(idx == 0, 1023, idx)]).astype(np.int8)   # Q = A * code, I = 0
+    c = KAPLAN_CFG if kind == 1 else BORRE_CFG
+
+    def two_epochs():
+        loop = (orc.KaplanLoop if kind == 1 else orc.BorreLoop)(fs, code, c, 0.0, 0)
+        rf = orc.iq_to_complex(raw)
+        with np.errstate(all="ignore"):
+            return [loop.step(rf[loop.current_sample:loop.current_sample + loop.n]) for _ in range(2)]
+    ref = two_epochs()
+    raw[2 * (ref[1]["start"] + ref[1]["n"]):] = 0       # silence from the first sample of the third epoch on
+    ref = two_epochs()
     engine.iq_alloc(n, FMT_CI8)
     engine.iq_upload(raw, 0)
     engine.code_slots(1)
     engine.load_gps_code(0, prn)
-    rf = orc.iq_to_complex(raw)
-    c = KAPLAN_CFG if kind == 1 else BORRE_CFG
-    loop = (orc.KaplanLoop if kind == 1 else orc.BorreLoop)(fs, code, c, 0.0, 0)
-    with np.errstate(all="ignore"):
-        ref = [loop.step(rf[loop.current_sample:loop.current_sample + loop.n]) for _ in range(2)]
     assert ref[0]["corr"][2] == 0.0 and ref[0]["corr"][3] > 0.9 * amp * ref[0]["n"]     # iPrompt = 0 exactly: atan(+inf)
     if kind == 0:
         assert ref[0]["carrier_err"] == orc.pll_costas(0.0, ref[0]["corr"][3]) and abs(ref[0]["carrier_err"] - 0.25) < 1e-12

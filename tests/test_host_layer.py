@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import REPO, load_golden
+from oracle import sydr_oracle as orc
 from fake_engine import OracleEngine
 from test_oracle_golden import trajectory_iq
 
@@ -247,6 +248,46 @@ def test_read_ahead_ticks_equal_plain_ticks(tmp_path, block_ms):
     assert mgr2._readahead is not None and mgr2._readahead.slabs_left > 0
     with pytest.raises(ValueError, match="next millisecond"):
         mgr2.addNewRFData(np.zeros(2 * int(fs * 1e-3), dtype=np.int8))
+
+
+def test_read_ahead_with_a_late_joiner_equals_plain_ticks(tmp_path):
+    """A second satellite is requested while blocks are being replayed: it acquires from the ring as usual, tracks by
+    plain device ticks until the next block, then lags the first channel by its acquisition time -- its epochs spill
+    past the end of a block, the first channel runs on by plain ticks meanwhile.  Every packet of every tick equal to
+    the plain loop's."""
+    fs, ms = 4e6, 260
+    spms = int(fs * 1e-3)
+    sats = [dict(prn=7, doppler=1750.0, code_phase=300.25, phase=0.1, amp=30.0),
+            dict(prn=19, doppler=-2250.0, code_phase=811.5, phase=0.6, amp=25.0)]
+    raw = orc.synth_iq(fs, ms * spms, sats, 10.0, 20261040)
+    path = tmp_path / "iq.bin"
+    raw.tofile(path)
+    cfg = channel_config(KAPLAN_INI)
+    cfg["ACQUISITION"]["non_coherent_integration"] = "3"
+
+    def receiver(read_ahead):
+        sig = RFSignal(dict(filepath=str(path), sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0,
+                            data_size=8))
+        mgr = ChannelManager(sig, engine=OracleEngine(), keepCorrelationMap=False)
+        mgr.addChannel(ChannelL1CA_Kaplan, cfg, 2)
+        mgr.requestTracking(7)
+        if read_ahead:
+            mgr.enableReadAhead(read_ahead)
+        ticks = []
+        for k in range(ms):
+            if k == 70:
+                mgr.requestTracking(19)
+            mgr.addNewRFData(sig.getMilliseconds(1))
+            ticks.append([dict(p) for p in mgr.run()])
+        return mgr, ticks
+
+    _, plain = receiver(0)
+    mgr, ahead = receiver(16)
+    for k, (a, b) in enumerate(zip(plain, ahead)):
+        key = lambda p: (p["cid"], p["type"].value)
+        assert sorted(a, key=key) == sorted(b, key=key), k
+    assert sum(1 for t in ahead for p in t if p["type"] is ChannelMessage.TRACKING_UPDATE and p["cid"] == 1) > 150
+    assert mgr.engine.bank_calls["step"] > 10
 
 
 def test_rfsignal_serves_the_recording_as_raw_integer_slabs(tmp_path):

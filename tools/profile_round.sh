@@ -1,0 +1,17 @@
+#!/bin/bash
+# Everything a round's profiles/ entry needs, on the GPU box:  tools/profile_round.sh <tag>
+#   1. tools/profile_bench.sh <tag>      rocprofv3 kernel statistics of the default bench command + separate PMC passes
+#   2. the same bench command WITHOUT the profiler (what the driver's own run measures)
+#   3. one-stream acquisitions under --kernel-trace --stats (tools/pcps_one_stream.py)
+# then, back in the build container:  python tools/summarize_pmc.py gpurun_out/prof_<tag> <tag>
+set -u
+TAG=${1:-r00}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+bash "$ROOT/tools/profile_bench.sh" "$TAG"
+cd "$ROOT" && python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_plain_run.json" 2> "$OUT/bench_plain_run.err"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pcps_one_stream" -- python3 "$ROOT/tools/pcps_one_stream.py" > "$OUT/pcps_one_stream.log" 2>&1
+find "$OUT/pcps_one_stream" -name "*kernel_trace.csv" -size +8M -delete
+tail -1 "$OUT/pcps_one_stream.log"
+tail -c 400 "$OUT/bench_plain_run.json"

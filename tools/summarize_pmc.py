@@ -119,3 +119,27 @@ if calls:
                  "pcps_workload": "sdr_pcps: 32 PRNs x 41 bins x 25000 samples, no map (1.05e9 algorithmic bytes)"})
 json.dump(info, open(os.path.join(repo, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(info, indent=1))
+
+# ---- the round's other artefacts: kernel statistics, bench lines, one-stream acquisition profile
+import shutil
+prof = os.path.join(repo, "profiles")
+for pattern, name in (("stats/*/*kernel_stats.csv", f"{tag}_bench_kernel_stats.csv"),
+                      ("pcps_one_stream/*/*kernel_stats.csv", f"{tag}_pcps_one_stream_kernel_stats.csv")):
+    hits = glob.glob(os.path.join(src, pattern))
+    if hits:
+        shutil.copyfile(hits[0], os.path.join(prof, name))
+for fname, name in (("bench.json", f"{tag}_bench.json"), ("bench_plain_run.json", f"{tag}_bench_plain_run.json")):
+    path = os.path.join(src, fname)
+    if os.path.exists(path) and os.path.getsize(path):
+        shutil.copyfile(path, os.path.join(prof, name))
+log = os.path.join(src, "pcps_one_stream.log")
+stats = os.path.join(prof, f"{tag}_pcps_one_stream_kernel_stats.csv")
+if os.path.exists(log) and os.path.exists(stats):
+    line = [l for l in open(log) if l.startswith("{")][-1]
+    rec = json.loads(line)
+    total_ns = sum(float(r["TotalDurationNs"]) for r in csv.DictReader(open(stats))
+                   if any(p in r["Name"] for p in PCPS) or "fast25k" in r["Name"])
+    rec["rocprof_kernel_ms_per_call"] = total_ns / 1e6 / rec["calls"]
+    rec["agreement"] = rec["rocprof_kernel_ms_per_call"] / rec["hip_event_kernel_ms_per_call"]
+    json.dump(rec, open(os.path.join(prof, f"{tag}_pcps_one_stream.json"), "w"), indent=1)
+    print(json.dumps(rec))
