@@ -892,4 +892,74 @@ __device__ __forceinline__ double reduce_taps(const double* accr, const double* 
     return s;
 }
 
+// ---- one wave, reduce-scatter form ------------------------------------------------------------------------------------
+// reduce_taps() sums each of the 2*NT accumulators over the 64 lanes separately (4 DPP stages + 8 v_readlane per value:
+// ~27 instructions each).  Here the lanes SHARE the work: at the step that pairs lane l with lane l ^ d, a lane keeps
+// one value of every pair of values and hands the other to its partner, so the list halves with every step (6 -> 3 ->
+// 2 -> 1 values for three taps) and only the last value is carried through the remaining steps: ~55 instructions in
+// all.  Afterwards every lane holds the wave total of ONE value -- which one depends on its low lane bits and is
+// returned in `slot` (2t: I of tap t, 2t + 1: Q); lanes 0..7 between them hold all of them.  The order of the additions
+// is fixed by the lane numbers: deterministic, as reduce_taps() is (the two differ in the last bits: another tree).
+template <int D>
+__device__ __forceinline__ double lane_xor_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (D == 1) {
+        lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xf, 0xf, true), hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xf, 0xf, true);
+    } else if constexpr (D == 2) {
+        lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xf, 0xf, true), hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xf, 0xf, true);
+    } else if constexpr (D == 4) {
+        // lanes with bit 2 set read four lanes down (row_shr:4 into banks 1 and 3), the others four lanes up
+        const int l1 = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xA, false), h1 = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xA, false);
+        lo = __builtin_amdgcn_update_dpp(l1, lo, 0x104, 0xf, 0x5, false), hi = __builtin_amdgcn_update_dpp(h1, hi, 0x104, 0xf, 0x5, false);
+    } else if constexpr (D == 8) {
+        const int l1 = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xC, false), h1 = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xC, false);
+        lo = __builtin_amdgcn_update_dpp(l1, lo, 0x108, 0xf, 0x3, false), hi = __builtin_amdgcn_update_dpp(h1, hi, 0x108, 0xf, 0x3, false);
+    } else if constexpr (D == 16) {
+        lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F), hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);   // bit mode: xor 0x10
+    } else {
+        const int addr = ((int)(threadIdx.x & 63) ^ 32) << 2;
+        lo = __builtin_amdgcn_ds_bpermute(addr, lo), hi = __builtin_amdgcn_ds_bpermute(addr, hi);
+    }
+    return __hiloint2double(hi, lo);
+}
+
+template <int N, int D>
+__device__ __forceinline__ void scatter_steps(double (&v)[N > 0 ? N : 1], int (&slot)[N > 0 ? N : 1], int lane, double& total, int& which) {
+    if constexpr (D > 32) {
+        static_assert(N == 1, "six halvings leave one value");
+        total = v[0], which = slot[0];
+    } else {
+        constexpr int M = (N + 1) / 2;
+        double nv[M];
+        int ns[M];
+        const bool upper = (lane & D) != 0;
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const double keep = upper ? v[2 * i + 1] : v[2 * i];
+            const double give = upper ? v[2 * i] : v[2 * i + 1];
+            nv[i] = keep + lane_xor_f64<D>(give);
+            ns[i] = upper ? slot[2 * i + 1] : slot[2 * i];
+        }
+        if constexpr (N & 1) {
+            nv[M - 1] = v[N - 1] + lane_xor_f64<D>(v[N - 1]);
+            ns[M - 1] = slot[N - 1];
+        }
+        scatter_steps<M, D * 2>(nv, ns, lane, total, which);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ double reduce_taps_scatter(const double* accr, const double* acci, int lane, int& slot) {
+    double v[2 * NT];
+    int s[2 * NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        v[2 * t] = accr[t], v[2 * t + 1] = acci[t];
+        s[2 * t] = 2 * t, s[2 * t + 1] = 2 * t + 1;
+    }
+    double total;
+    scatter_steps<2 * NT, 1>(v, s, lane, total, slot);
+    return total;
+}
+
 }  // namespace sdr

@@ -124,8 +124,17 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (
         correlate_epoch_wide<FMT, NT, true, (W ? W : kWide)>(ring, capacity, ep, dphi, K, lut, prefix, tid, lane, kWaveThreads, lane, accr, acci);
     else
         correlate_epoch<FMT, NT>(ring, capacity, ep, dphi, K, lut, lane, kWaveThreads, lane, accr, acci);
-    const double total = reduce_taps<NT, kWaveThreads>(accr, acci, red, lane);
-    if (lane < 2 * NT) out[(size_t)item * 2 * n_taps_total + 2 * tap0 + lane] = total;
+    if constexpr (NT == 3 || NT == 5) {
+        // one wave per item (also with four items per workgroup): the lanes share the reduction of the 2*NT sums
+        // (correlator.h: reduce_taps_scatter); the first eight (sixteen) lanes between them hold every total, each under
+        // the slot it ended up with
+        int slot;
+        const double total = reduce_taps_scatter<NT>(accr, acci, lane, slot);
+        if (lane < (NT == 3 ? 8 : 16)) out[(size_t)item * 2 * n_taps_total + 2 * tap0 + slot] = total;
+    } else {
+        const double total = reduce_taps<NT, kWaveThreads>(accr, acci, red, lane);
+        if (lane < 2 * NT) out[(size_t)item * 2 * n_taps_total + 2 * tap0 + lane] = total;
+    }
 #ifdef SDR_TRACE_WG
     if (tid == 0 && blockIdx.x < 65536) {
         unsigned hw;

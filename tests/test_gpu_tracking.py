@@ -545,12 +545,13 @@ def test_discriminator_corner_inputs_on_the_device(engine, kind):
     assert np.all(e3["corr"][:6] == 0.0) and e3["n_samples"] > 0
     ip2, qp2 = ref[1]["corr"][2], ref[1]["corr"][3]
     with np.errstate(all="ignore"):
-        assert np.isnan(orc.dll_nneml(0.0, 0.0, 0.0, 0.0)) and np.isnan(e3["dll"])
+        z = np.float64(0.0)                                   # (NumPy scalars, as the plugins hand them over: 0/0 is NaN, not an exception)
+        assert np.isnan(orc.dll_nneml(z, z, z, z)) and np.isnan(e3["dll"])
         if kind == 1:
             # Kaplan, PULL_IN, third epoch: the FLL discriminator runs; atan(0/0) - atan(q'/i') is NaN and reads as no error
-            assert orc.fll_atan(0.0, 0.0, ip2, qp2, 1e-3) == 0.0 and e3["fll"] == 0.0 and e3["pll"] == 0.0
+            assert orc.fll_atan(z, z, ip2, qp2, 1e-3) == 0.0 and e3["fll"] == 0.0 and e3["pll"] == 0.0
             assert e3["carrier_hz"] == ref[1]["carrier_hz"] + (e3["carrier_err"]) and np.isfinite(e3["carrier_hz"])
         else:
-            assert np.isnan(orc.pll_costas(0.0, 0.0)) and np.isnan(e3["carrier_err"])
+            assert np.isnan(orc.pll_costas(z, z)) and np.isnan(e3["carrier_err"])
     # the code NCO is NaN now: the device stops this channel after the third epoch instead of reading anywhere
     assert int(done[0]) == 3
