@@ -4,8 +4,10 @@ the plugin surface of sydr/channel/channel_l1ca_kaplan.py with the tracking stat
 Everything per-epoch (kaplan:342-619: correlators, discriminators, loop filters, lock indicators, NCO update,
 lock-state machine, bit sync) runs in `track_kernel` (sydr_amd/csrc/track.hip, loop_kind 1); this file only says
 which INI key feeds which `sdr_loop_cfg` field and under which of the reference's attribute names each state
-field is visible.  LNAV word / subframe decoding (kaplan:703-868, sydr/dsp/decoding.py) is outside the
-accelerated path (BASELINE.json: navigation untouched): the device delivers the bits (`navBits`)."""
+field is visible.  LNAV word / subframe decoding (kaplan:703-868, sydr/dsp/decoding.py) is outside the accelerated path
+(BASELINE.json: navigation untouched) and is not re-implemented: the device delivers the bits (`navBits`), and the decoder
+seam (`setDecoding` / `runDecoding`, sydr_amd/channel/navdecoder.py) hands them to the reference's own subframe methods, so
+that DECODING_UPDATE packets, `tow` and the TOW / EPH flags leave the manager as the reference's would."""
 from __future__ import annotations
 
 from ..utils.enumerations import LoopLockState

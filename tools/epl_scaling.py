@@ -16,11 +16,11 @@ rng = np.random.default_rng(1)
 n_items = 32000
 only = int(sys.argv[sys.argv.index('--only') + 1]) if '--only' in sys.argv else None
 reps = int(sys.argv[sys.argv.index('--reps') + 1]) if '--reps' in sys.argv else 5
-for n, step in ((3125, 0.32), (6250, 0.16), (12500, 0.0818), (25000, 0.04092), (50000, 0.02046), (100000, 0.01023)):
+for n, step in ((3125, 0.32), (6250, 0.16), (10000, 0.1023), (12500, 0.0818), (25000, 0.04092), (50000, 0.02046), (100000, 0.01023)):
     if only and n != only:
         continue
     items = make_items(np.arange(n_items) % 32, n, rng.integers(0, cap, n_items), 1000.0, 0.3, 0.01, step)
-    plan = e.epl_plan(items, (-0.5, 0.0, 0.5), 25e6)
+    plan = e.epl_plan(items, (-0.5, 0.0, 0.5), 25e6 * 0.04092 / step if step != 0.1023 else 10e6)
     plan.run(); e.sync()
     e.prof_reset(); e.prof_enable(True)
     for _ in range(reps):

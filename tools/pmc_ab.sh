@@ -9,9 +9,9 @@ cd /tmp && export TMPDIR=/tmp
 one() {
   tag=$1; lib=$2
   if [ "$lib" != "-" ]; then export SYDR_AMD_LIB=$ROOT/$lib; else unset SYDR_AMD_LIB; fi
-  python3 "$ROOT/tools/epl_scaling.py" --only 25000 --reps 40 > "$OUT/$tag.time.log" 2>&1
+  python3 "$ROOT/tools/epl_scaling.py" --only ${ONLY:-25000} --reps 40 > "$OUT/$tag.time.log" 2>&1
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY \
-     --output-format csv -d "$OUT/$tag" -- python3 "$ROOT/tools/epl_scaling.py" --only 25000 > "$OUT/$tag.pmc.log" 2>&1
+     --output-format csv -d "$OUT/$tag" -- python3 "$ROOT/tools/epl_scaling.py" --only ${ONLY:-25000} > "$OUT/$tag.pmc.log" 2>&1
   python3 - "$OUT/$tag" "$tag" <<'PY'
 import sys, glob, csv, collections
 acc = collections.defaultdict(float)
