@@ -103,6 +103,46 @@ def cpu_tracking_baseline(engine, items, n_items, budget_s):
     return out[:done], done, dt, rf
 
 
+def cpu_reference_c_baseline(rf, items, n_items, prns, budget_s):
+    """The reference's OWN compiled legacy correlator (oracle/_ref/tracking.so = sydr/c_functions/tracking.c built where
+    it lies, oracle/Makefile): generateReplica -> generateCarrier -> getCorrelator per tap, as
+    sydr/old/tracking/tracking_epl_c.py:105-137 called them, on the first items of the same workload.  1 core.
+    Returns (outputs, items done, seconds) or None where the library was not built."""
+    import ctypes as C
+    so = os.path.join(REPO, "oracle", "_ref", "tracking.so")
+    if not os.path.exists(so):
+        return None
+    from oracle import sydr_oracle as orc
+    lib = C.CDLL(so)
+    dp, zp, ip = C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)
+    lib.generateReplica.argtypes = [dp, C.c_size_t, C.c_double, C.c_double, dp, zp]
+    lib.generateCarrier.argtypes = [zp, zp, C.c_size_t, dp, dp]
+    lib.getCorrelator.argtypes = [dp, dp, ip, C.c_size_t, C.c_double, C.c_double, C.c_double, dp, dp]
+    codes = {int(s): orc.pad_code(orc.gold_code(int(prns[int(s)]))).astype(np.int32) for s in np.unique(items["code_slot"][:n_items])}
+    n_max = int(items["n_samples"][:n_items].max())
+    t = np.arange(0, n_max + 1) / FS
+    replica, i_sig, q_sig = np.zeros(n_max, dtype=np.complex128), np.zeros(n_max), np.zeros(n_max)
+    rem, ic, qc = np.zeros(1), np.zeros(1), np.zeros(1)
+    out = np.empty((n_items, 6))
+    done, t0 = 0, time.perf_counter()
+    for k in range(n_items):
+        it = items[k]
+        a, n = int(it["start_sample"]), int(it["n_samples"])
+        x = np.ascontiguousarray(rf[a:a + n])
+        lib.generateReplica(t.ctypes.data_as(dp), n, float(it["carrier_hz"]), float(it["rem_carrier"]), rem.ctypes.data_as(dp),
+                            replica.ctypes.data_as(zp))
+        lib.generateCarrier(x.ctypes.data_as(zp), replica.ctypes.data_as(zp), n, i_sig.ctypes.data_as(dp), q_sig.ctypes.data_as(dp))
+        code = codes[int(it["code_slot"])]
+        for tap, sp in enumerate(SPACING):
+            lib.getCorrelator(i_sig.ctypes.data_as(dp), q_sig.ctypes.data_as(dp), code.ctypes.data_as(ip), n,
+                              float(it["code_step"]), float(it["rem_code"]), sp, ic.ctypes.data_as(dp), qc.ctypes.data_as(dp))
+            out[k, 2 * tap], out[k, 2 * tap + 1] = ic[0], qc[0]
+        done = k + 1
+        if done % N_CH == 0 and time.perf_counter() - t0 > budget_s:
+            break
+    return out[:done], done, time.perf_counter() - t0
+
+
 def _mp_worker(args):
     """One reference-style channel process: all epochs of one channel through the oracle's EPL."""
     path, rows, code_prn = args
@@ -819,6 +859,16 @@ def main():
                                   "sample": f"first {done} channel-epochs ({done // N_CH} ms x 32 ch) of the same "
                                             f"stream through oracle/sydr_oracle.py:epl (NumPy), {dt:.1f} s",
                                   "max_rel_err_gpu_vs_oracle": err}
+        c_ref = cpu_reference_c_baseline(rf, items, done, [s["prn"] for s in sats], min(4.0, args.cpu_seconds))
+        if c_ref is not None:
+            c_out, c_done, c_dt = c_ref
+            c_err = float(np.max(np.abs(got[:c_done] - c_out) / scale[:c_done]))
+            result["cpu_baseline_reference_c"] = {
+                "value": float(items["n_samples"][:c_done].sum()) / N_CH / c_dt / 1e6, "unit": "Msamples/s", "cores": 1,
+                "kind": "reference",
+                "sample": f"first {c_done} channel-epochs of the same stream through the reference's own compiled legacy C "
+                          f"correlator (oracle/_ref/tracking.so: generateReplica, generateCarrier, getCorrelator x 3), {c_dt:.1f} s",
+                "max_rel_err_gpu_vs_reference_c": c_err}
         if args.cpu_mp_seconds > 0:
             hi_ms = min(n_epochs, 700)
             raw = eng.iq_download(int((items["start_sample"][:hi_ms * N_CH] + items["n_samples"][:hi_ms * N_CH]).max()), 0)

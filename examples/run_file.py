@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """Track an IQ recording with the reference's own configuration files.
 
-    python examples/run_file.py receiver.ini [--ms 2000] [--block 80] [--csv out.csv]
+    python examples/run_file.py receiver.ini [--ms 2000] [--block 80 | --read-ahead 50] [--csv out.csv]
 
 `receiver.ini` is the reference's receiver configuration (config/receiver.ini: [DEFAULT] nb_channels /
 ms_to_process, [RFSIGNAL], [SATELLITES] include_prn, [CHANNELS] gps_l1ca = <channel ini>).  What the reference's
 Receiver does around the hot path for the first stage of processing -- read the file millisecond by millisecond, give
 each requested PRN a channel, acquire, track -- is done here with the drop-in ChannelManager; once every channel
-tracks, blocks of `--block` ms go through the closed-loop kernel (`ChannelManager.runBlock`).  Navigation, measurements,
-database and report stay the reference's business (feed them the packets this script prints / writes)."""
+tracks, blocks of `--block` ms go through the closed-loop kernel (`ChannelManager.runBlock`); with `--read-ahead N`
+the loop stays the reference's own (one millisecond per iteration: `addNewRFData(getMilliseconds(1)); run()`) and the
+manager tracks N ms ahead behind it (`enableReadAhead`).  Subframes the channels decode are printed as they complete
+(DECODING_UPDATE; needs a decoder: by default the reference's own, where `sydr` is importable).  Navigation,
+measurements, database and report stay the reference's business (feed them the packets this script prints / writes)."""
 import argparse
 import configparser
 import os
@@ -30,6 +33,7 @@ def main(argv=None):
     ap.add_argument("receiver_ini")
     ap.add_argument("--ms", type=int, default=None, help="milliseconds to process (default: ms_to_process)")
     ap.add_argument("--block", type=int, default=80, help="epochs per closed-loop block once all channels track (0: per-tick only)")
+    ap.add_argument("--read-ahead", type=int, default=0, help="keep the per-millisecond loop and let the manager track this many ms ahead (overrides --block)")
     ap.add_argument("--csv", default=None, help="write one line per tracking epoch")
     args = ap.parse_args(argv)
 
@@ -49,6 +53,9 @@ def main(argv=None):
     mgr.addChannel(plugin, ccfg, max(len(prns), int(rcfg["DEFAULT"].get("nb_channels", len(prns)))))
     for p in prns:
         mgr.requestTracking(p)
+    if args.read_ahead:
+        mgr.enableReadAhead(args.read_ahead)
+        args.block = 0
     out = open(args.csv, "w") if args.csv else None
     if out:
         out.write("ms,cid,i_prompt,q_prompt,carrier_frequency,code_frequency,cn0,lock_state\n")
@@ -61,6 +68,8 @@ def main(argv=None):
             if p["type"] is ChannelMessage.ACQUISITION_UPDATE:
                 print(f"[{ms_now:6d} ms] channel {p['cid']}: acquisition bin {p['frequency_idx']} code {p['code_idx']} "
                       f"ratio {p['peak_ratio']:.2f} carrier {p['carrierFrequency']:+.1f} Hz")
+            elif p["type"] is ChannelMessage.DECODING_UPDATE:
+                print(f"[{ms_now:6d} ms] channel {p['cid']}: subframe {p['subframe_id']} decoded, TOW {p['tow']}")
             elif p["type"] is ChannelMessage.TRACKING_UPDATE:
                 n_track += 1
                 if out:

@@ -490,6 +490,13 @@ gps_l1ca = ./channel.ini
     assert abs(carriers[4] - 2100.0) < 30.0 and abs(carriers[9] + 3300.0) < 30.0, out
     rows = np.loadtxt(tmp_path / "out.csv", delimiter=",", skiprows=1)
     assert rows.shape[0] > 2 * 2400                 # both channels, nearly all of the 2600 ms
+    # the same recording through the reference's own loop (one millisecond per iteration) with the manager tracking ahead
+    mod.main([str(tmp_path / "receiver.ini"), "--read-ahead", "40", "--csv", str(tmp_path / "out_ra.csv")])
+    out = capsys.readouterr().out
+    carriers = {int(p): float(f) for p, f in re.findall(r"G(\d+): state TRACKING, carrier ([-+0-9.]+) Hz", out)}
+    assert set(carriers) == {4, 9} and abs(carriers[4] - 2100.0) < 30.0 and abs(carriers[9] + 3300.0) < 30.0, out
+    rows_ra = np.loadtxt(tmp_path / "out_ra.csv", delimiter=",", skiprows=1)
+    assert rows_ra.shape[0] > 2 * 2400
 
 
 @pytest.mark.parametrize("kind", [0, 1])
