@@ -275,6 +275,8 @@ class ChannelManager:
             return out
         bank = self.bank
         ra = self._readahead
+        if ra is not None and ra.bank is not bank:
+            ra.follow(bank)
         if (ra is not None and not ra.empty and self._pending is None and self._lists is not None and not acquiring
                 and not host_plugins and ra.version == version and ra.covers_active):
             # replaying a read-ahead block and nothing else is going on: everything this tick reports was worked out

@@ -51,6 +51,17 @@ class EpochSchedule:
     def empty(self) -> bool:
         return self.tick >= self.n_ticks
 
+    def follow(self, bank):
+        """The manager's bank was re-created to hold more channels (addChannel during a replay): its mirror rows were
+        copied over, so the schedule simply moves to it."""
+        if bank is not self.bank:
+            grow = bank.max_channels - len(self.busy)
+            if grow > 0:
+                self.busy = np.concatenate([self.busy, np.zeros(grow, dtype=bool)])
+                self.last_tick = np.concatenate([self.last_tick, np.full(grow, -1, dtype=np.int64)])
+                self.row_of = np.concatenate([self.row_of, np.full(grow, -1, dtype=np.int64)])
+            self.bank = bank
+
     def load(self, channels, records, done, states, unread_now):
         """Schedule `done[r]` epochs of `channels[r]`: epoch e is released by the first tick k whose slab completes it
         (unread_now + (k + 1) * spt >= samples up to its end), one epoch per channel and tick; move the bank's mirror
