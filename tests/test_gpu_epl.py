@@ -546,3 +546,16 @@ def test_whole_chip_tap_variant(engine):
     items = make_items(0, 50000, 100, 1000.0, 0.3, 0.01, 1.023e6 / 50e6)
     v, _ = run(items, (-1.0, -0.4, 0.0, 0.4, 1.0), 50e6, False)
     assert v == 65536 + 26 + 24
+
+
+def test_randomised_stress_of_the_straight_line_kernels(engine):
+    """tests/stress_static.py (shortened): the compile-time tap geometries at 25 / 50 MHz with random code Doppler, phases
+    at and next to zero, epochs that wrap the ring, carriers up to an intermediate frequency, and the ring rewritten in
+    pieces between launches (the flipped image the kernels read must follow) -- 640 channel-epochs against the oracle."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("stress_static", os.path.join(os.path.dirname(__file__), "stress_static.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    checked, worst = mod.run(8, 2026, eng=engine, n_items=80)
+    assert checked == 640 and worst < 1e-9
