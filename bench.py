@@ -240,7 +240,10 @@ def verify_across_ranks(eng, dist, torch, rank, local_rank, world, all_sats, min
             if r == 0:
                 continue
             theirs = shard_channels(len(all_sats), r, world)
-            assert theirs == info["channels"], "ranks disagree about the sharding"
+            if theirs != info["channels"]:                 # (never raise here: the other ranks wait for the verdict below)
+                verdict["ok"] = False
+                verdict["mismatches"].append({"rank": r, "channel": None, "why": "ranks disagree about the sharding"})
+                continue
             pick = sorted(set(int(round(x)) for x in np.linspace(0, len(theirs) - 1, VERIFY_PER_RANK)))
             sats = [all_sats[theirs[i]] for i in pick]
             for k, sat in enumerate(sats):
