@@ -893,6 +893,7 @@ __global__ __launch_bounds__(kThreads) void fft4_rows_kernel(const PassArgs a, i
 #define SDR_PCPS_OVERLAP_MB 100ll
 #endif
 #include "pcps_fast.h"   // register-resident kernels for N = 125 x 200 (needs Butterfly, PassArgs, Best, wave_best)
+#include "pcps_fastn.h"  // ... and for N = 20 / 50 / 250 x 200
 
 template <bool INV, int LOAD0, int STORE_LAST, int FMT, int TA, int TB>
 void run_four_step_t(sdr_engine* e, const FourStep& f, PassArgs a, int batch, double2* Z, double2* final_out) {
@@ -928,11 +929,19 @@ constexpr int kRowTile = SDR_PCPS_ROW_TILE;
 inline bool fast25k_applies(const sdr_engine* e, const FourStep& f) {
     return f.ok && f.N1 == fast25k::N1 && f.N2 == fast25k::N2 && !e->pcps_no_fast;
 }
+// the register-resident kernels of either header serve this length (they split it as N1 x 200 themselves)
+inline bool fast_applies(const sdr_engine* e, const FourStep& f) {
+    return fast25k_applies(e, f) || (f.ok && fastn::handles(f.N1 * f.N2) && !e->pcps_no_fast);
+}
+inline void fast_run(sdr_engine* e, const FourStep& f, PassArgs a, int batch, double2* Z, hipStream_t stream) {
+    if (fast25k_applies(e, f)) fast25k::run(e, a, batch, Z, stream);
+    else fastn::run(f.N1 * f.N2, a, batch, Z, stream);
+}
 template <bool INV, int LOAD0, int STORE_LAST, int FMT>
 void run_four_step(sdr_engine* e, const FourStep& f, PassArgs a, int batch, double2* Z, double2* final_out) {
     if constexpr (INV && LOAD0 == LOAD_MUL_CODE && STORE_LAST == STORE_MAG_MAX) {
-        if (fast25k_applies(e, f)) {      // the 1312 transforms of a map-free search at 25 MHz
-            fast25k::run(e, a, batch, Z, e->stream);
+        if (fast_applies(e, f)) {         // the transforms of a map-free search at 4 / 10 / 25 / 50 MHz
+            fast_run(e, f, a, batch, Z, e->stream);
             return;
         }
     }
@@ -942,7 +951,8 @@ void run_four_step(sdr_engine* e, const FourStep& f, PassArgs a, int batch, doub
 inline int records_per_transform(const FourStep& f) { return ((f.N1 + kRowTile - 1) / kRowTile) * (kThreads / 64); }
 // ... and of the main sweep, which may run the register-resident kernels
 inline int records_main_sweep(const sdr_engine* e, const FourStep& f) {
-    return fast25k_applies(e, f) ? fast25k::kRecordsPerTransform : records_per_transform(f);
+    if (fast25k_applies(e, f)) return fast25k::kRecordsPerTransform;
+    return fast_applies(e, f) ? fastn::records(f.N1 * f.N2) : records_per_transform(f);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1139,7 +1149,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
             // streams and two intermediates, so that one sweep's partial last rounds of workgroups (and its launch
             // ramps) are filled by the other's -- ordered behind the forward transforms and in front of the peak
             // kernels by two events.
-            const bool overlap = map_free && fast25k_applies(e, plan_four_step(N)) && n_prn > prn_chunk && !e->prof &&
+            const bool overlap = map_free && fast_applies(e, plan_four_step(N)) && n_prn > prn_chunk && !e->prof &&
                                  !e->pcps_no_overlap;
             if (overlap) {
                 if (!e->pcps_aux) {
@@ -1162,7 +1172,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
                     g.nbins = nbins;
                     g.scale = 1.0 / (double)N;
                     g.partials = (Best*)e->pcps_part.ptr + (size_t)p0 * nbins * records_main_sweep(e, plan_four_step(N));
-                    fast25k::run(e, g, pc * nbins, (sweep & 1) ? B : A, (sweep & 1) ? e->pcps_aux : e->stream);
+                    fast_run(e, plan_four_step(N), g, pc * nbins, (sweep & 1) ? B : A, (sweep & 1) ? e->pcps_aux : e->stream);
                     continue;
                 }
                 PassArgs g = {};
@@ -1349,7 +1359,7 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     if (map_free && e->pcps_prn_chunk == 0) {
         const int64_t per_prn = (int64_t)tbytes * nbins;
         // (two sweeps alive at a time where they alternate between two streams: pcps_run)
-        const bool two_alive = fast25k_applies(e, four) && !e->prof && !e->pcps_no_overlap;
+        const bool two_alive = fast_applies(e, four) && !e->prof && !e->pcps_no_overlap;
         const int fit = (int)std::max<int64_t>(1, ((two_alive ? SDR_PCPS_OVERLAP_MB : 200ll) << 20) / per_prn);
         if (fit < prn_chunk) {
             const int sweeps = (n_prn + fit - 1) / fit;
@@ -1363,7 +1373,7 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_a, work);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_b, work);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_code, tbytes * n_prn);
-    const size_t n_records = map_free ? (size_t)n_prn * (nbins + 1) * records_per_transform(four) + n_prn : 0;
+    const size_t n_records = map_free ? (size_t)n_prn * (nbins + 1) * std::max(records_per_transform(four), records_main_sweep(e, four)) + n_prn : 0;
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_map, (size_t)n_prn * (map_free ? 1 : nbins) * N * sizeof(double));
     if (!rc && coh > 1) rc = sdr_devbuf_reserve(e, &e->pcps_csum, (size_t)n_prn * nbins * tbytes);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_part, std::max((size_t)n_prn * kPeakParts, n_records) * sizeof(Best));

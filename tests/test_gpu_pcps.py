@@ -217,17 +217,16 @@ def test_map_free_search_equals_the_materialised_one(engine):
         finally:
             engine.set_option("pcps_materialise_map", 0)
         mb, mc, mr, cmap = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1, want_map=True)
-        if fs == 25e6:
-            # N = 125 x 200: the map-free sweep runs the register-resident kernels, whose transforms are ordered
-            # differently from the general ones behind the map -- same indices, ratio to rounding; with the general
-            # kernels forced the two searches are bit for bit the same again
-            assert np.array_equal(pb, qb) and np.array_equal(pc, qc)
-            np.testing.assert_allclose(pr, qr, rtol=1e-12, atol=0)
-            engine.set_option("pcps_general_kernels", 1)
-            try:
-                pb, pc, pr, _ = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1)
-            finally:
-                engine.set_option("pcps_general_kernels", 0)
+        # N = N1 x 200: the map-free sweep runs the register-resident kernels (pcps_fast.h, pcps_fastn.h), whose
+        # transforms are ordered differently from the general ones behind the map -- same indices, ratio to rounding;
+        # with the general kernels forced the two searches are bit for bit the same again
+        assert np.array_equal(pb, qb) and np.array_equal(pc, qc)
+        np.testing.assert_allclose(pr, qr, rtol=1e-12, atol=0)
+        engine.set_option("pcps_general_kernels", 1)
+        try:
+            pb, pc, pr, _ = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1)
+        finally:
+            engine.set_option("pcps_general_kernels", 0)
         assert np.array_equal(pb, qb) and np.array_equal(pc, qc) and pr.tobytes() == qr.tobytes()
         assert np.array_equal(pb, mb) and np.array_equal(pc, mc) and pr.tobytes() == mr.tobytes()
         for p in range(32):                                   # and against NumPy's own argmax of the returned map
@@ -263,15 +262,19 @@ def test_cached_code_spectra_follow_the_staged_codes(engine):
     assert [int(restaged[0][2]), int(restaged[1][2])] == peak and restaged[2][2] == pytest.approx(ratio, rel=1e-9)
 
 
-def test_register_resident_kernels_at_25_mhz_vs_oracle(engine):
-    """The map-free search at N = 25 000 runs its 1312 inverse transforms through the register-resident 125 x 200
-    kernels (pcps_fast.h): peaks and ratio against the oracle's map for present and absent satellites, an intermediate
-    frequency, other Doppler grids (21 / 41 / 81 / 101 bins: other workgroup-to-XCD mappings) and PRN counts that do
-    not fill a group, from a ring offset -- and the general kernels on the same inputs."""
-    rng = np.random.default_rng(250001)
-    fs, n = 25e6, 25000
-    for case, (if_hz, drange, dstep, n_prn) in enumerate(((0.0, 5000.0, 250.0, 6), (1250.0, 5000.0, 500.0, 5),
-                                                          (0.0, 4000.0, 100.0, 3), (-2000.0, 5000.0, 100.0, 1))):
+@pytest.mark.parametrize("fs", [25e6, 4e6, 10e6, 50e6])
+def test_register_resident_kernels_vs_oracle(engine, fs):
+    """The map-free search at N = N1 x 200 (4 / 10 / 25 / 50 MHz) runs its inverse transforms through the
+    register-resident kernels (pcps_fast.h: 125 x 200; pcps_fastn.h: 20 / 50 / 250 x 200): peaks and ratio against the
+    oracle's map for present and absent satellites, an intermediate frequency, other Doppler grids (21 / 41 / 81 / 101
+    bins: other workgroup-to-XCD mappings) and PRN counts that do not fill a group, from a ring offset -- and the
+    general kernels on the same inputs."""
+    rng = np.random.default_rng(250001 + int(fs) // 1000000)
+    n = orc.samples_per_code(fs)
+    cases = ((0.0, 5000.0, 250.0, 6), (1250.0, 5000.0, 500.0, 5), (0.0, 4000.0, 100.0, 3), (-2000.0, 5000.0, 100.0, 1))
+    if fs == 50e6:
+        cases = ((0.0, 5000.0, 250.0, 3), (1250.0, 2000.0, 100.0, 2), (-2000.0, 5000.0, 500.0, 1))     # (the oracle's maps take a while)
+    for case, (if_hz, drange, dstep, n_prn) in enumerate(cases):
         prns = [int(p) for p in rng.choice(np.arange(1, 33), n_prn, replace=False)]
         present = prns[:max(1, n_prn // 2)]
         sats = [dict(prn=p, doppler=float(rng.uniform(-3500, 3500)), code_phase=float(rng.uniform(0, 1023)),
