@@ -933,15 +933,25 @@ inline bool fast25k_applies(const sdr_engine* e, const FourStep& f) {
 inline bool fast_applies(const sdr_engine* e, const FourStep& f) {
     return fast25k_applies(e, f) || (f.ok && fastn::handles(f.N1 * f.N2) && !e->pcps_no_fast);
 }
+template <int STORE = STORE_MAG_MAX>
 inline void fast_run(sdr_engine* e, const FourStep& f, PassArgs a, int batch, double2* Z, hipStream_t stream) {
-    if (fast25k_applies(e, f)) fast25k::run(e, a, batch, Z, stream);
-    else fastn::run(f.N1 * f.N2, a, batch, Z, stream);
+    if (fast25k_applies(e, f)) {
+        if constexpr (STORE == STORE_MAG_MAX) {
+            fast25k::run(e, a, batch, Z, stream);
+        } else {
+            fast25k::run_cols(a, batch, Z, stream);
+            fastn::run_rows<fast25k::N1, STORE>(a, batch, Z, stream);
+        }
+    } else {
+        fastn::run<STORE>(f.N1 * f.N2, a, batch, Z, stream);
+    }
 }
 template <bool INV, int LOAD0, int STORE_LAST, int FMT>
 void run_four_step(sdr_engine* e, const FourStep& f, PassArgs a, int batch, double2* Z, double2* final_out) {
-    if constexpr (INV && LOAD0 == LOAD_MUL_CODE && STORE_LAST == STORE_MAG_MAX) {
-        if (fast_applies(e, f)) {         // the transforms of a map-free search at 4 / 10 / 25 / 50 MHz
-            fast_run(e, f, a, batch, Z, e->stream);
+    if constexpr (INV && LOAD0 == LOAD_MUL_CODE &&
+                  (STORE_LAST == STORE_MAG_MAX || STORE_LAST == STORE_MAG_ACC || STORE_LAST == STORE_CPLX_ACC)) {
+        if (fast_applies(e, f)) {         // the inverse transforms of a search at 4 / 10 / 25 / 50 MHz
+            fast_run<STORE_LAST>(e, f, a, batch, Z, e->stream);
             return;
         }
     }

@@ -314,6 +314,16 @@ __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, con
     }
 }
 
+// the column kernel alone (the map-writing row kernels are pcps_fastn.h's)
+inline void run_cols(PassArgs& a, int batch, double2* Z, hipStream_t stream) {
+    const size_t shA = (size_t)(N1 * kColT + N1) * sizeof(double2);
+    (void)hipFuncSetAttribute((const void*)cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shA);
+    a.n_prn = batch / a.nbins;
+    const int pairs = (N2 / kColT) * a.nbins;
+    const unsigned gridA = 8u * (unsigned)((pairs + 7) / 8) * (unsigned)a.n_prn;
+    hipLaunchKernelGGL(cols_kernel, dim3(gridA), dim3(kColThreads), shA, stream, a, Z);
+}
+
 inline void run(sdr_engine* e, PassArgs a, int batch, double2* Z, hipStream_t stream) {
     const size_t shA = (size_t)(N1 * kColT + N1) * sizeof(double2);
     const size_t shB = (size_t)(20 * kRowPitch + N2) * sizeof(double2);

@@ -198,8 +198,11 @@ __global__ __launch_bounds__(kThreadsN) void cols_kernel(const PassArgs a, doubl
     }
 }
 
-// Rows: fast25k::rows_kernel with the number of rows (and with it N) as a parameter.
-template <int N1>
+// Rows: fast25k::rows_kernel with the number of rows (and with it N) as a parameter, and with the map-writing stores:
+// STORE_MAG_MAX keeps the running maximum (map-free search); STORE_MAG_ACC writes / adds |.|/N into the map (a search
+// that returns its map, non-coherent sums); STORE_CPLX_ACC writes / adds the scaled complex value (coherent sums).
+// A thread's 20 outputs sit N1 apart; adjacent rows of the tile are adjacent in memory (runs of kRowT values).
+template <int N1, int STORE>
 __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, const double2* __restrict__ Z) {
     constexpr int N = N1 * N2;
     extern __shared__ double2 lds4[];
@@ -236,6 +239,41 @@ __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, con
         for (int g = 0; g < 20; ++g) lds4[g * kRowPitch + tid] = v[g];
     }
     __syncthreads();
+    if constexpr (STORE != STORE_MAG_MAX) {
+        if (!live) return;
+        const int s = r;
+        const int k1 = k1_0 + i;
+        const size_t base_o = (size_t)batch * N + k1;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int g = s + 10 * o;
+            const int kp = g / 4 + 5 * (g % 4);
+            double2 u[10];
+#pragma unroll
+            for (int rr = 0; rr < 10; ++rr) u[rr] = lds4[g * kRowPitch + rr + 10 * i];
+            idft10<N>(u, tw);
+            if constexpr (STORE == STORE_MAG_ACC) {
+                double old[10];
+                if (!a.first_block) {
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) old[j] = a.map[base_o + N1 * (kp + 20 * (j / 2 + 5 * (j % 2)))];
+                }
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const double mag = hypot(u[j].x * a.scale, u[j].y * a.scale);
+                    a.map[base_o + N1 * (kp + 20 * (j / 2 + 5 * (j % 2)))] = a.first_block ? 0.0 + mag : old[j] + mag;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const size_t at = base_o + N1 * (kp + 20 * (j / 2 + 5 * (j % 2)));
+                    const double2 sc = make_double2(u[j].x * a.scale, u[j].y * a.scale);
+                    a.csum[at] = a.first_block ? sc : cadd(a.csum[at], sc);
+                }
+            }
+        }
+        return;
+    }
     int best_i = 0x7fffffff;
     double best_v = -1.0;
     if (live) {
@@ -283,26 +321,32 @@ __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, con
     }
 }
 
-template <int N1, int R2, int T>
+template <int N1, int STORE>
+inline void run_rows(const PassArgs& a, int batch, const double2* Z, hipStream_t stream) {
+    const size_t shB = (size_t)(20 * kRowPitch + N2) * sizeof(double2);
+    (void)hipFuncSetAttribute((const void*)rows_kernel<N1, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shB);
+    hipLaunchKernelGGL((rows_kernel<N1, STORE>), dim3(row_tiles(N1), batch), dim3(kRowThreads), shB, stream, a, Z);
+}
+
+template <int N1, int R2, int T, int STORE>
 inline void run_n(PassArgs a, int batch, double2* Z, hipStream_t stream) {
     const size_t shA = R2 > 1 ? (size_t)(N1 * T + N1) * sizeof(double2) : 0;
-    const size_t shB = (size_t)(20 * kRowPitch + N2) * sizeof(double2);
     if (shA > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)cols_kernel<N1, R2, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shA);
-    (void)hipFuncSetAttribute((const void*)rows_kernel<N1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shB);
     a.n_prn = batch / a.nbins;
     const int pairs = (N2 / T) * a.nbins;
     const unsigned gridA = 8u * (unsigned)((pairs + 7) / 8) * (unsigned)a.n_prn;
     hipLaunchKernelGGL((cols_kernel<N1, R2, T>), dim3(gridA), dim3(kThreadsN), shA, stream, a, Z);
-    hipLaunchKernelGGL(rows_kernel<N1>, dim3(row_tiles(N1), batch), dim3(kRowThreads), shB, stream, a, Z);
+    run_rows<N1, STORE>(a, batch, Z, stream);
 }
 
 inline bool handles(int N) { return N == 4000 || N == 10000 || N == 50000; }
 inline int records(int N) { return records_per_transform(N / N2); }
+template <int STORE>
 inline void run(int N, PassArgs a, int batch, double2* Z, hipStream_t stream) {
-    if (N == 4000) run_n<20, 1, 100>(a, batch, Z, stream);
-    else if (N == 10000) run_n<50, 2, 50>(a, batch, Z, stream);
-    else run_n<250, 10, 10>(a, batch, Z, stream);
+    if (N == 4000) run_n<20, 1, 100, STORE>(a, batch, Z, stream);
+    else if (N == 10000) run_n<50, 2, 50, STORE>(a, batch, Z, stream);
+    else run_n<250, 10, 10, STORE>(a, batch, Z, stream);
 }
 
 }  // namespace fastn

@@ -196,8 +196,8 @@ def test_pcps_randomised_stress(engine):
 
 def test_map_free_search_equals_the_materialised_one(engine):
     """Indices + ratio without writing the map (running maximum in the inverse row kernel, winning rows recomputed
-    alone) == the same search with the map written and re-read -- bit for bit, ties, edge windows and absent PRNs
-    included (every PRN x 4/10/25 MHz x two Doppler grids)."""
+    alone) == the same search with the map written and re-read -- ties, edge windows and absent PRNs included (every
+    PRN x 4/10/25 MHz x two Doppler grids), with the register-resident and with the general kernels."""
     rng = np.random.default_rng(31)
     for fs, grid in ((4e6, (5000.0, 250.0)), (10e6, (5000.0, 300.0)), (25e6, (5000.0, 250.0)), (25e6, (2000.0, 100.0))):
         n = orc.samples_per_code(fs)
@@ -209,26 +209,34 @@ def test_map_free_search_equals_the_materialised_one(engine):
             engine.load_gps_code(s, s + 1)
         engine.iq_synth(sats, fs, 15.0, int(fs) % 1000 + 17, 0, n)
         slots = np.arange(32)
-        pb, pc, pr, none = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1)
-        assert none is None
-        engine.set_option("pcps_materialise_map", 1)
-        try:
-            qb, qc, qr, _ = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1)
-        finally:
-            engine.set_option("pcps_materialise_map", 0)
-        mb, mc, mr, cmap = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1, want_map=True)
-        # N = N1 x 200: the map-free sweep runs the register-resident kernels (pcps_fast.h, pcps_fastn.h), whose
-        # transforms are ordered differently from the general ones behind the map -- same indices, ratio to rounding;
-        # with the general kernels forced the two searches are bit for bit the same again
-        assert np.array_equal(pb, qb) and np.array_equal(pc, qc)
-        np.testing.assert_allclose(pr, qr, rtol=1e-12, atol=0)
-        engine.set_option("pcps_general_kernels", 1)
-        try:
-            pb, pc, pr, _ = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1)
-        finally:
-            engine.set_option("pcps_general_kernels", 0)
-        assert np.array_equal(pb, qb) and np.array_equal(pc, qc) and pr.tobytes() == qr.tobytes()
-        assert np.array_equal(pb, mb) and np.array_equal(pc, mc) and pr.tobytes() == mr.tobytes()
+        # N = N1 x 200: every search runs the register-resident kernels (pcps_fast.h, pcps_fastn.h), whose transforms
+        # are ordered differently from the general ones -- same indices, map and ratio to rounding.  Within a family
+        # of kernels the map-free search and the two that write the map agree bit for bit on the indices; on the
+        # ratio too with the general kernels (the second peak of the map-free search is theirs in both families).
+        found = {}
+        for general in (0, 1):
+            engine.set_option("pcps_general_kernels", general)
+            try:
+                pb, pc, pr, none = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1)
+                assert none is None
+                engine.set_option("pcps_materialise_map", 1)
+                try:
+                    qb, qc, qr, _ = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1)
+                finally:
+                    engine.set_option("pcps_materialise_map", 0)
+                mb, mc, mr, cmap = engine.pcps(slots, 0, fs, 0.0, grid[0], grid[1], 1, 1, want_map=True)
+            finally:
+                engine.set_option("pcps_general_kernels", 0)
+            assert np.array_equal(pb, qb) and np.array_equal(pc, qc) and np.array_equal(pb, mb) and np.array_equal(pc, mc)
+            assert qr.tobytes() == mr.tobytes()
+            if general:
+                assert pr.tobytes() == qr.tobytes()
+            else:
+                np.testing.assert_allclose(pr, qr, rtol=1e-12, atol=0)
+            found[general] = (pb, pc, pr, cmap)
+        assert np.array_equal(found[0][0], found[1][0]) and np.array_equal(found[0][1], found[1][1])
+        np.testing.assert_allclose(found[0][2], found[1][2], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(found[0][3], found[1][3], rtol=1e-12, atol=1e-12 * float(found[1][3].max()))
         for p in range(32):                                   # and against NumPy's own argmax of the returned map
             top = np.unravel_index(np.argmax(cmap[p]), cmap[p].shape)
             assert (int(pb[p]), int(pc[p])) == (int(top[0]), int(top[1]))
