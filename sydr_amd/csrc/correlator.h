@@ -43,7 +43,7 @@ constexpr double kTwoOverPi = 6.36619772367581382433e-01;
 // quarter turns (the k*hi product is exact inside the FMA), then the classic degree-13 / 14
 // minimax kernels (fdlibm k_sin / k_cos coefficients, < 1 ulp on the reduced range).  This
 // replaces the general libm sincos, whose Payne-Hanek path is dead weight here.
-__device__ __forceinline__ void sincos_reduced(double ph, double* s, double* c) {
+__host__ __device__ __forceinline__ void sincos_reduced(double ph, double* s, double* c) {
     const double k = rint(ph * kTwoOverPi);
     double t = __builtin_fma(-k, kHalfPiHi, ph);
     t = __builtin_fma(-k, kHalfPiLo, t);
@@ -156,7 +156,7 @@ struct EpochParams {
     double carrier_hz, rem_carrier, rem_code, code_step;
 };
 
-__device__ __forceinline__ double carrier_step(double carrier_hz, double fs) {
+__host__ __device__ __forceinline__ double carrier_step(double carrier_hz, double fs) {
     const double w = (carrier_hz * 2.0) * M_PI;  // tracking.py:102 uses np.pi
     return w / fs;
 }

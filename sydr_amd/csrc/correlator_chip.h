@@ -40,7 +40,7 @@ template <int NT>
 constexpr int chip_strip_slots() { return 2 * NT + 1; }   // double2 slots per lane (odd multiple of 16 B: conflict-free)
 
 // Predicted first sample i with y(i) > thr on the line y = i*step + shift.
-__device__ __forceinline__ int chip_first_above(double thr, double shift, double inv_step, bool& near) {
+__host__ __device__ __forceinline__ int chip_first_above(double thr, double shift, double inv_step, bool& near) {
     const double u = (thr - shift) * inv_step;
     const double fl = floor(u);
     const double fr = u - fl;
@@ -48,7 +48,7 @@ __device__ __forceinline__ int chip_first_above(double thr, double shift, double
     return (int)fl + 1;
 }
 // The same from exact evaluations of the reference expression around a prediction c.
-__device__ __forceinline__ int chip_first_above_exact(int c, double thr, double step, double shift) {
+__host__ __device__ __forceinline__ int chip_first_above_exact(int c, double thr, double step, double shift) {
     auto above = [&](int i) {
         double y = (double)i * step;   // reference arithmetic: separate multiply and add
         y = y + shift;
@@ -100,6 +100,106 @@ __device__ __forceinline__ double biased_sample(sdr_u32x2& pair, uint32_t w_flip
 // selector of v_perm_b32 for byte `byte` of the sample dword: result = [0x40][0xB0][that byte][0x00]
 constexpr uint32_t cvt_selector(int byte) { return 0x03020000u | ((uint32_t)(4 + byte) << 8) | 0x0Cu; }
 
+// What the chip-aligned routine needs of an epoch besides its samples and its rotations: wave-uniform integers that
+// follow from the taps' np.linspace constants alone.  The kernels with run-time positions derive them per epoch; for
+// the straight-line ones the HOST does, when a plan is made (epl.hip: sdr_epl_plan_create) -- the same function, the same
+// IEEE operations -- and a wave reads them with scalar loads: ~300 vector and ~200 scalar instructions less per epoch
+// (of ~5000: int64 conversions, the exact boundary evaluations of the first and last chip, a 64-bit modulo).
+template <int NT>
+struct ChipGeom {
+    int64_t Tfx, Ufx;           // samples per chip and the anchor line's offset U = -shift/step, Q32.32
+    uint64_t delta[NT];         // tap t's switch, in samples after the block start (Q32.32)
+    int q0, F;                  // chips q0 + 1 .. q0 + F of the anchor tap are whole
+    int head_end, tail_start;   // samples [0, head_end) and [tail_start, n) belong to the partial first and last chip
+    int m[NT], J[NT];           // integer part of delta_t; the chip q + J_t tap t sits on at the start of anchor chip q
+    int bad;                    // the uniform-position scheme does not cover this epoch
+};
+
+template <int NT, int KM, int KS, int KI>
+__host__ __device__ __forceinline__ void chip_geometry(int n, const double* shift, const double* step, const double* inv_step,
+                                                       ChipGeom<NT>& g) {
+    constexpr int A = NT / 2;
+    const double two32 = 4294967296.0;
+    g.q0 = (int)ceil(shift[A]);
+    double y_last = (double)(n - 1) * step[A];
+    y_last = y_last + shift[A];
+    const int q_last = (int)ceil(y_last);
+    g.F = q_last - g.q0 - 1;
+    g.head_end = n, g.tail_start = n;
+    if (g.F > 0) {
+        bool nr = false;
+        g.head_end = chip_first_above_exact(chip_first_above((double)g.q0, shift[A], inv_step[A], nr), (double)g.q0, step[A], shift[A]);
+        g.tail_start = chip_first_above_exact(chip_first_above((double)(q_last - 1), shift[A], inv_step[A], nr),
+                                              (double)(q_last - 1), step[A], shift[A]);
+    }
+    g.Tfx = (int64_t)rint(inv_step[A] * two32);
+    g.Ufx = (int64_t)floor(-shift[A] * inv_step[A] * two32);
+    const int M = (int)(g.Tfx >> 32);                                   // block length M or M + 1
+    bool bad = M < 1 || M + 1 > kChipMax || g.F > 16384 || (KM != 0 && M != KM);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        g.m[t] = M, g.J[t] = 0, g.delta[t] = 0;
+        if (t == A) continue;
+        // tap t sits on chip q + J_t at the block start of anchor chip q; its switch to q + J_t + 1 comes
+        // delta_t >= 0 samples later (delta_t < T)
+        const int64_t Ut = (int64_t)floor(-shift[t] * inv_step[t] * two32);
+        int j = (int)ceil(shift[t] - shift[A]) - 1;
+        int64_t d = (Ut - g.Ufx) + (int64_t)(1 + j) * g.Tfx;
+        if (d < 0) {
+            d += g.Tfx;
+            ++j;
+        } else if (d >= g.Tfx) {
+            d -= g.Tfx;
+            --j;
+        }
+        bad = bad || d < 0 || d >= g.Tfx;
+        g.J[t] = j;
+        g.delta[t] = (uint64_t)d;
+        g.m[t] = (int)(d >> 32);
+        bad = bad || (KS != 0 && (g.m[t] != KS || j != (t < A ? -1 : 0)));   // (KS: the tap sits on chip q - 1 / q at the block start)
+        // (KI: on chip q + (t - A) - 1 and switching at the block's first sample, or on q + (t - A) until its end)
+        bad = bad || (KI != 0 && !((j == (t - A) * KI - 1 && g.m[t] == 0) || (j == (t - A) * KI && g.m[t] >= M)));
+    }
+    g.bad = bad ? 1 : 0;
+}
+
+// The carrier rotations of a straight-line kernel's epoch: exp(-1j*k*dphi) inside a half block (k = 1 .. kStaticHalf),
+// over the D / D + 1 samples between a lane's blocks, and the biased conversion's share of a sum of kStaticHalf - 2 / - 1 /
+// - 0 samples (correlate_epoch_chip).  Evaluated by the host with the kernels' own sincos_reduced -- fused multiply-adds
+// and exact roundings on both sides, i.e. the same bits a wave would get -- and the same order of additions as the
+// wave's DPP prefix sum.
+constexpr int kStaticHalf = 13;                 // KS + 1 = (KM + 2) / 2 for KM = 24, KS = 12
+struct ChipRot {
+    double urc[kStaticHalf + 1], urs[kStaticHalf + 1];
+    double rd0c, rd0s, rd1c, rd1s;
+    double biasc[3], biass[3];
+};
+__host__ __device__ inline void chip_rotations(double dphi, int Dmin, ChipRot& r) {
+    double cs[16], sn[16];
+    for (int k = 0; k < 16; ++k) sincos_reduced(-(double)k * dphi, &sn[k], &cs[k]);
+    for (int k = 1; k <= kStaticHalf; ++k) r.urc[k] = cs[k], r.urs[k] = sn[k];
+    r.urc[0] = 1.0, r.urs[0] = 0.0;
+    sincos_reduced(-(double)Dmin * dphi, &r.rd0s, &r.rd0c);
+    sincos_reduced(-(double)(Dmin + 1) * dphi, &r.rd1s, &r.rd1c);
+    for (int st = 1; st < 16; st <<= 1)          // inclusive prefix sums as a row of 16 lanes forms them (row_shr:1, 2, 4, 8)
+        for (int l = 15; l >= st; --l) cs[l] += cs[l - st], sn[l] += sn[l - st];
+    for (int i = 0; i < 3; ++i) {
+        const int l = kStaticHalf - 3 + i;
+        const double re = cs[l] - sn[l], im = cs[l] + sn[l];
+        r.biasc[i] = re * 4224.0, r.biass[i] = im * 4224.0;
+    }
+}
+
+// One epoch of a plan as the straight-line kernels read it (device memory, one per item).
+template <int NT>
+struct ChipSetup {
+    double dphi;                                // carrier_step(carrier_hz, fs)
+    double shift[NT], step[NT], inv_step[NT];   // the taps' np.linspace constants (compute_tap_constants)
+    int64_t base;                               // start_sample % capacity; < 0: the chip-aligned routine does not apply (chip_variant_applies)
+    ChipGeom<NT> g;
+    ChipRot r;
+};
+
 // One lane's block, prepared one round ahead of its use (its loads are in flight while the previous block computes).
 template <int NT>
 struct ChipBlock {
@@ -138,9 +238,12 @@ struct ChipBlock {
 // a block in which the reference's rounding lets a tap switch a sample early or late (only possible within 2^-16 of
 // a sample, where the wave evaluates the reference expression exactly anyway) flags the epoch, which is redone per
 // sample.
+// G: chip_geometry() of the epoch, computed by the caller or read from the plan's ChipSetup; base = start_sample % capacity;
+// R (straight-line forms only): the plan's chip_rotations() of the epoch.
 template <int NT, bool SINGLE_WAVE, int KM = 0, int KS = 0, int KI = 0>
 __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ring, const void* __restrict__ ring_flipped, int64_t capacity,
                                                      const EpochParams& ep, double dphi, const EpochConsts<NT>& K,
+                                                     const ChipGeom<NT>& G, int64_t base, const ChipRot* R,
                                                      const uint32_t* lut, double2* strip_lds, double2* rot, int tid,
                                                      int lane, int stride, int edge_lane, double* accr, double* acci) {
     constexpr int A = NT / 2;                       // anchor tap: the centre one (prompt)
@@ -148,7 +251,6 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
     const int n = ep.n;
     const double* shift = K.shift;
     const double* step = K.step;
-    const double* inv_step = K.inv_step;
     double2* strip = strip_lds + tid * kSlots;
     const int wlane = threadIdx.x & 63;
 #pragma unroll
@@ -156,21 +258,11 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
 
     // ---- epoch geometry (wave-uniform): chips q0 .. q_last of the anchor tap; q0+1 .. q_last-1 are whole
     const double dphi_u = uniform(dphi), rem_carrier_u = uniform(ep.rem_carrier);
-    const int q0 = (int)ceil(shift[A]);
-    double y_last = (double)(n - 1) * step[A];
-    y_last = y_last + shift[A];
-    const int q_last = (int)ceil(y_last);
-    const int F = q_last - q0 - 1;                  // whole chips
-    int head_end = n, tail_start = n;
-    if (F > 0) {
-        bool nr = false;
-        head_end = chip_first_above_exact(chip_first_above((double)q0, shift[A], inv_step[A], nr), (double)q0, step[A], shift[A]);
-        tail_start = chip_first_above_exact(chip_first_above((double)(q_last - 1), shift[A], inv_step[A], nr),
-                                            (double)(q_last - 1), step[A], shift[A]);
-        head_end = __builtin_amdgcn_readfirstlane(head_end);
-        tail_start = __builtin_amdgcn_readfirstlane(tail_start);
-    }
-    const int64_t base = ep.start_sample % capacity;   // (the caller guarantees base + n + 32 <= capacity)
+    const int q0 = __builtin_amdgcn_readfirstlane(G.q0);
+    const int F = __builtin_amdgcn_readfirstlane(G.F);                  // whole chips
+    const int head_end = __builtin_amdgcn_readfirstlane(G.head_end);
+    const int tail_start = __builtin_amdgcn_readfirstlane(G.tail_start);
+    // (the caller guarantees base + n + 32 <= capacity)
     // (the straight-line forms build their samples from the sign-flipped image of the ring: see biased_sample())
     const char* ring_base = static_cast<const char*>(KM != 0 && (KS != 0 || KI != 0) && SDR_BIASED_CVT ? ring_flipped : ring) + base * 2;
 
@@ -184,42 +276,24 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
     double biasc[3] = {0.0, 0.0, 0.0}, biass[3] = {0.0, 0.0, 0.0};   // (biased conversion) the offset's share of a sum of kHalf - 2 / - 1 / - 0 samples
     // samples per chip as Q32.32, and the distance to a lane's next block: D or D + 1 samples
     const double two32 = 4294967296.0;
-    const int64_t Tfx = (int64_t)rint(inv_step[A] * two32);
-    const int64_t stride_fx = (int64_t)stride * Tfx;
+    int64_t Tfx = G.Tfx;
+    int64_t stride_fx = (int64_t)stride * Tfx;
     const int Dmin = (int)(stride_fx >> 32);
+    // (read from the plan these arrive in scalar registers, which the rotations of the sample loop need: the per-lane
+    // 64-bit arithmetic of the block boundaries takes them from vector registers, as when a wave derives them itself)
+    if constexpr (kStatic) asm volatile("" : "+v"(Tfx), "+v"(stride_fx));
     double rd0c = 1.0, rd0s = 0.0, rd1c = 1.0, rd1s = 0.0;  // the carrier rotations over D and D + 1 samples
     {
         double sn = 0.0, cs = 0.0;
         if constexpr (kStatic) {
-            // one evaluation per epoch serves both: lanes 0 .. 25 the in-block rotations, lanes 32 / 33 the two
-            // block-to-block ones
-            const double mult = wlane < 32 ? (double)wlane : (double)(Dmin + (wlane & 1));
-            sincos_reduced(-mult * dphi_u, &sn, &cs);
+            // (worked out by the host with the plan: chip_rotations())
+            static_assert(kHalf == kStaticHalf, "the plan's rotations are laid out for half blocks of 13 samples");
 #pragma unroll
-            for (int k = 1; k <= kHalf; ++k) urc[k] = lane_value(cs, k), urs[k] = lane_value(sn, k);
-            rd0c = lane_value(cs, 32), rd0s = lane_value(sn, 32);
-            rd1c = lane_value(cs, 33), rd1s = lane_value(sn, 33);
+            for (int k = 1; k <= kHalf; ++k) urc[k] = R->urc[k], urs[k] = R->urs[k];
+            rd0c = R->rd0c, rd0s = R->rd0s, rd1c = R->rd1c, rd1s = R->rd1s;
             if constexpr (SDR_BIASED_CVT) {
-                // B_n = 4224 * (1 + 1j) * sum_{k < n} exp(-1j*k*dphi): inclusive prefix sums over lanes 0 .. 15 (one DPP row)
-                double pc = cs, psn = sn;
-                auto shifted = [](double v, auto ctrl) {      // the value `ctrl` lanes to the left in the row of 16, 0.0 beyond its start
-                    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), decltype(ctrl)::value, 0xf, 0xf, false);
-                    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), decltype(ctrl)::value, 0xf, 0xf, false);
-                    return __hiloint2double(hi, lo);
-                };
-                static_for<0, 4>([&](auto st) {               // row_shr:1, 2, 4, 8
-                    constexpr int ctrl = 0x110 + (1 << decltype(st)::value);
-                    pc += shifted(pc, std::integral_constant<int, ctrl>{});
-                    psn += shifted(psn, std::integral_constant<int, ctrl>{});
-                });
-                // (both components of a sample carry the offset: its share of a sum is 4224 * (1 + 1j) * sum r_k)
-                {
-                    const double re = pc - psn, im = pc + psn;
-                    pc = re * kCvtBias, psn = im * kCvtBias;
-                }
-                biasc[0] = lane_value(pc, kHalf - 3), biass[0] = lane_value(psn, kHalf - 3);   // n = kHalf - 2
-                biasc[1] = lane_value(pc, kHalf - 2), biass[1] = lane_value(psn, kHalf - 2);   // n = kHalf - 1
-                biasc[2] = lane_value(pc, kHalf - 1), biass[2] = lane_value(psn, kHalf - 1);   // n = kHalf
+#pragma unroll
+                for (int i = 0; i < 3; ++i) biasc[i] = R->biasc[i], biass[i] = R->biass[i];
             }
         } else if (wlane < kChipMax) {
             sincos_reduced(-(double)wlane * dphi_u, &sn, &cs);
@@ -231,36 +305,18 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
     const int rounds = F > 0 ? (F + stride - 1) / stride : 0;
     if (rounds > 0) {
         // ---- the fixed-point line of the anchor tap, and each tap's constant offset on it
-        const int64_t Ufx = (int64_t)floor(-shift[A] * inv_step[A] * two32);
-        const int M = (int)(Tfx >> 32);                                   // block length M or M + 1
-        bad = bad || M < 1 || M + 1 > kChipMax || F > 16384 || (KM != 0 && M != KM);
+        int64_t Ufx = G.Ufx;
+        const int M = (int)(G.Tfx >> 32);                                 // block length M or M + 1
+        if constexpr (kStatic) asm volatile("" : "+v"(Ufx));
+        bad = bad || G.bad != 0;
         int m[NT], J[NT];
         uint64_t delta[NT];
         unsigned evmask = (1u << M) | (2u << M);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            m[t] = M, J[t] = 0, delta[t] = 0;
-            if (t == A) continue;
-            // tap t sits on chip q + J_t at the block start of anchor chip q; its switch to q + J_t + 1 comes
-            // delta_t >= 0 samples later (delta_t < T)
-            const int64_t Ut = (int64_t)floor(-shift[t] * inv_step[t] * two32);
-            int j = (int)ceil(shift[t] - shift[A]) - 1;
-            int64_t d = (Ut - Ufx) + (int64_t)(1 + j) * Tfx;
-            if (d < 0) {
-                d += Tfx;
-                ++j;
-            } else if (d >= Tfx) {
-                d -= Tfx;
-                --j;
-            }
-            bad = bad || d < 0 || d >= Tfx;
-            J[t] = j;
-            delta[t] = (uint64_t)d;
-            m[t] = (int)(d >> 32);
-            bad = bad || (KS != 0 && (m[t] != KS || j != (t < A ? -1 : 0)));   // (KS: the tap sits on chip q - 1 / q at the block start)
-            // (KI: on chip q + (t - A) - 1 and switching at the block's first sample, or on q + (t - A) until its end)
-            bad = bad || (KI != 0 && !((j == (t - A) * KI - 1 && m[t] == 0) || (j == (t - A) * KI && m[t] >= M)));
-            evmask |= (1u << m[t]) | (2u << m[t]);
+            m[t] = G.m[t], J[t] = G.J[t], delta[t] = G.delta[t];
+            if constexpr (kStatic) asm volatile("" : "+v"(m[t]), "+v"(J[t]), "+v"(delta[t]));
+            if (t != A) evmask |= (1u << m[t]) | (2u << m[t]);
         }
         const int k_last = M + 1;                       // no prefix beyond P_(M+1) is ever read
         int rank[NT];                                   // strip slot of position m_t (m_t + 1 sits in the next one)

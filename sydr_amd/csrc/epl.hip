@@ -19,6 +19,9 @@
 // The carrier replica exp(1j*(-(f*2.0*pi*(i/fs)) + rem)) is evaluated once per lane in fp64 (exact range reduction +
 // minimax sincos) and advanced by precomputed fp64 rotations inside a block and from block to block, which agrees
 // with the reference to ~1e-15 relative on the accumulators (the bar is 1e-6).
+#include <algorithm>
+#include <thread>
+
 #include "correlator.h"
 #include "correlator_chip.h"
 
@@ -66,8 +69,9 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (
                                                        int lut_words, int lut_stride,
                                                        const double* __restrict__ spacing, double fs,
                                                        int tap0, int n_taps_total,
-                                                       double* __restrict__ out) {
+                                                       double* __restrict__ out, const void* __restrict__ setups) {
     constexpr int kThreads = kWaveThreads * WPW;
+    constexpr bool kPre = W == kChipMax && FMT == SDR_FMT_CI8 && KM != 0 && (KS != 0 || KI != 0);   // the plan holds a ChipSetup per item
     extern __shared__ double smem[];
     double* red = smem;
     double2* prefix = reinterpret_cast<double2*>(red + WPW * 2 * NT);          // boundary variants: kThreads*9 slots; chip variant: strips + rotations
@@ -75,7 +79,8 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (
     uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + kScratchSlots);
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    // (the wave number as a scalar: what is indexed with it -- the item, its setup in the plan -- is then read with scalar loads)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 #ifdef SDR_TRACE_WG
     const unsigned long long t_start = wall_clock64();
 #endif
@@ -90,7 +95,8 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (
     const int column = (int)(blockIdx.x % group_stride);
     const sdr_epl_item it = items[have ? item : (column < n_items ? column : n_items - 1)];
     stage_lut<kThreads>(lut, luts + (size_t)it.code_slot * lut_stride, lut_words, tid);
-    const double dphi = carrier_step(it.carrier_hz, fs);
+    double dphi;
+    if constexpr (!kPre) dphi = carrier_step(it.carrier_hz, fs);
     EpochParams ep;
     ep.start_sample = it.start_sample;
     ep.n = it.n_samples;
@@ -99,18 +105,40 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (
     ep.rem_code = it.rem_code;
     ep.code_step = it.code_step;
     EpochConsts<NT> K;
-    if constexpr (W == kChipMax && FMT == SDR_FMT_CI8)
+    ChipGeom<NT> G;
+    const ChipRot* rot_plan = nullptr;
+    int64_t base = -1;
+    if constexpr (kPre) {
+        // everything wave-uniform that is not a sincos was worked out by the host when the plan was made: scalar loads
+        const ChipSetup<NT>& S = static_cast<const ChipSetup<NT>*>(setups)[have ? item : 0];
+        dphi = S.dphi;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            K.shift[q] = S.shift[q], K.step[q] = S.step[q], K.inv_step[q] = S.inv_step[q];
+            // (only the exact re-evaluations near a sample and the edge samples read these: vector registers, of which
+            // there are enough -- the scalar ones hold the sample loop's rotations)
+            asm volatile("" : "+v"(K.shift[q]), "+v"(K.step[q]), "+v"(K.inv_step[q]));
+        }
+        G = S.g;
+        rot_plan = &S.r;
+        base = S.base;
+    } else if constexpr (W == kChipMax && FMT == SDR_FMT_CI8) {
         compute_tap_constants<NT>(K, ep, spacing + tap0);   // (the chip-aligned core evaluates its own rotations)
-    else
+        if (chip_variant_applies(ep, capacity)) {
+            base = ep.start_sample % capacity;
+            chip_geometry<NT, KM, KS, KI>(ep.n, K.shift, K.step, K.inv_step, G);
+        }
+    } else {
         compute_constants<NT>(K, ep, spacing + tap0, dphi, kWaveThreads);
+    }
     __syncthreads();  // replica staged
     if (WPW > 1 && !have) return;
 
     double accr[NT], acci[NT];
     if constexpr (W == kChipMax && FMT == SDR_FMT_CI8) {
         // chip-aligned blocks (correlator_chip.h); an epoch it does not cover is redone per sample
-        const bool done = chip_variant_applies(ep, capacity) &&
-                          correlate_epoch_chip<NT, true, KM, KS, KI>(ring, ring_flipped, capacity, ep, dphi, K, lut, prefix,
+        const bool done = base >= 0 &&
+                          correlate_epoch_chip<NT, true, KM, KS, KI>(ring, ring_flipped, capacity, ep, dphi, K, G, base, rot_plan, lut, prefix,
                                                          prefix + kThreads * chip_strip_slots<NT>() + wave * kChipMax,
                                                          tid, lane, kWaveThreads, lane, accr, acci);
         if (!done) {
@@ -184,7 +212,8 @@ int ensure_doubled_luts(sdr_engine* e, hipStream_t stream) {
 
 template <int FMT, int NT>
 void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
-                int tap0, int n_taps_total, int lut_words, int wide, int group_stride, bool doubled, double* d_out) {
+                int tap0, int n_taps_total, int lut_words, int wide, int group_stride, bool doubled, double* d_out,
+                const void* d_setups) {
     // long replicas: four waves (four epochs of one channel) per workgroup around one staged table
     const int wpw = (lut_words >= kLongLutWords && group_stride > 0) ? 4 : 1;
     const int threads = kWaveThreads * wpw;
@@ -199,11 +228,12 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), shmem, stream, e->iq, (const void*)e->iq_flip, e->iq_capacity, d_items, n_items, stride,
                            doubled ? e->luts2 : e->luts, lut_words, doubled ? e->lut2_stride : e->lut_stride, d_spacing, fs, tap0,
-                           n_taps_total, d_out);
+                           n_taps_total, d_out, d_setups);
     };
     constexpr bool kOdd = NT == 3 || NT == 5;               // (the compile-time tap geometries exist for these)
-    const bool ki = (wide & kVariantKI) != 0 && FMT == SDR_FMT_CI8 && kOdd;
-    const bool ks = (wide & kVariantKS12) != 0 && FMT == SDR_FMT_CI8 && NT == 3;
+    // (the straight-line kernels read the plan's per-item setups: without them the run-time-position kernel serves the list)
+    const bool ki = (wide & kVariantKI) != 0 && FMT == SDR_FMT_CI8 && kOdd && d_setups != nullptr;
+    const bool ks = (wide & kVariantKS12) != 0 && FMT == SDR_FMT_CI8 && NT == 3 && d_setups != nullptr;
     wide &= 255;
     if (wpw == 4) {
         if (ki)                                              // taps whole (half-)chips apart: configs 4-5
@@ -238,22 +268,22 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
 
 template <int FMT>
 void launch_fmt(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
-                int n_taps, int lut_words, int wide, int group_stride, bool doubled, double* d_out) {
+                int n_taps, int lut_words, int wide, int group_stride, bool doubled, double* d_out, const void* d_setups) {
     // Taps are served in register-resident chunks of 5/3/2/1.
     int t0 = 0;
     while (t0 < n_taps) {
         int left = n_taps - t0;
         if (left >= 5) {
-            launch_one<FMT, 5>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, doubled, d_out);
+            launch_one<FMT, 5>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, doubled, d_out, d_setups);
             t0 += 5;
         } else if (left >= 3) {
-            launch_one<FMT, 3>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, doubled, d_out);
+            launch_one<FMT, 3>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, doubled, d_out, d_setups);
             t0 += 3;
         } else if (left == 2) {
-            launch_one<FMT, 2>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, doubled, d_out);
+            launch_one<FMT, 2>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, doubled, d_out, d_setups);
             t0 += 2;
         } else {
-            launch_one<FMT, 1>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, doubled, d_out);
+            launch_one<FMT, 1>(e, stream, d_items, n_items, d_spacing, fs, t0, n_taps, lut_words, wide, group_stride, doubled, d_out, d_setups);
             t0 += 1;
         }
     }
@@ -265,6 +295,8 @@ struct sdr_epl_plan {
     sdr_epl_item* d_items = nullptr;
     double* d_out = nullptr;
     double* d_spacing = nullptr;
+    char* d_setups = nullptr;   // straight-line kernels: one ChipSetup<n_taps> per item (correlator_chip.h), worked out by the host
+    size_t setup_bytes = 0;     // sizeof(ChipSetup<n_taps>), 0: none
     int n_items = 0;
     int n_taps = 0;
     int lut_words = 0;
@@ -279,6 +311,53 @@ struct sdr_epl_plan {
     // exactly these instead of the whole device
     std::vector<std::pair<hipStream_t, hipEvent_t>> ran_on;
 };
+
+// The per-epoch setup of the straight-line kernels (ChipSetup: tap constants, epoch geometry, ring position), item by
+// item as the kernels with run-time positions derive it per wave -- the same functions, the same IEEE operations (this
+// file is compiled with -ffp-contract=off on both sides); only 1/step is a division here and a Newton step there, and it
+// only ever predicts positions that are re-checked exactly near a sample.
+template <int NT, int KS, int KI>
+static void fill_chip_setups(const sdr_epl_item* items, int n_items, const double* spacing, double fs, int64_t capacity,
+                             std::vector<char>& bytes) {
+    bytes.resize((size_t)n_items * sizeof(sdr::ChipSetup<NT>));
+    sdr::ChipSetup<NT>* out = reinterpret_cast<sdr::ChipSetup<NT>*>(bytes.data());
+    // (~2 us per item, most of it the sixteen sincos evaluations: long lists are cut over the host's cores)
+    const int n_threads = n_items < 4096 ? 1 : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    auto fill = [&](int lo, int hi) {
+    for (int i = lo; i < hi; ++i) {
+        const sdr_epl_item& it = items[i];
+        sdr::ChipSetup<NT> S = {};
+        S.dphi = sdr::carrier_step(it.carrier_hz, fs);
+        const double nd = (double)it.n_samples;
+        for (int t = 0; t < NT; ++t) {             // compute_tap_constants(): np.linspace(shift, code_step*n + shift, n, endpoint=False)
+            const double shift = it.rem_code + spacing[t];
+            double stop = it.code_step * nd;
+            stop = stop + shift;
+            const double delta = stop - shift;
+            S.shift[t] = shift;
+            S.step[t] = delta / nd;
+            S.inv_step[t] = 1.0 / S.step[t];
+        }
+        const int64_t base = it.start_sample % capacity;
+        const bool applies = it.code_step >= sdr::kChipMinCodeStep && it.code_step <= sdr::kChipMaxCodeStep &&
+                             base + it.n_samples + 32 <= capacity;          // chip_variant_applies()
+        S.base = applies ? base : -1;
+        if (applies) {
+            sdr::chip_geometry<NT, 24, KS, KI>(it.n_samples, S.shift, S.step, S.inv_step, S.g);
+            sdr::chip_rotations(S.dphi, (int)(((int64_t)kWaveThreads * S.g.Tfx) >> 32), S.r);   // (one wave per epoch: a lane's blocks are 64 chips apart)
+        }
+        out[i] = S;
+    }
+    };
+    if (n_threads == 1) {
+        fill(0, n_items);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t)
+            pool.emplace_back(fill, (int)((int64_t)n_items * t / n_threads), (int)((int64_t)n_items * (t + 1) / n_threads));
+        for (auto& th : pool) th.join();
+    }
+}
 
 // Host-side check that no item can index outside the ring or the staged LUT.
 // scale = 2: the variant is chosen for the half-chip view (2*rem_code, 2*code_step, 2*spacing against tables of twice the length).
@@ -444,6 +523,25 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
                              hipMemcpyHostToDevice, e->stream);
     if (err == hipSuccess)
         err = hipMemcpyAsync(p->d_spacing, doubled ? spacing2 : spacing, n_taps * sizeof(double), hipMemcpyHostToDevice, e->stream);
+    std::vector<char> setups;
+    if (err == hipSuccess && e->iq_fmt == SDR_FMT_CI8 && (wide & (kVariantKS12 | kVariantKI))) {
+        const sdr_epl_item* src = doubled ? items2.data() : items;
+        const double* spc = doubled ? spacing2 : spacing;
+        if ((wide & kVariantKS12) && n_taps == 3) fill_chip_setups<3, 12, 0>(src, n_items, spc, fs, e->iq_capacity, setups);
+        else if ((wide & kVariantKI) && n_taps == 3) fill_chip_setups<3, 0, 1>(src, n_items, spc, fs, e->iq_capacity, setups);
+        else if ((wide & kVariantKI) && n_taps == 5) fill_chip_setups<5, 0, 1>(src, n_items, spc, fs, e->iq_capacity, setups);
+        if (!setups.empty()) {
+            p->setup_bytes = setups.size() / (size_t)n_items;
+            if (use_workspaces) {
+                if (sdr_devbuf_reserve(e, &e->ws_setups, setups.size()) != SDR_OK) err = hipErrorOutOfMemory;
+                else p->d_setups = (char*)e->ws_setups.ptr;
+            } else {
+                err = hipMalloc(&p->d_setups, setups.size());
+            }
+            if (err == hipSuccess)
+                err = hipMemcpyAsync(p->d_setups, setups.data(), setups.size(), hipMemcpyHostToDevice, e->stream);
+        }
+    }
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
     if (err != hipSuccess) {
         sdr_epl_plan_destroy(e, p);
@@ -480,14 +578,15 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
     const sdr_epl_item* items = p->d_items + first;
     double* out = p->d_out + (size_t)first * 2 * p->n_taps;
     const int n = (int)count;
+    const void* setups = p->d_setups ? p->d_setups + (size_t)first * p->setup_bytes : nullptr;
     {
         hipStream_t st = ctx->stream;
         ProfScope ps(e, "epl_kernel", st);
         switch (e->iq_fmt) {
-            case SDR_FMT_CI8: launch_fmt<SDR_FMT_CI8>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, p->doubled, out); break;
-            case SDR_FMT_CI16: launch_fmt<SDR_FMT_CI16>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, p->doubled, out); break;
-            case SDR_FMT_CF32: launch_fmt<SDR_FMT_CF32>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, p->doubled, out); break;
-            default: launch_fmt<SDR_FMT_CF64>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, p->doubled, out); break;
+            case SDR_FMT_CI8: launch_fmt<SDR_FMT_CI8>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, p->doubled, out, setups); break;
+            case SDR_FMT_CI16: launch_fmt<SDR_FMT_CI16>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, p->doubled, out, setups); break;
+            case SDR_FMT_CF32: launch_fmt<SDR_FMT_CF32>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, p->doubled, out, setups); break;
+            default: launch_fmt<SDR_FMT_CF64>(e, st, items, n, p->d_spacing, p->fs, p->n_taps, p->lut_words, p->wide, p->group_stride, p->doubled, out, setups); break;
         }
     }
     SDR_HIP(hipGetLastError());
@@ -535,6 +634,7 @@ void sdr_epl_plan_destroy(sdr_engine* e, sdr_epl_plan* p) {
         if (p->d_items) (void)hipFree(p->d_items);
         if (p->d_out) (void)hipFree(p->d_out);
         if (p->d_spacing) (void)hipFree(p->d_spacing);
+        if (p->d_setups) (void)hipFree(p->d_setups);
     }
     delete p;
 }

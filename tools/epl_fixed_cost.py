@@ -1,5 +1,6 @@
 """Per-epoch (fixed) against per-sample cost of epl_kernel at one code step: launches of 32 000 items of n samples,
-n varied at a fixed step; t(n) = a + b * n fitted per variant.  `--step 0.1023` (10 MHz, default) / 0.25575 / 0.04092."""
+n varied at a fixed step; t(n) = a + b * n fitted per variant.  `--step 0.1023` (10 MHz, default) / 0.25575 / 0.04092;
+`--only-n N`: one length only (under `rocprofv3 --pmc`: tools/pmc_fixed_cost.sh)."""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,7 +24,7 @@ for name, opts in options:
     for k, v in opts.items():
         e.set_option(k, v)
     pts = []
-    for n in (full // 4, full // 2, full):
+    for n in ([int(sys.argv[sys.argv.index('--only-n') + 1])] if '--only-n' in sys.argv else (full // 4, full // 2, full)):
         items = make_items(np.arange(n_items) % 32, n, rng.integers(0, cap - n - 64, n_items), 1000.0, 0.3, 0.01, step)
         plan = e.epl_plan(items, (-0.5, 0.0, 0.5), 1.023e6 / step)
         plan.run(); e.sync()
