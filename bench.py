@@ -762,7 +762,9 @@ def main():
         eng.load_gps_code(s, sat["prn"])
     eng.iq_synth(all_sats, FS, 12.0, 20260003, 0, total)
     items, n_epochs = truth_items(sats, FS, total)
-    plan = eng.epl_plan(items, SPACING, FS)
+    t_plan = time.perf_counter()
+    plan = eng.epl_plan(items, SPACING, FS)                 # validation, the per-epoch setups of the straight-line kernel, upload
+    plan_create_s = time.perf_counter() - t_plan
     n_run = n_epochs * N_CH                                 # every whole code period of the stream, every channel
     pass_samples = int(items["n_samples"][:n_run].sum())
     batch_stream = eng.stream_create()                      # one HIP stream per channel batch (north_star)
@@ -841,6 +843,9 @@ def main():
         "x_realtime": stream_samples / elapsed / FS,          # seconds of THE stream (all channels tracked) per second
         "channel_Msamples_per_s": job_ch_samples / elapsed / 1e6,
         "multi_gpu": multi_gpu,                               # N > 1: who took part, per-rank rates, cross-rank bitwise check
+        # outside the timed region, once per stream: the host checks every item and works out each epoch's setup
+        # (tap constants, chip geometry, carrier rotations: sdr_epl_plan_create); the steps re-run the same plan
+        "plan": {"create_ms": plan_create_s * 1e3, "items": int(len(items)), "host_threads": min(16, os.cpu_count() or 1)},
     }
     result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "epl_kernel",

@@ -7,8 +7,8 @@ HBM bytes per launch = 2 * FETCH_SIZE*1024 (gfx950: FETCH_SIZE reads exactly hal
 streaming read, MI355X_MICROARCH.md section HBM) + WRITE_SIZE*1024.
 
 Kernel variants are kept apart (`epl_kernel<0, 3, 26, 24>` is the headline launch, `<0, 5, ...>` the
-multi-GNSS one); the PCPS figure is the sum over every kernel of one sdr_pcps call (calls counted by
-their one ratio_kernel dispatch)."""
+multi-GNSS one); the PCPS figure is the sum over every kernel of one sdr_pcps call of the headline search (dispatches
+walked in order, a call ends with its one ratio_kernel dispatch; calls at other rates are left out)."""
 import collections
 import csv
 import glob
@@ -105,17 +105,36 @@ if multi:
         for counter, key in (("SQ_INSTS_VALU", "valu"), ("SQ_INSTS_LDS", "lds")):
             if m.get(counter):
                 info[f"multignss_{key}_insts_per_wave"] = big(m[counter]) / big(m["SQ_WAVES"])
-calls = len(agg.get("ratio_kernel", {}).get("FETCH_SIZE", []))
-if calls:
-    fetch = write = 0.0
-    per_kernel = {}
-    for k in agg:
-        if any(k.startswith(p) for p in PCPS) and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
-            f_, w_ = sum(agg[k]["FETCH_SIZE"]) * 1024 / calls, sum(agg[k]["WRITE_SIZE"]) * 1024 / calls
-            per_kernel[k] = {"read": 2 * f_, "write": w_}
-            fetch += f_
-            write += w_
-    info.update({"pcps_hbm_bytes_per_call": 2 * fetch + write, "pcps_calls_profiled": calls, "pcps_per_kernel": per_kernel,
+# The acquisition figure: the kernels of ONE sdr_pcps call of the headline search (N = 25 000: the calls that contain a
+# fast25k:: kernel -- the bench also runs searches at other rates, which share the small kernels).  Dispatches are walked
+# in order per counter pass; a call ends with its one ratio_kernel dispatch.
+def pcps_calls(counter):
+    per_kernel, calls = collections.defaultdict(float), 0
+    for path in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+        rows_ = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+        rows_.sort(key=lambda r: int(r["Dispatch_Id"]))
+        cur = []
+        for r in rows_:
+            k = short(r["Kernel_Name"])
+            if not any(k.startswith(p) for p in PCPS):
+                continue
+            cur.append((k, float(r["Counter_Value"])))
+            if k == "ratio_kernel":
+                if any(name.startswith("fast25k") for name, _ in cur):
+                    calls += 1
+                    for name, v in cur:
+                        per_kernel[name] += v
+                cur = []
+    return per_kernel, calls
+
+
+fetch_k, calls = pcps_calls("FETCH_SIZE")
+write_k, calls_w = pcps_calls("WRITE_SIZE")
+if calls and calls_w:
+    per_kernel = {k: {"read": 2 * fetch_k.get(k, 0.0) * 1024 / calls, "write": write_k.get(k, 0.0) * 1024 / calls_w}
+                  for k in sorted(set(fetch_k) | set(write_k))}
+    total = sum(v["read"] + v["write"] for v in per_kernel.values())
+    info.update({"pcps_hbm_bytes_per_call": total, "pcps_calls_profiled": calls, "pcps_per_kernel": per_kernel,
                  "pcps_workload": "sdr_pcps: 32 PRNs x 41 bins x 25000 samples, no map (1.05e9 algorithmic bytes)"})
 json.dump(info, open(os.path.join(repo, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(info, indent=1))
