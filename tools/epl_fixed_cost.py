@@ -19,6 +19,7 @@ n_items = 32000
 full = int(1022.5 / step)
 options = [("default", {})]
 if step <= 1 / 16:
+    options.append(("no_split_variant", {"epl_no_split_variant": 1}))      # run-time switch positions, LDS strip
     options.append(("no_chip_variant", {"epl_no_chip_variant": 1}))
 for name, opts in options:
     for k, v in opts.items():
