@@ -196,6 +196,8 @@ def kernel_of_variant(variant, n_taps, waves_per_group=1):
     """Name of the epl_kernel instantiation a plan of this variant launches on a ci8 ring, as tools/summarize_pmc.py
     spells it -- the key that ties committed counters (profiles/pmc_traffic.json) to the kernel a run actually used."""
     w = variant & 255
+    if variant & 8192:                                       # two chips per lane (correlator_chip2.h)
+        return f"epl2_kernel<{6 if variant & 16384 else 5}>"
     km = 24 if w >= 50 else 0
     ks = 12 if (variant & 0xF00) == 0xC00 else 0
     ki = 1 if variant & 4096 else 0
@@ -282,7 +284,7 @@ def verify_across_ranks(eng, dist, torch, rank, local_rank, world, all_sats, min
 def ref_config_leg(eng, cpu_seconds=4.0):
     """The reference's own shipped configuration (config/receiver.ini:18-20: 10 MHz, 8-bit I/Q;
     config/channels/channel_GPS_L1CA_kaplan.ini:6-10: PCPS with a 300 Hz grid, 1 x 10 ms non-coherent; taps +-0.5 chip),
-    32 channels: tracking throughput (the 8-sample boundary variant of the correlator serves this rate) and
+    32 channels: tracking throughput (the two-chips-per-lane kernel of correlator_chip2.h serves this rate) and
     acquisition time, each with its roofline by algorithmic bytes, the oracle timed beside it and checked against it."""
     from oracle import sydr_oracle as orc
     from sydr_amd.engine import FMT_CI8

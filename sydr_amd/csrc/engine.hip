@@ -184,6 +184,7 @@ int sdr_set_option(sdr_engine* e, const char* name, int value) {
     else if (!strcmp(name, "epl_no_chip_variant")) e->epl_no_chip = value != 0;
     else if (!strcmp(name, "epl_no_split_variant")) e->epl_no_split = value != 0;
     else if (!strcmp(name, "epl_no_half_chip_view")) e->epl_no_double = value != 0;
+    else if (!strcmp(name, "epl_no_two_chip_variant")) e->epl_no_chip2 = value != 0;
     else return sdr_fail(SDR_ERR_INVALID, "unknown option '%s'", name);
     return SDR_OK;
 }

@@ -104,6 +104,7 @@ struct sdr_engine {
     bool epl_no_chip = false;        // diagnostics: keep the 16-sample boundary variant where the chip-aligned one would run
     bool epl_no_double = false;      // diagnostics: keep the boundary variant where the half-chip view would run
     bool prof_calls_only = false;    // sdr_prof_enable(e, 2): only the "call_*" scopes record
+    bool epl_no_chip2 = false;       // diagnostics: keep the 8-sample boundary variant where the two-chip kernel would run
     bool epl_no_split = false;       // diagnostics: keep the run-time switch positions where the KS = 12 kernel would run
     int pcps_prn_chunk = 0;          // diagnostics: PRNs per inverse sweep (0 = as many as the work buffers hold)
     bool pcps_force_map = false;     // diagnostics / tests: materialise the map even when the caller does not ask for it

@@ -24,6 +24,7 @@
 
 #include "correlator.h"
 #include "correlator_chip.h"
+#include "correlator_chip2.h"
 
 #ifdef SDR_TRACE_WG
 // Debug build only (tools/wg_trace.py): per-workgroup start/end clock and hardware id.
@@ -42,6 +43,7 @@ constexpr int kWaveThreads = 64;  // one wave per channel-epoch: the ~5 us fixed
 // compiled in), then the compile-time tap geometry
 constexpr int kVariantKS12 = 256 * 12;   // three taps, the outer ones switching 12.x samples into the anchor's block
 constexpr int kVariantKI = 4096;         // taps whole (half-)chips apart: no switch inside a block
+constexpr int kVariantC2 = 8192;         // two chips per lane (correlator_chip2.h): segments of five samples, + 16384: of six
 constexpr int kLongLutWords = 4096;  // replicas of 16 KB and more (multi-period / BOC half-chip codes): four epochs share a staged copy
 
 // Dynamic LDS: [red: WPW*2*NT doubles][scratch: strips / rotations][lut: lut_words uint32]
@@ -210,6 +212,44 @@ int ensure_doubled_luts(sdr_engine* e, hipStream_t stream) {
     return SDR_OK;
 }
 
+// Two chips per lane (correlator_chip2.h): one wave per item, three taps, ci8 ring; the item's setup comes from the plan.
+// Dynamic LDS: [8 zero words][lut: lut_words uint32].
+template <int SEG>
+__global__ __launch_bounds__(kWaveThreads) void epl2_kernel(const void* __restrict__ ring, const void* __restrict__ ring_flipped,
+                                                            int64_t capacity, const sdr_epl_item* __restrict__ items, int n_items,
+                                                            const uint32_t* __restrict__ luts, int lut_words, int lut_stride,
+                                                            const double* __restrict__ spacing, double fs, double* __restrict__ out,
+                                                            const Chip2Setup<SEG>* __restrict__ setups) {
+    extern __shared__ double smem[];
+    uint32_t* zero_words = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* lut = zero_words + 8;
+    const int lane = threadIdx.x;
+    const int item = blockIdx.x;
+    const sdr_epl_item it = items[item];
+    stage_lut<kWaveThreads>(lut, luts + (size_t)it.code_slot * lut_stride, lut_words, lane);
+    if (lane < 8) zero_words[lane] = 0u;
+    EpochParams ep;
+    ep.start_sample = it.start_sample;
+    ep.n = it.n_samples;
+    ep.carrier_hz = it.carrier_hz;
+    ep.rem_carrier = it.rem_carrier;
+    ep.rem_code = it.rem_code;
+    ep.code_step = it.code_step;
+    const Chip2Setup<SEG>& S = setups[item];
+    __syncthreads();  // replica staged
+    double accr[3], acci[3];
+    const bool done = S.base >= 0 && correlate_epoch_chip2<SEG>(ring, ring_flipped, ep, S, lut, zero_words, lane, accr, acci);
+    if (!done) {     // an epoch the scheme does not cover: per sample
+        const double dphi = carrier_step(it.carrier_hz, fs);
+        EpochConsts<3> K2;
+        compute_constants<3>(K2, ep, spacing, dphi, kWaveThreads);
+        correlate_epoch<SDR_FMT_CI8, 3>(ring, capacity, ep, dphi, K2, lut, lane, kWaveThreads, lane, accr, acci);
+    }
+    int slot;
+    const double total = reduce_taps_scatter<3>(accr, acci, lane, slot);
+    if (lane < 8) out[(size_t)item * 6 + slot] = total;
+}
+
 template <int FMT, int NT>
 void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, int n_items, const double* d_spacing, double fs,
                 int tap0, int n_taps_total, int lut_words, int wide, int group_stride, bool doubled, double* d_out,
@@ -359,6 +399,35 @@ static void fill_chip_setups(const sdr_epl_item* items, int n_items, const doubl
     }
 }
 
+// ... and of the two-chip kernel (Chip2Setup); returns the number of items its scheme does not cover (their setups say
+// so, and the kernel redoes them per sample).
+template <int SEG>
+static int fill_chip2_setups(const sdr_epl_item* items, int n_items, const double* spacing, double fs, int64_t capacity,
+                             std::vector<char>& bytes) {
+    bytes.resize((size_t)n_items * sizeof(sdr::Chip2Setup<SEG>));
+    sdr::Chip2Setup<SEG>* out = reinterpret_cast<sdr::Chip2Setup<SEG>*>(bytes.data());
+    const int n_threads = n_items < 4096 ? 1 : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<int> missed(n_threads, 0);
+    auto fill = [&](int w, int lo, int hi) {
+        for (int i = lo; i < hi; ++i) {
+            const sdr_epl_item& it = items[i];
+            if (!sdr::chip2_setup<SEG>(it.n_samples, it.start_sample, capacity, it.carrier_hz, it.rem_code, it.code_step, spacing, fs, out[i]))
+                ++missed[w];
+        }
+    };
+    if (n_threads == 1) {
+        fill(0, 0, n_items);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t)
+            pool.emplace_back(fill, t, (int)((int64_t)n_items * t / n_threads), (int)((int64_t)n_items * (t + 1) / n_threads));
+        for (auto& th : pool) th.join();
+    }
+    int total = 0;
+    for (int m : missed) total += m;
+    return total;
+}
+
 // Host-side check that no item can index outside the ring or the staged LUT.
 // scale = 2: the variant is chosen for the half-chip view (2*rem_code, 2*code_step, 2*spacing against tables of twice the length).
 static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items, const double* spacing,
@@ -475,6 +544,18 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
         }
     }
 
+    // chips of 9.5 .. 10 or 11.5 .. 12 samples, three taps half a chip apart (the reference's shipped 10 MHz): two chips per lane,
+    // if (nearly) every item fits the scheme
+    std::vector<char> setups2;
+    if (e->iq_fmt == SDR_FMT_CI8 && n_taps == 3 && (wide & 255) == 8 && !doubled && !e->epl_no_chip2) {
+        const int m2 = (int)std::floor(2.0 / items[0].code_step);
+        int missed = n_items;
+        if (m2 == 19) missed = fill_chip2_setups<5>(items, n_items, spacing, fs, e->iq_capacity, setups2);
+        else if (m2 == 23) missed = fill_chip2_setups<6>(items, n_items, spacing, fs, e->iq_capacity, setups2);
+        if (missed <= n_items / 64) wide = 8 + kVariantC2 + (m2 == 23 ? 2 * kVariantC2 : 0);
+        else setups2.clear();
+    }
+
     sdr_epl_plan* p = new (std::nothrow) sdr_epl_plan();
     if (!p) return sdr_fail(SDR_ERR_NOMEM, "host allocation failed");
     p->n_items = n_items;
@@ -524,12 +605,15 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
     if (err == hipSuccess)
         err = hipMemcpyAsync(p->d_spacing, doubled ? spacing2 : spacing, n_taps * sizeof(double), hipMemcpyHostToDevice, e->stream);
     std::vector<char> setups;
-    if (err == hipSuccess && e->iq_fmt == SDR_FMT_CI8 && (wide & (kVariantKS12 | kVariantKI))) {
+    if (!setups2.empty()) setups.swap(setups2);
+    if (err == hipSuccess && e->iq_fmt == SDR_FMT_CI8 && (wide & 255) >= kChipMax && (wide & (kVariantKS12 | kVariantKI))) {
         const sdr_epl_item* src = doubled ? items2.data() : items;
         const double* spc = doubled ? spacing2 : spacing;
         if ((wide & kVariantKS12) && n_taps == 3) fill_chip_setups<3, 12, 0>(src, n_items, spc, fs, e->iq_capacity, setups);
         else if ((wide & kVariantKI) && n_taps == 3) fill_chip_setups<3, 0, 1>(src, n_items, spc, fs, e->iq_capacity, setups);
         else if ((wide & kVariantKI) && n_taps == 5) fill_chip_setups<5, 0, 1>(src, n_items, spc, fs, e->iq_capacity, setups);
+    }
+    if (err == hipSuccess) {
         if (!setups.empty()) {
             p->setup_bytes = setups.size() / (size_t)n_items;
             if (use_workspaces) {
@@ -571,7 +655,7 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
                         (long long)(first + count), p->n_items);
     if (p->doubled)
         if (int rc = ensure_doubled_luts(e, ctx->stream)) return rc;   // (a slot may have been re-staged since the plan was made)
-    if (e->iq_fmt == SDR_FMT_CI8 && (p->wide & (kVariantKS12 | kVariantKI))) {
+    if (e->iq_fmt == SDR_FMT_CI8 && (p->wide & (kVariantKS12 | kVariantKI | kVariantC2))) {
         const void* flipped = nullptr;                                   // (the straight-line kernels read the flipped ring image)
         if (int rc = sdr_iq_flipped(e, ctx->stream, &flipped)) return rc;
     }
@@ -579,7 +663,19 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
     double* out = p->d_out + (size_t)first * 2 * p->n_taps;
     const int n = (int)count;
     const void* setups = p->d_setups ? p->d_setups + (size_t)first * p->setup_bytes : nullptr;
-    {
+    if (e->iq_fmt == SDR_FMT_CI8 && (p->wide & kVariantC2) && setups) {      // two chips per lane: its own kernel
+        hipStream_t st = ctx->stream;
+        ProfScope ps(e, "epl_kernel", st);
+        const size_t shmem = 8 * sizeof(uint32_t) + (size_t)((p->lut_words + 3) & ~3) * sizeof(uint32_t);
+        if (p->wide & (2 * kVariantC2))
+            hipLaunchKernelGGL(epl2_kernel<6>, dim3(n), dim3(kWaveThreads), shmem, st, e->iq, (const void*)e->iq_flip, e->iq_capacity,
+                               items, n, e->luts, p->lut_words, e->lut_stride, p->d_spacing, p->fs, out,
+                               reinterpret_cast<const sdr::Chip2Setup<6>*>(setups));
+        else
+            hipLaunchKernelGGL(epl2_kernel<5>, dim3(n), dim3(kWaveThreads), shmem, st, e->iq, (const void*)e->iq_flip, e->iq_capacity,
+                               items, n, e->luts, p->lut_words, e->lut_stride, p->d_spacing, p->fs, out,
+                               reinterpret_cast<const sdr::Chip2Setup<5>*>(setups));
+    } else {
         hipStream_t st = ctx->stream;
         ProfScope ps(e, "epl_kernel", st);
         switch (e->iq_fmt) {

@@ -14,7 +14,7 @@ def run(rounds, seed, eng=None):
     eng = eng or Engine(0)
     checked, worst, refused = 0, 0.0, 0
     for r in range(rounds):
-        n_code = int(rng.choice([2046, 3000, 4000, 4092, 5000, 5115, 6138, 8184, 10000, 10230, 12000, 16368, 20460, 25000]))
+        n_code = int(rng.choice([2046, 3000, 4000, 4092, 5000, 5115, 6138, 8184, 10000, 10230, 12000, 16368, 20460, 25000, 50000, 4000, 10000]))
         if r % 5 == 4:
             n_code = int(rng.integers(2046, 12000))          # anything, including sizes with large prime factors
         if r % 10 == 9:

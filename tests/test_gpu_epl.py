@@ -559,3 +559,65 @@ def test_randomised_stress_of_the_straight_line_kernels(engine):
     spec.loader.exec_module(mod)
     checked, worst = mod.run(8, 2026, eng=engine, n_items=80)
     assert checked == 640 and worst < 1e-9
+
+
+@pytest.mark.parametrize("fs,seg", [(10e6, 5), (12e6, 6), (9.8e6, 5)])
+def test_two_chips_per_lane_variant(engine, fs, seg):
+    """Chips of 9.5 .. 10 (11.5 .. 12) samples, taps half a chip apart -- a C/A code at the reference's shipped 10 MHz
+    (config/receiver.ini:18-20), or at 12 MHz: a lane owns two whole chips of the prompt tap, every tap switch at a
+    compile-time position up to + 1 (correlator_chip2.h; the plan holds a host-made setup per item).  Random Doppler on
+    code and carrier, odd and even numbers of whole chips, odd starts, short and two-period epochs, zero code phase;
+    lists with a stray item the scheme does not cover (redone per sample inside the kernel) -- against the oracle, and
+    against the 8-sample boundary variant of the same library."""
+    rng = np.random.default_rng(int(fs) // 1000 + seg)
+    cap = 1 << 18
+    raw = rng.integers(-100, 100, 2 * cap).astype(np.int8)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(8, 1023, 2)
+    for s in range(8):
+        engine.load_gps_code(s, 3 * s + 2)
+    rf = orc.iq_to_complex(raw)
+    spacing = (-0.5, 0.0, 0.5)
+    for group in range(3):
+        n_items = 130
+        step = (1.023e6 + rng.uniform(-6, 6, n_items)) / fs
+        rem_code = rng.uniform(0, step)
+        rem_code[:6] = [0.0, 0.5 * step[1], 0.25 * step[2], 1e-9, step[4] / 2, step[5] * (1 - 1e-12)]
+        periods = np.where(rng.random(n_items) < 0.2, 2, 1)
+        n = np.ceil((1023 * periods - rem_code) / step).astype(np.int64) + rng.integers(-1, 2, n_items)
+        n[6:10] = [25, 3 * 4 * seg, 700, 64 * 4 * seg + 5]            # one block, a few, a round of blocks and a bit
+        if group == 1:
+            n[10:14] = n[10:14] - rng.integers(5, 12, 4)             # other parities of the number of whole chips
+        start = rng.integers(0, cap - 30000, n_items)
+        start[14:18] = [0, 1, cap - int(n[16]) - 40, 2 * (int(start[17]) // 2) + 1]
+        slot = rng.integers(0, 8, n_items)
+        f = rng.uniform(-6000, 6000, n_items)
+        rem_carrier = rng.uniform(0, 2 * np.pi, n_items)
+        if group == 2:                                               # a stray item: twice the code rate -> not this scheme's
+            step[20] *= 0.93
+        items = make_items(slot, n, start, f, rem_carrier, rem_code, step)
+        plan = engine.epl_plan(items, spacing, fs)
+        try:
+            assert plan.variant & 8192 and bool(plan.variant & 16384) == (seg == 6), (group, plan.variant)
+            plan.run()
+            got = plan.fetch()
+        finally:
+            plan.close()
+        engine.set_option("epl_no_two_chip_variant", 1)
+        try:
+            other = engine.epl_batch(items, spacing, fs)
+        finally:
+            engine.set_option("epl_no_two_chip_variant", 0)
+        for k in range(n_items):
+            x = orc.ring_slice(rf, int(start[k]), int(n[k]))
+            ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(3 * int(slot[k]) + 2)), fs, f[k], rem_carrier[k],
+                                   rem_code[k], step[k], spacing))
+            scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 50.0), 2)
+            assert np.max(np.abs(got[k] - ref) / scale) < 1e-9, (group, k, step[k], n[k], got[k], ref)
+            assert np.max(np.abs(other[k] - ref) / scale) < 1e-9, (group, k)
+    # chips of exactly ten samples: every switch on a sample, 2 * T = 20 -- not this scheme's; the plan keeps the boundary variant
+    items = make_items(0, 5000, 3, 100.0, 0.2, 0.01, 0.1)
+    plan = engine.epl_plan(items, spacing, 10.23e6)
+    assert not plan.variant & 8192
+    plan.close()

@@ -18,6 +18,8 @@ rng = np.random.default_rng(1)
 n_items = 32000
 full = int(1022.5 / step)
 options = [("default", {})]
+if 2 / 20 < step <= 2 / 19 or 2 / 24 < step <= 2 / 23:
+    options.append(("no_two_chip_variant", {"epl_no_two_chip_variant": 1}))   # 8-sample groups instead of two chips per lane
 if step <= 1 / 16:
     options.append(("no_split_variant", {"epl_no_split_variant": 1}))      # run-time switch positions, LDS strip
     options.append(("no_chip_variant", {"epl_no_chip_variant": 1}))
