@@ -212,10 +212,13 @@ int ensure_doubled_luts(sdr_engine* e, hipStream_t stream) {
     return SDR_OK;
 }
 
+#ifndef SDR_EPL2_WAVES
+#define SDR_EPL2_WAVES 3   // (a cap of 128 registers for four waves per SIMD spills into scratch: 0.296 instead of 0.192 ms per 32 000 epochs)
+#endif
 // Two chips per lane (correlator_chip2.h): one wave per item, three taps, ci8 ring; the item's setup comes from the plan.
 // Dynamic LDS: [8 zero words][lut: lut_words uint32].
 template <int SEG>
-__global__ __launch_bounds__(kWaveThreads) void epl2_kernel(const void* __restrict__ ring, const void* __restrict__ ring_flipped,
+__global__ __launch_bounds__(kWaveThreads, SDR_EPL2_WAVES) void epl2_kernel(const void* __restrict__ ring, const void* __restrict__ ring_flipped,
                                                             int64_t capacity, const sdr_epl_item* __restrict__ items, int n_items,
                                                             const uint32_t* __restrict__ luts, int lut_words, int lut_stride,
                                                             const double* __restrict__ spacing, double fs, double* __restrict__ out,
@@ -226,8 +229,6 @@ __global__ __launch_bounds__(kWaveThreads) void epl2_kernel(const void* __restri
     const int lane = threadIdx.x;
     const int item = blockIdx.x;
     const sdr_epl_item it = items[item];
-    stage_lut<kWaveThreads>(lut, luts + (size_t)it.code_slot * lut_stride, lut_words, lane);
-    if (lane < 8) zero_words[lane] = 0u;
     EpochParams ep;
     ep.start_sample = it.start_sample;
     ep.n = it.n_samples;
@@ -236,6 +237,8 @@ __global__ __launch_bounds__(kWaveThreads) void epl2_kernel(const void* __restri
     ep.rem_code = it.rem_code;
     ep.code_step = it.code_step;
     const Chip2Setup<SEG>& S = setups[item];
+    stage_lut<kWaveThreads>(lut, luts + (size_t)it.code_slot * lut_stride, lut_words, lane);
+    if (lane < 8) zero_words[lane] = 0u;
     __syncthreads();  // replica staged
     double accr[3], acci[3];
     const bool done = S.base >= 0 && correlate_epoch_chip2<SEG>(ring, ring_flipped, ep, S, lut, zero_words, lane, accr, acci);
