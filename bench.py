@@ -196,8 +196,8 @@ def kernel_of_variant(variant, n_taps, waves_per_group=1):
     """Name of the epl_kernel instantiation a plan of this variant launches on a ci8 ring, as tools/summarize_pmc.py
     spells it -- the key that ties committed counters (profiles/pmc_traffic.json) to the kernel a run actually used."""
     w = variant & 255
-    if variant & 8192:                                       # two chips per lane (correlator_chip2.h)
-        return f"epl2_kernel<{6 if variant & 16384 else 5}>"
+    if (variant >> 13) & 3:                                  # two chips per lane (correlator_chip2.h)
+        return "epl2_kernel<" + {1: "4,9,14,19", 2: "5,11,17,23"}[(variant >> 13) & 3] + ">"
     km = 24 if w >= 50 else 0
     ks = 12 if (variant & 0xF00) == 0xC00 else 0
     ki = 1 if variant & 4096 else 0

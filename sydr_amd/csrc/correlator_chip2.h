@@ -1,25 +1,26 @@
-// Two chips per lane: the straight-line form of correlator_chip.h for codes of 9.5 .. 10 (SEG = 5) or 11.5 .. 12 (SEG = 6)
-// samples per chip -- a C/A code at the reference's shipped 10 MHz (config/receiver.ini:18-20), or at 12 MHz -- three taps
-// half a chip apart, ci8 ring.
-//
-// At these rates one chip is too short for a lane (the per-block work of correlator_chip.h would be paid every ~10
-// samples), and 8 consecutive samples per lane (correlator.h's boundary variant) cost ~30 issue slots per sample.  Here a
-// lane owns TWO whole chips of the prompt tap, q and q + 1: 4*SEG - 1 or 4*SEG samples in which
-//      the early and late tap change chips   SEG - 1 | SEG    samples in      (half a chip: E from q - 1 to q, L from q to q + 1)
-//      the prompt tap changes chips        2*SEG - 1 | 2*SEG                  (q to q + 1)
-//      early and late change again         3*SEG - 1 | 3*SEG                  (E to q + 1, L to q + 2)
-//      the block ends                      4*SEG - 1 | 4*SEG
-// -- every position wave-uniform up to + 1, as in the one-chip forms.  The block is summed as FOUR segments of SEG samples
-// that each start at rotation 0 (SEG - 1 rotations in scalar registers); a segment keeps its sum before and after its last
-// sample, a lane picks the member its boundary needs, and the prefix sums at the four boundaries follow by turning the
-// segments with exp(-1j*SEG*g*dphi):
+// Two chips per lane: the straight-line form of correlator_chip.h with a block of TWO whole chips of the prompt tap, three
+// taps half a chip apart, ci8 ring.  Compiled for the boundary positions P0 < P1 < P2 < P3 (each "or one later"):
+//      <4, 9, 14, 19>     chips of 9.5 .. 10 samples: a C/A code at the reference's shipped 10 MHz (config/receiver.ini:18-20)
+//      <5, 11, 17, 23>    11.5 .. 12 samples: 12 MHz
+// (<12, 24, 36, 48>, the headline 25 MHz, works too and was measured: no faster than the one-chip form there.)
+// At the low rates one chip is too short for a lane (the per-block work of correlator_chip.h would be paid every ~10
+// samples), and 8 consecutive samples per lane (correlator.h's boundary variant) cost ~30 issue slots per sample.  A lane
+// owns chips q and q + 1: P3 or P3 + 1 samples in which
+//      the early and late tap change chips   P0 | P0 + 1   samples in      (half a chip: E from q - 1 to q, L from q to q + 1)
+//      the prompt tap changes chips          P1 | P1 + 1                   (q to q + 1)
+//      early and late change again           P2 | P2 + 1                   (E to q + 1, L to q + 2)
+//      the block ends                        P3 | P3 + 1
+// -- every position wave-uniform up to + 1, as in the one-chip forms.  The block is summed as FOUR segments (samples
+// [0, P0], (P0, P1], (P1, P2], (P2, P3]) that each start at rotation 0 (the longest segment's rotations in scalar
+// registers); a segment keeps its sum before and after its last sample, a lane picks the member its boundary needs, and the
+// prefix sums at the four boundaries follow by turning the segments with exp(-1j*start_g*dphi):
 //      Q1 = P_(s1) = sel_0      Q2 = P_(sP) = f_0 + T1*sel_1      Q3 = P_(s2) = f_0 + T1*f_1 + T2*sel_2      Q4 = P_n = ... + T3*sel_3
 // With the replica words c(q - 1), c(q), c(q + 1), c(q + 2) the taps' shares of the block are
 //      E = (c(q-1) - c(q))*Q1 + (c(q) - c(q+1))*Q3 + c(q+1)*Q4
 //      P =                      (c(q) - c(q+1))*Q2 + c(q+1)*Q4
 //      L = (c(q) - c(q+1))*Q1 + (c(q+1) - c(q+2))*Q3 + c(q+2)*Q4
 // Samples are built with the one-instruction biased conversion from the flipped ring image (correlator_chip.h); what the
-// offset puts into a segment sum of SEG - 1 / SEG samples is two complex constants per epoch.  Block boundaries come from
+// offset puts into a segment sum of L samples is one complex constant per length and epoch.  Block boundaries come from
 // the same Q32.32 line; a boundary within 2^-16 of a sample sends the wave through exact evaluations of the reference
 // expression; a lane that meets a position outside its pair flags the epoch, which is redone per sample.  Everything
 // wave-uniform that is not data -- tap constants, geometry, rotations -- is worked out by the host when the plan is made
@@ -32,8 +33,22 @@
 
 namespace sdr {
 
-template <int SEG>
+template <int P0, int P1, int P2, int P3>
+struct Chip2Shape {
+    static_assert(0 < P0 && P0 < P1 && P1 < P2 && P2 < P3, "boundary positions in order");
+    static constexpr int start(int g) { return g == 0 ? 0 : (g == 1 ? P0 + 1 : (g == 2 ? P1 + 1 : P2 + 1)); }
+    static constexpr int last(int g) { return g == 0 ? P0 : (g == 1 ? P1 : (g == 2 ? P2 : P3)); }   // the segment's last sample (when its boundary is "one later")
+    static constexpr int len(int g) { return last(g) + 1 - start(g); }
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    static constexpr int kMaxLen = cmax(cmax(len(0), len(1)), cmax(len(2), len(3)));
+    static constexpr int kSamples = P3 + 1;                     // a block holds P3 or P3 + 1 samples
+    static constexpr int kRawDwords = (kSamples + 1) / 2;
+    static constexpr int segment_of(int k) { return k <= P0 ? 0 : (k <= P1 ? 1 : (k <= P2 ? 2 : 3)); }
+};
+
+template <int P0, int P1, int P2, int P3>
 struct Chip2Setup {
+    using Shape = Chip2Shape<P0, P1, P2, P3>;
     double dphi;                       // carrier_step(carrier_hz, fs)
     double shift[3], step[3];          // the taps' np.linspace constants (exact re-evaluations, edge samples)
     int64_t base;                      // start_sample % capacity; < 0: this routine does not serve the epoch
@@ -42,17 +57,18 @@ struct Chip2Setup {
     int q0, F2;                        // block b < F2 holds chips q0 + 1 + 2b and q0 + 2 + 2b of the prompt tap
     int head_end, tail_start;          // samples [0, head_end) and [tail_start, n) are correlated one per lane
     int Dmin, pad;
-    double rc[SEG], rs[SEG];           // exp(-1j*k*dphi), k < SEG
-    double tc[4], ts[4];               // exp(-1j*SEG*g*dphi), g < 4
+    double rc[Shape::kMaxLen], rs[Shape::kMaxLen];   // exp(-1j*k*dphi), k < the longest segment
+    double tc[4], ts[4];               // exp(-1j*start_g*dphi)
     double rd0c, rd0s, rd1c, rd1s;     // over the Dmin / Dmin + 1 samples to a lane's next block
-    double b4c, b4s, b5c, b5s;         // the biased conversion's share of a segment sum of SEG - 1 / SEG samples
+    double bc[Shape::kMaxLen + 1], bs[Shape::kMaxLen + 1];   // the biased conversion's share of a segment sum of L samples, L <= the longest
 };
 
 // Host side (sdr_epl_plan_create): false when the two-chip scheme does not cover the item.
-template <int SEG>
+template <int P0, int P1, int P2, int P3>
 __host__ inline bool chip2_setup(int n, int64_t start_sample, int64_t capacity, double carrier_hz, double rem_code, double code_step,
-                                 const double* spacing, double fs, Chip2Setup<SEG>& S) {
-    S = Chip2Setup<SEG>{};
+                                 const double* spacing, double fs, Chip2Setup<P0, P1, P2, P3>& S) {
+    using Shape = Chip2Shape<P0, P1, P2, P3>;
+    S = Chip2Setup<P0, P1, P2, P3>{};
     S.base = -1;
     S.dphi = carrier_step(carrier_hz, fs);
     double inv[3];
@@ -72,9 +88,9 @@ __host__ inline bool chip2_setup(int n, int64_t start_sample, int64_t capacity, 
     const uint64_t dE = g.delta[0], dL = g.delta[2];
     const uint64_t gap = dE > dL ? dE - dL : dL - dE;
     const bool ok = !(T < ((int64_t)1 << 32)) && g.F >= 2 && g.F <= 32768 && base + n + 32 <= capacity &&
-                    (int)((2 * T) >> 32) == 4 * SEG - 1 && (int)(T >> 32) == 2 * SEG - 1 &&
-                    g.m[0] == SEG - 1 && g.m[2] == SEG - 1 && g.J[0] == -1 && g.J[2] == 0 && gap < ((uint64_t)1 << 12) &&
-                    (int)((dE + (uint64_t)T) >> 32) == 3 * SEG - 1 &&
+                    (int)((2 * T) >> 32) == P3 && (int)(T >> 32) == P1 &&
+                    g.m[0] == P0 && g.m[2] == P0 && g.J[0] == -1 && g.J[2] == 0 && gap < ((uint64_t)1 << 12) &&
+                    (int)((dE + (uint64_t)T) >> 32) == P2 &&
                     // (chip_geometry's own block-length test is for one chip per lane: only its other findings count)
                     g.delta[0] < (uint64_t)T && g.delta[2] < (uint64_t)T;
     if (!ok) return false;
@@ -89,38 +105,39 @@ __host__ inline bool chip2_setup(int n, int64_t start_sample, int64_t capacity, 
         S.tail_start = chip_first_above_exact(chip_first_above((double)(q_left - 1), S.shift[1], inv[1], nr), (double)(q_left - 1),
                                               S.step[1], S.shift[1]);
     }
-    if (S.head_end + (n - S.tail_start) > 64) return false;
+    if (S.head_end + (n - S.tail_start) > 128) return false;
     S.Dmin = (int)((128 * T) >> 32);            // a lane's blocks are 64 pairs of chips apart
-    for (int k = 0; k < SEG; ++k) sincos_reduced(-(double)k * S.dphi, &S.rs[k], &S.rc[k]);
-    for (int gseg = 0; gseg < 4; ++gseg) sincos_reduced(-(double)(SEG * gseg) * S.dphi, &S.ts[gseg], &S.tc[gseg]);
+    for (int k = 0; k < Shape::kMaxLen; ++k) sincos_reduced(-(double)k * S.dphi, &S.rs[k], &S.rc[k]);
+    for (int gseg = 0; gseg < 4; ++gseg) sincos_reduced(-(double)Shape::start(gseg) * S.dphi, &S.ts[gseg], &S.tc[gseg]);
     sincos_reduced(-(double)S.Dmin * S.dphi, &S.rd0s, &S.rd0c);
     sincos_reduced(-(double)(S.Dmin + 1) * S.dphi, &S.rd1s, &S.rd1c);
     double pc = 0.0, ps = 0.0;
-    for (int k = 0; k < SEG; ++k) {
+    S.bc[0] = S.bs[0] = 0.0;
+    for (int k = 0; k < Shape::kMaxLen; ++k) {
         pc += S.rc[k], ps += S.rs[k];
-        if (k == SEG - 2) S.b4c = (pc - ps) * kCvtBias, S.b4s = (pc + ps) * kCvtBias;
-        if (k == SEG - 1) S.b5c = (pc - ps) * kCvtBias, S.b5s = (pc + ps) * kCvtBias;
+        S.bc[k + 1] = (pc - ps) * kCvtBias, S.bs[k + 1] = (pc + ps) * kCvtBias;
     }
     S.base = base;
     return true;
 }
 
-template <int SEG>
+template <int RAW>
 struct Chip2Block {
-    uint32_t raw[2 * SEG];     // 4*SEG samples from the block's first one
+    uint32_t raw[RAW];         // the block's samples (and what follows them in the dwords)
     int S;                     // first sample (epoch-relative)
-    int d1, dP, d2, dn;        // position - (g*SEG - 1) of the four boundaries: 0 or 1
+    int d1, dP, d2, dn;        // position - P_g of the four boundaries: 0 or 1
 };
 
 // Returns false when a lane met a block the scheme does not cover (the caller redoes the epoch per sample).
 // zero_words: four zero words of LDS (the replica of a lane without a block).
-template <int SEG>
+template <int P0, int P1, int P2, int P3>
 __device__ __forceinline__ bool correlate_epoch_chip2(const void* __restrict__ ring, const void* __restrict__ ring_flipped,
-                                                      const EpochParams& ep, const Chip2Setup<SEG>& P, const uint32_t* lut,
+                                                      const EpochParams& ep, const Chip2Setup<P0, P1, P2, P3>& P, const uint32_t* lut,
                                                       const uint32_t* zero_words, int lane, double* accr, double* acci) {
+    using Shape = Chip2Shape<P0, P1, P2, P3>;
     constexpr int NT = 3, A = 1;
-    constexpr int KM = 4 * SEG - 1;
-    static_assert(SEG == 5 || SEG == 6, "segments of five or six samples");
+    constexpr int kRaw = Shape::kRawDwords;
+    constexpr int kMaxLen = Shape::kMaxLen;
 #pragma unroll
     for (int t = 0; t < NT; ++t) accr[t] = acci[t] = 0.0;
     const double dphi_u = P.dphi, rem_carrier_u = uniform(ep.rem_carrier);
@@ -141,12 +158,11 @@ __device__ __forceinline__ bool correlate_epoch_chip2(const void* __restrict__ r
     asm volatile("" : "+v"(Tfx), "+v"(Ufx), "+v"(delta), "+v"(stride_fx));
     double rd0c = P.rd0c, rd0s = P.rd0s, rd1c = P.rd1c, rd1s = P.rd1s;
     asm volatile("" : "+v"(rd0c), "+v"(rd0s), "+v"(rd1c), "+v"(rd1s));
-    double rc[SEG], rs[SEG], tc[4], ts[4];
+    double rc[kMaxLen], rs[kMaxLen], tc[4], ts[4];
 #pragma unroll
-    for (int k = 1; k < SEG; ++k) rc[k] = P.rc[k], rs[k] = P.rs[k];
+    for (int k = 1; k < kMaxLen; ++k) rc[k] = P.rc[k], rs[k] = P.rs[k];
 #pragma unroll
     for (int g = 1; g < 4; ++g) tc[g] = P.tc[g], ts[g] = P.ts[g];
-    const double b4c = P.b4c, b4s = P.b4s, b5c = P.b5c, b5s = P.b5s;
 
     bool bad = false;
     const int rounds = (F2 + 63) >> 6;
@@ -154,7 +170,7 @@ __device__ __forceinline__ bool correlate_epoch_chip2(const void* __restrict__ r
         const int last_idx = F2 - 1;
         const int64_t two32 = (int64_t)1 << 32;
         uint64_t u_cur = (uint64_t)(Ufx + (int64_t)q0 * Tfx + two32) + (uint64_t)((int64_t)(2 * lane) * Tfx);
-        auto prepare = [&](int round, uint64_t u0, Chip2Block<SEG>& b) {
+        auto prepare = [&](int round, uint64_t u0, Chip2Block<kRaw>& b) {
             const int idx = round * 64 + lane;
             const bool inside = idx <= last_idx;
             const uint64_t uS = inside ? u0 : (uint64_t)(Ufx + (int64_t)(q0 + 2 * last_idx) * Tfx + two32);
@@ -183,23 +199,22 @@ __device__ __forceinline__ bool correlate_epoch_chip2(const void* __restrict__ r
                 s1 = b1[0] - S, sP = bP - S, s2 = b2[0] - S, nn = bE - S;
             }
             b.S = S;
-            b.d1 = s1 - (SEG - 1), b.dP = sP - (2 * SEG - 1), b.d2 = s2 - (3 * SEG - 1), b.dn = nn - KM;
+            b.d1 = s1 - P0, b.dP = sP - P1, b.d2 = s2 - P2, b.dn = nn - P3;
             bad = bad || (unsigned)b.d1 > 1u || (unsigned)b.dP > 1u || (unsigned)b.d2 > 1u || (unsigned)b.dn > 1u;
-            const char* src = ring_base + (int64_t)S * 2;                  // 8*SEG bytes from a 2-byte aligned address
-            const uint4 w0 = *reinterpret_cast<const uint4*>(src);
-            const uint4 w1 = *reinterpret_cast<const uint4*>(src + 16);
-            b.raw[0] = w0.x, b.raw[1] = w0.y, b.raw[2] = w0.z, b.raw[3] = w0.w;
-            b.raw[4] = w1.x, b.raw[5] = w1.y, b.raw[6] = w1.z, b.raw[7] = w1.w;
-            if constexpr (SEG == 5) {
-                const uint2 w2 = *reinterpret_cast<const uint2*>(src + 32);
-                b.raw[8] = w2.x, b.raw[9] = w2.y;
-            } else {
-                const uint4 w2 = *reinterpret_cast<const uint4*>(src + 32);
-                b.raw[8] = w2.x, b.raw[9] = w2.y, b.raw[10] = w2.z, b.raw[11] = w2.w;
+            const char* src = ring_base + (int64_t)S * 2;                  // the block's dwords from a 2-byte aligned address
+            static_for<0, kRaw / 4>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const uint4 w = *reinterpret_cast<const uint4*>(src + 16 * i);
+                b.raw[4 * i] = w.x, b.raw[4 * i + 1] = w.y, b.raw[4 * i + 2] = w.z, b.raw[4 * i + 3] = w.w;
+            });
+            if constexpr (kRaw % 4 >= 2) {
+                const uint2 w = *reinterpret_cast<const uint2*>(src + 16 * (kRaw / 4));
+                b.raw[kRaw / 4 * 4] = w.x, b.raw[kRaw / 4 * 4 + 1] = w.y;
             }
+            if constexpr (kRaw % 2 == 1) b.raw[kRaw - 1] = *reinterpret_cast<const uint32_t*>(src + 4 * (kRaw - 1));
         };
 
-        Chip2Block<SEG> blk_a, blk_b;
+        Chip2Block<kRaw> blk_a, blk_b;
         prepare(0, u_cur, blk_a);
         double sb, cb;
         sincos_reduced(__builtin_fma(-(double)blk_a.S, dphi_u, rem_carrier_u), &sb, &cb);
@@ -207,37 +222,38 @@ __device__ __forceinline__ bool correlate_epoch_chip2(const void* __restrict__ r
         sdr_u32x2 zI = {0u, 0u}, zQ = {0u, 0u};
         asm volatile("" : "+v"(zI), "+v"(zQ));
 
-        auto process = [&](const Chip2Block<SEG>& b, int round, double sbk, double cbk) {
+        auto process = [&](const Chip2Block<kRaw>& b, int round, double sbk, double cbk) {
             uint32_t hi_const = 0x40B00000u;
             asm volatile("" : "+v"(hi_const));
             double pr = 0.0, pi = 0.0;
             double capr[4], capi[4], fr[4], fi[4];
-            static_for<0, 4 * SEG>([&](auto kc) {
+            static_for<0, Shape::kSamples>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                constexpr int g = k / SEG, j = k - g * SEG;
+                constexpr int g = Shape::segment_of(k), j = k - Shape::start(g);
                 const uint32_t w = b.raw[k >> 1];
                 const double ar = biased_sample(zI, w, cvt_selector((k & 1) ? 2 : 0), hi_const);
                 const double ai = biased_sample(zQ, w, cvt_selector((k & 1) ? 3 : 1), hi_const);
-                if constexpr (j == SEG - 1) capr[g] = pr, capi[g] = pi;
+                if constexpr (k == Shape::last(g)) capr[g] = pr, capi[g] = pi;      // the segment's sum before its last sample
                 if constexpr (j == 0) {
                     pr = ar, pi = ai;
                 } else {
                     pr = __builtin_fma(-ai, rs[j], __builtin_fma(ar, rc[j], pr));
                     pi = __builtin_fma(ai, rc[j], __builtin_fma(ar, rs[j], pi));
                 }
-                if constexpr (j == SEG - 1) fr[g] = pr, fi[g] = pi;
+                if constexpr (k == Shape::last(g)) fr[g] = pr, fi[g] = pi;
                 asm volatile("" : "+v"(pr), "+v"(pi), "+v"(zI), "+v"(zQ));
             });
             // the offset's shares out; every boundary picks the sum before or after its segment's last sample
             const int dsel[4] = {b.d1, b.dP, b.d2, b.dn};
             double sr[4], si[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                fr[g] -= b5c, fi[g] -= b5s;
-                const double cr = capr[g] - b4c, ci = capi[g] - b4s;
+            static_for<0, 4>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int L = Shape::len(g);
+                fr[g] -= P.bc[L], fi[g] -= P.bs[L];
+                const double cr = capr[g] - P.bc[L - 1], ci = capi[g] - P.bs[L - 1];
                 sr[g] = dsel[g] ? fr[g] : cr;
                 si[g] = dsel[g] ? fi[g] : ci;
-            }
+            });
             auto turned = [&](int g, double xr, double xi, double& outr, double& outi, double addr, double addi) {
                 outr = __builtin_fma(-xi, ts[g], __builtin_fma(xr, tc[g], addr));
                 outi = __builtin_fma(xi, tc[g], __builtin_fma(xr, ts[g], addi));
@@ -267,7 +283,7 @@ __device__ __forceinline__ bool correlate_epoch_chip2(const void* __restrict__ r
                 acci[t] = __builtin_fma(sbk, gr[t], __builtin_fma(cbk, gi[t], acci[t]));
             }
         };
-        auto advance = [&](const Chip2Block<SEG>& from, const Chip2Block<SEG>& to, int to_round) {
+        auto advance = [&](const Chip2Block<kRaw>& from, const Chip2Block<kRaw>& to, int to_round) {
             const unsigned dd = (unsigned)(to.S - from.S - Dmin);
             const bool alive = to_round * 64 + lane <= last_idx;
             bad = bad || (alive && dd > 1u);
@@ -293,7 +309,9 @@ __device__ __forceinline__ bool correlate_epoch_chip2(const void* __restrict__ r
         if (rounds & 1) process(blk_a, rounds - 1, sb, cb);
     }
     if (__any(bad)) return false;
-    edge_samples<SDR_FMT_CI8, NT>(ring, 0, ep, dphi_u, shift, step, lut, lane, head_end, tail_start, accr, acci, base);
+    // (up to three partial or left-over chips: more than a wave of samples at 25 MHz now and then)
+    for (int off = 0; off < head_end + (ep.n - tail_start); off += 64)
+        edge_samples<SDR_FMT_CI8, NT>(ring, 0, ep, dphi_u, shift, step, lut, lane + off, head_end, tail_start, accr, acci, base);
     return true;
 }
 

@@ -43,7 +43,7 @@ constexpr int kWaveThreads = 64;  // one wave per channel-epoch: the ~5 us fixed
 // compiled in), then the compile-time tap geometry
 constexpr int kVariantKS12 = 256 * 12;   // three taps, the outer ones switching 12.x samples into the anchor's block
 constexpr int kVariantKI = 4096;         // taps whole (half-)chips apart: no switch inside a block
-constexpr int kVariantC2 = 8192;         // two chips per lane (correlator_chip2.h): segments of five samples, + 16384: of six
+constexpr int kVariantC2 = 8192;         // two chips per lane (correlator_chip2.h), x 1 / 2: boundaries at <4,9,14,19> / <5,11,17,23>
 constexpr int kLongLutWords = 4096;  // replicas of 16 KB and more (multi-period / BOC half-chip codes): four epochs share a staged copy
 
 // Dynamic LDS: [red: WPW*2*NT doubles][scratch: strips / rotations][lut: lut_words uint32]
@@ -217,12 +217,12 @@ int ensure_doubled_luts(sdr_engine* e, hipStream_t stream) {
 #endif
 // Two chips per lane (correlator_chip2.h): one wave per item, three taps, ci8 ring; the item's setup comes from the plan.
 // Dynamic LDS: [8 zero words][lut: lut_words uint32].
-template <int SEG>
+template <int P0, int P1, int P2, int P3>
 __global__ __launch_bounds__(kWaveThreads, SDR_EPL2_WAVES) void epl2_kernel(const void* __restrict__ ring, const void* __restrict__ ring_flipped,
                                                             int64_t capacity, const sdr_epl_item* __restrict__ items, int n_items,
                                                             const uint32_t* __restrict__ luts, int lut_words, int lut_stride,
                                                             const double* __restrict__ spacing, double fs, double* __restrict__ out,
-                                                            const Chip2Setup<SEG>* __restrict__ setups) {
+                                                            const Chip2Setup<P0, P1, P2, P3>* __restrict__ setups) {
     extern __shared__ double smem[];
     uint32_t* zero_words = reinterpret_cast<uint32_t*>(smem);
     uint32_t* lut = zero_words + 8;
@@ -236,12 +236,12 @@ __global__ __launch_bounds__(kWaveThreads, SDR_EPL2_WAVES) void epl2_kernel(cons
     ep.rem_carrier = it.rem_carrier;
     ep.rem_code = it.rem_code;
     ep.code_step = it.code_step;
-    const Chip2Setup<SEG>& S = setups[item];
+    const Chip2Setup<P0, P1, P2, P3>& S = setups[item];
     stage_lut<kWaveThreads>(lut, luts + (size_t)it.code_slot * lut_stride, lut_words, lane);
     if (lane < 8) zero_words[lane] = 0u;
     __syncthreads();  // replica staged
     double accr[3], acci[3];
-    const bool done = S.base >= 0 && correlate_epoch_chip2<SEG>(ring, ring_flipped, ep, S, lut, zero_words, lane, accr, acci);
+    const bool done = S.base >= 0 && correlate_epoch_chip2<P0, P1, P2, P3>(ring, ring_flipped, ep, S, lut, zero_words, lane, accr, acci);
     if (!done) {     // an epoch the scheme does not cover: per sample
         const double dphi = carrier_step(it.carrier_hz, fs);
         EpochConsts<3> K2;
@@ -404,17 +404,18 @@ static void fill_chip_setups(const sdr_epl_item* items, int n_items, const doubl
 
 // ... and of the two-chip kernel (Chip2Setup); returns the number of items its scheme does not cover (their setups say
 // so, and the kernel redoes them per sample).
-template <int SEG>
+template <int P0, int P1, int P2, int P3>
 static int fill_chip2_setups(const sdr_epl_item* items, int n_items, const double* spacing, double fs, int64_t capacity,
                              std::vector<char>& bytes) {
-    bytes.resize((size_t)n_items * sizeof(sdr::Chip2Setup<SEG>));
-    sdr::Chip2Setup<SEG>* out = reinterpret_cast<sdr::Chip2Setup<SEG>*>(bytes.data());
+    using Setup = sdr::Chip2Setup<P0, P1, P2, P3>;
+    bytes.resize((size_t)n_items * sizeof(Setup));
+    Setup* out = reinterpret_cast<Setup*>(bytes.data());
     const int n_threads = n_items < 4096 ? 1 : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     std::vector<int> missed(n_threads, 0);
     auto fill = [&](int w, int lo, int hi) {
         for (int i = lo; i < hi; ++i) {
             const sdr_epl_item& it = items[i];
-            if (!sdr::chip2_setup<SEG>(it.n_samples, it.start_sample, capacity, it.carrier_hz, it.rem_code, it.code_step, spacing, fs, out[i]))
+            if (!sdr::chip2_setup<P0, P1, P2, P3>(it.n_samples, it.start_sample, capacity, it.carrier_hz, it.rem_code, it.code_step, spacing, fs, out[i]))
                 ++missed[w];
         }
     };
@@ -547,15 +548,17 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
         }
     }
 
-    // chips of 9.5 .. 10 or 11.5 .. 12 samples, three taps half a chip apart (the reference's shipped 10 MHz): two chips per lane,
-    // if (nearly) every item fits the scheme
+    // three taps half a chip apart and chips of 9.5 .. 10 or 11.5 .. 12 samples (the reference's shipped 10 MHz; 12 MHz): two
+    // chips per lane, if (nearly) every item fits the scheme.  (At 24 .. 24.5 samples per chip -- boundaries <12, 24, 36, 48> --
+    // the same kernel was measured against the one-chip form: 5 % fewer instructions per sample, 60 % more per epoch, at the
+    // register cap: 0.335 instead of 0.316 ms per 32 000 epochs.  Not instantiated.)
     std::vector<char> setups2;
-    if (e->iq_fmt == SDR_FMT_CI8 && n_taps == 3 && (wide & 255) == 8 && !doubled && !e->epl_no_chip2) {
+    if (e->iq_fmt == SDR_FMT_CI8 && n_taps == 3 && !doubled && !e->epl_no_chip2 && (wide & 255) == 8) {
         const int m2 = (int)std::floor(2.0 / items[0].code_step);
-        int missed = n_items;
-        if (m2 == 19) missed = fill_chip2_setups<5>(items, n_items, spacing, fs, e->iq_capacity, setups2);
-        else if (m2 == 23) missed = fill_chip2_setups<6>(items, n_items, spacing, fs, e->iq_capacity, setups2);
-        if (missed <= n_items / 64) wide = 8 + kVariantC2 + (m2 == 23 ? 2 * kVariantC2 : 0);
+        int missed = n_items, shape = 0;
+        if (m2 == 19) missed = fill_chip2_setups<4, 9, 14, 19>(items, n_items, spacing, fs, e->iq_capacity, setups2), shape = 1;
+        else if (m2 == 23) missed = fill_chip2_setups<5, 11, 17, 23>(items, n_items, spacing, fs, e->iq_capacity, setups2), shape = 2;
+        if (shape && missed <= n_items / 64) wide = (wide & 255) + kVariantC2 * shape;
         else setups2.clear();
     }
 
@@ -658,7 +661,7 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
                         (long long)(first + count), p->n_items);
     if (p->doubled)
         if (int rc = ensure_doubled_luts(e, ctx->stream)) return rc;   // (a slot may have been re-staged since the plan was made)
-    if (e->iq_fmt == SDR_FMT_CI8 && (p->wide & (kVariantKS12 | kVariantKI | kVariantC2))) {
+    if (e->iq_fmt == SDR_FMT_CI8 && (p->wide & (kVariantKS12 | kVariantKI | 3 * kVariantC2))) {
         const void* flipped = nullptr;                                   // (the straight-line kernels read the flipped ring image)
         if (int rc = sdr_iq_flipped(e, ctx->stream, &flipped)) return rc;
     }
@@ -666,18 +669,17 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
     double* out = p->d_out + (size_t)first * 2 * p->n_taps;
     const int n = (int)count;
     const void* setups = p->d_setups ? p->d_setups + (size_t)first * p->setup_bytes : nullptr;
-    if (e->iq_fmt == SDR_FMT_CI8 && (p->wide & kVariantC2) && setups) {      // two chips per lane: its own kernel
+    if (e->iq_fmt == SDR_FMT_CI8 && (p->wide & (3 * kVariantC2)) && setups) {      // two chips per lane: its own kernel
         hipStream_t st = ctx->stream;
         ProfScope ps(e, "epl_kernel", st);
         const size_t shmem = 8 * sizeof(uint32_t) + (size_t)((p->lut_words + 3) & ~3) * sizeof(uint32_t);
-        if (p->wide & (2 * kVariantC2))
-            hipLaunchKernelGGL(epl2_kernel<6>, dim3(n), dim3(kWaveThreads), shmem, st, e->iq, (const void*)e->iq_flip, e->iq_capacity,
-                               items, n, e->luts, p->lut_words, e->lut_stride, p->d_spacing, p->fs, out,
-                               reinterpret_cast<const sdr::Chip2Setup<6>*>(setups));
-        else
-            hipLaunchKernelGGL(epl2_kernel<5>, dim3(n), dim3(kWaveThreads), shmem, st, e->iq, (const void*)e->iq_flip, e->iq_capacity,
-                               items, n, e->luts, p->lut_words, e->lut_stride, p->d_spacing, p->fs, out,
-                               reinterpret_cast<const sdr::Chip2Setup<5>*>(setups));
+        const int shape = (p->wide / kVariantC2) & 3;
+        auto launch2 = [&](auto kernel, auto* typed) {
+            hipLaunchKernelGGL(kernel, dim3(n), dim3(kWaveThreads), shmem, st, e->iq, (const void*)e->iq_flip, e->iq_capacity,
+                               items, n, e->luts, p->lut_words, e->lut_stride, p->d_spacing, p->fs, out, typed);
+        };
+        if (shape == 1) launch2(epl2_kernel<4, 9, 14, 19>, reinterpret_cast<const sdr::Chip2Setup<4, 9, 14, 19>*>(setups));
+        else launch2(epl2_kernel<5, 11, 17, 23>, reinterpret_cast<const sdr::Chip2Setup<5, 11, 17, 23>*>(setups));
     } else {
         hipStream_t st = ctx->stream;
         ProfScope ps(e, "epl_kernel", st);

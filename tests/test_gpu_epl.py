@@ -563,9 +563,9 @@ def test_randomised_stress_of_the_straight_line_kernels(engine):
 
 @pytest.mark.parametrize("fs,seg", [(10e6, 5), (12e6, 6), (9.8e6, 5)])
 def test_two_chips_per_lane_variant(engine, fs, seg):
-    """Chips of 9.5 .. 10 (11.5 .. 12) samples, taps half a chip apart -- a C/A code at the reference's shipped 10 MHz
-    (config/receiver.ini:18-20), or at 12 MHz: a lane owns two whole chips of the prompt tap, every tap switch at a
-    compile-time position up to + 1 (correlator_chip2.h; the plan holds a host-made setup per item).  Random Doppler on
+    """Chips of 9.5 .. 10 (11.5 .. 12) samples, taps half a chip apart -- a C/A code at the reference's shipped
+    10 MHz (config/receiver.ini:18-20), or at 12 MHz: a lane owns two whole chips of the prompt tap,
+    every tap switch at a compile-time position up to + 1 (correlator_chip2.h; the plan holds a host-made setup per item).  Random Doppler on
     code and carrier, odd and even numbers of whole chips, odd starts, short and two-period epochs, zero code phase;
     lists with a stray item the scheme does not cover (redone per sample inside the kernel) -- against the oracle, and
     against the 8-sample boundary variant of the same library."""
@@ -599,7 +599,7 @@ def test_two_chips_per_lane_variant(engine, fs, seg):
         items = make_items(slot, n, start, f, rem_carrier, rem_code, step)
         plan = engine.epl_plan(items, spacing, fs)
         try:
-            assert plan.variant & 8192 and bool(plan.variant & 16384) == (seg == 6), (group, plan.variant)
+            assert (plan.variant >> 13) & 3 == {5: 1, 6: 2}[seg], (group, plan.variant)   # <4,9,14,19> / <5,11,17,23>
             plan.run()
             got = plan.fetch()
         finally:
@@ -619,5 +619,5 @@ def test_two_chips_per_lane_variant(engine, fs, seg):
     # chips of exactly ten samples: every switch on a sample, 2 * T = 20 -- not this scheme's; the plan keeps the boundary variant
     items = make_items(0, 5000, 3, 100.0, 0.2, 0.01, 0.1)
     plan = engine.epl_plan(items, spacing, 10.23e6)
-    assert not plan.variant & 8192
+    assert not (plan.variant >> 13) & 3
     plan.close()
