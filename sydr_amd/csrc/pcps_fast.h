@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kColThreads) void cols_kernel(const PassArgs a, dou
 }
 
 // Rows: workgroup = kRowT adjacent rows k1 of one transform; per-wave (maximum, first index) records instead of the map.
-// LDS: 20 * kRowPitch + N2 double2 (41 920 B).
+// LDS: 10 * kRowPitch + N2 double2 (22 560 B): the exchange takes two rounds.
 __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, const double2* __restrict__ Z) {
     extern __shared__ double2 lds4[];
     constexpr int T = kRowT;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, con
     const int i = tid / 10, r = tid - i * 10;
     const bool live = tid < 10 * T && k1_0 + i < N1;
     const double2* __restrict__ tw = a.tw;
-    double2* w200 = lds4 + 20 * kRowPitch;                   // w200^e, e < 200
+    double2* w200 = lds4 + 10 * kRowPitch;
     constexpr int kTabPerThread = (N2 + kRowThreads - 1) / kRowThreads;
     double2 wt[kTabPerThread];
 #pragma unroll
@@ -259,13 +259,10 @@ __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, con
             const int kp = g / 4 + 5 * (g % 4);
             v[g] = cmul_conj(v[g], w200[r * kp]);                // r * kp <= 171
         }
-#pragma unroll
-        for (int g = 0; g < 20; ++g) lds4[g * kRowPitch + tid] = v[g];
     }
-    __syncthreads();
     int best_i = 0x7fffffff;
     double best_v = -1.0;
-    if (live) {
+    {
         const int s = r;
         const int prn = batch / a.nbins;
         const int bin = batch - prn * a.nbins;
@@ -277,35 +274,47 @@ __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, con
             const int g = s + 10 * o;
             const int kp = g / 4 + 5 * (g % 4);
             double2 u[10];
+            // the exchange in two rounds of ten registers: half the LDS per workgroup, twice the workgroups on a CU (a
+            // workgroup's load, arithmetic and exchange phases do not overlap: more of them do) -- 42 -> 35 us per sweep
+            if (o) __syncthreads();
+            if (live) {
 #pragma unroll
-            for (int rr = 0; rr < 10; ++rr) u[rr] = lds4[g * kRowPitch + rr + 10 * i];
-            idft10(u, tw);
+                for (int gg = 0; gg < 10; ++gg) lds4[gg * kRowPitch + tid] = v[10 * o + gg];
+            }
+            __syncthreads();
+            if (live) {
 #pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                const int q = j / 2 + 5 * (j % 2);
-                const int k = k1 + N1 * (kp + 20 * q);           // position in the transform = code phase
-                const double2 x = u[j];
-                const double sq = __builtin_fma(x.x, x.x, x.y * x.y);
-                bool take = sq > best_sq;
-                // (ordering by the squared magnitude; candidates within 2^-48 of the lane's best go through the scaled
-                // hypot -- the reference's np.abs -- and an exact tie keeps the smaller index: np.argmax's first one.
-                // A wave-uniform branch: left as a lane condition the compiler flattens it and every candidate
-                // pays for two hypots)
-                const bool near = fabs(sq - best_sq) <= best_sq * 0x1p-48;
-                if (__builtin_expect(__any(near), 0)) {
-                    if (near) {
-                        const double m_new = hypot(x.x * a.scale, x.y * a.scale), m_old = hypot(best_x * a.scale, best_y * a.scale);
-                        take = m_new > m_old || (m_new == m_old && k < best_k);
+                for (int rr = 0; rr < 10; ++rr) u[rr] = lds4[s * kRowPitch + rr + 10 * i];
+                idft10(u, tw);
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const int q = j / 2 + 5 * (j % 2);
+                    const int k = k1 + N1 * (kp + 20 * q);           // position in the transform = code phase
+                    const double2 x = u[j];
+                    const double sq = __builtin_fma(x.x, x.x, x.y * x.y);
+                    bool take = sq > best_sq;
+                    // (ordering by the squared magnitude; candidates within 2^-48 of the lane's best go through the scaled
+                    // hypot -- the reference's np.abs -- and an exact tie keeps the smaller index: np.argmax's first one.
+                    // A wave-uniform branch: left as a lane condition the compiler flattens it and every candidate
+                    // pays for two hypots)
+                    const bool near = fabs(sq - best_sq) <= best_sq * 0x1p-48;
+                    if (__builtin_expect(__any(near), 0)) {
+                        if (near) {
+                            const double m_new = hypot(x.x * a.scale, x.y * a.scale), m_old = hypot(best_x * a.scale, best_y * a.scale);
+                            take = m_new > m_old || (m_new == m_old && k < best_k);
+                        }
                     }
+                    best_sq = take ? sq : best_sq;
+                    best_x = take ? x.x : best_x;
+                    best_y = take ? x.y : best_y;
+                    best_k = take ? k : best_k;
                 }
-                best_sq = take ? sq : best_sq;
-                best_x = take ? x.x : best_x;
-                best_y = take ? x.y : best_y;
-                best_k = take ? k : best_k;
             }
         }
-        best_i = bin * N + best_k;
-        best_v = 0.0 + hypot(best_x * a.scale, best_y * a.scale);   // (0.0 + |.|: the map's own rounding)
+        if (live) {
+            best_i = bin * N + best_k;
+            best_v = 0.0 + hypot(best_x * a.scale, best_y * a.scale);   // (0.0 + |.|: the map's own rounding)
+        }
     }
     wave_best(best_v, best_i);
     if ((tid & 63) == 63) {
@@ -326,7 +335,7 @@ inline void run_cols(PassArgs& a, int batch, double2* Z, hipStream_t stream) {
 
 inline void run(sdr_engine* e, PassArgs a, int batch, double2* Z, hipStream_t stream) {
     const size_t shA = (size_t)(N1 * kColT + N1) * sizeof(double2);
-    const size_t shB = (size_t)(20 * kRowPitch + N2) * sizeof(double2);
+    const size_t shB = (size_t)(10 * kRowPitch + N2) * sizeof(double2);
     (void)hipFuncSetAttribute((const void*)cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shA);
     (void)hipFuncSetAttribute((const void*)rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shB);
     a.n_prn = batch / a.nbins;

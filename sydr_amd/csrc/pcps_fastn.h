@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, con
     const int i = tid / 10, r = tid - i * 10;
     const bool live = tid < 10 * T && k1_0 + i < N1;
     const double2* __restrict__ tw = a.tw;
-    double2* w200 = lds4 + 20 * kRowPitch;                   // w200^e, e < 200
+    double2* w200 = lds4 + 10 * kRowPitch;                   // w200^e, e < 200 (behind the ten exchange slots)
     constexpr int kTabPerThread = (N2 + kRowThreads - 1) / kRowThreads;
     double2 wt[kTabPerThread];
 #pragma unroll
@@ -235,84 +235,81 @@ __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, con
             const int kp = g / 4 + 5 * (g % 4);
             v[g] = cmul_conj(v[g], w200[r * kp]);
         }
-#pragma unroll
-        for (int g = 0; g < 20; ++g) lds4[g * kRowPitch + tid] = v[g];
     }
-    __syncthreads();
-    if constexpr (STORE != STORE_MAG_MAX) {
-        if (!live) return;
-        const int s = r;
-        const int k1 = k1_0 + i;
-        const size_t base_o = (size_t)batch * N + k1;
-#pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const int g = s + 10 * o;
-            const int kp = g / 4 + 5 * (g % 4);
-            double2 u[10];
-#pragma unroll
-            for (int rr = 0; rr < 10; ++rr) u[rr] = lds4[g * kRowPitch + rr + 10 * i];
-            idft10<N>(u, tw);
-            if constexpr (STORE == STORE_MAG_ACC) {
-                double old[10];
-                if (!a.first_block) {
-#pragma unroll
-                    for (int j = 0; j < 10; ++j) old[j] = a.map[base_o + N1 * (kp + 20 * (j / 2 + 5 * (j % 2)))];
-                }
-#pragma unroll
-                for (int j = 0; j < 10; ++j) {
-                    const double mag = hypot(u[j].x * a.scale, u[j].y * a.scale);
-                    a.map[base_o + N1 * (kp + 20 * (j / 2 + 5 * (j % 2)))] = a.first_block ? 0.0 + mag : old[j] + mag;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 10; ++j) {
-                    const size_t at = base_o + N1 * (kp + 20 * (j / 2 + 5 * (j % 2)));
-                    const double2 sc = make_double2(u[j].x * a.scale, u[j].y * a.scale);
-                    a.csum[at] = a.first_block ? sc : cadd(a.csum[at], sc);
-                }
-            }
-        }
-        return;
-    }
+    // The exchange goes through LDS in two rounds of ten registers: half the LDS per workgroup, twice the workgroups on a CU
+    // (the load, arithmetic and exchange phases of a workgroup do not overlap: more of them do) -- 42 -> 35 us per sweep of
+    // 437 transforms at N = 25 000.  Every thread takes the barriers, live or not.
     int best_i = 0x7fffffff;
     double best_v = -1.0;
-    if (live) {
+    {
         const int s = r;
         const int prn = batch / a.nbins;
         const int bin = batch - prn * a.nbins;
         const int k1 = k1_0 + i;
+        const size_t base_o = (size_t)batch * N + k1;
         double best_sq = -1.0, best_x = 0.0, best_y = 0.0;
         int best_k = -1;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             const int g = s + 10 * o;
             const int kp = g / 4 + 5 * (g % 4);
-            double2 u[10];
+            if (o) __syncthreads();
+            if (live) {
 #pragma unroll
-            for (int rr = 0; rr < 10; ++rr) u[rr] = lds4[g * kRowPitch + rr + 10 * i];
-            idft10<N>(u, tw);
+                for (int gg = 0; gg < 10; ++gg) lds4[gg * kRowPitch + tid] = v[10 * o + gg];
+            }
+            __syncthreads();
+            if (live) {
+                double2 u[10];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                const int q = j / 2 + 5 * (j % 2);
-                const int k = k1 + N1 * (kp + 20 * q);
-                const double2 x = u[j];
-                const double sq = __builtin_fma(x.x, x.x, x.y * x.y);
-                bool take = sq > best_sq;
-                const bool near = fabs(sq - best_sq) <= best_sq * 0x1p-48;
-                if (__builtin_expect(__any(near), 0)) {
-                    if (near) {
-                        const double m_new = hypot(x.x * a.scale, x.y * a.scale), m_old = hypot(best_x * a.scale, best_y * a.scale);
-                        take = m_new > m_old || (m_new == m_old && k < best_k);
+                for (int rr = 0; rr < 10; ++rr) u[rr] = lds4[s * kRowPitch + rr + 10 * i];
+                idft10<N>(u, tw);
+                if constexpr (STORE == STORE_MAG_ACC) {
+                    double old[10];
+                    if (!a.first_block) {
+#pragma unroll
+                        for (int j = 0; j < 10; ++j) old[j] = a.map[base_o + N1 * (kp + 20 * (j / 2 + 5 * (j % 2)))];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) {
+                        const double mag = hypot(u[j].x * a.scale, u[j].y * a.scale);
+                        a.map[base_o + N1 * (kp + 20 * (j / 2 + 5 * (j % 2)))] = a.first_block ? 0.0 + mag : old[j] + mag;
+                    }
+                } else if constexpr (STORE == STORE_CPLX_ACC) {
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) {
+                        const size_t at = base_o + N1 * (kp + 20 * (j / 2 + 5 * (j % 2)));
+                        const double2 sc = make_double2(u[j].x * a.scale, u[j].y * a.scale);
+                        a.csum[at] = a.first_block ? sc : cadd(a.csum[at], sc);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) {
+                        const int q = j / 2 + 5 * (j % 2);
+                        const int k = k1 + N1 * (kp + 20 * q);
+                        const double2 x = u[j];
+                        const double sq = __builtin_fma(x.x, x.x, x.y * x.y);
+                        bool take = sq > best_sq;
+                        const bool near = fabs(sq - best_sq) <= best_sq * 0x1p-48;
+                        if (__builtin_expect(__any(near), 0)) {
+                            if (near) {
+                                const double m_new = hypot(x.x * a.scale, x.y * a.scale), m_old = hypot(best_x * a.scale, best_y * a.scale);
+                                take = m_new > m_old || (m_new == m_old && k < best_k);
+                            }
+                        }
+                        best_sq = take ? sq : best_sq;
+                        best_x = take ? x.x : best_x;
+                        best_y = take ? x.y : best_y;
+                        best_k = take ? k : best_k;
                     }
                 }
-                best_sq = take ? sq : best_sq;
-                best_x = take ? x.x : best_x;
-                best_y = take ? x.y : best_y;
-                best_k = take ? k : best_k;
             }
         }
-        best_i = bin * N + best_k;
-        best_v = 0.0 + hypot(best_x * a.scale, best_y * a.scale);
+        if constexpr (STORE != STORE_MAG_MAX) return;
+        if (live) {
+            best_i = bin * N + best_k;
+            best_v = 0.0 + hypot(best_x * a.scale, best_y * a.scale);
+        }
     }
     wave_best(best_v, best_i);
     if ((tid & 63) == 63) {
@@ -323,7 +320,7 @@ __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, con
 
 template <int N1, int STORE>
 inline void run_rows(const PassArgs& a, int batch, const double2* Z, hipStream_t stream) {
-    const size_t shB = (size_t)(20 * kRowPitch + N2) * sizeof(double2);
+    const size_t shB = (size_t)(10 * kRowPitch + N2) * sizeof(double2);
     (void)hipFuncSetAttribute((const void*)rows_kernel<N1, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shB);
     hipLaunchKernelGGL((rows_kernel<N1, STORE>), dim3(row_tiles(N1), batch), dim3(kRowThreads), shB, stream, a, Z);
 }
