@@ -14,6 +14,7 @@
 // accumulation into the last inverse pass.  fp64 throughout: the peak INDEX must
 // match NumPy's bit for bit, and a 1e-7 relative error could reorder near-ties.
 #include "engine_internal.h"
+#include "sincos_reduced.h"
 
 #include <cmath>
 #include <cstring>
@@ -192,7 +193,9 @@ __device__ __forceinline__ double2 load_elem(const PassArgs& a, int batch, int i
         pp = pp / a.fs;
         double arg = freq * pp;
         double s, c;
-        sincos(arg, &s, &c);
+        // (|arg| stays below ~2*pi*f*T: a few hundred radians -- the exact two-constant reduction and the minimax kernels
+        // of the correlators, < 1 ulp, instead of libm's general sincos with its large-argument path)
+        sdr::sincos_reduced(arg, &s, &c);
         return cmul(make_double2(c, -s), x);
     } else if (LOAD == LOAD_MUL_CODE) {
         int prn = batch / a.nbins, bin = batch - prn * a.nbins;
