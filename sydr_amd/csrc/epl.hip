@@ -554,7 +554,8 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
     // register cap: 0.335 instead of 0.316 ms per 32 000 epochs.  Not instantiated.)
     std::vector<char> setups2;
     if (e->iq_fmt == SDR_FMT_CI8 && n_taps == 3 && !doubled && !e->epl_no_chip2 && (wide & 255) == 8) {
-        const int m2 = (int)std::floor(2.0 / items[0].code_step);
+        const double two_chips = std::floor(2.0 / items[0].code_step);       // samples in two chips (any positive step got here)
+        const int m2 = two_chips == 19.0 ? 19 : (two_chips == 23.0 ? 23 : 0);
         int missed = n_items, shape = 0;
         if (m2 == 19) missed = fill_chip2_setups<4, 9, 14, 19>(items, n_items, spacing, fs, e->iq_capacity, setups2), shape = 1;
         else if (m2 == 23) missed = fill_chip2_setups<5, 11, 17, 23>(items, n_items, spacing, fs, e->iq_capacity, setups2), shape = 2;

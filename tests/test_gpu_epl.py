@@ -604,6 +604,13 @@ def test_two_chips_per_lane_variant(engine, fs, seg):
             got = plan.fetch()
         finally:
             plan.close()
+        if group == 0:                                               # a range of a fresh plan: its items' setups, not the first ones'
+            part = engine.epl_plan(items, spacing, fs)
+            try:
+                part.run(37, 50)
+                assert np.array_equal(part.fetch()[37:87], got[37:87])
+            finally:
+                part.close()
         engine.set_option("epl_no_two_chip_variant", 1)
         try:
             other = engine.epl_batch(items, spacing, fs)
