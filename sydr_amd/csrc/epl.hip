@@ -43,7 +43,7 @@ constexpr int kWaveThreads = 64;  // one wave per channel-epoch: the ~5 us fixed
 // compiled in), then the compile-time tap geometry
 constexpr int kVariantKS12 = 256 * 12;   // three taps, the outer ones switching 12.x samples into the anchor's block
 constexpr int kVariantKI = 4096;         // taps whole (half-)chips apart: no switch inside a block
-constexpr int kVariantC2 = 8192;         // two chips per lane (correlator_chip2.h), x 1 / 2: boundaries at <4,9,14,19> / <5,11,17,23>
+constexpr int kVariantC2 = 8192;         // several chips per lane (correlator_chip2.h), x 1 / 2: boundaries <4,9,14,19> / <5,11,17,23>
 constexpr int kLongLutWords = 4096;  // replicas of 16 KB and more (multi-period / BOC half-chip codes): four epochs share a staged copy
 
 // Dynamic LDS: [red: WPW*2*NT doubles][scratch: strips / rotations][lut: lut_words uint32]
@@ -215,14 +215,14 @@ int ensure_doubled_luts(sdr_engine* e, hipStream_t stream) {
 #ifndef SDR_EPL2_WAVES
 #define SDR_EPL2_WAVES 3   // (a cap of 128 registers for four waves per SIMD spills into scratch: 0.296 instead of 0.192 ms per 32 000 epochs)
 #endif
-// Two chips per lane (correlator_chip2.h): one wave per item, three taps, ci8 ring; the item's setup comes from the plan.
+// Several chips per lane (correlator_chip2.h): one wave per item, three taps, ci8 ring; the item's setup comes from the plan.
 // Dynamic LDS: [8 zero words][lut: lut_words uint32].
-template <int P0, int P1, int P2, int P3>
+template <int... P>
 __global__ __launch_bounds__(kWaveThreads, SDR_EPL2_WAVES) void epl2_kernel(const void* __restrict__ ring, const void* __restrict__ ring_flipped,
                                                             int64_t capacity, const sdr_epl_item* __restrict__ items, int n_items,
                                                             const uint32_t* __restrict__ luts, int lut_words, int lut_stride,
                                                             const double* __restrict__ spacing, double fs, double* __restrict__ out,
-                                                            const Chip2Setup<P0, P1, P2, P3>* __restrict__ setups) {
+                                                            const ChipNSetup<P...>* __restrict__ setups) {
     extern __shared__ double smem[];
     uint32_t* zero_words = reinterpret_cast<uint32_t*>(smem);
     uint32_t* lut = zero_words + 8;
@@ -236,12 +236,12 @@ __global__ __launch_bounds__(kWaveThreads, SDR_EPL2_WAVES) void epl2_kernel(cons
     ep.rem_carrier = it.rem_carrier;
     ep.rem_code = it.rem_code;
     ep.code_step = it.code_step;
-    const Chip2Setup<P0, P1, P2, P3>& S = setups[item];
+    const ChipNSetup<P...>& S = setups[item];
     stage_lut<kWaveThreads>(lut, luts + (size_t)it.code_slot * lut_stride, lut_words, lane);
     if (lane < 8) zero_words[lane] = 0u;
     __syncthreads();  // replica staged
     double accr[3], acci[3];
-    const bool done = S.base >= 0 && correlate_epoch_chip2<P0, P1, P2, P3>(ring, ring_flipped, ep, S, lut, zero_words, lane, accr, acci);
+    const bool done = S.base >= 0 && correlate_epoch_chipn<P...>(ring, ring_flipped, ep, S, lut, zero_words, lane, accr, acci);
     if (!done) {     // an epoch the scheme does not cover: per sample
         const double dphi = carrier_step(it.carrier_hz, fs);
         EpochConsts<3> K2;
@@ -402,12 +402,12 @@ static void fill_chip_setups(const sdr_epl_item* items, int n_items, const doubl
     }
 }
 
-// ... and of the two-chip kernel (Chip2Setup); returns the number of items its scheme does not cover (their setups say
+// ... and of the several-chips-per-lane kernel (ChipNSetup); returns the number of items its scheme does not cover (their setups say
 // so, and the kernel redoes them per sample).
-template <int P0, int P1, int P2, int P3>
-static int fill_chip2_setups(const sdr_epl_item* items, int n_items, const double* spacing, double fs, int64_t capacity,
+template <int... P>
+static int fill_chipn_setups(const sdr_epl_item* items, int n_items, const double* spacing, double fs, int64_t capacity,
                              std::vector<char>& bytes) {
-    using Setup = sdr::Chip2Setup<P0, P1, P2, P3>;
+    using Setup = sdr::ChipNSetup<P...>;
     bytes.resize((size_t)n_items * sizeof(Setup));
     Setup* out = reinterpret_cast<Setup*>(bytes.data());
     const int n_threads = n_items < 4096 ? 1 : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -415,7 +415,7 @@ static int fill_chip2_setups(const sdr_epl_item* items, int n_items, const doubl
     auto fill = [&](int w, int lo, int hi) {
         for (int i = lo; i < hi; ++i) {
             const sdr_epl_item& it = items[i];
-            if (!sdr::chip2_setup<P0, P1, P2, P3>(it.n_samples, it.start_sample, capacity, it.carrier_hz, it.rem_code, it.code_step, spacing, fs, out[i]))
+            if (!sdr::chipn_setup<P...>(it.n_samples, it.start_sample, capacity, it.carrier_hz, it.rem_code, it.code_step, spacing, fs, out[i]))
                 ++missed[w];
         }
     };
@@ -557,8 +557,10 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
         const double two_chips = std::floor(2.0 / items[0].code_step);       // samples in two chips (any positive step got here)
         const int m2 = two_chips == 19.0 ? 19 : (two_chips == 23.0 ? 23 : 0);
         int missed = n_items, shape = 0;
-        if (m2 == 19) missed = fill_chip2_setups<4, 9, 14, 19>(items, n_items, spacing, fs, e->iq_capacity, setups2), shape = 1;
-        else if (m2 == 23) missed = fill_chip2_setups<5, 11, 17, 23>(items, n_items, spacing, fs, e->iq_capacity, setups2), shape = 2;
+        // (three chips per lane at 10 MHz -- <4, 9, 14, 19, 24, 29> -- were measured: 27 registers spilled at the cap of three
+        // waves per SIMD, 0.44 instead of 0.57 of the roof)
+        if (m2 == 19) missed = fill_chipn_setups<4, 9, 14, 19>(items, n_items, spacing, fs, e->iq_capacity, setups2), shape = 1;
+        else if (m2 == 23) missed = fill_chipn_setups<5, 11, 17, 23>(items, n_items, spacing, fs, e->iq_capacity, setups2), shape = 2;
         if (shape && missed <= n_items / 64) wide = (wide & 255) + kVariantC2 * shape;
         else setups2.clear();
     }
@@ -679,8 +681,8 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
             hipLaunchKernelGGL(kernel, dim3(n), dim3(kWaveThreads), shmem, st, e->iq, (const void*)e->iq_flip, e->iq_capacity,
                                items, n, e->luts, p->lut_words, e->lut_stride, p->d_spacing, p->fs, out, typed);
         };
-        if (shape == 1) launch2(epl2_kernel<4, 9, 14, 19>, reinterpret_cast<const sdr::Chip2Setup<4, 9, 14, 19>*>(setups));
-        else launch2(epl2_kernel<5, 11, 17, 23>, reinterpret_cast<const sdr::Chip2Setup<5, 11, 17, 23>*>(setups));
+        if (shape == 1) launch2(epl2_kernel<4, 9, 14, 19>, reinterpret_cast<const sdr::ChipNSetup<4, 9, 14, 19>*>(setups));
+        else launch2(epl2_kernel<5, 11, 17, 23>, reinterpret_cast<const sdr::ChipNSetup<5, 11, 17, 23>*>(setups));
     } else {
         hipStream_t st = ctx->stream;
         ProfScope ps(e, "epl_kernel", st);

@@ -1,5 +1,5 @@
 // Host-side dump of what sdr_epl_plan_create works out per item for the straight-line correlators (correlator_chip.h:
-// chip_geometry; correlator_chip2.h: chip2_setup), for tests/test_plan_geometry.py to hold against the reference's own
+// chip_geometry; correlator_chip2.h: chipn_setup), for tests/test_plan_geometry.py to hold against the reference's own
 // chip-index expression.  Built with `hipcc --cuda-host-only`: no device code, no GPU.
 //   usage: chip_geometry_dump <fs> <n_items> <seed>   -> one line per item
 #include <hip/hip_runtime.h>
@@ -41,9 +41,9 @@ int main(int argc, char** argv) {
         printf("item n=%d rem_code=%.17g code_step=%.17g q0=%d F=%d head_end=%d tail_start=%d Tfx=%lld Ufx=%lld dE=%llu dL=%llu mE=%d mL=%d JE=%d JL=%d bad=%d",
                n, rem_code, code_step, g.q0, g.F, g.head_end, g.tail_start, (long long)g.Tfx, (long long)g.Ufx,
                (unsigned long long)g.delta[0], (unsigned long long)g.delta[2], g.m[0], g.m[2], g.J[0], g.J[2], g.bad);
-        Chip2Setup<4, 9, 14, 19> s2;
-        const bool ok2 = chip2_setup<4, 9, 14, 19>(n, 1000 + 7 * i, (int64_t)1 << 24, 1500.0, rem_code, code_step, spacing, fs, s2);
-        printf(" c2=%d F2=%d c2_tail=%d c2_Dmin=%d", ok2 ? 1 : 0, s2.F2, s2.tail_start, s2.Dmin);
+        ChipNSetup<4, 9, 14, 19> s2;
+        const bool ok2 = chipn_setup<4, 9, 14, 19>(n, 1000 + 7 * i, (int64_t)1 << 24, 1500.0, rem_code, code_step, spacing, fs, s2);
+        printf(" c2=%d F2=%d c2_tail=%d c2_Dmin=%d", ok2 ? 1 : 0, s2.FB, s2.tail_start, s2.Dmin);
         ChipRot r;
         const double dphi = carrier_step(1500.0 + 100.0 * i, fs);
         const int Dmin = (int)((64 * g.Tfx) >> 32);
