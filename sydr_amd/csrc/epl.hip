@@ -553,7 +553,8 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
     // the same kernel was measured against the one-chip form: 5 % fewer instructions per sample, 60 % more per epoch, at the
     // register cap: 0.335 instead of 0.316 ms per 32 000 epochs.  Not instantiated.)
     std::vector<char> setups2;
-    if (e->iq_fmt == SDR_FMT_CI8 && n_taps == 3 && !doubled && !e->epl_no_chip2 && (wide & 255) == 8) {
+    if (e->iq_fmt == SDR_FMT_CI8 && n_taps == 3 && !doubled && !e->epl_no_chip2 && (wide & 255) == 8 &&
+        lut_words < kLongLutWords) {          // (long multi-period replicas keep the four-epochs-per-workgroup kernels)
         const double two_chips = std::floor(2.0 / items[0].code_step);       // samples in two chips (any positive step got here)
         const int m2 = two_chips == 19.0 ? 19 : (two_chips == 23.0 ? 23 : 0);
         int missed = n_items, shape = 0;
