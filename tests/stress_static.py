@@ -1,5 +1,5 @@
 """Randomised GPU-vs-oracle stress of the straight-line E/P/L kernels (tap switch positions compiled in at 25 MHz +-0.5
-chip; whole-chip tap geometry at 25 / 50 MHz) and of the flipped ring image they read: code Doppler, phases at and next to
+chip; whole-chip tap geometry at 25 / 50 MHz; two chips per lane at 10 MHz) and of the flipped ring image they read: code Doppler, phases at and next to
 zero, one to four periods, n = N - 2 .. N + 2, epochs that wrap the ring (redone per sample inside the launch), carriers up
 to an intermediate frequency, full-scale samples, and the ring rewritten in pieces between launches (the image follows its
 dirty range).   Usage: python tests/stress_static.py [n_rounds] [seed]"""
@@ -14,6 +14,7 @@ GEOMETRIES = (  # fs, spacing, most periods per epoch, variant bits the plan mus
     (50e6, (-1.0, -0.5, 0.0, 0.5, 1.0), 4, 65536 + 26 + 24 + 4096),
     (25e6, (-1.0, 0.0, 1.0), 2, 26 + 24 + 4096),
     (50e6, (-0.5, 0.0, 0.5), 1, 65536 + 26 + 24 + 4096),
+    (10e6, (-0.5, 0.0, 0.5), 2, 8 + 8192),                      # two chips per lane (correlator_chip2.h): the shipped rate
 )
 
 
@@ -48,6 +49,14 @@ def run(rounds, seed, eng=None, n_items=160):
         n[:3] = [7, 61, 129][: 3]
         start = rng.integers(0, cap, n_items)                 # some epochs wrap the ring: redone per sample in the launch
         start[3] = cap - 5
+        if want & 8192:
+            # (a plan takes the two-chip kernel when at most 1 item in 64 falls outside its scheme: two strays here -- one
+            # tiny epoch, one that wraps the ring -- both redone per sample inside the launch)
+            n[1:3] = n[4:6]
+            if n_items < 128:
+                n[0] = n[6]                                   # (a short list: the wrapping epoch alone)
+            start = rng.integers(0, cap - 30000, n_items)
+            start[3] = cap - 5
         slot = rng.integers(0, 8, n_items)
         f = rng.uniform(-20000, 20000, n_items) * rng.choice([1.0, 1.0, 0.0, 200.0], n_items)
         ph = rng.uniform(-10, 10, n_items)
