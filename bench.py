@@ -765,7 +765,7 @@ def main():
     eng.iq_synth(all_sats, FS, 12.0, 20260003, 0, total)
     items, n_epochs = truth_items(sats, FS, total)
     t_plan = time.perf_counter()
-    plan = eng.epl_plan(items, SPACING, FS)                 # validation, the per-epoch setups of the straight-line kernel, upload
+    plan = eng.epl_plan(items, SPACING, FS)                 # validation and upload of the items, one launch for their per-epoch setups
     plan_create_s = time.perf_counter() - t_plan
     n_run = n_epochs * N_CH                                 # every whole code period of the stream, every channel
     pass_samples = int(items["n_samples"][:n_run].sum())
@@ -845,9 +845,10 @@ def main():
         "x_realtime": stream_samples / elapsed / FS,          # seconds of THE stream (all channels tracked) per second
         "channel_Msamples_per_s": job_ch_samples / elapsed / 1e6,
         "multi_gpu": multi_gpu,                               # N > 1: who took part, per-rank rates, cross-rank bitwise check
-        # outside the timed region, once per stream: the host checks every item and works out each epoch's setup
-        # (tap constants, chip geometry, carrier rotations: sdr_epl_plan_create); the steps re-run the same plan
-        "plan": {"create_ms": plan_create_s * 1e3, "items": int(len(items)), "host_threads": min(16, os.cpu_count() or 1)},
+        # outside the timed region, once per stream: the host checks every item, uploads the list, and one launch with a
+        # thread per item works out each epoch's setup (tap constants, chip geometry, carrier rotations:
+        # sdr_epl_plan_create); the steps re-run the same plan
+        "plan": {"create_ms": plan_create_s * 1e3, "items": int(len(items))},
     }
     result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "epl_kernel",

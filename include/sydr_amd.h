@@ -164,10 +164,11 @@ int sdr_epl_batch(sdr_engine* e, const sdr_epl_item* items, int n_items, const d
 
 /* Resident plans: items and outputs stay in HBM so a timed region holds only
  * kernel launches.  run is asynchronous on the engine stream.
- * Creating a plan checks every item against the ring and the staged replicas and, for lists the straight-line kernels
- * serve (ci8 ring, 24-25 samples per (half-)chip, taps +-0.5 chip or whole chips apart), works out each epoch's setup on
- * the host -- tap constants, chip geometry, carrier rotations: ~0.2 us per item over up to 16 threads, 480-560 bytes of
- * device memory per item -- so that the kernel starts an epoch with scalar loads instead of ~450 vector instructions. */
+ * Creating a plan checks every item against the ring and the staged replicas (host), uploads the list and, for lists the
+ * straight-line kernels serve (ci8 ring; 24-25 samples per (half-)chip with taps +-0.5 chip or whole chips apart; 9.5-10 or
+ * 11.5-12 samples per chip with taps +-0.5 chip), works out each epoch's setup -- tap constants, chip geometry, carrier
+ * rotations -- in one launch with a thread per item: 400-560 bytes of device memory per item, so that the correlator
+ * starts an epoch with scalar loads instead of ~450 vector instructions repeated in all 64 lanes. */
 typedef struct sdr_epl_plan sdr_epl_plan;
 int sdr_epl_plan_create(sdr_engine* e, const sdr_epl_item* items, int n_items,
                         const double* spacing, int n_taps, double fs, sdr_epl_plan** out);

@@ -200,6 +200,32 @@ struct ChipSetup {
     ChipRot r;
 };
 
+// ... and how one is made (one THREAD per item of a plan: epl.hip's chip_setup_kernel; the host builds of the tests).
+// stride: the lanes that share an epoch (a lane's blocks are that many chips apart).
+template <int NT, int KS, int KI>
+__host__ __device__ inline void chip_setup(int n, int64_t start_sample, int64_t capacity, double carrier_hz, double rem_code,
+                                           double code_step, const double* spacing, double fs, int stride, ChipSetup<NT>& S) {
+    S = ChipSetup<NT>{};
+    S.dphi = carrier_step(carrier_hz, fs);
+    const double nd = (double)n;
+    for (int t = 0; t < NT; ++t) {             // compute_tap_constants(): np.linspace(shift, code_step*n + shift, n, endpoint=False)
+        const double shift = rem_code + spacing[t];
+        double stop = code_step * nd;
+        stop = stop + shift;
+        const double delta = stop - shift;
+        S.shift[t] = shift;
+        S.step[t] = delta / nd;
+        S.inv_step[t] = 1.0 / S.step[t];       // (only ever predicts positions that are re-checked exactly near a sample)
+    }
+    const int64_t base = start_sample % capacity;
+    const bool applies = code_step >= kChipMinCodeStep && code_step <= kChipMaxCodeStep && base + n + 32 <= capacity;   // chip_variant_applies()
+    S.base = applies ? base : -1;
+    if (applies) {
+        chip_geometry<NT, 24, KS, KI>(n, S.shift, S.step, S.inv_step, S.g);
+        chip_rotations(S.dphi, (int)(((int64_t)stride * S.g.Tfx) >> 32), S.r);
+    }
+}
+
 // One lane's block, prepared one round ahead of its use (its loads are in flight while the previous block computes).
 template <int NT>
 struct ChipBlock {

@@ -21,7 +21,7 @@
 // is one complex constant per length and epoch.  Block boundaries come from the same Q32.32 line; a boundary within
 // 2^-16 of a sample sends the wave through exact evaluations of the reference expression; a lane that meets a position
 // outside its pair flags the epoch, which is redone per sample.  Everything wave-uniform that is not data -- tap
-// constants, geometry, rotations -- is worked out by the host when the plan is made (ChipNSetup, one per item), as for the
+// constants, geometry, rotations -- is worked out when the plan is made, one thread per item (ChipNSetup), as for the
 // one-chip forms.
 #pragma once
 
@@ -74,9 +74,10 @@ struct ChipNSetup {
     double bc[Shape::kMaxLen + 1], bs[Shape::kMaxLen + 1];   // the biased conversion's share of a segment sum of L samples
 };
 
-// Host side (sdr_epl_plan_create): false when the scheme does not cover the item.
+// One thread per item of a plan (epl.hip: chipn_setup_kernel; the host builds of the tests): false when the scheme does not
+// cover the item.
 template <int... P>
-__host__ inline bool chipn_setup(int n, int64_t start_sample, int64_t capacity, double carrier_hz, double rem_code, double code_step,
+__host__ __device__ inline bool chipn_setup(int n, int64_t start_sample, int64_t capacity, double carrier_hz, double rem_code, double code_step,
                                  const double* spacing, double fs, ChipNSetup<P...>& S) {
     using Shape = ChipNShape<P...>;
     constexpr int CH = Shape::CH;

@@ -20,7 +20,6 @@
 // minimax sincos) and advanced by precomputed fp64 rotations inside a block and from block to block, which agrees
 // with the reference to ~1e-15 relative on the accumulators (the bar is 1e-6).
 #include <algorithm>
-#include <thread>
 
 #include "correlator.h"
 #include "correlator_chip.h"
@@ -338,7 +337,7 @@ struct sdr_epl_plan {
     sdr_epl_item* d_items = nullptr;
     double* d_out = nullptr;
     double* d_spacing = nullptr;
-    char* d_setups = nullptr;   // straight-line kernels: one ChipSetup<n_taps> per item (correlator_chip.h), worked out by the host
+    char* d_setups = nullptr;   // straight-line kernels: one ChipSetup<n_taps> / ChipNSetup per item (correlator_chip.h, correlator_chip2.h)
     size_t setup_bytes = 0;     // sizeof(ChipSetup<n_taps>), 0: none
     int n_items = 0;
     int n_taps = 0;
@@ -355,81 +354,39 @@ struct sdr_epl_plan {
     std::vector<std::pair<hipStream_t, hipEvent_t>> ran_on;
 };
 
-// The per-epoch setup of the straight-line kernels (ChipSetup: tap constants, epoch geometry, ring position), item by
-// item as the kernels with run-time positions derive it per wave -- the same functions, the same IEEE operations (this
-// file is compiled with -ffp-contract=off on both sides); only 1/step is a division here and a Newton step there, and it
-// only ever predicts positions that are re-checked exactly near a sample.
+// The per-epoch setups of the straight-line kernels (ChipSetup / ChipNSetup: tap constants, epoch geometry, ring position,
+// carrier rotations), made when a plan is created: one THREAD per item -- what every wave of an epoch would otherwise
+// repeat in all of its 64 lanes -- with the same functions the run-time-position kernels call per wave.  1.92 M items
+// (60 s x 32 channels) take ~0.1 ms of one launch.
 template <int NT, int KS, int KI>
-static void fill_chip_setups(const sdr_epl_item* items, int n_items, const double* spacing, double fs, int64_t capacity,
-                             std::vector<char>& bytes) {
-    bytes.resize((size_t)n_items * sizeof(sdr::ChipSetup<NT>));
-    sdr::ChipSetup<NT>* out = reinterpret_cast<sdr::ChipSetup<NT>*>(bytes.data());
-    // (~2 us per item, most of it the sixteen sincos evaluations: long lists are cut over the host's cores)
-    const int n_threads = n_items < 4096 ? 1 : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-    auto fill = [&](int lo, int hi) {
-    for (int i = lo; i < hi; ++i) {
-        const sdr_epl_item& it = items[i];
-        sdr::ChipSetup<NT> S = {};
-        S.dphi = sdr::carrier_step(it.carrier_hz, fs);
-        const double nd = (double)it.n_samples;
-        for (int t = 0; t < NT; ++t) {             // compute_tap_constants(): np.linspace(shift, code_step*n + shift, n, endpoint=False)
-            const double shift = it.rem_code + spacing[t];
-            double stop = it.code_step * nd;
-            stop = stop + shift;
-            const double delta = stop - shift;
-            S.shift[t] = shift;
-            S.step[t] = delta / nd;
-            S.inv_step[t] = 1.0 / S.step[t];
-        }
-        const int64_t base = it.start_sample % capacity;
-        const bool applies = it.code_step >= sdr::kChipMinCodeStep && it.code_step <= sdr::kChipMaxCodeStep &&
-                             base + it.n_samples + 32 <= capacity;          // chip_variant_applies()
-        S.base = applies ? base : -1;
-        if (applies) {
-            sdr::chip_geometry<NT, 24, KS, KI>(it.n_samples, S.shift, S.step, S.inv_step, S.g);
-            sdr::chip_rotations(S.dphi, (int)(((int64_t)kWaveThreads * S.g.Tfx) >> 32), S.r);   // (one wave per epoch: a lane's blocks are 64 chips apart)
-        }
-        out[i] = S;
-    }
-    };
-    if (n_threads == 1) {
-        fill(0, n_items);
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < n_threads; ++t)
-            pool.emplace_back(fill, (int)((int64_t)n_items * t / n_threads), (int)((int64_t)n_items * (t + 1) / n_threads));
-        for (auto& th : pool) th.join();
-    }
+__global__ __launch_bounds__(256) void chip_setup_kernel(const sdr_epl_item* __restrict__ items, int n_items,
+                                                         const double* __restrict__ spacing, double fs, int64_t capacity,
+                                                         sdr::ChipSetup<NT>* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_items) return;
+    const sdr_epl_item it = items[i];
+    double sp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sp[t] = spacing[t];
+    sdr::ChipSetup<NT> S;
+    sdr::chip_setup<NT, KS, KI>(it.n_samples, it.start_sample, capacity, it.carrier_hz, it.rem_code, it.code_step, sp, fs,
+                                kWaveThreads, S);
+    out[i] = S;
 }
-
-// ... and of the several-chips-per-lane kernel (ChipNSetup); returns the number of items its scheme does not cover (their setups say
-// so, and the kernel redoes them per sample).
+// ... *missed counts the items the several-chips-per-lane scheme does not cover (their setups say so, and the kernel
+// redoes them per sample).
 template <int... P>
-static int fill_chipn_setups(const sdr_epl_item* items, int n_items, const double* spacing, double fs, int64_t capacity,
-                             std::vector<char>& bytes) {
-    using Setup = sdr::ChipNSetup<P...>;
-    bytes.resize((size_t)n_items * sizeof(Setup));
-    Setup* out = reinterpret_cast<Setup*>(bytes.data());
-    const int n_threads = n_items < 4096 ? 1 : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-    std::vector<int> missed(n_threads, 0);
-    auto fill = [&](int w, int lo, int hi) {
-        for (int i = lo; i < hi; ++i) {
-            const sdr_epl_item& it = items[i];
-            if (!sdr::chipn_setup<P...>(it.n_samples, it.start_sample, capacity, it.carrier_hz, it.rem_code, it.code_step, spacing, fs, out[i]))
-                ++missed[w];
-        }
-    };
-    if (n_threads == 1) {
-        fill(0, 0, n_items);
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < n_threads; ++t)
-            pool.emplace_back(fill, t, (int)((int64_t)n_items * t / n_threads), (int)((int64_t)n_items * (t + 1) / n_threads));
-        for (auto& th : pool) th.join();
-    }
-    int total = 0;
-    for (int m : missed) total += m;
-    return total;
+__global__ __launch_bounds__(256) void chipn_setup_kernel(const sdr_epl_item* __restrict__ items, int n_items,
+                                                          const double* __restrict__ spacing, double fs, int64_t capacity,
+                                                          sdr::ChipNSetup<P...>* __restrict__ out, int* __restrict__ missed) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_items) return;
+    const sdr_epl_item it = items[i];
+    const double sp[3] = {spacing[0], spacing[1], spacing[2]};
+    sdr::ChipNSetup<P...> S;
+    if (!sdr::chipn_setup<P...>(it.n_samples, it.start_sample, capacity, it.carrier_hz, it.rem_code, it.code_step, sp, fs, S))
+        atomicAdd(missed, 1);
+    out[i] = S;
 }
 
 // Host-side check that no item can index outside the ring or the staged LUT.
@@ -548,24 +505,6 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
         }
     }
 
-    // three taps half a chip apart and chips of 9.5 .. 10 or 11.5 .. 12 samples (the reference's shipped 10 MHz; 12 MHz): two
-    // chips per lane, if (nearly) every item fits the scheme.  (At 24 .. 24.5 samples per chip -- boundaries <12, 24, 36, 48> --
-    // the same kernel was measured against the one-chip form: 5 % fewer instructions per sample, 60 % more per epoch, at the
-    // register cap: 0.335 instead of 0.316 ms per 32 000 epochs.  Not instantiated.)
-    std::vector<char> setups2;
-    if (e->iq_fmt == SDR_FMT_CI8 && n_taps == 3 && !doubled && !e->epl_no_chip2 && (wide & 255) == 8 &&
-        lut_words < kLongLutWords) {          // (long multi-period replicas keep the four-epochs-per-workgroup kernels)
-        const double two_chips = std::floor(2.0 / items[0].code_step);       // samples in two chips (any positive step got here)
-        const int m2 = two_chips == 19.0 ? 19 : (two_chips == 23.0 ? 23 : 0);
-        int missed = n_items, shape = 0;
-        // (three chips per lane at 10 MHz -- <4, 9, 14, 19, 24, 29> -- were measured: 27 registers spilled at the cap of three
-        // waves per SIMD, 0.44 instead of 0.57 of the roof)
-        if (m2 == 19) missed = fill_chipn_setups<4, 9, 14, 19>(items, n_items, spacing, fs, e->iq_capacity, setups2), shape = 1;
-        else if (m2 == 23) missed = fill_chipn_setups<5, 11, 17, 23>(items, n_items, spacing, fs, e->iq_capacity, setups2), shape = 2;
-        if (shape && missed <= n_items / 64) wide = (wide & 255) + kVariantC2 * shape;
-        else setups2.clear();
-    }
-
     sdr_epl_plan* p = new (std::nothrow) sdr_epl_plan();
     if (!p) return sdr_fail(SDR_ERR_NOMEM, "host allocation failed");
     p->n_items = n_items;
@@ -614,26 +553,68 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
                              hipMemcpyHostToDevice, e->stream);
     if (err == hipSuccess)
         err = hipMemcpyAsync(p->d_spacing, doubled ? spacing2 : spacing, n_taps * sizeof(double), hipMemcpyHostToDevice, e->stream);
-    std::vector<char> setups;
-    if (!setups2.empty()) setups.swap(setups2);
-    if (err == hipSuccess && e->iq_fmt == SDR_FMT_CI8 && (wide & 255) >= kChipMax && (wide & (kVariantKS12 | kVariantKI))) {
-        const sdr_epl_item* src = doubled ? items2.data() : items;
-        const double* spc = doubled ? spacing2 : spacing;
-        if ((wide & kVariantKS12) && n_taps == 3) fill_chip_setups<3, 12, 0>(src, n_items, spc, fs, e->iq_capacity, setups);
-        else if ((wide & kVariantKI) && n_taps == 3) fill_chip_setups<3, 0, 1>(src, n_items, spc, fs, e->iq_capacity, setups);
-        else if ((wide & kVariantKI) && n_taps == 5) fill_chip_setups<5, 0, 1>(src, n_items, spc, fs, e->iq_capacity, setups);
+    // ---- the per-item setups of the straight-line kernels: one launch, one thread per item (items and spacings are on the device)
+    auto reserve_setups = [&](size_t bytes_per_item) {
+        p->setup_bytes = bytes_per_item;
+        const size_t bytes = bytes_per_item * (size_t)n_items;
+        if (use_workspaces) {
+            if (sdr_devbuf_reserve(e, &e->ws_setups, bytes + 64) != SDR_OK) err = hipErrorOutOfMemory;
+            else p->d_setups = (char*)e->ws_setups.ptr;
+        } else {
+            err = hipMalloc(&p->d_setups, bytes + 64);     // (+ the counter of items a scheme does not cover)
+        }
+    };
+    const unsigned setup_grid = (unsigned)((n_items + 255) / 256);
+    if (err == hipSuccess && e->iq_fmt == SDR_FMT_CI8 && (wide & 255) >= kChipMax && (wide & (kVariantKS12 | kVariantKI)) &&
+        (n_taps == 3 || n_taps == 5)) {
+        reserve_setups(n_taps == 3 ? sizeof(sdr::ChipSetup<3>) : sizeof(sdr::ChipSetup<5>));
+        if (err == hipSuccess) {
+            if ((wide & kVariantKS12) && n_taps == 3)
+                hipLaunchKernelGGL((chip_setup_kernel<3, 12, 0>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
+                                   p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups));
+            else if (n_taps == 3)
+                hipLaunchKernelGGL((chip_setup_kernel<3, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
+                                   p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups));
+            else
+                hipLaunchKernelGGL((chip_setup_kernel<5, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
+                                   p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<5>*>(p->d_setups));
+            err = hipGetLastError();
+        }
     }
-    if (err == hipSuccess) {
-        if (!setups.empty()) {
-            p->setup_bytes = setups.size() / (size_t)n_items;
-            if (use_workspaces) {
-                if (sdr_devbuf_reserve(e, &e->ws_setups, setups.size()) != SDR_OK) err = hipErrorOutOfMemory;
-                else p->d_setups = (char*)e->ws_setups.ptr;
-            } else {
-                err = hipMalloc(&p->d_setups, setups.size());
+    // three taps half a chip apart and chips of 9.5 .. 10 or 11.5 .. 12 samples (the reference's shipped 10 MHz; 12 MHz): two
+    // chips per lane, if (nearly) every item fits the scheme.  (At 24 .. 24.5 samples per chip -- boundaries <12, 24, 36, 48> --
+    // the same kernel was measured against the one-chip form: 5 % fewer instructions per sample, 60 % more per epoch, at the
+    // register cap: 0.335 instead of 0.316 ms per 32 000 epochs; three chips per lane at 10 MHz -- <4, 9, 14, 19, 24, 29> --
+    // spill 27 registers at three waves per SIMD: 0.44 instead of 0.57 of the roof.  Neither is instantiated.)
+    if (err == hipSuccess && e->iq_fmt == SDR_FMT_CI8 && n_taps == 3 && !doubled && !e->epl_no_chip2 && (wide & 255) == 8 &&
+        lut_words < kLongLutWords) {          // (long multi-period replicas keep the four-epochs-per-workgroup kernels)
+        const double two_chips = std::floor(2.0 / items[0].code_step);       // samples in two chips (any positive step got here)
+        const int shape = two_chips == 19.0 ? 1 : (two_chips == 23.0 ? 2 : 0);
+        if (shape) {
+            reserve_setups(shape == 1 ? sizeof(sdr::ChipNSetup<4, 9, 14, 19>) : sizeof(sdr::ChipNSetup<5, 11, 17, 23>));
+            int* d_missed = p->d_setups ? reinterpret_cast<int*>(p->d_setups + p->setup_bytes * (size_t)n_items) : nullptr;
+            int missed = n_items;
+            if (err == hipSuccess) err = hipMemsetAsync(d_missed, 0, sizeof(int), e->stream);
+            if (err == hipSuccess) {
+                if (shape == 1)
+                    hipLaunchKernelGGL((chipn_setup_kernel<4, 9, 14, 19>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items,
+                                       n_items, p->d_spacing, fs, e->iq_capacity,
+                                       reinterpret_cast<sdr::ChipNSetup<4, 9, 14, 19>*>(p->d_setups), d_missed);
+                else
+                    hipLaunchKernelGGL((chipn_setup_kernel<5, 11, 17, 23>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items,
+                                       n_items, p->d_spacing, fs, e->iq_capacity,
+                                       reinterpret_cast<sdr::ChipNSetup<5, 11, 17, 23>*>(p->d_setups), d_missed);
+                err = hipGetLastError();
             }
-            if (err == hipSuccess)
-                err = hipMemcpyAsync(p->d_setups, setups.data(), setups.size(), hipMemcpyHostToDevice, e->stream);
+            if (err == hipSuccess) err = hipMemcpyAsync(&missed, d_missed, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+            if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+            if (err == hipSuccess && missed <= n_items / 64) {
+                p->wide = wide = (wide & 255) + kVariantC2 * shape;
+            } else if (err == hipSuccess) {                 // too many strays: the boundary variant serves the list
+                if (!use_workspaces && p->d_setups) (void)hipFree(p->d_setups);
+                p->d_setups = nullptr;
+                p->setup_bytes = 0;
+            }
         }
     }
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);

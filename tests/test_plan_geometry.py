@@ -1,4 +1,5 @@
-"""What sdr_epl_plan_create works out on the HOST for the straight-line correlators -- the epoch geometry and the Q32.32 line
+"""What sdr_epl_plan_create works out per item for the straight-line correlators (one thread per item on the device; here a
+HOST build of the same __host__ __device__ functions) -- the epoch geometry and the Q32.32 line
 the block boundaries are predicted from (correlator_chip.h: chip_geometry, correlator_chip2.h: chipn_setup) -- held against
 the reference's own chip-index expression ceil(linspace(...)) (tracking.py:111-112, through the oracle) on the CPU: first
 and last partial chips, every block start, every tap switch.  The kernels trust a prediction unless it lies within 2^-16
