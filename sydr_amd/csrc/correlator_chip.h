@@ -417,6 +417,9 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                 b.ds[t] = sp - m[t];
                 bad = bad || (unsigned)b.ds[t] > 1u;
             }
+            // (KS, three taps: E and L switch half a chip into the block, on the same sample away from a `near` one -- one
+            // select serves both; a block where they differ flags the epoch)
+            if constexpr (KS != 0 && NT == 3) bad = bad || b.ds[0] != b.ds[2];
             // 13 dwords = 26 samples from the (2-byte aligned) address of sample S: gfx950 serves unaligned dword loads
             const char* src = ring_base + (int64_t)S * 2;
             const uint4 w0 = *reinterpret_cast<const uint4*>(src);
@@ -592,7 +595,7 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                 } else {
                     double2 ps;
                     if constexpr (kStatic)
-                        ps = b.ds[t] ? make_double2(capr[2], capi[2]) : make_double2(capr[0], capi[0]);
+                        ps = b.ds[NT == 3 ? 0 : t] ? make_double2(capr[2], capi[2]) : make_double2(capr[0], capi[0]);
                     else
                         ps = strip[rank[t] + b.ds[t]];
                     const int jt = kStatic ? (t < A ? -1 : 0) : J[t];      // (KS: checked when the epoch was set up)
