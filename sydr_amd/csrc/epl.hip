@@ -542,6 +542,7 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
         if (err == hipSuccess) err = hipMalloc(&p->d_spacing, SDR_MAX_TAPS * sizeof(double));
     }
     std::vector<sdr_epl_item> items2;
+    std::vector<char> host_setups;      // short lists: the setups are made on the host (kept until the final synchronisation)
     double spacing2[SDR_MAX_TAPS];
     if (doubled) {
         items2.assign(items, items + n_items);
@@ -568,7 +569,25 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
     if (err == hipSuccess && e->iq_fmt == SDR_FMT_CI8 && (wide & 255) >= kChipMax && (wide & (kVariantKS12 | kVariantKI)) &&
         (n_taps == 3 || n_taps == 5)) {
         reserve_setups(n_taps == 3 ? sizeof(sdr::ChipSetup<3>) : sizeof(sdr::ChipSetup<5>));
-        if (err == hipSuccess) {
+        if (err == hipSuccess && n_items < 4096) {
+            // a short list (sdr_epl_batch: one call per EPL()): the same function on the host, ~2 us per item, instead of a launch
+            const sdr_epl_item* src = doubled ? items2.data() : items;
+            const double* spc = doubled ? spacing2 : spacing;
+            host_setups.resize(p->setup_bytes * (size_t)n_items);
+            for (int i = 0; i < n_items; ++i) {
+                const sdr_epl_item& it = src[i];
+                if ((wide & kVariantKS12) && n_taps == 3)
+                    sdr::chip_setup<3, 12, 0>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
+                                              kWaveThreads, reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i]);
+                else if (n_taps == 3)
+                    sdr::chip_setup<3, 0, 1>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
+                                             kWaveThreads, reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i]);
+                else
+                    sdr::chip_setup<5, 0, 1>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
+                                             kWaveThreads, reinterpret_cast<sdr::ChipSetup<5>*>(host_setups.data())[i]);
+            }
+            err = hipMemcpyAsync(p->d_setups, host_setups.data(), host_setups.size(), hipMemcpyHostToDevice, e->stream);
+        } else if (err == hipSuccess) {
             if ((wide & kVariantKS12) && n_taps == 3)
                 hipLaunchKernelGGL((chip_setup_kernel<3, 12, 0>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
                                    p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups));
@@ -594,8 +613,25 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
             reserve_setups(shape == 1 ? sizeof(sdr::ChipNSetup<4, 9, 14, 19>) : sizeof(sdr::ChipNSetup<5, 11, 17, 23>));
             int* d_missed = p->d_setups ? reinterpret_cast<int*>(p->d_setups + p->setup_bytes * (size_t)n_items) : nullptr;
             int missed = n_items;
-            if (err == hipSuccess) err = hipMemsetAsync(d_missed, 0, sizeof(int), e->stream);
-            if (err == hipSuccess) {
+            if (err == hipSuccess && n_items < 4096) {
+                // a short list (sdr_epl_batch: one call per EPL()): the same function on the host, ~2 us per item, instead of a
+                // launch and a round trip for the count -- the call is latency, not throughput
+                host_setups.resize(p->setup_bytes * (size_t)n_items);
+                missed = 0;
+                for (int i = 0; i < n_items; ++i) {
+                    const sdr_epl_item& it = items[i];
+                    const bool ok = shape == 1
+                        ? sdr::chipn_setup<4, 9, 14, 19>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step,
+                                                         spacing, fs, reinterpret_cast<sdr::ChipNSetup<4, 9, 14, 19>*>(host_setups.data())[i])
+                        : sdr::chipn_setup<5, 11, 17, 23>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step,
+                                                          spacing, fs, reinterpret_cast<sdr::ChipNSetup<5, 11, 17, 23>*>(host_setups.data())[i]);
+                    missed += ok ? 0 : 1;
+                }
+                if (missed <= n_items / 64)      // (host_setups lives until the synchronisation that ends the plan's creation)
+                    err = hipMemcpyAsync(p->d_setups, host_setups.data(), host_setups.size(), hipMemcpyHostToDevice, e->stream);
+            } else if (err == hipSuccess) {
+              err = hipMemsetAsync(d_missed, 0, sizeof(int), e->stream);
+              if (err == hipSuccess) {
                 if (shape == 1)
                     hipLaunchKernelGGL((chipn_setup_kernel<4, 9, 14, 19>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items,
                                        n_items, p->d_spacing, fs, e->iq_capacity,
@@ -605,9 +641,10 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
                                        n_items, p->d_spacing, fs, e->iq_capacity,
                                        reinterpret_cast<sdr::ChipNSetup<5, 11, 17, 23>*>(p->d_setups), d_missed);
                 err = hipGetLastError();
+              }
+              if (err == hipSuccess) err = hipMemcpyAsync(&missed, d_missed, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+              if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
             }
-            if (err == hipSuccess) err = hipMemcpyAsync(&missed, d_missed, sizeof(int), hipMemcpyDeviceToHost, e->stream);
-            if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
             if (err == hipSuccess && missed <= n_items / 64) {
                 p->wide = wide = (wide & 255) + kVariantC2 * shape;
             } else if (err == hipSuccess) {                 // too many strays: the boundary variant serves the list
