@@ -628,3 +628,43 @@ def test_two_chips_per_lane_variant(engine, fs, seg):
     plan = engine.epl_plan(items, spacing, 10.23e6)
     assert not (plan.variant >> 13) & 3
     plan.close()
+
+
+@pytest.mark.parametrize("fs", [25e6, 10e6])
+def test_plan_setups_made_on_the_device_equal_the_host_made_ones(engine, fs):
+    """The per-item setups of the straight-line kernels are made by one launch (a thread per item) for lists of 4096 items
+    and more, and by the same functions on the host for shorter ones (sdr_epl_batch): one list of 5000 items as a whole
+    and in two halves -- bitwise the same accumulators -- and a sample of them against the oracle."""
+    rng = np.random.default_rng(int(fs) // 1000 + 9)
+    cap = 1 << 19
+    raw = rng.integers(-100, 100, 2 * cap).astype(np.int8)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(8)
+    for s in range(8):
+        engine.load_gps_code(s, 3 * s + 2)
+    n_items = 5000
+    step = (1.023e6 + rng.uniform(-6, 6, n_items)) / fs
+    rem_code = rng.uniform(0, step)
+    n = np.ceil((1023 - rem_code) / step).astype(np.int64) + rng.integers(-1, 2, n_items)
+    start = rng.integers(0, cap - 40000, n_items)
+    slot = rng.integers(0, 8, n_items)
+    f = rng.uniform(-6000, 6000, n_items)
+    rem_carrier = rng.uniform(0, 2 * np.pi, n_items)
+    items = make_items(slot, n, start, f, rem_carrier, rem_code, step)
+    spacing = (-0.5, 0.0, 0.5)
+    whole = engine.epl_plan(items, spacing, fs)
+    try:
+        assert whole.variant & (3072 if fs == 25e6 else 8192)           # the straight-line kernel of that rate
+        whole.run()
+        got = whole.fetch()
+    finally:
+        whole.close()
+    halves = np.concatenate([engine.epl_batch(items[:2500], spacing, fs), engine.epl_batch(items[2500:], spacing, fs)])
+    assert got.tobytes() == halves.tobytes()
+    rf = orc.iq_to_complex(raw)
+    for k in rng.choice(n_items, 12, replace=False):
+        x = orc.ring_slice(rf, int(start[k]), int(n[k]))
+        ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(3 * int(slot[k]) + 2)), fs, f[k], rem_carrier[k], rem_code[k], step[k], spacing))
+        scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 50.0), 2)
+        assert np.max(np.abs(got[k] - ref) / scale) < 1e-9, (k,)
