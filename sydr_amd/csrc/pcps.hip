@@ -15,6 +15,7 @@
 // match NumPy's bit for bit, and a 1e-7 relative error could reorder near-ties.
 #include "engine_internal.h"
 #include "sincos_reduced.h"
+#include "pcps_codelets.h"
 
 #include <cmath>
 #include <cstring>
@@ -32,10 +33,6 @@ enum LoadMode { LOAD_PLAIN = 0, LOAD_IQ_MIX = 1, LOAD_MUL_CODE = 2, LOAD_CODE_RE
 // writes one 16-byte record per wave (the map-free search: the caller only wants indices and ratio).
 enum StoreMode { STORE_PLAIN = 0, STORE_CONJ = 1, STORE_MAG_ACC = 2, STORE_CPLX_ACC = 3, STORE_MAG_MAX = 4 };
 
-struct Best {
-    double v;
-    long long i;
-};
 
 struct PassArgs {
     const double2* in;    // [batch][N]
@@ -71,8 +68,6 @@ struct PassArgs {
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 // multiply by -i (forward) or +i (inverse)
 template <bool INV>
 __device__ __forceinline__ double2 mul_mi(double2 a) {
@@ -633,27 +628,6 @@ __device__ __forceinline__ double2* lds_fft_auto(double2* a, double2* b, int Nsu
     }
 }
 
-// (value, index) maximum over the 64 lanes of a wave, left in lane 63: larger value, smaller index on ties.  DPP
-// row shifts inside each row of 16 lanes, then row broadcasts -- no LDS traffic.
-__device__ __forceinline__ void wave_best(double& v, int& i) {
-    auto step = [&](auto ctrl, auto rows) {
-        constexpr int C = decltype(ctrl)::value, RM = decltype(rows)::value;
-        const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), C, RM, 0xf, false);
-        const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), C, RM, 0xf, false);
-        const int oi = __builtin_amdgcn_update_dpp(i, i, C, RM, 0xf, false);
-        const double ov = __hiloint2double(hi, lo);
-        const bool take = ov > v || (ov == v && oi < i);
-        v = take ? ov : v;
-        i = take ? oi : i;
-    };
-    step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});  // row_shr:1
-    step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});  // row_shr:2
-    step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});  // row_shr:4
-    step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});  // row_shr:8  -> lane 15 of each row holds the row's best
-    step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1 and 3
-    step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's best
-}
-
 // The raw operands of one element of the fused first stage, fetched without being combined: the global loads of
 // several elements are issued back to back and waited for once (a loop of load -> use pays one memory round trip per
 // iteration, ~1 us each under load, which is what these kernels' time was made of).
@@ -963,7 +937,9 @@ void run_four_step(sdr_engine* e, const FourStep& f, PassArgs a, int batch, doub
 // per-wave records one map-free inverse sweep leaves per transform
 inline int records_per_transform(const FourStep& f) { return ((f.N1 + kRowTile - 1) / kRowTile) * (kThreads / 64); }
 // ... and of the main sweep, which may run the register-resident kernels
+inline bool fused_applies(const sdr_engine* e, const FourStep& f) { return fast25k_applies(e, f) && e->pcps_fused; }
 inline int records_main_sweep(const sdr_engine* e, const FourStep& f) {
+    if (fused_applies(e, f)) return SDR_PCPS_FUSED_RECORDS;
     if (fast25k_applies(e, f)) return fast25k::kRecordsPerTransform;
     return fast_applies(e, f) ? fastn::records(f.N1 * f.N2) : records_per_transform(f);
 }
@@ -1158,6 +1134,11 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
             f.bin_delta = bin_delta;
             run_fft<false, LOAD_IQ_MIX, STORE_PLAIN, FMT>(e, radices, f, nbins, A, B, F, "pcps_fwd_fft", blu);
 
+            if (map_free && fused_applies(e, plan_four_step(N))) {
+                // every (PRN, bin) transform of the search in ONE launch of persistent workgroups: no intermediate, no sweeps
+                if (int rcf = sdr_pcps_fused_sweep(e, F, C, tw, n_prn, nbins, N, e->pcps_part.ptr)) return rcf;
+                continue;
+            }
             // Register-resident kernels, several sweeps, nobody timing the stages: the sweeps alternate between two
             // streams and two intermediates, so that one sweep's partial last rounds of workgroups (and its launch
             // ramps) are filled by the other's -- ordered behind the forward transforms and in front of the peak

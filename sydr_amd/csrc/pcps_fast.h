@@ -38,31 +38,6 @@ constexpr int kRowPitch = 10 * kRowT + 1;                 // 16-byte slots per e
 constexpr int kRowTiles = (N1 + kRowT - 1) / kRowT;
 constexpr int kRecordsPerTransform = kRowTiles * (kRowThreads / 64);
 
-// Transform arithmetic with fused multiply-adds spelled out (pcps.hip is compiled with -ffp-contract=off for the
-// stages that must round like NumPy; a transform is free arithmetic and an FMA only makes it more accurate).
-__device__ __forceinline__ double2 cmulf(double2 a, double2 b) {       // a * b
-    return make_double2(__builtin_fma(-a.y, b.y, a.x * b.x), __builtin_fma(a.y, b.x, a.x * b.y));
-}
-__device__ __forceinline__ double2 cmul_conj(double2 a, double2 w) {   // a * conj(w)
-    return make_double2(__builtin_fma(a.y, w.y, a.x * w.x), __builtin_fma(-a.x, w.y, a.y * w.x));
-}
-// Inverse radix-5 butterfly: out[k] = sum_t v[t] exp(+2 pi i t k / 5); 36 instructions (the contracted-off general one: 48).
-__device__ __forceinline__ void ibf5(double2* v) {
-    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;  // cos(2pi/5), cos(4pi/5)
-    const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;   // sin(2pi/5), sin(4pi/5)
-    const double2 a1 = cadd(v[1], v[4]), b1 = csub(v[1], v[4]);
-    const double2 a2 = cadd(v[2], v[3]), b2 = csub(v[2], v[3]);
-    const double2 m1 = make_double2(__builtin_fma(c2, a2.x, __builtin_fma(c1, a1.x, v[0].x)), __builtin_fma(c2, a2.y, __builtin_fma(c1, a1.y, v[0].y)));
-    const double2 m2 = make_double2(__builtin_fma(c1, a2.x, __builtin_fma(c2, a1.x, v[0].x)), __builtin_fma(c1, a2.y, __builtin_fma(c2, a1.y, v[0].y)));
-    const double2 r1 = make_double2(__builtin_fma(s2, b2.x, s1 * b1.x), __builtin_fma(s2, b2.y, s1 * b1.y));
-    const double2 r2 = make_double2(__builtin_fma(-s1, b2.x, s2 * b1.x), __builtin_fma(-s1, b2.y, s2 * b1.y));
-    v[0] = cadd(v[0], cadd(a1, a2));
-    v[1] = make_double2(m1.x - r1.y, m1.y + r1.x);       // m1 + i r1
-    v[4] = make_double2(m1.x + r1.y, m1.y - r1.x);
-    v[2] = make_double2(m2.x - r2.y, m2.y + r2.x);
-    v[3] = make_double2(m2.x + r2.y, m2.y - r2.x);
-}
-
 // 25-point inverse transform of v[m], m = m1 + 5 m2: result A[kA + 5 kB] in v[5 kA + kB].
 __device__ __forceinline__ void idft25(double2* v, const double2* __restrict__ tw) {
 #pragma unroll

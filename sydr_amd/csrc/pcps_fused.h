@@ -1,0 +1,343 @@
+// One workgroup per (PRN, bin) inverse transform of the map-free PCPS search at N = 25 000 = 125 x 200 (25 MHz, 1 ms:
+// BASELINE configs[1]): the four-step intermediate never leaves the compute unit.  Included by pcps_fused.hip alone (its own
+// translation unit: built without MachineLICM, see the Makefile).
+//
+// The two-kernel four-step of pcps_fast.h writes the 400 KB intermediate of every transform to memory and reads it back
+// (1.07 GB per 32-PRN x 41-bin call; a kernel's dirty L2 lines are written back when it ends).  Here a 512-thread
+// workgroup -- alone on its CU: 2 waves per SIMD, up to 256 registers per lane, all 160 KiB of LDS -- keeps it:
+//
+//   column stage  (length 125 = 25 x 5; five threads per column, 100 columns at a time, two items per thread):
+//       A_r[k'] = sum_m x[r + 5m] w25^(m k'),  B_r[k'] = A_r[k'] w125^(r k')       25-point transform in registers
+//     and the 25 000 values B are PARKED: k' = kA + 5 kB belongs to round kA; rounds 0 and 1 go straight to the two LDS
+//     buffers (80 000 B each), rounds 2-4 stay in registers (30 points = 120 registers per thread) and move into a
+//     buffer as soon as its round has been consumed.
+//   round rho = 0..4 (25 rows k1 = rho + 5 s + 25 q of the intermediate, 80 KB, in place in one buffer):
+//       Y[k' + 25 q] = sum_r B_r[k'] w5^(r q)                                       thread (s, column): k' = rho + 5 s
+//       row stage (length 200 = 10 x 20, twenty threads per row, ten points each):
+//       z[n2] = Y[k1][n2] w_N^(n2 k1)                                               four-step twiddle: base * step^m
+//       A_e[k''] = sum_m z[e + 20m] w10^(m k''),  B_e[k''] = A_e[k''] w200^(e k'')  thread (row, e)
+//       X[k1 + 125 (k'' + 10 (2p + h))] = sum_t (B_t[k''] +- B_(t+10)[k'']) w20^(h t) w10^(t p)
+//                                                                                   thread (row, k'', h): radix-2 DIF on
+//                                                                                   the way in, then a 10-point transform
+//     and only the running (|.|/N, first index) maximum survives: one 16-byte record per wave and transform.
+//   (w = conjugated table entries: inverse transforms, unnormalised; 1/N enters with |.| as in pcps_fast.h.)
+//
+// The workgroups are persistent: workgroup (XCD x, slot s) walks its XCD's share of a host-made work list in steps of
+// 32, and the list is ordered in blocks of 4 bins x 8 PRNs so that the operands of the transforms an XCD has in flight
+// (12 arrays of 400 KB) mostly sit in its L2.
+#pragma once
+
+namespace fused25k {
+
+using fast25k::cmul_conj;
+using fast25k::cmulf;
+using fast25k::ibf5;
+
+constexpr int N1 = 125, N2 = 200, N = 25000;
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int kBuf = 25 * N2;                 // double2 per round buffer
+constexpr int kTab = 240;                     // w125^e (e <= 96) during the column stage, w200^e (e <= 171) during the rows
+constexpr size_t kLdsBytes = (size_t)(2 * kBuf + kTab) * sizeof(double2);
+static_assert(kLdsBytes == 160 * 1024, "the whole LDS of a CU");
+constexpr int kRecordsPerTransform = kWaves;
+constexpr int kSlotsPerXcd = 32;
+
+// exp(-2 pi i k / n) for the transforms' internal twiddles: literals (a wave-uniform table read costs scalar registers the
+// kernel does not have; the compiler materialises a literal where it is used)
+constexpr double kW25X[17] = {1.0, 0.9685831611286311, 0.8763066800438636, 0.7289686274214116, 0.5358267949789967, 0.30901699437494745, 0.06279051952931337, -0.18738131458572463, -0.42577929156507266, -0.6374239897486897, -0.8090169943749475, -0.9297764858882515, -0.9921147013144779, -0.9921147013144779, -0.9297764858882515, -0.8090169943749475, -0.6374239897486897};
+constexpr double kW25Y[17] = {0.0, -0.2486898871648548, -0.48175367410171527, -0.6845471059286887, -0.8443279255020151, -0.9510565162951535, -0.9980267284282716, -0.9822872507286887, -0.9048270524660196, -0.7705132427757893, -0.5877852522924731, -0.368124552684678, -0.12533323356430426, 0.12533323356430426, 0.368124552684678, 0.5877852522924731, 0.7705132427757893};
+constexpr double kW10X[5] = {1.0, 0.8090169943749475, 0.30901699437494745, -0.30901699437494745, -0.8090169943749475};
+constexpr double kW10Y[5] = {0.0, -0.5877852522924731, -0.9510565162951535, -0.9510565162951535, -0.5877852522924731};
+constexpr double kW20X[10] = {1.0, 0.9510565162951535, 0.8090169943749475, 0.5877852522924731, 0.30901699437494745, 0.0, -0.30901699437494745, -0.5877852522924731, -0.8090169943749475, -0.9510565162951535};
+constexpr double kW20Y[10] = {0.0, -0.30901699437494745, -0.5877852522924731, -0.8090169943749475, -0.9510565162951535, -1.0, -0.9510565162951535, -0.8090169943749475, -0.5877852522924731, -0.30901699437494745};
+
+// 10-point inverse transform of u[r], r = r1 + 2 r2: result X[qA + 5 qB] in u[2 qA + qB] (fast25k::idft10 with literal twiddles)
+__device__ __forceinline__ void idft10c(double2* u) {
+#pragma unroll
+    for (int r1 = 0; r1 < 2; ++r1) {
+        double2 t[5] = {u[r1], u[r1 + 2], u[r1 + 4], u[r1 + 6], u[r1 + 8]};
+        ibf5(t);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) u[r1 + 2 * k] = t[k];
+    }
+#pragma unroll
+    for (int qA = 1; qA < 5; ++qA) u[1 + 2 * qA] = cmul_conj(u[1 + 2 * qA], make_double2(kW10X[qA], kW10Y[qA]));
+#pragma unroll
+    for (int qA = 0; qA < 5; ++qA) {
+        const double2 a = u[2 * qA], b = u[2 * qA + 1];
+        u[2 * qA] = cadd(a, b);
+        u[2 * qA + 1] = csub(a, b);
+    }
+}
+
+// 16-byte load from a wave-uniform base plus a 32-bit per-lane byte offset (scalar base + vector offset addressing: no
+// 64-bit address per load in vector registers)
+__device__ __forceinline__ double2 ldg(const char* __restrict__ ubase, unsigned voff) {
+    return *reinterpret_cast<const double2*>(ubase + voff);
+}
+
+struct Args {
+    const double2* spec;       // [nbins][N] forward spectra of the Doppler-mixed block
+    const double2* code_spec;  // [n_prn][N]
+    const double2* tw;         // exp(-2 pi i m / N)
+    const int* work;           // transform numbers (prn * nbins + bin) in processing order
+    int xcd_first[9];          // XCD x owns work[xcd_first[x] .. xcd_first[x + 1])
+    int nbins;
+    double scale;
+    Best* partials;            // [transform][kRecordsPerTransform]
+};
+
+__global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
+    extern __shared__ double2 lds4[];
+    double2* const tab = lds4 + 2 * kBuf;
+    const double2* __restrict__ tw = a.tw;
+
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int w_end = a.xcd_first[xcd + 1];
+    for (int w = a.xcd_first[xcd] + slot; w < w_end; w += kSlotsPerXcd) {
+        const int batch = a.work[w];
+        const int prn = batch / a.nbins;
+        const int bin = batch - prn * a.nbins;
+
+        // Thread roles, re-derived per transform from an opaque copy of the thread number: left loop-invariant the compiler
+        // keeps every address of the loop body in registers across the whole loop -- and spills them.
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        // column stage / first half of a round: thread (r, c) of 5 x 100
+        const bool live = t_ < 500;
+        const int r = live ? t_ / 100 : 0, c = live ? t_ - 100 * r : 0;
+        const int cb = r * N2 + c;                          // its slot in a buffer row group
+        // row stage 1: thread (row i, e) of 25 x 20
+        const int ri = live ? t_ / 20 : 0, re = live ? t_ - 20 * ri : 0;
+        const int k1b = 5 * (ri / 5) + 25 * (ri % 5);       // its row's k1 = rho + k1b
+        // row stage 2: waves 0-3 take the even outputs (h = 0), waves 4-7 the odd ones: thread (row, k'') of 25 x 10
+        const int h = tid >> 8;
+        const int t2 = t_ & 255;
+        const bool live2 = t2 < 250;
+        const int si = live2 ? t2 / 10 : 0, sk = live2 ? t2 - 10 * si : 0;
+        const int kf0 = 5 * (si / 5) + 25 * (si % 5) + N1 * (sk + 10 * h);
+
+        if (tid < 97) tab[tid] = tw[(N / 125) * tid];
+        __syncthreads();   // the table; and every reader of the previous transform's last rounds is done with the buffers
+
+        // ---- column stage: two items of 25 points; rounds 0 / 1 to the buffers, rounds 2-4 parked.  Register budget
+        // (256 per lane, nothing may spill): a group of five points is multiplied and put through the first radix-5
+        // stage while the NEXT group's ten loads are in flight; while item 1 is transformed, ten of item 0's fifteen
+        // parked points wait in the LDS slots item 1 will fill at its end (a thread's own slots: no barrier).
+        double2 park[2][15];
+        const char* __restrict__ xs_u = reinterpret_cast<const char*>(a.spec + (size_t)bin * N);
+        const char* __restrict__ cs_u = reinterpret_cast<const char*>(a.code_spec + (size_t)prn * N);
+        const unsigned toff = (unsigned)cb * 16u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            double2* const eP = lds4 + cb + 100 * j;            // E slots of this (r, column): + 5 N2 kB; round 1: + kBuf
+            double2 v[25];
+            if (live) {
+                constexpr int kRowBytes = N2 * 16;              // one n1 step
+                double2 xa[5], ca[5];
+#pragma unroll
+                for (int m2 = 0; m2 < 5; ++m2) {
+                    xa[m2] = ldg(xs_u + 1600 * j + kRowBytes * 25 * m2, toff);
+                    ca[m2] = ldg(cs_u + 1600 * j + kRowBytes * 25 * m2, toff);
+                }
+                if (j == 1) {
+#pragma unroll
+                    for (int g = 0; g < 5; ++g) {
+                        eP[5 * N2 * g] = park[0][g];
+                        eP[kBuf + 5 * N2 * g] = park[0][5 + g];
+                    }
+                }
+#pragma unroll
+                for (int m1 = 0; m1 < 5; ++m1) {
+                    double2 xb[5], cb_[5];
+                    if (m1 < 4) {
+#pragma unroll
+                        for (int m2 = 0; m2 < 5; ++m2) {
+                            xb[m2] = ldg(xs_u + 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2), toff);
+                            cb_[m2] = ldg(cs_u + 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2), toff);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double2 t[5];
+#pragma unroll
+                    for (int m2 = 0; m2 < 5; ++m2) t[m2] = cmulf(xa[m2], ca[m2]);
+                    ibf5(t);
+                    v[m1] = t[0];
+#pragma unroll
+                    for (int kA = 1; kA < 5; ++kA)
+                        v[m1 + 5 * kA] = m1 ? cmul_conj(t[kA], make_double2(kW25X[m1 * kA], kW25Y[m1 * kA])) : t[kA];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m1 < 4) {
+#pragma unroll
+                        for (int m2 = 0; m2 < 5; ++m2) {
+                            xa[m2] = xb[m2];
+                            ca[m2] = cb_[m2];
+                        }
+                    }
+                }
+                // second stage of the 25-point transform and the twiddle between the column's two levels
+#pragma unroll
+                for (int kA = 0; kA < 5; ++kA) {
+                    double2 t[5] = {v[5 * kA], v[5 * kA + 1], v[5 * kA + 2], v[5 * kA + 3], v[5 * kA + 4]};
+                    ibf5(t);
+#pragma unroll
+                    for (int kB = 0; kB < 5; ++kB) {
+                        const int kp = kA + 5 * kB;
+                        v[5 * kA + kB] = kp ? cmul_conj(t[kB], tab[r * kp]) : t[kB];
+                    }
+                }
+                if (j == 1) {
+#pragma unroll
+                    for (int g = 0; g < 5; ++g) {
+                        park[0][g] = eP[5 * N2 * g];
+                        park[0][5 + g] = eP[kBuf + 5 * N2 * g];
+                    }
+                }
+#pragma unroll
+                for (int kB = 0; kB < 5; ++kB) {
+                    eP[5 * N2 * kB] = v[kB];
+                    eP[kBuf + 5 * N2 * kB] = v[5 + kB];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 15; ++g) park[j][g] = v[10 + g];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+
+        double best_sq = -1.0, best_x = 0.0, best_y = 0.0;
+        int best_k = -1;
+#pragma unroll
+        for (int rho = 0; rho < 5; ++rho) {
+            double2* const X = lds4 + ((rho & 1) ? kBuf : 0);
+            double2* const Xo = lds4 + ((rho & 1) ? 0 : kBuf);
+            // the row's four-step twiddle w_N^(k1 (e + 20 m)) = base * step^m: two scattered table reads, in flight
+            // over the first half of the round
+            const int k1 = rho + k1b;
+            const double2 tw_base = tw[k1 * re], tw_step = tw[20 * k1];
+            // Y[k' + 25 q], in place
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    double2* const col = X + 5 * cb - 4 * c + 100 * j;      // (r * 5) * N2 + c
+                    double2 t5[5];
+#pragma unroll
+                    for (int rr = 0; rr < 5; ++rr) t5[rr] = col[rr * N2];
+                    ibf5(t5);
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) col[q * N2] = t5[q];
+                }
+            }
+            if (rho == 0 && tid < 172) tab[tid] = tw[(N / 200) * tid];   // (every w125 read lies before the last barrier)
+            __syncthreads();
+            // the buffer of round rho - 1 is free now: round rho + 1 moves in from the registers
+            if (rho >= 1 && rho <= 3 && live) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int kB = 0; kB < 5; ++kB) Xo[cb + 100 * j + 5 * N2 * kB] = park[j][5 * (rho - 1) + kB];
+            }
+            // rows, first stage
+            double2 z[10];
+            if (live) {
+                const double2* __restrict__ rowz = X + ri * N2 + re;
+#pragma unroll
+                for (int m = 0; m < 10; ++m) z[m] = rowz[20 * m];
+                double2 t = tw_base;
+                z[0] = cmul_conj(z[0], t);
+#pragma unroll
+                for (int m = 1; m < 10; ++m) {
+                    t = cmulf(t, tw_step);
+                    z[m] = cmul_conj(z[m], t);
+                }
+                idft10c(z);
+#pragma unroll
+                for (int g = 1; g < 10; ++g) {
+                    const int kpp = g / 2 + 5 * (g % 2);
+                    z[g] = cmul_conj(z[g], tab[re * kpp]);
+                }
+            }
+            __syncthreads();   // every read of the row is done: the exchange goes in place
+            if (live) {
+                double2* const roww = X + ri * N2 + 10 * re;
+#pragma unroll
+                for (int g = 0; g < 10; ++g) {
+                    const int kpp = g / 2 + 5 * (g % 2);
+                    roww[kpp] = z[g];
+                }
+            }
+            __syncthreads();
+            // rows, second stage: 20 = 2 x 10, radix-2 decimation in frequency while reading
+            if (live2) {
+                double2 u[10];
+                const double2* __restrict__ row = X + si * N2 + sk;
+#pragma unroll
+                for (int t0 = 0; t0 < 10; t0 += 5) {     // (five pairs of reads in flight: registers)
+                    double2 lo[5], hi[5];
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) {
+                        lo[t] = row[10 * (t0 + t)];
+                        hi[t] = row[10 * (t0 + t + 10)];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) u[t0 + t] = h ? csub(lo[t], hi[t]) : cadd(lo[t], hi[t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (h) {
+#pragma unroll
+                    for (int t = 1; t < 10; ++t) u[t] = cmul_conj(u[t], make_double2(kW20X[t], kW20Y[t]));
+                }
+                idft10c(u);
+                const int k_first = kf0 + rho;
+#pragma unroll
+                for (int g = 0; g < 10; ++g) {
+                    const int p = g / 2 + 5 * (g % 2);
+                    const int k = k_first + 20 * N1 * p;              // code phase = position in the transform
+                    const double2 x = u[g];
+                    const double sq = __builtin_fma(x.x, x.x, x.y * x.y);
+                    bool take = sq > best_sq;
+                    // (ordering by the squared magnitude; candidates within 2^-48 of the lane's best go through the scaled
+                    // hypot -- the reference's np.abs -- and an exact tie keeps the smaller index: pcps_fast.h)
+                    const bool near = fabs(sq - best_sq) <= best_sq * 0x1p-48;
+                    if (__builtin_expect(__any(near), 0)) {
+                        if (near) {
+                            const double m_new = hypot(x.x * a.scale, x.y * a.scale), m_old = hypot(best_x * a.scale, best_y * a.scale);
+                            take = m_new > m_old || (m_new == m_old && k < best_k);
+                        }
+                    }
+                    best_sq = take ? sq : best_sq;
+                    best_x = take ? x.x : best_x;
+                    best_y = take ? x.y : best_y;
+                    best_k = take ? k : best_k;
+                }
+            }
+        }
+        int best_i = 0x7fffffff;
+        double best_v = -1.0;
+        if (live2) {
+            best_i = bin * N + best_k;
+            best_v = 0.0 + hypot(best_x * a.scale, best_y * a.scale);   // (0.0 + |.|: the map's own rounding)
+        }
+        wave_best(best_v, best_i);
+        if ((tid & 63) == 63) {
+            Best rec = {best_v, (long long)best_i};
+            a.partials[(size_t)batch * kRecordsPerTransform + (tid >> 6)] = rec;
+        }
+    }
+}
+
+// Processing order: blocks of 4 bins x 8 PRNs (32 transforms = one round of an XCD's 32 workgroups), dealt to the XCDs
+// in contiguous eighths.  `order` receives n_prn * nbins transform numbers, `first` the nine range limits.
+inline void make_work_list(int n_prn, int nbins, std::vector<int>& order, int first[9]) {
+    order.clear();
+    for (int b0 = 0; b0 < nbins; b0 += 4)
+        for (int p0 = 0; p0 < n_prn; p0 += 8)
+            for (int b = b0; b < b0 + 4 && b < nbins; ++b)
+                for (int p = p0; p < p0 + 8 && p < n_prn; ++p) order.push_back(p * nbins + b);
+    const int total = (int)order.size();
+    for (int x = 0; x <= 8; ++x) first[x] = (int)(((long long)total * x) / 8);
+}
+
+}  // namespace fused25k

@@ -1,0 +1,43 @@
+// The one-workgroup-per-transform inverse sweep of the map-free PCPS search (pcps_fused.h) and its launch.
+// Its own translation unit: at 256 registers per lane the kernel must not let MachineLICM hoist the literal twiddles
+// and the loop body's addresses out of the persistent loop (they would be spilled): built with -disable-machine-licm.
+// Reference: sydr/dsp/acquisition.py:57-70 (ifft(fft(x) * codeFFT), |.|) and :98-100 (the first maximum).
+#include "engine_internal.h"
+#include "pcps_codelets.h"
+
+#include <vector>
+
+namespace {
+#include "pcps_fused.h"
+static_assert(fused25k::kRecordsPerTransform == SDR_PCPS_FUSED_RECORDS, "records per transform");
+}  // namespace
+
+int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int nbins, int N, void* partials) {
+    if (N != fused25k::N) return sdr_fail(SDR_ERR_UNSUPPORTED, "fused PCPS sweep: N = %d", N);
+    if (e->pcps_work_prn != n_prn || e->pcps_work_bins != nbins) {
+        std::vector<int> order;
+        fused25k::make_work_list(n_prn, nbins, order, e->pcps_work_first);
+        if (int rc = sdr_devbuf_reserve(e, &e->pcps_work, order.size() * sizeof(int))) return rc;
+        // (pageable source, tiny: the copy is complete when the stream has been waited for)
+        SDR_HIP(hipMemcpyAsync(e->pcps_work.ptr, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        SDR_HIP(hipStreamSynchronize(e->stream));
+        e->pcps_work_prn = n_prn;
+        e->pcps_work_bins = nbins;
+    }
+    fused25k::Args a = {};
+    a.spec = (const double2*)F;
+    a.code_spec = (const double2*)C;
+    a.tw = (const double2*)tw;
+    a.work = (const int*)e->pcps_work.ptr;
+    for (int x = 0; x < 9; ++x) a.xcd_first[x] = e->pcps_work_first[x];
+    a.nbins = nbins;
+    a.scale = 1.0 / (double)N;
+    a.partials = (Best*)partials;
+    (void)hipFuncSetAttribute((const void*)fused25k::ifft_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)fused25k::kLdsBytes);
+    ProfScope ps(e, "pcps_inv_fft");
+    hipLaunchKernelGGL(fused25k::ifft_max_kernel, dim3(8 * fused25k::kSlotsPerXcd), dim3(fused25k::kThreads),
+                       fused25k::kLdsBytes, e->stream, a);
+    SDR_HIP(hipGetLastError());
+    return SDR_OK;
+}
