@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, con
             }
         }
         if (live) {
-            best_i = bin * N + best_k;
+            best_i = (bin + a.bin0) * N + best_k;
             best_v = 0.0 + hypot(best_x * a.scale, best_y * a.scale);   // (0.0 + |.|: the map's own rounding)
         }
     }

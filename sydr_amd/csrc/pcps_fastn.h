@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kRowThreads) void rows_kernel(const PassArgs a, con
         }
         if constexpr (STORE != STORE_MAG_MAX) return;
         if (live) {
-            best_i = bin * N + best_k;
+            best_i = (bin + a.bin0) * N + best_k;
             best_v = 0.0 + hypot(best_x * a.scale, best_y * a.scale);
         }
     }

@@ -27,6 +27,22 @@
 // (12 arrays of 400 KB) mostly sit in its L2.
 #pragma once
 
+// Build-time switches of the A/B variants (tools/build_variant.sh <tag> pcps_fused -DFUSED_...=0|1); measured on one
+// box, 32 PRNs x 41 bins, ms per call: all off 0.266; buffer loads 0.267; merged Y step 0.291; twiddles a round ahead
+// 0.273; reads first 0.267 (gpurun_out/r04_fused_var9.txt) -- the defaults are the fastest
+#ifndef FUSED_BUFLOAD
+#define FUSED_BUFLOAD 0      // operand loads as buffer loads (scalar descriptor + one per-lane offset) instead of 64-bit addresses
+#endif
+#ifndef FUSED_MERGE_Y
+#define FUSED_MERGE_Y 0      // the next round's Y-in-place step inside this round's second row stage (3 barriers per round, not 4)
+#endif
+#ifndef FUSED_TW_AHEAD
+#define FUSED_TW_AHEAD 0     // the row's two four-step twiddle reads requested a round ahead
+#endif
+#ifndef FUSED_READS_FIRST
+#define FUSED_READS_FIRST 0  // row stage 1: LDS reads in front of the parked round's stores
+#endif
+
 namespace fused25k {
 
 using fast25k::cmul_conj;
@@ -71,11 +87,33 @@ __device__ __forceinline__ void idft10c(double2* u) {
     }
 }
 
-// 16-byte load from a wave-uniform base plus a 32-bit per-lane byte offset (scalar base + vector offset addressing: no
-// 64-bit address per load in vector registers)
-__device__ __forceinline__ double2 ldg(const char* __restrict__ ubase, unsigned voff) {
-    return *reinterpret_cast<const double2*>(ubase + voff);
+// 16-byte buffer load: wave-uniform descriptor (base, bytes) + per-lane 32-bit byte offset + wave-uniform byte offset --
+// no 64-bit address per load in vector registers and no vector arithmetic for the 50 distances of an item
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
+#if FUSED_BUFLOAD
+struct Operand {
+    __amdgpu_buffer_rsrc_t rs;
+};
+__device__ __forceinline__ Operand make_operand(const double2* base) { return {make_rsrc(base, N * 16)}; }
+__device__ __forceinline__ double2 ldb(const Operand& o, unsigned voff, unsigned soff) {
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(o.rs, (int)voff, (int)soff, 0);
+    double2 d;
+    d.x = __hiloint2double((int)q.y, (int)q.x);
+    d.y = __hiloint2double((int)q.w, (int)q.z);
+    return d;
+}
+#else
+struct Operand {
+    const char* base;
+};
+__device__ __forceinline__ Operand make_operand(const double2* base) { return {reinterpret_cast<const char*>(base)}; }
+__device__ __forceinline__ double2 ldb(const Operand& o, unsigned voff, unsigned soff) {
+    return *reinterpret_cast<const double2*>((o.base + soff) + voff);
+}
+#endif
 
 struct Args {
     const double2* spec;       // [nbins][N] forward spectra of the Doppler-mixed block
@@ -88,8 +126,25 @@ struct Args {
     Best* partials;            // [transform][kRecordsPerTransform]
 };
 
+// Diagnostic build (-DSDR_FUSED_STAMPS, tools/pcps_fused_phases.py): wave 0 of every workgroup adds up the shader cycles
+// between phase boundaries; read back through sdr_debug_fused_stamps.  No stamp executes in the regular build.
+#ifdef SDR_FUSED_STAMPS
+__device__ unsigned long long g_fused_stamps[256][8];
+#define FUSED_STAMP(slot)                                                  \
+    do {                                                                   \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
+        if (tid == 0) g_fused_stamps[blockIdx.x][slot] += now_ - stamp_;   \
+        stamp_ = now_;                                                     \
+    } while (0)
+#else
+#define FUSED_STAMP(slot) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
     extern __shared__ double2 lds4[];
+#ifdef SDR_FUSED_STAMPS
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
     double2* const tab = lds4 + 2 * kBuf;
     const double2* __restrict__ tw = a.tw;
 
@@ -97,7 +152,14 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int w_end = a.xcd_first[xcd + 1];
     for (int w = a.xcd_first[xcd] + slot; w < w_end; w += kSlotsPerXcd) {
+#ifndef FUSED_SCALAR_WORK
+#define FUSED_SCALAR_WORK 1
+#endif
+#if FUSED_SCALAR_WORK
+        const int batch = __builtin_amdgcn_readfirstlane(a.work[w]);   // (wave-uniform: scalar base addresses below)
+#else
         const int batch = a.work[w];
+#endif
         const int prn = batch / a.nbins;
         const int bin = batch - prn * a.nbins;
 
@@ -121,14 +183,15 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
 
         if (tid < 97) tab[tid] = tw[(N / 125) * tid];
         __syncthreads();   // the table; and every reader of the previous transform's last rounds is done with the buffers
+        FUSED_STAMP(0);
 
         // ---- column stage: two items of 25 points; rounds 0 / 1 to the buffers, rounds 2-4 parked.  Register budget
         // (256 per lane, nothing may spill): a group of five points is multiplied and put through the first radix-5
         // stage while the NEXT group's ten loads are in flight; while item 1 is transformed, ten of item 0's fifteen
         // parked points wait in the LDS slots item 1 will fill at its end (a thread's own slots: no barrier).
         double2 park[2][15];
-        const char* __restrict__ xs_u = reinterpret_cast<const char*>(a.spec + (size_t)bin * N);
-        const char* __restrict__ cs_u = reinterpret_cast<const char*>(a.code_spec + (size_t)prn * N);
+        const Operand xs_u = make_operand(a.spec + (size_t)bin * N);
+        const Operand cs_u = make_operand(a.code_spec + (size_t)prn * N);
         const unsigned toff = (unsigned)cb * 16u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -139,8 +202,8 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
                 double2 xa[5], ca[5];
 #pragma unroll
                 for (int m2 = 0; m2 < 5; ++m2) {
-                    xa[m2] = ldg(xs_u + 1600 * j + kRowBytes * 25 * m2, toff);
-                    ca[m2] = ldg(cs_u + 1600 * j + kRowBytes * 25 * m2, toff);
+                    xa[m2] = ldb(xs_u, toff, 1600 * j + kRowBytes * 25 * m2);
+                    ca[m2] = ldb(cs_u, toff, 1600 * j + kRowBytes * 25 * m2);
                 }
                 if (j == 1) {
 #pragma unroll
@@ -155,8 +218,8 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
                     if (m1 < 4) {
 #pragma unroll
                         for (int m2 = 0; m2 < 5; ++m2) {
-                            xb[m2] = ldg(xs_u + 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2), toff);
-                            cb_[m2] = ldg(cs_u + 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2), toff);
+                            xb[m2] = ldb(xs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
+                            cb_[m2] = ldb(cs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -204,8 +267,35 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
 #pragma unroll
             for (int g = 0; g < 15; ++g) park[j][g] = v[10 + g];
             __builtin_amdgcn_sched_barrier(0);
+            FUSED_STAMP(1 + j);
         }
         __syncthreads();
+        FUSED_STAMP(3);
+
+        // Y[k' + 25 q] = sum_r B_r[k'] w5^(r q) of one round, in place (a thread reads and writes its own five slots)
+        auto y_in_place = [&](double2* X) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                double2* const col = X + 5 * cb - 4 * c + 100 * j;      // (r * 5) * N2 + c
+                double2 t5[5];
+#pragma unroll
+                for (int rr = 0; rr < 5; ++rr) t5[rr] = col[rr * N2];
+                ibf5(t5);
+#pragma unroll
+                for (int q = 0; q < 5; ++q) col[q * N2] = t5[q];
+            }
+        };
+        // the row's four-step twiddle w_N^(k1 (e + 20 m)) = base * step^m: two scattered table reads per round, requested
+        // a phase ahead
+#if FUSED_TW_AHEAD
+        double2 tw_base = tw[k1b * re], tw_step = tw[20 * k1b];
+#endif
+#if FUSED_MERGE_Y
+        if (live) y_in_place(lds4);
+        if (tid < 172) tab[tid] = tw[(N / 200) * tid];   // (every w125 read lies before the last barrier)
+        __syncthreads();
+        FUSED_STAMP(4);
+#endif
 
         double best_sq = -1.0, best_x = 0.0, best_y = 0.0;
         int best_k = -1;
@@ -213,38 +303,37 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
         for (int rho = 0; rho < 5; ++rho) {
             double2* const X = lds4 + ((rho & 1) ? kBuf : 0);
             double2* const Xo = lds4 + ((rho & 1) ? 0 : kBuf);
-            // the row's four-step twiddle w_N^(k1 (e + 20 m)) = base * step^m: two scattered table reads, in flight
-            // over the first half of the round
-            const int k1 = rho + k1b;
-            const double2 tw_base = tw[k1 * re], tw_step = tw[20 * k1];
-            // Y[k' + 25 q], in place
-            if (live) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    double2* const col = X + 5 * cb - 4 * c + 100 * j;      // (r * 5) * N2 + c
-                    double2 t5[5];
-#pragma unroll
-                    for (int rr = 0; rr < 5; ++rr) t5[rr] = col[rr * N2];
-                    ibf5(t5);
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) col[q * N2] = t5[q];
-                }
-            }
+#if !FUSED_TW_AHEAD
+            const double2 tw_base = tw[(rho + k1b) * re], tw_step = tw[20 * (rho + k1b)];
+#endif
+#if !FUSED_MERGE_Y
+            if (live) y_in_place(X);
             if (rho == 0 && tid < 172) tab[tid] = tw[(N / 200) * tid];   // (every w125 read lies before the last barrier)
             __syncthreads();
-            // the buffer of round rho - 1 is free now: round rho + 1 moves in from the registers
-            if (rho >= 1 && rho <= 3 && live) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int kB = 0; kB < 5; ++kB) Xo[cb + 100 * j + 5 * N2 * kB] = park[j][5 * (rho - 1) + kB];
-            }
-            // rows, first stage
+            FUSED_STAMP(4);
+#endif
+            // ---- rows, first stage (reads first; then the parked round rho + 1 moves into the buffer round rho - 1 has
+            // left -- its stores drain while the transform computes)
             double2 z[10];
             if (live) {
                 const double2* __restrict__ rowz = X + ri * N2 + re;
+#if FUSED_READS_FIRST
 #pragma unroll
                 for (int m = 0; m < 10; ++m) z[m] = rowz[20 * m];
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                if (rho >= 1 && rho <= 3) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int kB = 0; kB < 5; ++kB) Xo[cb + 100 * j + 5 * N2 * kB] = park[j][5 * (rho - 1) + kB];
+                }
+#if FUSED_READS_FIRST
+                __builtin_amdgcn_sched_barrier(0);
+#else
+#pragma unroll
+                for (int m = 0; m < 10; ++m) z[m] = rowz[20 * m];
+#endif
                 double2 t = tw_base;
                 z[0] = cmul_conj(z[0], t);
 #pragma unroll
@@ -259,7 +348,14 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
                     z[g] = cmul_conj(z[g], tab[re * kpp]);
                 }
             }
+#if FUSED_TW_AHEAD
+            if (rho < 4) {
+                tw_base = tw[(rho + 1 + k1b) * re];
+                tw_step = tw[20 * (rho + 1 + k1b)];
+            }
+#endif
             __syncthreads();   // every read of the row is done: the exchange goes in place
+            FUSED_STAMP(5);
             if (live) {
                 double2* const roww = X + ri * N2 + 10 * re;
 #pragma unroll
@@ -269,9 +365,11 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
                 }
             }
             __syncthreads();
-            // rows, second stage: 20 = 2 x 10, radix-2 decimation in frequency while reading
+            FUSED_STAMP(6);
+            // ---- rows, second stage: 20 = 2 x 10, radix-2 decimation in frequency while reading; and the next round's Y
+            // in place in the other buffer (its stores overlap this stage's arithmetic)
+            double2 u[10];
             if (live2) {
-                double2 u[10];
                 const double2* __restrict__ row = X + si * N2 + sk;
 #pragma unroll
                 for (int t0 = 0; t0 < 10; t0 += 5) {     // (five pairs of reads in flight: registers)
@@ -285,6 +383,14 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
                     for (int t = 0; t < 5; ++t) u[t0 + t] = h ? csub(lo[t], hi[t]) : cadd(lo[t], hi[t]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+#if FUSED_MERGE_Y
+            if (rho < 4 && live) y_in_place(Xo);
+#ifdef FUSED_MERGE_SB
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#endif
+            if (live2) {
                 if (h) {
 #pragma unroll
                     for (int t = 1; t < 10; ++t) u[t] = cmul_conj(u[t], make_double2(kW20X[t], kW20Y[t]));
@@ -313,6 +419,10 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
                     best_k = take ? k : best_k;
                 }
             }
+#if FUSED_MERGE_Y
+            if (rho < 4) __syncthreads();   // (the last round's readers meet the next transform's first barrier)
+#endif
+            FUSED_STAMP(7);
         }
         int best_i = 0x7fffffff;
         double best_v = -1.0;
@@ -335,7 +445,7 @@ inline void make_work_list(int n_prn, int nbins, std::vector<int>& order, int fi
     for (int b0 = 0; b0 < nbins; b0 += 4)
         for (int p0 = 0; p0 < n_prn; p0 += 8)
             for (int b = b0; b < b0 + 4 && b < nbins; ++b)
-                for (int p = p0; p < p0 + 8 && p < n_prn; ++p) order.push_back(p * nbins + b);
+                for (int p = p0; p < p0 + 8 && p < n_prn; ++p) order.push_back(p * nbins + b);   // (nbins: the bins THIS sweep covers)
     const int total = (int)order.size();
     for (int x = 0; x <= 8; ++x) first[x] = (int)(((long long)total * x) / 8);
 }

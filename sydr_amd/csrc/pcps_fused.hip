@@ -41,3 +41,14 @@ int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void
     SDR_HIP(hipGetLastError());
     return SDR_OK;
 }
+
+#ifdef SDR_FUSED_STAMPS
+extern "C" int sdr_debug_fused_stamps(unsigned long long* out, int reset) {
+    if (out) SDR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(fused25k::g_fused_stamps), sizeof(unsigned long long) * 256 * 8));
+    if (reset) {
+        static unsigned long long zeros[256 * 8];
+        SDR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(fused25k::g_fused_stamps), zeros, sizeof(zeros)));
+    }
+    return SDR_OK;
+}
+#endif

@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 TAG=$1; UNIT=$2; shift 2
 mkdir -p "$ROOT/tools/scratch/var"
 cd "$ROOT/sydr_amd/csrc"
-EXTRA=""; { [ "$UNIT" = track_dense ] || [ "$UNIT" = pcps_fused ]; } && EXTRA="-mllvm -disable-machine-licm"
+EXTRA=""; { [ "$UNIT" = track_dense ] || [ "$UNIT" = pcps_fused ]; } && [ -z "$KEEP_LICM" ] && EXTRA="-mllvm -disable-machine-licm"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-result $EXTRA "$@" -c $UNIT.hip -o /tmp/var_${TAG}_$UNIT.o
 OBJS=""
 for u in engine codes epl pcps pcps_fused track track_dense; do
