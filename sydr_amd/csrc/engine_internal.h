@@ -113,7 +113,7 @@ struct sdr_engine {
     hipEvent_t pcps_ev[2] = {nullptr, nullptr};
     bool pcps_no_fast = false;       // diagnostics: keep the general four-step kernels where the N = 125 x 200 ones would run
     bool pcps_force_passes = false;  // diagnostics: use the one-kernel-per-radix-pass transform instead of the four-step one
-    bool pcps_fused = false;         // map-free search at N = 125 x 200: one workgroup per (PRN, bin) transform (pcps_fused.h)
+    bool pcps_fused = true;          // map-free search at N = 125 x 200 of a round of 256 transforms or more: one workgroup per (PRN, bin) transform (pcps_fused.h); "pcps_fused" = 0: the two-kernel sweeps
     DevBuf pcps_work;                // its work list (transform numbers in processing order)
     int pcps_work_prn = 0, pcps_work_bins = 0;   // ... and the grid it was made for
     int pcps_work_first[9] = {0};
@@ -162,3 +162,6 @@ int sdr_set_device(sdr_engine* e);
 // SDR_PCPS_FUSED_RECORDS (value, index) records per transform in `partials` ([transform][record], 16 bytes each).
 #define SDR_PCPS_FUSED_RECORDS 8
 int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int nbins, int N, void* partials);
+// records per PRN that sweep leaves (PRN-major: [prn][records]); a search that is not a whole number of rounds of its 256
+// workgroups has its last transforms cut into five units of SDR_PCPS_FUSED_RECORDS records each
+int sdr_pcps_fused_records_per_prn(int n_prn, int nbins);

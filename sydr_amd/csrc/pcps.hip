@@ -402,14 +402,11 @@ __global__ __launch_bounds__(kThreads) void peak_finish_kernel(const double* __r
 __global__ __launch_bounds__(kThreads) void argmax_records_kernel(const Best* __restrict__ recs, int per_prn, int N,
                                                                   Best* __restrict__ tops,
                                                                   long long* __restrict__ out_bin,
-                                                                  long long* __restrict__ out_code,
-                                                                  const Best* __restrict__ recs2 = nullptr, int per_prn2 = 0) {
+                                                                  long long* __restrict__ out_code) {
     __shared__ Best sh[kThreads / 64];
     const int prn = blockIdx.x;
     Best mine = {-1.0, 0x7fffffffffffffffLL};
     for (int i = threadIdx.x; i < per_prn; i += kThreads) mine = better(mine, recs[(size_t)prn * per_prn + i]);
-    // (second region: the last bins of a search whose first bins went through the fused sweep)
-    for (int i = threadIdx.x; i < per_prn2; i += kThreads) mine = better(mine, recs2[(size_t)prn * per_prn2 + i]);
     const Best top = block_best(mine, sh);
     if (threadIdx.x == 0) {
         tops[prn] = top;
@@ -944,18 +941,13 @@ void run_four_step(sdr_engine* e, const FourStep& f, PassArgs a, int batch, doub
 inline int records_per_transform(const FourStep& f) { return ((f.N1 + kRowTile - 1) / kRowTile) * (kThreads / 64); }
 // ... and of the main sweep, which may run the register-resident kernels
 inline bool fused_applies(const sdr_engine* e, const FourStep& f) { return fast25k_applies(e, f) && e->pcps_fused; }
-// How many of a map-free search's Doppler bins the fused sweep takes (all PRNs of each): its 256 persistent workgroups
-// work in rounds of one transform each (~35 us), so it is given whole rounds and the remainder -- up to half a round --
-// goes through the two-kernel path (~8 us + 0.19 us per transform); a search of less than one round stays there entirely.
-inline int fused_bins(const sdr_engine* e, const FourStep& f, int n_prn, int nbins) {
-    if (!fused_applies(e, f)) return 0;
-    const int rounds = (n_prn * nbins) / 256;
-    if (rounds == 0) return 0;
-    const int bins = std::min(nbins, (256 * rounds) / n_prn);
-    return n_prn * (nbins - bins) > 128 ? nbins : bins;
+// The fused sweep takes a map-free search whole when it fills at least one round of its 256 persistent workgroups (a
+// smaller search is quicker through the two-kernel path: ~8 us + 0.19 us per transform against ~35 us per round).
+inline bool fused_takes(const sdr_engine* e, const FourStep& f, int n_prn, int nbins) {
+    return fused_applies(e, f) && n_prn * nbins >= 256;
 }
 inline int records_main_sweep(const sdr_engine* e, const FourStep& f) {
-    if (fast25k_applies(e, f)) return std::max((int)SDR_PCPS_FUSED_RECORDS, fast25k::kRecordsPerTransform);   // (sizing: either path)
+    if (fast25k_applies(e, f)) return fast25k::kRecordsPerTransform;
     return fast_applies(e, f) ? fastn::records(f.N1 * f.N2) : records_per_transform(f);
 }
 
@@ -1149,25 +1141,9 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
             f.bin_delta = bin_delta;
             run_fft<false, LOAD_IQ_MIX, STORE_PLAIN, FMT>(e, radices, f, nbins, A, B, F, "pcps_fwd_fft", blu);
 
-            const int bins_fused = map_free ? fused_bins(e, plan_four_step(N), n_prn, nbins) : 0;
-            if (bins_fused > 0) {
-                // the (PRN, bin) transforms of the first bins_fused bins in ONE launch of persistent workgroups -- whole
-                // multiples of the 256 workgroups -- and the few left over through the two-kernel path: no intermediate
-                // to speak of, no sweeps
-                if (int rcf = sdr_pcps_fused_sweep(e, F, C, tw, n_prn, bins_fused, N, e->pcps_part.ptr)) return rcf;
-                if (bins_fused < nbins) {
-                    PassArgs g = {};
-                    g.tw = tw;
-                    g.N = N;
-                    g.in = F + (size_t)bins_fused * N;
-                    g.code_spec = C;
-                    g.nbins = nbins - bins_fused;
-                    g.bin0 = bins_fused;
-                    g.scale = 1.0 / (double)N;
-                    g.partials = (Best*)e->pcps_part.ptr + (size_t)n_prn * bins_fused * SDR_PCPS_FUSED_RECORDS;
-                    ProfScope ps(e, "pcps_inv_fft");
-                    fast25k::run(e, g, n_prn * (nbins - bins_fused), A, e->stream);
-                }
+            if (map_free && fused_takes(e, plan_four_step(N), n_prn, nbins)) {
+                // every (PRN, bin) transform of the search in ONE launch of persistent workgroups: no intermediate, no sweeps
+                if (int rcf = sdr_pcps_fused_sweep(e, F, C, tw, n_prn, nbins, N, e->pcps_part.ptr)) return rcf;
                 continue;
             }
             // Register-resident kernels, several sweeps, nobody timing the stages: the sweeps alternate between two
@@ -1246,20 +1222,13 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
         // the map was never written: maximum from the per-wave records, then the winning row of every PRN alone
         // (1/nbins of one inverse sweep) for the second peak
         const FourStep four = plan_four_step(N);
-        const int bins_fused = fused_bins(e, four, n_prn, nbins);
-        const int per_bin = fast25k_applies(e, four) ? fast25k::kRecordsPerTransform
-                                                      : (fast_applies(e, four) ? fastn::records(N) : records_per_transform(four));
-        // records: [prn][bins_fused][SDR_PCPS_FUSED_RECORDS] of the fused sweep, then [prn][nbins - bins_fused][per_bin]
-        const int per_prn1 = bins_fused * SDR_PCPS_FUSED_RECORDS, per_prn2 = (nbins - bins_fused) * per_bin;
-        Best* tops = parts + (size_t)n_prn * nbins * records_main_sweep(e, four);
+        const int per_prn = fused_takes(e, four, n_prn, nbins) ? sdr_pcps_fused_records_per_prn(n_prn, nbins)
+                                                               : nbins * records_main_sweep(e, four);
+        Best* tops = parts + (size_t)n_prn * per_prn;
         {
             ProfScope ps(e, "pcps_peak");
-            if (bins_fused > 0)
-                hipLaunchKernelGGL(argmax_records_kernel, dim3(n_prn), dim3(kThreads), 0, e->stream, parts, per_prn1, N, tops,
-                                   dev_bin, dev_code, parts + (size_t)n_prn * per_prn1, per_prn2);
-            else
-                hipLaunchKernelGGL(argmax_records_kernel, dim3(n_prn), dim3(kThreads), 0, e->stream, parts, per_prn2, N, tops,
-                                   dev_bin, dev_code, (const Best*)nullptr, 0);
+            hipLaunchKernelGGL(argmax_records_kernel, dim3(n_prn), dim3(kThreads), 0, e->stream, parts, per_prn, N, tops,
+                               dev_bin, dev_code);
         }
         PassArgs g = {};
         g.tw = tw;
@@ -1407,7 +1376,8 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_a, work);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_b, work);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_code, tbytes * n_prn);
-    const size_t n_records = map_free ? (size_t)n_prn * (nbins + 1) * std::max(records_per_transform(four), records_main_sweep(e, four)) + n_prn : 0;
+    // (the fused sweep leaves at most 5 x SDR_PCPS_FUSED_RECORDS records per transform)
+    const size_t n_records = map_free ? (size_t)n_prn * (nbins + 1) * std::max(std::max(records_per_transform(four), records_main_sweep(e, four)), 5 * SDR_PCPS_FUSED_RECORDS) + n_prn : 0;
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_map, (size_t)n_prn * (map_free ? 1 : nbins) * N * sizeof(double));
     if (!rc && coh > 1) rc = sdr_devbuf_reserve(e, &e->pcps_csum, (size_t)n_prn * nbins * tbytes);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_part, std::max((size_t)n_prn * kPeakParts, n_records) * sizeof(Best));

@@ -115,15 +115,22 @@ __device__ __forceinline__ double2 ldb(const Operand& o, unsigned voff, unsigned
 }
 #endif
 
+// One unit of work of a persistent workgroup: a whole (PRN, bin) transform, or -- for the transforms left over when the
+// search is not a whole number of rounds of 256 -- ONE of a transform's five rounds: the column stage then computes that
+// round's fifth of its outputs only (all operands are still read), so that the tail of the launch is a fifth of a round
+// on 5 x as many compute units.  `record`: where its kRecordsPerTransform records go (PRN-major for the peak kernel).
+struct WorkItem {
+    int prn, bin, round, record;
+};
+
 struct Args {
     const double2* spec;       // [nbins][N] forward spectra of the Doppler-mixed block
     const double2* code_spec;  // [n_prn][N]
     const double2* tw;         // exp(-2 pi i m / N)
-    const int* work;           // transform numbers (prn * nbins + bin) in processing order
+    const WorkItem* work;      // in processing order
     int xcd_first[9];          // XCD x owns work[xcd_first[x] .. xcd_first[x + 1])
-    int nbins;
     double scale;
-    Best* partials;            // [transform][kRecordsPerTransform]
+    Best* partials;            // [work item's record slot][kRecordsPerTransform]
 };
 
 // Diagnostic build (-DSDR_FUSED_STAMPS, tools/pcps_fused_phases.py): wave 0 of every workgroup adds up the shader cycles
@@ -140,109 +147,97 @@ __device__ unsigned long long g_fused_stamps[256][8];
 #define FUSED_STAMP(slot) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
-    extern __shared__ double2 lds4[];
+// One unit of work (a whole transform, or round `mode` of one) by the 512 threads of the workgroup.
+template <bool WHOLE>
+__device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int tid, const int prn, const int bin, const int mode,
+                                         const int rec_slot
 #ifdef SDR_FUSED_STAMPS
-    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+                                         , unsigned long long& stamp_
 #endif
+) {
     double2* const tab = lds4 + 2 * kBuf;
     const double2* __restrict__ tw = a.tw;
+    // Thread roles, re-derived per transform from an opaque copy of the thread number: left loop-invariant the compiler
+    // keeps every address of the loop body in registers across the whole loop -- and spills them.
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+    // column stage / first half of a round: thread (r, c) of 5 x 100
+    const bool live = t_ < 500;
+    const int r = live ? t_ / 100 : 0, c = live ? t_ - 100 * r : 0;
+    const int cb = r * N2 + c;                          // its slot in a buffer row group
+    // row stage 1: thread (row i, e) of 25 x 20
+    const int ri = live ? t_ / 20 : 0, re = live ? t_ - 20 * ri : 0;
+    const int k1b = 5 * (ri / 5) + 25 * (ri % 5);       // its row's k1 = rho + k1b
+    // row stage 2: waves 0-3 take the even outputs (h = 0), waves 4-7 the odd ones: thread (row, k'') of 25 x 10
+    const int h = tid >> 8;
+    const int t2 = t_ & 255;
+    const bool live2 = t2 < 250;
+    const int si = live2 ? t2 / 10 : 0, sk = live2 ? t2 - 10 * si : 0;
+    const int kf0 = 5 * (si / 5) + 25 * (si % 5) + N1 * (sk + 10 * h);
 
-    const int tid = threadIdx.x;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int w_end = a.xcd_first[xcd + 1];
-    for (int w = a.xcd_first[xcd] + slot; w < w_end; w += kSlotsPerXcd) {
-#ifndef FUSED_SCALAR_WORK
-#define FUSED_SCALAR_WORK 1
-#endif
-#if FUSED_SCALAR_WORK
-        const int batch = __builtin_amdgcn_readfirstlane(a.work[w]);   // (wave-uniform: scalar base addresses below)
-#else
-        const int batch = a.work[w];
-#endif
-        const int prn = batch / a.nbins;
-        const int bin = batch - prn * a.nbins;
+    if (tid < 97) tab[tid] = tw[(N / 125) * tid];
+    __syncthreads();   // the table; and every reader of the previous transform's last rounds is done with the buffers
+    FUSED_STAMP(0);
 
-        // Thread roles, re-derived per transform from an opaque copy of the thread number: left loop-invariant the compiler
-        // keeps every address of the loop body in registers across the whole loop -- and spills them.
-        int t_ = tid;
-        asm volatile("" : "+v"(t_));
-        // column stage / first half of a round: thread (r, c) of 5 x 100
-        const bool live = t_ < 500;
-        const int r = live ? t_ / 100 : 0, c = live ? t_ - 100 * r : 0;
-        const int cb = r * N2 + c;                          // its slot in a buffer row group
-        // row stage 1: thread (row i, e) of 25 x 20
-        const int ri = live ? t_ / 20 : 0, re = live ? t_ - 20 * ri : 0;
-        const int k1b = 5 * (ri / 5) + 25 * (ri % 5);       // its row's k1 = rho + k1b
-        // row stage 2: waves 0-3 take the even outputs (h = 0), waves 4-7 the odd ones: thread (row, k'') of 25 x 10
-        const int h = tid >> 8;
-        const int t2 = t_ & 255;
-        const bool live2 = t2 < 250;
-        const int si = live2 ? t2 / 10 : 0, sk = live2 ? t2 - 10 * si : 0;
-        const int kf0 = 5 * (si / 5) + 25 * (si % 5) + N1 * (sk + 10 * h);
-
-        if (tid < 97) tab[tid] = tw[(N / 125) * tid];
-        __syncthreads();   // the table; and every reader of the previous transform's last rounds is done with the buffers
-        FUSED_STAMP(0);
-
-        // ---- column stage: two items of 25 points; rounds 0 / 1 to the buffers, rounds 2-4 parked.  Register budget
-        // (256 per lane, nothing may spill): a group of five points is multiplied and put through the first radix-5
-        // stage while the NEXT group's ten loads are in flight; while item 1 is transformed, ten of item 0's fifteen
-        // parked points wait in the LDS slots item 1 will fill at its end (a thread's own slots: no barrier).
-        double2 park[2][15];
-        const Operand xs_u = make_operand(a.spec + (size_t)bin * N);
-        const Operand cs_u = make_operand(a.code_spec + (size_t)prn * N);
-        const unsigned toff = (unsigned)cb * 16u;
+    // ---- column stage: two items of 25 points; rounds 0 / 1 to the buffers, rounds 2-4 parked.  Register budget
+    // (256 per lane, nothing may spill): a group of five points is multiplied and put through the first radix-5
+    // stage while the NEXT group's ten loads are in flight; while item 1 is transformed, ten of item 0's fifteen
+    // parked points wait in the LDS slots item 1 will fill at its end (a thread's own slots: no barrier).
+    double2 park[2][15];
+    const Operand xs_u = make_operand(a.spec + (size_t)bin * N);
+    const Operand cs_u = make_operand(a.code_spec + (size_t)prn * N);
+    const unsigned toff = (unsigned)cb * 16u;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            double2* const eP = lds4 + cb + 100 * j;            // E slots of this (r, column): + 5 N2 kB; round 1: + kBuf
-            double2 v[25];
-            if (live) {
-                constexpr int kRowBytes = N2 * 16;              // one n1 step
-                double2 xa[5], ca[5];
+    for (int j = 0; j < 2; ++j) {
+        double2* const eP = lds4 + cb + 100 * j;            // E slots of this (r, column): + 5 N2 kB; round 1: + kBuf
+        double2 v[25];
+        if (live) {
+            constexpr int kRowBytes = N2 * 16;              // one n1 step
+            double2 xa[5], ca[5];
 #pragma unroll
-                for (int m2 = 0; m2 < 5; ++m2) {
-                    xa[m2] = ldb(xs_u, toff, 1600 * j + kRowBytes * 25 * m2);
-                    ca[m2] = ldb(cs_u, toff, 1600 * j + kRowBytes * 25 * m2);
+            for (int m2 = 0; m2 < 5; ++m2) {
+                xa[m2] = ldb(xs_u, toff, 1600 * j + kRowBytes * 25 * m2);
+                ca[m2] = ldb(cs_u, toff, 1600 * j + kRowBytes * 25 * m2);
+            }
+            if (j == 1 && WHOLE) {
+#pragma unroll
+                for (int g = 0; g < 5; ++g) {
+                    eP[5 * N2 * g] = park[0][g];
+                    eP[kBuf + 5 * N2 * g] = park[0][5 + g];
                 }
-                if (j == 1) {
+            }
 #pragma unroll
-                    for (int g = 0; g < 5; ++g) {
-                        eP[5 * N2 * g] = park[0][g];
-                        eP[kBuf + 5 * N2 * g] = park[0][5 + g];
+            for (int m1 = 0; m1 < 5; ++m1) {
+                double2 xb[5], cb_[5];
+                if (m1 < 4) {
+#pragma unroll
+                    for (int m2 = 0; m2 < 5; ++m2) {
+                        xb[m2] = ldb(xs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
+                        cb_[m2] = ldb(cs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                double2 t[5];
 #pragma unroll
-                for (int m1 = 0; m1 < 5; ++m1) {
-                    double2 xb[5], cb_[5];
-                    if (m1 < 4) {
+                for (int m2 = 0; m2 < 5; ++m2) t[m2] = cmulf(xa[m2], ca[m2]);
+                ibf5(t);
+                v[m1] = t[0];
 #pragma unroll
-                        for (int m2 = 0; m2 < 5; ++m2) {
-                            xb[m2] = ldb(xs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
-                            cb_[m2] = ldb(cs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    double2 t[5];
+                for (int kA = 1; kA < 5; ++kA)
+                    v[m1 + 5 * kA] = m1 ? cmul_conj(t[kA], make_double2(kW25X[m1 * kA], kW25Y[m1 * kA])) : t[kA];
+                __builtin_amdgcn_sched_barrier(0);
+                if (m1 < 4) {
 #pragma unroll
-                    for (int m2 = 0; m2 < 5; ++m2) t[m2] = cmulf(xa[m2], ca[m2]);
-                    ibf5(t);
-                    v[m1] = t[0];
-#pragma unroll
-                    for (int kA = 1; kA < 5; ++kA)
-                        v[m1 + 5 * kA] = m1 ? cmul_conj(t[kA], make_double2(kW25X[m1 * kA], kW25Y[m1 * kA])) : t[kA];
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (m1 < 4) {
-#pragma unroll
-                        for (int m2 = 0; m2 < 5; ++m2) {
-                            xa[m2] = xb[m2];
-                            ca[m2] = cb_[m2];
-                        }
+                    for (int m2 = 0; m2 < 5; ++m2) {
+                        xa[m2] = xb[m2];
+                        ca[m2] = cb_[m2];
                     }
                 }
-                // second stage of the 25-point transform and the twiddle between the column's two levels
+            }
+            // second stage of the 25-point transform and the twiddle between the column's two levels
 #pragma unroll
-                for (int kA = 0; kA < 5; ++kA) {
+            for (int kA = 0; kA < 5; ++kA) {
+                if (WHOLE || mode == kA) {          // (a single round: its five outputs alone, straight into the first buffer)
                     double2 t[5] = {v[5 * kA], v[5 * kA + 1], v[5 * kA + 2], v[5 * kA + 3], v[5 * kA + 4]};
                     ibf5(t);
 #pragma unroll
@@ -250,7 +245,13 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
                         const int kp = kA + 5 * kB;
                         v[5 * kA + kB] = kp ? cmul_conj(t[kB], tab[r * kp]) : t[kB];
                     }
+                    if (!WHOLE) {
+#pragma unroll
+                        for (int kB = 0; kB < 5; ++kB) eP[5 * N2 * kB] = v[5 * kA + kB];
+                    }
                 }
+            }
+            if (WHOLE) {
                 if (j == 1) {
 #pragma unroll
                     for (int g = 0; g < 5; ++g) {
@@ -264,190 +265,228 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
                     eP[kBuf + 5 * N2 * kB] = v[5 + kB];
                 }
             }
-#pragma unroll
-            for (int g = 0; g < 15; ++g) park[j][g] = v[10 + g];
-            __builtin_amdgcn_sched_barrier(0);
-            FUSED_STAMP(1 + j);
         }
-        __syncthreads();
-        FUSED_STAMP(3);
+#pragma unroll
+        for (int g = 0; g < 15; ++g) park[j][g] = v[10 + g];
+        __builtin_amdgcn_sched_barrier(0);
+        FUSED_STAMP(1 + j);
+    }
+    __syncthreads();
+    FUSED_STAMP(3);
 
-        // Y[k' + 25 q] = sum_r B_r[k'] w5^(r q) of one round, in place (a thread reads and writes its own five slots)
-        auto y_in_place = [&](double2* X) {
+    // Y[k' + 25 q] = sum_r B_r[k'] w5^(r q) of one round, in place (a thread reads and writes its own five slots)
+    auto y_in_place = [&](double2* X) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                double2* const col = X + 5 * cb - 4 * c + 100 * j;      // (r * 5) * N2 + c
-                double2 t5[5];
+        for (int j = 0; j < 2; ++j) {
+            double2* const col = X + 5 * cb - 4 * c + 100 * j;      // (r * 5) * N2 + c
+            double2 t5[5];
 #pragma unroll
-                for (int rr = 0; rr < 5; ++rr) t5[rr] = col[rr * N2];
-                ibf5(t5);
+            for (int rr = 0; rr < 5; ++rr) t5[rr] = col[rr * N2];
+            ibf5(t5);
 #pragma unroll
-                for (int q = 0; q < 5; ++q) col[q * N2] = t5[q];
-            }
-        };
-        // the row's four-step twiddle w_N^(k1 (e + 20 m)) = base * step^m: two scattered table reads per round, requested
-        // a phase ahead
+            for (int q = 0; q < 5; ++q) col[q * N2] = t5[q];
+        }
+    };
+    // the row's four-step twiddle w_N^(k1 (e + 20 m)) = base * step^m: two scattered table reads per round, requested
+    // a phase ahead
 #if FUSED_TW_AHEAD
-        double2 tw_base = tw[k1b * re], tw_step = tw[20 * k1b];
+    double2 tw_base = tw[k1b * re], tw_step = tw[20 * k1b];
 #endif
 #if FUSED_MERGE_Y
-        if (live) y_in_place(lds4);
-        if (tid < 172) tab[tid] = tw[(N / 200) * tid];   // (every w125 read lies before the last barrier)
+    if (live) y_in_place(lds4);
+    if (tid < 172) tab[tid] = tw[(N / 200) * tid];   // (every w125 read lies before the last barrier)
+    __syncthreads();
+    FUSED_STAMP(4);
+#endif
+
+    double best_sq = -1.0, best_x = 0.0, best_y = 0.0;
+    int best_k = -1;
+#pragma unroll
+    for (int rho = 0; rho < 5; ++rho) {
+        if (!WHOLE && mode != rho) continue;
+        double2* const X = lds4 + ((WHOLE && (rho & 1)) ? kBuf : 0);
+        double2* const Xo = lds4 + ((rho & 1) ? 0 : kBuf);
+#if !FUSED_TW_AHEAD
+        const double2 tw_base = tw[(rho + k1b) * re], tw_step = tw[20 * (rho + k1b)];
+#endif
+#if !FUSED_MERGE_Y
+        if (live) y_in_place(X);
+        if ((rho == 0 || !WHOLE) && tid < 172) tab[tid] = tw[(N / 200) * tid];   // (every w125 read lies before the last barrier)
         __syncthreads();
         FUSED_STAMP(4);
 #endif
-
-        double best_sq = -1.0, best_x = 0.0, best_y = 0.0;
-        int best_k = -1;
-#pragma unroll
-        for (int rho = 0; rho < 5; ++rho) {
-            double2* const X = lds4 + ((rho & 1) ? kBuf : 0);
-            double2* const Xo = lds4 + ((rho & 1) ? 0 : kBuf);
-#if !FUSED_TW_AHEAD
-            const double2 tw_base = tw[(rho + k1b) * re], tw_step = tw[20 * (rho + k1b)];
-#endif
-#if !FUSED_MERGE_Y
-            if (live) y_in_place(X);
-            if (rho == 0 && tid < 172) tab[tid] = tw[(N / 200) * tid];   // (every w125 read lies before the last barrier)
-            __syncthreads();
-            FUSED_STAMP(4);
-#endif
-            // ---- rows, first stage (reads first; then the parked round rho + 1 moves into the buffer round rho - 1 has
-            // left -- its stores drain while the transform computes)
-            double2 z[10];
-            if (live) {
-                const double2* __restrict__ rowz = X + ri * N2 + re;
+        // ---- rows, first stage (reads first; then the parked round rho + 1 moves into the buffer round rho - 1 has
+        // left -- its stores drain while the transform computes)
+        double2 z[10];
+        if (live) {
+            const double2* __restrict__ rowz = X + ri * N2 + re;
 #if FUSED_READS_FIRST
 #pragma unroll
-                for (int m = 0; m < 10; ++m) z[m] = rowz[20 * m];
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-                if (rho >= 1 && rho <= 3) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int kB = 0; kB < 5; ++kB) Xo[cb + 100 * j + 5 * N2 * kB] = park[j][5 * (rho - 1) + kB];
-                }
-#if FUSED_READS_FIRST
-                __builtin_amdgcn_sched_barrier(0);
-#else
-#pragma unroll
-                for (int m = 0; m < 10; ++m) z[m] = rowz[20 * m];
-#endif
-                double2 t = tw_base;
-                z[0] = cmul_conj(z[0], t);
-#pragma unroll
-                for (int m = 1; m < 10; ++m) {
-                    t = cmulf(t, tw_step);
-                    z[m] = cmul_conj(z[m], t);
-                }
-                idft10c(z);
-#pragma unroll
-                for (int g = 1; g < 10; ++g) {
-                    const int kpp = g / 2 + 5 * (g % 2);
-                    z[g] = cmul_conj(z[g], tab[re * kpp]);
-                }
-            }
-#if FUSED_TW_AHEAD
-            if (rho < 4) {
-                tw_base = tw[(rho + 1 + k1b) * re];
-                tw_step = tw[20 * (rho + 1 + k1b)];
-            }
-#endif
-            __syncthreads();   // every read of the row is done: the exchange goes in place
-            FUSED_STAMP(5);
-            if (live) {
-                double2* const roww = X + ri * N2 + 10 * re;
-#pragma unroll
-                for (int g = 0; g < 10; ++g) {
-                    const int kpp = g / 2 + 5 * (g % 2);
-                    roww[kpp] = z[g];
-                }
-            }
-            __syncthreads();
-            FUSED_STAMP(6);
-            // ---- rows, second stage: 20 = 2 x 10, radix-2 decimation in frequency while reading; and the next round's Y
-            // in place in the other buffer (its stores overlap this stage's arithmetic)
-            double2 u[10];
-            if (live2) {
-                const double2* __restrict__ row = X + si * N2 + sk;
-#pragma unroll
-                for (int t0 = 0; t0 < 10; t0 += 5) {     // (five pairs of reads in flight: registers)
-                    double2 lo[5], hi[5];
-#pragma unroll
-                    for (int t = 0; t < 5; ++t) {
-                        lo[t] = row[10 * (t0 + t)];
-                        hi[t] = row[10 * (t0 + t + 10)];
-                    }
-#pragma unroll
-                    for (int t = 0; t < 5; ++t) u[t0 + t] = h ? csub(lo[t], hi[t]) : cadd(lo[t], hi[t]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-#if FUSED_MERGE_Y
-            if (rho < 4 && live) y_in_place(Xo);
-#ifdef FUSED_MERGE_SB
+            for (int m = 0; m < 10; ++m) z[m] = rowz[20 * m];
             __builtin_amdgcn_sched_barrier(0);
 #endif
-#endif
-            if (live2) {
-                if (h) {
+            if (rho >= 1 && rho <= 3 && WHOLE) {
 #pragma unroll
-                    for (int t = 1; t < 10; ++t) u[t] = cmul_conj(u[t], make_double2(kW20X[t], kW20Y[t]));
-                }
-                idft10c(u);
-                const int k_first = kf0 + rho;
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int g = 0; g < 10; ++g) {
-                    const int p = g / 2 + 5 * (g % 2);
-                    const int k = k_first + 20 * N1 * p;              // code phase = position in the transform
-                    const double2 x = u[g];
-                    const double sq = __builtin_fma(x.x, x.x, x.y * x.y);
-                    bool take = sq > best_sq;
-                    // (ordering by the squared magnitude; candidates within 2^-48 of the lane's best go through the scaled
-                    // hypot -- the reference's np.abs -- and an exact tie keeps the smaller index: pcps_fast.h)
-                    const bool near = fabs(sq - best_sq) <= best_sq * 0x1p-48;
-                    if (__builtin_expect(__any(near), 0)) {
-                        if (near) {
-                            const double m_new = hypot(x.x * a.scale, x.y * a.scale), m_old = hypot(best_x * a.scale, best_y * a.scale);
-                            take = m_new > m_old || (m_new == m_old && k < best_k);
-                        }
-                    }
-                    best_sq = take ? sq : best_sq;
-                    best_x = take ? x.x : best_x;
-                    best_y = take ? x.y : best_y;
-                    best_k = take ? k : best_k;
-                }
+                    for (int kB = 0; kB < 5; ++kB) Xo[cb + 100 * j + 5 * N2 * kB] = park[j][5 * (rho - 1) + kB];
             }
-#if FUSED_MERGE_Y
-            if (rho < 4) __syncthreads();   // (the last round's readers meet the next transform's first barrier)
+#if FUSED_READS_FIRST
+            __builtin_amdgcn_sched_barrier(0);
+#else
+#pragma unroll
+            for (int m = 0; m < 10; ++m) z[m] = rowz[20 * m];
 #endif
-            FUSED_STAMP(7);
+            double2 t = tw_base;
+            z[0] = cmul_conj(z[0], t);
+#pragma unroll
+            for (int m = 1; m < 10; ++m) {
+                t = cmulf(t, tw_step);
+                z[m] = cmul_conj(z[m], t);
+            }
+            idft10c(z);
+#pragma unroll
+            for (int g = 1; g < 10; ++g) {
+                const int kpp = g / 2 + 5 * (g % 2);
+                z[g] = cmul_conj(z[g], tab[re * kpp]);
+            }
         }
-        int best_i = 0x7fffffff;
-        double best_v = -1.0;
+#if FUSED_TW_AHEAD
+        if (rho < 4) {
+            tw_base = tw[(rho + 1 + k1b) * re];
+            tw_step = tw[20 * (rho + 1 + k1b)];
+        }
+#endif
+        __syncthreads();   // every read of the row is done: the exchange goes in place
+        FUSED_STAMP(5);
+        if (live) {
+            double2* const roww = X + ri * N2 + 10 * re;
+#pragma unroll
+            for (int g = 0; g < 10; ++g) {
+                const int kpp = g / 2 + 5 * (g % 2);
+                roww[kpp] = z[g];
+            }
+        }
+        __syncthreads();
+        FUSED_STAMP(6);
+        // ---- rows, second stage: 20 = 2 x 10, radix-2 decimation in frequency while reading; and the next round's Y
+        // in place in the other buffer (its stores overlap this stage's arithmetic)
+        double2 u[10];
         if (live2) {
-            best_i = bin * N + best_k;
-            best_v = 0.0 + hypot(best_x * a.scale, best_y * a.scale);   // (0.0 + |.|: the map's own rounding)
+            const double2* __restrict__ row = X + si * N2 + sk;
+#pragma unroll
+            for (int t0 = 0; t0 < 10; t0 += 5) {     // (five pairs of reads in flight: registers)
+                double2 lo[5], hi[5];
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    lo[t] = row[10 * (t0 + t)];
+                    hi[t] = row[10 * (t0 + t + 10)];
+                }
+#pragma unroll
+                for (int t = 0; t < 5; ++t) u[t0 + t] = h ? csub(lo[t], hi[t]) : cadd(lo[t], hi[t]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        wave_best(best_v, best_i);
-        if ((tid & 63) == 63) {
-            Best rec = {best_v, (long long)best_i};
-            a.partials[(size_t)batch * kRecordsPerTransform + (tid >> 6)] = rec;
+#if FUSED_MERGE_Y
+        if (rho < 4 && live) y_in_place(Xo);
+#ifdef FUSED_MERGE_SB
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#endif
+        if (live2) {
+            if (h) {
+#pragma unroll
+                for (int t = 1; t < 10; ++t) u[t] = cmul_conj(u[t], make_double2(kW20X[t], kW20Y[t]));
+            }
+            idft10c(u);
+            const int k_first = kf0 + rho;
+#pragma unroll
+            for (int g = 0; g < 10; ++g) {
+                const int p = g / 2 + 5 * (g % 2);
+                const int k = k_first + 20 * N1 * p;              // code phase = position in the transform
+                const double2 x = u[g];
+                const double sq = __builtin_fma(x.x, x.x, x.y * x.y);
+                bool take = sq > best_sq;
+                // (ordering by the squared magnitude; candidates within 2^-48 of the lane's best go through the scaled
+                // hypot -- the reference's np.abs -- and an exact tie keeps the smaller index: pcps_fast.h)
+                const bool near = fabs(sq - best_sq) <= best_sq * 0x1p-48;
+                if (__builtin_expect(__any(near), 0)) {
+                    if (near) {
+                        const double m_new = hypot(x.x * a.scale, x.y * a.scale), m_old = hypot(best_x * a.scale, best_y * a.scale);
+                        take = m_new > m_old || (m_new == m_old && k < best_k);
+                    }
+                }
+                best_sq = take ? sq : best_sq;
+                best_x = take ? x.x : best_x;
+                best_y = take ? x.y : best_y;
+                best_k = take ? k : best_k;
+            }
         }
+#if FUSED_MERGE_Y
+        if (rho < 4) __syncthreads();   // (the last round's readers meet the next transform's first barrier)
+#endif
+        FUSED_STAMP(7);
+    }
+    int best_i = 0x7fffffff;
+    double best_v = -1.0;
+    if (live2) {
+        best_i = bin * N + best_k;
+        best_v = 0.0 + hypot(best_x * a.scale, best_y * a.scale);   // (0.0 + |.|: the map's own rounding)
+    }
+    wave_best(best_v, best_i);
+    if ((tid & 63) == 63) {
+        Best rec = {best_v, (long long)best_i};
+        a.partials[(size_t)rec_slot * kRecordsPerTransform + (tid >> 6)] = rec;
     }
 }
 
-// Processing order: blocks of 4 bins x 8 PRNs (32 transforms = one round of an XCD's 32 workgroups), dealt to the XCDs
-// in contiguous eighths.  `order` receives n_prn * nbins transform numbers, `first` the nine range limits.
-inline void make_work_list(int n_prn, int nbins, std::vector<int>& order, int first[9]) {
-    order.clear();
-    for (int b0 = 0; b0 < nbins; b0 += 4)
+__global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
+    extern __shared__ double2 lds4[];
+#ifdef SDR_FUSED_STAMPS
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#define FUSED_STAMP_ARG , stamp_
+#else
+#define FUSED_STAMP_ARG
+#endif
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int w_end = a.xcd_first[xcd + 1];
+    for (int w = a.xcd_first[xcd] + slot; w < w_end; w += kSlotsPerXcd) {
+        // (wave-uniform: scalar base addresses in the unit)
+        const int prn = __builtin_amdgcn_readfirstlane(a.work[w].prn), bin = __builtin_amdgcn_readfirstlane(a.work[w].bin);
+        const int mode = __builtin_amdgcn_readfirstlane(a.work[w].round);     // -1: the whole transform; else that round only
+        const int rec_slot = __builtin_amdgcn_readfirstlane(a.work[w].record);
+        if (mode < 0) one_unit<true>(a, lds4, tid, prn, bin, mode, rec_slot FUSED_STAMP_ARG);
+        else one_unit<false>(a, lds4, tid, prn, bin, mode, rec_slot FUSED_STAMP_ARG);
+    }
+}
+
+// Processing order and record slots of a search over bins [0, nbins) x n_prn PRNs.  The first `bins_whole` bins are done
+// as whole transforms: blocks of 4 bins x 8 PRNs (32 transforms = one round of an XCD's 32 workgroups, so that the
+// operands an XCD has in flight mostly sit in its L2), dealt to the XCDs in contiguous eighths; the transforms of the
+// remaining bins are cut into their five rounds, dealt out behind the whole ones (a workgroup's last, short unit).
+// Record slots are PRN-major: PRN p owns slots [p * per_prn, (p + 1) * per_prn), per_prn = bins_whole + 5 (nbins - bins_whole).
+inline int make_work_list(int n_prn, int nbins, int bins_whole, std::vector<WorkItem>& order, int first[9]) {
+    const int per_prn = bins_whole + 5 * (nbins - bins_whole);
+    std::vector<WorkItem> whole, parts;
+    for (int b0 = 0; b0 < bins_whole; b0 += 4)
         for (int p0 = 0; p0 < n_prn; p0 += 8)
-            for (int b = b0; b < b0 + 4 && b < nbins; ++b)
-                for (int p = p0; p < p0 + 8 && p < n_prn; ++p) order.push_back(p * nbins + b);   // (nbins: the bins THIS sweep covers)
-    const int total = (int)order.size();
-    for (int x = 0; x <= 8; ++x) first[x] = (int)(((long long)total * x) / 8);
+            for (int b = b0; b < b0 + 4 && b < bins_whole; ++b)
+                for (int p = p0; p < p0 + 8 && p < n_prn; ++p) whole.push_back({p, b, -1, p * per_prn + b});
+    for (int b = bins_whole; b < nbins; ++b)
+        for (int p = 0; p < n_prn; ++p)
+            for (int rho = 0; rho < 5; ++rho) parts.push_back({p, b, rho, p * per_prn + bins_whole + 5 * (b - bins_whole) + rho});
+    // XCD x: its eighth of the whole transforms, then its eighth of the single rounds (its workgroups walk the list in
+    // steps of 32: whole transforms first, the short units last)
+    order.clear();
+    const int nw = (int)whole.size(), np = (int)parts.size();
+    first[0] = 0;
+    for (int x = 0; x < 8; ++x) {
+        for (int i = (int)(((long long)nw * x) / 8); i < (int)(((long long)nw * (x + 1)) / 8); ++i) order.push_back(whole[i]);
+        for (int i = (int)(((long long)np * x) / 8); i < (int)(((long long)np * (x + 1)) / 8); ++i) order.push_back(parts[i]);
+        first[x + 1] = (int)order.size();
+    }
+    return per_prn;
 }
 
 }  // namespace fused25k

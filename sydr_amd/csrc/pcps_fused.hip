@@ -12,14 +12,33 @@ namespace {
 static_assert(fused25k::kRecordsPerTransform == SDR_PCPS_FUSED_RECORDS, "records per transform");
 }  // namespace
 
+// How the fused sweep cuts a search of n_prn x nbins transforms: whole transforms for the bins that fill whole rounds of
+// its 256 workgroups, single rounds for the rest (returns the records per PRN the sweep leaves).
+static int fused_plan(int n_prn, int nbins, int* bins_whole) {
+    const int rounds = (n_prn * nbins) / 256;
+    int bw = rounds > 0 ? (256 * rounds) / n_prn : 0;
+    if (bw > nbins) bw = nbins;
+    // (more than a round's worth left over -- few PRNs, many bins -- : cutting buys nothing, whole transforms throughout)
+    if (n_prn * (nbins - bw) > 256) bw = nbins;
+    *bins_whole = bw;
+    return bw + 5 * (nbins - bw);
+}
+
+int sdr_pcps_fused_records_per_prn(int n_prn, int nbins) {
+    int bw;
+    return fused_plan(n_prn, nbins, &bw) * SDR_PCPS_FUSED_RECORDS;
+}
+
 int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int nbins, int N, void* partials) {
     if (N != fused25k::N) return sdr_fail(SDR_ERR_UNSUPPORTED, "fused PCPS sweep: N = %d", N);
     if (e->pcps_work_prn != n_prn || e->pcps_work_bins != nbins) {
-        std::vector<int> order;
-        fused25k::make_work_list(n_prn, nbins, order, e->pcps_work_first);
-        if (int rc = sdr_devbuf_reserve(e, &e->pcps_work, order.size() * sizeof(int))) return rc;
+        std::vector<fused25k::WorkItem> order;
+        int bins_whole;
+        fused_plan(n_prn, nbins, &bins_whole);
+        fused25k::make_work_list(n_prn, nbins, bins_whole, order, e->pcps_work_first);
+        if (int rc = sdr_devbuf_reserve(e, &e->pcps_work, order.size() * sizeof(fused25k::WorkItem))) return rc;
         // (pageable source, tiny: the copy is complete when the stream has been waited for)
-        SDR_HIP(hipMemcpyAsync(e->pcps_work.ptr, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        SDR_HIP(hipMemcpyAsync(e->pcps_work.ptr, order.data(), order.size() * sizeof(fused25k::WorkItem), hipMemcpyHostToDevice, e->stream));
         SDR_HIP(hipStreamSynchronize(e->stream));
         e->pcps_work_prn = n_prn;
         e->pcps_work_bins = nbins;
@@ -28,9 +47,8 @@ int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void
     a.spec = (const double2*)F;
     a.code_spec = (const double2*)C;
     a.tw = (const double2*)tw;
-    a.work = (const int*)e->pcps_work.ptr;
+    a.work = (const fused25k::WorkItem*)e->pcps_work.ptr;
     for (int x = 0; x < 9; ++x) a.xcd_first[x] = e->pcps_work_first[x];
-    a.nbins = nbins;
     a.scale = 1.0 / (double)N;
     a.partials = (Best*)partials;
     (void)hipFuncSetAttribute((const void*)fused25k::ifft_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -270,6 +270,51 @@ def test_cached_code_spectra_follow_the_staged_codes(engine):
     assert [int(restaged[0][2]), int(restaged[1][2])] == peak and restaged[2][2] == pytest.approx(ratio, rel=1e-9)
 
 
+@pytest.mark.parametrize("n_prn,drange,dstep", [(32, 5000.0, 250.0), (8, 5000.0, 250.0), (16, 3750.0, 500.0), (32, 4000.0, 100.0),
+                                                  (5, 5000.0, 50.0)])
+def test_fused_sweep_vs_two_kernel_sweeps_and_oracle(engine, n_prn, drange, dstep):
+    """A map-free search at 25 MHz of 256 transforms or more runs its inverse transforms in ONE launch of persistent
+    workgroups, one (PRN, bin) transform per workgroup (pcps_fused.h): whole rounds of 256 and a tail cut into single
+    rounds (32 x 41 and 8 x 41: both; 16 x 16 = 256: no tail; 32 x 81: ten rounds and a tail; 5 x 201: more than a
+    round left over -- whole transforms throughout).  Peaks equal to the two-kernel sweeps' bit for bit, ratios to
+    rounding, and both equal to the oracle's for the PRNs checked; a constant stream (every value of a row ties) must
+    give the first index."""
+    fs = 25e6
+    rng = np.random.default_rng(9000 + n_prn + int(dstep))
+    n = orc.samples_per_code(fs)
+    prns = [int(p) for p in rng.choice(np.arange(1, 33), n_prn, replace=False)]
+    sats = [dict(prn=p, doppler=float(rng.uniform(-3500, 3500)), code_phase=float(rng.uniform(0, 1023)),
+                 phase=float(rng.random()), amp=float(rng.uniform(5, 10))) for p in prns[::2]]
+    start = int(rng.integers(0, 64))
+    cap = (n + start + 7) // 8 * 8
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.code_slots(n_prn)
+    for s, p in enumerate(prns):
+        engine.load_gps_code(s, p)
+    engine.iq_synth(sats, fs, 12.0, 4242, 0, cap)
+    nbins = len(np.arange(-drange, drange + 1, dstep))
+    assert n_prn * nbins >= 256
+    res = {}
+    for fused in (1, 0):
+        engine.set_option("pcps_fused", fused)
+        try:
+            res[fused] = engine.pcps(np.arange(n_prn), start, fs, 0.0, drange, dstep, 1, 1)
+        finally:
+            engine.set_option("pcps_fused", 1)
+    assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1], res[0][1])
+    np.testing.assert_allclose(res[1][2], res[0][2], rtol=1e-12, atol=0)
+    rf = orc.iq_to_complex(engine.iq_download(cap, 0))
+    x = rf[start:start + n].reshape(1, -1)
+    for s in (0, 1, n_prn - 1):
+        m = orc.pcps_map(x, 0.0, fs, orc.code_spectrum(orc.gold_code(prns[s]), fs), drange, dstep, n)
+        peak, ratio = orc.two_peak_compare(m, n, round(fs / orc.CODE_RATE))
+        assert peak == [int(res[1][0][s]), int(res[1][1][s])], prns[s]
+        assert res[1][2][s] == pytest.approx(ratio, rel=1e-9)
+    engine.iq_upload(np.zeros(2 * cap, dtype=np.int8), 0)
+    pb, pc, _, _ = engine.pcps(np.arange(n_prn), 0, fs, 0.0, drange, dstep, 1, 1)
+    assert np.all(pb == 0) and np.all(pc == 0)
+
+
 @pytest.mark.parametrize("fs", [25e6, 4e6, 10e6, 50e6])
 def test_register_resident_kernels_vs_oracle(engine, fs):
     """The map-free search at N = N1 x 200 (4 / 10 / 25 / 50 MHz) runs its inverse transforms through the
