@@ -117,6 +117,8 @@ struct sdr_engine {
     DevBuf pcps_work;                // its work list (transform numbers in processing order)
     int pcps_work_prn = 0, pcps_work_bins = 0;   // ... and the grid it was made for
     int pcps_work_first[9] = {0};
+    DevBuf pcps_theta;               // its two per-PRN bound arrays (pcps_fused.h Args::theta), the PRN count they are for, the one in use
+    int pcps_theta_prn = 0, pcps_theta_flip = 0;
 
     // profiling
     bool prof = false;

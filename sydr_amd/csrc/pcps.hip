@@ -407,8 +407,9 @@ __global__ __launch_bounds__(kThreads) void argmax_records_kernel(const Best* __
     const int prn = blockIdx.x;
     Best mine = {-1.0, 0x7fffffffffffffffLL};
     for (int i = threadIdx.x; i < per_prn; i += kThreads) mine = better(mine, recs[(size_t)prn * per_prn + i]);
-    const Best top = block_best(mine, sh);
+    Best top = block_best(mine, sh);
     if (threadIdx.x == 0) {
+        if (top.v < 0.0) top.i = 0;      // (no record at all: never an index the second sweep would read a row with)
         tops[prn] = top;
         out_bin[prn] = top.i / N;
         out_code[prn] = top.i - (top.i / N) * N;

@@ -131,6 +131,13 @@ struct Args {
     int xcd_first[9];          // XCD x owns work[xcd_first[x] .. xcd_first[x + 1])
     double scale;
     Best* partials;            // [work item's record slot][kRecordsPerTransform]
+    // theta[p]: bits of the largest |.|/N any workgroup has recorded for PRN p so far in THIS launch (0 at its start).  A
+    // value of PRN p's map below it can neither be the map's maximum nor tie with it, so a round whose ten new values per
+    // lane all lie below it (with a margin of 2^-40) skips the candidate bookkeeping: after the first round of workgroups
+    // nearly every one does.  theta_next: the next launch's array, zeroed by this one.
+    unsigned long long* theta;
+    unsigned long long* theta_next;
+    int n_prn;
 };
 
 // Diagnostic build (-DSDR_FUSED_STAMPS, tools/pcps_fused_phases.py): wave 0 of every workgroup adds up the shader cycles
@@ -301,6 +308,12 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
 
     double best_sq = -1.0, best_x = 0.0, best_y = 0.0;
     int best_k = -1;
+    // (squared, unscaled, a little low: the bound the lanes' squared magnitudes are screened against)
+    double floor_sq;
+    {
+        const double th = __longlong_as_double((long long)__hip_atomic_load(&a.theta[prn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) * (double)N;
+        floor_sq = th * th * (1.0 - 0x1p-40);
+    }
 #pragma unroll
     for (int rho = 0; rho < 5; ++rho) {
         if (!WHOLE && mode != rho) continue;
@@ -400,26 +413,63 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
             }
             idft10c(u);
             const int k_first = kf0 + rho;
+            double sqv[10];
 #pragma unroll
-            for (int g = 0; g < 10; ++g) {
-                const int p = g / 2 + 5 * (g % 2);
-                const int k = k_first + 20 * N1 * p;              // code phase = position in the transform
-                const double2 x = u[g];
-                const double sq = __builtin_fma(x.x, x.x, x.y * x.y);
-                bool take = sq > best_sq;
-                // (ordering by the squared magnitude; candidates within 2^-48 of the lane's best go through the scaled
-                // hypot -- the reference's np.abs -- and an exact tie keeps the smaller index: pcps_fast.h)
-                const bool near = fabs(sq - best_sq) <= best_sq * 0x1p-48;
-                if (__builtin_expect(__any(near), 0)) {
-                    if (near) {
-                        const double m_new = hypot(x.x * a.scale, x.y * a.scale), m_old = hypot(best_x * a.scale, best_y * a.scale);
-                        take = m_new > m_old || (m_new == m_old && k < best_k);
+            for (int g = 0; g < 10; ++g) sqv[g] = __builtin_fma(u[g].x, u[g].x, u[g].y * u[g].y);
+            const double m01 = fmax(sqv[0], sqv[1]), m23 = fmax(sqv[2], sqv[3]), m45 = fmax(sqv[4], sqv[5]), m67 = fmax(sqv[6], sqv[7]),
+                         m89 = fmax(sqv[8], sqv[9]);
+            const double round_max = fmax(fmax(fmax(m01, m23), fmax(m45, m67)), m89);
+            // (the lane's own best with the same margin: a value within 2^-48 of it must still meet it below)
+            const bool candidate = round_max >= fmax(floor_sq, best_sq * (1.0 - 0x1p-40));
+            if (__any(candidate)) {
+#ifdef SDR_FUSED_STAMPS
+                if (tid == 0) g_fused_stamps[blockIdx.x][6] += 1000000;    // (diagnostic: rounds of wave 0 that keep books)
+#endif
+                // Ordering by the squared magnitude.  A candidate within 2^-48 of the lane's best has to be compared through
+                // the scaled hypot -- the reference's np.abs -- with an exact tie keeping the smaller index (pcps_fast.h): the
+                // round is then redone from the state it started with by ONE run-time loop over a copy of the ten values
+                // (a private array: scratch memory, touched on this path alone).  Inlined per candidate that comparison
+                // made the kernel several times the instruction cache.
+                const double sq0 = best_sq, x0 = best_x, y0 = best_y;
+                const int k0 = best_k;
+                bool tie = false;
+#pragma unroll
+                for (int g = 0; g < 10; ++g) {
+                    const int p = g / 2 + 5 * (g % 2);
+                    const int k = k_first + 20 * N1 * p;              // code phase = position in the transform
+                    const double sq = sqv[g];
+                    const bool take = sq > best_sq;
+                    tie |= fabs(sq - best_sq) <= best_sq * 0x1p-48;
+                    best_sq = take ? sq : best_sq;
+                    best_x = take ? u[g].x : best_x;
+                    best_y = take ? u[g].y : best_y;
+                    best_k = take ? k : best_k;
+                }
+                if (__builtin_expect(__any(tie), 0)) {
+                    double2 copy[10];
+#pragma unroll
+                    for (int g = 0; g < 10; ++g) copy[g] = u[g];
+                    best_sq = sq0;
+                    best_x = x0;
+                    best_y = y0;
+                    best_k = k0;
+#pragma unroll 1
+                    for (int g = 0; g < 10; ++g) {
+                        const int p = g / 2 + 5 * (g % 2);
+                        const int k = k_first + 20 * N1 * p;
+                        const double2 x = copy[g];
+                        const double sq = __builtin_fma(x.x, x.x, x.y * x.y);
+                        bool take = sq > best_sq;
+                        if (fabs(sq - best_sq) <= best_sq * 0x1p-48) {
+                            const double m_new = hypot(x.x * a.scale, x.y * a.scale), m_old = hypot(best_x * a.scale, best_y * a.scale);
+                            take = m_new > m_old || (m_new == m_old && k < best_k);
+                        }
+                        best_sq = take ? sq : best_sq;
+                        best_x = take ? x.x : best_x;
+                        best_y = take ? x.y : best_y;
+                        best_k = take ? k : best_k;
                     }
                 }
-                best_sq = take ? sq : best_sq;
-                best_x = take ? x.x : best_x;
-                best_y = take ? x.y : best_y;
-                best_k = take ? k : best_k;
             }
         }
 #if FUSED_MERGE_Y
@@ -429,7 +479,7 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     }
     int best_i = 0x7fffffff;
     double best_v = -1.0;
-    if (live2) {
+    if (live2 && best_k >= 0) {
         best_i = bin * N + best_k;
         best_v = 0.0 + hypot(best_x * a.scale, best_y * a.scale);   // (0.0 + |.|: the map's own rounding)
     }
@@ -437,6 +487,7 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     if ((tid & 63) == 63) {
         Best rec = {best_v, (long long)best_i};
         a.partials[(size_t)rec_slot * kRecordsPerTransform + (tid >> 6)] = rec;
+        if (best_v > 0.0) atomicMax(&a.theta[prn], (unsigned long long)__double_as_longlong(best_v));   // (positive doubles order as integers)
     }
 }
 
@@ -450,6 +501,8 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
 #endif
     const int tid = threadIdx.x;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if (blockIdx.x == 0)
+        for (int p = tid; p < a.n_prn; p += kThreads) a.theta_next[p] = 0ull;
     const int w_end = a.xcd_first[xcd + 1];
     for (int w = a.xcd_first[xcd] + slot; w < w_end; w += kSlotsPerXcd) {
         // (wave-uniform: scalar base addresses in the unit)

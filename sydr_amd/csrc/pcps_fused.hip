@@ -51,6 +51,17 @@ int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void
     for (int x = 0; x < 9; ++x) a.xcd_first[x] = e->pcps_work_first[x];
     a.scale = 1.0 / (double)N;
     a.partials = (Best*)partials;
+    // the two per-PRN bound arrays (this launch's, the next one's): both zero when made, each launch zeroes the other's
+    if (e->pcps_theta_prn != n_prn) {
+        if (int rc = sdr_devbuf_reserve(e, &e->pcps_theta, 2 * (size_t)n_prn * sizeof(unsigned long long))) return rc;
+        SDR_HIP(hipMemsetAsync(e->pcps_theta.ptr, 0, 2 * (size_t)n_prn * sizeof(unsigned long long), e->stream));
+        e->pcps_theta_prn = n_prn;
+        e->pcps_theta_flip = 0;
+    }
+    a.theta = (unsigned long long*)e->pcps_theta.ptr + (size_t)e->pcps_theta_flip * n_prn;
+    a.theta_next = (unsigned long long*)e->pcps_theta.ptr + (size_t)(e->pcps_theta_flip ^ 1) * n_prn;
+    a.n_prn = n_prn;
+    e->pcps_theta_flip ^= 1;
     (void)hipFuncSetAttribute((const void*)fused25k::ifft_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)fused25k::kLdsBytes);
     ProfScope ps(e, "pcps_inv_fft");
