@@ -314,7 +314,12 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
         const double th = __longlong_as_double((long long)__hip_atomic_load(&a.theta[prn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) * (double)N;
         floor_sq = th * th * (1.0 - 0x1p-40);
     }
-#pragma unroll
+    // (unrolled: as a run-time loop -- FUSED_UNROLL_ROUNDS 1: buffer offsets and the parked registers' cases decided per round,
+    // half the code -- a 32-PRN call measured 0.250 against 0.237 ms)
+#ifndef FUSED_UNROLL_ROUNDS
+#define FUSED_UNROLL_ROUNDS 5
+#endif
+#pragma unroll FUSED_UNROLL_ROUNDS
     for (int rho = 0; rho < 5; ++rho) {
         if (!WHOLE && mode != rho) continue;
         double2* const X = lds4 + ((WHOLE && (rho & 1)) ? kBuf : 0);
@@ -338,11 +343,16 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
             for (int m = 0; m < 10; ++m) z[m] = rowz[20 * m];
             __builtin_amdgcn_sched_barrier(0);
 #endif
-            if (rho >= 1 && rho <= 3 && WHOLE) {
+            if (WHOLE) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int rr = 1; rr <= 3; ++rr) {          // (wave-uniform cases: the register index must be a constant)
+                    if (rho == rr) {
 #pragma unroll
-                    for (int kB = 0; kB < 5; ++kB) Xo[cb + 100 * j + 5 * N2 * kB] = park[j][5 * (rho - 1) + kB];
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int kB = 0; kB < 5; ++kB) Xo[cb + 100 * j + 5 * N2 * kB] = park[j][5 * (rr - 1) + kB];
+                    }
+                }
             }
 #if FUSED_READS_FIRST
             __builtin_amdgcn_sched_barrier(0);
