@@ -84,7 +84,9 @@ int sdr_prof_reset(sdr_engine* e);
  * four-step transform; "pcps_general_kernels" = 1 keeps the general four-step kernels where the register-resident
  * 125 x 200 ones would run; "pcps_prn_chunk" = n searches n PRNs per inverse sweep; "pcps_one_stream" = 1 keeps the sweeps of a map-free search on one stream;
  * "pcps_fused" = 0 keeps a map-free search at 25 MHz on the two-kernel sweeps where one launch of persistent workgroups, one
- * (PRN, bin) transform per workgroup, would run (256 transforms or more); "epl_no_chip_variant",
+ * (PRN, bin) transform per workgroup, would run (256 transforms or more); "pcps_no_spectra_cache" = 1
+ * recomputes conj(fft(code)) in every search, as the reference does (channel_l1ca_kaplan.py:184-185), instead of keeping
+ * the spectra of the staged codes; "epl_no_chip_variant",
  * "epl_no_split_variant", "epl_no_half_chip_view" = 1 keep the E/P/L correlator from its chip-aligned core, from the
  * kernel with the tap switch positions compiled in, from the half-chip view of 32-52 samples per chip.  Integer
  * results do not depend on any of them, floating ones to rounding. */

@@ -1106,7 +1106,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
             key.push_back(e->code_stamp[h_slots[i]]);
         }
     }
-    const bool spectra_cached = !have_spectra && key == e->pcps_spec_key;
+    const bool spectra_cached = !have_spectra && key == e->pcps_spec_key && !e->pcps_no_spec_cache;
     if (have_spectra) e->pcps_spec_key.clear();
     if (!have_spectra && !spectra_cached) {
         e->pcps_spec_key.clear();   // (valid again only once the new spectra are queued without error, below)
