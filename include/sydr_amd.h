@@ -176,6 +176,11 @@ int sdr_epl_batch(sdr_engine* e, const sdr_epl_item* items, int n_items, const d
 typedef struct sdr_epl_plan sdr_epl_plan;
 int sdr_epl_plan_create(sdr_engine* e, const sdr_epl_item* items, int n_items,
                         const double* spacing, int n_taps, double fs, sdr_epl_plan** out);
+/* The same for a list that is already in DEVICE memory (a closed-loop launch's trajectory turned into items, a list another
+ * kernel produced): copied device to device -- the plan owns its items either way -- and checked there, one thread per item;
+ * nothing crosses the host but the verdict.  (The host form checks long lists the same way, behind their upload.) */
+int sdr_epl_plan_create_dev(sdr_engine* e, const sdr_epl_item* items_dev, int n_items,
+                            const double* spacing, int n_taps, double fs, sdr_epl_plan** out);
 int sdr_epl_plan_run(sdr_engine* e, sdr_epl_plan* p);
 /* Launch only items [first, first+count) of the plan (e.g. one second of a long stream). */
 int sdr_epl_plan_run_range(sdr_engine* e, sdr_epl_plan* p, int64_t first, int64_t count);

@@ -120,6 +120,7 @@ _PROTOTYPES = {
     "sdr_code_upsample": (C.c_int, [_VP, C.c_int, C.c_double, C.c_int64, _VP]),
     "sdr_epl_batch": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, C.c_double, _VP]),
     "sdr_epl_plan_create": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, C.c_double, C.POINTER(_VP)]),
+    "sdr_epl_plan_create_dev": (C.c_int, [_VP, _VP, C.c_int, _VP, C.c_int, C.c_double, C.POINTER(_VP)]),
     "sdr_epl_plan_run": (C.c_int, [_VP, _VP]),
     "sdr_epl_plan_run_range": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64]),
     "sdr_epl_plan_fetch": (C.c_int, [_VP, _VP, _VP]),

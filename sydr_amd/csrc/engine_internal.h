@@ -88,7 +88,7 @@ struct sdr_engine {
     int64_t luts2_generation = -1, luts2_stamp = -1;
 
     // workspaces
-    DevBuf ws_items, ws_out, ws_spacing, ws_setups;
+    DevBuf ws_items, ws_out, ws_spacing, ws_setups, ws_stats;
     DevBuf pcps_fwd, pcps_a, pcps_b, pcps_code, pcps_tw, pcps_map, pcps_csum, pcps_part, pcps_res;
     DevBuf track_state, track_cfg;
     int n_cus = 0;              // compute units of the device (sizes the closed-loop clusters)

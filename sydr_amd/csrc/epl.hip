@@ -20,6 +20,9 @@
 // minimax sincos) and advanced by precomputed fp64 rotations inside a block and from block to block, which agrees
 // with the reference to ~1e-15 relative on the accumulators (the bar is 1e-6).
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
 
 #include "correlator.h"
 #include "correlator_chip.h"
@@ -389,138 +392,304 @@ __global__ __launch_bounds__(256) void chipn_setup_kernel(const sdr_epl_item* __
     out[i] = S;
 }
 
-// Host-side check that no item can index outside the ring or the staged LUT.
+// ---- validation of a list: no item may index outside the ring or the staged replica, and what the list as a whole
+// allows (the kernel variant) follows from every item.  One function per item for both sides: the host walks short lists
+// (one call per EPL(): latency), one THREAD per item checks long ones behind their upload (1.92 M items of a 60 s x 32
+// channel plan took the host 20-30 ms of the 34 ms a plan cost; the launch takes ~0.1 ms).
 // scale = 2: the variant is chosen for the half-chip view (2*rem_code, 2*code_step, 2*spacing against tables of twice the length).
-static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items, const double* spacing,
-                          int n_taps, double scale, int* lut_words, int* wide) {
-    double smin = spacing[0], smax = spacing[0];
-    for (int t = 1; t < n_taps; ++t) {
-        smin = spacing[t] < smin ? spacing[t] : smin;
-        smax = spacing[t] > smax ? spacing[t] : smax;
-    }
-    int maxlen = 0;
-    double max_step = 0.0, min_step = 1e300;
-    const double s_anchor = scale * spacing[n_taps < 5 ? n_taps / 2 : 2];   // centre tap of the first chunk of taps the kernels serve together
-    bool all_m24 = true;
-    bool all_s12 = n_taps == 3;   // both outer taps switch chips 12.x samples into the anchor's block (KS = 12 kernel)
-    bool all_ki = n_taps == 3 || n_taps == 5;   // tap t exactly (t - A) chips from the anchor (KI kernel)
-    for (int t = 0; all_ki && t < n_taps; ++t) all_ki = scale * spacing[t] - s_anchor == (double)(t - n_taps / 2);
-    for (int i = 0; i < n_items; ++i) {
-        const sdr_epl_item& it = items[i];
-        // (before anything is derived from them: a zero n_samples or a NaN code_step would be cast to an integer below)
-        if (it.code_slot < 0 || it.code_slot >= e->n_slots || e->code_len_host[it.code_slot] <= 0)
-            return sdr_fail(SDR_ERR_INVALID, "item %d: code slot %d is not staged", i, it.code_slot);
-        if (it.n_samples <= 0 || it.n_samples > e->iq_capacity)
-            return sdr_fail(SDR_ERR_RANGE, "item %d: n_samples %d outside (0, ring capacity]", i, it.n_samples);
-        if (it.start_sample < 0) return sdr_fail(SDR_ERR_RANGE, "item %d: negative start_sample", i);
-        if (!(it.code_step > 0.0) || !std::isfinite(it.code_step) || !std::isfinite(it.rem_code) ||
-            !std::isfinite(it.rem_carrier) || !std::isfinite(it.carrier_hz))
-            return sdr_fail(SDR_ERR_INVALID, "item %d: non-finite or non-positive NCO parameter", i);
-        {   // samples per chip of the anchor tap's np.linspace step, exactly as the kernel derives it (correlator_chip.h)
-            const double two32 = 4294967296.0;
-            const double nd = (double)it.n_samples;
-            auto line = [&](double spc, double& sh, double& inv) {
-                sh = scale * it.rem_code + spc;
-                double stop = (scale * it.code_step) * nd;
-                stop = stop + sh;
-                inv = 1.0 / ((stop - sh) / nd);
-            };
-            double sh, inv;
-            line(s_anchor, sh, inv);
-            const bool in_range = inv >= 1.0 && inv < 1024.0;   // (samples per chip; false for NaN / Inf as well)
-            const int64_t tfx = in_range ? (int64_t)std::rint(inv * two32) : 0;
-            all_m24 = all_m24 && (int)(tfx >> 32) == 24;
-            for (int t = 0; all_s12 && all_m24 && t < 3; t += 2) {
-                // the kernel's own derivation of the switch offset (a Q32.32 sample count); its reciprocal is a Newton
-                // step, not a division, so a margin of 2^-10 sample keeps the two from disagreeing about the integer part
-                double sht, invt;
-                line(scale * spacing[t], sht, invt);
-                const int64_t ufx = (int64_t)std::floor(-sh * inv * two32), ut = (int64_t)std::floor(-sht * invt * two32);
-                const int j = (int)std::ceil(sht - sh) - 1;
-                int64_t d = (ut - ufx) + (int64_t)(1 + j) * tfx;
-                if (d < 0) d += tfx; else if (d >= tfx) d -= tfx;
-                const int64_t margin = (int64_t)1 << 22;
-                all_s12 = d >= ((int64_t)12 << 32) + margin && d < ((int64_t)13 << 32) - margin;
-            }
+struct ItemRules {
+    int n_slots, lut_stride, n_taps;
+    int64_t iq_capacity;
+    double scale, smin, smax, s_anchor, sp0, sp2;
+    bool want_s12;
+};
+struct ItemStats {                 // of the items seen so far
+    int first_bad, bad_code;       // lowest index of an invalid item (INT_MAX: none) and what is wrong with it
+    int maxlen;
+    unsigned long long max_step_bits, min_step_bits;   // (positive doubles order as integers)
+    int all_m24, all_s12;
+};
+enum ItemError { ITEM_OK = 0, ITEM_SLOT, ITEM_SAMPLES, ITEM_START, ITEM_NCO, ITEM_REPLICA };
+
+// What is wrong with one item (ITEM_OK: nothing) and its share of the list's statistics.  lo / hi: its code phase range.
+__host__ __device__ inline int check_item(const sdr_epl_item& it, const ItemRules& r, const int32_t* code_len, int& maxlen,
+                                          double& step_scaled, bool& m24, bool& s12, double& lo, double& hi) {
+    // (before anything is derived from them: a zero n_samples or a NaN code_step would be cast to an integer below)
+    if (it.code_slot < 0 || it.code_slot >= r.n_slots || code_len[it.code_slot] <= 0) return ITEM_SLOT;
+    if (it.n_samples <= 0 || it.n_samples > r.iq_capacity) return ITEM_SAMPLES;
+    if (it.start_sample < 0) return ITEM_START;
+    // (finite: x - x is 0 for every finite x and NaN otherwise -- one spelling for both sides)
+    auto finite = [](double x) { return x - x == 0.0; };
+    if (!(it.code_step > 0.0) || !finite(it.code_step) || !finite(it.rem_code) || !finite(it.rem_carrier) || !finite(it.carrier_hz))
+        return ITEM_NCO;
+    {   // samples per chip of the anchor tap's np.linspace step, exactly as the kernel derives it (correlator_chip.h)
+        const double two32 = 4294967296.0;
+        const double nd = (double)it.n_samples;
+        auto line = [&](double spc, double& sh, double& inv) {
+            sh = r.scale * it.rem_code + spc;
+            double stop = (r.scale * it.code_step) * nd;
+            stop = stop + sh;
+            inv = 1.0 / ((stop - sh) / nd);
+        };
+        double sh, inv;
+        line(r.s_anchor, sh, inv);
+        const bool in_range = inv >= 1.0 && inv < 1024.0;   // (samples per chip; false for NaN / Inf as well)
+        const int64_t tfx = in_range ? (int64_t)rint(inv * two32) : 0;
+        m24 = (int)(tfx >> 32) == 24;
+        s12 = r.want_s12 && m24;
+        for (int t = 0; s12 && t < 3; t += 2) {
+            // the kernel's own derivation of the switch offset (a Q32.32 sample count); its reciprocal is a Newton
+            // step, not a division, so a margin of 2^-10 sample keeps the two from disagreeing about the integer part
+            double sht, invt;
+            line(r.scale * (t ? r.sp2 : r.sp0), sht, invt);
+            const int64_t ufx = (int64_t)floor(-sh * inv * two32), ut = (int64_t)floor(-sht * invt * two32);
+            const int j = (int)ceil(sht - sh) - 1;
+            int64_t d = (ut - ufx) + (int64_t)(1 + j) * tfx;
+            if (d < 0) d += tfx; else if (d >= tfx) d -= tfx;
+            const int64_t margin = (int64_t)1 << 22;
+            s12 = d >= ((int64_t)12 << 32) + margin && d < ((int64_t)13 << 32) - margin;
         }
-        if (scale * it.code_step > max_step) max_step = scale * it.code_step;
-        if (scale * it.code_step < min_step) min_step = scale * it.code_step;
-        const double lo = std::ceil(it.rem_code + smin);
-        const double hi = std::ceil(it.code_step * (double)it.n_samples + it.rem_code + smax);
-        const int reach = e->lut_stride - SDR_LUT_PAD - 2;  // largest padded index the staged row serves
-        if (lo < -(double)SDR_LUT_PAD || hi > (double)reach)
+    }
+    step_scaled = r.scale * it.code_step;
+    lo = ceil(it.rem_code + r.smin);
+    hi = ceil(it.code_step * (double)it.n_samples + it.rem_code + r.smax);
+    const int reach = r.lut_stride - SDR_LUT_PAD - 2;  // largest padded index the staged row serves
+    if (lo < -(double)SDR_LUT_PAD || hi > (double)reach) return ITEM_REPLICA;
+    maxlen = (int)hi;
+    return ITEM_OK;
+}
+
+__device__ __forceinline__ unsigned long long dbits(double x) { return (unsigned long long)__double_as_longlong(x); }
+
+// Two rule sets at once (the list as it is and its half-chip view): one upload, one launch, one read-back.
+__global__ __launch_bounds__(256) void validate_items_kernel(const sdr_epl_item* __restrict__ items, int n_items, ItemRules r1,
+                                                             ItemRules r2, const int32_t* __restrict__ code_len,
+                                                             ItemStats* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool have = i < n_items;
+    sdr_epl_item it = {};
+    if (have) it = items[i];
+    for (int v = 0; v < 2; ++v) {
+        const ItemRules& r = v ? r2 : r1;
+        // (a lane without an item, or with a bad one, carries the neutral element of every reduction: all 64 lanes take part)
+        int maxlen = 0, bad = 0;
+        double step = 0.0, lo, hi;
+        bool m24 = true, s12 = true;
+        if (have) bad = check_item(it, r, code_len, maxlen, step, m24, s12, lo, hi);
+        const bool good = have && !bad;
+        int ml = good ? maxlen : 0;
+        unsigned long long mx = good ? dbits(step) : 0ull, mn = good ? dbits(step) : ~0ull;
+        int a24 = (!good || m24) ? 1 : 0, a12 = (!good || s12) ? 1 : 0;
+        int fb = bad ? i : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ml = max(ml, __shfl_xor(ml, off, 64));
+            const unsigned long long ox = __shfl_xor(mx, off, 64), on = __shfl_xor(mn, off, 64);
+            mx = ox > mx ? ox : mx;
+            mn = on < mn ? on : mn;
+            a24 &= __shfl_xor(a24, off, 64);
+            a12 &= __shfl_xor(a12, off, 64);
+            fb = min(fb, __shfl_xor(fb, off, 64));
+        }
+        ItemStats* o = out + v;
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&o->maxlen, ml);
+            atomicMax(&o->max_step_bits, mx);
+            atomicMin(&o->min_step_bits, mn);
+            if (!a24) atomicAnd(&o->all_m24, 0);
+            if (!a12) atomicAnd(&o->all_s12, 0);
+            if (fb != 0x7fffffff) atomicMin(&o->first_bad, fb);
+        }
+    }
+}
+
+static ItemRules item_rules(const sdr_engine* e, const double* spacing, int n_taps, double scale) {
+    ItemRules r = {};
+    r.n_slots = e->n_slots;
+    r.lut_stride = e->lut_stride;
+    r.n_taps = n_taps;
+    r.iq_capacity = e->iq_capacity;
+    r.scale = scale;
+    r.smin = r.smax = spacing[0];
+    for (int t = 1; t < n_taps; ++t) {
+        r.smin = spacing[t] < r.smin ? spacing[t] : r.smin;
+        r.smax = spacing[t] > r.smax ? spacing[t] : r.smax;
+    }
+    r.s_anchor = scale * spacing[n_taps < 5 ? n_taps / 2 : 2];   // centre tap of the first chunk of taps the kernels serve together
+    r.sp0 = spacing[0];
+    r.sp2 = n_taps >= 3 ? spacing[2] : 0.0;
+    r.want_s12 = n_taps == 3;   // both outer taps switch chips 12.x samples into the anchor's block (KS = 12 kernel)
+    return r;
+}
+
+static int item_error(const sdr_engine* e, const sdr_epl_item& it, int index, int code, double lo, double hi) {
+    switch (code) {
+        case ITEM_SLOT: return sdr_fail(SDR_ERR_INVALID, "item %d: code slot %d is not staged", index, it.code_slot);
+        case ITEM_SAMPLES: return sdr_fail(SDR_ERR_RANGE, "item %d: n_samples %d outside (0, ring capacity]", index, it.n_samples);
+        case ITEM_START: return sdr_fail(SDR_ERR_RANGE, "item %d: negative start_sample", index);
+        case ITEM_NCO: return sdr_fail(SDR_ERR_INVALID, "item %d: non-finite or non-positive NCO parameter", index);
+        default:
             return sdr_fail(SDR_ERR_RANGE,
                             "item %d: code phase range [%g, %g] leaves the staged replica [-%d, %d] "
-                            "(stage more code periods with sdr_code_slots_ex)", i, lo, hi, SDR_LUT_PAD, reach);
-        if ((int)hi > maxlen) maxlen = (int)hi;
+                            "(stage more code periods with sdr_code_slots_ex)", index, lo, hi, SDR_LUT_PAD,
+                            e->lut_stride - SDR_LUT_PAD - 2);
     }
-    *lut_words = maxlen + SDR_LUT_PAD + 2;
-    const bool boundary_ok = min_step >= sdr::kFastMinCodeStep && scale * e->lut_stride < sdr::kFastMaxLutWords;
-    *wide = !boundary_ok ? 0 : (max_step <= sdr::kFastMaxCodeStep ? 16 : (max_step <= sdr::kFastMaxCodeStep8 ? 8 : 0));
+}
+
+// The kernel variant a list of these statistics gets (0: per sample; 8 / 16: boundary variants; kChipMax + ...: chip-aligned).
+static int variant_of(const sdr_engine* e, const ItemRules& r, const double* spacing, double max_step, double min_step, bool all_m24,
+                      bool all_s12) {
+    bool all_ki = r.n_taps == 3 || r.n_taps == 5;   // tap t exactly (t - A) chips from the anchor (KI kernel)
+    for (int t = 0; all_ki && t < r.n_taps; ++t) all_ki = r.scale * spacing[t] - r.s_anchor == (double)(t - r.n_taps / 2);
+    const bool boundary_ok = min_step >= sdr::kFastMinCodeStep && r.scale * e->lut_stride < sdr::kFastMaxLutWords;
+    int wide = !boundary_ok ? 0 : (max_step <= sdr::kFastMaxCodeStep ? 16 : (max_step <= sdr::kFastMaxCodeStep8 ? 8 : 0));
     // every item inside the chip-aligned variant's range (ci8 ring): lanes own whole chips instead of 16 samples
     if (boundary_ok && e->iq_fmt == SDR_FMT_CI8 && min_step >= sdr::kChipMinCodeStep && max_step <= sdr::kChipMaxCodeStep &&
         !e->epl_no_chip)
-        *wide = sdr::kChipMax + (all_m24 ? 24 : 0) +
-                ((all_m24 && all_s12 && !e->epl_no_split) ? kVariantKS12 : 0) +
-                ((all_m24 && all_ki && !e->epl_no_split) ? kVariantKI : 0);
+        wide = sdr::kChipMax + (all_m24 ? 24 : 0) +
+               ((all_m24 && all_s12 && !e->epl_no_split) ? kVariantKS12 : 0) +
+               ((all_m24 && all_ki && !e->epl_no_split) ? kVariantKI : 0);
+    return wide;
+}
+
+// Host walk (short lists; and the one bad item of a long list, for its message: index0 = its place in the list).
+static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items, const double* spacing,
+                          int n_taps, double scale, int* lut_words, int* wide, int index0 = 0) {
+    const ItemRules r = item_rules(e, spacing, n_taps, scale);
+    int maxlen = 0;
+    double max_step = 0.0, min_step = 1e300;
+    bool all_m24 = true, all_s12 = r.want_s12;
+    for (int i = 0; i < n_items; ++i) {
+        int ml = 0;
+        double step = 0.0, lo = 0.0, hi = 0.0;
+        bool m24 = true, s12 = true;
+        if (const int bad = check_item(items[i], r, e->code_len_host.data(), ml, step, m24, s12, lo, hi))
+            return item_error(e, items[i], index0 + i, bad, lo, hi);
+        all_m24 = all_m24 && m24;
+        all_s12 = all_s12 && s12;
+        if (step > max_step) max_step = step;
+        if (step < min_step) min_step = step;
+        if (ml > maxlen) maxlen = ml;
+    }
+    *lut_words = maxlen + SDR_LUT_PAD + 2;
+    *wide = variant_of(e, r, spacing, max_step, min_step, all_m24, all_s12);
     return SDR_OK;
+}
+
+// The same for a list that is already on the device (long lists: behind their upload).  ok2: the half-chip view's rules
+// were met as well (lw2 / wide2 then hold its answers).
+static int validate_items_dev(sdr_engine* e, const sdr_epl_item* d_items, const sdr_epl_item* h_items, int n_items,
+                              const double* spacing, int n_taps, int* lut_words, int* wide, bool* ok2, int* lw2, int* wide2) {
+    const ItemRules r1 = item_rules(e, spacing, n_taps, 1.0), r2 = item_rules(e, spacing, n_taps, 2.0);
+    if (int rc = sdr_devbuf_reserve(e, &e->ws_stats, 2 * sizeof(ItemStats))) return rc;
+    if (int rc = sdr_pinned_reserve(e, &e->ctx0, 2 * sizeof(ItemStats))) return rc;
+    ItemStats* host = static_cast<ItemStats*>(e->ctx0.pinned);
+    for (int v = 0; v < 2; ++v) {
+        host[v] = ItemStats{0x7fffffff, 0, 0, 0ull, ~0ull, 1, (v ? r2 : r1).want_s12 ? 1 : 0};
+    }
+    SDR_HIP(hipMemcpyAsync(e->ws_stats.ptr, host, 2 * sizeof(ItemStats), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(validate_items_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, e->stream, d_items, n_items, r1, r2,
+                       (const int32_t*)e->code_len, static_cast<ItemStats*>(e->ws_stats.ptr));
+    SDR_HIP(hipGetLastError());
+    SDR_HIP(hipMemcpyAsync(host, e->ws_stats.ptr, 2 * sizeof(ItemStats), hipMemcpyDeviceToHost, e->stream));
+    SDR_HIP(hipStreamSynchronize(e->stream));
+    auto as_double = [](unsigned long long b) { double d; std::memcpy(&d, &b, sizeof(d)); return d; };
+    if (host[0].first_bad != 0x7fffffff) {
+        const int i = host[0].first_bad;
+        sdr_epl_item it;
+        if (h_items) it = h_items[i];
+        else SDR_HIP(hipMemcpy(&it, d_items + i, sizeof(it), hipMemcpyDeviceToHost));
+        int lw, wd;
+        const int rc = validate_items(e, &it, 1, spacing, n_taps, 1.0, &lw, &wd, i);   // (the message, from the host's own walk of that item)
+        return rc ? rc : sdr_fail(SDR_ERR_INVALID, "item %d: rejected by the device check", i);
+    }
+    *lut_words = host[0].maxlen + SDR_LUT_PAD + 2;
+    *wide = variant_of(e, r1, spacing, as_double(host[0].max_step_bits), as_double(host[0].min_step_bits), host[0].all_m24 != 0,
+                       host[0].all_s12 != 0);
+    *ok2 = host[1].first_bad == 0x7fffffff;
+    if (*ok2) {
+        *lw2 = host[1].maxlen + SDR_LUT_PAD + 2;
+        *wide2 = variant_of(e, r2, spacing, as_double(host[1].max_step_bits), as_double(host[1].min_step_bits), host[1].all_m24 != 0,
+                            host[1].all_s12 != 0);
+    }
+    return SDR_OK;
+}
+
+// (half-chip view of a list on the device: 2 * rem_code, 2 * code_step)
+__global__ __launch_bounds__(256) void double_items_kernel(sdr_epl_item* __restrict__ items, int n_items) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_items) return;
+    items[i].rem_code *= 2.0;
+    items[i].code_step *= 2.0;
 }
 
 extern "C" {
 
-static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_items, const double* spacing,
+static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_epl_item* d_src, int n_items, const double* spacing,
                             int n_taps, double fs, bool use_workspaces, sdr_epl_plan** out);
 
 int sdr_epl_plan_create(sdr_engine* e, const sdr_epl_item* items, int n_items, const double* spacing,
                         int n_taps, double fs, sdr_epl_plan** out) {
-    return plan_create_impl(e, items, n_items, spacing, n_taps, fs, false, out);
+    if (!items) return sdr_fail(SDR_ERR_INVALID, "no items");
+    return plan_create_impl(e, items, nullptr, n_items, spacing, n_taps, fs, false, out);
 }
 
+int sdr_epl_plan_create_dev(sdr_engine* e, const sdr_epl_item* items_dev, int n_items, const double* spacing,
+                            int n_taps, double fs, sdr_epl_plan** out) {
+    if (!items_dev) return sdr_fail(SDR_ERR_INVALID, "no items");
+    return plan_create_impl(e, nullptr, items_dev, n_items, spacing, n_taps, fs, false, out);
+}
+
+// items: the list in host memory, or d_src: the list in device memory (copied: the plan owns its items either way).
 // use_workspaces: the one-shot sdr_epl_batch (the function-level drop-in calls it once per EPL()) keeps its three device
 // buffers in the engine between calls instead of allocating and freeing them every time.
-static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_items, const double* spacing,
+static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_epl_item* d_src, int n_items, const double* spacing,
                             int n_taps, double fs, bool use_workspaces, sdr_epl_plan** out) {
     if (int rc = sdr_set_device(e)) return rc;
     if (!out) return sdr_fail(SDR_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!e->iq) return sdr_fail(SDR_ERR_STATE, "IQ ring not allocated");
     if (!e->codes) return sdr_fail(SDR_ERR_STATE, "code slots not allocated");
-    if (!items || n_items <= 0) return sdr_fail(SDR_ERR_INVALID, "no items");
+    if ((!items && !d_src) || n_items <= 0) return sdr_fail(SDR_ERR_INVALID, "no items");
     if (!spacing || n_taps < 1 || n_taps > SDR_MAX_TAPS)
         return sdr_fail(SDR_ERR_INVALID, "n_taps %d outside 1..%d", n_taps, SDR_MAX_TAPS);
     if (!(fs > 0.0)) return sdr_fail(SDR_ERR_INVALID, "fs must be positive");
     int lut_words = 0;
     int wide = 0;
-    if (int rc = validate_items(e, items, n_items, spacing, n_taps, 1.0, &lut_words, &wide)) return rc;
+    const bool timing = getenv("SDR_PLAN_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    // a short list is checked by the host before anything is allocated (one call per EPL(): latency); a long one by one
+    // thread per item behind its upload
+    const bool long_list = d_src != nullptr || n_items >= 4096;
     // a list that misses the chip-aligned correlator only because a chip holds too many samples (32-52: GPS L1 C/A at
     // 50 MHz) runs on the half-chip view of its replicas
     bool doubled = false;
-    if (wide < sdr::kChipMax && e->iq_fmt == SDR_FMT_CI8 && !e->epl_no_chip && !e->epl_no_double) {
-        int lw2 = 0, wide2 = 0;
-        if (validate_items(e, items, n_items, spacing, n_taps, 2.0, &lw2, &wide2) == SDR_OK && wide2 >= sdr::kChipMax) {
+    auto consider_half_chip_view = [&](bool ok2, int lw2, int wide2) -> int {
+        if (wide < sdr::kChipMax && e->iq_fmt == SDR_FMT_CI8 && !e->epl_no_chip && !e->epl_no_double && ok2 && wide2 >= sdr::kChipMax) {
             if (int rc = ensure_doubled_luts(e, e->stream)) return rc;
             doubled = true;
             wide = wide2;
             lut_words = 2 * lut_words < e->lut2_stride ? 2 * lut_words : e->lut2_stride;
+            (void)lw2;
         }
+        return SDR_OK;
+    };
+    if (!long_list) {
+        if (int rc = validate_items(e, items, n_items, spacing, n_taps, 1.0, &lut_words, &wide)) return rc;
+        int lw2 = 0, wide2 = 0;
+        bool ok2 = false;
+        if (wide < sdr::kChipMax && e->iq_fmt == SDR_FMT_CI8 && !e->epl_no_chip && !e->epl_no_double)
+            ok2 = validate_items(e, items, n_items, spacing, n_taps, 2.0, &lw2, &wide2) == SDR_OK;
+        if (int rc = consider_half_chip_view(ok2, lw2, wide2)) return rc;
     }
+    const double t_valid = now();
 
     sdr_epl_plan* p = new (std::nothrow) sdr_epl_plan();
     if (!p) return sdr_fail(SDR_ERR_NOMEM, "host allocation failed");
     p->n_items = n_items;
     p->n_taps = n_taps;
     p->fs = fs;
-    p->lut_words = lut_words;
-    p->wide = wide;
-    p->doubled = doubled;
-    // the period of the code-slot pattern, if the list has one (what lets four epochs of a channel share a staged table)
-    if (lut_words >= kLongLutWords) {
-        int c = 1;
-        while (c < n_items && items[c].code_slot != items[0].code_slot) ++c;
-        bool periodic = c < n_items || n_items == 1;
-        for (int i = 0; periodic && i + c < n_items; ++i) periodic = items[i].code_slot == items[i + c].code_slot;
-        p->group_stride = periodic ? c : 0;
-    }
     p->code_generation = e->code_generation;
     p->ring_capacity = e->iq_capacity;
     hipError_t err = hipSuccess;
@@ -541,17 +710,54 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
         if (err == hipSuccess) err = hipMalloc(&p->d_out, (size_t)n_items * 2 * n_taps * sizeof(double));
         if (err == hipSuccess) err = hipMalloc(&p->d_spacing, SDR_MAX_TAPS * sizeof(double));
     }
-    std::vector<sdr_epl_item> items2;
+    const double t_alloc = now();
+    if (err == hipSuccess)
+        err = hipMemcpyAsync(p->d_items, d_src ? d_src : items, (size_t)n_items * sizeof(sdr_epl_item),
+                             d_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream);
+    if (err == hipSuccess && long_list) {
+        int lw2 = 0, wide2 = 0;
+        bool ok2 = false;
+        int rc = validate_items_dev(e, p->d_items, items, n_items, spacing, n_taps, &lut_words, &wide, &ok2, &lw2, &wide2);
+        if (!rc) rc = consider_half_chip_view(ok2, lw2, wide2);
+        if (rc) {
+            sdr_epl_plan_destroy(e, p);
+            return rc;
+        }
+    }
+    p->lut_words = lut_words;
+    p->wide = wide;
+    p->doubled = doubled;
+    // the period of the code-slot pattern, if the list has one (what lets four epochs of a channel share a staged table)
+    std::vector<sdr_epl_item> fetched;          // (a device list of long replicas: its slots are read back for this)
+    if (err == hipSuccess && lut_words >= kLongLutWords) {
+        const sdr_epl_item* h = items;
+        if (!h) {
+            fetched.resize(n_items);
+            err = hipMemcpy(fetched.data(), p->d_items, (size_t)n_items * sizeof(sdr_epl_item), hipMemcpyDeviceToHost);
+            h = fetched.data();
+        }
+        if (err == hipSuccess) {
+            int c = 1;
+            while (c < n_items && h[c].code_slot != h[0].code_slot) ++c;
+            bool periodic = c < n_items || n_items == 1;
+            for (int i = 0; periodic && i + c < n_items; ++i) periodic = h[i].code_slot == h[i + c].code_slot;
+            p->group_stride = periodic ? c : 0;
+        }
+    }
+    std::vector<sdr_epl_item> items2;   // short lists on the half-chip view: the host's copy with 2 * rem_code, 2 * code_step (for its setups)
     std::vector<char> host_setups;      // short lists: the setups are made on the host (kept until the final synchronisation)
     double spacing2[SDR_MAX_TAPS];
     if (doubled) {
-        items2.assign(items, items + n_items);
-        for (sdr_epl_item& it : items2) it.rem_code *= 2.0, it.code_step *= 2.0;
+        if (items && !long_list) {
+            items2.assign(items, items + n_items);
+            for (sdr_epl_item& it : items2) it.rem_code *= 2.0, it.code_step *= 2.0;
+        }
         for (int t = 0; t < n_taps; ++t) spacing2[t] = 2.0 * spacing[t];
+        if (err == hipSuccess) {
+            hipLaunchKernelGGL(double_items_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, e->stream, p->d_items, n_items);
+            err = hipGetLastError();
+        }
     }
-    if (err == hipSuccess)
-        err = hipMemcpyAsync(p->d_items, doubled ? items2.data() : items, (size_t)n_items * sizeof(sdr_epl_item),
-                             hipMemcpyHostToDevice, e->stream);
     if (err == hipSuccess)
         err = hipMemcpyAsync(p->d_spacing, doubled ? spacing2 : spacing, n_taps * sizeof(double), hipMemcpyHostToDevice, e->stream);
     // ---- the per-item setups of the straight-line kernels: one launch, one thread per item (items and spacings are on the device)
@@ -569,7 +775,7 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
     if (err == hipSuccess && e->iq_fmt == SDR_FMT_CI8 && (wide & 255) >= kChipMax && (wide & (kVariantKS12 | kVariantKI)) &&
         (n_taps == 3 || n_taps == 5)) {
         reserve_setups(n_taps == 3 ? sizeof(sdr::ChipSetup<3>) : sizeof(sdr::ChipSetup<5>));
-        if (err == hipSuccess && n_items < 4096) {
+        if (err == hipSuccess && !long_list) {
             // a short list (sdr_epl_batch: one call per EPL()): the same function on the host, ~2 us per item, instead of a launch
             const sdr_epl_item* src = doubled ? items2.data() : items;
             const double* spc = doubled ? spacing2 : spacing;
@@ -607,13 +813,16 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
     // spill 27 registers at three waves per SIMD: 0.44 instead of 0.57 of the roof.  Neither is instantiated.)
     if (err == hipSuccess && e->iq_fmt == SDR_FMT_CI8 && n_taps == 3 && !doubled && !e->epl_no_chip2 && (wide & 255) == 8 &&
         lut_words < kLongLutWords) {          // (long multi-period replicas keep the four-epochs-per-workgroup kernels)
-        const double two_chips = std::floor(2.0 / items[0].code_step);       // samples in two chips (any positive step got here)
+        sdr_epl_item first = {};
+        if (items) first = items[0];
+        else err = hipMemcpy(&first, p->d_items, sizeof(first), hipMemcpyDeviceToHost);
+        const double two_chips = err == hipSuccess ? std::floor(2.0 / first.code_step) : 0.0;   // samples in two chips (any positive step got here)
         const int shape = two_chips == 19.0 ? 1 : (two_chips == 23.0 ? 2 : 0);
         if (shape) {
             reserve_setups(shape == 1 ? sizeof(sdr::ChipNSetup<4, 9, 14, 19>) : sizeof(sdr::ChipNSetup<5, 11, 17, 23>));
             int* d_missed = p->d_setups ? reinterpret_cast<int*>(p->d_setups + p->setup_bytes * (size_t)n_items) : nullptr;
             int missed = n_items;
-            if (err == hipSuccess && n_items < 4096) {
+            if (err == hipSuccess && !long_list) {
                 // a short list (sdr_epl_batch: one call per EPL()): the same function on the host, ~2 us per item, instead of a
                 // launch and a round trip for the count -- the call is latency, not throughput
                 host_setups.resize(p->setup_bytes * (size_t)n_items);
@@ -654,7 +863,11 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, int n_item
             }
         }
     }
+    const double t_queued = now();
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    if (timing)
+        fprintf(stderr, "plan_create %d items: validate %.2f ms, alloc %.2f, queue copies+setups %.2f, sync %.2f\n", n_items,
+                t_valid - t_begin, t_alloc - t_valid, t_queued - t_alloc, now() - t_queued);
     if (err != hipSuccess) {
         sdr_epl_plan_destroy(e, p);
         return sdr_fail(err == hipErrorOutOfMemory ? SDR_ERR_NOMEM : SDR_ERR_HIP, "plan setup failed: %s",
@@ -766,7 +979,7 @@ int sdr_epl_batch(sdr_engine* e, const sdr_epl_item* items, int n_items, const d
                   double fs, double* out) {
     if (!out) return sdr_fail(SDR_ERR_INVALID, "out is NULL");
     sdr_epl_plan* p = nullptr;
-    if (int rc = plan_create_impl(e, items, n_items, spacing, n_taps, fs, true, &p)) return rc;
+    if (int rc = plan_create_impl(e, items, nullptr, n_items, spacing, n_taps, fs, true, &p)) return rc;
     int rc = sdr_epl_plan_run(e, p);
     if (!rc) rc = sdr_epl_plan_fetch(e, p, out);
     sdr_epl_plan_destroy(e, p);

@@ -26,14 +26,21 @@ def make_items(code_slot, n_samples, start_sample, carrier_hz, rem_carrier, rem_
 class EplPlan:
     """Items + outputs resident in HBM; run() only launches kernels (asynchronous)."""
 
-    def __init__(self, engine: "Engine", items: np.ndarray, spacing, fs: float):
+    def __init__(self, engine: "Engine", items, spacing, fs: float, device_items: int = 0, n_items: int = 0):
+        """items: the list (host array), or device_items: the address of n_items items in DEVICE memory
+        (sdr_epl_plan_create_dev: copied there and checked there)."""
         self._e = engine
         self._lib = _lib.load()
-        items = np.ascontiguousarray(items, dtype=EPL_ITEM_DTYPE)
         spacing = np.ascontiguousarray(spacing, dtype=np.float64)
-        self.n_items = len(items)
         self.n_taps = len(spacing)
         self._h = C.c_void_p()
+        if device_items:
+            self.n_items = int(n_items)
+            check(self._lib.sdr_epl_plan_create_dev(engine._h, C.c_void_p(int(device_items)), self.n_items, ptr(spacing),
+                                                    self.n_taps, float(fs), C.byref(self._h)))
+            return
+        items = np.ascontiguousarray(items, dtype=EPL_ITEM_DTYPE)
+        self.n_items = len(items)
         check(self._lib.sdr_epl_plan_create(engine._h, ptr(items), self.n_items, ptr(spacing), self.n_taps,
                                             float(fs), C.byref(self._h)))
 
@@ -250,6 +257,10 @@ class Engine:
         check(self._lib.sdr_epl_batch(self._h, ptr(items), len(items), ptr(spacing), len(spacing), float(fs),
                                       ptr(out)))
         return out
+
+    def epl_plan_dev(self, device_items: int, n_items: int, spacing, fs) -> EplPlan:
+        """A plan of n_items items that are already in device memory at address device_items."""
+        return EplPlan(self, None, spacing, fs, device_items=device_items, n_items=n_items)
 
     def epl_plan(self, items, spacing, fs) -> EplPlan:
         return EplPlan(self, items, spacing, fs)

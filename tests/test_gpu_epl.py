@@ -668,3 +668,96 @@ def test_plan_setups_made_on_the_device_equal_the_host_made_ones(engine, fs):
         ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(3 * int(slot[k]) + 2)), fs, f[k], rem_carrier[k], rem_code[k], step[k], spacing))
         scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 50.0), 2)
         assert np.max(np.abs(got[k] - ref) / scale) < 1e-9, (k,)
+
+
+def _hip():
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    return hip
+
+
+def test_long_lists_are_checked_on_the_device_like_short_ones_on_the_host(engine):
+    """sdr_epl_plan_create checks a list of 4096 items or more with one thread per item behind its upload (the host's walk
+    of 1.92 M items was most of what a plan cost) and a shorter one on the host, with ONE function for both: the same
+    variant for the same kind of list at 25 / 10 / 50 / 4 MHz, the same status and message for every kind of bad item
+    wherever it sits (the lowest bad index is the one reported), and a list handed over in device memory
+    (sdr_epl_plan_create_dev) gives the plan of the same list in host memory, bit for bit."""
+    import ctypes
+    from sydr_amd import SdrError
+    rng = np.random.default_rng(77)
+    cap = 1 << 20
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(rng.integers(-90, 90, 2 * cap).astype(np.int8), 0)
+    engine.code_slots(4)
+    for s in range(3):
+        engine.load_gps_code(s, s + 5)                       # (slot 3 stays empty)
+    spacing = (-0.5, 0.0, 0.5)
+
+    def some_items(fs, count):
+        step = (1.023e6 + rng.uniform(-4, 4, count)) / fs
+        rem_code = rng.uniform(0, step)
+        n = np.ceil((1023 - rem_code) / step).astype(np.int64)
+        return make_items(rng.integers(0, 3, count), n, rng.integers(0, cap - 60000, count), rng.uniform(-5000, 5000, count),
+                          rng.uniform(0, 6.28, count), rem_code, step)
+
+    for fs in (25e6, 10e6, 50e6, 4e6):
+        items = some_items(fs, 6000)
+        long_plan, short_plan = engine.epl_plan(items, spacing, fs), engine.epl_plan(items[:3000], spacing, fs)
+        try:
+            assert long_plan.variant == short_plan.variant, fs
+            long_plan.run()
+            short_plan.run()
+            assert long_plan.fetch()[:3000].tobytes() == short_plan.fetch().tobytes()
+        finally:
+            long_plan.close()
+            short_plan.close()
+    fs = 25e6
+    good = some_items(fs, 5000)
+    for field, value in (("code_slot", 3), ("code_slot", 9), ("code_slot", -1), ("n_samples", 0), ("n_samples", cap + 1),
+                         ("start_sample", -5), ("code_step", 0.0), ("code_step", float("nan")), ("rem_code", float("inf")),
+                         ("carrier_hz", float("nan")), ("rem_code", -30.0), ("code_step", 0.3)):
+        for where in (0, 2500, 4999):
+            bad = good.copy()
+            bad[field][where] = value
+            bad[field][min(4999, where + 7)] = value           # (a second one further on: the first is reported)
+            with pytest.raises(SdrError) as long_err:
+                engine.epl_plan(bad, spacing, fs)
+            with pytest.raises(SdrError) as short_err:
+                engine.epl_plan(bad[where:where + 1], spacing, fs)
+            assert f"item {where}:" in str(long_err.value), (field, value, where, str(long_err.value))
+            assert str(long_err.value).replace(f"item {where}:", "item 0:") == str(short_err.value)
+    # the list in device memory
+    hip = _hip()
+    items = some_items(fs, 5000)
+    d = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d), items.nbytes) == 0
+    try:
+        assert hip.hipMemcpy(d, items.ctypes.data_as(ctypes.c_void_p), items.nbytes, 1) == 0
+        on_dev, on_host = engine.epl_plan_dev(d.value, len(items), spacing, fs), engine.epl_plan(items, spacing, fs)
+        try:
+            assert on_dev.variant == on_host.variant and on_dev.variant & 3072
+            on_dev.run()
+            on_host.run()
+            assert on_dev.fetch().tobytes() == on_host.fetch().tobytes()
+        finally:
+            on_dev.close()
+            on_host.close()
+        bad = items.copy()
+        bad["n_samples"][1234] = 0
+        assert hip.hipMemcpy(d, bad.ctypes.data_as(ctypes.c_void_p), bad.nbytes, 1) == 0
+        with pytest.raises(SdrError) as err:
+            engine.epl_plan_dev(d.value, len(bad), spacing, fs)
+        assert "item 1234:" in str(err.value)
+        short = some_items(fs, 100)                                   # (a short list on the device goes the same way)
+        assert hip.hipMemcpy(d, short.ctypes.data_as(ctypes.c_void_p), short.nbytes, 1) == 0
+        on_dev = engine.epl_plan_dev(d.value, 100, spacing, fs)
+        try:
+            on_dev.run()
+            assert on_dev.fetch().tobytes() == engine.epl_batch(short, spacing, fs).tobytes()
+        finally:
+            on_dev.close()
+    finally:
+        hip.hipFree(d)
