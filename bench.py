@@ -882,13 +882,22 @@ def main():
             epochs_per_launch = ch_samples / max(1, n_launches) * len(items) / max(1.0, float(items["n_samples"].sum()))
             ran = kernel_of_variant(plan.variant, len(SPACING))
             result["roofline"]["kernel_variant"] = ran
+            import sydr_amd
+            build_id = sydr_amd.load().sdr_build_id().decode()
+            result["build_id"] = build_id
             if info.get("epl_kernel", "").replace(" ", "") != ran:
                 # the committed counters were taken on another instantiation: they say nothing about this run
                 result["roofline"]["traffic_note"] = (f"profiles/pmc_traffic.json holds counters of {info.get('epl_kernel')!r}, "
                                                       f"this run launched {ran!r}: no traffic figure")
                 info = {}
+            elif info.get("build_id") != build_id:
+                # ... or on a library built from other sources (the same template name can hide another kernel body)
+                result["roofline"]["traffic_note"] = (f"profiles/pmc_traffic.json was taken on build {info.get('build_id')!r}, "
+                                                      f"this library is build {build_id!r}: no traffic / instruction figures")
+                info = {}
             else:
-                result["roofline"]["traffic_source"] = {"file": info.get("source"), "git_head": info.get("git_head")}
+                result["roofline"]["traffic_source"] = {"file": info.get("source"), "git_head": info.get("git_head"),
+                                                        "build_id": info.get("build_id")}
             if info.get("epl_kernel_hbm_bytes_per_epoch"):   # counters are per channel-epoch (one workgroup each), scaled to this launch size
                 result["roofline"]["traffic"] = info["epl_kernel_hbm_bytes_per_epoch"] * epochs_per_launch
                 # the same bytes as a rate: what the memory system actually moves (the 32 channels share the stream
@@ -1034,7 +1043,11 @@ def acquisition_leg(eng, rf):
     pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            out["roofline"]["traffic"] = json.load(open(pmc)).get("pcps_hbm_bytes_per_call")
+            import sydr_amd
+            info = json.load(open(pmc))
+            if info.get("build_id") == sydr_amd.load().sdr_build_id().decode():     # (counters of THIS build only)
+                out["roofline"]["traffic"] = info.get("pcps_hbm_bytes_per_call")
+                out["roofline"]["traffic_over_algorithmic"] = info.get("pcps_hbm_bytes_per_call") / algo if info.get("pcps_hbm_bytes_per_call") else None
         except Exception:
             pass
     return out

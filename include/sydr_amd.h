@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SDR_ABI_VERSION 3
+#define SDR_ABI_VERSION 4   /* 4: + sdr_build_id, sdr_epl_plan_create_dev (additive) */
 
 typedef struct sdr_engine sdr_engine;
 
@@ -61,6 +61,9 @@ enum sdr_iq_format {
 /* ---------------------------------------------------------------- library */
 const char* sdr_last_error(void);
 int sdr_abi_version(void);
+/* First 16 hex digits of the SHA-256 over the library's sources as they were when it was built (the .hip / .h files of
+ * sydr_amd/csrc in name order, then this header): what a profile or a counter file names as the build it was taken on. */
+const char* sdr_build_id(void);
 /* Number of visible GPUs (0 on a CPU-only host; never an error there). */
 int sdr_device_count(int* n);
 

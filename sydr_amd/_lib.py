@@ -98,6 +98,7 @@ _VP = C.c_void_p
 _PROTOTYPES = {
     "sdr_last_error": (C.c_char_p, []),
     "sdr_abi_version": (C.c_int, []),
+    "sdr_build_id": (C.c_char_p, []),
     "sdr_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "sdr_engine_create": (C.c_int, [C.c_int, C.POINTER(_VP)]),
     "sdr_engine_destroy": (None, [_VP]),
@@ -151,7 +152,7 @@ _PROTOTYPES = {
     "sdr_epl_plan_run_range_on": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int]),
     "sdr_epl_plan_variant": (C.c_int, [_VP]),
 }
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -173,6 +174,19 @@ def load():
         raise ImportError("libsydr_amd.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def source_build_id() -> str:
+    """sdr_build_id() of a library built from the sources in the tree NOW (the Makefile's recipe): differs from the loaded
+    library's when that was built from other sources."""
+    import hashlib
+    src = os.path.join(_HERE, "csrc")
+    names = sorted(n for n in os.listdir(src) if (n.endswith(".hip") or n.endswith(".h")) and n != "build_id.h")
+    h = hashlib.sha256()
+    for n in names:
+        h.update(open(os.path.join(src, n), "rb").read())
+    h.update(open(os.path.join(os.path.dirname(_HERE), "include", "sydr_amd.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def exported_symbols():

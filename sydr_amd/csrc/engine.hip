@@ -1,5 +1,6 @@
 // Engine lifetime, error text, IQ ring in HBM, per-kernel hipEvent timing.
 #include "engine_internal.h"
+#include "build_id.h"
 
 #include <cstring>
 
@@ -226,6 +227,7 @@ int sdr_hbm_copy_rate(sdr_engine* e, int64_t n_bytes, int reps, double* gbps) {
 const char* sdr_last_error(void) { return g_last_error.c_str(); }
 
 int sdr_abi_version(void) { return SDR_ABI_VERSION; }
+const char* sdr_build_id(void) { return SDR_BUILD_ID; }
 
 int sdr_device_count(int* n) {
     if (!n) return sdr_fail(SDR_ERR_INVALID, "n is NULL");

@@ -6,6 +6,8 @@ TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+# the build the counters belong to (tools/summarize_pmc.py refuses them when the tree has moved on)
+(cd "$ROOT" && python3 -c "import sydr_amd; print(sydr_amd.load().sdr_build_id().decode())") > "$OUT/build_id.txt"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 20 --warmup 5 --cpu-seconds 2 --cpu-mp-seconds 3"   # the driver's command, short CPU legs
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_stats.log" 2>&1

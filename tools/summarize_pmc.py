@@ -18,14 +18,28 @@ import re
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
+force = "--force" in sys.argv[3:]
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PCPS = ("fft4_rows_kernel", "fft4_cols_kernel", "fast25k", "fft_pass_kernel", "argmax", "ratio_kernel", "peak_", "second_peak",
+# The counters belong to the library that was profiled (build_id.txt, written by tools/profile_bench.sh from sdr_build_id()):
+# if the sources in the tree hash to something else now -- a kernel was edited after the profile was taken -- the summary would
+# describe another build than the one bench.py runs, so nothing is written.
+sys.path.insert(0, repo)
+from sydr_amd import _lib as _sydr_lib
+try:
+    profiled_build = open(os.path.join(src, "build_id.txt")).read().strip()
+except OSError:
+    profiled_build = ""
+tree_build = _sydr_lib.source_build_id()
+if profiled_build != tree_build and not force:
+    sys.exit(f"summarize_pmc: the profile in {src} was taken on build {profiled_build or '(unknown)'}, the sources in the tree are "
+             f"build {tree_build}: re-take the profile (tools/profile_round.sh) instead of summarising a stale one (--force overrides)")
+PCPS = ("fft4_rows_kernel", "fft4_cols_kernel", "fast25k", "fused25k", "fft_pass_kernel", "argmax", "ratio_kernel", "peak_", "second_peak",
         "chirp", "upsample_batch_kernel", "mix_", "twiddle_kernel")
 
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"((?:fast25k::)?[A-Za-z0-9_]+)(<[^>]*>)?", name)
+    m = re.match(r"((?:fast25k::|fused25k::|fastn::)?[A-Za-z0-9_]+)(<[^>]*>)?", name)
     base, targs = m.group(1), m.group(2) or ""
     if base in ("epl_kernel", "track_kernel", "fft4_rows_kernel", "fft4_cols_kernel", "fft_pass_kernel"):
         return base + targs.replace(", ", ",")
@@ -60,7 +74,7 @@ try:
 except OSError:
     head, dirty = "", False
 info = {"correction": "FETCH_SIZE doubled (gfx950, 16-B/lane streaming reads)", "source": f"profiles/{tag}_pmc_summary.csv",
-        "git_head": head + ("+uncommitted" if dirty else ""),
+        "git_head": head + ("+uncommitted" if dirty else ""), "build_id": profiled_build,
         "note": "counters belong to the kernel VARIANT named here; bench.py prints them only for a run of that variant"}
 # the headline launch: ci8, 3 taps; the full 32000-epoch launches are the dispatches with the most waves
 head = [k for k in agg if k.startswith("epl_kernel<0,3,")]
@@ -120,7 +134,7 @@ def pcps_calls(counter):
                 continue
             cur.append((k, float(r["Counter_Value"])))
             if k == "ratio_kernel":
-                if any(name.startswith("fast25k") for name, _ in cur):
+                if any(name.startswith(("fast25k", "fused25k")) for name, _ in cur):
                     calls += 1
                     for name, v in cur:
                         per_kernel[name] += v
@@ -157,7 +171,7 @@ if os.path.exists(log) and os.path.exists(stats):
     line = [l for l in open(log) if l.startswith("{")][-1]
     rec = json.loads(line)
     total_ns = sum(float(r["TotalDurationNs"]) for r in csv.DictReader(open(stats))
-                   if any(p in r["Name"] for p in PCPS) or "fast25k" in r["Name"])
+                   if any(p in r["Name"] for p in PCPS))
     rec["rocprof_kernel_ms_per_call"] = total_ns / 1e6 / rec["calls"]
     rec["agreement"] = rec["rocprof_kernel_ms_per_call"] / rec["hip_event_kernel_ms_per_call"]
     json.dump(rec, open(os.path.join(prof, f"{tag}_pcps_one_stream.json"), "w"), indent=1)
