@@ -281,6 +281,73 @@ def verify_across_ranks(eng, dist, torch, rank, local_rank, world, all_sats, min
     return record
 
 
+def rates_leg(eng, seconds=2.0):
+    """E/P/L throughput of 32 channels x 3 taps at the sampling rates a receiver front end is likely to have
+    (gnsssignal.py:62-70 takes any fs; config/receiver.ini:18): which kernel variant a plan of that rate gets and what it
+    reaches of the roof by SURVEY 8(d)'s bytes -- one launch per pass over a `seconds` stream, outputs of the first
+    epochs checked against the oracle."""
+    from oracle import sydr_oracle as orc
+    from sydr_amd.engine import FMT_CI8
+    out = []
+    for fs in (4e6, 10e6, 12e6, 16.368e6, 20e6, 25e6, 32e6, 50e6):
+        total = int(seconds * fs) // 8 * 8
+        eng.iq_alloc(total, FMT_CI8)
+        eng.code_slots(N_CH)
+        sats = satellites(N_CH, seed=20260020)
+        for k, sat in enumerate(sats):
+            eng.load_gps_code(k, sat["prn"])
+        eng.iq_synth(sats, fs, 12.0, 20260020, 0, total)
+        items, n_epochs = truth_items(sats, fs, total)
+        plan = eng.epl_plan(items, SPACING, fs)
+        n_run = n_epochs * N_CH
+        for _ in range(40):                                    # (clocks: tools/epl_ramp.py)
+            plan.run(0, n_run)
+        eng.sync()
+        eng.prof_reset()
+        eng.prof_enable(True)
+        steps = 20
+        for _ in range(steps):
+            plan.run(0, n_run)
+        eng.sync()
+        eng.prof_enable(False)
+        kern_ms, launches = eng.prof_read("epl_kernel")
+        eng.prof_reset()
+        ch_samples = float(items["n_samples"][:n_run].sum())
+        avg_s = kern_ms / max(1, launches) * 1e-3
+        got = plan.fetch()
+        variant = plan.variant
+        plan.close()
+        n_chk = N_CH * 2
+        hi = int((items["start_sample"][:n_chk] + items["n_samples"][:n_chk]).max())
+        rf = orc.iq_to_complex(eng.iq_download(hi, 0))
+        err = 0.0
+        for k in range(n_chk):
+            it = items[k]
+            a, n = int(it["start_sample"]), int(it["n_samples"])
+            ref = np.array(orc.epl(rf[a:a + n], orc.pad_code(orc.gold_code(sats[int(it["code_slot"])]["prn"])), fs, float(it["carrier_hz"]),
+                                   float(it["rem_carrier"]), float(it["rem_code"]), float(it["code_step"]), SPACING))
+            scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), 1.0), 2)
+            err = max(err, float(np.max(np.abs(got[k] - ref) / scale)))
+        if err > 1e-6:
+            raise SystemExit(f"GPU/oracle mismatch in the rates leg at {fs:g} Hz: {err:.3e}")
+        w = variant & 255
+        family = "two chips per lane, straight line" if (variant >> 13) & 3 else ("half-chip view, " if variant & 65536 else "")
+        if not (variant >> 13) & 3:
+            family += ("one chip per lane, straight line (compile-time block length and tap positions)" if (variant & 0xF00) == 0xC00 else
+                       "one chip per lane, whole-chip taps" if variant & 4096 else
+                       "one chip per lane, compile-time block length" if w >= 50 else
+                       "one chip per lane, run-time positions" if w >= 26 else
+                       f"{w}-sample boundary groups" if w else "per sample")
+        out.append({"fs_hz": fs, "samples_per_chip": fs / CODE_RATE, "Msamples_per_s": ch_samples / N_CH / avg_s / 1e6 if launches else 0.0,
+                    "x_realtime": ch_samples / N_CH / avg_s / fs if launches else 0.0, "kernel_variant": kernel_of_variant(variant & 0xFFFF, len(SPACING)),
+                    "correlator": family, "plan_variant": int(variant),
+                    "roofline_frac": 2.0 * ch_samples / avg_s / 1e9 / HBM_PEAK_GBS if launches else 0.0,
+                    "max_rel_err_gpu_vs_oracle": err})
+    return {"config": {"workload": f"32 channels, E/P/L +-0.5 chip, ci8, {seconds:g} s stream per rate, one launch per pass (kernel time "
+                                   "from HIP events on the launch stream); roofline_frac = 2 B per channel-sample / 8 TB/s"},
+            "rates": out}
+
+
 def ref_config_leg(eng, cpu_seconds=4.0):
     """The reference's own shipped configuration (config/receiver.ini:18-20: 10 MHz, 8-bit I/Q;
     config/channels/channel_GPS_L1CA_kaplan.ini:6-10: PCPS with a 300 Hz grid, 1 x 10 ms non-coherent; taps +-0.5 chip),
@@ -345,8 +412,8 @@ def ref_config_leg(eng, cpu_seconds=4.0):
                 "kernel_variant": kernel_of_variant(variant, len(SPACING)),
                 "roofline": {"bound": "hbm", "achieved": 2.0 * ch_samples / avg_s / 1e9 if launches else 0.0, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": 2.0 * ch_samples / avg_s / 1e9 / HBM_PEAK_GBS if launches else 0.0,
-                             "traffic": None, "kernel": "epl_kernel", "avg_launch_ms": avg_s * 1e3, "launches": int(launches),
-                             "algorithmic_bytes_per_launch": 2.0 * ch_samples},
+                             "traffic": None, "kernel": kernel_of_variant(variant, len(SPACING)), "avg_launch_ms": avg_s * 1e3,
+                             "launches": int(launches), "algorithmic_bytes_per_launch": 2.0 * ch_samples},
                 "cpu_baseline": {"value": float(items["n_samples"][:done].sum()) / N_CH / cpu_dt / 1e6, "unit": "Msamples/s",
                                  "cores": 1, "kind": "port", "sample": f"first {done} channel-epochs of the same stream "
                                  f"through oracle/sydr_oracle.py:epl, {cpu_dt:.1f} s", "max_rel_err_gpu_vs_oracle": err}}
@@ -714,6 +781,7 @@ def main():
     ap.add_argument("--no-per-tick", action="store_true")
     ap.add_argument("--no-multignss", action="store_true")
     ap.add_argument("--no-ref-config", action="store_true")
+    ap.add_argument("--no-rates", action="store_true", help="skip the E/P/L leg over the other sampling rates")
     ap.add_argument("--cpu-mp-seconds", type=float, default=10.0, help="budget of the all-cores CPU baseline (0: skip)")
     ap.add_argument("--closed-loop-epochs", type=int, default=2000)
     args = ap.parse_args()
@@ -955,6 +1023,8 @@ def main():
         result["closed_loop"] = closed_loop_leg(eng, items, min(n_epochs, args.closed_loop_epochs))
         result["closed_loop_dense"] = closed_loop_leg(eng, items, min(n_epochs, args.closed_loop_epochs, 1000), n_ch=768)
     plan.close()
+    if rank == 0 and world == 1 and not args.no_rates:
+        result["rates"] = rates_leg(eng)
     if rank == 0 and world == 1 and not args.no_per_tick:
         result["per_tick"] = per_tick_leg(eng)
         result["per_tick_readahead"] = per_tick_leg(eng, read_ahead=50)

@@ -34,7 +34,7 @@ namespace sdr {
 
 constexpr int kChipMax = 26;                      // samples a lane's block may hold (k = 0..25)
 constexpr double kChipMinCodeStep = 1.0 / 25.9;   // blocks of at most 26 samples
-constexpr double kChipMaxCodeStep = 1.0 / 16.0;   // below ~16 samples per chip the 16-sample boundary variant is as good
+constexpr double kChipMaxCodeStep = 1.0 / 15.5;   // (16.368 MHz is 16.0 samples per chip: Doppler must not decide the kernel; 31-32 MHz through the half-chip view)
 constexpr int kChipRawDwords = 13;                // 52 bytes: 26 samples
 template <int NT>
 constexpr int chip_strip_slots() { return 2 * NT + 1; }   // double2 slots per lane (odd multiple of 16 B: conflict-free)

@@ -544,7 +544,10 @@ static int variant_of(const sdr_engine* e, const ItemRules& r, const double* spa
     const bool boundary_ok = min_step >= sdr::kFastMinCodeStep && r.scale * e->lut_stride < sdr::kFastMaxLutWords;
     int wide = !boundary_ok ? 0 : (max_step <= sdr::kFastMaxCodeStep ? 16 : (max_step <= sdr::kFastMaxCodeStep8 ? 8 : 0));
     // every item inside the chip-aligned variant's range (ci8 ring): lanes own whole chips instead of 16 samples
-    if (boundary_ok && e->iq_fmt == SDR_FMT_CI8 && min_step >= sdr::kChipMinCodeStep && max_step <= sdr::kChipMaxCodeStep &&
+    // (the half-chip view only where a half chip holds 16 samples or more: at 31-32 MHz -- 15.6 per half chip -- the
+    // 16-sample boundary groups of the plain list were measured faster, 0.47 against 0.37 of the roof)
+    const double chip_max_step = r.scale == 2.0 ? 1.0 / 16.0 : sdr::kChipMaxCodeStep;
+    if (boundary_ok && e->iq_fmt == SDR_FMT_CI8 && min_step >= sdr::kChipMinCodeStep && max_step <= chip_max_step &&
         !e->epl_no_chip)
         wide = sdr::kChipMax + (all_m24 ? 24 : 0) +
                ((all_m24 && all_s12 && !e->epl_no_split) ? kVariantKS12 : 0) +
