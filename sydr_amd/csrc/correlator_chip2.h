@@ -83,6 +83,9 @@ __host__ __device__ inline bool chipn_setup(int n, int64_t start_sample, int64_t
     constexpr int CH = Shape::CH;
     S = ChipNSetup<P...>{};
     S.base = -1;
+    // (4 .. 64 samples per chip, far around anything the shapes cover: a step outside it -- a denormal passes the list's
+    // "positive and finite" -- must not reach the fixed-point conversions below: undefined on the host, `make check-sanitize`)
+    if (!(code_step >= 1.0 / 64.0 && code_step <= 0.25) || n < 1) return false;
     S.dphi = carrier_step(carrier_hz, fs);
     double inv[3];
     const double nd = (double)n;

@@ -27,6 +27,7 @@
 #include "correlator.h"
 #include "correlator_chip.h"
 #include "correlator_chip2.h"
+#include "epl_items.h"
 
 #ifdef SDR_TRACE_WG
 // Debug build only (tools/wg_trace.py): per-workgroup start/end clock and hardware id.
@@ -396,69 +397,6 @@ __global__ __launch_bounds__(256) void chipn_setup_kernel(const sdr_epl_item* __
 // allows (the kernel variant) follows from every item.  One function per item for both sides: the host walks short lists
 // (one call per EPL(): latency), one THREAD per item checks long ones behind their upload (1.92 M items of a 60 s x 32
 // channel plan took the host 20-30 ms of the 34 ms a plan cost; the launch takes ~0.1 ms).
-// scale = 2: the variant is chosen for the half-chip view (2*rem_code, 2*code_step, 2*spacing against tables of twice the length).
-struct ItemRules {
-    int n_slots, lut_stride, n_taps;
-    int64_t iq_capacity;
-    double scale, smin, smax, s_anchor, sp0, sp2;
-    bool want_s12;
-};
-struct ItemStats {                 // of the items seen so far
-    int first_bad, bad_code;       // lowest index of an invalid item (INT_MAX: none) and what is wrong with it
-    int maxlen;
-    unsigned long long max_step_bits, min_step_bits;   // (positive doubles order as integers)
-    int all_m24, all_s12;
-};
-enum ItemError { ITEM_OK = 0, ITEM_SLOT, ITEM_SAMPLES, ITEM_START, ITEM_NCO, ITEM_REPLICA };
-
-// What is wrong with one item (ITEM_OK: nothing) and its share of the list's statistics.  lo / hi: its code phase range.
-__host__ __device__ inline int check_item(const sdr_epl_item& it, const ItemRules& r, const int32_t* code_len, int& maxlen,
-                                          double& step_scaled, bool& m24, bool& s12, double& lo, double& hi) {
-    // (before anything is derived from them: a zero n_samples or a NaN code_step would be cast to an integer below)
-    if (it.code_slot < 0 || it.code_slot >= r.n_slots || code_len[it.code_slot] <= 0) return ITEM_SLOT;
-    if (it.n_samples <= 0 || it.n_samples > r.iq_capacity) return ITEM_SAMPLES;
-    if (it.start_sample < 0) return ITEM_START;
-    // (finite: x - x is 0 for every finite x and NaN otherwise -- one spelling for both sides)
-    auto finite = [](double x) { return x - x == 0.0; };
-    if (!(it.code_step > 0.0) || !finite(it.code_step) || !finite(it.rem_code) || !finite(it.rem_carrier) || !finite(it.carrier_hz))
-        return ITEM_NCO;
-    {   // samples per chip of the anchor tap's np.linspace step, exactly as the kernel derives it (correlator_chip.h)
-        const double two32 = 4294967296.0;
-        const double nd = (double)it.n_samples;
-        auto line = [&](double spc, double& sh, double& inv) {
-            sh = r.scale * it.rem_code + spc;
-            double stop = (r.scale * it.code_step) * nd;
-            stop = stop + sh;
-            inv = 1.0 / ((stop - sh) / nd);
-        };
-        double sh, inv;
-        line(r.s_anchor, sh, inv);
-        const bool in_range = inv >= 1.0 && inv < 1024.0;   // (samples per chip; false for NaN / Inf as well)
-        const int64_t tfx = in_range ? (int64_t)rint(inv * two32) : 0;
-        m24 = (int)(tfx >> 32) == 24;
-        s12 = r.want_s12 && m24;
-        for (int t = 0; s12 && t < 3; t += 2) {
-            // the kernel's own derivation of the switch offset (a Q32.32 sample count); its reciprocal is a Newton
-            // step, not a division, so a margin of 2^-10 sample keeps the two from disagreeing about the integer part
-            double sht, invt;
-            line(r.scale * (t ? r.sp2 : r.sp0), sht, invt);
-            const int64_t ufx = (int64_t)floor(-sh * inv * two32), ut = (int64_t)floor(-sht * invt * two32);
-            const int j = (int)ceil(sht - sh) - 1;
-            int64_t d = (ut - ufx) + (int64_t)(1 + j) * tfx;
-            if (d < 0) d += tfx; else if (d >= tfx) d -= tfx;
-            const int64_t margin = (int64_t)1 << 22;
-            s12 = d >= ((int64_t)12 << 32) + margin && d < ((int64_t)13 << 32) - margin;
-        }
-    }
-    step_scaled = r.scale * it.code_step;
-    lo = ceil(it.rem_code + r.smin);
-    hi = ceil(it.code_step * (double)it.n_samples + it.rem_code + r.smax);
-    const int reach = r.lut_stride - SDR_LUT_PAD - 2;  // largest padded index the staged row serves
-    if (lo < -(double)SDR_LUT_PAD || hi > (double)reach) return ITEM_REPLICA;
-    maxlen = (int)hi;
-    return ITEM_OK;
-}
-
 __device__ __forceinline__ unsigned long long dbits(double x) { return (unsigned long long)__double_as_longlong(x); }
 
 // Two rule sets at once (the list as it is and its half-chip view): one upload, one launch, one read-back.

@@ -33,7 +33,9 @@ __host__ __device__ __forceinline__ void sincos_reduced(double ph, double* s, do
     pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
     pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
     const double cs = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
-    const int q = (int)k;
+    // the quadrant k mod 4 without converting k itself (a finite but absurd phase -- |ph| > 3.4e9 rad -- would overflow the
+    // conversion: undefined on the host, found by `make check-sanitize`; same bits as (int)k & 3 wherever that is defined)
+    const int q = (int)(k - 4.0 * floor(k * 0.25));
     const double a = (q & 1) ? cs : sn;
     const double b = (q & 1) ? sn : cs;
     *s = (q & 2) ? -a : a;
