@@ -281,6 +281,17 @@ def verify_across_ranks(eng, dist, torch, rank, local_rank, world, all_sats, min
     return record
 
 
+def counters_of_this_build():
+    """profiles/pmc_traffic.json when it was taken on the library this process runs (sdr_build_id), else {}."""
+    pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    try:
+        import sydr_amd
+        info = json.load(open(pmc))
+        return info if info.get("build_id") == sydr_amd.load().sdr_build_id().decode() else {}
+    except Exception:
+        return {}
+
+
 def rates_leg(eng, seconds=2.0):
     """E/P/L throughput of 32 channels x 3 taps at the sampling rates a receiver front end is likely to have
     (gnsssignal.py:62-70 takes any fs; config/receiver.ini:18): which kernel variant a plan of that rate gets and what it
@@ -417,6 +428,10 @@ def ref_config_leg(eng, cpu_seconds=4.0):
                 "cpu_baseline": {"value": float(items["n_samples"][:done].sum()) / N_CH / cpu_dt / 1e6, "unit": "Msamples/s",
                                  "cores": 1, "kind": "port", "sample": f"first {done} channel-epochs of the same stream "
                                  f"through oracle/sydr_oracle.py:epl, {cpu_dt:.1f} s", "max_rel_err_gpu_vs_oracle": err}}
+    info = counters_of_this_build()
+    if info.get("epl2_kernel", "").replace(" ", "") == tracking["kernel_variant"] and info.get("epl2_kernel_hbm_bytes_per_epoch"):
+        tracking["roofline"]["traffic"] = info["epl2_kernel_hbm_bytes_per_epoch"] * n_run      # (counters per channel-epoch x this launch)
+        tracking["roofline"]["traffic_over_algorithmic"] = tracking["roofline"]["traffic"] / (2.0 * ch_samples)
     # acquisition as the shipped ini asks for it: +-5 kHz @ 300 Hz (34 bins), 1 ms coherent x 10 non-coherent
     slots = np.arange(N_CH)
     rng_hz, step_hz, coh, noncoh = 5000.0, 300.0, 1, 10
@@ -455,6 +470,9 @@ def ref_config_leg(eng, cpu_seconds=4.0):
                                 "kernel": "pcps_* (all kernels of one sdr_pcps call)", "algorithmic_bytes_per_call": algo},
                    "cpu_baseline": {"value": cpu_ms, "unit": "ms/PRN", "cores": 1, "kind": "port",
                                     "sample": "2 PRNs x 34 bins x 10 blocks through oracle/sydr_oracle.py:pcps_map"}}
+    if info.get("pcps_10mhz_hbm_bytes_per_call"):
+        acquisition["roofline"]["traffic"] = info["pcps_10mhz_hbm_bytes_per_call"]
+        acquisition["roofline"]["traffic_over_algorithmic"] = info["pcps_10mhz_hbm_bytes_per_call"] / algo
     return {"config": {"workload": "the reference's shipped configuration: fs=10 MHz ci8 (config/receiver.ini:18-20), 32 channels, "
                                    "E/P/L +-0.5 chip, 20 s stream in one launch per pass; PCPS +-5 kHz @ 300 Hz (34 bins), "
                                    "1 ms x 10 non-coherent (channel_GPS_L1CA_kaplan.ini:6-10), code spectra cached between calls"},
@@ -699,7 +717,8 @@ def multignss_workload(args, rank, local_rank, world, torch, dist, eng=None, emi
                                  "ms_total_32_prn": acq_ms, "kernel_ms_32_prn": k_ms, "peaks_match_oracle": True,
                                  "roofline": {"bound": "hbm", "achieved": algo / (k_ms * 1e-3) / 1e9 if k_ms else 0.0, "peak": HBM_PEAK_GBS,
                                               "unit": "GB/s", "frac": algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else 0.0,
-                                              "traffic": None, "kernel": "pcps_* (general four-step kernels)",
+                                              "traffic": counters_of_this_build().get("pcps_50mhz_hbm_bytes_per_call"),
+                                              "kernel": "pcps_* (all kernels of one sdr_pcps call: register-resident 250 x 200)",
                                               "algorithmic_bytes_per_call": algo}}
     if rank == 0 and world == 1 and not args.no_closed_loop:
         result["closed_loop"] = closed_loop_multignss_leg(eng, gps_items[:n_gps], e1_items[:n_e1], fs, taps,

@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 20 --warmup 5 --cpu-seconds 2 --cpu-mp-seconds 3"   # the driver's command, short CPU legs
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_stats.log" 2>&1
-PARGS="--steps 2 --warmup 1 --stream-seconds 6 --cpu-seconds 0.2 --cpu-mp-seconds 0 --no-closed-loop --no-per-tick --no-ref-config --no-rates"
+PARGS="--steps 2 --warmup 1 --stream-seconds 6 --cpu-seconds 0.2 --cpu-mp-seconds 0 --no-closed-loop --no-per-tick --no-rates"   # (the ref_config and multignss legs run: their kernels get counters too)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" $PARGS > "$OUT/bench_pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" $PARGS > "$OUT/bench_pmc_write.log" 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- python3 "$ROOT/bench.py" $PARGS > "$OUT/bench_pmc_sq.log" 2>&1

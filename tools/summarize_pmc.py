@@ -33,7 +33,7 @@ tree_build = _sydr_lib.source_build_id()
 if profiled_build != tree_build and not force:
     sys.exit(f"summarize_pmc: the profile in {src} was taken on build {profiled_build or '(unknown)'}, the sources in the tree are "
              f"build {tree_build}: re-take the profile (tools/profile_round.sh) instead of summarising a stale one (--force overrides)")
-PCPS = ("fft4_rows_kernel", "fft4_cols_kernel", "fast25k", "fused25k", "fft_pass_kernel", "argmax", "ratio_kernel", "peak_", "second_peak",
+PCPS = ("fft4_rows_kernel", "fft4_cols_kernel", "fast25k", "fused25k", "fastn::", "mag_acc_kernel", "fft_pass_kernel", "argmax", "ratio_kernel", "peak_", "second_peak",
         "chirp", "upsample_batch_kernel", "mix_", "twiddle_kernel")
 
 
@@ -41,7 +41,8 @@ def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     m = re.match(r"((?:fast25k::|fused25k::|fastn::)?[A-Za-z0-9_]+)(<[^>]*>)?", name)
     base, targs = m.group(1), m.group(2) or ""
-    if base in ("epl_kernel", "track_kernel", "fft4_rows_kernel", "fft4_cols_kernel", "fft_pass_kernel"):
+    if base in ("epl_kernel", "epl2_kernel", "track_kernel", "fft4_rows_kernel", "fft4_cols_kernel", "fft_pass_kernel", "fastn::cols_kernel",
+                "fastn::rows_kernel"):
         return base + targs.replace(", ", ",")
     return base[:48]
 
@@ -122,7 +123,7 @@ if multi:
 # The acquisition figure: the kernels of ONE sdr_pcps call of the headline search (N = 25 000: the calls that contain a
 # fast25k:: kernel -- the bench also runs searches at other rates, which share the small kernels).  Dispatches are walked
 # in order per counter pass; a call ends with its one ratio_kernel dispatch.
-def pcps_calls(counter):
+def pcps_calls(counter, marker=("fast25k", "fused25k")):
     per_kernel, calls = collections.defaultdict(float), 0
     for path in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
         rows_ = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
@@ -134,7 +135,7 @@ def pcps_calls(counter):
                 continue
             cur.append((k, float(r["Counter_Value"])))
             if k == "ratio_kernel":
-                if any(name.startswith(("fast25k", "fused25k")) for name, _ in cur):
+                if any(name.startswith(marker) for name, _ in cur):
                     calls += 1
                     for name, v in cur:
                         per_kernel[name] += v
@@ -150,6 +151,25 @@ if calls and calls_w:
     total = sum(v["read"] + v["write"] for v in per_kernel.values())
     info.update({"pcps_hbm_bytes_per_call": total, "pcps_calls_profiled": calls, "pcps_per_kernel": per_kernel,
                  "pcps_workload": "sdr_pcps: 32 PRNs x 41 bins x 25000 samples, no map (1.05e9 algorithmic bytes)"})
+# ... and of the searches at the other rates bench.py runs (their register-resident kernels carry N1 = N / 200 as a template
+# argument: 50 -> the reference's shipped 10 MHz, 250 -> 50 MHz)
+for marker, key, what in ((("fastn::cols_kernel<50,",), "pcps_10mhz", "ref_config leg: 32 PRNs x 34 bins x 10 blocks x 10000 samples, map accumulated"),
+                          (("fastn::cols_kernel<250,",), "pcps_50mhz", "multignss leg: 32 PRNs x 41 bins x 50000 samples, no map")):
+    f_k, c_f = pcps_calls("FETCH_SIZE", marker)
+    w_k, c_w = pcps_calls("WRITE_SIZE", marker)
+    if c_f and c_w:
+        info[f"{key}_hbm_bytes_per_call"] = sum(2 * v * 1024 / c_f for v in f_k.values()) + sum(v * 1024 / c_w for v in w_k.values())
+        info[f"{key}_calls_profiled"] = c_f
+        info[f"{key}_workload"] = what
+# the two-chips-per-lane kernel of the ref_config tracking leg (one single-wave workgroup per channel-epoch)
+two = [k for k in agg if k.startswith("epl2_kernel<") and agg[k].get("FETCH_SIZE") and agg[k].get("WRITE_SIZE") and agg[k].get("SQ_WAVES")]
+if two:
+    k = max(two, key=lambda k: mean(agg[k]["SQ_WAVES"]))
+    m = agg[k]
+    big = lambda v: mean([x for x in v if x >= 0.5 * max(v)])
+    info.update({"epl2_kernel": k, "epl2_kernel_hbm_bytes_per_epoch": (2 * big(m["FETCH_SIZE"]) + big(m["WRITE_SIZE"])) * 1024 / big(m["SQ_WAVES"])})
+    if m.get("SQ_INSTS_VALU"):
+        info["epl2_kernel_valu_insts_per_epoch"] = big(m["SQ_INSTS_VALU"]) / big(m["SQ_WAVES"])
 json.dump(info, open(os.path.join(repo, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(info, indent=1))
 
