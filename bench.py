@@ -198,8 +198,8 @@ def kernel_of_variant(variant, n_taps, waves_per_group=1):
     w = variant & 255
     if (variant >> 13) & 3:                                  # two chips per lane (correlator_chip2.h)
         return "epl2_kernel<" + {1: "4,9,14,19", 2: "5,11,17,23"}[(variant >> 13) & 3] + ">"
-    km = 24 if w >= 50 else 0
-    ks = 12 if (variant & 0xF00) == 0xC00 else 0
+    km = w - 26 if w > 26 else 0
+    ks = (variant & 0xF00) >> 8
     ki = 1 if variant & 4096 else 0
     base = 26 if w >= 26 else w
     return f"epl_kernel<0,{n_taps},{base},{km},{waves_per_group},{ks},{ki}>"
@@ -344,9 +344,9 @@ def rates_leg(eng, seconds=2.0):
         w = variant & 255
         family = "two chips per lane, straight line" if (variant >> 13) & 3 else ("half-chip view, " if variant & 65536 else "")
         if not (variant >> 13) & 3:
-            family += ("one chip per lane, straight line (compile-time block length and tap positions)" if (variant & 0xF00) == 0xC00 else
+            family += ("one chip per lane, straight line (compile-time block length and tap positions)" if (variant & 0xF00) else
                        "one chip per lane, whole-chip taps" if variant & 4096 else
-                       "one chip per lane, compile-time block length" if w >= 50 else
+                       "one chip per lane, compile-time block length" if w > 26 else
                        "one chip per lane, run-time positions" if w >= 26 else
                        f"{w}-sample boundary groups" if w else "per sample")
         out.append({"fs_hz": fs, "samples_per_chip": fs / CODE_RATE, "Msamples_per_s": ch_samples / N_CH / avg_s / 1e6 if launches else 0.0,

@@ -168,23 +168,28 @@ __host__ __device__ __forceinline__ void chip_geometry(int n, const double* shif
 // - 0 samples (correlate_epoch_chip).  Evaluated by the host with the kernels' own sincos_reduced -- fused multiply-adds
 // and exact roundings on both sides, i.e. the same bits a wave would get -- and the same order of additions as the
 // wave's DPP prefix sum.
-constexpr int kStaticHalf = 13;                 // KS + 1 = (KM + 2) / 2 for KM = 24, KS = 12
+constexpr int kStaticHalf = 13;                 // the longest half block a straight-line kernel sums: KS + 1 = (KM + 2) / 2 for KM = 24, KS = 12
+// The half block of a straight-line geometry -- samples 0 .. KS (taps switching inside the block) or (KM + 2) / 2 (whole-chip
+// taps) -- and the shortest sum whose share of the conversion's offset is kept: KM - half samples (the second half up to
+// the M-th sample), then + 1, + 2.
+constexpr int chip_half(int KM, int KS, int KI) { return KI != 0 ? (KM + 2) / 2 : KS + 1; }
 struct ChipRot {
     double urc[kStaticHalf + 1], urs[kStaticHalf + 1];
     double rd0c, rd0s, rd1c, rd1s;
     double biasc[3], biass[3];
 };
-__host__ __device__ inline void chip_rotations(double dphi, int Dmin, ChipRot& r) {
+// half: chip_half() of the kernel's geometry; cmin = KM - half.
+__host__ __device__ inline void chip_rotations(double dphi, int Dmin, ChipRot& r, int half = kStaticHalf, int cmin = kStaticHalf - 2) {
     double cs[16], sn[16];
     for (int k = 0; k < 16; ++k) sincos_reduced(-(double)k * dphi, &sn[k], &cs[k]);
-    for (int k = 1; k <= kStaticHalf; ++k) r.urc[k] = cs[k], r.urs[k] = sn[k];
+    for (int k = 1; k <= half; ++k) r.urc[k] = cs[k], r.urs[k] = sn[k];
     r.urc[0] = 1.0, r.urs[0] = 0.0;
     sincos_reduced(-(double)Dmin * dphi, &r.rd0s, &r.rd0c);
     sincos_reduced(-(double)(Dmin + 1) * dphi, &r.rd1s, &r.rd1c);
     for (int st = 1; st < 16; st <<= 1)          // inclusive prefix sums as a row of 16 lanes forms them (row_shr:1, 2, 4, 8)
         for (int l = 15; l >= st; --l) cs[l] += cs[l - st], sn[l] += sn[l - st];
     for (int i = 0; i < 3; ++i) {
-        const int l = kStaticHalf - 3 + i;
+        const int l = cmin + i - 1;                 // (a sum of cmin + i samples: rotations 0 .. l)
         const double re = cs[l] - sn[l], im = cs[l] + sn[l];
         r.biasc[i] = re * 4224.0, r.biass[i] = im * 4224.0;
     }
@@ -202,7 +207,7 @@ struct ChipSetup {
 
 // ... and how one is made (one THREAD per item of a plan: epl.hip's chip_setup_kernel; the host builds of the tests).
 // stride: the lanes that share an epoch (a lane's blocks are that many chips apart).
-template <int NT, int KS, int KI>
+template <int NT, int KM, int KS, int KI>
 __host__ __device__ inline void chip_setup(int n, int64_t start_sample, int64_t capacity, double carrier_hz, double rem_code,
                                            double code_step, const double* spacing, double fs, int stride, ChipSetup<NT>& S) {
     S = ChipSetup<NT>{};
@@ -221,8 +226,8 @@ __host__ __device__ inline void chip_setup(int n, int64_t start_sample, int64_t 
     const bool applies = code_step >= kChipMinCodeStep && code_step <= kChipMaxCodeStep && base + n + 32 <= capacity;   // chip_variant_applies()
     S.base = applies ? base : -1;
     if (applies) {
-        chip_geometry<NT, 24, KS, KI>(n, S.shift, S.step, S.inv_step, S.g);
-        chip_rotations(S.dphi, (int)(((int64_t)stride * S.g.Tfx) >> 32), S.r);
+        chip_geometry<NT, KM, KS, KI>(n, S.shift, S.step, S.inv_step, S.g);
+        chip_rotations(S.dphi, (int)(((int64_t)stride * S.g.Tfx) >> 32), S.r, chip_half(KM, KS, KI), KM - chip_half(KM, KS, KI));
     }
 }
 
@@ -297,7 +302,7 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
     // k = 1 .. KS + 1 are needed and they fit in scalar registers -- no LDS reads in the sample loop at all)
     static_assert(!(KS != 0 && KI != 0), "either the taps switch inside the block (KS) or with it (KI)");
     constexpr bool kStatic = KM != 0 && (KS != 0 || KI != 0);
-    constexpr int kHalf = KI != 0 ? (KM + 2) / 2 : KS + 1;
+    constexpr int kHalf = chip_half(KM, KS, KI);
     double urc[kStatic ? kHalf + 1 : 1], urs[kStatic ? kHalf + 1 : 1];
     double biasc[3] = {0.0, 0.0, 0.0}, biass[3] = {0.0, 0.0, 0.0};   // (biased conversion) the offset's share of a sum of kHalf - 2 / - 1 / - 0 samples
     // samples per chip as Q32.32, and the distance to a lane's next block: D or D + 1 samples
@@ -313,7 +318,7 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
         double sn = 0.0, cs = 0.0;
         if constexpr (kStatic) {
             // (worked out by the host with the plan: chip_rotations())
-            static_assert(kHalf == kStaticHalf, "the plan's rotations are laid out for half blocks of 13 samples");
+            static_assert(kHalf <= kStaticHalf, "the plan's rotations are laid out for half blocks of up to 13 samples");
 #pragma unroll
             for (int k = 1; k <= kHalf; ++k) urc[k] = R->urc[k], urs[k] = R->urs[k];
             rd0c = R->rd0c, rd0s = R->rd0s, rd1c = R->rd1c, rd1s = R->rd1s;
@@ -487,8 +492,8 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                 static_assert(2 * kHalf >= KM + 1 && kHalf < KM, "two halves of at most KS + 1 samples cover the block");
                 // first half: samples 0 .. KS (P_KS is its running sum before the last one, P_(KS+1) its total);
                 // second half: samples KS+1 .. KM summed from rotation 0 again, turned by exp(-1j*(KS+1)*dphi) where read
-                static_assert(!SDR_BIASED_CVT || (KM - kHalf == kHalf - 2 && (KS == 0 || KS == kHalf - 1)),
-                              "the offset's shares are kept for sums of kHalf - 2, kHalf - 1 and kHalf samples");
+                static_assert(!SDR_BIASED_CVT || (2 * kHalf - KM >= 1 && 2 * kHalf - KM <= 2 && (KS == 0 || KS == kHalf - 1)),
+                              "the offset's shares are kept for sums of KM - kHalf, + 1 and + 2 samples: kHalf must be one of the last two");
                 uint32_t flipped[kChipRawDwords];
                 uint32_t hi_const = 0x40B00000u;
                 if constexpr (SDR_BIASED_CVT) {
@@ -555,10 +560,11 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
             if constexpr (kStatic && SDR_BIASED_CVT) {
                 // what the offset of 4224 per sample put into each sum that is read (its first sample has rotation 1:
                 // the sums start from the biased sample itself, and sum_{k<n} r_k includes that r_0 = 1)
-                pr -= biasc[1], pi -= biass[1];                    // second half, KM + 1 - kHalf = kHalf - 1 samples
+                constexpr int iFirst = 2 * kHalf - KM;             // (biasc[i]: a sum of KM - kHalf + i samples)
+                pr -= biasc[1], pi -= biass[1];                    // second half, KM + 1 - kHalf samples
                 capr[1] -= biasc[0], capi[1] -= biass[0];          // ... before its last sample
-                capr[2] -= biasc[2], capi[2] -= biass[2];          // first half: kHalf samples
-                if constexpr (KS != 0) capr[0] -= biasc[1], capi[0] -= biass[1];   // P_KS: kHalf - 1 samples
+                capr[2] -= biasc[iFirst], capi[2] -= biass[iFirst];      // first half: kHalf samples
+                if constexpr (KS != 0) capr[0] -= biasc[iFirst - 1], capi[0] -= biass[iFirst - 1];   // P_KS: kHalf - 1 samples
             }
             if constexpr (kStatic) {
                 const double qr = b.dn ? pr : capr[1], qi = b.dn ? pi : capi[1];   // second half up to M or M + 1 samples

@@ -44,7 +44,9 @@ using namespace sdr;
 constexpr int kWaveThreads = 64;  // one wave per channel-epoch: the ~5 us fixed latency of a workgroup is amortised over 4x more work
 // plan variant word (sdr_epl_plan_variant): low byte = samples a lane owns (0 / 8 / 16 / 26, + 24 when the block length is
 // compiled in), then the compile-time tap geometry
-constexpr int kVariantKS12 = 256 * 12;   // three taps, the outer ones switching 12.x samples into the anchor's block
+constexpr int kVariantKS12 = 256 * 12;   // three taps, the outer ones switching 12.x samples into the anchor's block (24 / 25 samples per chip)
+constexpr int kVariantKSMask = 256 * 15; // ... in general: KS in bits 8-11, with the block length KM in the low byte (kChipMax + KM)
+constexpr int kVariantKS9 = 256 * 9;     // 19 / 20 samples per chip (20 MHz): KM = 19, KS = 9
 constexpr int kVariantKI = 4096;         // taps whole (half-)chips apart: no switch inside a block
 constexpr int kVariantC2 = 8192;         // several chips per lane (correlator_chip2.h), x 1 / 2: boundaries <4,9,14,19> / <5,11,17,23>
 constexpr int kLongLutWords = 4096;  // replicas of 16 KB and more (multi-period / BOC half-chip codes): four epochs share a staged copy
@@ -279,7 +281,8 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
     constexpr bool kOdd = NT == 3 || NT == 5;               // (the compile-time tap geometries exist for these)
     // (the straight-line kernels read the plan's per-item setups: without them the run-time-position kernel serves the list)
     const bool ki = (wide & kVariantKI) != 0 && FMT == SDR_FMT_CI8 && kOdd && d_setups != nullptr;
-    const bool ks = (wide & kVariantKS12) != 0 && FMT == SDR_FMT_CI8 && NT == 3 && d_setups != nullptr;
+    const int ks_of = FMT == SDR_FMT_CI8 && NT == 3 && d_setups != nullptr ? (wide & kVariantKSMask) / 256 : 0;
+    const bool ks = ks_of != 0;
     wide &= 255;
     if (wpw == 4) {
         if (ki)                                              // taps whole (half-)chips apart: configs 4-5
@@ -296,13 +299,15 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
             launch(epl_kernel<FMT, NT, 0, 0, 4>);
         return;
     }
-    if (ks)                                                  // ... and both outer taps switching at sample 12 or 13
+    if (ks && ks_of == 9)                                    // 19 / 20 samples per chip, the outer taps switching at sample 9 or 10
+        launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), (NT == 3 ? 19 : 0), 1, (NT == 3 ? 9 : 0)>);
+    else if (ks)                                             // 24 / 25 samples per chip, both outer taps switching at sample 12 or 13
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 1, (NT == 3 ? 12 : 0)>);
     else if (ki)
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 1, 0, (kOdd ? 1 : 0)>);
-    else if (wide >= kChipMax + 24 && FMT == SDR_FMT_CI8)   // chip-aligned, every epoch with 24 or 25 samples per chip
+    else if (wide == kChipMax + 24 && FMT == SDR_FMT_CI8)   // chip-aligned, every epoch with 24 or 25 samples per chip
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24>);
-    else if (wide == kChipMax && FMT == SDR_FMT_CI8)
+    else if (wide >= kChipMax && FMT == SDR_FMT_CI8)
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16)>);
     else if (wide == 16)
         launch(epl_kernel<FMT, NT, 16>);
@@ -362,7 +367,7 @@ struct sdr_epl_plan {
 // carrier rotations), made when a plan is created: one THREAD per item -- what every wave of an epoch would otherwise
 // repeat in all of its 64 lanes -- with the same functions the run-time-position kernels call per wave.  1.92 M items
 // (60 s x 32 channels) take ~0.1 ms of one launch.
-template <int NT, int KS, int KI>
+template <int NT, int KM, int KS, int KI>
 __global__ __launch_bounds__(256) void chip_setup_kernel(const sdr_epl_item* __restrict__ items, int n_items,
                                                          const double* __restrict__ spacing, double fs, int64_t capacity,
                                                          sdr::ChipSetup<NT>* __restrict__ out) {
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(256) void chip_setup_kernel(const sdr_epl_item* __r
 #pragma unroll
     for (int t = 0; t < NT; ++t) sp[t] = spacing[t];
     sdr::ChipSetup<NT> S;
-    sdr::chip_setup<NT, KS, KI>(it.n_samples, it.start_sample, capacity, it.carrier_hz, it.rem_code, it.code_step, sp, fs,
+    sdr::chip_setup<NT, KM, KS, KI>(it.n_samples, it.start_sample, capacity, it.carrier_hz, it.rem_code, it.code_step, sp, fs,
                                 kWaveThreads, S);
     out[i] = S;
 }
@@ -412,12 +417,13 @@ __global__ __launch_bounds__(256) void validate_items_kernel(const sdr_epl_item*
         // (a lane without an item, or with a bad one, carries the neutral element of every reduction: all 64 lanes take part)
         int maxlen = 0, bad = 0;
         double step = 0.0, lo, hi;
-        bool m24 = true, s12 = true;
-        if (have) bad = check_item(it, r, code_len, maxlen, step, m24, s12, lo, hi);
+        int m_chip = 0;
+        bool split = true;
+        if (have) bad = check_item(it, r, code_len, maxlen, step, m_chip, split, lo, hi);
         const bool good = have && !bad;
         int ml = good ? maxlen : 0;
         unsigned long long mx = good ? dbits(step) : 0ull, mn = good ? dbits(step) : ~0ull;
-        int a24 = (!good || m24) ? 1 : 0, a12 = (!good || s12) ? 1 : 0;
+        int mlo = good ? m_chip : 0x7fffffff, mhi = good ? m_chip : 0, a12 = (!good || split) ? 1 : 0;
         int fb = bad ? i : 0x7fffffff;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -425,7 +431,8 @@ __global__ __launch_bounds__(256) void validate_items_kernel(const sdr_epl_item*
             const unsigned long long ox = __shfl_xor(mx, off, 64), on = __shfl_xor(mn, off, 64);
             mx = ox > mx ? ox : mx;
             mn = on < mn ? on : mn;
-            a24 &= __shfl_xor(a24, off, 64);
+            mlo = min(mlo, __shfl_xor(mlo, off, 64));
+            mhi = max(mhi, __shfl_xor(mhi, off, 64));
             a12 &= __shfl_xor(a12, off, 64);
             fb = min(fb, __shfl_xor(fb, off, 64));
         }
@@ -434,8 +441,9 @@ __global__ __launch_bounds__(256) void validate_items_kernel(const sdr_epl_item*
             atomicMax(&o->maxlen, ml);
             atomicMax(&o->max_step_bits, mx);
             atomicMin(&o->min_step_bits, mn);
-            if (!a24) atomicAnd(&o->all_m24, 0);
-            if (!a12) atomicAnd(&o->all_s12, 0);
+            atomicMin(&o->m_lo, mlo);
+            atomicMax(&o->m_hi, mhi);
+            if (!a12) atomicAnd(&o->all_split, 0);
             if (fb != 0x7fffffff) atomicMin(&o->first_bad, fb);
         }
     }
@@ -475,8 +483,12 @@ static int item_error(const sdr_engine* e, const sdr_epl_item& it, int index, in
 }
 
 // The kernel variant a list of these statistics gets (0: per sample; 8 / 16: boundary variants; kChipMax + ...: chip-aligned).
-static int variant_of(const sdr_engine* e, const ItemRules& r, const double* spacing, double max_step, double min_step, bool all_m24,
-                      bool all_s12) {
+// m_lo / m_hi: the list's range of whole samples per chip; all_split: ItemStats::all_split.
+static int variant_of(const sdr_engine* e, const ItemRules& r, const double* spacing, double max_step, double min_step, int m_lo, int m_hi,
+                      bool all_split) {
+    const bool all_m24 = m_lo == 24 && m_hi == 24;
+    const bool all_s12 = all_m24 && all_split;
+    const bool all_s9 = m_lo == 19 && m_hi == 19 && all_split;          // (20 MHz: the KM = 19, KS = 9 instantiation)
     bool all_ki = r.n_taps == 3 || r.n_taps == 5;   // tap t exactly (t - A) chips from the anchor (KI kernel)
     for (int t = 0; all_ki && t < r.n_taps; ++t) all_ki = r.scale * spacing[t] - r.s_anchor == (double)(t - r.n_taps / 2);
     const bool boundary_ok = min_step >= sdr::kFastMinCodeStep && r.scale * e->lut_stride < sdr::kFastMaxLutWords;
@@ -489,7 +501,8 @@ static int variant_of(const sdr_engine* e, const ItemRules& r, const double* spa
         !e->epl_no_chip)
         wide = sdr::kChipMax + (all_m24 ? 24 : 0) +
                ((all_m24 && all_s12 && !e->epl_no_split) ? kVariantKS12 : 0) +
-               ((all_m24 && all_ki && !e->epl_no_split) ? kVariantKI : 0);
+               ((all_m24 && all_ki && !e->epl_no_split) ? kVariantKI : 0) +
+               ((all_s9 && !e->epl_no_split) ? 19 + kVariantKS9 : 0);
     return wide;
 }
 
@@ -499,21 +512,24 @@ static int validate_items(sdr_engine* e, const sdr_epl_item* items, int n_items,
     const ItemRules r = item_rules(e, spacing, n_taps, scale);
     int maxlen = 0;
     double max_step = 0.0, min_step = 1e300;
-    bool all_m24 = true, all_s12 = r.want_s12;
+    int m_lo = 0x7fffffff, m_hi = 0;
+    bool all_split = r.want_s12;
     for (int i = 0; i < n_items; ++i) {
         int ml = 0;
         double step = 0.0, lo = 0.0, hi = 0.0;
-        bool m24 = true, s12 = true;
-        if (const int bad = check_item(items[i], r, e->code_len_host.data(), ml, step, m24, s12, lo, hi))
+        int m_chip = 0;
+        bool split = true;
+        if (const int bad = check_item(items[i], r, e->code_len_host.data(), ml, step, m_chip, split, lo, hi))
             return item_error(e, items[i], index0 + i, bad, lo, hi);
-        all_m24 = all_m24 && m24;
-        all_s12 = all_s12 && s12;
+        m_lo = m_chip < m_lo ? m_chip : m_lo;
+        m_hi = m_chip > m_hi ? m_chip : m_hi;
+        all_split = all_split && split;
         if (step > max_step) max_step = step;
         if (step < min_step) min_step = step;
         if (ml > maxlen) maxlen = ml;
     }
     *lut_words = maxlen + SDR_LUT_PAD + 2;
-    *wide = variant_of(e, r, spacing, max_step, min_step, all_m24, all_s12);
+    *wide = variant_of(e, r, spacing, max_step, min_step, m_lo, m_hi, all_split);
     return SDR_OK;
 }
 
@@ -526,7 +542,7 @@ static int validate_items_dev(sdr_engine* e, const sdr_epl_item* d_items, const 
     if (int rc = sdr_pinned_reserve(e, &e->ctx0, 2 * sizeof(ItemStats))) return rc;
     ItemStats* host = static_cast<ItemStats*>(e->ctx0.pinned);
     for (int v = 0; v < 2; ++v) {
-        host[v] = ItemStats{0x7fffffff, 0, 0, 0ull, ~0ull, 1, (v ? r2 : r1).want_s12 ? 1 : 0};
+        host[v] = ItemStats{0x7fffffff, 0, 0, 0ull, ~0ull, 0x7fffffff, 0, (v ? r2 : r1).want_s12 ? 1 : 0};
     }
     SDR_HIP(hipMemcpyAsync(e->ws_stats.ptr, host, 2 * sizeof(ItemStats), hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(validate_items_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, e->stream, d_items, n_items, r1, r2,
@@ -545,13 +561,13 @@ static int validate_items_dev(sdr_engine* e, const sdr_epl_item* d_items, const 
         return rc ? rc : sdr_fail(SDR_ERR_INVALID, "item %d: rejected by the device check", i);
     }
     *lut_words = host[0].maxlen + SDR_LUT_PAD + 2;
-    *wide = variant_of(e, r1, spacing, as_double(host[0].max_step_bits), as_double(host[0].min_step_bits), host[0].all_m24 != 0,
-                       host[0].all_s12 != 0);
+    *wide = variant_of(e, r1, spacing, as_double(host[0].max_step_bits), as_double(host[0].min_step_bits), host[0].m_lo, host[0].m_hi,
+                       host[0].all_split != 0);
     *ok2 = host[1].first_bad == 0x7fffffff;
     if (*ok2) {
         *lw2 = host[1].maxlen + SDR_LUT_PAD + 2;
-        *wide2 = variant_of(e, r2, spacing, as_double(host[1].max_step_bits), as_double(host[1].min_step_bits), host[1].all_m24 != 0,
-                            host[1].all_s12 != 0);
+        *wide2 = variant_of(e, r2, spacing, as_double(host[1].max_step_bits), as_double(host[1].min_step_bits), host[1].m_lo, host[1].m_hi,
+                            host[1].all_split != 0);
     }
     return SDR_OK;
 }
@@ -713,7 +729,7 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
         }
     };
     const unsigned setup_grid = (unsigned)((n_items + 255) / 256);
-    if (err == hipSuccess && e->iq_fmt == SDR_FMT_CI8 && (wide & 255) >= kChipMax && (wide & (kVariantKS12 | kVariantKI)) &&
+    if (err == hipSuccess && e->iq_fmt == SDR_FMT_CI8 && (wide & 255) >= kChipMax && (wide & (kVariantKSMask | kVariantKI)) &&
         (n_taps == 3 || n_taps == 5)) {
         reserve_setups(n_taps == 3 ? sizeof(sdr::ChipSetup<3>) : sizeof(sdr::ChipSetup<5>));
         if (err == hipSuccess && !long_list) {
@@ -723,26 +739,32 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
             host_setups.resize(p->setup_bytes * (size_t)n_items);
             for (int i = 0; i < n_items; ++i) {
                 const sdr_epl_item& it = src[i];
-                if ((wide & kVariantKS12) && n_taps == 3)
-                    sdr::chip_setup<3, 12, 0>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
-                                              kWaveThreads, reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i]);
+                if ((wide & kVariantKSMask) == kVariantKS12 && n_taps == 3)
+                    sdr::chip_setup<3, 24, 12, 0>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
+                                                  kWaveThreads, reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i]);
+                else if ((wide & kVariantKSMask) == kVariantKS9 && n_taps == 3)
+                    sdr::chip_setup<3, 19, 9, 0>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
+                                                 kWaveThreads, reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i]);
                 else if (n_taps == 3)
-                    sdr::chip_setup<3, 0, 1>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
+                    sdr::chip_setup<3, 24, 0, 1>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
                                              kWaveThreads, reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i]);
                 else
-                    sdr::chip_setup<5, 0, 1>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
+                    sdr::chip_setup<5, 24, 0, 1>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
                                              kWaveThreads, reinterpret_cast<sdr::ChipSetup<5>*>(host_setups.data())[i]);
             }
             err = hipMemcpyAsync(p->d_setups, host_setups.data(), host_setups.size(), hipMemcpyHostToDevice, e->stream);
         } else if (err == hipSuccess) {
-            if ((wide & kVariantKS12) && n_taps == 3)
-                hipLaunchKernelGGL((chip_setup_kernel<3, 12, 0>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
+            if ((wide & kVariantKSMask) == kVariantKS12 && n_taps == 3)
+                hipLaunchKernelGGL((chip_setup_kernel<3, 24, 12, 0>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
+                                   p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups));
+            else if ((wide & kVariantKSMask) == kVariantKS9 && n_taps == 3)
+                hipLaunchKernelGGL((chip_setup_kernel<3, 19, 9, 0>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
                                    p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups));
             else if (n_taps == 3)
-                hipLaunchKernelGGL((chip_setup_kernel<3, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
+                hipLaunchKernelGGL((chip_setup_kernel<3, 24, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
                                    p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups));
             else
-                hipLaunchKernelGGL((chip_setup_kernel<5, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
+                hipLaunchKernelGGL((chip_setup_kernel<5, 24, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
                                    p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<5>*>(p->d_setups));
             err = hipGetLastError();
         }
@@ -837,7 +859,7 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
                         (long long)(first + count), p->n_items);
     if (p->doubled)
         if (int rc = ensure_doubled_luts(e, ctx->stream)) return rc;   // (a slot may have been re-staged since the plan was made)
-    if (e->iq_fmt == SDR_FMT_CI8 && (p->wide & (kVariantKS12 | kVariantKI | 3 * kVariantC2))) {
+    if (e->iq_fmt == SDR_FMT_CI8 && (p->wide & (kVariantKSMask | kVariantKI | 3 * kVariantC2))) {
         const void* flipped = nullptr;                                   // (the straight-line kernels read the flipped ring image)
         if (int rc = sdr_iq_flipped(e, ctx->stream, &flipped)) return rc;
     }

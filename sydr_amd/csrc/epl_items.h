@@ -22,13 +22,14 @@ struct ItemStats {                 // of the items seen so far
     int first_bad, bad_code;       // lowest index of an invalid item (INT_MAX: none) and what is wrong with it
     int maxlen;
     unsigned long long max_step_bits, min_step_bits;   // (positive doubles order as integers)
-    int all_m24, all_s12;
+    int m_lo, m_hi;                // whole samples per chip of the anchor tap's line: lowest and highest of the list
+    int all_split;                 // every item's outer taps switch chips floor(M / 2) samples into the anchor's block (with margin)
 };
 enum ItemError { ITEM_OK = 0, ITEM_SLOT, ITEM_SAMPLES, ITEM_START, ITEM_NCO, ITEM_REPLICA };
 
 // What is wrong with one item (ITEM_OK: nothing) and its share of the list's statistics.  lo / hi: its code phase range.
 __host__ __device__ inline int check_item(const sdr_epl_item& it, const ItemRules& r, const int32_t* code_len, int& maxlen,
-                                          double& step_scaled, bool& m24, bool& s12, double& lo, double& hi) {
+                                          double& step_scaled, int& m_chip, bool& split, double& lo, double& hi) {
     // (before anything is derived from them: a zero n_samples or a NaN code_step would be cast to an integer below)
     if (it.code_slot < 0 || it.code_slot >= r.n_slots || code_len[it.code_slot] <= 0) return ITEM_SLOT;
     if (it.n_samples <= 0 || it.n_samples > r.iq_capacity) return ITEM_SAMPLES;
@@ -58,9 +59,12 @@ __host__ __device__ inline int check_item(const sdr_epl_item& it, const ItemRule
         line(r.s_anchor, sh, inv);
         const bool in_range = inv >= 1.0 && inv < 1024.0;   // (samples per chip; false for NaN / Inf as well)
         const int64_t tfx = in_range ? (int64_t)rint(inv * two32) : 0;
-        m24 = (int)(tfx >> 32) == 24;
-        s12 = r.want_s12 && m24;
-        for (int t = 0; s12 && t < 3; t += 2) {
+        m_chip = (int)(tfx >> 32);
+        // (the straight-line kernels: the outer taps switch KS = floor(M / 2) samples into the anchor's block -- 12.x at 24.x
+        // samples per chip, 9.x at 19.x)
+        const int ks = m_chip >> 1;
+        split = r.want_s12 && m_chip >= 2;
+        for (int t = 0; split && t < 3; t += 2) {
             // the kernel's own derivation of the switch offset (a Q32.32 sample count); its reciprocal is a Newton
             // step, not a division, so a margin of 2^-10 sample keeps the two from disagreeing about the integer part
             double sht, invt;
@@ -70,7 +74,7 @@ __host__ __device__ inline int check_item(const sdr_epl_item& it, const ItemRule
             int64_t d = (ut - ufx) + (int64_t)(1 + j) * tfx;
             if (d < 0) d += tfx; else if (d >= tfx) d -= tfx;
             const int64_t margin = (int64_t)1 << 22;
-            s12 = d >= ((int64_t)12 << 32) + margin && d < ((int64_t)13 << 32) - margin;
+            split = d >= ((int64_t)ks << 32) + margin && d < ((int64_t)(ks + 1) << 32) - margin;
         }
     }
     return ITEM_OK;

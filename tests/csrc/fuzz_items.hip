@@ -74,8 +74,9 @@ int main(int argc, char** argv) {
                 r.sp0 = spacing[0], r.sp2 = spacing[2], r.want_s12 = taps == 3;
                 int maxlen = 0;
                 double st = 0.0, lo = 0.0, hi = 0.0;
-                bool m24 = true, s12 = true;
-                const int bad = check_item(it, r, code_len, maxlen, st, m24, s12, lo, hi);
+                int m_chip = 0;
+                bool split = true;
+                const int bad = check_item(it, r, code_len, maxlen, st, m_chip, split, lo, hi);
                 ++rejected[bad];
                 ok_all = ok_all && bad == ITEM_OK;
                 if (bad != ITEM_OK && scale == 1.0) break;
@@ -86,9 +87,10 @@ int main(int argc, char** argv) {
             // what plan creation does next for an accepted item (the same functions its setup kernels run per thread)
             volatile double sink = 0.0;
             if (taps == 3) {
-                ChipSetup<3> a, b;
-                chip_setup<3, 12, 0>(it.n_samples, it.start_sample, 1 << 20, it.carrier_hz, it.rem_code, it.code_step, spacing, fs, 64, a);
-                chip_setup<3, 0, 1>(it.n_samples, it.start_sample, 1 << 20, it.carrier_hz, it.rem_code, it.code_step, spacing, fs, 64, b);
+                ChipSetup<3> a, b, b9;
+                chip_setup<3, 19, 9, 0>(it.n_samples, it.start_sample, 1 << 20, it.carrier_hz, it.rem_code, it.code_step, spacing, fs, 64, b9);
+                chip_setup<3, 24, 12, 0>(it.n_samples, it.start_sample, 1 << 20, it.carrier_hz, it.rem_code, it.code_step, spacing, fs, 64, a);
+                chip_setup<3, 24, 0, 1>(it.n_samples, it.start_sample, 1 << 20, it.carrier_hz, it.rem_code, it.code_step, spacing, fs, 64, b);
                 ChipNSetup<4, 9, 14, 19> c;
                 ChipNSetup<5, 11, 17, 23> d;
                 const bool c_ok = chipn_setup<4, 9, 14, 19>(it.n_samples, it.start_sample, 1 << 20, it.carrier_hz, it.rem_code, it.code_step, spacing, fs, c);
@@ -96,7 +98,7 @@ int main(int argc, char** argv) {
                 sink = a.dphi + b.dphi + (double)(c_ok + d_ok);
             } else {
                 ChipSetup<5> a;
-                chip_setup<5, 0, 1>(it.n_samples, it.start_sample, 1 << 20, it.carrier_hz, it.rem_code, it.code_step, spacing, fs, 64, a);
+                chip_setup<5, 24, 0, 1>(it.n_samples, it.start_sample, 1 << 20, it.carrier_hz, it.rem_code, it.code_step, spacing, fs, 64, a);
                 sink = a.dphi;
             }
             (void)sink;

@@ -761,3 +761,60 @@ def test_long_lists_are_checked_on_the_device_like_short_ones_on_the_host(engine
             on_dev.close()
     finally:
         hip.hipFree(d)
+
+
+def test_compile_time_tap_switch_variant_at_20_mhz(engine):
+    """The straight-line kernel is written for a block length KM and a switch position KS = floor(KM / 2); besides 24 / 12
+    (25 MHz) it is instantiated for 19 / 9: 20 MHz, 19.55 samples per chip, the outer taps switching 9.8 samples into the
+    prompt tap's chip.  Long and short lists (setups by the launch / on the host) against the oracle and against the
+    run-time-position kernel; odd epochs (short, n = N +- 1, an intermediate frequency, exact-integer phases) fall back
+    inside the launch; a list that spans two block lengths (19 and 20 samples per chip) must not select it."""
+    rng = np.random.default_rng(20261020)
+    fs = 20e6
+    cap = 8 * 50000
+    raw = rng.integers(-100, 100, 2 * cap).astype(np.int8)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(8, 1023, 3)
+    for s in range(8):
+        engine.load_gps_code(s, 3 * s + 2)
+    rf = orc.iq_to_complex(raw)
+    half = (-0.5, 0.0, 0.5)
+    for n_items in (96, 4200):
+        step = (1.023e6 + rng.uniform(-4, 4, n_items)) / fs
+        rem_code = rng.uniform(0, step)
+        rem_code[:6] = [0.0, 0.5, 0.25, 1e-9, step[4] / 2, step[5] * (1 - 1e-12)]
+        periods = rng.integers(1, 3, n_items)
+        n = np.ceil((1023 * periods - rem_code) / step).astype(np.int64) + rng.integers(-1, 2, n_items)
+        n[6:10] = [3, 40, 70, 21]
+        start = rng.integers(0, cap - 50000, n_items)
+        start[10:13] = [0, 1, cap - int(n[12]) - 1]
+        slot = rng.integers(0, 8, n_items)
+        f = rng.uniform(-6000, 6000, n_items)
+        f[13:16] = [0.0, 4.092e6, -4.092e6]
+        rem_carrier = rng.uniform(0, 2 * np.pi, n_items)
+        items = make_items(slot, n, start, f, rem_carrier, rem_code, step)
+        got = {}
+        for no_split in (0, 1):
+            engine.set_option("epl_no_split_variant", no_split)
+            try:
+                plan = engine.epl_plan(items, half, fs)
+                plan.run()
+                got[no_split] = (plan.variant, plan.fetch())
+                plan.close()
+            finally:
+                engine.set_option("epl_no_split_variant", 0)
+        assert got[0][0] == 26 + 19 + 256 * 9 and got[1][0] == 26
+        for k in (range(n_items) if n_items < 1000 else rng.choice(n_items, 60, replace=False)):
+            x = orc.ring_slice(rf, int(start[k]), int(n[k]))
+            ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(3 * int(slot[k]) + 2)), fs, f[k], rem_carrier[k], rem_code[k], step[k], half))
+            scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 50.0), 2)
+            for no_split in (0, 1):
+                assert np.max(np.abs(got[no_split][1][k] - ref) / scale) < 1e-9, (n_items, k, no_split, step[k], n[k])
+    # 20.46 MHz is exactly 20.0 samples per chip: Doppler decides between 19 and 20 -- not this kernel's list
+    items2 = items[:200].copy()
+    items2["code_step"] = (1.023e6 + rng.uniform(-4, 4, 200)) / 20.46e6
+    items2["n_samples"] = np.ceil((1023 - items2["rem_code"]) / items2["code_step"]).astype(np.int64)
+    plan = engine.epl_plan(items2, half, 20.46e6)
+    assert plan.variant == 26
+    plan.close()
