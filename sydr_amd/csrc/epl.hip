@@ -285,7 +285,7 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
     const bool ks = ks_of != 0;
     wide &= 255;
     if (wpw == 4) {
-        if (ki)                                              // taps whole (half-)chips apart: configs 4-5
+        if (ki && wide == kChipMax + 24)                     // taps whole (half-)chips apart: configs 4-5
             launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 4, 0, (kOdd ? 1 : 0)>);
         else if (wide >= kChipMax + 24 && FMT == SDR_FMT_CI8)     // (every epoch with 24 or 25 samples per chip: BOC(1,1) half-chips at 50 MHz)
             launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 4>);
@@ -303,6 +303,8 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), (NT == 3 ? 19 : 0), 1, (NT == 3 ? 9 : 0)>);
     else if (ks)                                             // 24 / 25 samples per chip, both outer taps switching at sample 12 or 13
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 1, (NT == 3 ? 12 : 0)>);
+    else if (ki && wide == kChipMax + 15)                    // 15 / 16 samples per half chip (31-32.7 MHz on the half-chip view)
+        launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), (NT == 3 ? 15 : 24), 1, 0, (kOdd ? 1 : 0)>);
     else if (ki)
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 1, 0, (kOdd ? 1 : 0)>);
     else if (wide == kChipMax + 24 && FMT == SDR_FMT_CI8)   // chip-aligned, every epoch with 24 or 25 samples per chip
@@ -486,23 +488,26 @@ static int item_error(const sdr_engine* e, const sdr_epl_item& it, int index, in
 // m_lo / m_hi: the list's range of whole samples per chip; all_split: ItemStats::all_split.
 static int variant_of(const sdr_engine* e, const ItemRules& r, const double* spacing, double max_step, double min_step, int m_lo, int m_hi,
                       bool all_split) {
+    bool all_ki = r.n_taps == 3 || r.n_taps == 5;   // tap t exactly (t - A) chips from the anchor (KI kernel)
+    for (int t = 0; all_ki && t < r.n_taps; ++t) all_ki = r.scale * spacing[t] - r.s_anchor == (double)(t - r.n_taps / 2);
     const bool all_m24 = m_lo == 24 && m_hi == 24;
     const bool all_s12 = all_m24 && all_split;
     const bool all_s9 = m_lo == 19 && m_hi == 19 && all_split;          // (20 MHz: the KM = 19, KS = 9 instantiation)
-    bool all_ki = r.n_taps == 3 || r.n_taps == 5;   // tap t exactly (t - A) chips from the anchor (KI kernel)
-    for (int t = 0; all_ki && t < r.n_taps; ++t) all_ki = r.scale * spacing[t] - r.s_anchor == (double)(t - r.n_taps / 2);
+    const bool all_m15 = m_lo == 15 && m_hi == 15;                      // (31-32.7 MHz on the half-chip view: KM = 15, whole-chip taps)
     const bool boundary_ok = min_step >= sdr::kFastMinCodeStep && r.scale * e->lut_stride < sdr::kFastMaxLutWords;
     int wide = !boundary_ok ? 0 : (max_step <= sdr::kFastMaxCodeStep ? 16 : (max_step <= sdr::kFastMaxCodeStep8 ? 8 : 0));
     // every item inside the chip-aligned variant's range (ci8 ring): lanes own whole chips instead of 16 samples
     // (the half-chip view only where a half chip holds 16 samples or more: at 31-32 MHz -- 15.6 per half chip -- the
     // 16-sample boundary groups of the plain list were measured faster, 0.47 against 0.37 of the roof)
-    const double chip_max_step = r.scale == 2.0 ? 1.0 / 16.0 : sdr::kChipMaxCodeStep;
+    // ... unless every half chip holds 15.x samples and the taps sit whole half-chips apart: the KM = 15 whole-chip-tap kernel
+    const double chip_max_step = r.scale == 2.0 && !(all_m15 && all_ki && r.n_taps == 3 && !e->epl_no_split) ? 1.0 / 16.0 : sdr::kChipMaxCodeStep;
     if (boundary_ok && e->iq_fmt == SDR_FMT_CI8 && min_step >= sdr::kChipMinCodeStep && max_step <= chip_max_step &&
         !e->epl_no_chip)
         wide = sdr::kChipMax + (all_m24 ? 24 : 0) +
                ((all_m24 && all_s12 && !e->epl_no_split) ? kVariantKS12 : 0) +
                ((all_m24 && all_ki && !e->epl_no_split) ? kVariantKI : 0) +
-               ((all_s9 && !e->epl_no_split) ? 19 + kVariantKS9 : 0);
+               ((all_s9 && !e->epl_no_split) ? 19 + kVariantKS9 : 0) +
+               ((all_m15 && all_ki && r.n_taps == 3 && r.scale == 2.0 && !e->epl_no_split) ? 15 + kVariantKI : 0);
     return wide;
 }
 
@@ -745,6 +750,9 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
                 else if ((wide & kVariantKSMask) == kVariantKS9 && n_taps == 3)
                     sdr::chip_setup<3, 19, 9, 0>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
                                                  kWaveThreads, reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i]);
+                else if (n_taps == 3 && (wide & 255) == kChipMax + 15)
+                    sdr::chip_setup<3, 15, 0, 1>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
+                                                 kWaveThreads, reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i]);
                 else if (n_taps == 3)
                     sdr::chip_setup<3, 24, 0, 1>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
                                              kWaveThreads, reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i]);
@@ -759,6 +767,9 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
                                    p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups));
             else if ((wide & kVariantKSMask) == kVariantKS9 && n_taps == 3)
                 hipLaunchKernelGGL((chip_setup_kernel<3, 19, 9, 0>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
+                                   p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups));
+            else if (n_taps == 3 && (wide & 255) == kChipMax + 15)
+                hipLaunchKernelGGL((chip_setup_kernel<3, 15, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
                                    p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups));
             else if (n_taps == 3)
                 hipLaunchKernelGGL((chip_setup_kernel<3, 24, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,

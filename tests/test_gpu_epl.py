@@ -818,3 +818,48 @@ def test_compile_time_tap_switch_variant_at_20_mhz(engine):
     plan = engine.epl_plan(items2, half, 20.46e6)
     assert plan.variant == 26
     plan.close()
+
+
+@pytest.mark.parametrize("n_items", [150, 4300])
+def test_whole_chip_tap_variant_on_the_half_chip_view_at_32_mhz(engine, n_items):
+    """31-32.7 MHz: a chip holds 30.3-32 samples, a half chip 15.x -- the half-chip view with the whole-chip-tap kernel
+    compiled for blocks of 15 / 16 samples (KM = 15; 16-sample boundary groups before: 0.47 of the roof against 0.68).
+    Against the oracle and against the boundary variant, short and long lists, odd epochs included."""
+    rng = np.random.default_rng(3200 + n_items)
+    fs = 32e6
+    cap = 8 * 70000
+    raw = rng.integers(-100, 100, 2 * cap).astype(np.int8)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(8, 1023, 2)
+    for s in range(8):
+        engine.load_gps_code(s, 3 * s + 2)
+    rf = orc.iq_to_complex(raw)
+    half = (-0.5, 0.0, 0.5)
+    step = (1.023e6 + rng.uniform(-4, 4, n_items)) / fs
+    rem_code = rng.uniform(0, step)
+    rem_code[:4] = [0.0, 0.5, 0.25, 1e-9]
+    n = np.ceil((1023 - rem_code) / step).astype(np.int64) + rng.integers(-1, 2, n_items)
+    n[4:8] = [3, 40, 70, 33]
+    start = rng.integers(0, cap - 70000, n_items)
+    slot = rng.integers(0, 8, n_items)
+    f = rng.uniform(-6000, 6000, n_items)
+    rem_carrier = rng.uniform(0, 2 * np.pi, n_items)
+    items = make_items(slot, n, start, f, rem_carrier, rem_code, step)
+    got = {}
+    for plain in (0, 1):
+        engine.set_option("epl_no_half_chip_view", plain)
+        try:
+            plan = engine.epl_plan(items, half, fs)
+            plan.run()
+            got[plain] = (plan.variant, plan.fetch())
+            plan.close()
+        finally:
+            engine.set_option("epl_no_half_chip_view", 0)
+    assert got[0][0] == 65536 + 26 + 15 + 4096 and got[1][0] == 16
+    for k in (range(n_items) if n_items < 1000 else rng.choice(n_items, 60, replace=False)):
+        x = orc.ring_slice(rf, int(start[k]), int(n[k]))
+        ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(3 * int(slot[k]) + 2)), fs, f[k], rem_carrier[k], rem_code[k], step[k], half))
+        scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 50.0), 2)
+        for plain in (0, 1):
+            assert np.max(np.abs(got[plain][1][k] - ref) / scale) < 1e-9, (k, plain, step[k], n[k])
