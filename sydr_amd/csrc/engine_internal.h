@@ -114,6 +114,7 @@ struct sdr_engine {
     bool pcps_no_fast = false;       // diagnostics: keep the general four-step kernels where the N = 125 x 200 ones would run
     bool pcps_no_spec_cache = false; // "pcps_no_spectra_cache": conj(fft(code)) recomputed by every search, as the reference does (kaplan:184-185)
     bool pcps_force_passes = false;  // diagnostics: use the one-kernel-per-radix-pass transform instead of the four-step one
+    bool pcps_slow_second = false;   // "pcps_general_second_sweep": peak kernel + general four-step pair where the fused second sweep would run
     bool pcps_fused = true;          // map-free search at N = 125 x 200 of a round of 256 transforms or more: one workgroup per (PRN, bin) transform (pcps_fused.h); "pcps_fused" = 0: the two-kernel sweeps
     DevBuf pcps_work;                // its work list (transform numbers in processing order)
     int pcps_work_prn = 0, pcps_work_bins = 0;   // ... and the grid it was made for
@@ -168,3 +169,7 @@ int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void
 // records per PRN that sweep leaves (PRN-major: [prn][records]); a search that is not a whole number of rounds of its 256
 // workgroups has its last transforms cut into five units of SDR_PCPS_FUSED_RECORDS records each
 int sdr_pcps_fused_records_per_prn(int n_prn, int nbins);
+// The second sweep of such a search in one launch: the first peaks from `recs` ([n_prn][per_prn] records) into tops / dev_bin /
+// dev_code, and 5 x SDR_PCPS_FUSED_RECORDS records per PRN of its winning row's allowed columns into `seconds`.
+int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int N, int spc, const void* recs,
+                          int per_prn, void* tops, void* dev_bin, void* dev_code, void* seconds);

@@ -1226,27 +1226,34 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
         const int per_prn = fused_takes(e, four, n_prn, nbins) ? sdr_pcps_fused_records_per_prn(n_prn, nbins)
                                                                : nbins * records_main_sweep(e, four);
         Best* tops = parts + (size_t)n_prn * per_prn;
-        {
-            ProfScope ps(e, "pcps_peak");
-            hipLaunchKernelGGL(argmax_records_kernel, dim3(n_prn), dim3(kThreads), 0, e->stream, parts, per_prn, N, tops,
-                               dev_bin, dev_code);
+        Best* seconds = tops + n_prn;      // [n_prn][records of the second sweep]
+        int per_second = records_per_transform(four);
+        if (fused_takes(e, four, n_prn, nbins) && !e->pcps_slow_second) {
+            // first peaks + second sweep in one launch of n_prn x 5 workgroups (pcps_fused.h ifft_second_kernel)
+            if (int rc2 = sdr_pcps_fused_second(e, F, C, tw, n_prn, N, spc, parts, per_prn, tops, dev_bin, dev_code, seconds)) return rc2;
+            per_second = 5 * SDR_PCPS_FUSED_RECORDS;
+        } else {
+            {
+                ProfScope ps(e, "pcps_peak");
+                hipLaunchKernelGGL(argmax_records_kernel, dim3(n_prn), dim3(kThreads), 0, e->stream, parts, per_prn, N, tops,
+                                   dev_bin, dev_code);
+            }
+            PassArgs g = {};
+            g.tw = tw;
+            g.N = N;
+            g.in = F;
+            g.code_spec = C;
+            g.nbins = nbins;
+            g.scale = 1.0 / (double)N;
+            g.sel_bin = dev_bin;
+            g.tops = tops;
+            g.spc = spc;
+            g.partials = seconds;
+            run_fft<true, LOAD_MUL_CODE_SEL, STORE_MAG_MAX, FMT>(e, radices, g, n_prn, A, B, nullptr, "pcps_inv_fft", blu);
         }
-        PassArgs g = {};
-        g.tw = tw;
-        g.N = N;
-        g.in = F;
-        g.code_spec = C;
-        g.nbins = nbins;
-        g.scale = 1.0 / (double)N;
-        g.sel_bin = dev_bin;
-        g.tops = tops;
-        g.spc = spc;
-        Best* seconds = tops + n_prn;      // [n_prn][records_per_transform]
-        g.partials = seconds;
-        run_fft<true, LOAD_MUL_CODE_SEL, STORE_MAG_MAX, FMT>(e, radices, g, n_prn, A, B, nullptr, "pcps_inv_fft", blu);
         {
             ProfScope ps(e, "pcps_peak");
-            hipLaunchKernelGGL(ratio_kernel, dim3(n_prn), dim3(64), 0, e->stream, seconds, records_per_transform(plan_four_step(N)),
+            hipLaunchKernelGGL(ratio_kernel, dim3(n_prn), dim3(64), 0, e->stream, seconds, per_second,
                                tops, dev_bin, dev_code, res_bin, res_code, res_ratio);
         }
         SDR_HIP(hipGetLastError());

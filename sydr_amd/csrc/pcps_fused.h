@@ -155,9 +155,12 @@ __device__ unsigned long long g_fused_stamps[256][8];
 #endif
 
 // One unit of work (a whole transform, or round `mode` of one) by the 512 threads of the workgroup.
-template <bool WHOLE>
+// SECOND: the unit belongs to the second sweep -- the winning Doppler row of a PRN again, the maximum over the columns
+// TwoCorrelationPeakComparison allows: [0, a1) U [b0, b1) (acquisition.py:98-111); flat index = the code phase;
+// no bound from the first sweep (the second peak lies below it).
+template <bool WHOLE, bool SECOND = false>
 __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int tid, const int prn, const int bin, const int mode,
-                                         const int rec_slot
+                                         const int rec_slot, const int a1 = 0, const int b0 = 0, const int b1 = 0
 #ifdef SDR_FUSED_STAMPS
                                          , unsigned long long& stamp_
 #endif
@@ -309,8 +312,8 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     double best_sq = -1.0, best_x = 0.0, best_y = 0.0;
     int best_k = -1;
     // (squared, unscaled, a little low: the bound the lanes' squared magnitudes are screened against)
-    double floor_sq;
-    {
+    double floor_sq = 0.0;
+    if constexpr (!SECOND) {
         const double th = __longlong_as_double((long long)__hip_atomic_load(&a.theta[prn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) * (double)N;
         floor_sq = th * th * (1.0 - 0x1p-40);
     }
@@ -425,7 +428,13 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
             const int k_first = kf0 + rho;
             double sqv[10];
 #pragma unroll
-            for (int g = 0; g < 10; ++g) sqv[g] = __builtin_fma(u[g].x, u[g].x, u[g].y * u[g].y);
+            for (int g = 0; g < 10; ++g) {
+                sqv[g] = __builtin_fma(u[g].x, u[g].x, u[g].y * u[g].y);
+                if constexpr (SECOND) {        // (a column the peak comparison excludes never becomes a candidate: -2 loses against -1)
+                    const int k = k_first + 20 * N1 * (g / 2 + 5 * (g % 2));
+                    sqv[g] = (k < a1 || (k >= b0 && k < b1)) ? sqv[g] : -2.0;
+                }
+            }
             const double m01 = fmax(sqv[0], sqv[1]), m23 = fmax(sqv[2], sqv[3]), m45 = fmax(sqv[4], sqv[5]), m67 = fmax(sqv[6], sqv[7]),
                          m89 = fmax(sqv[8], sqv[9]);
             const double round_max = fmax(fmax(fmax(m01, m23), fmax(m45, m67)), m89);
@@ -449,7 +458,7 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
                     const int k = k_first + 20 * N1 * p;              // code phase = position in the transform
                     const double sq = sqv[g];
                     const bool take = sq > best_sq;
-                    tie |= fabs(sq - best_sq) <= best_sq * 0x1p-48;
+                    tie |= sq >= 0.0 && fabs(sq - best_sq) <= best_sq * 0x1p-48;
                     best_sq = take ? sq : best_sq;
                     best_x = take ? u[g].x : best_x;
                     best_y = take ? u[g].y : best_y;
@@ -468,9 +477,10 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
                         const int p = g / 2 + 5 * (g % 2);
                         const int k = k_first + 20 * N1 * p;
                         const double2 x = copy[g];
-                        const double sq = __builtin_fma(x.x, x.x, x.y * x.y);
+                        double sq = __builtin_fma(x.x, x.x, x.y * x.y);
+                        if (SECOND && !(k < a1 || (k >= b0 && k < b1))) sq = -2.0;
                         bool take = sq > best_sq;
-                        if (fabs(sq - best_sq) <= best_sq * 0x1p-48) {
+                        if (sq >= 0.0 && fabs(sq - best_sq) <= best_sq * 0x1p-48) {
                             const double m_new = hypot(x.x * a.scale, x.y * a.scale), m_old = hypot(best_x * a.scale, best_y * a.scale);
                             take = m_new > m_old || (m_new == m_old && k < best_k);
                         }
@@ -490,14 +500,15 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     int best_i = 0x7fffffff;
     double best_v = -1.0;
     if (live2 && best_k >= 0) {
-        best_i = bin * N + best_k;
+        best_i = (SECOND ? 0 : bin * N) + best_k;
         best_v = 0.0 + hypot(best_x * a.scale, best_y * a.scale);   // (0.0 + |.|: the map's own rounding)
     }
     wave_best(best_v, best_i);
     if ((tid & 63) == 63) {
         Best rec = {best_v, (long long)best_i};
         a.partials[(size_t)rec_slot * kRecordsPerTransform + (tid >> 6)] = rec;
-        if (best_v > 0.0) atomicMax(&a.theta[prn], (unsigned long long)__double_as_longlong(best_v));   // (positive doubles order as integers)
+        if constexpr (!SECOND)
+            if (best_v > 0.0) atomicMax(&a.theta[prn], (unsigned long long)__double_as_longlong(best_v));   // (positive doubles order as integers)
     }
 }
 
@@ -522,6 +533,81 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
         if (mode < 0) one_unit<true>(a, lds4, tid, prn, bin, mode, rec_slot FUSED_STAMP_ARG);
         else one_unit<false>(a, lds4, tid, prn, bin, mode, rec_slot FUSED_STAMP_ARG);
     }
+}
+
+// The second sweep of a map-free search in one launch of n_prn x 5 workgroups: workgroup (PRN p, round rho) finds PRN p's first
+// peak from the records of the first sweep (every one of the five the same few KB: cheaper than a launch in front of it;
+// the round-0 workgroup hands it on), then does round rho of that PRN's winning row with the maximum over the allowed
+// columns -- five records sets of kRecordsPerTransform per PRN in `seconds` for the ratio kernel.  Replaces the peak
+// kernel and the general four-step pair (three launches, ~26 us of a 32-PRN call).
+struct SecondArgs {
+    Args a;                    // spec / code_spec / tw / scale as in the first sweep; a.partials = seconds
+    const Best* recs;          // [n_prn][per_prn] records of the first sweep
+    int per_prn, n_prn;
+    int spc;                   // samples per chip (the exclusion window's half width)
+    Best* tops;                // [n_prn] out
+    long long* out_bin;        // [n_prn] out
+    long long* out_code;
+};
+
+__global__ __launch_bounds__(kThreads) void ifft_second_kernel(const SecondArgs s) {
+    extern __shared__ double2 lds4[];
+    const int tid = threadIdx.x;
+    // (the five workgroups of a PRN read the same two 400 KB arrays: block numbers equal modulo 8 share an XCD's L2)
+    const int prn8 = (int)(gridDim.x / 5);
+    const int rho = blockIdx.x / prn8, prn = blockIdx.x - rho * prn8;
+    if (prn >= s.n_prn) return;
+    // first peak: larger value, smaller flat index on ties (np.argmax's first occurrence)
+    Best* const sh = reinterpret_cast<Best*>(lds4);
+    {
+        double v = -1.0;
+        long long i = 0x7fffffffffffffffLL;
+        for (int k = tid; k < s.per_prn; k += kThreads) {
+            const Best b = s.recs[(size_t)prn * s.per_prn + k];
+            if (b.v > v || (b.v == v && b.i < i)) v = b.v, i = b.i;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_down(v, off, 64);
+            const long long oi = __shfl_down(i, off, 64);
+            if (ov > v || (ov == v && oi < i)) v = ov, i = oi;
+        }
+        if ((tid & 63) == 0) sh[tid >> 6] = Best{v, i};
+    }
+    __syncthreads();
+    Best top = sh[0];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w)
+        if (sh[w].v > top.v || (sh[w].v == top.v && sh[w].i < top.i)) top = sh[w];
+    if (top.v < 0.0) top.i = 0;          // (no record at all: never an index a row is read with)
+    const int bin = __builtin_amdgcn_readfirstlane((int)(top.i / N));
+    const int code = __builtin_amdgcn_readfirstlane((int)(top.i - (long long)bin * N));
+    if (rho == 0 && tid == 0) {
+        s.tops[prn] = top;
+        s.out_bin[prn] = bin;
+        s.out_code[prn] = code;
+    }
+    int a1 = 0, b0 = 0, b1 = 0;
+    {
+        const int e0 = code - s.spc, e1 = code + s.spc;
+        if (e0 < 1) {
+            b0 = e1;
+            b1 = N - 1;
+        } else if (e1 >= N) {
+            a1 = e0;
+        } else {
+            a1 = e0;
+            b0 = e1;
+            b1 = N - 1;
+        }
+    }
+    __syncthreads();                     // (the record scratch is the first buffer)
+#ifdef SDR_FUSED_STAMPS
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+    one_unit<false, true>(s.a, lds4, tid, prn, bin, rho, prn * 5 + rho, a1, b0, b1, stamp_);
+#else
+    one_unit<false, true>(s.a, lds4, tid, prn, bin, rho, prn * 5 + rho, a1, b0, b1);
+#endif
 }
 
 // Processing order and record slots of a search over bins [0, nbins) x n_prn PRNs.  The first `bins_whole` bins are done

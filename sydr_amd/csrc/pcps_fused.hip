@@ -71,6 +71,30 @@ int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void
     return SDR_OK;
 }
 
+int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int N, int spc, const void* recs,
+                          int per_prn, void* tops, void* dev_bin, void* dev_code, void* seconds) {
+    if (N != fused25k::N) return sdr_fail(SDR_ERR_UNSUPPORTED, "fused PCPS sweep: N = %d", N);
+    fused25k::SecondArgs s = {};
+    s.a.spec = (const double2*)F;
+    s.a.code_spec = (const double2*)C;
+    s.a.tw = (const double2*)tw;
+    s.a.scale = 1.0 / (double)N;
+    s.a.partials = (Best*)seconds;
+    s.recs = (const Best*)recs;
+    s.per_prn = per_prn;
+    s.n_prn = n_prn;
+    s.spc = spc;
+    s.tops = (Best*)tops;
+    s.out_bin = (long long*)dev_bin;
+    s.out_code = (long long*)dev_code;
+    (void)hipFuncSetAttribute((const void*)fused25k::ifft_second_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)fused25k::kLdsBytes);
+    ProfScope ps(e, "pcps_inv_fft");
+    hipLaunchKernelGGL(fused25k::ifft_second_kernel, dim3(5 * ((n_prn + 7) / 8 * 8)), dim3(fused25k::kThreads), fused25k::kLdsBytes, e->stream, s);
+    SDR_HIP(hipGetLastError());
+    return SDR_OK;
+}
+
 #ifdef SDR_FUSED_STAMPS
 extern "C" int sdr_debug_fused_stamps(unsigned long long* out, int reset) {
     if (out) SDR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(fused25k::g_fused_stamps), sizeof(unsigned long long) * 256 * 8));
