@@ -17,6 +17,7 @@
 // file is the host side: launch geometry, the sdr_track_closed_loop* entry points and the device-resident channel
 // bank (sdr_bank_*).
 #include "correlator.h"
+#include "correlator_chip.h"
 
 #include <cstring>
 
@@ -666,9 +667,37 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         if (!single) {
             const bool boundary_ok = use_prefix && ep.code_step >= kFastMinCodeStep && !epoch_wraps(ep, capacity);  // (uniform)
             EpochConsts<kTaps> K;
+            // (uniform) the chip-aligned core will be tried: it reads the taps' constants only, not the in-group rotations
+            bool try_chip = false;
+#ifndef SDR_TRACK_NO_CHIP
+            // (the 256-thread dense form only: in the 512-thread form a lane owns two chips and the routine's per-epoch part
+            // outweighs them -- measured 10.1 against 9.4 us per epoch at 256 channels)
+            if constexpr (FMT == SDR_FMT_CI8 && kTaps == 3 && !kCluster && THREADS == 256)
+                try_chip = boundary_ok && ep.code_step >= kChipMinCodeStep && ep.code_step <= kChipMaxCodeStep && ring_pos + ep.n + 32 <= capacity;
+#endif
+            // (the in-group rotations are computed either way: taking compute_tap_constants() on the chip path and these only
+            // on a fallback was measured at 26.5 instead of 15.8 us per epoch in the 168-register form -- it spills)
             compute_constants<kTaps>(K, ep, sh->spacing, dphi, cluster_lanes);
             TRACK_MARK(1);
-            if (boundary_ok && ep.code_step <= kFastMaxCodeStep)         // 16-sample boundary variant above ~17 MHz
+            // one-workgroup forms, ci8, three taps, 24 / 25 samples per chip (the headline 25 MHz): lanes own whole chips
+            // (correlator_chip.h, block length compiled in, tap positions at run time: ~14 instead of ~17.5 issue slots per
+            // sample); its strips and rotations live where the boundary variants keep their prefix sums
+            bool chip_done = false;
+#ifndef SDR_TRACK_NO_CHIP
+            if constexpr (FMT == SDR_FMT_CI8 && kTaps == 3 && !kCluster && THREADS == 256) {
+                static_assert(THREADS * chip_strip_slots<3>() + (THREADS / 64) * kChipMax <= THREADS * kPrefixSlots, "strips + rotations fit the prefix area");
+                if (try_chip) {
+                    ChipGeom<3> G;
+                    chip_geometry<3, 24, 0, 0>(ep.n, K.shift, K.step, K.inv_step, G);
+                    if (!__builtin_amdgcn_readfirstlane(G.bad))
+                        chip_done = correlate_epoch_chip<3, false, 24, 0, 0>(ring, nullptr, capacity, ep, dphi, K, G, ring_pos, nullptr, lut, prefix,
+                                                                             prefix + THREADS * chip_strip_slots<3>() + (tid >> 6) * kChipMax,
+                                                                             tid, lane_global, cluster_lanes, edge_lane, accr, acci);
+                }
+            }
+#endif
+            if (chip_done) {
+            } else if (boundary_ok && ep.code_step <= kFastMaxCodeStep)         // 16-sample boundary variant above ~17 MHz
                 correlate_epoch_wide<FMT, kTaps, false, 16>(ring, capacity, ep, dphi, K, lut, prefix, tid, lane_global, cluster_lanes, edge_lane, accr, acci);
             else if (boundary_ok && ep.code_step <= kFastMaxCodeStep8)   // 8-sample boundary variant above ~8.2 MHz
                 correlate_epoch_wide<FMT, kTaps, false, 8>(ring, capacity, ep, dphi, K, lut, prefix, tid, lane_global, cluster_lanes, edge_lane, accr, acci);
