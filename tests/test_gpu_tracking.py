@@ -220,6 +220,48 @@ def test_closed_loop_more_channels_than_compute_units(engine):
     assert traj[5].tobytes() == traj[200].tobytes()      # same inputs, same kernel: bitwise the same
 
 
+@pytest.mark.parametrize("kind", [1, 0])
+def test_dense_form_at_25_mhz_matches_the_oracle_loops(engine, kind):
+    """More channels than compute units at the headline rate: the 256-thread kernel (three workgroups per CU) correlates
+    with the chip-aligned core there (correlator_chip.h: block length compiled in, tap positions at run time) instead of
+    the 16-sample boundary groups.  260 channels on one synthetic stream from the same state: the oracle's loops (pinned
+    by the goldens) over the same stream give the same integers and the same loop quantities, for both plugins."""
+    fs, ms, prn = 25e6, 130, 11
+    n = int(ms * fs * 1e-3)
+    sat = dict(prn=prn, doppler=-1750.0, code_phase=893.6, phase=0.4, amp=9.0)
+    engine.iq_alloc(n, FMT_CI8)
+    engine.code_slots(1)
+    engine.load_gps_code(0, prn)
+    engine.iq_synth([sat], fs, 14.0, 4711, 0, n)
+    rf = orc.iq_to_complex(engine.iq_download(n, 0))
+    pb, pc, _, _ = engine.pcps([0], 0, fs, 0.0, 5000.0, 250.0, 1, 1)
+    n_code = orc.samples_per_code(fs)
+    n0 = orc.required_samples(0.0, orc.CODE_RATE / fs)
+    carrier, _, cur = orc.post_acquisition(0.0, 5000.0, 250.0, [int(pb[0]), int(pc[0])], 0, n_code, n0)
+    c = KAPLAN_CFG if kind == 1 else BORRE_CFG
+    loop = (orc.KaplanLoop if kind == 1 else orc.BorreLoop)(fs, orc.gold_code(prn), c, carrier, cur)
+    epochs = 100
+    ref = [loop.step(rf[loop.current_sample:loop.current_sample + loop.n]) for _ in range(epochs)]
+    n_ch = 260
+    states, traj = engine.track_closed_loop([initial_state(kind, fs, carrier, cur, c) for _ in range(n_ch)], loop_cfg(kind, fs, c), epochs)
+    corr_ref = np.array([r["corr"] for r in ref])
+    for k in (0, 131, 259):
+        tr = traj[k]
+        assert np.array_equal(tr["start_sample"], [r["start"] for r in ref])
+        assert np.array_equal(tr["n_samples"], [r["n"] for r in ref])
+        for t in range(3):
+            mag = np.hypot(corr_ref[:, 2 * t], corr_ref[:, 2 * t + 1])
+            err = np.hypot(tr["corr"][:, 2 * t] - corr_ref[:, 2 * t], tr["corr"][:, 2 * t + 1] - corr_ref[:, 2 * t + 1])
+            assert np.all(err <= RTOL * np.maximum(mag, 1.0)), (k, t, (err / mag).max())
+        assert close(tr["carrier_hz"], [r["carrier_hz"] for r in ref]) and close(tr["code_hz"], [r["code_hz"] for r in ref])
+        assert close(tr["carrier_err"], [r["carrier_err"] for r in ref], scale=1.0)
+        assert close(tr["code_err"], [r["code_err"] for r in ref], scale=1.0)
+        if kind == 1:
+            assert np.array_equal(tr["lock_state"], [r["lock_state"] for r in ref])
+            assert np.array_equal(tr["track_flags"], [r["flags"] for r in ref])
+    assert traj[7].tobytes() == traj[201].tobytes()      # same inputs, same kernel: bitwise the same
+
+
 def test_closed_loop_across_the_ring_seam_at_25_mhz(engine):
     """A 100 ms ring (the reference's size) fed block by block: epochs that straddle the end of the ring take the
     per-sample correlator, the others the boundary variant -- the trajectory is that of the uninterrupted stream."""
