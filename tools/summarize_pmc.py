@@ -33,7 +33,7 @@ tree_build = _sydr_lib.source_build_id()
 if profiled_build != tree_build and not force:
     sys.exit(f"summarize_pmc: the profile in {src} was taken on build {profiled_build or '(unknown)'}, the sources in the tree are "
              f"build {tree_build}: re-take the profile (tools/profile_round.sh) instead of summarising a stale one (--force overrides)")
-PCPS = ("fft4_rows_kernel", "fft4_cols_kernel", "fast25k", "fused25k", "fastn::", "mag_acc_kernel", "fft_pass_kernel", "argmax", "ratio_kernel", "peak_", "second_peak",
+PCPS = ("fft4_rows_kernel", "fft4_cols_kernel", "fast25k", "fused25k", "fastn::", "mag_acc_kernel", "peak_finish_kernel", "argmax_part_kernel", "fft_pass_kernel", "argmax", "ratio_kernel", "peak_", "second_peak",
         "chirp", "upsample_batch_kernel", "mix_", "twiddle_kernel")
 
 
@@ -134,7 +134,7 @@ def pcps_calls(counter, marker=("fast25k", "fused25k")):
             if not any(k.startswith(p) for p in PCPS):
                 continue
             cur.append((k, float(r["Counter_Value"])))
-            if k == "ratio_kernel":
+            if k in ("ratio_kernel", "peak_finish_kernel"):        # (the call's last kernel: map-free / with a map)
                 if any(name.startswith(marker) for name, _ in cur):
                     calls += 1
                     for name, v in cur:
@@ -194,5 +194,13 @@ if os.path.exists(log) and os.path.exists(stats):
                    if any(p in r["Name"] for p in PCPS))
     rec["rocprof_kernel_ms_per_call"] = total_ns / 1e6 / rec["calls"]
     rec["agreement"] = rec["rocprof_kernel_ms_per_call"] / rec["hip_event_kernel_ms_per_call"]
+    # (the event pair of the traced process also spans what the tracer adds between a call's kernels; the figure bench.py
+    # reports comes from an untraced process: held against that one too)
+    plain = os.path.join(src, "bench_plain_run.json")
+    try:
+        rec["bench_kernel_ms_32_prn_untraced"] = json.load(open(plain))["acquisition"]["kernel_ms_32_prn"]
+        rec["agreement_with_untraced_bench"] = rec["rocprof_kernel_ms_per_call"] / rec["bench_kernel_ms_32_prn_untraced"]
+    except Exception:
+        pass
     json.dump(rec, open(os.path.join(prof, f"{tag}_pcps_one_stream.json"), "w"), indent=1)
     print(json.dumps(rec))
