@@ -461,8 +461,9 @@ def ref_config_leg(eng, cpu_seconds=4.0):
     cpu_ms = (time.perf_counter() - t0) / 2 * 1e3
     if not ok:
         raise SystemExit("PCPS peak mismatch vs oracle in the ref_config leg")
-    # SURVEY 8d per (PRN, bin) and millisecond block: 16 spectrum + 16 code spectrum + 8 of the map that accumulates the blocks
-    algo = N_CH * bins * noncoh * 40.0 * n_code
+    # SURVEY 8d per (PRN, bin) and millisecond block: 16 spectrum + 16 code spectrum; the 8 of a map that accumulates the blocks
+    # are not charged: the call asks for indices and ratio and the search keeps the non-coherent sum in registers (pcps_fused10k.h)
+    algo = N_CH * bins * noncoh * 32.0 * n_code
     acquisition = {"metric": "acquisition ms/PRN", "value": acq_ms / N_CH, "unit": "ms/PRN", "ms_total_32_prn": acq_ms,
                    "kernel_ms_32_prn": pk_ms, "cpu_ms_per_prn_1core": cpu_ms, "peaks_match_oracle": bool(ok),
                    "roofline": {"bound": "hbm", "achieved": algo / (pk_ms * 1e-3) / 1e9 if pk_ms else 0.0, "peak": HBM_PEAK_GBS,
@@ -475,7 +476,8 @@ def ref_config_leg(eng, cpu_seconds=4.0):
         acquisition["roofline"]["traffic_over_algorithmic"] = info["pcps_10mhz_hbm_bytes_per_call"] / algo
     return {"config": {"workload": "the reference's shipped configuration: fs=10 MHz ci8 (config/receiver.ini:18-20), 32 channels, "
                                    "E/P/L +-0.5 chip, 20 s stream in one launch per pass; PCPS +-5 kHz @ 300 Hz (34 bins), "
-                                   "1 ms x 10 non-coherent (channel_GPS_L1CA_kaplan.ini:6-10), code spectra cached between calls"},
+                                   "1 ms x 10 non-coherent (channel_GPS_L1CA_kaplan.ini:6-10), indices + ratio (no map: 32 N bytes per "
+                                   "(PRN, bin, block)), code spectra cached between calls"},
             "tracking": tracking, "acquisition": acquisition}
 
 

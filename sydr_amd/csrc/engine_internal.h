@@ -169,6 +169,12 @@ int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void
 // records per PRN that sweep leaves (PRN-major: [prn][records]); a search that is not a whole number of rounds of its 256
 // workgroups has its last transforms cut into five units of SDR_PCPS_FUSED_RECORDS records each
 int sdr_pcps_fused_records_per_prn(int n_prn, int nbins);
+// pcps_fused10k.h: a search at N = 10 000 that wants indices and ratio only (coh = 1, any number of non-coherent blocks): one
+// workgroup per (PRN, bin) keeps the transform in its LDS and the non-coherent sum in registers; F_all = [noncoh][nbins][N]
+// forward spectra, records = n_prn * nbins * SDR_PCPS_FUSED10K_RECORD_BYTES bytes of scratch; the results go to out_*.
+#define SDR_PCPS_FUSED10K_RECORD_BYTES 32
+int sdr_pcps_fused10k_search(sdr_engine* e, const void* F_all, const void* C, const void* tw, int n_prn, int nbins, int noncoh, int N, int spc,
+                             void* records, void* out_bin, void* out_code, void* out_ratio);
 // The second sweep of such a search in one launch: the first peaks from `recs` ([n_prn][per_prn] records) into tops / dev_bin /
 // dev_code, and 5 x SDR_PCPS_FUSED_RECORDS records per PRN of its winning row's allowed columns into `seconds`.
 int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int N, int spc, const void* recs,

@@ -66,6 +66,8 @@ struct PassArgs {
     // STORE_MAG_MAX of the register-resident kernels: `in` starts at Doppler bin bin0 of the search (a sweep over the last
     // bins only: the fused sweep took the others) -- added to the bin of the records' flat index
     int bin0;
+    // LOAD_IQ_MIX over several blocks at once: bins per block (0: the batch is one block's bins)
+    int iq_blocks;
 };
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
@@ -182,7 +184,11 @@ __device__ __forceinline__ double2 load_elem(const PassArgs& a, int batch, int i
         return a.in[(size_t)batch * a.N + idx];
     } else if (LOAD == LOAD_IQ_MIX) {
         // acquisition.py:33,42-45,53: carrier = exp(-1j*freq*phasePoints), phasePoints[m] = ((m*2)*pi)/fs
-        int64_t pos = (a.first_sample + idx) % a.capacity;
+        // (iq_blocks > 0: the batch holds that many Doppler bins of several consecutive blocks of N samples -- transform b is
+        // bin b % iq_blocks of block b / iq_blocks: every non-coherent block of a search in one launch)
+        const int blk = a.iq_blocks > 0 ? batch / a.iq_blocks : 0;
+        batch -= blk * a.iq_blocks;
+        int64_t pos = (a.first_sample + (int64_t)blk * a.N + idx) % a.capacity;
         double2 x = ring_sample<FMT>(a.ring, pos);
         double bin = a.bin_start + (double)batch * a.bin_delta;
         double freq = a.if_hz - bin;
@@ -1083,7 +1089,7 @@ void run_fft(sdr_engine* e, const std::vector<int>& radices, PassArgs a, int bat
 template <int FMT>
 int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int n_prn, int64_t start, double fs, double if_hz,
              double bin_start, double bin_delta, int nbins, int N, int spc, int coh, int noncoh,
-             const std::vector<int>& radices, int prn_chunk, bool have_spectra, const BluPlan* blu, bool map_free) {
+             const std::vector<int>& radices, int prn_chunk, bool have_spectra, const BluPlan* blu, bool map_free, bool fused10k) {
     double2* F = (double2*)e->pcps_fwd.ptr;
     double2* A = (double2*)e->pcps_a.ptr;
     double2* B = (double2*)e->pcps_b.ptr;
@@ -1126,6 +1132,29 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
         e->pcps_spec_key = key;
     }
 
+    if (fused10k) {
+        // N = 10 000, indices and ratio only, one coherent millisecond per block: the forward transforms of every block
+        // first, then ONE launch that keeps each (PRN, bin)'s transform in LDS and its non-coherent sum in registers and
+        // finds both peaks (pcps_fused10k.h) -- no map, no intermediate, no second sweep
+        {
+            PassArgs f = {};
+            f.tw = tw;
+            f.N = N;
+            f.ring = e->iq;
+            f.capacity = e->iq_capacity;
+            f.first_sample = start;
+            f.carrier_offset = 0;            // (one coherent millisecond per block: the carrier restarts with every block)
+            f.fs = fs;
+            f.if_hz = if_hz;
+            f.bin_start = bin_start;
+            f.bin_delta = bin_delta;
+            f.iq_blocks = nbins;             // all blocks in one batch: [block][bin]
+            run_fft<false, LOAD_IQ_MIX, STORE_PLAIN, FMT>(e, radices, f, nbins * noncoh, A, B, F, "pcps_fwd_fft", blu);
+        }
+        long long* out_bin = e->pcps_res_direct ? (long long*)e->pcps_res_direct : (long long*)e->pcps_res.ptr;
+        return sdr_pcps_fused10k_search(e, F, C, tw, n_prn, nbins, noncoh, N, spc, e->pcps_part.ptr, out_bin, out_bin + n_prn,
+                                        (double*)(out_bin + 2 * n_prn));
+    }
     for (int inc = 0; inc < noncoh; ++inc) {
         for (int ic = 0; ic < coh; ++ic) {
             // Forward transforms of the Doppler-mixed millisecond, all bins at once.
@@ -1378,17 +1407,21 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
         }
     }
     if (e->pcps_prn_chunk > 0) prn_chunk = std::min(prn_chunk, e->pcps_prn_chunk);
+    // (32 units and more: below that the two-kernel path's many small workgroups finish sooner than one unit per CU)
+    const bool fused10k = !corr_map && coh == 1 && N == 10000 && !use_blu && four.ok && !e->pcps_force_passes && !e->pcps_force_map &&
+                          e->pcps_fused && !e->pcps_no_fast && (int64_t)n_prn * nbins >= 32;
     if (nbins > 65535 || n_prn > 65535) return sdr_fail(SDR_ERR_UNSUPPORTED, "grid too large");
-    const size_t work = tbytes * (size_t)std::max(prn_chunk * nbins, std::max(n_prn, nbins));
-    int rc = sdr_devbuf_reserve(e, &e->pcps_fwd, tbytes * (size_t)std::max(nbins, n_prn));
+    const size_t work = tbytes * (size_t)std::max(fused10k ? nbins * noncoh : prn_chunk * nbins, std::max(n_prn, nbins));
+    int rc = sdr_devbuf_reserve(e, &e->pcps_fwd, tbytes * (size_t)std::max(fused10k ? nbins * noncoh : nbins, n_prn));
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_a, work);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_b, work);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_code, tbytes * n_prn);
     // (the fused sweep leaves at most 5 x SDR_PCPS_FUSED_RECORDS records per transform)
     const size_t n_records = map_free ? (size_t)n_prn * (nbins + 1) * std::max(std::max(records_per_transform(four), records_main_sweep(e, four)), 5 * SDR_PCPS_FUSED_RECORDS) + n_prn : 0;
-    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_map, (size_t)n_prn * (map_free ? 1 : nbins) * N * sizeof(double));
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_map, (size_t)n_prn * ((map_free || fused10k) ? 1 : nbins) * N * sizeof(double));
     if (!rc && coh > 1) rc = sdr_devbuf_reserve(e, &e->pcps_csum, (size_t)n_prn * nbins * tbytes);
-    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_part, std::max((size_t)n_prn * kPeakParts, n_records) * sizeof(Best));
+    if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_part, std::max(std::max((size_t)n_prn * kPeakParts, n_records) * sizeof(Best),
+                                                                 fused10k ? (size_t)n_prn * nbins * SDR_PCPS_FUSED10K_RECORD_BYTES : 0));
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_res, (size_t)n_prn * 3 * sizeof(double) + n_prn * sizeof(int32_t));
     if (rc) return rc;
     if (e->pcps_tw_n != N) {
@@ -1455,10 +1488,10 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     // (one event pair around every kernel of the search: its in-stream time; while it records, the search stays on one stream)
     ProfScope whole(e, "call_pcps");
     switch (e->iq_fmt) {
-        case SDR_FMT_CI8: rc = pcps_run<SDR_FMT_CI8>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
-        case SDR_FMT_CI16: rc = pcps_run<SDR_FMT_CI16>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
-        case SDR_FMT_CF32: rc = pcps_run<SDR_FMT_CF32>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
-        default: rc = pcps_run<SDR_FMT_CF64>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free); break;
+        case SDR_FMT_CI8: rc = pcps_run<SDR_FMT_CI8>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free, fused10k); break;
+        case SDR_FMT_CI16: rc = pcps_run<SDR_FMT_CI16>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free, fused10k); break;
+        case SDR_FMT_CF32: rc = pcps_run<SDR_FMT_CF32>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free, fused10k); break;
+        default: rc = pcps_run<SDR_FMT_CF64>(e, d_slots, code_slots, n_prn, start_sample, fs, if_hz, bin_start, bin_delta, nbins, N, spc, coh, noncoh, radices, prn_chunk, hs, use_blu ? &blu : nullptr, map_free, fused10k); break;
     }
     }
     e->pcps_res_direct = nullptr;

@@ -9,7 +9,9 @@
 
 namespace {
 #include "pcps_fused.h"
+#include "pcps_fused10k.h"
 static_assert(fused25k::kRecordsPerTransform == SDR_PCPS_FUSED_RECORDS, "records per transform");
+static_assert(sizeof(fused10k::UnitRecord) == SDR_PCPS_FUSED10K_RECORD_BYTES, "unit record");
 }  // namespace
 
 // How the fused sweep cuts a search of n_prn x nbins transforms: whole transforms for the bins that fill whole rounds of
@@ -91,6 +93,30 @@ int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* C, const voi
                               (int)fused25k::kLdsBytes);
     ProfScope ps(e, "pcps_inv_fft");
     hipLaunchKernelGGL(fused25k::ifft_second_kernel, dim3(5 * ((n_prn + 7) / 8 * 8)), dim3(fused25k::kThreads), fused25k::kLdsBytes, e->stream, s);
+    SDR_HIP(hipGetLastError());
+    return SDR_OK;
+}
+
+int sdr_pcps_fused10k_search(sdr_engine* e, const void* F_all, const void* C, const void* tw, int n_prn, int nbins, int noncoh, int N, int spc,
+                             void* records, void* out_bin, void* out_code, void* out_ratio) {
+    if (N != fused10k::N) return sdr_fail(SDR_ERR_UNSUPPORTED, "fused 10 MHz PCPS search: N = %d", N);
+    fused10k::Args a = {};
+    a.spec = (const double2*)F_all;
+    a.code_spec = (const double2*)C;
+    a.tw = (const double2*)tw;
+    a.n_prn = n_prn, a.nbins = nbins, a.noncoh = noncoh, a.spc = spc;
+    a.scale = 1.0 / (double)N;
+    a.records = (fused10k::UnitRecord*)records;
+    (void)hipFuncSetAttribute((const void*)fused10k::search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused10k::kLdsBytes);
+    {
+        ProfScope ps(e, "pcps_inv_fft");
+        hipLaunchKernelGGL(fused10k::search_kernel, dim3(256), dim3(fused10k::kThreads), fused10k::kLdsBytes, e->stream, a);
+    }
+    {
+        ProfScope ps(e, "pcps_peak");
+        hipLaunchKernelGGL(fused10k::peaks_kernel, dim3(n_prn), dim3(64), 0, e->stream, a.records, nbins, (long long*)out_bin,
+                           (long long*)out_code, (double*)out_ratio);
+    }
     SDR_HIP(hipGetLastError());
     return SDR_OK;
 }

@@ -315,6 +315,48 @@ def test_fused_sweep_vs_two_kernel_sweeps_and_oracle(engine, n_prn, drange, dste
     assert np.all(pb == 0) and np.all(pc == 0)
 
 
+@pytest.mark.parametrize("n_prn,noncoh,drange,dstep,if_hz", [(32, 10, 5000.0, 300.0, 0.0), (4, 10, 5000.0, 300.0, 0.0), (32, 1, 5000.0, 250.0, 0.0),
+                                                                 (1, 3, 5000.0, 250.0, 1250.0), (7, 2, 2000.0, 100.0, 0.0)])
+def test_fused_search_at_10_mhz_vs_the_map_accumulating_path_and_oracle(engine, n_prn, noncoh, drange, dstep, if_hz):
+    """The reference's shipped search (10 MHz, 300 Hz grid, 1 ms x 10 non-coherent) when the caller wants indices and ratio:
+    one workgroup per (PRN, bin) keeps the 10 000-point transform in its LDS, the non-coherent sum in registers, and finds
+    the row's first AND second peak itself (pcps_fused10k.h) -- no map, no second sweep.  Against the path that accumulates
+    the map in memory (`pcps_fused` = 0): same indices, ratio to rounding; against the oracle's map for the PRNs checked;
+    a constant stream (every value ties) gives the first index."""
+    fs = 10e6
+    rng = np.random.default_rng(1000 + n_prn + noncoh)
+    n = orc.samples_per_code(fs)
+    prns = [int(p) for p in rng.choice(np.arange(1, 33), n_prn, replace=False)]
+    sats = [dict(prn=p, doppler=float(rng.uniform(-3500, 3500)), code_phase=float(rng.uniform(0, 1023)),
+                 phase=float(rng.random()), amp=float(rng.uniform(4, 8))) for p in prns[::2]]
+    start = int(rng.integers(0, 64))
+    cap = (n * noncoh + start + 7) // 8 * 8
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.code_slots(n_prn)
+    for s, p in enumerate(prns):
+        engine.load_gps_code(s, p)
+    engine.iq_synth(sats, fs, 14.0, 777 + noncoh, 0, cap)
+    res = {}
+    for fused in (1, 0):
+        engine.set_option("pcps_fused", fused)
+        try:
+            res[fused] = engine.pcps(np.arange(n_prn), start, fs, if_hz, drange, dstep, 1, noncoh)
+        finally:
+            engine.set_option("pcps_fused", 1)
+    assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1], res[0][1])
+    np.testing.assert_allclose(res[1][2], res[0][2], rtol=1e-12, atol=0)
+    rf = orc.iq_to_complex(engine.iq_download(cap, 0))
+    x = rf[start:start + n * noncoh].reshape(1, -1)
+    for s in sorted({0, n_prn - 1}):
+        m = orc.pcps_map(x, if_hz, fs, orc.code_spectrum(orc.gold_code(prns[s]), fs), drange, dstep, n, 1, noncoh)
+        peak, ratio = orc.two_peak_compare(m, n, round(fs / orc.CODE_RATE))
+        assert peak == [int(res[1][0][s]), int(res[1][1][s])], prns[s]
+        assert res[1][2][s] == pytest.approx(ratio, rel=1e-9)
+    engine.iq_upload(np.zeros(2 * cap, dtype=np.int8), 0)
+    pb, pc, _, _ = engine.pcps(np.arange(n_prn), 0, fs, if_hz, drange, dstep, 1, noncoh)
+    assert np.all(pb == 0) and np.all(pc == 0)
+
+
 @pytest.mark.parametrize("fs", [25e6, 4e6, 10e6, 50e6])
 def test_register_resident_kernels_vs_oracle(engine, fs):
     """The map-free search at N = N1 x 200 (4 / 10 / 25 / 50 MHz) runs its inverse transforms through the
