@@ -33,13 +33,13 @@ tree_build = _sydr_lib.source_build_id()
 if profiled_build != tree_build and not force:
     sys.exit(f"summarize_pmc: the profile in {src} was taken on build {profiled_build or '(unknown)'}, the sources in the tree are "
              f"build {tree_build}: re-take the profile (tools/profile_round.sh) instead of summarising a stale one (--force overrides)")
-PCPS = ("fft4_rows_kernel", "fft4_cols_kernel", "fast25k", "fused25k", "fastn::", "mag_acc_kernel", "peak_finish_kernel", "argmax_part_kernel", "fft_pass_kernel", "argmax", "ratio_kernel", "peak_", "second_peak",
+PCPS = ("fft4_rows_kernel", "fft4_cols_kernel", "fast25k", "fused25k", "fused10k", "fastn::", "mag_acc_kernel", "peak_finish_kernel", "argmax_part_kernel", "fft_pass_kernel", "argmax", "ratio_kernel", "peak_", "second_peak",
         "chirp", "upsample_batch_kernel", "mix_", "twiddle_kernel")
 
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"((?:fast25k::|fused25k::|fastn::)?[A-Za-z0-9_]+)(<[^>]*>)?", name)
+    m = re.match(r"((?:fast25k::|fused25k::|fused10k::|fastn::)?[A-Za-z0-9_]+)(<[^>]*>)?", name)
     base, targs = m.group(1), m.group(2) or ""
     if base in ("epl_kernel", "epl2_kernel", "track_kernel", "fft4_rows_kernel", "fft4_cols_kernel", "fft_pass_kernel", "fastn::cols_kernel",
                 "fastn::rows_kernel"):
@@ -134,7 +134,7 @@ def pcps_calls(counter, marker=("fast25k", "fused25k")):
             if not any(k.startswith(p) for p in PCPS):
                 continue
             cur.append((k, float(r["Counter_Value"])))
-            if k in ("ratio_kernel", "peak_finish_kernel"):        # (the call's last kernel: map-free / with a map)
+            if k in ("ratio_kernel", "peak_finish_kernel", "fused10k::peaks_kernel"):   # (the call's last kernel: map-free / with a map / 10 MHz fused)
                 if any(name.startswith(marker) for name, _ in cur):
                     calls += 1
                     for name, v in cur:
@@ -153,7 +153,7 @@ if calls and calls_w:
                  "pcps_workload": "sdr_pcps: 32 PRNs x 41 bins x 25000 samples, no map (1.05e9 algorithmic bytes)"})
 # ... and of the searches at the other rates bench.py runs (their register-resident kernels carry N1 = N / 200 as a template
 # argument: 50 -> the reference's shipped 10 MHz, 250 -> 50 MHz)
-for marker, key, what in ((("fastn::cols_kernel<50,",), "pcps_10mhz", "ref_config leg: 32 PRNs x 34 bins x 10 blocks x 10000 samples, map accumulated"),
+for marker, key, what in ((("fastn::cols_kernel<50,", "fused10k::search_kernel"), "pcps_10mhz", "ref_config leg: 32 PRNs x 34 bins x 10 blocks x 10000 samples, indices + ratio (no map)"),
                           (("fastn::cols_kernel<250,",), "pcps_50mhz", "multignss leg: 32 PRNs x 41 bins x 50000 samples, no map")):
     f_k, c_f = pcps_calls("FETCH_SIZE", marker)
     w_k, c_w = pcps_calls("WRITE_SIZE", marker)
