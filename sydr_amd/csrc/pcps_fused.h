@@ -150,8 +150,10 @@ __device__ unsigned long long g_fused_stamps[256][8];
         if (tid == 0) g_fused_stamps[blockIdx.x][slot] += now_ - stamp_;   \
         stamp_ = now_;                                                     \
     } while (0)
+#define FUSED_DFLT(x)                 /* (the stamp reference follows these parameters: no defaults in this build) */
 #else
 #define FUSED_STAMP(slot) do { } while (0)
+#define FUSED_DFLT(x) = x
 #endif
 
 // One unit of work (a whole transform, or round `mode` of one) by the 512 threads of the workgroup.
@@ -160,7 +162,7 @@ __device__ unsigned long long g_fused_stamps[256][8];
 // no bound from the first sweep (the second peak lies below it).
 template <bool WHOLE, bool SECOND = false>
 __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int tid, const int prn, const int bin, const int mode,
-                                         const int rec_slot, const int a1 = 0, const int b0 = 0, const int b1 = 0
+                                         const int rec_slot, const int a1 FUSED_DFLT(0), const int b0 FUSED_DFLT(0), const int b1 FUSED_DFLT(0)
 #ifdef SDR_FUSED_STAMPS
                                          , unsigned long long& stamp_
 #endif
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
     extern __shared__ double2 lds4[];
 #ifdef SDR_FUSED_STAMPS
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
-#define FUSED_STAMP_ARG , stamp_
+#define FUSED_STAMP_ARG , 0, 0, 0, stamp_
 #else
 #define FUSED_STAMP_ARG
 #endif
