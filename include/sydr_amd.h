@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SDR_ABI_VERSION 4   /* 4: + sdr_build_id, sdr_epl_plan_create_dev (additive) */
+#define SDR_ABI_VERSION 4   /* 4: + sdr_build_id, sdr_epl_plan_create_dev, sdr_bank_tick_mirrored, sdr_iq_upload_begin (additive) */
 
 typedef struct sdr_engine sdr_engine;
 
@@ -89,7 +89,8 @@ int sdr_prof_reset(sdr_engine* e);
  * "pcps_fused" = 0 keeps a map-free search at 25 MHz on the two-kernel sweeps where one launch of persistent workgroups, one
  * (PRN, bin) transform per workgroup, would run (256 transforms or more); "pcps_no_spectra_cache" = 1
  * recomputes conj(fft(code)) in every search, as the reference does (channel_l1ca_kaplan.py:184-185), instead of keeping
- * the spectra of the staged codes; "epl_no_chip_variant",
+ * the spectra of the staged codes; "ingest_by_copy_command" = 1 moves the slabs of sdr_iq_upload_begin / sdr_bank_tick
+ * into the ring with a copy command instead of the ingest kernel; "epl_no_chip_variant",
  * "epl_no_split_variant", "epl_no_half_chip_view" = 1 keep the E/P/L correlator from its chip-aligned core, from the
  * kernel with the tap switch positions compiled in, from the half-chip view of 32-52 samples per chip.  Integer
  * results do not depend on any of them, floating ones to rounding. */
@@ -358,6 +359,45 @@ int sdr_bank_step(sdr_engine* e, sdr_bank* b, const int32_t* channels, int n_ch,
 int sdr_bank_tick(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
                   const int32_t* channels, int n_ch, sdr_track_epoch* records, sdr_track_state* states_out,
                   int32_t* epochs_done);
+
+/* The same tick with the reference's per-tick bookkeeping done here instead of in the caller's language: which
+ * channels are ready (channel.py:137-146 -- the ring holds their next epoch completely: getNbUnreadSamples >=
+ * track_requiredSamples), one epoch for those, and the caller's MIRRORS of the bank brought up to date in place --
+ * what ChannelManager.run() needs to make its TRACKING_UPDATE and CHANNEL_UPDATE packets (channelManager.py:149-188,
+ * channel.py:205-228) is in `records` / `updates` when the call returns.  Every array has max_channels rows and is
+ * owned by the caller; rows of channels that do not run are not touched. */
+typedef struct sdr_tick_update {      /* one CHANNEL_UPDATE (channel.py:205-228) */
+    int32_t channel;
+    int32_t track_flags;              /* the device's TrackingFlags bits | host_flags[channel]            */
+    int64_t unread;                   /* unprocessed_samples: getNbUnreadSamples(currentSample) afterwards */
+    int64_t epochs_since_tow;         /* code_since_tow                                                    */
+} sdr_tick_update;
+typedef struct sdr_tick_mirror {
+    int32_t max_channels;             /* rows of every array = the bank's max_channels                     */
+    int32_t reserved;
+    sdr_track_state* states;          /* in/out: state of every channel as last put / advanced             */
+    sdr_track_epoch* last;            /* out: the newest epoch record per channel                          */
+    int64_t* epochs_since_tow;        /* in/out (nullable): += 1 per epoch run (codeSinceTOW)              */
+    const uint8_t* tracking;          /* in: channel is in ChannelState.TRACKING                           */
+    uint8_t* lost;                    /* in/out: the device parked the channel (its NCO left the replica / the ring) */
+    const int64_t* host_flags;        /* in (nullable): TrackingFlags bits the host owns (the decoder's)   */
+    int32_t* ran;                     /* out: channels that completed an epoch in this tick, ascending     */
+    sdr_track_epoch* records;         /* out: their records, same order                                    */
+    sdr_tick_update* updates;         /* out: one row per channel with tracking != 0, ascending            */
+    int32_t n_ran, n_updates;         /* out                                                               */
+    int32_t n_nav_bits;               /* out: records of this tick with nav_bit >= 0                       */
+    int32_t n_lost;                   /* out: channels parked by this tick                                 */
+    int64_t max_unread;               /* out: largest `unread` among the channels still running            */
+} sdr_tick_mirror;
+/* iq may be NULL / n_samples 0 when the slab was handed over with sdr_iq_upload_begin already; write_index = the
+ * ring's write index AFTER this tick's slab (CircularBuffer.idxWrite). */
+int sdr_bank_tick_mirrored(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
+                           int64_t write_index, sdr_tick_mirror* m);
+/* sdr_iq_upload without the wait: the samples are copied out of `iq` before the call returns (the caller may reuse
+ * its buffer), their transfer into the ring is queued on the engine's stream and ordered before everything queued
+ * there afterwards (slabs above 1 MiB are uploaded synchronously).  sdr_engine_sync completes it for readers on
+ * other streams.  Lets addNewRFData start the transfer while the caller is still on its way to run(). */
+int sdr_iq_upload_begin(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset);
 
 /* ------------------------------------------------- streams (one per channel batch)
  * north_star: "one HIP stream per channel batch".  Stream ids are small positive integers owned by the engine;

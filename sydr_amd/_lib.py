@@ -94,6 +94,25 @@ TRACK_EPOCH_DTYPE = np.dtype([("start_sample", np.int64), ("n_samples", np.int32
                               ("cn0", np.float64), ("pll_lock", np.float64), ("fll_lock", np.float64),
                               ("track_flags", np.int32), ("nav_bit", np.int32)], align=True)
 
+
+
+class TickUpdate(C.Structure):
+    _fields_ = [("channel", C.c_int32), ("track_flags", C.c_int32), ("unread", C.c_int64), ("epochs_since_tow", C.c_int64)]
+
+
+TICK_UPDATE_DTYPE = np.dtype(TickUpdate)
+
+
+class TickMirror(C.Structure):
+    """sdr_tick_mirror (include/sydr_amd.h): the caller's mirrors of the bank, updated in place by sdr_bank_tick_mirrored."""
+    _fields_ = [("max_channels", C.c_int32), ("reserved", C.c_int32),
+                ("states", C.c_void_p), ("last", C.c_void_p), ("epochs_since_tow", C.c_void_p),
+                ("tracking", C.c_void_p), ("lost", C.c_void_p), ("host_flags", C.c_void_p),
+                ("ran", C.c_void_p), ("records", C.c_void_p), ("updates", C.c_void_p),
+                ("n_ran", C.c_int32), ("n_updates", C.c_int32), ("n_nav_bits", C.c_int32), ("n_lost", C.c_int32),
+                ("max_unread", C.c_int64)]
+
+
 _VP = C.c_void_p
 _PROTOTYPES = {
     "sdr_last_error": (C.c_char_p, []),
@@ -147,6 +166,8 @@ _PROTOTYPES = {
     "sdr_bank_get": (C.c_int, [_VP, _VP, C.c_int, _VP]),
     "sdr_bank_step": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, _VP, _VP, _VP, _VP, C.c_int, _VP, C.c_int]),
     "sdr_bank_tick": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int, _VP, _VP, _VP]),
+    "sdr_bank_tick_mirrored": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.POINTER(TickMirror)]),
+    "sdr_iq_upload_begin": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64]),
     "sdr_stream_create": (C.c_int, [_VP, C.POINTER(C.c_int)]),
     "sdr_stream_sync": (C.c_int, [_VP, C.c_int]),
     "sdr_epl_plan_run_range_on": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int]),

@@ -53,6 +53,9 @@ class ChannelBank:
         self.tracking = np.zeros(self.max_channels, dtype=bool)            # channels in ChannelState.TRACKING
         self.lost = np.zeros(self.max_channels, dtype=bool)                # NCO ran away on the device: channel parked
         self._dirty = np.zeros(self.max_channels, dtype=bool)
+        self._any_dirty = False
+        self._kinds = None                                                 # cfg["loop_kind"] as a list (see kinds)
+        self._bound = None                                                 # the device's sdr_tick_mirror over these arrays
         self.nav_bits = [[] for _ in range(self.max_channels)]
 
     def grown(self, max_channels: int) -> "ChannelBank":
@@ -64,18 +67,31 @@ class ChannelBank:
         big.nav_bits[:n] = self.nav_bits
         big.decoders[:n] = self.decoders
         big._dirty[:n] = self.cfg["n_taps"] != 0
+        big._any_dirty = True
         self.close()
         return big
 
     # ------------------------------------------------------------------ mirror <-> HBM
     def touch(self, ch: int):
         self._dirty[ch] = True
+        self._any_dirty = True
+        self._kinds = None
 
     def flush(self):
         """Upload every channel whose mirror was written by the host since the last step."""
+        if not self._any_dirty:
+            return
         for ch in np.flatnonzero(self._dirty):
             self.device.put(int(ch), self.state[ch], self.cfg[ch])
         self._dirty[:] = False
+        self._any_dirty = False
+
+    @property
+    def kinds(self):
+        """cfg["loop_kind"] of every channel as a plain list (re-made after a channel was configured)."""
+        if self._kinds is None:
+            self._kinds = self.cfg["loop_kind"].tolist()
+        return self._kinds
 
     def refresh(self, ch: int):
         self.state[ch] = self.device.get(ch)
@@ -161,6 +177,33 @@ class ChannelBank:
             self._absorb(channels, rec.reshape(-1, 1), states, done)
         return rec, done
 
+    def tick_ready(self, raw, ring_offset):
+        """The whole tick in one library call (sdr_bank_tick_mirrored): readiness, one epoch for the ready channels,
+        this mirror updated in place.  -> (ran, records, updates, max_unread): OWNED copies of the channels that
+        completed an epoch, their records, and one sdr_tick_update row per tracking channel."""
+        self.flush()
+        dev = self.device
+        if self._bound is None:
+            self._bound = dev.bind_mirror(self.state, self.last, self.code_since_tow, self.tracking, self.lost, self.host_flags)
+        m = dev.tick_mirrored(raw, ring_offset, self.ring.idxWrite)
+        n = m.n_ran
+        ran, rec = dev.ran[:n].copy(), dev.records[:n].copy()
+        upd = dev.updates[:m.n_updates].copy()
+        if m.n_nav_bits:
+            bits, decoders, through_decoder = rec["nav_bit"], self.decoders, False
+            for r in np.flatnonzero(bits >= 0).tolist():
+                ch = int(ran[r])
+                if decoders[ch] is None:
+                    self.nav_bits[ch].append(int(bits[r]))
+                else:
+                    self._new_bit(ch, int(bits[r]), int(rec["track_flags"][r]), 0, 1)
+                    through_decoder = True
+            if through_decoder:     # the decoder owns flag bits and restarts the code count at a subframe (kaplan:833)
+                chans = upd["channel"]
+                upd["epochs_since_tow"] = self.code_since_tow[chans]
+                upd["track_flags"] = self.state["track_flags"][chans] | self.host_flags[chans]
+        return ran, rec, upd, m.max_unread
+
     def step(self, channels, n_epochs: int = 1, stream: int = 0):
         """`n_epochs` epochs for `channels`; returns (records [n][n_epochs], epochs_done [n])."""
         self.flush()
@@ -189,77 +232,239 @@ def tracking_packet(cid: int, kind: int, rec) -> dict:
     return pkt
 
 
-def tracking_packets_builder(cids, kinds, records):
-    """build(i) -> the TRACKING_UPDATE packet of row i, for a whole tick's records at once: the structured array is
-    turned into plain Python tuples in ONE call the first time any packet is read (field access on NumPy records costs
-    more per packet than the dict itself)."""
-    names = records.dtype.names
-    at = {name: k for k, name in enumerate(names)}
-    i_corr, i_chz, i_code, i_cerr, i_coderr = at["corr"], at["carrier_hz"], at["code_hz"], at["carrier_err"], at["code_err"]
-    i_dll, i_pll, i_fll, i_cn0, i_plock, i_flock, i_lock = (at["dll"], at["pll"], at["fll"], at["cn0"], at["pll_lock"],
-                                                            at["fll_lock"], at["lock_state"])
-    rows = []
+class LazyPacket(dict):
+    """A result packet (a dict, as the reference's channels send them) whose values are filled in when somebody asks
+    for one: it is born holding "cid" and "type" -- what `Receiver._updateDatabaseFromChannels` (receiver.py:291-299)
+    looks at to route it -- and everything else (`_src.full(cid)`) arrives on the first access to another key or to
+    the packet as a whole (len, iteration, items, ==, pickling ...).  Keys the consumer adds before that are kept.
+    At 32 channels the 64 dicts of a tick cost more host time than the tick's device call; most consumers read a
+    handful of keys of a handful of packets."""
+    __slots__ = ("_src",)
 
-    def build(i):
-        if not rows:
-            rows.extend(records.tolist())
-        r = rows[i]
-        corr = r[i_corr]
-        pkt = {"cid": int(cids[i]), "type": ChannelMessage.TRACKING_UPDATE,
+    def _fill(self):
+        try:
+            src = self._src
+        except AttributeError:
+            return
+        if src is None:
+            return
+        self._src = None
+        mine = dict.copy(self)
+        full = src.full(dict.__getitem__(self, "cid"))
+        dict.clear(self)
+        dict.update(self, full)
+        dict.update(self, mine)        # (what the consumer wrote meanwhile wins; "cid" / "type" keep their places)
+
+    def __missing__(self, key):
+        try:
+            pending = self._src is not None
+        except AttributeError:
+            pending = False
+        if not pending:
+            raise KeyError(key)
+        self._fill()
+        return dict.__getitem__(self, key)
+
+    def _filled(name):
+        plain = getattr(dict, name)
+
+        def method(self, *args, **kwargs):
+            self._fill()
+            return plain(self, *args, **kwargs)
+        method.__name__ = name
+        return method
+
+    for _name in ("__iter__", "__len__", "__contains__", "__reversed__", "__delitem__", "keys", "values", "items", "get",
+                  "pop", "popitem", "setdefault", "copy", "__repr__", "__or__", "__ror__", "__ior__"):
+        locals()[_name] = _filled(_name)
+    del _name, _filled
+
+    def __eq__(self, other):
+        if not isinstance(other, dict):      # (`packet == None` of receiver.py:292 must not cost a fill)
+            return NotImplemented
+        self._fill()
+        if isinstance(other, LazyPacket):
+            other._fill()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other):
+        eq = self.__eq__(other)
+        return eq if eq is NotImplemented else not eq
+
+    __hash__ = None
+
+    def clear(self):
+        self._src = None
+        dict.clear(self)
+
+    def __reduce_ex__(self, protocol):
+        self._fill()
+        return (dict, (dict.copy(self),))    # travels (pickle, queues) as the plain dict it stands for
+
+
+_TEMPLATES = {}     # (message type, cid) -> the two keys a packet is born with
+
+
+def packet_templates(kind, cids):
+    """The {"cid", "type"} dicts LazyPackets of `kind` for the channels `cids` (a list of ints) are copied from."""
+    out = []
+    for c in cids:
+        t = _TEMPLATES.get((kind, c))
+        if t is None:
+            t = _TEMPLATES[(kind, c)] = {"cid": c, "type": kind}
+        out.append(t)
+    return out
+
+
+class TrackingRows:
+    """Source of one tick's TRACKING_UPDATE packets (keys of channel_l1ca_kaplan.py:653-676 = the DB columns,
+    io/database.py:76-93; Borre has no lock indicators: channel_l1ca_borre.py:430-449 sends NaN / zeros there): the
+    tick's epoch records, turned into plain Python values in ONE call the first time any packet is filled (field
+    access on NumPy records costs more per packet than the dict itself)."""
+    __slots__ = ("cids", "kinds", "records", "_rows", "_row_of", "_templates")
+    _AT = {name: k for k, name in enumerate(TRACK_EPOCH_DTYPE.names)}
+
+    def __init__(self, cids, kinds, records, templates=None):
+        """cids: channel per record (array or list); kinds: loop kind per CHANNEL NUMBER (a list indexed by cid) or per
+        record (an array of len(cids))."""
+        self.cids, self.kinds, self.records = cids, kinds, records
+        self._rows = self._row_of = None
+        self._templates = templates
+
+    def __len__(self):
+        return len(self.cids)
+
+    def templates(self):
+        if self._templates is None:
+            cids = self.cids.tolist() if isinstance(self.cids, np.ndarray) else list(self.cids)
+            self._templates = packet_templates(ChannelMessage.TRACKING_UPDATE, cids)
+        return self._templates
+
+    def full(self, cid):
+        if self._rows is None:
+            self._rows = self.records.tolist()
+            cids = self.cids.tolist() if isinstance(self.cids, np.ndarray) else list(self.cids)
+            self._row_of = {c: i for i, c in enumerate(cids)}
+            if isinstance(self.kinds, np.ndarray):
+                self.kinds = dict(zip(cids, self.kinds.tolist()))
+        return self.row(self._row_of[cid], cid)
+
+    def row(self, i, cid):
+        at = self._AT
+        r = self._rows[i]
+        corr = r[at["corr"]]
+        pkt = {"cid": cid, "type": ChannelMessage.TRACKING_UPDATE,
                "i_early": corr[0], "q_early": corr[1], "i_prompt": corr[2], "q_prompt": corr[3], "i_late": corr[4],
-               "q_late": corr[5], "carrier_frequency": r[i_chz], "code_frequency": r[i_code],
-               "carrier_frequency_error": r[i_cerr], "code_frequency_error": r[i_coderr],
-               "dll": r[i_dll], "pll": r[i_pll], "fll": r[i_fll]}
-        if kinds[i] == KIND_KAPLAN:
-            pkt["cn0"], pkt["pll_lock"], pkt["fll_lock"] = r[i_cn0], r[i_plock], r[i_flock]
-            pkt["lock_state"] = LoopLockState(r[i_lock])
+               "q_late": corr[5], "carrier_frequency": r[at["carrier_hz"]], "code_frequency": r[at["code_hz"]],
+               "carrier_frequency_error": r[at["carrier_err"]], "code_frequency_error": r[at["code_err"]],
+               "dll": r[at["dll"]], "pll": r[at["pll"]], "fll": r[at["fll"]]}
+        if self.kinds[cid] == KIND_KAPLAN:
+            pkt["cn0"], pkt["pll_lock"], pkt["fll_lock"] = r[at["cn0"]], r[at["pll_lock"]], r[at["fll_lock"]]
+            pkt["lock_state"] = LoopLockState(r[at["lock_state"]])
         else:
             pkt["cn0"], pkt["pll_lock"], pkt["fll_lock"], pkt["lock_state"] = np.nan, 0.0, 0.0, 0
         return pkt
+
+
+def tracking_packets_builder(cids, kinds, records):
+    """build(i) -> the (eager) TRACKING_UPDATE packet of row i of a tick's records."""
+    src = TrackingRows(cids, kinds, records)
+
+    def build(i):
+        return src.full(int(cids[i]))
     return build
+
+
+class UpdateRows:
+    """Source of one tick's CHANNEL_UPDATE packets (channel.py:205-228) from values captured at the end of the tick.
+    `tow` is what the reference's `Channel.tow` holds: the int 0 until a subframe was decoded, then HOW TOW + 1.24 s
+    (kaplan:810-822)."""
+    __slots__ = ("cids", "states", "flags", "tows", "tow_decoded", "unread", "code", "samples_per_ms", "_rows", "_templates")
+
+    def __init__(self, cids, states, flags, tows, tow_decoded, unread, code_since_tow, samples_per_ms, templates=None):
+        """cids / flags / unread / code_since_tow: one value per packet; states: ChannelState per packet; tows /
+        tow_decoded: per packet (arrays of len(cids)) or per CHANNEL NUMBER (longer arrays, indexed by cid)."""
+        self.cids, self.states, self.flags, self.tows, self.tow_decoded = cids, states, flags, tows, tow_decoded
+        self.unread, self.code, self.samples_per_ms = unread, code_since_tow, samples_per_ms
+        self._rows = None
+        self._templates = templates
+
+    def __len__(self):
+        return len(self.cids)
+
+    def _cid_list(self):
+        return self.cids.tolist() if isinstance(self.cids, np.ndarray) else list(self.cids)
+
+    def templates(self):
+        if self._templates is None:
+            self._templates = packet_templates(ChannelMessage.CHANNEL_UPDATE, self._cid_list())
+        return self._templates
+
+    def full(self, cid):
+        if self._rows is None:
+            cids = self._cid_list()
+            tows, dec = np.asarray(self.tows), np.asarray(self.tow_decoded)
+            if len(tows) != len(cids):
+                tows, dec = tows[cids], dec[cids]
+            unread = np.asarray(self.unread)
+            code = np.asarray(self.code)
+            since = code + unread / self.samples_per_ms
+            self._rows = {c: row for c, row in zip(cids, zip(self.states, np.asarray(self.flags).tolist(), tows.tolist(),
+                                                             dec.tolist(), since.tolist(), unread.tolist(), code.tolist()))}
+        state, flags, tow, dec, since, unread, code = self._rows[cid]
+        return {"cid": cid, "type": ChannelMessage.CHANNEL_UPDATE, "state": state, "tracking_flags": _flags(flags),
+                "tow": tow if dec else 0, "time_since_tow": since, "unprocessed_samples": unread, "code_since_tow": code}
 
 
 class TickPackets(Sequence):
     """The flat packet list `ChannelManager.run()` returns (channelManager.py:149-188), built on demand.
 
     Everything a packet needs is captured when the tick ends (epoch records, flags, unread counts), so reading it
-    later gives what an eager list would have held; the dicts themselves are only made when somebody looks --
-    at 32 channels they cost more host time than the whole device step."""
+    later gives what an eager list would have held.  Nothing is made until somebody looks at the sequence; then the
+    tick's TRACKING_UPDATE / CHANNEL_UPDATE packets come as LazyPackets (two keys each, the rest on demand)."""
 
     def __init__(self):
-        self._parts = []      # (count, builder(i) -> dict)
-        self._cache = {}
+        self._parts = []      # (count, source with templates() / full(cid)  |  builder(i) -> dict)
+        self._list = None
         self._n = 0
 
     def add(self, count: int, builder):
         if count:
-            self._parts.append((self._n, count, builder))
+            self._parts.append((count, builder))
             self._n += count
+            self._list = None
+
+    def add_lazy(self, source):
+        """`source`: TrackingRows / UpdateRows -- len(), templates(), full(cid)."""
+        self.add(len(source), source)
 
     def add_ready(self, packets):
         packets = list(packets)
         self.add(len(packets), packets.__getitem__)
 
+    def _packets(self):
+        out = self._list
+        if out is None:
+            out = []
+            for count, src in self._parts:
+                if callable(src):
+                    out.extend(map(src, range(count)))
+                else:
+                    fresh = list(map(LazyPacket, src.templates()))
+                    for p in fresh:
+                        p._src = src
+                    out += fresh
+            self._list = out
+        return out
+
     def __len__(self):
         return self._n
 
     def __getitem__(self, i):
-        if isinstance(i, slice):
-            return [self[k] for k in range(*i.indices(self._n))]
-        if i < 0:
-            i += self._n
-        if not 0 <= i < self._n:
-            raise IndexError(i)
-        hit = self._cache.get(i)
-        if hit is None:
-            for first, count, builder in self._parts:
-                if first <= i < first + count:
-                    hit = self._cache[i] = builder(i - first)
-                    break
-        return hit
+        return self._packets()[i]
 
     def __iter__(self):
-        return (self[i] for i in range(self._n))
+        return iter(self._packets())
 
     def __eq__(self, other):
         return list(self) == list(other)
@@ -269,8 +474,7 @@ class TickPackets(Sequence):
 
 
 def channel_update_builder(cids, states, flags, tows, tow_decoded, since_tow_ms, unread, code_since_tow):
-    """CHANNEL_UPDATE packets (channel.py:205-228) from values captured at the end of the tick.  `tow` is what the
-    reference's `Channel.tow` holds: the int 0 until a subframe was decoded, then HOW TOW + 1.24 s (kaplan:810-822)."""
+    """build(i) -> the (eager) CHANNEL_UPDATE packet of row i."""
     def build(i):
         return {"cid": int(cids[i]), "type": ChannelMessage.CHANNEL_UPDATE, "state": states[i],
                 "tracking_flags": _flags(int(flags[i])), "tow": float(tows[i]) if tow_decoded[i] else 0,
@@ -279,5 +483,5 @@ def channel_update_builder(cids, states, flags, tows, tow_decoded, since_tow_ms,
     return build
 
 
-__all__ = ["ChannelBank", "TickPackets", "tracking_packet", "tracking_packets_builder", "channel_update_builder", "KIND_BORRE", "KIND_KAPLAN",
-           "ChannelState"]
+__all__ = ["ChannelBank", "TickPackets", "LazyPacket", "TrackingRows", "UpdateRows", "packet_templates", "tracking_packet",
+           "tracking_packets_builder", "channel_update_builder", "KIND_BORRE", "KIND_KAPLAN", "ChannelState"]

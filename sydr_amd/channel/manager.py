@@ -19,7 +19,8 @@ import numpy as np
 from ..engine import FMT_CF64, FMT_CI16, FMT_CI8, Engine
 from ..utils.devicering import CircularBuffer
 from ..utils.enumerations import ChannelState
-from .bank import TickPackets, channel_update_builder, tracking_packet, tracking_packets_builder
+from ..utils.enumerations import ChannelMessage
+from .bank import TickPackets, TrackingRows, UpdateRows, packet_templates, tracking_packet
 from .tracked import DeviceTrackedChannel
 
 
@@ -35,7 +36,8 @@ def shard_channels(n_items: int, rank: int, world_size: int) -> list[int]:
 
 class ChannelManager:
     TIMEOUT = 1
-    DEFER_BYTES = 1 << 20         # slabs up to this size ride in the next run()'s device call; longer ones upload at once
+    DEFER_BYTES = 1 << 20         # slabs up to this size are queued for the ring without waiting; longer ones upload at once
+    STEADY_TICK = True            # all active channels tracking on the device: the tick is one sdr_bank_tick_mirrored call
 
     def __init__(self, rfSignal, engine: Engine | None = None, device_id: int = 0, keepCorrelationMap: bool = True,
                  ring_ms: int = 100):
@@ -54,9 +56,10 @@ class ChannelManager:
         self._slots = 0
         self._readahead = None        # EpochSchedule once enableReadAhead() was called (readahead.py)
         self._ra_ms = 0
-        self._pending = None          # (owned copy of the slab handed to addNewRFData, ring offset): uploaded by the next run()
-        self._stage_buf = None        # the host buffer those copies live in (re-used from tick to tick)
-        self._lists = None            # (state version, active, acquiring, host-side plugins, cids, states) of the last tick
+        self._pending = False         # a slab's transfer into the ring is queued on the engine's stream, not waited for
+        self._lists = None            # (state version, active, acquiring, host-side plugins, cids, states, ...) of the last tick
+        self._unread_max = None       # most unread samples of any running channel after the last tick, when known
+        self._samples_per_ms = self.rfSignal.samplingFrequency / 1e3
 
     @property
     def bank(self):
@@ -209,17 +212,17 @@ class ChannelManager:
                 return None
         self._flush_pending()
         staged, offset, count = self.sharedBuffer.stage(data)
-        self._guard_unread(count)
-        if staged.nbytes > self.DEFER_BYTES:
-            self.engine.iq_upload(staged, offset)         # a long slab gains nothing from riding in the tick's call
+        if self.sharedBuffer.full and (self._unread_max is None or self._unread_max + count > self.sharedBuffer.maxSize):
+            self._guard_unread(count)
+        self._unread_max = None
+        if staged.nbytes > self.DEFER_BYTES or not hasattr(self.engine, "iq_upload_begin"):
+            self.engine.iq_upload(staged, offset)
         else:
-            # the reference copies at this point (circularbuffer.py:54-82): keep an OWNED copy, so that a caller who
-            # reuses its buffer before run() cannot change what enters the ring
-            if self._stage_buf is None or self._stage_buf.dtype != staged.dtype or self._stage_buf.size < staged.size:
-                self._stage_buf = np.empty(max(staged.size, 1), dtype=staged.dtype)
-            own = self._stage_buf[:staged.size]
-            np.copyto(own, staged.reshape(-1))
-            self._pending = (own, offset)
+            # the reference copies at this point (circularbuffer.py:54-82); so does this: the samples are copied out of
+            # the caller's buffer before the call returns, and their transfer into the ring runs while the caller is on
+            # its way to run() -- ordered before the tick's launch, waited for by the tick's one synchronisation
+            self.engine.iq_upload_begin(staged, offset)
+            self._pending = True
         self.sharedBuffer.shiftIdxWrite(count)
 
     def _guard_unread(self, count: int):
@@ -236,10 +239,11 @@ class ChannelManager:
                              "run the channels first")
 
     def _flush_pending(self):
-        if self._pending is not None:
-            staged, offset = self._pending
-            self._pending = None
-            self.engine.iq_upload(staged, offset)
+        """Wait for a slab whose transfer was only queued (anything that may read the ring from another stream, or
+        hand the ring's memory to somebody else, comes through here first)."""
+        if self._pending:
+            self._pending = False
+            self.engine.sync()
 
     def getChannel(self, channelID):
         if channelID not in self.channels:
@@ -261,7 +265,7 @@ class ChannelManager:
         # stateVersion when they do, so a tracking receiver does not walk its channel objects every millisecond
         version = getattr(self.sharedBuffer, "stateVersion", None)
         if self._lists is not None and self._lists[0] == (version, self.nbChannels):
-            _, active, acquiring, host_plugins, cids_active, states_active = self._lists
+            _, active, acquiring, host_plugins, cids_active, states_active, steady, upd_templates = self._lists
         else:
             active = [ch for ch in self.channels.values() if ch.channelState is not ChannelState.IDLE]
             acquiring = [ch for ch in active if ch.channelState is ChannelState.ACQUIRING]
@@ -269,7 +273,13 @@ class ChannelManager:
             cids_active = np.array([ch.channelID for ch in active], dtype=np.int64)
             states_active = [ch.channelState for ch in active]
             cacheable = version is not None and all(isinstance(ch, DeviceTrackedChannel) for ch in self.channels.values())
-            self._lists = ((version, self.nbChannels), active, acquiring, host_plugins, cids_active, states_active) if cacheable else None
+            # steady: every active channel is tracking on the device -- the tick is one library call (_tick_steady)
+            steady = bool(cacheable and active and not acquiring and not host_plugins
+                          and all(st is ChannelState.TRACKING for st in states_active))
+            upd_templates = packet_templates(ChannelMessage.CHANNEL_UPDATE, cids_active.tolist())
+            self._lists = (((version, self.nbChannels), active, acquiring, host_plugins, cids_active, states_active, steady,
+                            upd_templates) if cacheable else None)
+            self._unread_max = None
         if not active:
             self._flush_pending()
             return out
@@ -277,20 +287,24 @@ class ChannelManager:
         ra = self._readahead
         if ra is not None and ra.bank is not bank:
             ra.follow(bank)
-        if (ra is not None and not ra.empty and self._pending is None and self._lists is not None and not acquiring
-                and not host_plugins and ra.version == version and ra.covers_active):
+        if ra is None or ra.empty:
+            if steady and self.STEADY_TICK and self._lists is not None and bank is not None:
+                return self._tick_steady(out, bank, cids_active, states_active, upd_templates)
+        elif (not self._pending and self._lists is not None and not acquiring and not host_plugins
+                and ra.version == version and ra.covers_active):
             # replaying a read-ahead block and nothing else is going on: everything this tick reports was worked out
             # when the block was computed (readahead.py)
             k = ra.tick
             entry, decoded = ra.release()
             if entry is not None:
-                out.add(len(entry[0]), tracking_packets_builder(entry[0], bank.cfg["loop_kind"][entry[0]], entry[1]))
+                out.add_lazy(TrackingRows(entry[0], bank.kinds, entry[1]))
             if decoded:
                 out.add_ready(decoded)
             unread, flags, code, tow, tow_dec = ra.updates(k)
-            since = code + unread / (self.rfSignal.samplingFrequency / 1e3)
-            out.add(len(active), channel_update_builder(cids_active, states_active, flags, tow, tow_dec, since, unread, code))
+            out.add_lazy(UpdateRows(cids_active, states_active, flags, tow, tow_dec, unread, code, self._samples_per_ms,
+                                    upd_templates))
             return out
+        self._unread_max = None
         ready = bank.ready() if bank is not None else np.zeros(0, dtype=np.int32)
         released, ra_tick = None, None
         if ra is not None and not ra.empty:
@@ -298,24 +312,13 @@ class ChannelManager:
                 ready = ready[~ra.busy[ready]]               # (their next epochs are computed already: not to be run again)
             ra_tick = ra.tick
             released = ra.release()                          # epochs (and subframes) a block run computed for this tick
-        # one device call: ring ingest + one epoch for every ready channel
-        staged, offset = self._pending if self._pending is not None else (None, 0)
-        try:
-            if bank is not None and staged is None and not len(ready):
-                rec, done = None, None                       # (nothing for the device to do in this tick)
-            elif bank is not None:
-                rec, done = bank.tick(staged, offset, ready)
-            elif staged is not None:
-                self.engine.iq_upload(staged, offset)
-            self._pending = None
-        except Exception:
-            # the write index already counts this slab: whatever stopped the tick, its samples must still reach the ring
-            # (uploading them twice is harmless) before anybody reads it again
-            try:
-                self._flush_pending()
-            finally:
-                self._pending = None
-            raise
+        # one device call: one epoch for every ready channel, behind the slab addNewRFData queued
+        if bank is not None and len(ready):
+            rec, done = bank.tick(None, 0, ready)
+            self._pending = False                            # (the call ended with a synchronisation of the stream)
+        else:
+            rec, done = None, None                           # (nothing for the device to do in this tick)
+            self._flush_pending()
         if acquiring:
             out.add_ready(self._acquire(acquiring))
         for ch in host_plugins:   # plugins that keep their loops on the host (e.g. the reference's class behind the seams mixin)
@@ -324,13 +327,12 @@ class ChannelManager:
         if released is not None:
             entry, decoded = released
             if entry is not None:
-                out.add(len(entry[0]), tracking_packets_builder(entry[0], bank.cfg["loop_kind"][entry[0]], entry[1]))
+                out.add_lazy(TrackingRows(entry[0], bank.kinds, entry[1]))
             if decoded:
                 out.add_ready(decoded)
         if len(ready):
             ran = np.flatnonzero(done > 0)
-            cids, kinds, rec = ready[ran], bank.cfg["loop_kind"][ready[ran]], rec[ran]
-            out.add(len(ran), tracking_packets_builder(cids, kinds, rec))
+            out.add_lazy(TrackingRows(ready[ran], bank.kinds, rec[ran]))
             if bank.decoded:                                  # subframes completed by this tick's bits (kaplan:71-73)
                 out.add_ready(pkt for _, _, pkt in bank.take_decoded())
         # channel updates: everything they report is captured now, the dicts are made when read (acquisition may have
@@ -338,6 +340,7 @@ class ChannelManager:
         if getattr(self.sharedBuffer, "stateVersion", None) != version or self._lists is None:
             cids = np.array([ch.channelID for ch in active], dtype=np.int64)
             states = [ch.channelState for ch in active]
+            upd_templates = None
         else:
             cids, states = cids_active, states_active
         if bank is not None:
@@ -351,10 +354,25 @@ class ChannelManager:
                 if sel.any():
                     for dst, src in zip((unread, flags, code, tow, tow_dec), ra.updates(ra_tick)):
                         dst[sel] = src[rows[sel]]
-            since = code + unread / (self.rfSignal.samplingFrequency / 1e3)
-            out.add(len(active), channel_update_builder(cids, states, flags, tow, tow_dec, since, unread, code))
+            out.add_lazy(UpdateRows(cids, states, flags, tow, tow_dec, unread, code, self._samples_per_ms, upd_templates))
         else:
             out.add_ready(ch.prepareChannelUpdate() for ch in active)
+        return out
+
+    def _tick_steady(self, out, bank, cids_active, states_active, upd_templates):
+        """The tick of a receiver whose active channels are all tracking on the device: ONE library call
+        (sdr_bank_tick_mirrored, behind the slab addNewRFData queued) decides who is ready, runs their epoch, brings
+        the bank's mirror up to date and leaves what the packets report; the packets themselves are made when read."""
+        ran, rec, upd, self._unread_max = bank.tick_ready(None, 0)
+        self._pending = False                                # (the call ended with a synchronisation of the stream)
+        if len(ran):
+            out.add_lazy(TrackingRows(ran, bank.kinds, rec))
+            if bank.decoded:                                  # subframes completed by this tick's bits (kaplan:71-73)
+                out.add_ready(pkt for _, _, pkt in bank.take_decoded())
+        if len(upd) != len(cids_active):                     # (cannot happen while the lists stand; never guess)
+            raise RuntimeError("channel bank and channel manager disagree about the tracking channels")
+        out.add_lazy(UpdateRows(cids_active, states_active, upd["track_flags"], bank.tow.copy(), bank.tow_decoded.copy(),
+                                upd["unread"], upd["epochs_since_tow"], self._samples_per_ms, upd_templates))
         return out
 
     def _acquire(self, acquiring):

@@ -33,7 +33,8 @@ class EpochSchedule:
 
     def __init__(self, bank, samples_per_tick: int):
         self.bank, self.spt = bank, int(samples_per_tick)
-        self.by_tick = {}            # tick number -> (channel ids, records)
+        self._starts = self._cids_sorted = self._records_sorted = None   # the block's epochs in tick order + the slice per tick
+        self._finishing = {}         # tick number -> channels whose last computed epoch that tick releases
         self.decoded = {}            # tick number -> [DECODING_UPDATE packets]
         self.tick = 0                # ticks released so far
         self.n_ticks = 0             # ticks this block's epochs spread over
@@ -68,7 +69,9 @@ class EpochSchedule:
         to the end of the block and work out every tick's channel updates."""
         bank, spt = self.bank, self.spt
         n_ch = len(channels)
-        self.tick, self.by_tick, self.decoded, self.n_ticks = 0, {}, {}, 0
+        self.tick, self.decoded, self.n_ticks = 0, {}, 0
+        self._starts = self._cids_sorted = self._records_sorted = None
+        self._finishing = {}
         self.cids64 = channels.astype(np.int64)
         self.row_of[:] = -1
         self.row_of[self.cids64] = np.arange(n_ch)
@@ -79,19 +82,24 @@ class EpochSchedule:
         ends = np.cumsum(lengths, axis=1)
         first = np.maximum(0, -(-(ends - unread_now[:, None]) // spt) - 1)          # ceil(.) - 1
         valid = np.arange(n_max)[None, :] < done[:, None]
-        for e in range(1, n_max):
-            first[:, e] = np.maximum(first[:, e], first[:, e - 1] + 1)
+        # at most one epoch per channel and tick: first[e] >= first[e - 1] + 1, i.e. first[e] - e never decreases
+        steps = np.arange(n_max)[None, :]
+        first = np.maximum.accumulate(first - steps, axis=1) + steps
         first = np.where(valid, first, -1)
         n_ticks = self.n_ticks = int(first.max()) + 1
         rows, cols = np.nonzero(valid)
         ticks = first[rows, cols]
+        # the epochs in the order of their ticks (channels ascending inside a tick): tick k releases one slice of these
         order = np.argsort(ticks, kind="stable")
-        rows_s, cols_s, ticks_s = rows[order], cols[order], ticks[order]
-        cuts = np.flatnonzero(np.diff(ticks_s)) + 1
-        for r, c, t in zip(np.split(rows_s, cuts), np.split(cols_s, cuts), np.split(ticks_s, cuts)):
-            self.by_tick[int(t[0])] = (self.cids64[r], records[r, c])
+        rows_s, cols_s = rows[order], cols[order]
+        self._starts = np.searchsorted(ticks[order], np.arange(n_ticks + 1)).tolist()
+        self._cids_sorted = self.cids64[rows_s]
+        self._records_sorted = records[rows_s, cols_s]
         self.busy[channels[done > 0]] = True
-        self.last_tick[channels] = first.max(axis=1)
+        last = first.max(axis=1)
+        self.last_tick[channels] = last
+        for t in np.unique(last[done > 0]).tolist():       # tick -> the channels whose last computed epoch it releases
+            self._finishing[t] = channels[(last == t) & (done > 0)]
 
         # ---- per tick: samples consumed, device flags, code count (one epoch per channel and tick at most)
         epoch_at = np.full((n_ticks, n_ch), -1, dtype=np.int64)                     # epoch released by (tick, channel)
@@ -103,30 +111,37 @@ class EpochSchedule:
         unread = unread_now[None, :] + (np.arange(n_ticks)[:, None] + 1) * spt - consumed
         latest = np.maximum.accumulate(np.where(ran, epoch_at, -1), axis=0)          # newest released epoch so far
         flags0 = bank.state["track_flags"][channels].astype(np.int64)
-        dev_flags = np.where(latest >= 0, records["track_flags"][ch_rows, np.maximum(latest, 0)], flags0[None, :])
+        rec_flags = records["track_flags"]
+        dev_flags = np.where(latest >= 0, rec_flags[ch_rows, np.maximum(latest, 0)], flags0[None, :])
         count = np.cumsum(ran, axis=0)
         code_count = bank.code_since_tow[channels][None, :] + count
         host = np.repeat(bank.host_flags[channels][None, :], n_ticks, axis=0)
         tow = np.repeat(bank.tow[channels][None, :], n_ticks, axis=0)
         tow_dec = np.repeat(bank.tow_decoded[channels][None, :], n_ticks, axis=0)
 
-        # ---- the block's navigation bits through the decoders, channel by channel in epoch order (navdecoder.py)
-        bit_rows, bit_cols = np.nonzero((records["nav_bit"][:, :n_max] >= 0) & valid)
-        for r, e in zip(bit_rows, bit_cols):
-            ch, k = int(channels[r]), int(first[r, e])
-            bit = int(records["nav_bit"][r, e])
-            bank.nav_bits[ch].append(bit)
+        # ---- the block's navigation bits: kept per channel in epoch order, and through the channel's decoder when it
+        # has one (navdecoder.py)
+        nav = records["nav_bit"][:, :n_max]
+        has_bit = (nav >= 0) & valid
+        for r in np.flatnonzero(has_bit.any(axis=1)).tolist():
+            ch = int(channels[r])
+            epochs = np.flatnonzero(has_bit[r])
+            bits = nav[r, epochs].tolist()
             decoder = bank.decoders[ch]
             if decoder is None:
+                bank.nav_bits[ch].extend(bits)
                 continue
-            flags, event = decoder.push(bit, int(records["track_flags"][r, e]) | int(host[k, r]))
-            host[k:, r] = flags & HOST_FLAGS
-            if event is not None:
-                tow[k:, r], tow_dec[k:, r] = event.channel_tow, True
-                code_count[k:, r] = count[k:, r] - count[k, r]                      # (kaplan:833: the count restarts here)
-                self.decoded.setdefault(k, []).append({"cid": ch, "type": ChannelMessage.DECODING_UPDATE,
-                                                       "subframe_id": event.subframe_id, "tow": event.tow,
-                                                       "bits": event.bits})
+            for e, bit in zip(epochs.tolist(), bits):
+                k = int(first[r, e])
+                bank.nav_bits[ch].append(bit)
+                flags, event = decoder.push(bit, int(rec_flags[r, e]) | int(host[k, r]))
+                host[k:, r] = flags & HOST_FLAGS
+                if event is not None:
+                    tow[k:, r], tow_dec[k:, r] = event.channel_tow, True
+                    code_count[k:, r] = count[k:, r] - count[k, r]                  # (kaplan:833: the count restarts here)
+                    self.decoded.setdefault(k, []).append({"cid": ch, "type": ChannelMessage.DECODING_UPDATE,
+                                                           "subframe_id": event.subframe_id, "tow": event.tow,
+                                                           "bits": event.bits})
         self.upd = dict(unread=unread, flags=dev_flags | host, code=code_count, tow=tow, tow_dec=tow_dec)
 
         # ---- the mirror moves to the end of the block
@@ -137,16 +152,20 @@ class EpochSchedule:
         bank.host_flags[channels], bank.tow[channels], bank.tow_decoded[channels] = host[-1], tow[-1], tow_dec[-1]
 
     def release(self):
-        """(channel ids, records, DECODING_UPDATE packets) of the tick that has just received its slab."""
+        """((channel ids, records) | None, DECODING_UPDATE packets | None) of the tick that has just received its slab."""
         k = self.tick
         self.tick += 1
-        entry = self.by_tick.pop(k, None)
+        entry = None
+        if self._starts is not None and k < self.n_ticks:
+            lo, hi = self._starts[k], self._starts[k + 1]
+            if hi > lo:
+                entry = (self._cids_sorted[lo:hi], self._records_sorted[lo:hi])
         if k + 1 >= self.n_ticks:
             self.busy[:] = False
-        elif entry is not None:
-            done = self.last_tick[entry[0]] == k
-            if done.any():
-                self.busy[entry[0][done]] = False
+        else:
+            finishing = self._finishing.get(k)
+            if finishing is not None:
+                self.busy[finishing] = False
         return entry, self.decoded.pop(k, None)
 
     def updates(self, k):

@@ -141,6 +141,17 @@ __global__ __launch_bounds__(256) void flip_sign_bits_kernel(const uint4* __rest
     }
 }
 
+// sdr_iq_upload_async: 16-byte granules of a page-locked slab into the ring at granule `first` (modulo the ring).
+__global__ __launch_bounds__(256) void ingest_kernel(const uint4* __restrict__ src, uint4* __restrict__ ring, size_t n16, size_t first,
+                                                     size_t ring16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        size_t d = first + i;
+        if (d >= ring16) d -= ring16;
+        ring[d] = src[i];
+    }
+}
+
 int sdr_iq_flipped(sdr_engine* e, hipStream_t stream, const void** out) {
     if (e->iq_fmt != SDR_FMT_CI8 || !e->iq) return sdr_fail(SDR_ERR_STATE, "the flipped ring image exists for ci8 rings only");
     const size_t bytes = (size_t)e->iq_capacity * 2 + 256;        // (the same slack as the ring itself)
@@ -184,6 +195,7 @@ int sdr_set_option(sdr_engine* e, const char* name, int value) {
     else if (!strcmp(name, "pcps_fused")) e->pcps_fused = value != 0;
     else if (!strcmp(name, "pcps_general_second_sweep")) e->pcps_slow_second = value != 0;
     else if (!strcmp(name, "pcps_no_spectra_cache")) e->pcps_no_spec_cache = value != 0;
+    else if (!strcmp(name, "ingest_by_copy_command")) e->ingest_by_copy = value != 0;
     else if (!strcmp(name, "pcps_prn_chunk")) e->pcps_prn_chunk = value;
     else if (!strcmp(name, "epl_no_chip_variant")) e->epl_no_chip = value != 0;
     else if (!strcmp(name, "epl_no_split_variant")) e->epl_no_split = value != 0;
@@ -481,5 +493,24 @@ int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_
     e->slab_flip ^= 1;
     char* stage = (char*)e->slab_pinned + (e->slab_flip ? e->slab_bytes : 0);
     memcpy(stage, iq, bytes);
+    // A KERNEL pulls the slab out of the page-locked buffer (16 bytes per lane over PCIe) instead of a copy command: the
+    // tick's launch follows it on the same queue with nothing but the queue's own ordering in between, where a DMA
+    // engine's copy puts a cross-queue signal in front of the kernel that needs the samples (measured on the tick: the
+    // host's wait 28.3 -> see DESIGN.md).  Needs 16-byte granules; anything else takes the copy command.
+    const size_t sb = sdr_fmt_bytes(e->iq_fmt);
+    const int64_t cap = e->iq_capacity;
+    if (e->iq && ring_offset >= 0 && n_samples <= cap && !e->ingest_by_copy) {
+        const int64_t off = ring_offset % cap;
+        const size_t off_b = (size_t)off * sb, cap_b = (size_t)cap * sb;
+        if (off_b % 16 == 0 && bytes % 16 == 0 && cap_b % 16 == 0) {
+            sdr_iq_mark_written(e, off, n_samples);
+            const size_t n16 = bytes / 16;
+            const unsigned blocks = (unsigned)((n16 + 255) / 256 < 64 ? (n16 + 255) / 256 : 64);
+            hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)stage, (uint4*)e->iq, n16,
+                               off_b / 16, cap_b / 16);
+            SDR_HIP(hipGetLastError());
+            return SDR_OK;
+        }
+    }
     return iq_copy(e, stage, n_samples, ring_offset, true, false);
 }

@@ -112,6 +112,7 @@ struct sdr_engine {
     hipStream_t pcps_aux = nullptr;  // second stream of the map-free search (odd sweeps), its two ordering events
     hipEvent_t pcps_ev[2] = {nullptr, nullptr};
     bool pcps_no_fast = false;       // diagnostics: keep the general four-step kernels where the N = 125 x 200 ones would run
+    bool ingest_by_copy = false;     // "ingest_by_copy_command": queued slabs go into the ring by hipMemcpyAsync, not by the ingest kernel
     bool pcps_no_spec_cache = false; // "pcps_no_spectra_cache": conj(fft(code)) recomputed by every search, as the reference does (kaplan:184-185)
     bool pcps_force_passes = false;  // diagnostics: use the one-kernel-per-radix-pass transform instead of the four-step one
     bool pcps_slow_second = false;   // "pcps_general_second_sweep": peak kernel + general four-step pair where the fused second sweep would run

@@ -19,6 +19,8 @@
 #include "correlator.h"
 #include "correlator_chip.h"
 
+#include <algorithm>
+#include <chrono>
 #include <cstring>
 
 #ifdef SDR_TRACE_TRACK
@@ -1039,6 +1041,9 @@ struct sdr_bank {
     std::vector<int32_t> n_taps;          // host mirror of what was put: taps per channel, 0 = channel never put
     std::vector<int32_t> slot;
     int64_t code_generation = 0;
+    // scratch of sdr_bank_tick_mirrored (kept between ticks: no allocation in the steady state)
+    std::vector<int32_t> tick_list, tick_done;
+    std::vector<sdr_track_state> tick_states;
 };
 
 extern "C" {
@@ -1195,10 +1200,30 @@ int sdr_bank_get(sdr_engine* e, sdr_bank* b, int ch, sdr_track_state* st) {
     return SDR_OK;
 }
 
+// Diagnostics build (-DSDR_TICK_TIMING): where the host side of a one-epoch step spends its time (stderr, every 128 calls).
+#ifdef SDR_TICK_TIMING
+static double g_tick_t[8], g_tick_sum[8];
+static long g_tick_calls;
+#define TICK_CLOCK(k) g_tick_t[k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count()
+#define TICK_REPORT()                                                                                                       \
+    do {                                                                                                                    \
+        for (int k_ = 1; k_ <= 4; ++k_) g_tick_sum[k_] += g_tick_t[k_] - g_tick_t[k_ - 1];                                  \
+        if (++g_tick_calls % 128 == 0) {                                                                                    \
+            fprintf(stderr, "[tick timing] prepare %.2f  launch %.2f  wait %.2f  copy-out %.2f us\n", g_tick_sum[1] / 128,   \
+                    g_tick_sum[2] / 128, g_tick_sum[3] / 128, g_tick_sum[4] / 128);                                          \
+            for (int k_ = 0; k_ < 8; ++k_) g_tick_sum[k_] = 0;                                                              \
+        }                                                                                                                   \
+    } while (0)
+#else
+#define TICK_CLOCK(k) ((void)0)
+#define TICK_REPORT() ((void)0)
+#endif
+
 // Shared by sdr_bank_step / sdr_bank_tick: everything between the optional ingest and the final synchronisation.
 static int bank_run(sdr_engine* e, sdr_bank* b, StreamCtx* ctx, const int32_t* channels, int n_ch, int n_epochs,
                     sdr_track_epoch* records, sdr_track_state* states_out, int32_t* epochs_done, int8_t* nav_bits,
                     int max_bits, int32_t* n_bits) {
+    TICK_CLOCK(0);
     if (!e->iq) return sdr_fail(SDR_ERR_STATE, "IQ ring not allocated");
     if (!e->codes) return sdr_fail(SDR_ERR_STATE, "code slots not allocated");
     if ((nav_bits && (max_bits < 1 || !n_bits)) || (!nav_bits && n_bits))
@@ -1252,8 +1277,10 @@ static int bank_run(sdr_engine* e, sdr_bank* b, StreamCtx* ctx, const int32_t* c
     r.n_ch = n_ch, r.n_epochs = n_epochs, r.n_taps = nt;
     r.keep = records ? 1 : 0;
     r.max_bits = max_bits;
+    bool identity = true;             // channels 0 .. n-1 in order (a receiver's usual tick): the kernel needs no list
+    for (int c = 0; c < n_ch && identity; ++c) identity = channels[c] == c;
     if (direct) {
-        r.d_map = p_head + 4 + 2 * n_ch;
+        r.d_map = identity ? nullptr : p_head + 4 + 2 * n_ch;   // (a list in page-locked memory costs every workgroup a PCIe round trip)
         r.d_done = p_head + 4;
         r.d_nbits = nav_bits ? p_head + 4 + n_ch : nullptr;
         r.d_bits = nav_bits ? p_bits : nullptr;
@@ -1273,7 +1300,9 @@ static int bank_run(sdr_engine* e, sdr_bank* b, StreamCtx* ctx, const int32_t* c
     }
     int parts = 1;
     int* d_fault = nullptr;
+    TICK_CLOCK(1);
     if (int rc2 = launch_track(e, ctx, r, &parts, &d_fault)) return rc2;
+    TICK_CLOCK(2);
     if (!direct) {
         SDR_HIP(hipMemcpyAsync(p_head, d_fault, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         SDR_HIP(hipMemcpyAsync(p_head + 4, r.d_done, (size_t)n_ch * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1293,6 +1322,7 @@ static int bank_run(sdr_engine* e, sdr_bank* b, StreamCtx* ctx, const int32_t* c
         if (nav_bits) SDR_HIP(hipMemcpyAsync(p_bits, r.d_bits, bits_bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
     SDR_HIP(hipStreamSynchronize(ctx->stream));
+    TICK_CLOCK(3);
     if (p_head[0])
         return sdr_fail(SDR_ERR_HIP, "closed-loop tracking: a workgroup of a %d-part cluster never published its sums", parts);
     if (epochs_done) memcpy(epochs_done, p_head + 4, (size_t)n_ch * sizeof(int32_t));
@@ -1302,6 +1332,8 @@ static int bank_run(sdr_engine* e, sdr_bank* b, StreamCtx* ctx, const int32_t* c
     }
     if (states_out) memcpy(states_out, p_states, st_bytes);
     if (records) memcpy(records, p_rec, rec_bytes);
+    TICK_CLOCK(4);
+    TICK_REPORT();
     return SDR_OK;
 }
 
@@ -1327,6 +1359,114 @@ int sdr_bank_tick(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples,
         return SDR_OK;
     }
     return bank_run(e, b, &e->ctx0, channels, n_ch, 1, records, states_out, epochs_done, nullptr, 0, nullptr);
+}
+
+
+// The tick with its bookkeeping here instead of in the caller's language: which channels are ready (channel.py:137-146
+// -- the ring holds their next epoch completely), their epoch, and the caller's mirrors brought up to date in place.
+int sdr_bank_tick_mirrored(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
+                           int64_t write_index, sdr_tick_mirror* m) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!b) return sdr_fail(SDR_ERR_INVALID, "bank is NULL");
+    if (!m || !m->states || !m->last || !m->tracking || !m->lost || !m->ran || !m->records || !m->updates)
+        return sdr_fail(SDR_ERR_INVALID, "tick mirror: a required array is NULL");
+    if (m->max_channels != b->max_channels)
+        return sdr_fail(SDR_ERR_INVALID, "tick mirror has %d rows, the bank %d channels", m->max_channels, b->max_channels);
+    if (!e->iq) return sdr_fail(SDR_ERR_STATE, "IQ ring not allocated");
+    const int64_t cap = e->iq_capacity;
+    if (write_index < 0 || write_index >= cap) return sdr_fail(SDR_ERR_RANGE, "write index outside the ring");
+    if (n_samples > 0)
+        if (int rc = sdr_iq_upload_async(e, iq, n_samples, ring_offset)) return rc;
+    auto unread_of = [&](int ch) {
+        int64_t cur = m->states[ch].current_sample % cap;
+        if (cur < 0) cur += cap;
+        return cur <= write_index ? write_index - cur : cap - cur + write_index;   // circularbuffer.py:139-148
+    };
+    // ready channels, grouped by tap count (one launch per group: the kernels are compiled per tap count)
+    std::vector<int32_t>& list = b->tick_list;
+    m->n_ran = m->n_nav_bits = m->n_lost = 0;
+    int taps_seen[2] = {0, 0};
+    list.clear();
+    for (int ch = 0; ch < b->max_channels; ++ch) {
+        if (!m->tracking[ch] || m->lost[ch] || !b->n_taps[ch]) continue;
+        if (unread_of(ch) < m->states[ch].n_samples) continue;
+        list.push_back(ch);
+        const int nt = b->n_taps[ch];
+        if (taps_seen[0] == 0 || taps_seen[0] == nt) taps_seen[0] = nt;
+        else taps_seen[1] = nt;
+    }
+    if (list.empty()) {
+        if (n_samples > 0) SDR_HIP(hipStreamSynchronize(e->ctx0.stream));
+    } else {
+        const int n = (int)list.size();
+        b->tick_states.resize((size_t)n);
+        b->tick_done.resize((size_t)n);
+        int at = 0;
+        for (int g = 0; g < 2 && taps_seen[g]; ++g) {
+            // (stable partition: the group's channels to the front of the remaining range, ascending)
+            int n_g = n - at;
+            if (taps_seen[1]) {
+                n_g = (int)(std::stable_partition(list.begin() + at, list.end(),
+                                                  [&](int32_t ch) { return b->n_taps[ch] == taps_seen[g]; }) -
+                            (list.begin() + at));
+            }
+            if (int rc = bank_run(e, b, &e->ctx0, list.data() + at, n_g, 1, m->records + at, b->tick_states.data() + at,
+                                  b->tick_done.data() + at, nullptr, 0, nullptr))
+                return rc;
+            at += n_g;
+        }
+        if (taps_seen[1]) {   // back to ascending channel order, records and states with them
+            std::vector<int> order((size_t)n);
+            for (int i = 0; i < n; ++i) order[(size_t)i] = i;
+            std::sort(order.begin(), order.end(), [&](int x, int y) { return list[(size_t)x] < list[(size_t)y]; });
+            std::vector<int32_t> l2((size_t)n), d2((size_t)n);
+            std::vector<sdr_track_state> s2((size_t)n);
+            std::vector<sdr_track_epoch> r2((size_t)n);
+            for (int i = 0; i < n; ++i) {
+                const size_t o = (size_t)order[(size_t)i];
+                l2[(size_t)i] = list[o], d2[(size_t)i] = b->tick_done[o], s2[(size_t)i] = b->tick_states[o], r2[(size_t)i] = m->records[o];
+            }
+            list = l2, b->tick_done = d2, b->tick_states = s2;
+            memcpy(m->records, r2.data(), (size_t)n * sizeof(sdr_track_epoch));
+        }
+        // mirrors; a channel the device parked (its NCO left the replica / the ring) reports no epoch
+        int w = 0;
+        for (int i = 0; i < n; ++i) {
+            const int ch = list[(size_t)i];
+            m->states[ch] = b->tick_states[(size_t)i];
+            if (b->tick_done[(size_t)i] < 1) {
+                m->lost[ch] = 1;
+                ++m->n_lost;
+                continue;
+            }
+            if (w != i) m->records[w] = m->records[i];
+            m->last[ch] = m->records[w];
+            if (m->epochs_since_tow) m->epochs_since_tow[ch] += 1;
+            if (m->records[w].nav_bit >= 0) ++m->n_nav_bits;
+            m->ran[w++] = ch;
+        }
+        m->n_ran = w;
+    }
+    // what each tracking channel's CHANNEL_UPDATE reports after this tick (channel.py:205-228)
+    int nu = 0;
+    int64_t max_unread = 0;
+    for (int ch = 0; ch < b->max_channels; ++ch) {
+        if (!m->tracking[ch]) continue;
+        sdr_tick_update& u = m->updates[nu++];
+        u.channel = ch;
+        u.track_flags = m->states[ch].track_flags | (m->host_flags ? (int32_t)m->host_flags[ch] : 0);
+        u.unread = unread_of(ch);
+        u.epochs_since_tow = m->epochs_since_tow ? m->epochs_since_tow[ch] : 0;
+        if (!m->lost[ch] && u.unread > max_unread) max_unread = u.unread;
+    }
+    m->n_updates = nu;
+    m->max_unread = max_unread;
+    return SDR_OK;
+}
+
+int sdr_iq_upload_begin(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset) {
+    if (!e) return sdr_fail(SDR_ERR_INVALID, "null engine");
+    return sdr_iq_upload_async(e, iq, n_samples, ring_offset);
 }
 
 }  // extern "C"

@@ -128,6 +128,41 @@ class Bank:
                                       ptr(states) if n else None, ptr(done) if n else None))
         return rec, states, done
 
+    def bind_mirror(self, states, last, epochs_since_tow, tracking, lost, host_flags):
+        """The caller's mirrors of the bank (NumPy arrays of max_channels rows, kept alive by the caller) as the
+        sdr_tick_mirror `tick_mirrored` updates in place.  Per-tick outputs: `ran`, `records`, `updates` (views of
+        arrays this object owns: copy what has to outlive the next tick)."""
+        n = self.max_channels
+        for a, dt in ((states, TRACK_STATE_DTYPE), (last, TRACK_EPOCH_DTYPE), (epochs_since_tow, np.int64),
+                      (tracking, np.bool_), (lost, np.bool_), (host_flags, np.int64)):
+            if a.dtype != dt or a.shape != (n,) or not a.flags.c_contiguous:
+                raise ValueError("tick mirror arrays must be contiguous, one row per bank channel, in the bank's dtypes")
+        self.ran = np.zeros(n, dtype=np.int32)
+        self.records = np.zeros(n, dtype=TRACK_EPOCH_DTYPE)
+        self.updates = np.zeros(n, dtype=_lib.TICK_UPDATE_DTYPE)
+        self._mirror_arrays = (states, last, epochs_since_tow, tracking, lost, host_flags)
+        m = self._mirror = _lib.TickMirror()
+        m.max_channels = n
+        m.states, m.last, m.epochs_since_tow = states.ctypes.data, last.ctypes.data, epochs_since_tow.ctypes.data
+        m.tracking, m.lost, m.host_flags = tracking.ctypes.data, lost.ctypes.data, host_flags.ctypes.data
+        m.ran, m.records, m.updates = self.ran.ctypes.data, self.records.ctypes.data, self.updates.ctypes.data
+        self._mirror_ref = C.byref(m)
+        return m
+
+    def tick_mirrored(self, raw, ring_offset: int, write_index: int):
+        """One receiver tick with the readiness test and the mirror updates in the library (sdr_bank_tick_mirrored);
+        `raw` None when the slab went in with Engine.iq_upload_begin.  -> the bound sdr_tick_mirror (n_ran, n_updates,
+        n_nav_bits, n_lost, max_unread; the rows in `ran` / `records` / `updates`)."""
+        n_samples = 0
+        if raw is not None:
+            raw = self._e._ring_samples(raw)
+            n_samples = raw.size // 2
+        status = self._lib.sdr_bank_tick_mirrored(self._e._h, self._h, ptr(raw) if n_samples else None, n_samples,
+                                                  ring_offset, write_index, self._mirror_ref)
+        if status:
+            check(status)
+        return self._mirror
+
     def close(self):
         if self._h and self._e._h:
             self._lib.sdr_bank_destroy(self._e._h, self._h)
@@ -207,6 +242,12 @@ class Engine:
         """raw: interleaved I,Q in the ring's element type (complex128 accepted for FMT_CF64)."""
         raw = self._ring_samples(raw)
         check(self._lib.sdr_iq_upload(self._h, ptr(raw), raw.size // 2, int(ring_offset)))
+
+    def iq_upload_begin(self, raw: np.ndarray, ring_offset: int = 0):
+        """iq_upload without the wait (sdr_iq_upload_begin): `raw` is copied before the call returns, the transfer is
+        ordered before everything queued on the engine's stream afterwards; `sync()` completes it."""
+        raw = self._ring_samples(raw)
+        check(self._lib.sdr_iq_upload_begin(self._h, raw.ctypes.data, raw.size // 2, int(ring_offset)))
 
     def iq_download(self, n_samples: int, ring_offset: int = 0) -> np.ndarray:
         out = np.empty(2 * int(n_samples), dtype=_lib.fmt_dtype(self.iq_fmt))

@@ -206,6 +206,67 @@ class OracleBank:
         return rec[:, 0], states, done
 
 
+def _bind_mirror(self, states, last, epochs_since_tow, tracking, lost, host_flags):
+    from types import SimpleNamespace
+    from sydr_amd._lib import TICK_UPDATE_DTYPE
+    n = self.max_channels
+    self.ran = np.zeros(n, dtype=np.int32)
+    self.records = np.zeros(n, dtype=TRACK_EPOCH_DTYPE)
+    self.updates = np.zeros(n, dtype=TICK_UPDATE_DTYPE)
+    self._mirror_arrays = (states, last, epochs_since_tow, tracking, lost, host_flags)
+    self._mirror = SimpleNamespace(n_ran=0, n_updates=0, n_nav_bits=0, n_lost=0, max_unread=0)
+    return self._mirror
+
+
+def _tick_mirrored(self, raw, ring_offset, write_index):
+    """sdr_bank_tick_mirrored restated (sydr_amd/csrc/track.hip): readiness from the mirror, one epoch for the ready
+    channels, the mirror and the per-tick rows updated in place."""
+    states, last, since, tracking, lost, host_flags = self._mirror_arrays
+    m, cap = self._mirror, self.e.iq_capacity
+    if raw is not None:
+        self.e.iq_upload(raw, ring_offset)
+
+    def unread_of(ch):
+        cur = int(states["current_sample"][ch]) % cap
+        return write_index - cur if cur <= write_index else cap - cur + write_index
+    ready = [ch for ch in range(self.max_channels) if tracking[ch] and not lost[ch] and ch in self.states
+             and unread_of(ch) >= int(states["n_samples"][ch])]
+    m.n_ran = m.n_nav_bits = m.n_lost = 0
+    if ready:
+        self.calls["tick"] += 1
+        rec, st, done, _ = self.step(ready, 1)
+        w = 0
+        for i, ch in enumerate(ready):
+            states[ch] = st[i]
+            if done[i] < 1:
+                lost[ch] = True
+                m.n_lost += 1
+                continue
+            self.records[w] = rec[i, 0]
+            last[ch] = rec[i, 0]
+            since[ch] += 1
+            m.n_nav_bits += int(rec[i, 0]["nav_bit"] >= 0)
+            self.ran[w] = ch
+            w += 1
+        m.n_ran = w
+    nu, m.max_unread = 0, 0
+    for ch in range(self.max_channels):
+        if not tracking[ch]:
+            continue
+        u = self.updates[nu]
+        u["channel"], u["track_flags"] = ch, int(states["track_flags"][ch]) | int(host_flags[ch])
+        u["unread"], u["epochs_since_tow"] = unread_of(ch), since[ch]
+        if not lost[ch]:
+            m.max_unread = max(m.max_unread, int(u["unread"]))
+        nu += 1
+    m.n_updates = nu
+    return m
+
+
+OracleBank.bind_mirror = _bind_mirror
+OracleBank.tick_mirrored = _tick_mirrored
+
+
 def _make_bank(self, max_channels):
     bank = OracleBank(self, max_channels)
     self.bank_calls = bank.calls          # (what the host layer asked of the device: ticks / block steps)
@@ -214,6 +275,8 @@ def _make_bank(self, max_channels):
 
 OracleEngine.bank = _make_bank
 OracleEngine._ring_samples = lambda self, raw: np.asarray(raw)
+OracleEngine.iq_upload_begin = OracleEngine.iq_upload         # (nothing to wait for on the host)
+OracleEngine.sync = lambda self: None
 
 
 def _serial_search(self, code_slots, start_sample, fs, doppler_range, doppler_step, noncoh=1, want_map=False,

@@ -304,3 +304,65 @@ def test_read_ahead_on_the_device_equals_plain_ticks(engine, tmp_path):
         n_trk += sum(1 for p in b if "i_prompt" in p)
     assert worst < 1e-9, worst
     assert n_trk > 8 * 350 + 4 * 200
+
+
+def test_library_side_tick_equals_the_general_tick(engine):
+    """The steady tick (sdr_bank_tick_mirrored: readiness, the epoch and the mirror updates in ONE library call, the
+    slab queued by addNewRFData) against the manager's general tick (readiness and mirrors in NumPy around
+    sdr_bank_tick): 12 channels at 10 MHz from acquisition on, every packet of every tick equal bit for bit, the
+    channel objects' attributes too -- and the packets are dicts that fill themselves when read."""
+    import configparser
+    import os
+    import pickle
+    from conftest import REPO
+    from sydr_amd.channel.bank import LazyPacket
+    from sydr_amd.channel.l1ca_kaplan import ChannelL1CA_Kaplan
+    from sydr_amd.channel.manager import ChannelManager
+    from sydr_amd.signal.iqsource import RFSignal
+    from sydr_amd.utils.enumerations import ChannelMessage
+    fs, n_ms = 10e6, 300
+    spms = int(fs * 1e-3)
+    rng = np.random.default_rng(6060)
+    sats = [dict(prn=1 + c, doppler=float(250.0 * rng.integers(-15, 16) + rng.uniform(-40, 40)),
+                 code_phase=float(rng.uniform(0, 1023)), phase=float(rng.uniform(0, 1)), amp=5.0) for c in range(12)]
+    total = n_ms * spms
+    engine.iq_alloc(total, FMT_CI8)
+    engine.code_slots(32)
+    engine.iq_synth(sats, fs, 10.0, 6061, 0, total)
+    raw = engine.iq_download(total, 0)
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(REPO, "examples", "channel_GPS_L1CA_kaplan.ini"))
+
+    def receiver(steady):
+        rf = RFSignal(dict(filepath="none", sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0, data_size=8))
+        mgr = ChannelManager(rf, engine=engine, keepCorrelationMap=False)
+        mgr.STEADY_TICK = steady
+        mgr.addChannel(ChannelL1CA_Kaplan, cfg, 12)
+        for s in sats:
+            mgr.requestTracking(s["prn"])
+        ticks, lazy = [], 0
+        for k in range(n_ms):
+            mgr.addNewRFData(raw[2 * k * spms:2 * (k + 1) * spms])
+            pk = mgr.run()
+            if k == 200:
+                # born with two keys; anything else fills them; what the consumer wrote stays; they travel as dicts
+                p = [q for q in pk if q["type"] is ChannelMessage.TRACKING_UPDATE][0]
+                assert isinstance(p, LazyPacket) and dict.__len__(p) == 2 and not (p == None)   # noqa: E711 (receiver.py:292)
+                p["channel_id"] = 77
+                assert dict.__len__(p) == 3 and p["i_prompt"] == p["i_prompt"] and len(p) == 20 and p["channel_id"] == 77
+                assert type(pickle.loads(pickle.dumps(p))) is dict and pickle.loads(pickle.dumps(p)) == p
+                del p["channel_id"]
+            lazy += sum(isinstance(q, LazyPacket) for q in pk)
+            ticks.append([dict(q) for q in pk])
+        attrs = [(ch.carrierFrequency, ch.codeFrequency, ch.currentSample, ch.codeSinceTOW, int(ch.trackFlags), len(ch.navBits))
+                 for ch in mgr.channels.values()]
+        mgr.close()
+        return ticks, attrs, lazy
+
+    general, attrs_g, _ = receiver(False)
+    steady, attrs_s, lazy = receiver(True)
+    assert lazy > 2 * 12 * 200
+    assert sum(p["type"] is ChannelMessage.TRACKING_UPDATE for t in steady for p in t) > 12 * 250
+    for k, (a, b) in enumerate(zip(general, steady)):
+        assert a == b, k
+    assert attrs_g == attrs_s

@@ -113,8 +113,8 @@ def test_manager_kaplan_lock_state_machine():
 
 
 def test_manager_batches_channels_into_single_launches():
-    """Three channels: one PCPS call for all of them, then ONE device call per tick (ring ingest + an epoch of every
-    ready channel)."""
+    """Three channels: one PCPS call for all of them, then ONE device call per tick that has an epoch to run (an epoch
+    of every ready channel, behind the slab addNewRFData queued)."""
     fs, spms = 4e6, 4000
     from oracle import sydr_oracle as orc
     sats = [dict(prn=p, doppler=d, code_phase=c, phase=0.1, amp=8.0) for p, d, c in
@@ -130,7 +130,9 @@ def test_manager_batches_channels_into_single_launches():
     assert eng.calls["pcps"] == 1
     n_trk = sum(p["type"] is ChannelMessage.TRACKING_UPDATE for t in ticks for p in t)
     dev = mgr.bank.device
-    assert dev.calls == dict(step=dev.calls["step"], tick=30, channels=n_trk) and eng.calls["epl_batch"] == 0
+    ticks_with_epochs = sum(any(p["type"] is ChannelMessage.TRACKING_UPDATE for p in t) for t in ticks)
+    assert 25 <= ticks_with_epochs <= 30
+    assert dev.calls == dict(step=dev.calls["step"], tick=ticks_with_epochs, channels=n_trk) and eng.calls["epl_batch"] == 0
     assert all(mgr.getChannel(c).channelState is ChannelState.TRACKING for c in range(3))
     for c, s in enumerate(sats):
         assert abs(mgr.getChannel(c).carrierFrequency - s["doppler"]) < 300.0
@@ -161,11 +163,14 @@ def test_ring_bookkeeping_matches_reference_semantics():
 
 
 def test_pending_slab_is_owned_and_survives_a_failed_tick():
-    """addNewRFData defers the ring write to the next run(): the reference copies at addNewRFData time
-    (circularbuffer.py:54-82), so what reaches the ring must be what the caller held THEN, and a tick that fails
-    must not lose the slab the write index already counts."""
+    """addNewRFData copies the slab out of the caller's buffer at once, as the reference does (circularbuffer.py:54-82),
+    and only QUEUES its transfer into the ring (Engine.iq_upload_begin): what reaches the ring is what the caller held
+    THEN, the tick's device call is ordered behind it, and a tick that fails cannot lose a slab the write index
+    already counts."""
     fs, spms = 4e6, 4000
     eng = OracleEngine()
+    begun = []
+    eng.iq_upload_begin = lambda raw, off: (begun.append(int(off)), OracleEngine.iq_upload(eng, raw, off))[1]
     mgr = ChannelManager(rf_signal(fs), engine=eng)
     mgr.addChannel(ChannelL1CA_Kaplan, channel_config(KAPLAN_INI), 1)
     mgr.requestTracking(7)
@@ -173,26 +178,36 @@ def test_pending_slab_is_owned_and_survives_a_failed_tick():
     slab = rng.integers(-100, 100, 2 * spms).astype(np.int8)
     want = slab.copy()
     mgr.addNewRFData(slab)
+    assert begun == [0] and mgr._pending is True
     slab[:] = 0                                     # the caller re-uses its buffer before run()
     mgr.run()
-    assert np.array_equal(eng.iq_download(spms, 0), want)
-    # a device call that raises: the slab still enters the ring, the exception still surfaces
+    assert mgr._pending is False and np.array_equal(eng.iq_download(spms, 0), want)
+    # a device call that raises: the slab is in the ring (queued before the call), the exception surfaces
     second = rng.integers(-100, 100, 2 * spms).astype(np.int8)
     mgr.addNewRFData(second)
-    bank, boom = mgr.bank, RuntimeError("tick failed")
+    boom = RuntimeError("tick failed")
 
-    def failing_tick(raw, offset, channels):
+    def failing(*a, **k):
         raise boom
-    real_tick, bank.tick = bank.tick, failing_tick
+    bank = mgr.bank
+    real = (mgr._acquire, bank.tick, bank.tick_ready)
+    mgr._acquire = bank.tick = bank.tick_ready = failing       # (whichever this tick needs)
     with pytest.raises(RuntimeError):
         mgr.run()
-    bank.tick = real_tick
-    assert mgr._pending is None and np.array_equal(eng.iq_download(spms, spms), second)
-    # slabs beyond DEFER_BYTES go to the ring at once
+    mgr._acquire, bank.tick, bank.tick_ready = real
+    assert np.array_equal(eng.iq_download(spms, spms), second)
+    # a second slab without a run() in between waits for the first one's transfer (the staging buffer is re-used)
+    synced = []
+    eng.sync = lambda: synced.append(1)
+    mgr._pending = True
+    mgr.addNewRFData(rng.integers(-100, 100, 2 * spms).astype(np.int8))
+    assert synced == [1]
+    # slabs beyond DEFER_BYTES go to the ring synchronously
+    mgr.run()
     long = rng.integers(-100, 100, 2 * spms * 20).astype(np.int8)
     mgr.DEFER_BYTES = 1 << 10
     mgr.addNewRFData(long)
-    assert mgr._pending is None and np.array_equal(eng.iq_download(20 * spms, 2 * spms), long)
+    assert mgr._pending is False and np.array_equal(eng.iq_download(20 * spms, 3 * spms), long)
 
 
 @pytest.mark.parametrize("block_ms", [50, 7])

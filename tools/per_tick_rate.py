@@ -1,7 +1,9 @@
 """The literal drop-in mode: ChannelManager.addNewRFData(1 ms) + run() per millisecond, 32 channels @ 25 MHz,
-the host as IQ source.  One tick = ONE device call (ring ingest + one epoch of every ready channel from the
-device-resident bank).  Reported twice: with the packet dicts left unread (what a consumer that only wants some
-of them pays) and with every packet materialised (what the reference's Receiver loop does)."""
+the host as IQ source.  One tick = the slab queued for the ring (sdr_iq_upload_begin) + ONE library call
+(sdr_bank_tick_mirrored: who is ready, one epoch for them from the device-resident bank, the host's mirrors updated
+in place).  Reported twice: with the packets left unread (what a consumer that only wants some of them pays) and
+with the "type" of every packet read (what the reference's Receiver loop does to route them, receiver.py:291-299;
+the packets are dicts that fill themselves when more is asked of them)."""
 import configparser, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,9 +17,13 @@ from sydr_amd.utils.enumerations import ChannelMessage, ChannelState
 FS = bench.FS
 
 
+WARMUP_MS = 100     # ticks not counted: acquisition, the first launches of each kernel (code objects load on first use), the first block
+
+
 def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0):
     """read_ahead > 0: the same loop with ChannelManager.enableReadAhead(read_ahead) and the stream served from a file
-    through this package's RFSignal (what lets the manager look ahead); the calls per tick are the reference's."""
+    through this package's RFSignal (what lets the manager look ahead); the calls per tick are the reference's.
+    The first WARMUP_MS ticks are fed and run but not counted (their time is reported as warmup_ms_total)."""
     eng = engine or Engine(0)
     # synthesise the stream on the device, then bring it to the host: the host is the IQ source in this mode
     total = int(n_ms * 1e-3 * FS) // 8 * 8
@@ -40,7 +46,7 @@ def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0):
     if read_ahead:
         mgr.enableReadAhead(read_ahead)
     spms = int(FS * 1e-3)
-    lazy, eager, other = [], [], 0.0
+    lazy, eager, other, warm = [], [], 0.0, 0.0
     pr = None
     if profile:
         import cProfile
@@ -54,7 +60,9 @@ def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0):
         t1 = time.perf_counter()
         tracking = sum(1 for p in pk if p["type"] is ChannelMessage.TRACKING_UPDATE)   # materialises every packet
         t2 = time.perf_counter()
-        if tracking == n_ch:
+        if k < WARMUP_MS:
+            warm += t2 - t0
+        elif tracking == n_ch:
             lazy.append(t1 - t0)
             eager.append(t2 - t0)
         else:
@@ -75,7 +83,7 @@ def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0):
                x_realtime=1e-3 / avg(lazy) if lazy else None,
                ms_per_tick_all_packets_read=avg(eager) * 1e3 if eager else None,
                x_realtime_all_packets_read=1e-3 / avg(eager) if eager else None,
-               other_ticks_ms_total=other * 1e3)
+               other_ticks_ms_total=other * 1e3, warmup_ms_excluded=WARMUP_MS, warmup_ms_total=warm * 1e3)
     if tmp is not None:
         tmp.close()
     return res

@@ -22,20 +22,21 @@ mgr.addChannel(ChannelL1CA_Kaplan, cfg, n_ch)
 for s in sats: mgr.requestTracking(s["prn"])
 spms = int(FS * 1e-3)
 lib = eng._lib
-orig = lib.sdr_bank_tick
-acc = []
-def timed(*a):
-    t0 = time.perf_counter(); r = orig(*a); acc.append(time.perf_counter() - t0); return r
-class L: pass
-# monkeypatch through Bank object's lib handle
-bank_dev = None
+acc, acc_up = [], []
+def timed_of(orig, into):
+    def timed(*a):
+        t0 = time.perf_counter(); r = orig(*a); into.append(time.perf_counter() - t0); return r
+    return timed
+timed = timed_of(lib.sdr_bank_tick_mirrored, acc)
+timed_up = timed_of(lib.sdr_iq_upload_begin, acc_up)
+class Wrap:
+    def __getattr__(self, n):
+        return timed if n == "sdr_bank_tick_mirrored" else timed_up if n == "sdr_iq_upload_begin" else getattr(lib, n)
 tt = []
 for k in range(n_ms):
     if k == 50:
-        bank_dev = mgr.bank.device
-        class Wrap:
-            def __getattr__(self, n): return timed if n == "sdr_bank_tick" else getattr(lib, n)
-        bank_dev._lib = Wrap()
+        mgr.bank.device._lib = Wrap()
+        eng._lib = Wrap()
     t0 = time.perf_counter()
     mgr.addNewRFData(raw[2 * k * spms:2 * (k + 1) * spms])
     t1 = time.perf_counter()
@@ -43,7 +44,8 @@ for k in range(n_ms):
     t2 = time.perf_counter()
     tt.append((t1 - t0, t2 - t1))
 tt = np.array(tt[100:]); acc_a = np.array(acc[50:])
-print("addNewRFData us", np.median(tt[:,0])*1e6, "run us", np.median(tt[:,1])*1e6, "sdr_bank_tick us", np.median(acc_a)*1e6)
+print("addNewRFData us", np.median(tt[:,0])*1e6, "of which sdr_iq_upload_begin", np.median(acc_up[50:])*1e6, "run us", np.median(tt[:,1])*1e6,
+      "of which sdr_bank_tick_mirrored us", np.median(acc_a)*1e6)
 # kernel-only: prof
 eng.prof_enable(True); eng.prof_reset()
 rec, st, done, _ = mgr.bank.device.step(np.arange(32, dtype=np.int32), 1)
