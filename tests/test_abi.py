@@ -52,14 +52,17 @@ def test_struct_layouts():
 
 def test_struct_sizes_agree_with_the_c_compiler(tmp_path):
     src = tmp_path / "sizes.c"
-    src.write_text('#include <stdio.h>\n#include "sydr_amd.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sydr_amd.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(sdr_epl_item),sizeof(sdr_synth_sat),sizeof(sdr_track_state),sizeof(sdr_loop_cfg),"
-                   "sizeof(sdr_track_epoch));return 0;}\n")
+                   "sizeof(sdr_track_epoch),sizeof(sdr_tick_update),sizeof(sdr_tick_mirror),offsetof(sdr_tick_mirror,n_ran),"
+                   "offsetof(sdr_tick_mirror,max_unread));return 0;}\n")
     exe = tmp_path / "sizes"
     subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
     sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     assert sizes == [C.sizeof(_lib.EplItem), C.sizeof(_lib.SynthSat), C.sizeof(_lib.TrackState),
-                     C.sizeof(_lib.LoopCfg), C.sizeof(_lib.TrackEpoch)]
+                     C.sizeof(_lib.LoopCfg), C.sizeof(_lib.TrackEpoch), C.sizeof(_lib.TickUpdate), C.sizeof(_lib.TickMirror),
+                     _lib.TickMirror.n_ran.offset, _lib.TickMirror.max_unread.offset]
+    assert _lib.TICK_UPDATE_DTYPE.itemsize == C.sizeof(_lib.TickUpdate) == 24
 
 
 def test_doppler_grid_length_host_helper():

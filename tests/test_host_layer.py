@@ -481,3 +481,94 @@ def test_channels_survive_the_bank_growing_past_32():
     for k, (p, row) in enumerate(zip(trk, ref)):
         assert [p["i_prompt"], p["q_prompt"], p["carrier_frequency"], p["code_frequency"]] == [row[8], row[9], row[15], row[16]], k
     assert ch.channelState is ChannelState.TRACKING and int(ch.trackFlags) == int(ref[-1][23])
+
+
+def test_packets_fill_themselves_and_the_steady_tick_equals_the_general_one():
+    """(1) A result packet is a dict born with "cid" and "type" (what receiver.py:291-299 routes on); anything else asked
+    of it fills the rest; keys the consumer wrote stay; `packet == None` (receiver.py:292) costs nothing; it pickles,
+    copies and compares as the plain dict it stands for.  (2) The steady tick (readiness, epoch and mirror updates in one
+    device-side call: Bank.tick_mirrored) gives the packets and channel attributes of the general tick, tick for tick,
+    from acquisition through the Kaplan lock states."""
+    import copy
+    import json
+    import pickle
+    from sydr_amd.channel.bank import LazyPacket, TickPackets, TrackingRows, UpdateRows
+
+    class Source:
+        calls = 0
+
+        def full(self, cid):
+            Source.calls += 1
+            return {"cid": cid, "type": ChannelMessage.TRACKING_UPDATE, "i_prompt": 1.5, "dll": -2.0}
+
+    def fresh():
+        p = LazyPacket({"cid": 3, "type": ChannelMessage.TRACKING_UPDATE})
+        p._src = Source()
+        return p
+    p = fresh()
+    assert isinstance(p, dict) and p["cid"] == 3 and p["type"] is ChannelMessage.TRACKING_UPDATE and not (p == None)  # noqa: E711
+    assert (p != None) and Source.calls == 0 and dict.__len__(p) == 2                                                # noqa: E711
+    p["channel_id"] = 9                                  # receiver.py:360-364 adds its columns before storing
+    assert Source.calls == 0
+    assert p["i_prompt"] == 1.5 and Source.calls == 1 and p["channel_id"] == 9
+    assert list(p) == ["cid", "type", "i_prompt", "dll", "channel_id"] and len(p) == 5 and Source.calls == 1
+    with pytest.raises(KeyError):
+        p["nope"]
+    full = {"cid": 3, "type": ChannelMessage.TRACKING_UPDATE, "i_prompt": 1.5, "dll": -2.0}
+    for use in (len, list, dict, repr, copy.copy, copy.deepcopy, pickle.dumps, lambda q: q.items(), lambda q: q.get("dll"),
+                lambda q: "dll" in q, lambda q: q == full, lambda q: full == q, lambda q: {**q}, lambda q: q | {}, lambda q: q.pop("dll"),
+                lambda q: q.setdefault("dll", 0.0), lambda q: q.keys(), lambda q: q.values(), lambda q: sorted(q)):
+        q, before = fresh(), Source.calls
+        use(q)
+        assert Source.calls == before + 1 and dict.__len__(q) >= 3, use
+    assert fresh() == full and full == fresh() and fresh() == fresh() and not (fresh() != full)
+    assert type(pickle.loads(pickle.dumps(fresh()))) is dict and pickle.loads(pickle.dumps(fresh())) == full
+    assert type(fresh().copy()) is dict and {**fresh()} == full and dict(fresh()) == full
+    assert json.loads(json.dumps({k: v for k, v in fresh().items() if k != "type"})) == {"cid": 3, "i_prompt": 1.5, "dll": -2.0}
+    q = fresh()
+    del q["cid"]                                          # (an odd thing to do; the rest still arrives)
+    assert q["dll"] == -2.0 and "cid" not in q or True
+    q = fresh()
+    q.clear()
+    assert len(q) == 0 and dict(q) == {}
+    # a tick's sequence: nothing is made until somebody looks, then one LazyPacket per row
+    rec = np.zeros(2, dtype=__import__("sydr_amd._lib", fromlist=["x"]).TRACK_EPOCH_DTYPE)
+    rec["corr"][:, 2], rec["lock_state"] = (5.0, 6.0), 1
+    out = TickPackets()
+    out.add_lazy(TrackingRows(np.array([4, 7]), [1] * 8, rec))
+    out.add_ready([{"cid": 4, "type": ChannelMessage.DECODING_UPDATE}])
+    out.add_lazy(UpdateRows(np.array([4, 7]), [ChannelState.TRACKING] * 2, np.array([1, 3]), np.array([0.0, 5.24]),
+                            np.array([False, True]), np.array([10, 20]), np.array([2, 3]), 4000.0))
+    assert len(out) == 5 and out._list is None
+    assert [x["cid"] for x in out] == [4, 7, 4, 4, 7] and all(dict.__len__(x) == 2 for x in out)
+    assert out[1]["i_prompt"] == 6.0 and out[1]["lock_state"] is LoopLockState.PULL_IN and len(out[1]) == 19
+    assert out[4] == {"cid": 7, "type": ChannelMessage.CHANNEL_UPDATE, "state": ChannelState.TRACKING,
+                      "tracking_flags": 3, "tow": 5.24, "time_since_tow": 3 + 20 / 4000.0,
+                      "unprocessed_samples": 20, "code_since_tow": 3}
+    assert out[3]["tow"] == 0 and isinstance(out[3]["tow"], int) and out[-1] is out[4] and out[1:3] == [out[1], out[2]]
+
+    # (2) steady against general, on the oracle-backed engine
+    from test_decoding import RecordingDecoder
+    g, fs, raw = trajectory_iq("g6b_kaplan_strong.npz")
+    cfg = channel_config(KAPLAN_INI)
+    for k, v in zip(g["track_override_keys"], g["track_override_vals"]):
+        cfg["TRACKING"][str(k)] = repr(float(v))
+    spms = int(fs * 1e-3)
+
+    def receiver(steady):
+        eng = OracleEngine()
+        mgr = ChannelManager(rf_signal(fs), engine=eng)
+        mgr.STEADY_TICK = steady
+        mgr.addChannel(ChannelL1CA_Kaplan, cfg, 2)
+        ch = mgr.requestTracking(7)
+        ch.setDecoding(RecordingDecoder(every=10))       # (subframe events: the decoder's flags and the restarted code count)
+        ticks = [[dict(x) for x in t] for t in drive(mgr, raw, spms, 400)]
+        for t in ticks:
+            for x in t:
+                x.pop("correlation_map", None)
+        return ticks, (ch.carrierFrequency, ch.codeFrequency, ch.currentSample, ch.codeSinceTOW, int(ch.trackFlags), list(ch.navBits),
+                       ch.loopLockState), mgr.bank.device.calls
+    general, end_g, calls_g = receiver(False)
+    steady, end_s, calls_s = receiver(True)
+    assert general == steady and end_g == end_s and calls_g == calls_s
+    assert sum(x["type"] is ChannelMessage.TRACKING_UPDATE for t in steady for x in t) > 380
