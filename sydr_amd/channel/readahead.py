@@ -28,6 +28,17 @@ from .navdecoder import HOST_FLAGS
 from ..utils.enumerations import ChannelMessage
 
 
+def _take_records(records, rows, cols):
+    """records[rows, cols] of a C-contiguous 2-D structured array whose item size is a multiple of 8, as a row gather
+    over 64-bit words (NumPy's fancy indexing of structured items goes item by item through its generic copy: 200 us
+    for the 1600 records of a block against ~10)."""
+    dt = records.dtype
+    if records.ndim != 2 or dt.itemsize % 8 or not records.flags.c_contiguous:
+        return records[rows, cols]
+    words = records.view(np.uint64).reshape(records.shape[0] * records.shape[1], dt.itemsize // 8)
+    return words[np.asarray(rows) * records.shape[1] + np.asarray(cols)].view(dt).reshape(-1)
+
+
 class EpochSchedule:
     """Epochs a block run computed ahead of the ticks that release them."""
 
@@ -94,7 +105,7 @@ class EpochSchedule:
         rows_s, cols_s = rows[order], cols[order]
         self._starts = np.searchsorted(ticks[order], np.arange(n_ticks + 1)).tolist()
         self._cids_sorted = self.cids64[rows_s]
-        self._records_sorted = records[rows_s, cols_s]
+        self._records_sorted = _take_records(records, rows_s, cols_s)
         self.busy[channels[done > 0]] = True
         last = first.max(axis=1)
         self.last_tick[channels] = last
@@ -122,32 +133,39 @@ class EpochSchedule:
         # ---- the block's navigation bits: kept per channel in epoch order, and through the channel's decoder when it
         # has one (navdecoder.py)
         nav = records["nav_bit"][:, :n_max]
-        has_bit = (nav >= 0) & valid
-        for r in np.flatnonzero(has_bit.any(axis=1)).tolist():
-            ch = int(channels[r])
-            epochs = np.flatnonzero(has_bit[r])
-            bits = nav[r, epochs].tolist()
-            decoder = bank.decoders[ch]
-            if decoder is None:
-                bank.nav_bits[ch].extend(bits)
-                continue
-            for e, bit in zip(epochs.tolist(), bits):
-                k = int(first[r, e])
-                bank.nav_bits[ch].append(bit)
-                flags, event = decoder.push(bit, int(rec_flags[r, e]) | int(host[k, r]))
-                host[k:, r] = flags & HOST_FLAGS
-                if event is not None:
-                    tow[k:, r], tow_dec[k:, r] = event.channel_tow, True
-                    code_count[k:, r] = count[k:, r] - count[k, r]                  # (kaplan:833: the count restarts here)
-                    self.decoded.setdefault(k, []).append({"cid": ch, "type": ChannelMessage.DECODING_UPDATE,
-                                                           "subframe_id": event.subframe_id, "tow": event.tow,
-                                                           "bits": event.bits})
+        bit_rows, bit_cols = np.nonzero((nav >= 0) & valid)               # (row-major: a channel's bits in epoch order)
+        if len(bit_rows):
+            bit_values = nav[bit_rows, bit_cols].tolist()
+            bounds = np.searchsorted(bit_rows, np.arange(n_ch + 1)).tolist()
+            bit_epochs = bit_cols.tolist()
+            for r in np.unique(bit_rows).tolist():
+                ch = int(channels[r])
+                lo, hi = bounds[r], bounds[r + 1]
+                decoder = bank.decoders[ch]
+                if decoder is None:
+                    bank.nav_bits[ch].extend(bit_values[lo:hi])
+                    continue
+                for e, bit in zip(bit_epochs[lo:hi], bit_values[lo:hi]):
+                    k = int(first[r, e])
+                    bank.nav_bits[ch].append(bit)
+                    flags, event = decoder.push(bit, int(rec_flags[r, e]) | int(host[k, r]))
+                    host[k:, r] = flags & HOST_FLAGS
+                    if event is not None:
+                        tow[k:, r], tow_dec[k:, r] = event.channel_tow, True
+                        code_count[k:, r] = count[k:, r] - count[k, r]              # (kaplan:833: the count restarts here)
+                        self.decoded.setdefault(k, []).append({"cid": ch, "type": ChannelMessage.DECODING_UPDATE,
+                                                               "subframe_id": event.subframe_id, "tow": event.tow,
+                                                               "bits": event.bits})
         self.upd = dict(unread=unread, flags=dev_flags | host, code=code_count, tow=tow, tow_dec=tow_dec)
 
         # ---- the mirror moves to the end of the block
         has = done > 0
-        bank.state[channels] = states
-        bank.last[channels[has]] = records[np.flatnonzero(has), done[has] - 1]
+        lo, hi = int(channels[0]), int(channels[-1])
+        if hi - lo + 1 == n_ch and bool((np.diff(channels) == 1).all()):   # (the usual case: a run of channel numbers)
+            bank.state[lo:hi + 1] = states
+        else:
+            bank.state[channels] = states
+        bank.last[channels[has]] = _take_records(records, np.flatnonzero(has), done[has] - 1)
         bank.code_since_tow[channels] = code_count[-1]
         bank.host_flags[channels], bank.tow[channels], bank.tow_decoded[channels] = host[-1], tow[-1], tow_dec[-1]
 

@@ -822,13 +822,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             for (int k2 = 0; k2 < 2 * kTaps; ++k2) corr[k2] = uniform(sh->corr[k2]);
         }
         ring_pos = ring_pos_next;
-#ifdef SDR_TRACK_SETPRIO
-        __builtin_amdgcn_s_setprio(3);
-#endif
         if (role_ok && role < 4) loop_update<kTaps>(sh, u, corr, role, rlane, lk);
-#ifdef SDR_TRACK_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
 #ifdef SDR_TRACE_TRACK
         if (rlane == 0 && role < 4 && ch == 0 && part == 0) g_track_phase[48 + role] += wall_clock64() - role_mark_;
 #endif
