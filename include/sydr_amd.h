@@ -90,7 +90,9 @@ int sdr_prof_reset(sdr_engine* e);
  * (PRN, bin) transform per workgroup, would run (256 transforms or more); "pcps_no_spectra_cache" = 1
  * recomputes conj(fft(code)) in every search, as the reference does (channel_l1ca_kaplan.py:184-185), instead of keeping
  * the spectra of the staged codes; "ingest_by_copy_command" = 1 moves the slabs of sdr_iq_upload_begin / sdr_bank_tick
- * into the ring with a copy command instead of the ingest kernel; "epl_no_chip_variant",
+ * into the ring with a copy command instead of the ingest kernel; "track_one_launch_tick" = 1 runs a one-epoch step
+ * (sdr_bank_tick*, sdr_bank_step with n_epochs = 1) as one workgroup per channel in one launch instead of two launches
+ * on the cluster a block of epochs would use (same time; other order of additions); "epl_no_chip_variant",
  * "epl_no_split_variant", "epl_no_half_chip_view" = 1 keep the E/P/L correlator from its chip-aligned core, from the
  * kernel with the tap switch positions compiled in, from the half-chip view of 32-52 samples per chip.  Integer
  * results do not depend on any of them, floating ones to rounding. */

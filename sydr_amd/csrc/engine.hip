@@ -196,6 +196,7 @@ int sdr_set_option(sdr_engine* e, const char* name, int value) {
     else if (!strcmp(name, "pcps_general_second_sweep")) e->pcps_slow_second = value != 0;
     else if (!strcmp(name, "pcps_no_spectra_cache")) e->pcps_no_spec_cache = value != 0;
     else if (!strcmp(name, "ingest_by_copy_command")) e->ingest_by_copy = value != 0;
+    else if (!strcmp(name, "track_one_launch_tick")) e->track_one_launch_tick = value != 0;
     else if (!strcmp(name, "pcps_prn_chunk")) e->pcps_prn_chunk = value;
     else if (!strcmp(name, "epl_no_chip_variant")) e->epl_no_chip = value != 0;
     else if (!strcmp(name, "epl_no_split_variant")) e->epl_no_split = value != 0;

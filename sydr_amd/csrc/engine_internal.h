@@ -45,6 +45,8 @@ struct DevBuf {
 struct StreamCtx {
     hipStream_t stream = nullptr;
     DevBuf traj, bits, xchg;     // closed-loop launch scratch: epoch records, [list][n_bits][done] + bits, cluster exchange lines
+    void* xchg_tagged = nullptr; // the exchange-line buffer the two-launch ticks' tags refer to (zeroed when it changes)
+    unsigned tick_seq = 0;       // sequence number in those tags
     void* pinned = nullptr;      // page-locked host staging for the small per-step results
     size_t pinned_bytes = 0;
 };
@@ -112,6 +114,7 @@ struct sdr_engine {
     hipStream_t pcps_aux = nullptr;  // second stream of the map-free search (odd sweeps), its two ordering events
     hipEvent_t pcps_ev[2] = {nullptr, nullptr};
     bool pcps_no_fast = false;       // diagnostics: keep the general four-step kernels where the N = 125 x 200 ones would run
+    bool track_one_launch_tick = false;  // "track_one_launch_tick": a one-epoch step as one workgroup per channel in one launch
     bool ingest_by_copy = false;     // "ingest_by_copy_command": queued slabs go into the ring by hipMemcpyAsync, not by the ingest kernel
     bool pcps_no_spec_cache = false; // "pcps_no_spectra_cache": conj(fft(code)) recomputed by every search, as the reference does (kaplan:184-185)
     bool pcps_force_passes = false;  // diagnostics: use the one-kernel-per-radix-pass transform instead of the four-step one

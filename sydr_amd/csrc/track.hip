@@ -489,6 +489,11 @@ constexpr int kXchgStageWords = 256;   // per role wave: up to 4 wave-wide loads
 // is indexed by the position in the list.  Any of these outputs, ch_map and the fault word may live in page-locked
 // host memory (a receiver tick reads its few KB of results without a single copy command).
 // THREADS == 256 && WAVES == 1 is the CLUSTER form (parts >= 2 workgroups per channel, cooperative launch).
+// A ONE-EPOCH step of that form (a receiver tick) needs no cooperative launch when it is cut at the exchange: phase 1 =
+// the cluster's workgroups correlate and publish their sums, then end; phase 2 = one workgroup per channel collects the
+// parts' sums (same order, same bits as the cooperative kernel) and runs the loop update.  Nobody waits for a peer inside
+// a kernel, so two plain launches do (phase = 0: the whole epoch loop in one launch).  tag_base: added to the exchange
+// words' epoch tag, so that lines left by earlier launches cannot validate (the phases do not zero the lines).
 template <int FMT, int THREADS, int WAVES, int NT>
 __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __restrict__ ring, int64_t capacity,
                                                         sdr_track_state* __restrict__ states,
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                                                         const uint32_t* __restrict__ luts,
                                                         int lut_words, int lut_stride, int use_prefix,
                                                         int n_ch, int parts, unsigned long long* xchg,
-                                                        int* __restrict__ fault) {
+                                                        int* __restrict__ fault, int phase, unsigned tag_base) {
     constexpr int kTaps = NT;
     constexpr int kXchgWords = xchg_words(NT);
     constexpr bool kCluster = THREADS == 256 && WAVES == 1;
@@ -516,7 +521,12 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8): the parts of one channel are
     // blockIdx-es with the same residue, so a cluster shares one XCD's L2 for its exchange lines.
     int ch, part;
-    if (parts == 1 || gridDim.x % (8 * parts) != 0) {
+    const bool collect_only = kCluster && phase == 2;      // (uniform) second half of a two-launch tick: no correlation here
+    const bool publish_only = kCluster && phase == 1;      // (uniform) first half: ends after publishing its sums
+    if (collect_only) {
+        ch = blockIdx.x;
+        part = 0;
+    } else if (parts == 1 || gridDim.x % (8 * parts) != 0) {
         ch = blockIdx.x / parts;
         part = blockIdx.x % parts;
     } else {
@@ -546,7 +556,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         sh->fault = 0;
     }
     const int slot = states[sidx].code_slot;
-    stage_lut<THREADS>(lut, luts + (size_t)slot * lut_stride, lut_words, tid);
+    if (!collect_only) stage_lut<THREADS>(lut, luts + (size_t)slot * lut_stride, lut_words, tid);
     const double fs = cfg_ptr->fs;
     UpdateCtx u;
     u.fs = fs;
@@ -646,10 +656,12 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         u.rec = (writer && keep_traj) ? traj + ((size_t)ch * n_epochs + epoch) : nullptr;
 
         double accr[kTaps], acci[kTaps];
-        bool single = false;
+#pragma unroll
+        for (int t = 0; t < kTaps; ++t) accr[t] = acci[t] = 0.0;
+        bool single = collect_only;                            // (phase 2: neither correlator runs)
         int64_t ring_pos_next = ring_pos + ep.n;               // (n <= capacity: checked by the role that announced it)
         if (ring_pos_next >= capacity) ring_pos_next -= capacity;
-        if constexpr (kCluster) {
+        if constexpr (kCluster) if (!collect_only) {
             const SingleGeometry geo = single_geometry(ring_pos, ep.n, capacity);
             single = use_prefix && ep.code_step >= kFastMinCodeStep && ep.code_step <= kFastMaxCodeStep && geo.fits &&
                      geo.groups <= cluster_lanes;
@@ -716,7 +728,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
 #ifdef SDR_TRACE_TRACK
         unsigned long long role_mark_ = 0;
 #endif
-        if constexpr (kCluster) total = reduce_taps_rows<kTaps, THREADS, 3>(accr, acci, red, tid);   // value v in lanes v*G.. of wave 3
+        if constexpr (kCluster) total = collect_only ? 0.0 : reduce_taps_rows<kTaps, THREADS, 3>(accr, acci, red, tid);   // value v in lanes v*G.. of wave 3
         else total = reduce_taps<kTaps, THREADS, 0>(accr, acci, red, tid);
         TRACK_MARK(3);
 #ifdef SDR_TRACE_TRACK
@@ -737,14 +749,15 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             // wave 3 publishes epoch k+1 only after the workgroup's reduction barrier of that epoch, i.e. after
             // all its role waves have finished reading epoch k).
             unsigned long long* lines = xchg + ((size_t)ch * 2 + (epoch & 1)) * kMaxParts * kXchgWordsMax;
-            const unsigned long long tag = (unsigned long long)(unsigned)(epoch + 1) << 32;
-            if (role == 3) {   // lane 2v+h publishes half h of value v (lanes 0..2*NT-1 hold the values)
+            const unsigned long long tag = (unsigned long long)((unsigned)(epoch + 1) + tag_base) << 32;
+            if (role == 3 && !collect_only) {   // lane 2v+h publishes half h of value v (lanes 0..2*NT-1 hold the values)
                 const double v = __shfl(total, ((rlane >> 1) & 15) * collector_group_lanes(NT), 64);
                 if (rlane < 4 * kTaps) {
                     const unsigned half = (rlane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
                     __hip_atomic_store(lines + part * kXchgWords + rlane, tag | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            if (publish_only) return;   // (the whole workgroup: phase 2 takes it from here, in the next launch)
             // Request the next epoch's samples now -- after this epoch's last use of `cur`, before the wait for the
             // peers, so that nothing waits on them: they arrive while this wave sleeps (the counter a wave waits on
             // retires loads in order, and these are ~0.4 us older than the first poll).
@@ -773,7 +786,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                 // down (tools/ubench_sload.hip: a store -> load round trip is 1029 cycles alone, 1664 with every
                 // workgroup polling).  Sleeping ~1000 cycles before the first poll: 5.2 -> 4.8 us per epoch at 32
                 // channels (measured 4 / 8 / 12 / 16 / 20 / 28 x 64 cycles: 5.13, 4.97, 4.94, 4.82, 4.87, 5.04).
-                __builtin_amdgcn_s_sleep(kXchgSleep);
+                if (!collect_only) __builtin_amdgcn_s_sleep(kXchgSleep);   // (phase 2: the words were there before this launch began)
                 for (long spins = 0; spins < kSpinLimit; ++spins) {
                     bool ok = true;
 #pragma unroll
@@ -837,6 +850,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
 #endif
     // End state: the roles kept the LDS copy of the state current (the lock role hands its registers back now); one lane
     // of the recording part writes it out.
+    if (publish_only) return;   // (only reached when the channel was stopped before its epoch: phase 2 reports that)
     if (role == 2 && rlane == 0) lock_regs_store(lk, sh);
     __syncthreads();
     if (tid == 0 && writer) {
@@ -929,6 +943,8 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
     int32_t* d_done = r.d_done;
     const int nt = r.n_taps;
 
+    int phase = 0;
+    unsigned tag_base = 0;
     // One attempt with `parts` workgroups per channel.
     auto attempt = [&](int parts, bool* too_big) -> hipError_t {
         // more channels than CUs: smaller workgroups, two or three of which share a CU, so that one channel's
@@ -945,16 +961,18 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
         const size_t shmem = shmem_base + (up ? prefix_bytes : 0);
         *too_big = shmem > 160u * 1024u;
         if (*too_big) return hipSuccess;
-        if (parts > 1)  // tags of a previous launch must not validate this one's polls
+        if (parts > 1 && !phase)  // tags of a previous launch must not validate this one's polls
             if (hipError_t me = hipMemsetAsync(ctx->xchg.ptr, 0, xchg_bytes + 16, ctx->stream)) return me;
         void* args[] = {&d_iq, &cap, &d_st, &d_st_copy, &d_map, &d_cfgs, &cfg_stride, &n_ep, &d_traj, &keep, &d_bits, &mb,
-                        &d_nbits, &d_done, &d_luts, &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault};
+                        &d_nbits, &d_done, &d_luts, &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault, &phase, &tag_base};
         if (dense) return sdr_track_dense_launch(e->iq_fmt, nt, r.n_ch, shmem, ctx->stream, args);
         hipError_t err = hipSuccess;
         auto launch = [&](auto kernel) {
             // more than 64 KB of dynamic LDS has to be granted per kernel
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-            if (parts > 1)  // the parts of a cluster wait for each other: all workgroups must be resident
+            if (phase)      // a two-launch tick: nobody waits for a peer inside either kernel
+                err = hipLaunchKernel((const void*)kernel, dim3(phase == 1 ? r.n_ch * parts : r.n_ch), dim3(threads), args, shmem, ctx->stream);
+            else if (parts > 1)  // the parts of a cluster wait for each other: all workgroups must be resident
                 err = hipLaunchCooperativeKernel((const void*)kernel, dim3(r.n_ch * parts), dim3(threads), args,
                                                  (unsigned)shmem, ctx->stream);
             else
@@ -991,6 +1009,39 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
         while (parts < kMaxParts && (long)r.n_ch * parts * 2 <= (long)e->n_cus) parts *= 2;
     }
     if (!r.fault_word) SDR_HIP(hipMemsetAsync(d_fault, 0, 16, ctx->stream));
+    // A one-epoch step (a receiver tick) on the cluster a block of epochs would get -- the same partition, the same order of
+    // additions, the same bits -- as TWO plain launches cut at the exchange (see track_kernel): 17.4 us of one workgroup
+    // per channel became ~11 on eight, without the +15-19 us a cooperative launch costs the host.
+    if (!forced && r.n_epochs == 1 && !e->track_one_launch_tick) {
+        int p2 = 1;
+        while (p2 < kMaxParts && (long)r.n_ch * p2 * 2 <= (long)e->n_cus) p2 *= 2;
+        if (p2 > 1) {
+            // the lines are not zeroed per tick: this launch's tag (bit 31 set: no epoch tag of a block launch has it) has
+            // never been stored in them -- unless the buffer is new or the 31-bit sequence wrapped: zero it then
+            if (ctx->xchg_tagged != ctx->xchg.ptr || ctx->tick_seq >= 0x7ffffff0u) {
+                SDR_HIP(hipMemsetAsync(ctx->xchg.ptr, 0, xchg_bytes + 16, ctx->stream));
+                ctx->xchg_tagged = ctx->xchg.ptr;
+                ctx->tick_seq = 0;
+            }
+            tag_base = 0x80000000u | ++ctx->tick_seq;
+            hipError_t err = hipSuccess;
+            bool too_big = false;
+            {
+                ProfScope ps(e, "track_kernel", ctx->stream);
+                phase = 1;
+                err = attempt(p2, &too_big);
+                phase = 2;
+                if (err == hipSuccess && !too_big) err = attempt(p2, &too_big);
+                phase = 0;
+            }
+            if (too_big) return sdr_fail(SDR_ERR_RANGE, "closed-loop tracking: code table does not fit the LDS");
+            if (err != hipSuccess)
+                return sdr_fail(SDR_ERR_HIP, "closed-loop tick launch (%d channels x %d parts) failed: %s", r.n_ch, p2, hipGetErrorString(err));
+            SDR_HIP(hipGetLastError());
+            if (parts_used) *parts_used = p2;
+            return SDR_OK;
+        }
+    }
     hipError_t launch_err = hipSuccess;
     {
         ProfScope ps(e, "track_kernel", ctx->stream);

@@ -38,6 +38,41 @@ def test_bank_steps_equal_the_closed_loop_run(engine):
         engine.track_cluster(0)
 
 
+def test_one_epoch_steps_run_on_the_cluster_a_block_launch_uses(engine):
+    """With the cluster size left to the library, a one-epoch step (a receiver tick) runs as two plain launches cut at
+    the exchange of the partial sums, on the 8 workgroups per channel the 60-epoch cooperative launch spreads a channel
+    over: 40 single epochs + a block of 20 == the 60 epochs of one launch, bit for bit; and the one-launch form of the
+    tick (`track_one_launch_tick`) agrees with it to rounding."""
+    g, fs, raw = trajectory_iq()
+    n = raw.size // 2 // 8 * 8
+    engine.iq_alloc(n, FMT_CI8)
+    engine.iq_upload(raw[:2 * n], 0)
+    engine.code_slots(2)
+    engine.load_gps_code(1, 7)
+    acq = g["kaplan_acq"]
+    st_k = initial_state(1, fs, acq[3], int(acq[5]), KAPLAN_CFG, slot=1)
+    st_b = initial_state(0, fs, acq[3], int(acq[5]), BORRE_CFG, slot=1)
+    _bank_vs_closed_loop(engine, fs, st_k, st_b)
+    recs = {}
+    for one_launch in (0, 1):
+        engine.set_option("track_one_launch_tick", one_launch)
+        try:
+            bank = engine.bank(4)
+            bank.put(0, as_row(st_k, TRACK_STATE_DTYPE), as_row(loop_cfg(1, fs, KAPLAN_CFG), LOOP_CFG_DTYPE))
+            recs[one_launch] = np.concatenate([bank.step([0], 1)[0][0] for _ in range(30)])
+            bank.close()
+        finally:
+            engine.set_option("track_one_launch_tick", 0)
+    a, b = recs[0], recs[1]
+    assert a.tobytes() != b.tobytes()                       # (another order of additions: the forms do differ in the last bits)
+    for name in ("start_sample", "n_samples", "lock_state", "track_flags", "nav_bit"):
+        assert np.array_equal(a[name], b[name]), name
+    scale = np.hypot(a["corr"][:, 2], a["corr"][:, 3])[:, None]
+    assert np.max(np.abs(a["corr"] - b["corr"]) / scale) < 1e-9
+    for name in ("carrier_hz", "code_hz", "dll", "pll", "fll", "cn0"):
+        assert np.allclose(a[name], b[name], rtol=1e-9, atol=1e-9), name
+
+
 def _bank_vs_closed_loop(engine, fs, st_k, st_b):
     ref_k, traj_k = engine.track_closed_loop([st_k], loop_cfg(1, fs, KAPLAN_CFG), 60)
     ref_b, traj_b = engine.track_closed_loop([st_b], loop_cfg(0, fs, BORRE_CFG), 60)
@@ -284,8 +319,7 @@ def test_read_ahead_on_the_device_equals_plain_ticks(engine, tmp_path):
 
     plain, _ = receiver(0)
     ahead, _ = receiver(40)
-    # a block launch spreads a channel over several workgroups, the one-epoch tick kernel does not: the partial sums are
-    # added in another order, so floating fields agree to rounding (1e-9 of the prompt magnitude), everything else exactly
+    # (floating fields compared relative to the prompt magnitude; everything else exactly)
     n_trk, worst = 0, 0.0
     for k, (a, b) in enumerate(zip(plain, ahead)):
         key = lambda p: (p["cid"], p["type"].value)
@@ -302,7 +336,10 @@ def test_read_ahead_on_the_device_equals_plain_ticks(engine, tmp_path):
                 else:
                     assert p[name] == q[name] or name == "peak_ratio", (k, name, p[name], q[name])
         n_trk += sum(1 for p in b if "i_prompt" in p)
-    assert worst < 1e-9, worst
+    # a tick runs its epoch on the cluster a block launch would use (two plain launches cut at the exchange of the partial
+    # sums: track.hip, launch_track): up to 32 channels both spread a channel over 8 workgroups -- same partition, same
+    # order of additions, same bits
+    assert worst == 0.0, worst
     assert n_trk > 8 * 350 + 4 * 200
 
 
