@@ -302,17 +302,32 @@ class LazyPacket(dict):
         return (dict, (dict.copy(self),))    # travels (pickle, queues) as the plain dict it stands for
 
 
-_TEMPLATES = {}     # (message type, cid) -> the two keys a packet is born with
+_TEMPLATES = {}       # (message type's value, cid) -> the two keys a packet is born with
+_TEMPLATE_LISTS = {}  # (message type's value, the channel numbers' type and bytes) -> the list of those for a whole tick
 
 
 def packet_templates(kind, cids):
-    """The {"cid", "type"} dicts LazyPackets of `kind` for the channels `cids` (a list of ints) are copied from."""
+    """The {"cid", "type"} dicts LazyPackets of `kind` for the channels `cids` (an integer array or a list of ints) are
+    copied from.  A receiver's ticks report the same channels over and over: the list itself is remembered per channel
+    set (a few entries: the sets differ only while channels come and go)."""
+    code = kind.value                    # (an int: hashing the enum member itself is a Python-level call per key)
+    key = None
+    if isinstance(cids, np.ndarray):
+        key = (code, cids.dtype.char, cids.tobytes())
+        hit = _TEMPLATE_LISTS.get(key)
+        if hit is not None:
+            return hit
+        cids = cids.tolist()
     out = []
     for c in cids:
-        t = _TEMPLATES.get((kind, c))
+        t = _TEMPLATES.get((code, c))
         if t is None:
-            t = _TEMPLATES[(kind, c)] = {"cid": c, "type": kind}
+            t = _TEMPLATES[(code, c)] = {"cid": c, "type": kind}
         out.append(t)
+    if key is not None:
+        if len(_TEMPLATE_LISTS) > 4096:
+            _TEMPLATE_LISTS.clear()
+        _TEMPLATE_LISTS[key] = out
     return out
 
 
@@ -336,8 +351,7 @@ class TrackingRows:
 
     def templates(self):
         if self._templates is None:
-            cids = self.cids.tolist() if isinstance(self.cids, np.ndarray) else list(self.cids)
-            self._templates = packet_templates(ChannelMessage.TRACKING_UPDATE, cids)
+            self._templates = packet_templates(ChannelMessage.TRACKING_UPDATE, self.cids)
         return self._templates
 
     def full(self, cid):
@@ -382,8 +396,9 @@ class UpdateRows:
     __slots__ = ("cids", "states", "flags", "tows", "tow_decoded", "unread", "code", "samples_per_ms", "_rows", "_templates")
 
     def __init__(self, cids, states, flags, tows, tow_decoded, unread, code_since_tow, samples_per_ms, templates=None):
-        """cids / flags / unread / code_since_tow: one value per packet; states: ChannelState per packet; tows /
-        tow_decoded: per packet (arrays of len(cids)) or per CHANNEL NUMBER (longer arrays, indexed by cid)."""
+        """cids / flags / unread / code_since_tow: one value per packet (or flags = the tick's sdr_tick_update rows and
+        unread = code_since_tow = None); states: ChannelState per packet; tows / tow_decoded: per packet (arrays of
+        len(cids)) or per CHANNEL NUMBER (longer arrays, indexed by cid)."""
         self.cids, self.states, self.flags, self.tows, self.tow_decoded = cids, states, flags, tows, tow_decoded
         self.unread, self.code, self.samples_per_ms = unread, code_since_tow, samples_per_ms
         self._rows = None
@@ -397,11 +412,14 @@ class UpdateRows:
 
     def templates(self):
         if self._templates is None:
-            self._templates = packet_templates(ChannelMessage.CHANNEL_UPDATE, self._cid_list())
+            self._templates = packet_templates(ChannelMessage.CHANNEL_UPDATE, self.cids)
         return self._templates
 
     def full(self, cid):
         if self._rows is None:
+            if self.unread is None:      # `flags` holds a tick's sdr_tick_update rows: the three columns come from it
+                upd = self.flags
+                self.flags, self.unread, self.code = upd["track_flags"], upd["unread"], upd["epochs_since_tow"]
             cids = self._cid_list()
             tows, dec = np.asarray(self.tows), np.asarray(self.tow_decoded)
             if len(tows) != len(cids):

@@ -210,9 +210,18 @@ class ChannelManager:
                 return self._accept_prefetched(data)
             if self._ra_ms and ra.empty and self._open_window(data):
                 return None
-        self._flush_pending()
-        staged, offset, count = self.sharedBuffer.stage(data)
-        if self.sharedBuffer.full and (self._unread_max is None or self._unread_max + count > self.sharedBuffer.maxSize):
+        if self._pending:
+            self._flush_pending()
+        ring = self.sharedBuffer
+        if (type(data) is np.ndarray and data.ndim == 1 and data.dtype == ring.rawDtype and data.flags.c_contiguous
+                and not data.size & 1 and data.size):
+            # the usual slab -- interleaved I,Q in the ring's own element type: nothing to convert (stage() does the rest)
+            staged, offset, count = data, ring.idxWrite, data.size >> 1
+            if ring.maxSize % count:
+                raise ValueError("Data shift need to be a multiple from the max buffer size.")
+        else:
+            staged, offset, count = ring.stage(data)
+        if ring.full and (self._unread_max is None or self._unread_max + count > ring.maxSize):
             self._guard_unread(count)
         self._unread_max = None
         if staged.nbytes > self.DEFER_BYTES or not hasattr(self.engine, "iq_upload_begin"):
@@ -223,7 +232,7 @@ class ChannelManager:
             # its way to run() -- ordered before the tick's launch, waited for by the tick's one synchronisation
             self.engine.iq_upload_begin(staged, offset)
             self._pending = True
-        self.sharedBuffer.shiftIdxWrite(count)
+        ring.shiftIdxWrite(count)
 
     def _guard_unread(self, count: int):
         """Refuse to overwrite samples a tracking channel has not consumed yet (the reference would silently wrap:
@@ -276,7 +285,7 @@ class ChannelManager:
             # steady: every active channel is tracking on the device -- the tick is one library call (_tick_steady)
             steady = bool(cacheable and active and not acquiring and not host_plugins
                           and all(st is ChannelState.TRACKING for st in states_active))
-            upd_templates = packet_templates(ChannelMessage.CHANNEL_UPDATE, cids_active.tolist())
+            upd_templates = packet_templates(ChannelMessage.CHANNEL_UPDATE, cids_active)
             self._lists = (((version, self.nbChannels), active, acquiring, host_plugins, cids_active, states_active, steady,
                             upd_templates) if cacheable else None)
             self._unread_max = None
@@ -371,8 +380,8 @@ class ChannelManager:
                 out.add_ready(pkt for _, _, pkt in bank.take_decoded())
         if len(upd) != len(cids_active):                     # (cannot happen while the lists stand; never guess)
             raise RuntimeError("channel bank and channel manager disagree about the tracking channels")
-        out.add_lazy(UpdateRows(cids_active, states_active, upd["track_flags"], bank.tow.copy(), bank.tow_decoded.copy(),
-                                upd["unread"], upd["epochs_since_tow"], self._samples_per_ms, upd_templates))
+        out.add_lazy(UpdateRows(cids_active, states_active, upd, bank.tow.copy(), bank.tow_decoded.copy(), None, None,
+                                self._samples_per_ms, upd_templates))     # (flags / unread / code count: the rows of `upd`)
         return out
 
     def _acquire(self, acquiring):

@@ -147,18 +147,19 @@ class Bank:
         m.tracking, m.lost, m.host_flags = tracking.ctypes.data, lost.ctypes.data, host_flags.ctypes.data
         m.ran, m.records, m.updates = self.ran.ctypes.data, self.records.ctypes.data, self.updates.ctypes.data
         self._mirror_ref = C.byref(m)
+        self._tick_no_slab = (self._e._h, self._h, None, 0)        # leading arguments of a tick whose slab is queued already
         return m
 
     def tick_mirrored(self, raw, ring_offset: int, write_index: int):
         """One receiver tick with the readiness test and the mirror updates in the library (sdr_bank_tick_mirrored);
         `raw` None when the slab went in with Engine.iq_upload_begin.  -> the bound sdr_tick_mirror (n_ran, n_updates,
         n_nav_bits, n_lost, max_unread; the rows in `ran` / `records` / `updates`)."""
-        n_samples = 0
-        if raw is not None:
+        if raw is None:
+            status = self._lib.sdr_bank_tick_mirrored(*self._tick_no_slab, ring_offset, write_index, self._mirror_ref)
+        else:
             raw = self._e._ring_samples(raw)
-            n_samples = raw.size // 2
-        status = self._lib.sdr_bank_tick_mirrored(self._e._h, self._h, ptr(raw) if n_samples else None, n_samples,
-                                                  ring_offset, write_index, self._mirror_ref)
+            status = self._lib.sdr_bank_tick_mirrored(self._e._h, self._h, ptr(raw), raw.size // 2, ring_offset, write_index,
+                                                      self._mirror_ref)
         if status:
             check(status)
         return self._mirror
@@ -246,8 +247,11 @@ class Engine:
     def iq_upload_begin(self, raw: np.ndarray, ring_offset: int = 0):
         """iq_upload without the wait (sdr_iq_upload_begin): `raw` is copied before the call returns, the transfer is
         ordered before everything queued on the engine's stream afterwards; `sync()` completes it."""
-        raw = self._ring_samples(raw)
-        check(self._lib.sdr_iq_upload_begin(self._h, raw.ctypes.data, raw.size // 2, int(ring_offset)))
+        if not (type(raw) is np.ndarray and raw.ndim == 1 and raw.flags.c_contiguous and raw.dtype == _lib.fmt_dtype(self.iq_fmt)):
+            raw = self._ring_samples(raw)
+        status = self._lib.sdr_iq_upload_begin(self._h, raw.ctypes.data, raw.size >> 1, ring_offset)
+        if status:
+            check(status)
 
     def iq_download(self, n_samples: int, ring_offset: int = 0) -> np.ndarray:
         out = np.empty(2 * int(n_samples), dtype=_lib.fmt_dtype(self.iq_fmt))

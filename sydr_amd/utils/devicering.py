@@ -28,6 +28,8 @@ class CircularBuffer:
         self.sharedMemory = sharedMemory  # accepted for signature compatibility; unused (no shm, no fork)
         self.fmt = fmt if fmt is not None else _FMT_OF_DTYPE.get(np.dtype(dtype), FMT_CF64)
         engine.iq_alloc(self.maxSize, self.fmt)
+        # element type of the interleaved I,Q the ring stores (what a slab needs no conversion from)
+        self.rawDtype = np.dtype({FMT_CI8: np.int8, FMT_CI16: np.int16}.get(self.fmt, np.float64 if self.fmt == FMT_CF64 else np.float32))
         self.full = False
         self.idxWrite = 0
         self.idxRead = 0
