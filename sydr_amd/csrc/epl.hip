@@ -47,6 +47,7 @@ constexpr int kWaveThreads = 64;  // one wave per channel-epoch: the ~5 us fixed
 constexpr int kVariantKS12 = 256 * 12;   // three taps, the outer ones switching 12.x samples into the anchor's block (24 / 25 samples per chip)
 constexpr int kVariantKSMask = 256 * 15; // ... in general: KS in bits 8-11, with the block length KM in the low byte (kChipMax + KM)
 constexpr int kVariantKS9 = 256 * 9;     // 19 / 20 samples per chip (20 MHz): KM = 19, KS = 9
+constexpr int kVariantKM1516 = 16;       // (added to kChipMax) 15.x or 16.x samples per chip by the epoch: both block lengths compiled in
 constexpr int kVariantKI = 4096;         // taps whole (half-)chips apart: no switch inside a block
 constexpr int kVariantC2 = 8192;         // several chips per lane (correlator_chip2.h), x 1 / 2: boundaries <4,9,14,19> / <5,11,17,23>
 constexpr int kLongLutWords = 4096;  // replicas of 16 KB and more (multi-period / BOC half-chip codes): four epochs share a staged copy
@@ -63,14 +64,19 @@ constexpr int kLongLutWords = 4096;  // replicas of 16 KB and more (multi-period
 #ifndef SDR_EPL_WAVES
 #define SDR_EPL_WAVES 1
 #endif
-template <int FMT, int NT, int W, int KM = 0, int WPW = 1, int KS = 0, int KI = 0>
+// KM2 != 0 (with KS = KI = 0): the list's epochs have KM or KM2 = KM + 1 whole samples per chip by the sign of their code
+// Doppler (16.368 MHz: exactly 16.0) -- both block lengths are compiled in and an epoch takes the body of its own.
+template <int FMT, int NT, int W, int KM = 0, int WPW = 1, int KS = 0, int KI = 0, int KM2 = 0>
 #ifndef SDR_EPL_KS_WAVES
 #define SDR_EPL_KS_WAVES 3   // (the KS kernel sits at the 168-register cap of three waves per SIMD; two waves: 0.306 instead of 0.286 ms per stream-second)
 #endif
 #ifndef SDR_EPL_KI_WAVES
 #define SDR_EPL_KI_WAVES 1
 #endif
-__global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (KI != 0 ? SDR_EPL_KI_WAVES : SDR_EPL_WAVES))) void epl_kernel(const void* __restrict__ ring, const void* __restrict__ ring_flipped, int64_t capacity,
+#ifndef SDR_EPL_KM2_WAVES
+#define SDR_EPL_KM2_WAVES 1
+#endif
+__global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (KI != 0 ? SDR_EPL_KI_WAVES : (KM2 != 0 ? SDR_EPL_KM2_WAVES : SDR_EPL_WAVES)))) void epl_kernel(const void* __restrict__ ring, const void* __restrict__ ring_flipped, int64_t capacity,
                                                        const sdr_epl_item* __restrict__ items, int n_items, int group_stride,
                                                        const uint32_t* __restrict__ luts,
                                                        int lut_words, int lut_stride,
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (
         compute_tap_constants<NT>(K, ep, spacing + tap0);   // (the chip-aligned core evaluates its own rotations)
         if (chip_variant_applies(ep, capacity)) {
             base = ep.start_sample % capacity;
-            chip_geometry<NT, KM, KS, KI>(ep.n, K.shift, K.step, K.inv_step, G);
+            chip_geometry<NT, (KM2 != 0 ? 0 : KM), KS, KI>(ep.n, K.shift, K.step, K.inv_step, G);   // (two lengths: the body is chosen below)
         }
     } else {
         compute_constants<NT>(K, ep, spacing + tap0, dphi, kWaveThreads);
@@ -144,10 +150,23 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (
     double accr[NT], acci[NT];
     if constexpr (W == kChipMax && FMT == SDR_FMT_CI8) {
         // chip-aligned blocks (correlator_chip.h); an epoch it does not cover is redone per sample
-        const bool done = base >= 0 &&
-                          correlate_epoch_chip<NT, true, KM, KS, KI>(ring, ring_flipped, capacity, ep, dphi, K, G, base, rot_plan, lut, prefix,
-                                                         prefix + kThreads * chip_strip_slots<NT>() + wave * kChipMax,
-                                                         tid, lane, kWaveThreads, lane, accr, acci);
+        bool done = false;
+        if constexpr (KM2 != 0) {
+            static_assert(KS == 0 && KI == 0 && !kPre, "two block lengths: tap positions at run time, no plan setups");
+            const int M = __builtin_amdgcn_readfirstlane((int)(G.Tfx >> 32));
+            double2* const rot = prefix + kThreads * chip_strip_slots<NT>() + wave * kChipMax;
+            if (base >= 0 && M == KM)
+                done = correlate_epoch_chip<NT, true, KM, 0, 0>(ring, ring_flipped, capacity, ep, dphi, K, G, base, rot_plan, lut, prefix, rot,
+                                                                 tid, lane, kWaveThreads, lane, accr, acci);
+            else if (base >= 0 && M == KM2)
+                done = correlate_epoch_chip<NT, true, KM2, 0, 0>(ring, ring_flipped, capacity, ep, dphi, K, G, base, rot_plan, lut, prefix, rot,
+                                                                  tid, lane, kWaveThreads, lane, accr, acci);
+        } else {
+            done = base >= 0 &&
+                   correlate_epoch_chip<NT, true, KM, KS, KI>(ring, ring_flipped, capacity, ep, dphi, K, G, base, rot_plan, lut, prefix,
+                                                              prefix + kThreads * chip_strip_slots<NT>() + wave * kChipMax,
+                                                              tid, lane, kWaveThreads, lane, accr, acci);
+        }
         if (!done) {
             // (its own copy of the per-epoch constants: the in-group rotations the per-sample routine wants would
             // otherwise sit in 64 scalar registers across the whole chip-aligned path)
@@ -309,6 +328,9 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 1, 0, (kOdd ? 1 : 0)>);
     else if (wide == kChipMax + 24 && FMT == SDR_FMT_CI8)   // chip-aligned, every epoch with 24 or 25 samples per chip
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24>);
+    else if (wide == kChipMax + kVariantKM1516 && FMT == SDR_FMT_CI8 && NT == 3) {   // 15.x or 16.x samples per chip, epoch by epoch
+        if constexpr (FMT == SDR_FMT_CI8 && NT == 3) launch(epl_kernel<FMT, NT, kChipMax, 15, 1, 0, 0, 16>);
+    }
     else if (wide >= kChipMax && FMT == SDR_FMT_CI8)
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16)>);
     else if (wide == 16)
@@ -494,6 +516,7 @@ static int variant_of(const sdr_engine* e, const ItemRules& r, const double* spa
     const bool all_s12 = all_m24 && all_split;
     const bool all_s9 = m_lo == 19 && m_hi == 19 && all_split;          // (20 MHz: the KM = 19, KS = 9 instantiation)
     const bool all_m15 = m_lo == 15 && m_hi == 15;                      // (31-32.7 MHz on the half-chip view: KM = 15, whole-chip taps)
+    const bool all_m1516 = m_lo >= 15 && m_hi <= 16 && r.n_taps == 3 && r.scale == 1.0;   // (16.368 MHz: 16.0 -- 15.x or 16.x by the Doppler's sign)
     const bool boundary_ok = min_step >= sdr::kFastMinCodeStep && r.scale * e->lut_stride < sdr::kFastMaxLutWords;
     int wide = !boundary_ok ? 0 : (max_step <= sdr::kFastMaxCodeStep ? 16 : (max_step <= sdr::kFastMaxCodeStep8 ? 8 : 0));
     // every item inside the chip-aligned variant's range (ci8 ring): lanes own whole chips instead of 16 samples
@@ -507,7 +530,8 @@ static int variant_of(const sdr_engine* e, const ItemRules& r, const double* spa
                ((all_m24 && all_s12 && !e->epl_no_split) ? kVariantKS12 : 0) +
                ((all_m24 && all_ki && !e->epl_no_split) ? kVariantKI : 0) +
                ((all_s9 && !e->epl_no_split) ? 19 + kVariantKS9 : 0) +
-               ((all_m15 && all_ki && r.n_taps == 3 && r.scale == 2.0 && !e->epl_no_split) ? 15 + kVariantKI : 0);
+               ((all_m15 && all_ki && r.n_taps == 3 && r.scale == 2.0 && !e->epl_no_split) ? 15 + kVariantKI : 0) +
+               ((all_m1516 && !e->epl_no_split) ? kVariantKM1516 : 0);
     return wide;
 }
 

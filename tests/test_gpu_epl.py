@@ -820,6 +820,67 @@ def test_compile_time_tap_switch_variant_at_20_mhz(engine):
     plan.close()
 
 
+def test_two_block_lengths_in_one_kernel_at_16_368_mhz(engine):
+    """16.368 MHz is exactly 16.0 samples per chip: an epoch's chips hold 15.x or 16.x samples by the sign of its code
+    Doppler, so one list holds both.  The kernel with BOTH block lengths compiled in (`sdr_epl_plan_variant` = 26 + 16) takes
+    such lists -- every epoch the body of its own length, tap positions at run time (at +-0.5 chip the taps switch ON a
+    sample: nothing to compile in).  Long and short lists against the oracle and against the run-time-position kernel;
+    all-positive and all-negative Doppler lists take it too; odd epochs fall back inside the launch; 17.x samples per chip
+    in the list: not this kernel."""
+    rng = np.random.default_rng(16368)
+    fs = 16.368e6
+    cap = 8 * 40000
+    raw = rng.integers(-100, 100, 2 * cap).astype(np.int8)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(8, 1023, 3)
+    for s in range(8):
+        engine.load_gps_code(s, 3 * s + 2)
+    rf = orc.iq_to_complex(raw)
+    half = (-0.5, 0.0, 0.5)
+    for n_items, sign in ((96, 0), (4200, 0), (300, 1), (300, -1)):
+        dop = rng.uniform(-4, 4, n_items) if sign == 0 else sign * rng.uniform(0.01, 4, n_items)
+        step = (1.023e6 + dop) / fs
+        rem_code = rng.uniform(0, step)
+        rem_code[:6] = [0.0, 0.5, 0.25, 1e-9, step[4] / 2, step[5] * (1 - 1e-12)]
+        periods = rng.integers(1, 3, n_items)
+        n = np.ceil((1023 * periods - rem_code) / step).astype(np.int64) + rng.integers(-1, 2, n_items)
+        n[6:10] = [3, 40, 70, 21]
+        start = rng.integers(0, cap - 40000, n_items)
+        start[10:13] = [0, 1, cap - int(n[12]) - 1]
+        slot = rng.integers(0, 8, n_items)
+        f = rng.uniform(-6000, 6000, n_items)
+        f[13:16] = [0.0, 4.092e6, -4.092e6]
+        rem_carrier = rng.uniform(0, 2 * np.pi, n_items)
+        items = make_items(slot, n, start, f, rem_carrier, rem_code, step)
+        got = {}
+        for no_split in (0, 1):
+            engine.set_option("epl_no_split_variant", no_split)
+            try:
+                plan = engine.epl_plan(items, half, fs)
+                plan.run()
+                got[no_split] = (plan.variant, plan.fetch())
+                plan.close()
+            finally:
+                engine.set_option("epl_no_split_variant", 0)
+        assert got[0][0] == 26 + 16 and got[1][0] == 26, (n_items, sign, got[0][0], got[1][0])
+        if sign == 0:
+            assert (step > 1 / 16).any() and (step < 1 / 16).any()        # both block lengths in the list
+        for k in (range(n_items) if n_items < 1000 else rng.choice(n_items, 60, replace=False)):
+            x = orc.ring_slice(rf, int(start[k]), int(n[k]))
+            ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(3 * int(slot[k]) + 2)), fs, f[k], rem_carrier[k], rem_code[k], step[k], half))
+            scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 50.0), 2)
+            for no_split in (0, 1):
+                assert np.max(np.abs(got[no_split][1][k] - ref) / scale) < 1e-9, (n_items, k, no_split, step[k], n[k])
+    # 17.4 MHz: 17.0 samples per chip -- 16.x and 17.x: outside the pair compiled in
+    items2 = items[:200].copy()
+    items2["code_step"] = (1.023e6 + rng.uniform(-4, 4, 200)) / 17.391e6
+    items2["n_samples"] = np.ceil((1023 - items2["rem_code"]) / items2["code_step"]).astype(np.int64)
+    plan = engine.epl_plan(items2, half, 17.391e6)
+    assert plan.variant == 26
+    plan.close()
+
+
 @pytest.mark.parametrize("n_items", [150, 4300])
 def test_whole_chip_tap_variant_on_the_half_chip_view_at_32_mhz(engine, n_items):
     """31-32.7 MHz: a chip holds 30.3-32 samples, a half chip 15.x -- the half-chip view with the whole-chip-tap kernel
