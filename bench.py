@@ -204,7 +204,7 @@ def kernel_of_variant(variant, n_taps, waves_per_group=1):
     ks = (variant & 0xF00) >> 8
     ki = 1 if variant & 4096 else 0
     base = 26 if w >= 26 else w
-    return f"epl_kernel<0,{n_taps},{base},{km},{waves_per_group},{ks},{ki}>"
+    return f"epl_kernel<0,{n_taps},{base},{km},{waves_per_group},{ks},{ki},0>"      # (last: no second block length)
 
 
 def device_identity(torch, local_rank):
