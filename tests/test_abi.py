@@ -96,10 +96,10 @@ def test_product_never_imports_the_oracle():
                     assert "test_host_layer" not in text and "fake_engine" not in text, f   # (they would pull the oracle in)
 
 
-def _build_c_example(tmp_path):
-    exe = tmp_path / "acquire_track"
+def _build_c_example(tmp_path, name="acquire_track"):
+    exe = tmp_path / name
     subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"),
-                           os.path.join(REPO, "examples", "acquire_track.c"), "-L", os.path.join(REPO, "sydr_amd"),
+                           os.path.join(REPO, "examples", name + ".c"), "-L", os.path.join(REPO, "sydr_amd"),
                            "-lsydr_amd", "-lm", "-Wl,-rpath," + os.path.join(REPO, "sydr_amd"), "-o", str(exe)])
     return exe
 
@@ -108,6 +108,20 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
     """The boundary is a C-ABI: the header compiles as C99 and a client written in C (examples/acquire_track.c)
     links against the library with nothing but the header."""
     _build_c_example(tmp_path)
+    _build_c_example(tmp_path, "receiver_loop")
+
+
+@pytest.mark.gpu
+def test_c_receiver_loop_ticks_through_the_mirrored_call(tmp_path):
+    """examples/receiver_loop.c: the reference receiver's per-millisecond loop from plain C -- sdr_iq_upload_begin +
+    sdr_bank_tick_mirrored per tick, 32 channels @ 25 MHz from acquisition on: every channel ends on its satellite's
+    Doppler, an epoch per channel and tick, navigation bits counted by the call."""
+    out = subprocess.check_output([str(_build_c_example(tmp_path, "receiver_loop")), "300"], text=True, timeout=120)
+    m = re.search(r"(\d+) ticks, (\d+) epochs, (\d+) navigation bits, (\d+) of 32 channels on their Doppler", out)
+    assert m, out
+    ticks, epochs, bits, locked = (int(g) for g in m.groups())
+    assert ticks == 300 and locked == 32 and epochs >= 32 * 297 and bits >= 20, out
+    assert re.search(r"us per tick", out), out
 
 
 @pytest.mark.gpu
