@@ -403,3 +403,76 @@ def test_library_side_tick_equals_the_general_tick(engine):
     for k, (a, b) in enumerate(zip(general, steady)):
         assert a == b, k
     assert attrs_g == attrs_s
+
+
+def test_mirrored_tick_with_three_and_five_tap_channels(engine):
+    """sdr_bank_tick_mirrored when the ready channels do not all run the same number of taps (the kernels are compiled per
+    tap count: one launch per group inside the call): channels 0, 2, 4, 5 track E/P/L, channels 1 and 3 VE/E/P/L/VL on the
+    same satellite; `ran`, the records and the mirror rows come back in ascending channel order, each channel's record and
+    state bit for bit what stepping its own group alone gives; a channel without a complete epoch is left out."""
+    import ctypes as C
+    from sydr_amd import _lib
+    from sydr_amd._lib import TICK_UPDATE_DTYPE, TRACK_EPOCH_DTYPE
+    g, fs, raw = trajectory_iq()
+    n = raw.size // 2 // 8 * 8
+    engine.iq_alloc(n, FMT_CI8)
+    engine.iq_upload(raw[:2 * n], 0)
+    engine.code_slots(2)
+    engine.load_gps_code(1, 7)
+    acq = g["kaplan_acq"]
+    taps_of = [3, 5, 3, 5, 3, 3]
+    cfg3 = loop_cfg(1, fs, KAPLAN_CFG)
+    cfg5 = loop_cfg(1, fs, KAPLAN_CFG)
+    cfg5.n_taps = 5
+    for t, (w, nar) in enumerate(zip((-1.0, -0.5, 0.0, 0.5, 1.0), (-0.5, -0.25, 0.0, 0.25, 0.5))):
+        cfg5.spacing_wide[t], cfg5.spacing_narrow[t] = w, nar
+    st0 = initial_state(1, fs, acq[3], int(acq[5]), KAPLAN_CFG, slot=1)
+    spms = int(fs * 1e-3)
+
+    def fresh_bank():
+        bank = engine.bank(6)
+        for ch, nt in enumerate(taps_of):
+            bank.put(ch, as_row(st0, TRACK_STATE_DTYPE), as_row(cfg5 if nt == 5 else cfg3, LOOP_CFG_DTYPE))
+        return bank
+    # reference: each tap group stepped on its own, epoch by epoch
+    ref_bank = fresh_bank()
+    n_ticks = 25
+    ref_rec = {ch: [] for ch in range(6)}
+    for k in range(n_ticks):
+        for group in ([0, 2, 4, 5], [1, 3]):
+            rec, states, done, _ = ref_bank.step(group, 1)
+            assert list(done) == [1] * len(group)
+            for i, ch in enumerate(group):
+                ref_rec[ch].append(rec[i, 0].copy())
+    ref_bank.close()
+    # the mirrored tick over all six
+    bank = fresh_bank()
+    states = np.zeros(6, dtype=TRACK_STATE_DTYPE)
+    for ch in range(6):
+        states[ch] = as_row(st0, TRACK_STATE_DTYPE)
+    last = np.zeros(6, dtype=TRACK_EPOCH_DTYPE)
+    since, host_flags = np.zeros(6, dtype=np.int64), np.zeros(6, dtype=np.int64)
+    tracking, lost = np.ones(6, dtype=bool), np.zeros(6, dtype=bool)
+    tracking[5] = False                                     # (not tracking: never runs, no update row)
+    m = bank.bind_mirror(states, last, since, tracking, lost, host_flags)
+    got = {ch: [] for ch in range(6)}
+    for k in range(n_ticks + 3):
+        # the write index as a receiver's would stand: far enough ahead for every channel's next epoch -- except in
+        # tick 3, when nothing new has arrived and nobody has a complete epoch
+        write = (int(states["current_sample"].max()) + int(states["n_samples"].max()) + 8) % n if k != 3 else int(states["current_sample"].max()) % n
+        bank.tick_mirrored(None, 0, write)
+        ran = bank.ran[:m.n_ran].tolist()
+        if k == 3:
+            assert ran == [] and m.n_updates == 5
+            continue
+        assert ran == [0, 1, 2, 3, 4] and m.n_updates == 5 and m.n_lost == 0
+        assert bank.updates["channel"][:5].tolist() == [0, 1, 2, 3, 4]
+        for i, ch in enumerate(ran):
+            got[ch].append(bank.records[i].copy())
+            assert last[ch].tobytes() == bank.records[i].tobytes()
+        assert (bank.updates["epochs_since_tow"][:5] == since[:5]).all() and since[5] == 0
+    for ch in range(5):
+        a = np.array(got[ch][:n_ticks]).tobytes()
+        b = np.array(ref_rec[ch]).tobytes()
+        assert len(got[ch]) == n_ticks + 2 and a == b, ch
+    bank.close()
