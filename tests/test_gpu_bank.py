@@ -476,3 +476,57 @@ def test_mirrored_tick_with_three_and_five_tap_channels(engine):
         b = np.array(ref_rec[ch]).tobytes()
         assert len(got[ch]) == n_ticks + 2 and a == b, ch
     bank.close()
+
+
+def test_mirrored_tick_refuses_what_it_cannot_trust(engine):
+    """sdr_bank_tick_mirrored validates its mirror before anything reaches the device: missing arrays, a mirror of another
+    size than the bank, a write index outside the ring -- an error code and a message, no launch."""
+    import ctypes as C
+    from sydr_amd import _lib
+    from sydr_amd._lib import SdrError, TRACK_EPOCH_DTYPE
+    engine.iq_alloc(80000, FMT_CI8)
+    engine.code_slots(2)
+    engine.load_gps_code(0, 3)
+    bank = engine.bank(4)
+    states, last = np.zeros(4, dtype=TRACK_STATE_DTYPE), np.zeros(4, dtype=TRACK_EPOCH_DTYPE)
+    since, host_flags = np.zeros(4, dtype=np.int64), np.zeros(4, dtype=np.int64)
+    tracking, lost = np.zeros(4, dtype=bool), np.zeros(4, dtype=bool)
+    with pytest.raises(ValueError):
+        bank.bind_mirror(states[:3], last, since, tracking, lost, host_flags)         # rows != bank channels
+    with pytest.raises(ValueError):
+        bank.bind_mirror(states, last, since.astype(np.int32), tracking, lost, host_flags)
+    m = bank.bind_mirror(states, last, since, tracking, lost, host_flags)
+    bank.tick_mirrored(None, 0, 0)                            # nothing tracking: nothing runs, no update rows
+    assert (m.n_ran, m.n_updates, m.n_lost) == (0, 0, 0)
+    with pytest.raises(SdrError, match="write index"):
+        bank.tick_mirrored(None, 0, 80000)
+    with pytest.raises(SdrError, match="write index"):
+        bank.tick_mirrored(None, 0, -1)
+    lib = _lib.load()
+    broken = _lib.TickMirror.from_buffer_copy(m)
+    broken.records = None
+    assert lib.sdr_bank_tick_mirrored(engine._h, bank._h, None, 0, 0, 0, C.byref(broken)) != 0
+    assert b"NULL" in lib.sdr_last_error()
+    broken = _lib.TickMirror.from_buffer_copy(m)
+    broken.max_channels = 5
+    assert lib.sdr_bank_tick_mirrored(engine._h, bank._h, None, 0, 0, 0, C.byref(broken)) != 0
+    assert b"rows" in lib.sdr_last_error()
+    # a tracking flag on a channel that was never put into the bank: it has no epoch to run, but reports its row
+    tracking[2] = True
+    bank.tick_mirrored(None, 0, 100)
+    assert (m.n_ran, m.n_updates) == (0, 1) and bank.updates["channel"][0] == 2
+    # a slab queued without waiting is in the ring when the tick returns
+    slab = np.arange(-100, 100, dtype=np.int8)
+    engine.iq_upload_begin(slab, 16)
+    bank.tick_mirrored(None, 0, 116)
+    assert np.array_equal(engine.iq_download(100, 16), slab)
+    # ... also when it does not fit the ingest kernel's 16-byte granules, or wraps the ring
+    odd = np.arange(-30, 30, dtype=np.int8)
+    engine.iq_upload_begin(odd, 7)
+    engine.sync()
+    assert np.array_equal(engine.iq_download(30, 7), odd)
+    wrap = (np.arange(64) % 100).astype(np.int8)
+    engine.iq_upload_begin(wrap, 80000 - 16)
+    engine.sync()
+    assert np.array_equal(engine.iq_download(32, 80000 - 16), wrap)
+    bank.close()
