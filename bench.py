@@ -198,7 +198,7 @@ def kernel_of_variant(variant, n_taps, waves_per_group=1):
     w = variant & 255
     if (variant >> 13) & 3:                                  # two chips per lane (correlator_chip2.h)
         return "epl2_kernel<" + {1: "4,9,14,19", 2: "5,11,17,23"}[(variant >> 13) & 3] + ">"
-    if w == 26 + 16:                                         # 15.x / 16.x samples per chip: both block lengths in one kernel
+    if w == 26 + 16 and not variant & (0xF00 | 4096):        # 15.x / 16.x samples per chip: both block lengths in one kernel
         return f"epl_kernel<0,{n_taps},26,15,{waves_per_group},0,0,16>"
     km = w - 26 if w > 26 else 0
     ks = (variant & 0xF00) >> 8
@@ -302,7 +302,7 @@ def rates_leg(eng, seconds=2.0):
     from oracle import sydr_oracle as orc
     from sydr_amd.engine import FMT_CI8
     out = []
-    for fs in (4e6, 10e6, 12e6, 16.368e6, 20e6, 25e6, 32e6, 50e6):
+    for fs in (4e6, 10e6, 12e6, 16.368e6, 18e6, 20e6, 22e6, 25e6, 32e6, 40e6, 50e6):
         total = int(seconds * fs) // 8 * 8
         eng.iq_alloc(total, FMT_CI8)
         eng.code_slots(N_CH)
@@ -348,7 +348,7 @@ def rates_leg(eng, seconds=2.0):
         if not (variant >> 13) & 3:
             family += ("one chip per lane, straight line (compile-time block length and tap positions)" if (variant & 0xF00) else
                        "one chip per lane, whole-chip taps" if variant & 4096 else
-                       "one chip per lane, both block lengths (15 / 16) compiled in, run-time tap positions" if w == 26 + 16 else
+                       "one chip per lane, both block lengths (15 / 16) compiled in, run-time tap positions" if w == 26 + 16 and not variant & (0xF00 | 4096) else
                        "one chip per lane, compile-time block length" if w > 26 else
                        "one chip per lane, run-time positions" if w >= 26 else
                        f"{w}-sample boundary groups" if w else "per sample")

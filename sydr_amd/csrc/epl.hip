@@ -37,170 +37,11 @@ extern "C" int sdr_debug_read_trace(unsigned long long* dst, int n) {
 }
 #endif
 
+#include "epl_kernel.h"
+
 namespace {
 
 using namespace sdr;
-
-constexpr int kWaveThreads = 64;  // one wave per channel-epoch: the ~5 us fixed latency of a workgroup is amortised over 4x more work
-// plan variant word (sdr_epl_plan_variant): low byte = samples a lane owns (0 / 8 / 16 / 26, + 24 when the block length is
-// compiled in), then the compile-time tap geometry
-constexpr int kVariantKS12 = 256 * 12;   // three taps, the outer ones switching 12.x samples into the anchor's block (24 / 25 samples per chip)
-constexpr int kVariantKSMask = 256 * 15; // ... in general: KS in bits 8-11, with the block length KM in the low byte (kChipMax + KM)
-constexpr int kVariantKS9 = 256 * 9;     // 19 / 20 samples per chip (20 MHz): KM = 19, KS = 9
-constexpr int kVariantKM1516 = 16;       // (added to kChipMax) 15.x or 16.x samples per chip by the epoch: both block lengths compiled in
-constexpr int kVariantKI = 4096;         // taps whole (half-)chips apart: no switch inside a block
-constexpr int kVariantC2 = 8192;         // several chips per lane (correlator_chip2.h), x 1 / 2: boundaries <4,9,14,19> / <5,11,17,23>
-constexpr int kLongLutWords = 4096;  // replicas of 16 KB and more (multi-period / BOC half-chip codes): four epochs share a staged copy
-
-// Dynamic LDS: [red: WPW*2*NT doubles][scratch: strips / rotations][lut: lut_words uint32]
-//
-// One WAVE per item; WPW = 1: one workgroup per item.  (A persistent grid-stride variant that keeps the replica in
-// LDS across items was measured slower: holding two items' parameters pushed the kernel from 4 to 2 resident waves
-// per SIMD -- 1.15 ms vs 0.87 ms per 32 000-item launch -- so hardware workgroup dispatch does the scheduling.)
-// WPW = 4 (long replicas): a 33 KB table per single-wave workgroup leaves 3 waves on a CU; four waves of a workgroup
-// correlate four epochs of the SAME channel -- items i, i+C, i+2C, i+3C of a list whose code slots repeat with
-// period C (the plan checks that) -- against one staged copy, 8 waves per CU.
-// W: samples a lane owns per iteration of the boundary variant (16 or 8), 0 = the per-sample variant.
-#ifndef SDR_EPL_WAVES
-#define SDR_EPL_WAVES 1
-#endif
-// KM2 != 0 (with KS = KI = 0): the list's epochs have KM or KM2 = KM + 1 whole samples per chip by the sign of their code
-// Doppler (16.368 MHz: exactly 16.0) -- both block lengths are compiled in and an epoch takes the body of its own.
-template <int FMT, int NT, int W, int KM = 0, int WPW = 1, int KS = 0, int KI = 0, int KM2 = 0>
-#ifndef SDR_EPL_KS_WAVES
-#define SDR_EPL_KS_WAVES 3   // (the KS kernel sits at the 168-register cap of three waves per SIMD; two waves: 0.306 instead of 0.286 ms per stream-second)
-#endif
-#ifndef SDR_EPL_KI_WAVES
-#define SDR_EPL_KI_WAVES 1
-#endif
-#ifndef SDR_EPL_KM2_WAVES
-#define SDR_EPL_KM2_WAVES 1
-#endif
-__global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (KI != 0 ? SDR_EPL_KI_WAVES : (KM2 != 0 ? SDR_EPL_KM2_WAVES : SDR_EPL_WAVES)))) void epl_kernel(const void* __restrict__ ring, const void* __restrict__ ring_flipped, int64_t capacity,
-                                                       const sdr_epl_item* __restrict__ items, int n_items, int group_stride,
-                                                       const uint32_t* __restrict__ luts,
-                                                       int lut_words, int lut_stride,
-                                                       const double* __restrict__ spacing, double fs,
-                                                       int tap0, int n_taps_total,
-                                                       double* __restrict__ out, const void* __restrict__ setups) {
-    constexpr int kThreads = kWaveThreads * WPW;
-    constexpr bool kPre = W == kChipMax && FMT == SDR_FMT_CI8 && KM != 0 && (KS != 0 || KI != 0);   // the plan holds a ChipSetup per item
-    extern __shared__ double smem[];
-    double* red = smem;
-    double2* prefix = reinterpret_cast<double2*>(red + WPW * 2 * NT);          // boundary variants: kThreads*9 slots; chip variant: strips + rotations
-    constexpr int kScratchSlots = W == kChipMax ? kThreads * chip_strip_slots<NT>() + WPW * kChipMax : (W ? kThreads * kPrefixSlots : 0);
-    uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + kScratchSlots);
-
-    const int tid = threadIdx.x;
-    // (the wave number as a scalar: what is indexed with it -- the item, its setup in the plan -- is then read with scalar loads)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-#ifdef SDR_TRACE_WG
-    const unsigned long long t_start = wall_clock64();
-#endif
-    int item = blockIdx.x;
-    if (WPW > 1) {
-        const int g = blockIdx.x / group_stride, c = blockIdx.x - g * group_stride;
-        item = (g * WPW + wave) * group_stride + c;
-    }
-    const bool have = item < n_items;
-    // (a wave without an item still stages its share of the table: the slot of its group's column c = item c of the
-    // range -- clamped, because a range shorter than the stride launches columns that hold no item at all)
-    const int column = (int)(blockIdx.x % group_stride);
-    const sdr_epl_item it = items[have ? item : (column < n_items ? column : n_items - 1)];
-    stage_lut<kThreads>(lut, luts + (size_t)it.code_slot * lut_stride, lut_words, tid);
-    double dphi;
-    if constexpr (!kPre) dphi = carrier_step(it.carrier_hz, fs);
-    EpochParams ep;
-    ep.start_sample = it.start_sample;
-    ep.n = it.n_samples;
-    ep.carrier_hz = it.carrier_hz;
-    ep.rem_carrier = it.rem_carrier;
-    ep.rem_code = it.rem_code;
-    ep.code_step = it.code_step;
-    EpochConsts<NT> K;
-    ChipGeom<NT> G;
-    const ChipRot* rot_plan = nullptr;
-    int64_t base = -1;
-    if constexpr (kPre) {
-        // everything wave-uniform that is not a sincos was worked out by the host when the plan was made: scalar loads
-        const ChipSetup<NT>& S = static_cast<const ChipSetup<NT>*>(setups)[have ? item : 0];
-        dphi = S.dphi;
-#pragma unroll
-        for (int q = 0; q < NT; ++q) {
-            K.shift[q] = S.shift[q], K.step[q] = S.step[q], K.inv_step[q] = S.inv_step[q];
-            // (only the exact re-evaluations near a sample and the edge samples read these: vector registers, of which
-            // there are enough -- the scalar ones hold the sample loop's rotations)
-            asm volatile("" : "+v"(K.shift[q]), "+v"(K.step[q]), "+v"(K.inv_step[q]));
-        }
-        G = S.g;
-        rot_plan = &S.r;
-        base = S.base;
-    } else if constexpr (W == kChipMax && FMT == SDR_FMT_CI8) {
-        compute_tap_constants<NT>(K, ep, spacing + tap0);   // (the chip-aligned core evaluates its own rotations)
-        if (chip_variant_applies(ep, capacity)) {
-            base = ep.start_sample % capacity;
-            chip_geometry<NT, (KM2 != 0 ? 0 : KM), KS, KI>(ep.n, K.shift, K.step, K.inv_step, G);   // (two lengths: the body is chosen below)
-        }
-    } else {
-        compute_constants<NT>(K, ep, spacing + tap0, dphi, kWaveThreads);
-    }
-    __syncthreads();  // replica staged
-    if (WPW > 1 && !have) return;
-
-    double accr[NT], acci[NT];
-    if constexpr (W == kChipMax && FMT == SDR_FMT_CI8) {
-        // chip-aligned blocks (correlator_chip.h); an epoch it does not cover is redone per sample
-        bool done = false;
-        if constexpr (KM2 != 0) {
-            static_assert(KS == 0 && KI == 0 && !kPre, "two block lengths: tap positions at run time, no plan setups");
-            const int M = __builtin_amdgcn_readfirstlane((int)(G.Tfx >> 32));
-            double2* const rot = prefix + kThreads * chip_strip_slots<NT>() + wave * kChipMax;
-            if (base >= 0 && M == KM)
-                done = correlate_epoch_chip<NT, true, KM, 0, 0>(ring, ring_flipped, capacity, ep, dphi, K, G, base, rot_plan, lut, prefix, rot,
-                                                                 tid, lane, kWaveThreads, lane, accr, acci);
-            else if (base >= 0 && M == KM2)
-                done = correlate_epoch_chip<NT, true, KM2, 0, 0>(ring, ring_flipped, capacity, ep, dphi, K, G, base, rot_plan, lut, prefix, rot,
-                                                                  tid, lane, kWaveThreads, lane, accr, acci);
-        } else {
-            done = base >= 0 &&
-                   correlate_epoch_chip<NT, true, KM, KS, KI>(ring, ring_flipped, capacity, ep, dphi, K, G, base, rot_plan, lut, prefix,
-                                                              prefix + kThreads * chip_strip_slots<NT>() + wave * kChipMax,
-                                                              tid, lane, kWaveThreads, lane, accr, acci);
-        }
-        if (!done) {
-            // (its own copy of the per-epoch constants: the in-group rotations the per-sample routine wants would
-            // otherwise sit in 64 scalar registers across the whole chip-aligned path)
-            EpochConsts<NT> K2;
-            compute_constants<NT>(K2, ep, spacing + tap0, dphi, kWaveThreads);
-            correlate_epoch<FMT, NT>(ring, capacity, ep, dphi, K2, lut, lane, kWaveThreads, lane, accr, acci);
-        }
-    } else if (W != 0 && !epoch_wraps(ep, capacity))
-        correlate_epoch_wide<FMT, NT, true, (W ? W : kWide)>(ring, capacity, ep, dphi, K, lut, prefix, tid, lane, kWaveThreads, lane, accr, acci);
-    else
-        correlate_epoch<FMT, NT>(ring, capacity, ep, dphi, K, lut, lane, kWaveThreads, lane, accr, acci);
-    if constexpr (NT == 3 || NT == 5) {
-        // one wave per item (also with four items per workgroup): the lanes share the reduction of the 2*NT sums
-        // (correlator.h: reduce_taps_scatter); the first eight (sixteen) lanes between them hold every total, each under
-        // the slot it ended up with
-        int slot;
-        const double total = reduce_taps_scatter<NT>(accr, acci, lane, slot);
-        if (lane < (NT == 3 ? 8 : 16)) out[(size_t)item * 2 * n_taps_total + 2 * tap0 + slot] = total;
-    } else {
-        const double total = reduce_taps<NT, kWaveThreads>(accr, acci, red, lane);
-        if (lane < 2 * NT) out[(size_t)item * 2 * n_taps_total + 2 * tap0 + lane] = total;
-    }
-#ifdef SDR_TRACE_WG
-    if (tid == 0 && blockIdx.x < 65536) {
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_wg_trace[3 * blockIdx.x] = t_start;
-        g_wg_trace[3 * blockIdx.x + 1] = wall_clock64();
-        g_wg_trace[3 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
-    }
-#endif
-}
 
 // Half-chip view of the staged replicas: every chip twice.  A code of 32-52 samples per chip (GPS L1 C/A at 50 MHz)
 // presented as a code of twice the chips at twice the rate has 16-26 samples per (half-)chip and runs on the
@@ -318,7 +159,22 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
             launch(epl_kernel<FMT, NT, 0, 0, 4>);
         return;
     }
-    if (ks && ks_of == 9)                                    // 19 / 20 samples per chip, the outer taps switching at sample 9 or 10
+    // the straight-line kernels of the other block lengths (ci8, three taps) live in epl_straight.hip: launched through their address
+    auto launch_by_address = [&](const void* kernel) {
+        const void* ring = e->iq;
+        const void* flipped = (const void*)e->iq_flip;
+        int64_t cap = e->iq_capacity;
+        int n = n_items, gs = stride, lw = lut_words, ls = doubled ? e->lut2_stride : e->lut_stride, t0 = tap0, nt = n_taps_total;
+        const uint32_t* luts = doubled ? e->luts2 : e->luts;
+        void* args[] = {&ring, &flipped, &cap, &d_items, &n, &gs, &luts, &lw, &ls, &d_spacing, &fs, &t0, &nt, &d_out, &d_setups};
+        if (shmem > 64u * 1024u) (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipLaunchKernel(kernel, dim3(grid), dim3(threads), args, shmem, stream);
+    };
+    const int km = wide - kChipMax;
+    const void* elsewhere = (ks && km != 24 && km != 19) ? sdr_epl_ks_kernel(km) : (ki && NT == 3 && km != 24 && km != 15) ? sdr_epl_ki_kernel(km) : nullptr;
+    if (elsewhere)
+        launch_by_address(elsewhere);
+    else if (ks && ks_of == 9)                               // 19 / 20 samples per chip, the outer taps switching at sample 9 or 10
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), (NT == 3 ? 19 : 0), 1, (NT == 3 ? 9 : 0)>);
     else if (ks)                                             // 24 / 25 samples per chip, both outer taps switching at sample 12 or 13
         launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 1, (NT == 3 ? 12 : 0)>);
@@ -513,10 +369,12 @@ static int variant_of(const sdr_engine* e, const ItemRules& r, const double* spa
     bool all_ki = r.n_taps == 3 || r.n_taps == 5;   // tap t exactly (t - A) chips from the anchor (KI kernel)
     for (int t = 0; all_ki && t < r.n_taps; ++t) all_ki = r.scale * spacing[t] - r.s_anchor == (double)(t - r.n_taps / 2);
     const bool all_m24 = m_lo == 24 && m_hi == 24;
-    const bool all_s12 = all_m24 && all_split;
-    const bool all_s9 = m_lo == 19 && m_hi == 19 && all_split;          // (20 MHz: the KM = 19, KS = 9 instantiation)
     const bool all_m15 = m_lo == 15 && m_hi == 15;                      // (31-32.7 MHz on the half-chip view: KM = 15, whole-chip taps)
     const bool all_m1516 = m_lo >= 15 && m_hi <= 16 && r.n_taps == 3 && r.scale == 1.0;   // (16.368 MHz: 16.0 -- 15.x or 16.x by the Doppler's sign)
+    // one block length KM throughout, three taps: the straight-line kernels exist for KM = 16 .. 25 (epl.hip's own: 24 / 12,
+    // 19 / 9, the whole-chip-tap forms of 24 and 15; the rest: epl_straight.hip) -- with the outer taps' switch position
+    // floor(KM / 2) compiled in (+-0.5 chip, `all_split`) or with taps whole (half-)chips apart (`all_ki`)
+    const int km_one = m_lo == m_hi && m_lo >= 16 && m_lo <= 25 && r.n_taps == 3 ? m_lo : 0;
     const bool boundary_ok = min_step >= sdr::kFastMinCodeStep && r.scale * e->lut_stride < sdr::kFastMaxLutWords;
     int wide = !boundary_ok ? 0 : (max_step <= sdr::kFastMaxCodeStep ? 16 : (max_step <= sdr::kFastMaxCodeStep8 ? 8 : 0));
     // every item inside the chip-aligned variant's range (ci8 ring): lanes own whole chips instead of 16 samples
@@ -525,13 +383,21 @@ static int variant_of(const sdr_engine* e, const ItemRules& r, const double* spa
     // ... unless every half chip holds 15.x samples and the taps sit whole half-chips apart: the KM = 15 whole-chip-tap kernel
     const double chip_max_step = r.scale == 2.0 && !(all_m15 && all_ki && r.n_taps == 3 && !e->epl_no_split) ? 1.0 / 16.0 : sdr::kChipMaxCodeStep;
     if (boundary_ok && e->iq_fmt == SDR_FMT_CI8 && min_step >= sdr::kChipMinCodeStep && max_step <= chip_max_step &&
-        !e->epl_no_chip)
-        wide = sdr::kChipMax + (all_m24 ? 24 : 0) +
-               ((all_m24 && all_s12 && !e->epl_no_split) ? kVariantKS12 : 0) +
-               ((all_m24 && all_ki && !e->epl_no_split) ? kVariantKI : 0) +
-               ((all_s9 && !e->epl_no_split) ? 19 + kVariantKS9 : 0) +
-               ((all_m15 && all_ki && r.n_taps == 3 && r.scale == 2.0 && !e->epl_no_split) ? 15 + kVariantKI : 0) +
-               ((all_m1516 && !e->epl_no_split) ? kVariantKM1516 : 0);
+        !e->epl_no_chip) {
+        wide = sdr::kChipMax;
+        if (all_m24 && r.n_taps != 3)                       // (five taps: the 24 / 25 forms alone)
+            wide += 24 + ((all_ki && !e->epl_no_split) ? kVariantKI : 0);
+        else if (km_one && all_split && !e->epl_no_split)
+            wide += km_one + 256 * (km_one / 2);
+        else if (km_one && all_ki && !e->epl_no_split)
+            wide += km_one + kVariantKI;
+        else if (all_m24)                                   // block length compiled in, tap positions at run time
+            wide += 24;
+        else if (all_m15 && all_ki && r.n_taps == 3 && r.scale == 2.0 && !e->epl_no_split)
+            wide += 15 + kVariantKI;
+        else if (all_m1516 && !e->epl_no_split)
+            wide += kVariantKM1516;
+    }
     return wide;
 }
 
@@ -766,42 +632,46 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
             const sdr_epl_item* src = doubled ? items2.data() : items;
             const double* spc = doubled ? spacing2 : spacing;
             host_setups.resize(p->setup_bytes * (size_t)n_items);
+            const int km = (wide & 255) - kChipMax;
+            const bool ks = (wide & kVariantKSMask) != 0;
             for (int i = 0; i < n_items; ++i) {
                 const sdr_epl_item& it = src[i];
-                if ((wide & kVariantKSMask) == kVariantKS12 && n_taps == 3)
-                    sdr::chip_setup<3, 24, 12, 0>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
-                                                  kWaveThreads, reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i]);
-                else if ((wide & kVariantKSMask) == kVariantKS9 && n_taps == 3)
-                    sdr::chip_setup<3, 19, 9, 0>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
-                                                 kWaveThreads, reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i]);
-                else if (n_taps == 3 && (wide & 255) == kChipMax + 15)
-                    sdr::chip_setup<3, 15, 0, 1>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
-                                                 kWaveThreads, reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i]);
-                else if (n_taps == 3)
-                    sdr::chip_setup<3, 24, 0, 1>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
-                                             kWaveThreads, reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i]);
-                else
+                if (n_taps == 5) {
                     sdr::chip_setup<5, 24, 0, 1>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
-                                             kWaveThreads, reinterpret_cast<sdr::ChipSetup<5>*>(host_setups.data())[i]);
+                                                 kWaveThreads, reinterpret_cast<sdr::ChipSetup<5>*>(host_setups.data())[i]);
+                    continue;
+                }
+                sdr::ChipSetup<3>& S = reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i];
+                switch (km * 2 + (ks ? 1 : 0)) {
+#define SDR_SETUP_CASE(K)                                                                                                                      \
+    case 2 * K + 1: sdr::chip_setup<3, K, K / 2, 0>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs, kWaveThreads, S); break; \
+    case 2 * K: sdr::chip_setup<3, K, 0, 1>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs, kWaveThreads, S); break;
+                    SDR_SETUP_CASE(15) SDR_SETUP_CASE(16) SDR_SETUP_CASE(17) SDR_SETUP_CASE(18) SDR_SETUP_CASE(19) SDR_SETUP_CASE(20)
+                    SDR_SETUP_CASE(21) SDR_SETUP_CASE(22) SDR_SETUP_CASE(23) SDR_SETUP_CASE(24) SDR_SETUP_CASE(25)
+#undef SDR_SETUP_CASE
+                    default: err = hipErrorInvalidValue; break;
+                }
             }
-            err = hipMemcpyAsync(p->d_setups, host_setups.data(), host_setups.size(), hipMemcpyHostToDevice, e->stream);
+            if (err == hipSuccess) err = hipMemcpyAsync(p->d_setups, host_setups.data(), host_setups.size(), hipMemcpyHostToDevice, e->stream);
         } else if (err == hipSuccess) {
-            if ((wide & kVariantKSMask) == kVariantKS12 && n_taps == 3)
-                hipLaunchKernelGGL((chip_setup_kernel<3, 24, 12, 0>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
-                                   p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups));
-            else if ((wide & kVariantKSMask) == kVariantKS9 && n_taps == 3)
-                hipLaunchKernelGGL((chip_setup_kernel<3, 19, 9, 0>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
-                                   p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups));
-            else if (n_taps == 3 && (wide & 255) == kChipMax + 15)
-                hipLaunchKernelGGL((chip_setup_kernel<3, 15, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
-                                   p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups));
-            else if (n_taps == 3)
-                hipLaunchKernelGGL((chip_setup_kernel<3, 24, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
-                                   p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups));
-            else
+            const int km = (wide & 255) - kChipMax;
+            const bool ks = (wide & kVariantKSMask) != 0;
+            if (n_taps == 5) {
                 hipLaunchKernelGGL((chip_setup_kernel<5, 24, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
                                    p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<5>*>(p->d_setups));
-            err = hipGetLastError();
+            } else {
+                sdr::ChipSetup<3>* d3 = reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups);
+                switch (km * 2 + (ks ? 1 : 0)) {
+#define SDR_SETUP_CASE(K)                                                                                                              \
+    case 2 * K + 1: hipLaunchKernelGGL((chip_setup_kernel<3, K, K / 2, 0>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items, p->d_spacing, fs, e->iq_capacity, d3); break; \
+    case 2 * K: hipLaunchKernelGGL((chip_setup_kernel<3, K, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items, p->d_spacing, fs, e->iq_capacity, d3); break;
+                    SDR_SETUP_CASE(15) SDR_SETUP_CASE(16) SDR_SETUP_CASE(17) SDR_SETUP_CASE(18) SDR_SETUP_CASE(19) SDR_SETUP_CASE(20)
+                    SDR_SETUP_CASE(21) SDR_SETUP_CASE(22) SDR_SETUP_CASE(23) SDR_SETUP_CASE(24) SDR_SETUP_CASE(25)
+#undef SDR_SETUP_CASE
+                    default: err = hipErrorInvalidValue; break;
+                }
+            }
+            if (err == hipSuccess) err = hipGetLastError();
         }
     }
     // three taps half a chip apart and chips of 9.5 .. 10 or 11.5 .. 12 samples (the reference's shipped 10 MHz; 12 MHz): two

@@ -17,6 +17,9 @@ GEOMETRIES = (  # fs, spacing, most periods per epoch, variant bits the plan mus
     (10e6, (-0.5, 0.0, 0.5), 2, 8 + 8192),                      # two chips per lane (correlator_chip2.h): the shipped rate
     (20e6, (-0.5, 0.0, 0.5), 2, 26 + 19 + 256 * 9),             # round 4: block length 19, switch at 9
     (32e6, (-0.5, 0.0, 0.5), 1, 65536 + 26 + 15 + 4096),        # round 4: half-chip view, block length 15, whole-chip taps
+    (18e6, (-0.5, 0.0, 0.5), 2, 26 + 17 + 256 * 8),             # round 4: the other block lengths (epl_straight.hip) -- 17 / 8 ...
+    (22e6, (-1.0, 0.0, 1.0), 2, 26 + 21 + 4096),                # ... 21 with whole-chip taps ...
+    (40e6, (-0.5, 0.0, 0.5), 1, 65536 + 26 + 19 + 4096),        # ... 19 on the half-chip view
 )
 
 

@@ -820,6 +820,79 @@ def test_compile_time_tap_switch_variant_at_20_mhz(engine):
     plan.close()
 
 
+@pytest.mark.parametrize("km", [16, 17, 18, 20, 21, 22, 23, 25])
+def test_straight_line_kernels_of_every_block_length(engine, km):
+    """The straight-line kernel exists for every block length KM = 16 .. 25 (epl_straight.hip carries the ones epl.hip does
+    not): a list at KM.5 samples per chip gets `epl_kernel<.., KM, .., KM / 2>` at +-0.5 chip spacing (plan variant 26 + KM +
+    256 * (KM / 2)) and the whole-chip-tap form at +-1 chip (26 + KM + 4096), on the half-chip view at twice the rate too.
+    Long and short lists (setups by a launch / on the host) against the oracle and the run-time-position kernel, odd epochs
+    included (they fall back inside the launch)."""
+    rng = np.random.default_rng(7000 + km)
+    fs = 1.023e6 * (km + 0.5)
+    n_code = int(fs * 1e-3) + 1
+    cap = 8 * 2 * n_code
+    raw = rng.integers(-100, 100, 2 * cap).astype(np.int8)
+    engine.iq_alloc(cap, FMT_CI8)
+    engine.iq_upload(raw, 0)
+    engine.code_slots(8, 1023, 3)
+    for s in range(8):
+        engine.load_gps_code(s, 3 * s + 2)
+    rf = orc.iq_to_complex(raw)
+    for spacing, want in (((-0.5, 0.0, 0.5), 26 + km + 256 * (km // 2)), ((-1.0, 0.0, 1.0), 26 + km + 4096)):
+        for n_items in (90, 4200):
+            step = (1.023e6 + rng.uniform(-4, 4, n_items)) / fs
+            rem_code = rng.uniform(0, step)
+            rem_code[:6] = [0.0, 0.5, 0.25, 1e-9, step[4] / 2, step[5] * (1 - 1e-12)]
+            periods = rng.integers(1, 3, n_items)
+            n = np.ceil((1023 * periods - rem_code) / step).astype(np.int64) + rng.integers(-1, 2, n_items)
+            n[6:10] = [3, 40, 70, 21]
+            start = rng.integers(0, cap - 2 * n_code - 64, n_items)
+            start[10:13] = [0, 1, cap - int(n[12]) - 1]
+            slot = rng.integers(0, 8, n_items)
+            f = rng.uniform(-6000, 6000, n_items)
+            f[13:16] = [0.0, 4.092e6, -4.092e6]
+            rem_carrier = rng.uniform(0, 2 * np.pi, n_items)
+            items = make_items(slot, n, start, f, rem_carrier, rem_code, step)
+            got = {}
+            for no_split in (0, 1):
+                engine.set_option("epl_no_split_variant", no_split)
+                try:
+                    plan = engine.epl_plan(items, spacing, fs)
+                    plan.run()
+                    got[no_split] = (plan.variant, plan.fetch())
+                    plan.close()
+                finally:
+                    engine.set_option("epl_no_split_variant", 0)
+            assert got[0][0] == want and got[1][0] == 26, (spacing, n_items, got[0][0], got[1][0])
+            for k in (range(n_items) if n_items < 1000 else rng.choice(n_items, 50, replace=False)):
+                x = orc.ring_slice(rf, int(start[k]), int(n[k]))
+                ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(3 * int(slot[k]) + 2)), fs, f[k], rem_carrier[k], rem_code[k], step[k], spacing))
+                scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 50.0), 2)
+                for no_split in (0, 1):
+                    assert np.max(np.abs(got[no_split][1][k] - ref) / scale) < 1e-9, (spacing, n_items, k, no_split, step[k], n[k])
+    # the half-chip view: twice the rate, +-0.5 chip = +-1 half chip -> the whole-chip-tap form of the same block length
+    fs2 = 2 * fs
+    n_items = 300
+    step = (1.023e6 + rng.uniform(-4, 4, n_items)) / fs2
+    rem_code = rng.uniform(0, step)
+    n = np.ceil((1023 - rem_code) / step).astype(np.int64) + rng.integers(-1, 2, n_items)
+    start = rng.integers(0, cap - 2 * n_code - 64, n_items)
+    slot = rng.integers(0, 8, n_items)
+    f = rng.uniform(-6000, 6000, n_items)
+    rem_carrier = rng.uniform(0, 2 * np.pi, n_items)
+    items = make_items(slot, n, start, f, rem_carrier, rem_code, step)
+    plan = engine.epl_plan(items, (-0.5, 0.0, 0.5), fs2)
+    plan.run()
+    got2 = plan.fetch()
+    assert plan.variant == 65536 + 26 + km + 4096, plan.variant
+    plan.close()
+    for k in rng.choice(n_items, 40, replace=False):
+        x = orc.ring_slice(rf, int(start[k]), int(n[k]))
+        ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(3 * int(slot[k]) + 2)), fs2, f[k], rem_carrier[k], rem_code[k], step[k], (-0.5, 0.0, 0.5)))
+        scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 50.0), 2)
+        assert np.max(np.abs(got2[k] - ref) / scale) < 1e-9, (k, step[k], n[k])
+
+
 def test_two_block_lengths_in_one_kernel_at_16_368_mhz(engine):
     """16.368 MHz is exactly 16.0 samples per chip: an epoch's chips hold 15.x or 16.x samples by the sign of its code
     Doppler, so one list holds both.  The kernel with BOTH block lengths compiled in (`sdr_epl_plan_variant` = 26 + 16) takes
