@@ -409,8 +409,11 @@ int sdr_stream_sync(sdr_engine* e, int stream_id);
 /* sdr_epl_plan_run_range on a chosen stream (asynchronous; sdr_stream_sync or sdr_epl_plan_fetch completes it). */
 int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int64_t count, int stream_id);
 /* Diagnostics: which correlator variant the plan's items selected -- 0 per-sample, 8 / 16 boundary variant with that
- * many samples per lane, 26 chip-aligned; + 24 when the block length is compiled in (every epoch 24 or 25 samples per
- * chip), + 16 when two are (every epoch 15.x or 16.x samples per chip: 16.368 MHz); + 256 * 12 when the outer taps' switch position is too (both 12.x samples into the prompt tap's chip);
+ * many samples per lane, 26 chip-aligned; + KM when the block length is compiled in (every epoch KM.x samples per chip,
+ * KM = 16 .. 25; 15 on the half-chip view) and with it + 256 * floor(KM / 2) when the outer taps' switch position is too
+ * (three taps half a chip apart: both switch floor(KM / 2).x samples into the prompt tap's chip) or + 4096 when the taps sit
+ * whole (half-)chips apart; 26 + 16 alone: two block lengths compiled in (every epoch 15.x or 16.x samples per chip:
+ * 16.368 MHz); + 8192 * k: several chips per lane (8.2 - 12 samples per chip);
  * + 65536 when the plan runs on the half-chip view of its replicas (32-52 samples per chip: every chip twice).  The
  * results do not depend on it beyond the tolerance of the free arithmetic. */
 int sdr_epl_plan_variant(const sdr_epl_plan* p);
