@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SDR_ABI_VERSION 4   /* 4: + sdr_build_id, sdr_epl_plan_create_dev, sdr_bank_tick_mirrored, sdr_iq_upload_begin (additive) */
+#define SDR_ABI_VERSION 4   /* 4: + sdr_build_id, sdr_epl_plan_create_dev, sdr_bank_tick_mirrored, sdr_iq_upload_begin, sdr_block_schedule, sdr_bank_step_begin / _end (additive) */
 
 typedef struct sdr_engine sdr_engine;
 
@@ -356,6 +356,14 @@ int sdr_bank_get(sdr_engine* e, sdr_bank* b, int ch, sdr_track_state* st);
 int sdr_bank_step(sdr_engine* e, sdr_bank* b, const int32_t* channels, int n_ch, int n_epochs,
                   sdr_track_epoch* records, sdr_track_state* states_out, int32_t* epochs_done,
                   int8_t* nav_bits, int max_bits, int32_t* n_bits, int stream_id);
+/* sdr_bank_step (on the engine's stream, records and states always produced) in two halves: _begin queues the launch and
+ * the copies of its results into page-locked memory and returns at once; _end waits and hands them out.  One step may be
+ * in flight per bank; work queued on the engine's stream in between (a tick, an upload) runs after it.  Lets a receiver
+ * that tracks ahead (sydr_amd/channel/readahead.py) have its next block computed while it still hands out the current
+ * one's packets.  SDR_ERR_STATE: _begin with a step in flight, _end without one. */
+int sdr_bank_step_begin(sdr_engine* e, sdr_bank* b, const int32_t* channels, int n_ch, int n_epochs);
+int sdr_bank_step_end(sdr_engine* e, sdr_bank* b, sdr_track_epoch* records /* [n_ch][n_epochs] */, sdr_track_state* states_out,
+                      int32_t* epochs_done);
 /* One receiver tick: copy n_samples new host samples into the ring at ring_offset (CircularBuffer.shift), then
  * one epoch for the listed channels (n_ch may be 0: ingest only).  One stream synchronisation in all. */
 int sdr_bank_tick(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
@@ -400,6 +408,25 @@ int sdr_bank_tick_mirrored(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n
  * there afterwards (slabs above 1 MiB are uploaded synchronously).  sdr_engine_sync completes it for readers on
  * other streams.  Lets addNewRFData start the transfer while the caller is still on its way to run(). */
 int sdr_iq_upload_begin(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset);
+
+/* Host-only helper of a receiver that tracks ahead (no device work): `records[n_ch][n_cols]` hold `done[r]` epochs per channel
+ * computed in one sdr_bank_step while the host still feeds its per-millisecond loop (receiver.py:120-131); this works out
+ * which tick releases which epoch -- the first tick k whose slab completes it (channel.py:137-146): unread_now[r] +
+ * (k + 1) * samples_per_tick >= the samples up to its end, one epoch per channel and tick (channelManager.py:149-188) -- and
+ * what every tick's CHANNEL_UPDATE reports (channel.py:205-228).  Outputs (caller-allocated): first[n_ch][n_cols] = the tick
+ * of each epoch (-1: not run); *n_ticks; the epochs in tick order (channels ascending inside a tick) as order_rows /
+ * order_cols / records_sorted [sum of done], tick k's slice being [starts[k], starts[k + 1]) (starts: max_ticks + 1 entries);
+ * last_records[n_ch] = each channel's newest record; per tick and channel [max_ticks][n_ch] (row stride n_ch): unread samples
+ * after the tick, the device's TrackingFlags bits (flags0 before the channel's first epoch) and code_since0 + epochs released
+ * so far; last_tick[n_ch] = the tick of each channel's last epoch (-1: none); the navigation bits the block decided, channel by
+ * channel in epoch order: bit_rows / bit_cols / bit_values [up to sum of done], *n_bits of them.  SDR_ERR_RANGE when an epoch
+ * would fall beyond max_ticks. */
+int sdr_block_schedule(const sdr_track_epoch* records, int n_ch, int n_cols, const int32_t* done, const int64_t* unread_now,
+                       int64_t samples_per_tick, const int64_t* flags0, const int64_t* code_since0, int max_ticks,
+                       int32_t* first, int32_t* n_ticks, int32_t* order_rows, int32_t* order_cols, int32_t* starts,
+                       sdr_track_epoch* records_sorted, sdr_track_epoch* last_records, int64_t* unread, int64_t* dev_flags,
+                       int64_t* code_count, int32_t* last_tick, int32_t* bit_rows, int32_t* bit_cols, int32_t* bit_values,
+                       int32_t* n_bits);
 
 /* ------------------------------------------------- streams (one per channel batch)
  * north_star: "one HIP stream per channel batch".  Stream ids are small positive integers owned by the engine;

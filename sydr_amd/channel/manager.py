@@ -38,6 +38,7 @@ class ChannelManager:
     TIMEOUT = 1
     DEFER_BYTES = 1 << 20         # slabs up to this size are queued for the ring without waiting; longer ones upload at once
     STEADY_TICK = True            # all active channels tracking on the device: the tick is one sdr_bank_tick_mirrored call
+    PREFETCH = True               # read-ahead: the next block is queued on the device while the current one is handed out
 
     def __init__(self, rfSignal, engine: Engine | None = None, device_id: int = 0, keepCorrelationMap: bool = True,
                  ring_ms: int = 100):
@@ -59,6 +60,7 @@ class ChannelManager:
         self._pending = False         # a slab's transfer into the ring is queued on the engine's stream, not waited for
         self._lists = None            # (state version, active, acquiring, host-side plugins, cids, states, ...) of the last tick
         self._unread_max = None       # most unread samples of any running channel after the last tick, when known
+        self._ahead = None            # read-ahead: the block queued on the device after the one being handed out (_track_ahead)
         self._samples_per_ms = self.rfSignal.samplingFrequency / 1e3
 
     @property
@@ -121,31 +123,44 @@ class ChannelManager:
         return first if same else None
 
     def _open_window(self, data) -> bool:
-        """Prefetch and track the next block if everything allows it; True when `data` was consumed that way."""
+        """Track the next block ahead if everything allows it (or take over the one that was started while the last block
+        was being handed out); True when `data` was consumed that way."""
         ra, bank, ring = self._readahead, self.bank, self.sharedBuffer
         spt = ra.spt
+        ahead = self._ahead
+        if ahead is not None and ahead["bank"] is not bank:
+            ahead = self._ahead = None                        # (the bank was re-created from the mirror: it starts the block again)
         if data.size != 2 * spt or self.nbChannels == 0:
-            return False
-        chans = [ch for ch in self.channels.values() if ch.channelState is not ChannelState.IDLE]
-        if not chans or any(not isinstance(ch, DeviceTrackedChannel) or ch.channelState is not ChannelState.TRACKING
-                            or ch.lostLock for ch in chans):
+            if ahead is not None:
+                raise ValueError("addNewRFData: a block of the recording is being tracked ahead; the slab must be its next millisecond")
             return False
         first = self._recording_position(data)
-        if first is None:
-            return False
-        rec = self.rfSignal._recording()
-        cids = np.array([ch.channelID for ch in chans], dtype=np.int32)
+        if ahead is not None:
+            if first != ahead["first"]:
+                raise ValueError("addNewRFData: a block of the recording is being tracked ahead; the slab must be the recording's "
+                                 f"next millisecond (sample {ahead['first']}); call enableReadAhead(0) and finish the block to feed other data")
+            cids, k, block = ahead["cids"], ahead["k"], ahead["block"]
+        else:
+            chans = [ch for ch in self.channels.values() if ch.channelState is not ChannelState.IDLE]
+            if not chans or any(not isinstance(ch, DeviceTrackedChannel) or ch.channelState is not ChannelState.TRACKING
+                                or ch.lostLock for ch in chans):
+                return False
+            if first is None:
+                return False
+            rec = self.rfSignal._recording()
+            cids = np.array([ch.channelID for ch in chans], dtype=np.int32)
         unread = bank.unread(cids)
-        room = (ring.maxSize - int(unread.max())) // spt - 1          # milliseconds the ring can take without overwriting
-        k = min(self._ra_ms, (rec.size // 2 - first) // spt, room)
-        if k < 4:
-            return False
-        self._flush_pending()
-        block = rec[2 * first:2 * (first + k * spt)]
-        self.engine.iq_upload(block, ring.idxWrite)
-        # every epoch that is complete inside the block, one persistent launch per group of equal epoch counts (and one
-        # more single-epoch launch for a channel whose last epoch just fits)
-        bank.flush()
+        if ahead is None:
+            room = (ring.maxSize - int(unread.max())) // spt - 1      # milliseconds the ring can take without overwriting
+            k = min(self._ra_ms, (rec.size // 2 - first) // spt, room)
+            if k < 4:
+                return False
+            self._flush_pending()
+            block = rec[2 * first:2 * (first + k * spt)]
+            self.engine.iq_upload(block, ring.idxWrite)
+            bank.flush()
+        # every epoch that is complete inside the block: ONE persistent launch of as many epochs as every channel has room
+        # for, then a launch per group of channels with equal numbers of epochs left (one or two more: an epoch that just fits)
         avail = unread + k * spt
         width = k + 2
         records = np.zeros((len(cids), width), dtype=bank.last.dtype)
@@ -153,6 +168,7 @@ class ChannelManager:
         used = np.zeros(len(cids), dtype=np.int64)               # samples of the epochs run so far
         states = bank.state[cids].copy()
         pending = np.ones(len(cids), dtype=bool)
+        first_pass = True
         while pending.any():
             rows = np.flatnonzero(pending)
             left = avail[rows] - used[rows]
@@ -160,10 +176,19 @@ class ChannelManager:
             budget = np.minimum(left // (n_next + 1), width - done[rows])
             budget = np.where((budget == 0) & (left >= n_next) & (done[rows] < width), 1, budget)   # the last epoch just fits
             pending[rows[budget <= 0]] = False
-            for n_ep in np.unique(budget[budget > 0]):
-                grp = rows[budget == n_ep]
-                n_ep = int(n_ep)
-                rec_g, st_g, done_g, _ = bank.device.step(cids[grp], n_ep, want_records=True, want_bits=False)
+            if first_pass and ahead is None and (budget > 0).any():
+                budget = np.where(budget > 0, budget[budget > 0].min(), budget)   # (everybody's common part first: one launch)
+            groups = [(int(n_ep), rows[budget == n_ep]) for n_ep in np.unique(budget[budget > 0])]
+            if first_pass and ahead is not None:
+                # the launch that was queued while the previous block was handed out: its channels, its epoch count
+                groups = [(ahead["n_ep"], np.arange(len(cids)))]
+                pending[:] = True
+            for n_ep, grp in groups:
+                if first_pass and ahead is not None:
+                    rec_g, st_g, done_g = bank.device.step_end()
+                    self._ahead = ahead = None
+                else:
+                    rec_g, st_g, done_g, _ = bank.device.step(cids[grp], n_ep, want_records=True, want_bits=False)
                 if (done_g == n_ep).all() and (done[grp] == done[grp[0]]).all():
                     records[grp, done[grp[0]]:done[grp[0]] + n_ep] = rec_g      # (the usual case: one slice assignment)
                     done[grp] += n_ep
@@ -176,14 +201,51 @@ class ChannelManager:
                             pending[r] = False
                 used[grp] += np.where(np.arange(n_ep)[None, :] < done_g[:, None], rec_g["n_samples"], 0).sum(axis=1)
                 states[grp] = st_g
+            first_pass = False
         ra.load(cids, records, done, states, unread)
         ra.raw, ra.first, ra.slabs_left, ra.slab_no = block, first, k, 0
         ra.raw_address = block.__array_interface__["data"][0]
         ra.version = getattr(ring, "stateVersion", None)       # (while it stands, the scheduled channels are all there is)
         lists = self._lists
         ra.covers_active = lists is not None and np.array_equal(lists[4], ra.cids64)
+        self._track_ahead(cids, first + k * spt, k, avail - used, states, pending_lost=bank.lost[cids])
         self._accept_prefetched(data)
         return True
+
+    def _track_ahead(self, cids, first, k_now, unread_then, states, pending_lost):
+        """Queue the block AFTER the one just loaded (sdr_bank_step_begin: its samples into the ring, one launch of the epochs
+        every channel has room for) so that the device works on it while this one's packets are handed out; `_open_window`
+        takes it over when its first millisecond arrives.  Nothing is queued when the recording ends, the ring cannot hold
+        both blocks, a channel was parked, or read-ahead was switched off."""
+        ring, bank, spt = self.sharedBuffer, self.bank, self._readahead.spt
+        if not self._ra_ms or not self.PREFETCH or not hasattr(bank.device, "step_begin") or pending_lost.any():
+            return
+        rec = self.rfSignal._recording()
+        # the ring has to hold both blocks beside whatever any channel has not read yet -- the block's own channels (what
+        # they will have left at its end) and everybody else who is active (a late joiner lags by its acquisition time)
+        mine = set(int(c) for c in cids)
+        behind = [int(unread_then.max())] + [ring.getNbUnreadSamples(ch.currentSample) for ch in self.channels.values()
+                                             if ch.channelState is not ChannelState.IDLE and ch.channelID not in mine]
+        room = (ring.maxSize - max(behind)) // spt - k_now - 1
+        k = min(self._ra_ms, (rec.size // 2 - first) // spt, room)
+        if any(ch.channelState is ChannelState.IDLE for ch in self.channels.values()):
+            # a channel started later begins reading at ring position 0 (channel.py:93: currentSample = 0) -- samples the
+            # plain loop would still hold there must not be replaced ahead of their time: the block stops at the ring's end
+            start = (ring.idxWrite + k_now * spt) % ring.maxSize
+            k = min(k, (ring.maxSize - start) // spt) if start else 0
+        if k < 4:
+            return
+        avail = unread_then + k * spt
+        n_next = states["n_samples"].astype(np.int64)
+        budget = np.minimum(avail // (n_next + 1), k + 2)
+        if (budget <= 0).any():
+            return
+        n_ep = int(budget.min())
+        block = rec[2 * first:2 * (first + k * spt)]
+        self.engine.iq_upload(block, (ring.idxWrite + k_now * spt) % ring.maxSize)
+        bank.flush()
+        bank.device.step_begin(cids, n_ep)
+        self._ahead = dict(bank=bank, first=first, k=k, cids=cids, n_ep=n_ep, block=block)
 
     def _accept_prefetched(self, data):
         ra = self._readahead
@@ -208,7 +270,7 @@ class ChannelManager:
         if ra is not None:
             if ra.slabs_left:
                 return self._accept_prefetched(data)
-            if self._ra_ms and ra.empty and self._open_window(data):
+            if (self._ra_ms or self._ahead is not None) and ra.empty and self._open_window(data):
                 return None
         if self._pending:
             self._flush_pending()
@@ -261,6 +323,9 @@ class ChannelManager:
 
     def close(self):
         self._flush_pending()
+        if self._ahead is not None and self._ahead["bank"] is self.bank:
+            self.bank.device.step_end()                       # (a block queued ahead: let it finish before the bank goes)
+        self._ahead = None
         self.channels.clear()
         if self.bank is not None:
             self.bank.close()
@@ -415,8 +480,8 @@ class ChannelManager:
         read that has not been written.  Returns the per-epoch TRACKING_UPDATE packets, channel by channel, epoch
         by epoch, followed by one CHANNEL_UPDATE per tracking channel."""
         self._flush_pending()
-        if self._readahead is not None and (self._readahead.slabs_left or not self._readahead.empty):
-            raise RuntimeError("runBlock while a read-ahead block is being replayed: finish its ticks first")
+        if (self._readahead is not None and (self._readahead.slabs_left or not self._readahead.empty)) or self._ahead is not None:
+            raise RuntimeError("runBlock while a read-ahead block is being replayed or tracked ahead: finish its ticks first")
         out = TickPackets()
         bank = self.bank
         chans = [ch for ch in self.channels.values() if ch.channelState is ChannelState.TRACKING and not ch.lostLock]

@@ -15,28 +15,27 @@ CHANNEL_UPDATE packets the unread samples, flags, code count and TOW of every ch
 (the navigation bits of the block go through the channels' decoders in order at that point; a subframe they complete
 is released with the tick of its bit) -- so a replayed tick costs a dictionary lookup.
 
+While a block is handed out the NEXT one is already on the device (`ChannelManager._track_ahead`: its samples in the ring,
+its epochs queued with `sdr_bank_step_begin`); the tick that needs it only collects the results -- no tick waits for a
+launch.  It is queued only where the plain loop could not tell the difference: the ring must hold both blocks beside
+what every active channel has not read yet, and while a channel is still IDLE (it would start reading at ring position 0)
+the block queued ahead ends at the ring's end.  (The block being handed out may itself cover ring position 0 ahead of its
+time: a channel STARTED during those ticks searches newer samples than the plain loop's stale ones.)
+
 The reference's calls do not change.  What differs while a block is replayed: attributes read from a channel OBJECT
 (carrierFrequency, currentSample, navBits ...) show the state at the END of the block; the packets -- all the
 reference's receiver ever sees of a channel, which lives in another process there -- are those of the tick.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
+from .. import _lib
 from .bank import tracking_packets_builder
 from .navdecoder import HOST_FLAGS
 from ..utils.enumerations import ChannelMessage
-
-
-def _take_records(records, rows, cols):
-    """records[rows, cols] of a C-contiguous 2-D structured array whose item size is a multiple of 8, as a row gather
-    over 64-bit words (NumPy's fancy indexing of structured items goes item by item through its generic copy: 200 us
-    for the 1600 records of a block against ~10)."""
-    dt = records.dtype
-    if records.ndim != 2 or dt.itemsize % 8 or not records.flags.c_contiguous:
-        return records[rows, cols]
-    words = records.view(np.uint64).reshape(records.shape[0] * records.shape[1], dt.itemsize // 8)
-    return words[np.asarray(rows) * records.shape[1] + np.asarray(cols)].view(dt).reshape(-1)
 
 
 class EpochSchedule:
@@ -89,55 +88,67 @@ class EpochSchedule:
         n_max = int(done.max()) if n_ch else 0
         if n_max == 0:
             return
-        lengths = records["n_samples"][:, :n_max].astype(np.int64)
-        ends = np.cumsum(lengths, axis=1)
-        first = np.maximum(0, -(-(ends - unread_now[:, None]) // spt) - 1)          # ceil(.) - 1
-        valid = np.arange(n_max)[None, :] < done[:, None]
-        # at most one epoch per channel and tick: first[e] >= first[e - 1] + 1, i.e. first[e] - e never decreases
-        steps = np.arange(n_max)[None, :]
-        first = np.maximum.accumulate(first - steps, axis=1) + steps
-        first = np.where(valid, first, -1)
-        n_ticks = self.n_ticks = int(first.max()) + 1
-        rows, cols = np.nonzero(valid)
-        ticks = first[rows, cols]
-        # the epochs in the order of their ticks (channels ascending inside a tick): tick k releases one slice of these
-        order = np.argsort(ticks, kind="stable")
-        rows_s, cols_s = rows[order], cols[order]
-        self._starts = np.searchsorted(ticks[order], np.arange(n_ticks + 1)).tolist()
-        self._cids_sorted = self.cids64[rows_s]
-        self._records_sorted = _take_records(records, rows_s, cols_s)
-        self.busy[channels[done > 0]] = True
-        last = first.max(axis=1)
-        self.last_tick[channels] = last
-        for t in np.unique(last[done > 0]).tolist():       # tick -> the channels whose last computed epoch it releases
-            self._finishing[t] = channels[(last == t) & (done > 0)]
-
-        # ---- per tick: samples consumed, device flags, code count (one epoch per channel and tick at most)
-        epoch_at = np.full((n_ticks, n_ch), -1, dtype=np.int64)                     # epoch released by (tick, channel)
-        epoch_at[ticks, rows] = cols
-        ran = epoch_at >= 0
-        safe = np.where(ran, epoch_at, 0)
-        ch_rows = np.arange(n_ch)[None, :]
-        consumed = np.cumsum(np.where(ran, lengths[ch_rows, safe], 0), axis=0)
-        unread = unread_now[None, :] + (np.arange(n_ticks)[:, None] + 1) * spt - consumed
-        latest = np.maximum.accumulate(np.where(ran, epoch_at, -1), axis=0)          # newest released epoch so far
+        # ---- which tick releases which epoch, and what every tick's channel updates report: one pass in the library
+        # (sdr_block_schedule, csrc/schedule.hip -- host code; the same in NumPy array operations was 0.4 ms per block)
+        lib = _lib.load()
+        records = np.ascontiguousarray(records)
+        n_cols = records.shape[1]
+        done32 = np.ascontiguousarray(done, dtype=np.int32)
+        unread64 = np.ascontiguousarray(unread_now, dtype=np.int64)
         flags0 = bank.state["track_flags"][channels].astype(np.int64)
+        since0 = np.ascontiguousarray(bank.code_since_tow[channels], dtype=np.int64)
+        max_ticks = n_cols + 8
+        total = int(done32.sum())
+        first = np.empty((n_ch, n_cols), dtype=np.int32)
+        n_ticks_c = C.c_int32(0)
+        rows_s, cols_s = np.empty(total, dtype=np.int32), np.empty(total, dtype=np.int32)
+        starts = np.empty(max_ticks + 1, dtype=np.int32)
+        records_sorted = np.empty(total, dtype=records.dtype)
+        last_records = np.empty(n_ch, dtype=records.dtype)
+        unread = np.empty((max_ticks, n_ch), dtype=np.int64)
+        dev_flags, code_count = np.empty_like(unread), np.empty_like(unread)
+        last = np.empty(n_ch, dtype=np.int32)
+        bit_rows, bit_cols, bit_vals = (np.empty(total, dtype=np.int32) for _ in range(3))
+        n_bits_c = C.c_int32(0)
+        status = lib.sdr_block_schedule(records.ctypes.data, n_ch, n_cols, done32.ctypes.data, unread64.ctypes.data, self.spt,
+                                        flags0.ctypes.data, since0.ctypes.data, max_ticks, first.ctypes.data, C.byref(n_ticks_c),
+                                        rows_s.ctypes.data, cols_s.ctypes.data, starts.ctypes.data, records_sorted.ctypes.data,
+                                        last_records.ctypes.data, unread.ctypes.data, dev_flags.ctypes.data, code_count.ctypes.data,
+                                        last.ctypes.data, bit_rows.ctypes.data, bit_cols.ctypes.data, bit_vals.ctypes.data, C.byref(n_bits_c))
+        if status:
+            _lib.check(status)
+        n_ticks = self.n_ticks = n_ticks_c.value
+        unread, dev_flags, code_count = unread[:n_ticks], dev_flags[:n_ticks], code_count[:n_ticks]
+        self._starts = starts[:n_ticks + 1].tolist()
+        self._cids_sorted = self.cids64[rows_s]
+        self._records_sorted = records_sorted
+        self.busy[channels[done > 0]] = True
+        self.last_tick[channels] = last
+        by_tick = {}                                       # tick -> the channels whose last computed epoch it releases
+        for ch, t in zip(channels.tolist(), last.tolist()):
+            if t >= 0:
+                by_tick.setdefault(t, []).append(ch)
+        self._finishing = {t: np.array(chs, dtype=channels.dtype) for t, chs in by_tick.items()}
+        count = code_count - since0[None, :]                # (epochs released so far: a subframe restarts the code count from it)
         rec_flags = records["track_flags"]
-        dev_flags = np.where(latest >= 0, rec_flags[ch_rows, np.maximum(latest, 0)], flags0[None, :])
-        count = np.cumsum(ran, axis=0)
-        code_count = bank.code_since_tow[channels][None, :] + count
-        host = np.repeat(bank.host_flags[channels][None, :], n_ticks, axis=0)
-        tow = np.repeat(bank.tow[channels][None, :], n_ticks, axis=0)
-        tow_dec = np.repeat(bank.tow_decoded[channels][None, :], n_ticks, axis=0)
+        decoders = [bank.decoders[int(c)] for c in channels]
+        if any(d is not None for d in decoders):            # (the decoders own flag bits and the time of week: per tick from here on)
+            host = np.repeat(bank.host_flags[channels][None, :], n_ticks, axis=0)
+            tow = np.repeat(bank.tow[channels][None, :], n_ticks, axis=0)
+            tow_dec = np.repeat(bank.tow_decoded[channels][None, :], n_ticks, axis=0)
+        else:                                                # (nobody writes them: one row serves every tick)
+            host = np.broadcast_to(bank.host_flags[channels], (n_ticks, n_ch))
+            tow = np.broadcast_to(bank.tow[channels], (n_ticks, n_ch))
+            tow_dec = np.broadcast_to(bank.tow_decoded[channels], (n_ticks, n_ch))
 
         # ---- the block's navigation bits: kept per channel in epoch order, and through the channel's decoder when it
         # has one (navdecoder.py)
-        nav = records["nav_bit"][:, :n_max]
-        bit_rows, bit_cols = np.nonzero((nav >= 0) & valid)               # (row-major: a channel's bits in epoch order)
-        if len(bit_rows):
-            bit_values = nav[bit_rows, bit_cols].tolist()
+        n_bits = n_bits_c.value
+        if n_bits:
+            bit_rows = bit_rows[:n_bits]
+            bit_values = bit_vals[:n_bits].tolist()
+            bit_epochs = bit_cols[:n_bits].tolist()
             bounds = np.searchsorted(bit_rows, np.arange(n_ch + 1)).tolist()
-            bit_epochs = bit_cols.tolist()
             for r in np.unique(bit_rows).tolist():
                 ch = int(channels[r])
                 lo, hi = bounds[r], bounds[r + 1]
@@ -165,7 +176,10 @@ class EpochSchedule:
             bank.state[lo:hi + 1] = states
         else:
             bank.state[channels] = states
-        bank.last[channels[has]] = _take_records(records, np.flatnonzero(has), done[has] - 1)
+        if hi - lo + 1 == n_ch and bool(has.all()) and bool((np.diff(channels) == 1).all()):
+            bank.last[lo:hi + 1] = last_records
+        else:
+            bank.last[channels[has]] = last_records[has]
         bank.code_since_tow[channels] = code_count[-1]
         bank.host_flags[channels], bank.tow[channels], bank.tow_decoded[channels] = host[-1], tow[-1], tow_dec[-1]
 

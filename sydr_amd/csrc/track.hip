@@ -1085,6 +1085,9 @@ int check_state(sdr_engine* e, const sdr_track_state* st, int index) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------- channel bank
+struct BankPending;
+struct sdr_bank;
+static void sdr_bank_free_pending(sdr_bank* b);
 struct sdr_bank {
     int max_channels = 0;
     sdr_track_state* d_states = nullptr;  // [max_channels] -- the tracking state of this GPU's channels lives here
@@ -1092,6 +1095,9 @@ struct sdr_bank {
     std::vector<int32_t> n_taps;          // host mirror of what was put: taps per channel, 0 = channel never put
     std::vector<int32_t> slot;
     int64_t code_generation = 0;
+    // sdr_bank_step_begin / _end: scratch of their own (a tick between the two halves must not touch the results), on the engine's stream
+    StreamCtx async_ctx;
+    BankPending* pending = nullptr;
     // scratch of sdr_bank_tick_mirrored (kept between ticks: no allocation in the steady state)
     std::vector<int32_t> tick_list, tick_done;
     std::vector<sdr_track_state> tick_states;
@@ -1222,6 +1228,10 @@ void sdr_bank_destroy(sdr_engine* e, sdr_bank* b) {
     }
     if (b->d_states) (void)hipFree(b->d_states);
     if (b->d_cfgs) (void)hipFree(b->d_cfgs);
+    for (DevBuf* d : {&b->async_ctx.traj, &b->async_ctx.bits, &b->async_ctx.xchg})
+        if (d->ptr) (void)hipFree(d->ptr);
+    if (b->async_ctx.pinned) (void)hipHostFree(b->async_ctx.pinned);
+    sdr_bank_free_pending(b);
     delete b;
 }
 
@@ -1270,11 +1280,53 @@ static long g_tick_calls;
 #define TICK_REPORT() ((void)0)
 #endif
 
+// A bank step whose launch and result copies are queued but not waited for (sdr_bank_step_begin / _end).
+struct BankPending {
+    bool active = false;
+    StreamCtx* ctx = nullptr;
+    int n_ch = 0, n_epochs = 0, parts = 1;
+    int32_t* p_head = nullptr;
+    sdr_track_state* p_states = nullptr;
+    sdr_track_epoch* p_rec = nullptr;
+    int8_t* p_bits = nullptr;
+    size_t rec_bytes = 0, st_bytes = 0, bits_bytes = 0;
+};
+
+static void sdr_bank_free_pending(sdr_bank* b) {
+    delete b->pending;
+    b->pending = nullptr;
+}
+
+// What is left of a step once everything is queued: wait, check, hand the results out of the page-locked block.
+static int bank_collect(BankPending& P, sdr_track_epoch* records, sdr_track_state* states_out, int32_t* epochs_done, int8_t* nav_bits,
+                        int32_t* n_bits) {
+    P.active = false;
+    SDR_HIP(hipStreamSynchronize(P.ctx->stream));
+    TICK_CLOCK(3);
+    if (P.p_head[0])
+        return sdr_fail(SDR_ERR_HIP, "closed-loop tracking: a workgroup of a %d-part cluster never published its sums", P.parts);
+    if (epochs_done) memcpy(epochs_done, P.p_head + 4, (size_t)P.n_ch * sizeof(int32_t));
+    if (nav_bits) {
+        memcpy(n_bits, P.p_head + 4 + P.n_ch, (size_t)P.n_ch * sizeof(int32_t));
+        memcpy(nav_bits, P.p_bits, P.bits_bytes);
+    }
+    if (states_out) memcpy(states_out, P.p_states, P.st_bytes);
+    if (records) memcpy(records, P.p_rec, P.rec_bytes);
+    TICK_CLOCK(4);
+    TICK_REPORT();
+    return SDR_OK;
+}
+
 // Shared by sdr_bank_step / sdr_bank_tick: everything between the optional ingest and the final synchronisation.
+// defer != nullptr: queue only (records and states are produced whatever the pointers say) and describe the step in *defer.
 static int bank_run(sdr_engine* e, sdr_bank* b, StreamCtx* ctx, const int32_t* channels, int n_ch, int n_epochs,
                     sdr_track_epoch* records, sdr_track_state* states_out, int32_t* epochs_done, int8_t* nav_bits,
-                    int max_bits, int32_t* n_bits) {
+                    int max_bits, int32_t* n_bits, BankPending* defer = nullptr) {
     TICK_CLOCK(0);
+    if (defer) {   // (any non-null value: the queueing part below only asks whether they are wanted)
+        records = reinterpret_cast<sdr_track_epoch*>(defer);
+        states_out = reinterpret_cast<sdr_track_state*>(defer);
+    }
     if (!e->iq) return sdr_fail(SDR_ERR_STATE, "IQ ring not allocated");
     if (!e->codes) return sdr_fail(SDR_ERR_STATE, "code slots not allocated");
     if ((nav_bits && (max_bits < 1 || !n_bits)) || (!nav_bits && n_bits))
@@ -1372,20 +1424,13 @@ static int bank_run(sdr_engine* e, sdr_bank* b, StreamCtx* ctx, const int32_t* c
         if (records) SDR_HIP(hipMemcpyAsync(p_rec, ctx->traj.ptr, rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
         if (nav_bits) SDR_HIP(hipMemcpyAsync(p_bits, r.d_bits, bits_bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
-    SDR_HIP(hipStreamSynchronize(ctx->stream));
-    TICK_CLOCK(3);
-    if (p_head[0])
-        return sdr_fail(SDR_ERR_HIP, "closed-loop tracking: a workgroup of a %d-part cluster never published its sums", parts);
-    if (epochs_done) memcpy(epochs_done, p_head + 4, (size_t)n_ch * sizeof(int32_t));
-    if (nav_bits) {
-        memcpy(n_bits, p_head + 4 + n_ch, (size_t)n_ch * sizeof(int32_t));
-        memcpy(nav_bits, p_bits, bits_bytes);
-    }
-    if (states_out) memcpy(states_out, p_states, st_bytes);
-    if (records) memcpy(records, p_rec, rec_bytes);
-    TICK_CLOCK(4);
-    TICK_REPORT();
-    return SDR_OK;
+    BankPending local;
+    BankPending& P = defer ? *defer : local;
+    P.active = true, P.ctx = ctx, P.n_ch = n_ch, P.n_epochs = n_epochs, P.parts = parts;
+    P.p_head = p_head, P.p_states = p_states, P.p_rec = p_rec, P.p_bits = p_bits;
+    P.rec_bytes = rec_bytes, P.st_bytes = st_bytes, P.bits_bytes = bits_bytes;
+    if (defer) return SDR_OK;
+    return bank_collect(P, records, states_out, epochs_done, nav_bits, n_bits);
 }
 
 int sdr_bank_step(sdr_engine* e, sdr_bank* b, const int32_t* channels, int n_ch, int n_epochs,
@@ -1396,6 +1441,25 @@ int sdr_bank_step(sdr_engine* e, sdr_bank* b, const int32_t* channels, int n_ch,
     StreamCtx* ctx = sdr_stream_ctx(e, stream_id);
     if (!ctx) return sdr_fail(SDR_ERR_INVALID, "stream id %d does not exist", stream_id);
     return bank_run(e, b, ctx, channels, n_ch, n_epochs, records, states_out, epochs_done, nav_bits, max_bits, n_bits);
+}
+
+// sdr_bank_step in two halves.  _begin queues the launch and the copies of its results into page-locked memory on the
+// engine's stream and returns; _end waits for them and hands them out.  One step may be in flight per bank; whatever is
+// queued on the stream in between (a tick, an upload) runs after the step, as the stream orders it.
+int sdr_bank_step_begin(sdr_engine* e, sdr_bank* b, const int32_t* channels, int n_ch, int n_epochs) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!b) return sdr_fail(SDR_ERR_INVALID, "bank is NULL");
+    if (!b->pending) b->pending = new BankPending();
+    if (b->pending->active) return sdr_fail(SDR_ERR_STATE, "a step of this bank is already in flight: sdr_bank_step_end first");
+    b->async_ctx.stream = e->ctx0.stream;
+    return bank_run(e, b, &b->async_ctx, channels, n_ch, n_epochs, nullptr, nullptr, nullptr, nullptr, 0, nullptr, b->pending);
+}
+
+int sdr_bank_step_end(sdr_engine* e, sdr_bank* b, sdr_track_epoch* records, sdr_track_state* states_out, int32_t* epochs_done) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!b) return sdr_fail(SDR_ERR_INVALID, "bank is NULL");
+    if (!b->pending || !b->pending->active) return sdr_fail(SDR_ERR_STATE, "no step of this bank is in flight");
+    return bank_collect(*b->pending, records, states_out, epochs_done, nullptr, nullptr);
 }
 
 int sdr_bank_tick(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,

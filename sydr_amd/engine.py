@@ -111,6 +111,25 @@ class Bank:
         nav = [bits[c, :n_bits[c]].copy() for c in range(n)] if want_bits else None
         return rec, states, done, nav
 
+    def step_begin(self, channels, n_epochs: int):
+        """`step` without the wait (sdr_bank_step_begin): the launch and the copies of its results are queued on the
+        engine's stream; `step_end()` hands them out.  One step in flight per bank."""
+        channels = np.ascontiguousarray(channels, dtype=np.int32)
+        check(self._lib.sdr_bank_step_begin(self._e._h, self._h, ptr(channels), len(channels), int(n_epochs)))
+        self._in_flight = (len(channels), int(n_epochs))
+
+    def step_end(self):
+        """-> (records[n][n_epochs], states[n], epochs_done[n]) of the step `step_begin` queued."""
+        if getattr(self, "_in_flight", None) is None:
+            check(self._lib.sdr_bank_step_end(self._e._h, self._h, None, None, None))      # (the library says what is wrong)
+        n, n_epochs = self._in_flight
+        self._in_flight = None
+        rec = np.empty((n, n_epochs), dtype=TRACK_EPOCH_DTYPE)
+        states = np.empty(n, dtype=TRACK_STATE_DTYPE)
+        done = np.zeros(n, dtype=np.int32)
+        check(self._lib.sdr_bank_step_end(self._e._h, self._h, ptr(rec), ptr(states), ptr(done)))
+        return rec, states, done
+
     def tick(self, raw, ring_offset: int, channels):
         """One receiver tick: `raw` (the ring's format, may be None) goes into the ring at ring_offset, then the
         listed channels run one epoch.  -> (records[n], states[n], epochs_done[n])"""

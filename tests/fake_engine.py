@@ -263,6 +263,18 @@ def _tick_mirrored(self, raw, ring_offset, write_index):
     return m
 
 
+def _step_begin(self, channels, n_epochs):
+    rec, states, done, _ = self.step(channels, n_epochs)      # (nothing runs beside the host here: the work is done at once)
+    self._in_flight = (rec, states, done)
+
+
+def _step_end(self):
+    out, self._in_flight = self._in_flight, None
+    return out
+
+
+OracleBank.step_begin = _step_begin
+OracleBank.step_end = _step_end
 OracleBank.bind_mirror = _bind_mirror
 OracleBank.tick_mirrored = _tick_mirrored
 

@@ -530,3 +530,45 @@ def test_mirrored_tick_refuses_what_it_cannot_trust(engine):
     engine.sync()
     assert np.array_equal(engine.iq_download(32, 80000 - 16), wrap)
     bank.close()
+
+
+def test_step_in_two_halves_equals_the_step(engine):
+    """sdr_bank_step_begin + sdr_bank_step_end = sdr_bank_step: the same records, states and epoch counts bit for bit; a tick
+    queued between the halves runs after the step (the stream orders them) and leaves its results alone; a second begin
+    while one is in flight and an end without a begin are refused."""
+    from sydr_amd._lib import SdrError
+    g, fs, raw = trajectory_iq()
+    n = raw.size // 2 // 8 * 8
+    engine.iq_alloc(n, FMT_CI8)
+    engine.iq_upload(raw[:2 * n], 0)
+    engine.code_slots(2)
+    engine.load_gps_code(1, 7)
+    acq = g["kaplan_acq"]
+    st_k = initial_state(1, fs, acq[3], int(acq[5]), KAPLAN_CFG, slot=1)
+    st_b = initial_state(0, fs, acq[3], int(acq[5]), BORRE_CFG, slot=1)
+
+    def fresh():
+        bank = engine.bank(4)
+        bank.put(0, as_row(st_k, TRACK_STATE_DTYPE), as_row(loop_cfg(1, fs, KAPLAN_CFG), LOOP_CFG_DTYPE))
+        bank.put(2, as_row(st_b, TRACK_STATE_DTYPE), as_row(loop_cfg(0, fs, BORRE_CFG), LOOP_CFG_DTYPE))
+        bank.put(3, as_row(st_k, TRACK_STATE_DTYPE), as_row(loop_cfg(1, fs, KAPLAN_CFG), LOOP_CFG_DTYPE))
+        return bank
+    a = fresh()
+    rec_a, st_a, done_a, _ = a.step([0, 2], 30)
+    tick_a = a.tick(None, 0, np.array([3], dtype=np.int32))
+    a.close()
+    b = fresh()
+    with pytest.raises(SdrError, match="no step"):
+        b.step_end()
+    b.step_begin([0, 2], 30)
+    with pytest.raises(SdrError, match="already in flight"):
+        b.step_begin([3], 1)
+    tick_b = b.tick(None, 0, np.array([3], dtype=np.int32))     # (another channel, queued behind the step, its own scratch)
+    rec_b, st_b2, done_b = b.step_end()
+    assert rec_a.tobytes() == rec_b.tobytes() and st_a.tobytes() == st_b2.tobytes() and list(done_a) == list(done_b) == [30, 30]
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(tick_a, tick_b))
+    b.step_begin([0, 2], 5)                                      # (and again: the halves can be used over and over)
+    rec_c, _, done_c = b.step_end()
+    assert list(done_c) == [5, 5] and rec_c["start_sample"][0, 0] == rec_b["start_sample"][0, -1] + rec_b["n_samples"][0, -1]
+    b.step_begin([0], 3)
+    b.close()                                                    # (a bank destroyed with a step in flight waits for it)

@@ -572,3 +572,83 @@ def test_packets_fill_themselves_and_the_steady_tick_equals_the_general_one():
     steady, end_s, calls_s = receiver(True)
     assert general == steady and end_g == end_s and calls_g == calls_s
     assert sum(x["type"] is ChannelMessage.TRACKING_UPDATE for t in steady for x in t) > 380
+
+
+def test_block_schedule_in_the_library_equals_the_array_formulation():
+    """sdr_block_schedule (host code of libsydr_amd.so, no GPU): which tick releases which epoch of a block tracked ahead and
+    what every tick's channel updates report -- against the same rules written as NumPy array operations (what
+    readahead.py did before): random channel counts, epoch lengths around a millisecond, channels that stopped early,
+    channels that ran nothing, epochs already complete when the block starts."""
+    import ctypes as C
+    from sydr_amd import _lib
+    from sydr_amd._lib import TRACK_EPOCH_DTYPE
+    lib = _lib.load()
+    rng = np.random.default_rng(20261004)
+    for trial in range(60):
+        n_ch, n_cols, spt = int(rng.integers(1, 41)), int(rng.integers(1, 60)), int(rng.choice([4000, 10000, 25000]))
+        rec = np.zeros((n_ch, n_cols), dtype=TRACK_EPOCH_DTYPE)
+        rec["n_samples"] = spt + rng.integers(-2, 3, (n_ch, n_cols))
+        if trial % 5 == 0:
+            rec["n_samples"] = rec["n_samples"] // 4 * (1 + trial % 3)              # epochs of other lengths than a tick
+        rec["track_flags"] = rng.integers(0, 8, (n_ch, n_cols))
+        rec["nav_bit"] = np.where(rng.random((n_ch, n_cols)) < 0.06, rng.integers(0, 2, (n_ch, n_cols)), -1)
+        rec["carrier_hz"] = rng.normal(size=(n_ch, n_cols))
+        done = rng.integers(0, n_cols + 1, n_ch).astype(np.int32)
+        done[rng.random(n_ch) < 0.6] = n_cols
+        if trial % 7 == 0:
+            done[0] = 0
+        unread = rng.integers(0, 3 * spt, n_ch).astype(np.int64)
+        flags0, since0 = rng.integers(0, 8, n_ch).astype(np.int64), rng.integers(0, 5000, n_ch).astype(np.int64)
+        n_max = int(done.max())
+        # ---- the array formulation
+        lengths = rec["n_samples"].astype(np.int64)
+        ends = np.cumsum(lengths, axis=1)
+        first = np.maximum(0, -(-(ends - unread[:, None]) // spt) - 1)
+        for e in range(1, n_cols):
+            first[:, e] = np.maximum(first[:, e], first[:, e - 1] + 1)
+        valid = np.arange(n_cols)[None, :] < done[:, None]
+        first = np.where(valid, first, -1)
+        n_ticks = int(first.max()) + 1 if n_max else 0
+        rows, cols = np.nonzero(valid)
+        ticks = first[rows, cols]
+        order = np.argsort(ticks, kind="stable")
+        # ---- the library
+        total, max_ticks = int(done.sum()), n_cols + 3 * 3 + 8
+        out_first = np.empty((n_ch, n_cols), dtype=np.int32)
+        nt, nb = C.c_int32(-1), C.c_int32(-1)
+        rs, cs, br, bc, bv = (np.empty(max(total, 1), dtype=np.int32) for _ in range(5))
+        starts = np.empty(max_ticks + 1, dtype=np.int32)
+        rsorted, lastr = np.empty(max(total, 1), dtype=rec.dtype), np.empty(n_ch, dtype=rec.dtype)
+        un, df, cc = (np.empty((max_ticks, n_ch), dtype=np.int64) for _ in range(3))
+        last = np.empty(n_ch, dtype=np.int32)
+        status = lib.sdr_block_schedule(rec.ctypes.data, n_ch, n_cols, done.ctypes.data, unread.ctypes.data, spt, flags0.ctypes.data,
+                                        since0.ctypes.data, max_ticks, out_first.ctypes.data, C.byref(nt), rs.ctypes.data, cs.ctypes.data,
+                                        starts.ctypes.data, rsorted.ctypes.data, lastr.ctypes.data, un.ctypes.data, df.ctypes.data,
+                                        cc.ctypes.data, last.ctypes.data, br.ctypes.data, bc.ctypes.data, bv.ctypes.data, C.byref(nb))
+        assert status == 0, lib.sdr_last_error()
+        assert nt.value == n_ticks and np.array_equal(out_first, first), trial
+        assert np.array_equal(rs[:total], rows[order]) and np.array_equal(cs[:total], cols[order])
+        assert rsorted[:total].tobytes() == rec[rows[order], cols[order]].tobytes()
+        assert np.array_equal(starts[:n_ticks + 1], np.searchsorted(ticks[order], np.arange(n_ticks + 1)))
+        assert np.array_equal(last, np.where(done > 0, first.max(axis=1), -1))
+        for r in range(n_ch):
+            if done[r]:
+                assert lastr[r].tobytes() == rec[r, done[r] - 1].tobytes()
+        if n_ticks:
+            epoch_at = np.full((n_ticks, n_ch), -1, dtype=np.int64)
+            epoch_at[ticks, rows] = cols
+            ran = epoch_at >= 0
+            ch_rows = np.arange(n_ch)[None, :]
+            consumed = np.cumsum(np.where(ran, lengths[ch_rows, np.where(ran, epoch_at, 0)], 0), axis=0)
+            latest = np.maximum.accumulate(np.where(ran, epoch_at, -1), axis=0)
+            assert np.array_equal(un[:n_ticks], unread[None, :] + (np.arange(n_ticks)[:, None] + 1) * spt - consumed)
+            assert np.array_equal(df[:n_ticks], np.where(latest >= 0, rec["track_flags"][ch_rows, np.maximum(latest, 0)], flags0[None, :]))
+            assert np.array_equal(cc[:n_ticks], since0[None, :] + np.cumsum(ran, axis=0))
+        b_rows, b_cols = np.nonzero((rec["nav_bit"] >= 0) & valid)
+        assert nb.value == len(b_rows) and np.array_equal(br[:nb.value], b_rows) and np.array_equal(bc[:nb.value], b_cols)
+        assert np.array_equal(bv[:nb.value], rec["nav_bit"][b_rows, b_cols])
+    # an epoch beyond the ticks the caller made room for: refused
+    assert lib.sdr_block_schedule(rec.ctypes.data, n_ch, n_cols, done.ctypes.data, unread.ctypes.data, spt, flags0.ctypes.data,
+                                  since0.ctypes.data, 1, out_first.ctypes.data, C.byref(nt), rs.ctypes.data, cs.ctypes.data,
+                                  starts.ctypes.data, rsorted.ctypes.data, lastr.ctypes.data, un.ctypes.data, df.ctypes.data,
+                                  cc.ctypes.data, last.ctypes.data, br.ctypes.data, bc.ctypes.data, bv.ctypes.data, C.byref(nb)) != 0 or n_ticks <= 1

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../sydr_amd/csrc"
 mkdir -p /tmp/sdr_trace_build
-for f in engine codes epl epl_straight pcps pcps_fused track track_dense; do
+for f in engine codes epl epl_straight pcps pcps_fused track track_dense schedule; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DSDR_TRACE_WG -DSDR_TRACE_TRACK -I../../include -c $f.hip -o /tmp/sdr_trace_build/$f.o &
 done
 wait

@@ -9,7 +9,7 @@ cd "$ROOT/sydr_amd/csrc"
 EXTRA=""; { [ "$UNIT" = track_dense ] || [ "$UNIT" = pcps_fused ]; } && [ -z "$KEEP_LICM" ] && EXTRA="-mllvm -disable-machine-licm"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-result $EXTRA "$@" -c $UNIT.hip -o /tmp/var_${TAG}_$UNIT.o
 OBJS=""
-for u in engine codes epl epl_straight pcps pcps_fused track track_dense; do
+for u in engine codes epl epl_straight pcps pcps_fused track track_dense schedule; do
   if [ $u = $UNIT ]; then OBJS="$OBJS /tmp/var_${TAG}_$UNIT.o"; else OBJS="$OBJS $u.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/scratch/var/lib_$TAG.so" $OBJS
