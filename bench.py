@@ -183,11 +183,20 @@ def cpu_baseline_all_cores(raw, items, prns, n_epochs, budget_s):
             rows = [(int(a), int(b), float(f), float(rc), float(rk), float(cs)) for a, b, f, rc, rk, cs in
                     zip(it["start_sample"], it["n_samples"], it["carrier_hz"], it["rem_carrier"], it["rem_code"], it["code_step"])]
             jobs.append((path, rows, int(prns[c])))
-        with mp.get_context("spawn").Pool(procs) as pool:
-            pool.map(_mp_warm, range(procs * 2))
+        # (bounded waits: a worker that never comes back must not hang the whole bench line -- this leg is a reported
+        # baseline, the line is the contract; a timeout is reported as such)
+        pool = mp.get_context("spawn").Pool(procs)
+        try:
+            pool.map_async(_mp_warm, range(procs * 2)).get(timeout=180)
             t0 = time.perf_counter()
-            res = pool.map(_mp_worker, jobs, chunksize=1)
+            res = pool.map_async(_mp_worker, jobs, chunksize=1).get(timeout=max(120.0, 20.0 * budget_s))
             dt = time.perf_counter() - t0
+            pool.close()
+        except mp.TimeoutError:
+            pool.terminate()
+            return None, procs, 0.0, epochs
+        finally:
+            pool.terminate()
     ch_samples = sum(r[0] for r in res)
     return ch_samples / N_CH / dt / 1e6, procs, dt, epochs
 
@@ -1037,9 +1046,10 @@ def main():
             mval, procs, mdt, mep = cpu_baseline_all_cores(raw, items, [s["prn"] for s in sats], hi_ms, args.cpu_mp_seconds)
             result["cpu_baseline_mp"] = {"value": mval, "unit": "Msamples/s", "cores": procs, "host_cpus": os.cpu_count(),
                                          "kind": "port",
-                                         "sample": f"{mep} ms x 32 ch of the same stream, one oracle process per channel "
-                                                   f"(the reference's process-per-channel design) over a pool of {procs} "
-                                                   f"spawned workers, {mdt:.1f} s wall"}
+                                         "sample": (f"{mep} ms x 32 ch of the same stream, one oracle process per channel "
+                                                    f"(the reference's process-per-channel design) over a pool of {procs} "
+                                                    f"spawned workers, {mdt:.1f} s wall") if mval is not None else
+                                                   f"the pool of {procs} spawned workers did not finish in time: no figure"}
             del raw
         if not args.no_acquisition:
             result["acquisition"] = acquisition_leg(eng, rf)
