@@ -652,3 +652,47 @@ def test_block_schedule_in_the_library_equals_the_array_formulation():
                                   since0.ctypes.data, 1, out_first.ctypes.data, C.byref(nt), rs.ctypes.data, cs.ctypes.data,
                                   starts.ctypes.data, rsorted.ctypes.data, lastr.ctypes.data, un.ctypes.data, df.ctypes.data,
                                   cc.ctypes.data, last.ctypes.data, br.ctypes.data, bc.ctypes.data, bv.ctypes.data, C.byref(nb)) != 0 or n_ticks <= 1
+
+
+def test_read_ahead_switched_off_while_a_block_is_queued_ahead(tmp_path):
+    """enableReadAhead(0) in the middle of a replay, with the next block already queued on the device: the block being
+    handed out and the queued one are both handed out tick by tick, then the loop is the plain one again -- every packet of
+    every tick equal to the plain loop's; close() with a block queued ahead lets it finish."""
+    g, fs, raw = trajectory_iq("g6b_kaplan_strong.npz")
+    path = tmp_path / "iq.bin"
+    raw.tofile(path)
+    cfg = channel_config(KAPLAN_INI)
+    for k, v in zip(g["track_override_keys"], g["track_override_vals"]):
+        cfg["TRACKING"][str(k)] = repr(float(v))
+
+    def receiver(read_ahead, off_at=None, n_ms=140):
+        sig = RFSignal(dict(filepath=str(path), sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0, data_size=8))
+        eng = OracleEngine()
+        mgr = ChannelManager(sig, engine=eng)
+        mgr.addChannel(ChannelL1CA_Kaplan, cfg, 1)
+        mgr.requestTracking(7)
+        if read_ahead:
+            mgr.enableReadAhead(read_ahead)
+        ticks, queued = [], 0
+        for k in range(n_ms):
+            if k == off_at:
+                assert mgr._ahead is not None                  # (a block is queued ahead at this point)
+                mgr.enableReadAhead(0)
+            mgr.addNewRFData(sig.getMilliseconds(1))
+            ticks.append([dict(p) for p in mgr.run()])
+            queued += mgr._ahead is not None
+        return mgr, eng, ticks, queued
+
+    _, _, plain, _ = receiver(0)
+    mgr, eng, ahead, queued = receiver(20, off_at=50)
+    for k, (a, b) in enumerate(zip(plain, ahead)):
+        for p in a + b:
+            p.pop("correlation_map", None)
+        assert a == b, k
+    assert mgr._ahead is None and 20 < queued < 75             # queued while on; taken over after the switch; none since
+    assert eng.bank_calls["tick"] > 40                         # the plain loop again for the rest
+    mgr.close()
+    mgr2, _, _, _ = receiver(20, n_ms=60)
+    assert mgr2._ahead is not None
+    mgr2.close()                                               # (collects the queued block before the bank goes)
+    assert mgr2._ahead is None
