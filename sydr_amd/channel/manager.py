@@ -208,7 +208,10 @@ class ChannelManager:
         ra.version = getattr(ring, "stateVersion", None)       # (while it stands, the scheduled channels are all there is)
         lists = self._lists
         ra.covers_active = lists is not None and np.array_equal(lists[4], ra.cids64)
-        self._track_ahead(cids, first + k * spt, k, avail - used, states, pending_lost=bank.lost[cids])
+        # (a block whose epochs spill past its own ticks -- a late joiner working off its backlog, one epoch per tick -- is
+        # followed by plain ticks until the next one can start: nothing may be queued on the device behind it)
+        if ra.n_ticks <= k:
+            self._track_ahead(cids, first + k * spt, k, avail - used, states, pending_lost=bank.lost[cids])
         self._accept_prefetched(data)
         return True
 

@@ -1000,12 +1000,14 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
     // Cluster size: as many workgroups per channel as the GPU has room for (1 per CU), up to 8.  When the
     // cooperative launch is refused (GPU shared or partitioned: not every workgroup could be resident) the
     // automatic choice halves the cluster until the launch goes through; a forced size fails instead.
-    // Runs of a few epochs (a receiver tick) are not worth a cooperative launch (+15-19 us on the host).
+    // One epoch (a receiver tick) takes the same cluster as two plain launches (below: a cooperative launch costs the host
+    // +15-19 us); two epochs or more take the cooperative launch -- so that what a channel's epochs add up to does not
+    // depend on how they are batched into steps (a block of 49 + a step of 2 == a block of 51, bit for bit).
     const int forced = r.force_parts ? r.force_parts : e->track_force_parts;
     int parts = 1;
     if (forced) {
         parts = forced;
-    } else if (r.n_epochs > 4) {
+    } else if (r.n_epochs > 1) {
         while (parts < kMaxParts && (long)r.n_ch * parts * 2 <= (long)e->n_cus) parts *= 2;
     }
     if (!r.fault_word) SDR_HIP(hipMemsetAsync(d_fault, 0, 16, ctx->stream));
