@@ -572,3 +572,42 @@ def test_step_in_two_halves_equals_the_step(engine):
     assert list(done_c) == [5, 5] and rec_c["start_sample"][0, 0] == rec_b["start_sample"][0, -1] + rec_b["n_samples"][0, -1]
     b.step_begin([0], 3)
     b.close()                                                    # (a bank destroyed with a step in flight waits for it)
+
+
+def test_mirrored_tick_parks_a_runaway_channel_alone(engine):
+    """A channel whose NCO has run away (carrier beyond any sampling rate) is stopped by the device before its epoch: the
+    mirrored tick reports it in n_lost, sets its `lost` flag, hands out no record for it and never lists it again; the other
+    channels' records are what they are without it; its CHANNEL_UPDATE row stays."""
+    from sydr_amd._lib import TRACK_EPOCH_DTYPE
+    g, fs, raw = trajectory_iq()
+    n = raw.size // 2 // 8 * 8
+    engine.iq_alloc(n, FMT_CI8)
+    engine.iq_upload(raw[:2 * n], 0)
+    engine.code_slots(2)
+    engine.load_gps_code(1, 7)
+    acq = g["kaplan_acq"]
+    st0 = initial_state(1, fs, acq[3], int(acq[5]), KAPLAN_CFG, slot=1)
+    cfg = as_row(loop_cfg(1, fs, KAPLAN_CFG), LOOP_CFG_DTYPE)
+    rows = [as_row(st0, TRACK_STATE_DTYPE) for _ in range(3)]
+    rows[1]["carrier_hz"] = 2e9
+    ref = engine.bank(3)
+    ref.put(0, rows[0], cfg)
+    want = [ref.step([0], 1)[0][0, 0].copy() for _ in range(6)]
+    ref.close()
+    bank = engine.bank(3)
+    states = np.zeros(3, dtype=TRACK_STATE_DTYPE)
+    for ch in range(3):
+        bank.put(ch, rows[ch], cfg)
+        states[ch] = rows[ch]
+    last = np.zeros(3, dtype=TRACK_EPOCH_DTYPE)
+    since, host_flags = np.zeros(3, dtype=np.int64), np.zeros(3, dtype=np.int64)
+    tracking, lost = np.ones(3, dtype=bool), np.zeros(3, dtype=bool)
+    m = bank.bind_mirror(states, last, since, tracking, lost, host_flags)
+    for k in range(6):
+        write = (int(states["current_sample"][[0, 2]].max()) + int(states["n_samples"].max()) + 8) % n
+        bank.tick_mirrored(None, 0, write)
+        assert bank.ran[:m.n_ran].tolist() == [0, 2] and m.n_updates == 3 and m.n_lost == (1 if k == 0 else 0)
+        assert lost.tolist() == [False, True, False] and since.tolist() == [k + 1, 0, k + 1]
+        assert bank.records[0].tobytes() == want[k].tobytes() == bank.records[1].tobytes()
+    assert states["carrier_hz"][1] == 2e9 and last["n_samples"][1] == 0       # (its state as it was put; no record ever)
+    bank.close()
