@@ -1,7 +1,8 @@
 """Soak of the literal per-millisecond loop with read-ahead against the plain loop on the real engine: 32 channels @ 25 MHz
 (the headline geometry), a few seconds of stream, read-ahead blocks of random lengths re-drawn now and then (the next
 block queued on the device while the current one is handed out), late joiners -- every packet of every tick equal to the
-plain loop's, bit for bit (both run an epoch on the cluster of 8 workgroups).  Usage: python tests/stress_readahead.py [ms] [seed]"""
+plain loop's, bit for bit (both run an epoch on the cluster of 8 workgroups).  --general: the plain loop's library-side tick
+against the manager's general tick instead.  Usage: python tests/stress_readahead.py [ms] [seed] [--general]"""
 import configparser, os, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +14,7 @@ from sydr_amd.signal.iqsource import RFSignal
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(n_ms=2000, seed=1, fs=25e6, n_ch=32):
+def run(n_ms=2000, seed=1, fs=25e6, n_ch=32, general=False):
     rng = np.random.default_rng(seed)
     eng = Engine(0)
     spms = int(fs * 1e-3)
@@ -30,9 +31,10 @@ def run(n_ms=2000, seed=1, fs=25e6, n_ch=32):
     late = sorted(int(t) for t in rng.integers(150, n_ms // 2, 6))          # ticks at which one more satellite is requested
     redraw = {int(t): int(b) for t, b in zip(rng.integers(100, n_ms - 100, 8), rng.choice([7, 16, 25, 40, 50], 8))}
 
-    def receiver(read_ahead):
+    def receiver(read_ahead, steady=True):
         rf = RFSignal(dict(filepath=tmp.name, sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0, data_size=8))
         mgr = ChannelManager(rf, engine=eng, keepCorrelationMap=False)
+        mgr.STEADY_TICK = steady
         mgr.addChannel(ChannelL1CA_Kaplan, cfg, n_ch)
         for s in sats[:n_ch - len(late)]:
             mgr.requestTracking(s["prn"])
@@ -54,7 +56,10 @@ def run(n_ms=2000, seed=1, fs=25e6, n_ch=32):
         return ticks, dt, queued
 
     plain, t_plain, _ = receiver(0)
-    ahead, t_ahead, queued = receiver(50)
+    if general:      # the library-side tick (sdr_bank_tick_mirrored) against the manager's general tick instead
+        ahead, t_ahead, queued = receiver(0, steady=False)
+    else:
+        ahead, t_ahead, queued = receiver(50)
     n_pk = 0
     for k, (a, b) in enumerate(zip(plain, ahead)):
         key = lambda p: (p["cid"], p["type"].value)
@@ -72,6 +77,11 @@ def run(n_ms=2000, seed=1, fs=25e6, n_ch=32):
 if __name__ == "__main__":
     n_ms = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    n_pk, t_plain, t_ahead, queued = run(n_ms, seed)
+    general = "--general" in sys.argv
+    n_pk, t_plain, t_ahead, queued = run(n_ms, seed, general=general)
+    if general:
+        print(f"{n_ms} ticks x 32 channels: {n_pk} packets equal bit for bit between the library-side tick ({t_plain:.2f} s) and the "
+              f"manager's general tick ({t_ahead:.2f} s)")
+        sys.exit(0)
     print(f"{n_ms} ticks x 32 channels: {n_pk} packets equal bit for bit between the plain loop ({t_plain:.2f} s incl. materialising) and "
           f"read-ahead ({t_ahead:.2f} s; a block queued ahead during {queued} ticks)")
