@@ -20,6 +20,7 @@ GEOMETRIES = (  # fs, spacing, most periods per epoch, variant bits the plan mus
     (18e6, (-0.5, 0.0, 0.5), 2, 26 + 17 + 256 * 8),             # round 4: the other block lengths (epl_straight.hip) -- 17 / 8 ...
     (22e6, (-1.0, 0.0, 1.0), 2, 26 + 21 + 4096),                # ... 21 with whole-chip taps ...
     (40e6, (-0.5, 0.0, 0.5), 1, 65536 + 26 + 19 + 4096),        # ... 19 on the half-chip view
+    (16.368e6, (-0.5, 0.0, 0.5), 2, 26 + 16),                   # round 4: exactly 16.0 per chip -- block lengths 15 and 16 in one kernel
 )
 
 
