@@ -816,6 +816,9 @@ def main():
     ap.add_argument("--no-ref-config", action="store_true")
     ap.add_argument("--no-rates", action="store_true", help="skip the E/P/L leg over the other sampling rates")
     ap.add_argument("--cpu-mp-seconds", type=float, default=10.0, help="budget of the all-cores CPU baseline (0: skip)")
+    ap.add_argument("--watchdog-seconds", type=float, default=300.0,
+                    help="if the legs AFTER the timed headline measurement have not finished by then, print the line with what "
+                         "there is and exit (0: no watchdog)")
     ap.add_argument("--closed-loop-epochs", type=int, default=2000)
     args = ap.parse_args()
 
@@ -976,6 +979,25 @@ def main():
                           # fp64 vector peak 78.6 TFLOP/s): the kernel is VALU-issue-bound, not HBM-bound
                           "fp64_vector": {"achieved_tflops": flops / avg_kernel_s / 1e12 if launches else 0.0,
                                           "peak_tflops": 78.6, "frac": flops / avg_kernel_s / 78.6e12 if launches else 0.0}}
+    # The line is the contract: everything after this point is additional legs.  Should one of them never return (a stuck
+    # worker process, a device call that does not come back), a watchdog thread prints the line as it stands and ends the
+    # process -- the headline measurement above is complete at this point.
+    if args.watchdog_seconds > 0 and world == 1:
+        import threading
+
+        def _give_up():
+            result["watchdog"] = (f"a leg after the headline measurement had not finished {args.watchdog_seconds:.0f} s on: "
+                                  "the line carries what was measured until then")
+            try:
+                sys.stdout.write(json.dumps(result, default=str) + "\n")
+                sys.stdout.flush()
+            finally:
+                os._exit(0)
+        _watchdog = threading.Timer(args.watchdog_seconds, _give_up)
+        _watchdog.daemon = True
+        _watchdog.start()
+    else:
+        _watchdog = None
     pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
@@ -1072,6 +1094,8 @@ def main():
         m = multignss_workload(margs, rank, local_rank, world, torch, dist, emit=False)
         result["multignss"] = {k: m[k] for k in ("metric", "value", "unit", "ms_per_step", "x_realtime", "config", "roofline",
                                                   "cpu_baseline", "acquisition", "closed_loop") if k in m}
+    if _watchdog is not None:
+        _watchdog.cancel()
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
