@@ -490,7 +490,9 @@ def ref_config_leg(eng, cpu_seconds=4.0):
                                    "E/P/L +-0.5 chip, 20 s stream in one launch per pass; PCPS +-5 kHz @ 300 Hz (34 bins), "
                                    "1 ms x 10 non-coherent (channel_GPS_L1CA_kaplan.ini:6-10), indices + ratio (no map: 32 N bytes per "
                                    "(PRN, bin, block)), code spectra cached between calls"},
-            "tracking": tracking, "acquisition": acquisition}
+            "tracking": tracking, "acquisition": acquisition,
+            # the loops closed on the device at this rate (clusters of 8 workgroups per channel, 8-sample boundary groups)
+            "closed_loop": closed_loop_leg(eng, items, min(n_epochs, 2000), fs=fs)}
 
 
 def per_tick_leg(eng, read_ahead=0):
@@ -501,14 +503,15 @@ def per_tick_leg(eng, read_ahead=0):
     return per_tick_rate.measure(600 if read_ahead else 300, N_CH, engine=eng, read_ahead=read_ahead)
 
 
-def closed_loop_leg(eng, items, n_epochs, n_ch=N_CH):
+def closed_loop_leg(eng, items, n_epochs, n_ch=N_CH, fs=None):
     """On-device loop closure (persistent workgroups, Kaplan loops): latency-bound, so it is reported beside,
     not instead of, the open-loop correlator throughput.  n_ch = 32: each channel on a cluster of 8 CUs (lowest
     latency); n_ch = 768: channels beyond 32 re-track the same 32 satellites, three workgroups per CU (highest
     aggregate channel x real-time rate)."""
     from sydr_amd._lib import LoopCfg, TrackState
+    fs = FS if fs is None else fs
     cfg = LoopCfg()
-    cfg.loop_kind, cfg.n_taps, cfg.fs = 1, 3, FS
+    cfg.loop_kind, cfg.n_taps, cfg.fs = 1, 3, fs
     for t, s in enumerate(SPACING):
         cfg.spacing_wide[t] = cfg.spacing_narrow[t] = s
     wn = 2.0 * 8.0 * 0.7 / (4.0 * 0.7**2 + 1)              # channel_GPS_L1CA_kaplan.ini DLL: 2 Hz, zeta 0.7, gain 1
@@ -521,7 +524,7 @@ def closed_loop_leg(eng, items, n_epochs, n_ch=N_CH):
         st = TrackState()
         st.code_slot, st.n_samples, st.current_sample = int(it["code_slot"]), int(it["n_samples"]), int(it["start_sample"])
         st.carrier_hz, st.code_hz = float(it["carrier_hz"]), CODE_RATE
-        st.rem_carrier, st.rem_code, st.code_step = float(it["rem_carrier"]), float(it["rem_code"]), CODE_RATE / FS
+        st.rem_carrier, st.rem_code, st.code_step = float(it["rem_carrier"]), float(it["rem_code"]), CODE_RATE / fs
         st.fll_bw, st.pll_bw, st.lock_state = 100.0, 25.0, 1
         states.append(st)
     eng.track_closed_loop([TrackState.from_buffer_copy(s) for s in states], cfg, 50, want_traj=False)  # warm
@@ -535,10 +538,10 @@ def closed_loop_leg(eng, items, n_epochs, n_ch=N_CH):
     eng.prof_reset()
     samples = float(np.mean([e.current_sample - s.current_sample for e, s in zip(end, states)]))
     lost = sum(abs(e.carrier_hz - s.carrier_hz) > 100.0 for e, s in zip(end, states))
-    return {"metric": f"closed-loop tracking, {n_ch} channels, loop closure on device (Kaplan FLL/PLL/DLL)",
+    return {"metric": f"closed-loop tracking, {n_ch} channels" + ("" if fs == FS else f" @{fs / 1e6:g} MHz") + ", loop closure on device (Kaplan FLL/PLL/DLL)",
             "epochs": n_epochs, "kernel_ms": kern_ms, "wall_ms": wall * 1e3,
-            "x_realtime": samples / FS / (kern_ms * 1e-3), "Msamples_per_s": samples / (kern_ms * 1e-3) / 1e6,
-            "channel_realtimes": n_ch * samples / FS / (kern_ms * 1e-3),
+            "x_realtime": samples / fs / (kern_ms * 1e-3), "Msamples_per_s": samples / (kern_ms * 1e-3) / 1e6,
+            "channel_realtimes": n_ch * samples / fs / (kern_ms * 1e-3),
             "us_per_epoch": kern_ms * 1e3 / n_epochs, "channels_lost": int(lost)}
 
 
