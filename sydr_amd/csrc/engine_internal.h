@@ -169,7 +169,9 @@ int sdr_set_device(sdr_engine* e);
 // epl_straight.hip: the straight-line E/P/L kernels (ci8, three taps) of the block lengths epl.hip does not instantiate itself;
 // nullptr for a length there is none for.  Arguments: those of epl_kernel (epl_kernel.h).
 const void* sdr_epl_ks_kernel(int km);   // outer taps switching floor(KM / 2).x samples into the block
-const void* sdr_epl_ki_kernel(int km);   // taps whole (half-)chips apart
+const void* sdr_epl_ki_kernel(int km);   // three taps whole (half-)chips apart
+const void* sdr_epl_ki5_kernel(int km);  // five taps whole (half-)chips apart
+const void* sdr_epl_km_kernel(int km);   // three taps, the block length alone compiled in (tap positions at run time)
 
 // pcps_fused.hip: every (PRN, bin) inverse transform of a map-free search at N = 25 000 in one launch; leaves
 // SDR_PCPS_FUSED_RECORDS (value, index) records per transform in `partials` ([transform][record], 16 bytes each).

@@ -147,7 +147,7 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
     if (wpw == 4) {
         if (ki && wide == kChipMax + 24)                     // taps whole (half-)chips apart: configs 4-5
             launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 4, 0, (kOdd ? 1 : 0)>);
-        else if (wide >= kChipMax + 24 && FMT == SDR_FMT_CI8)     // (every epoch with 24 or 25 samples per chip: BOC(1,1) half-chips at 50 MHz)
+        else if (wide == kChipMax + 24 && FMT == SDR_FMT_CI8)     // (every epoch with 24 or 25 samples per chip: BOC(1,1) half-chips at 50 MHz)
             launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 24, 4>);
         else if (wide >= kChipMax && FMT == SDR_FMT_CI8)
             launch(epl_kernel<FMT, NT, (FMT == SDR_FMT_CI8 ? kChipMax : 16), 0, 4>);
@@ -171,7 +171,11 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
         (void)hipLaunchKernel(kernel, dim3(grid), dim3(threads), args, shmem, stream);
     };
     const int km = wide - kChipMax;
-    const void* elsewhere = (ks && km != 24 && km != 19) ? sdr_epl_ks_kernel(km) : (ki && NT == 3 && km != 24 && km != 15) ? sdr_epl_ki_kernel(km) : nullptr;
+    const void* elsewhere = (ks && km != 24 && km != 19)                    ? sdr_epl_ks_kernel(km)
+                            : (ki && NT == 3 && km != 24 && km != 15)       ? sdr_epl_ki_kernel(km)
+                            : (ki && NT == 5 && km != 24)                   ? sdr_epl_ki5_kernel(km)
+                            : (!ks && !ki && FMT == SDR_FMT_CI8 && NT == 3 && km >= 17 && km != 24) ? sdr_epl_km_kernel(km)
+                                                                            : nullptr;
     if (elsewhere)
         launch_by_address(elsewhere);
     else if (ks && ks_of == 9)                               // 19 / 20 samples per chip, the outer taps switching at sample 9 or 10
@@ -385,14 +389,17 @@ static int variant_of(const sdr_engine* e, const ItemRules& r, const double* spa
     if (boundary_ok && e->iq_fmt == SDR_FMT_CI8 && min_step >= sdr::kChipMinCodeStep && max_step <= chip_max_step &&
         !e->epl_no_chip) {
         wide = sdr::kChipMax;
-        if (all_m24 && r.n_taps != 3)                       // (five taps: the 24 / 25 forms alone)
-            wide += 24 + ((all_ki && !e->epl_no_split) ? kVariantKI : 0);
+        const int km5 = m_lo == m_hi && m_lo >= 16 && m_lo <= 25 && r.n_taps == 5 ? m_lo : 0;
+        if (km5 && all_ki && !e->epl_no_split)              // five taps whole (half-)chips apart
+            wide += km5 + kVariantKI;
+        else if (all_m24 && r.n_taps != 3)                  // (other tap counts: the 24 / 25 form with run-time positions alone)
+            wide += 24;
         else if (km_one && all_split && !e->epl_no_split)
             wide += km_one + 256 * (km_one / 2);
         else if (km_one && all_ki && !e->epl_no_split)
             wide += km_one + kVariantKI;
-        else if (all_m24)                                   // block length compiled in, tap positions at run time
-            wide += 24;
+        else if (all_m24 || (km_one >= 17 && !e->epl_no_split))   // block length compiled in, tap positions at run time
+            wide += all_m24 ? 24 : km_one;
         else if (all_m15 && all_ki && r.n_taps == 3 && r.scale == 2.0 && !e->epl_no_split)
             wide += 15 + kVariantKI;
         else if (all_m1516 && !e->epl_no_split)
@@ -637,8 +644,15 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
             for (int i = 0; i < n_items; ++i) {
                 const sdr_epl_item& it = src[i];
                 if (n_taps == 5) {
-                    sdr::chip_setup<5, 24, 0, 1>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs,
-                                                 kWaveThreads, reinterpret_cast<sdr::ChipSetup<5>*>(host_setups.data())[i]);
+                    sdr::ChipSetup<5>& S5 = reinterpret_cast<sdr::ChipSetup<5>*>(host_setups.data())[i];
+                    switch (km) {
+#define SDR_SETUP5_CASE(K) \
+    case K: sdr::chip_setup<5, K, 0, 1>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step, spc, fs, kWaveThreads, S5); break;
+                        SDR_SETUP5_CASE(16) SDR_SETUP5_CASE(17) SDR_SETUP5_CASE(18) SDR_SETUP5_CASE(19) SDR_SETUP5_CASE(20) SDR_SETUP5_CASE(21)
+                        SDR_SETUP5_CASE(22) SDR_SETUP5_CASE(23) SDR_SETUP5_CASE(24) SDR_SETUP5_CASE(25)
+#undef SDR_SETUP5_CASE
+                        default: err = hipErrorInvalidValue; break;
+                    }
                     continue;
                 }
                 sdr::ChipSetup<3>& S = reinterpret_cast<sdr::ChipSetup<3>*>(host_setups.data())[i];
@@ -657,8 +671,15 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
             const int km = (wide & 255) - kChipMax;
             const bool ks = (wide & kVariantKSMask) != 0;
             if (n_taps == 5) {
-                hipLaunchKernelGGL((chip_setup_kernel<5, 24, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items,
-                                   p->d_spacing, fs, e->iq_capacity, reinterpret_cast<sdr::ChipSetup<5>*>(p->d_setups));
+                sdr::ChipSetup<5>* d5 = reinterpret_cast<sdr::ChipSetup<5>*>(p->d_setups);
+                switch (km) {
+#define SDR_SETUP5_CASE(K) \
+    case K: hipLaunchKernelGGL((chip_setup_kernel<5, K, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items, p->d_spacing, fs, e->iq_capacity, d5); break;
+                    SDR_SETUP5_CASE(16) SDR_SETUP5_CASE(17) SDR_SETUP5_CASE(18) SDR_SETUP5_CASE(19) SDR_SETUP5_CASE(20) SDR_SETUP5_CASE(21)
+                    SDR_SETUP5_CASE(22) SDR_SETUP5_CASE(23) SDR_SETUP5_CASE(24) SDR_SETUP5_CASE(25)
+#undef SDR_SETUP5_CASE
+                    default: err = hipErrorInvalidValue; break;
+                }
             } else {
                 sdr::ChipSetup<3>* d3 = reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups);
                 switch (km * 2 + (ks ? 1 : 0)) {

@@ -824,7 +824,8 @@ def test_compile_time_tap_switch_variant_at_20_mhz(engine):
 def test_straight_line_kernels_of_every_block_length(engine, km):
     """The straight-line kernel exists for every block length KM = 16 .. 25 (epl_straight.hip carries the ones epl.hip does
     not): a list at KM.5 samples per chip gets `epl_kernel<.., KM, .., KM / 2>` at +-0.5 chip spacing (plan variant 26 + KM +
-    256 * (KM / 2)) and the whole-chip-tap form at +-1 chip (26 + KM + 4096), on the half-chip view at twice the rate too.
+    256 * (KM / 2)), the whole-chip-tap form at +-1 chip (26 + KM + 4096) -- on the half-chip view at twice the rate too, with
+    three taps and with five -- and the block length alone (26 + KM) at any other spacing.
     Long and short lists (setups by a launch / on the host) against the oracle and the run-time-position kernel, odd epochs
     included (they fall back inside the launch)."""
     rng = np.random.default_rng(7000 + km)
@@ -838,7 +839,10 @@ def test_straight_line_kernels_of_every_block_length(engine, km):
     for s in range(8):
         engine.load_gps_code(s, 3 * s + 2)
     rf = orc.iq_to_complex(raw)
-    for spacing, want in (((-0.5, 0.0, 0.5), 26 + km + 256 * (km // 2)), ((-1.0, 0.0, 1.0), 26 + km + 4096)):
+    # (+-0.25 chip -- a narrow correlator: neither switch position nor whole chips, the block length alone is compiled in;
+    # at 16.x samples per chip that is the two-length kernel's list)
+    for spacing, want in (((-0.5, 0.0, 0.5), 26 + km + 256 * (km // 2)), ((-1.0, 0.0, 1.0), 26 + km + 4096),
+                          ((-0.25, 0.0, 0.25), 26 + km)):
         for n_items in (90, 4200):
             step = (1.023e6 + rng.uniform(-4, 4, n_items)) / fs
             rem_code = rng.uniform(0, step)
@@ -881,16 +885,17 @@ def test_straight_line_kernels_of_every_block_length(engine, km):
     f = rng.uniform(-6000, 6000, n_items)
     rem_carrier = rng.uniform(0, 2 * np.pi, n_items)
     items = make_items(slot, n, start, f, rem_carrier, rem_code, step)
-    plan = engine.epl_plan(items, (-0.5, 0.0, 0.5), fs2)
-    plan.run()
-    got2 = plan.fetch()
-    assert plan.variant == 65536 + 26 + km + 4096, plan.variant
-    plan.close()
-    for k in rng.choice(n_items, 40, replace=False):
-        x = orc.ring_slice(rf, int(start[k]), int(n[k]))
-        ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(3 * int(slot[k]) + 2)), fs2, f[k], rem_carrier[k], rem_code[k], step[k], (-0.5, 0.0, 0.5)))
-        scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 50.0), 2)
-        assert np.max(np.abs(got2[k] - ref) / scale) < 1e-9, (k, step[k], n[k])
+    for spacing in ((-0.5, 0.0, 0.5), (-1.0, -0.5, 0.0, 0.5, 1.0)):        # three taps, and five: VE / E / P / L / VL
+        plan = engine.epl_plan(items, spacing, fs2)
+        plan.run()
+        got2 = plan.fetch()
+        assert plan.variant == 65536 + 26 + km + 4096, (spacing, plan.variant)
+        plan.close()
+        for k in rng.choice(n_items, 40, replace=False):
+            x = orc.ring_slice(rf, int(start[k]), int(n[k]))
+            ref = np.array(orc.epl(x, orc.pad_code(orc.gold_code(3 * int(slot[k]) + 2)), fs2, f[k], rem_carrier[k], rem_code[k], step[k], spacing))
+            scale = np.repeat(np.maximum(np.hypot(ref[0::2], ref[1::2]), np.sqrt(float(n[k])) * 50.0), 2)
+            assert np.max(np.abs(got2[k] - ref) / scale) < 1e-9, (spacing, k, step[k], n[k])
 
 
 def test_two_block_lengths_in_one_kernel_at_16_368_mhz(engine):
