@@ -153,6 +153,11 @@ class ChannelManager:
         if ahead is None:
             room = (ring.maxSize - int(unread.max())) // spt - 1      # milliseconds the ring can take without overwriting
             k = min(self._ra_ms, (rec.size // 2 - first) // spt, room)
+            if any(ch.channelState is ChannelState.IDLE for ch in self.channels.values()):
+                # a channel started later begins reading at ring position 0 (channel.py:93) with everything up to the write
+                # index unread: samples written there ahead of the write index's own wrap would be searched in place of the
+                # stale ones the plain loop still holds -- while a channel is IDLE no block crosses the ring's end
+                k = min(k, (ring.maxSize - ring.idxWrite) // spt)
             if k < 4:
                 return False
             self._flush_pending()

@@ -19,8 +19,9 @@ While a block is handed out the NEXT one is already on the device (`ChannelManag
 its epochs queued with `sdr_bank_step_begin`); the tick that needs it only collects the results -- no tick waits for a
 launch.  It is queued only where the plain loop could not tell the difference: the ring must hold both blocks beside
 what every active channel has not read yet, and while a channel is still IDLE (it would start reading at ring position 0)
-the block queued ahead ends at the ring's end.  (The block being handed out may itself cover ring position 0 ahead of its
-time: a channel STARTED during those ticks searches newer samples than the plain loop's stale ones.)
+no block -- the one handed out or the one queued ahead -- crosses the ring's end, and the one queued ahead does not start
+there either: samples written at ring position 0 before the write index's own wrap would be searched by a channel started
+meanwhile in place of the stale ones the plain loop still holds.
 
 The reference's calls do not change.  What differs while a block is replayed: attributes read from a channel OBJECT
 (carrierFrequency, currentSample, navBits ...) show the state at the END of the block; the packets -- all the

@@ -2,7 +2,8 @@
 (the headline geometry), a few seconds of stream, read-ahead blocks of random lengths re-drawn now and then (the next
 block queued on the device while the current one is handed out), late joiners -- every packet of every tick equal to the
 plain loop's, bit for bit (both run an epoch on the cluster of 8 workgroups).  --general: the plain loop's library-side tick
-against the manager's general tick instead.  Usage: python tests/stress_readahead.py [ms] [seed] [--general]"""
+against the manager's general tick instead.  --steady: every channel
+requested at the start (no late joiners: a block is queued ahead all the time).  Usage: python tests/stress_readahead.py [ms] [seed] [--general] [--steady]"""
 import configparser, os, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +15,7 @@ from sydr_amd.signal.iqsource import RFSignal
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(n_ms=2000, seed=1, fs=25e6, n_ch=32, general=False):
+def run(n_ms=2000, seed=1, fs=25e6, n_ch=32, general=False, steady=False):
     rng = np.random.default_rng(seed)
     eng = Engine(0)
     spms = int(fs * 1e-3)
@@ -28,7 +29,7 @@ def run(n_ms=2000, seed=1, fs=25e6, n_ch=32, general=False):
     eng.iq_download(total, 0).tofile(tmp.name)
     cfg = configparser.ConfigParser()
     cfg.read(os.path.join(REPO, "examples", "channel_GPS_L1CA_kaplan.ini"))
-    late = sorted(int(t) for t in rng.integers(150, n_ms // 2, 6))          # ticks at which one more satellite is requested
+    late = [] if steady else sorted(int(t) for t in rng.integers(150, n_ms // 2, 6))   # ticks at which one more satellite is requested
     redraw = {int(t): int(b) for t, b in zip(rng.integers(100, n_ms - 100, 8), rng.choice([7, 16, 25, 40, 50], 8))}
 
     def receiver(read_ahead, steady=True):
@@ -78,7 +79,7 @@ if __name__ == "__main__":
     n_ms = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     general = "--general" in sys.argv
-    n_pk, t_plain, t_ahead, queued = run(n_ms, seed, general=general)
+    n_pk, t_plain, t_ahead, queued = run(n_ms, seed, general=general, steady="--steady" in sys.argv)
     if general:
         print(f"{n_ms} ticks x 32 channels: {n_pk} packets equal bit for bit between the library-side tick ({t_plain:.2f} s) and the "
               f"manager's general tick ({t_ahead:.2f} s)")
