@@ -24,7 +24,16 @@ GEOMETRIES = (  # fs, spacing, most periods per epoch, variant bits the plan mus
 )
 
 
-def run(rounds, seed, eng=None, n_items=160):
+# every block length of epl_straight.hip in every form (python tests/stress_static.py <rounds> <seed> --all-lengths)
+ALL_LENGTHS = tuple(g for km in range(16, 26) for g in (
+    (1.023e6 * (km + 0.5), (-0.5, 0.0, 0.5), 2, 26 + km + 256 * (km // 2)),
+    (1.023e6 * (km + 0.5), (-1.0, 0.0, 1.0), 2, 26 + km + 4096),
+    (1.023e6 * (km + 0.5), (-0.25, 0.0, 0.25), 2, 26 + km),
+    (2.046e6 * (km + 0.5), (-0.5, 0.0, 0.5), 1, 65536 + 26 + km + 4096),
+    (2.046e6 * (km + 0.5), (-1.0, -0.5, 0.0, 0.5, 1.0), 1, 65536 + 26 + km + 4096)))
+
+
+def run(rounds, seed, eng=None, n_items=160, geometries=None):
     """Returns (channel-epochs checked, worst relative error); raises AssertionError on the first mismatch."""
     rng = np.random.default_rng(seed)
     eng = eng or Engine(0)
@@ -39,7 +48,8 @@ def run(rounds, seed, eng=None, n_items=160):
         eng.load_gps_code(s, p)
     codes = [orc.pad_code(orc.gold_code(p)) for p in prns]
     for r in range(rounds):
-        fs, spacing, per_hi, want = GEOMETRIES[r % len(GEOMETRIES)]
+        geometries = geometries or GEOMETRIES
+        fs, spacing, per_hi, want = geometries[r % len(geometries)]
         # a piece of the ring is rewritten before every launch but the first: the flipped image must follow
         if r:
             lo = int(rng.integers(0, cap - 1000))
@@ -88,5 +98,6 @@ def run(rounds, seed, eng=None, n_items=160):
 
 if __name__ == "__main__":
     t0 = time.time()
-    checked, worst = run(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    checked, worst = run(int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+                         geometries=ALL_LENGTHS if "--all-lengths" in sys.argv else None)
     print(f"{checked} random channel-epochs checked in {time.time() - t0:.1f} s, worst relative error {worst:.2e}")
