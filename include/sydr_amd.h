@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SDR_ABI_VERSION 4   /* 4: + sdr_build_id, sdr_epl_plan_create_dev, sdr_bank_tick_mirrored, sdr_iq_upload_begin, sdr_block_schedule, sdr_bank_step_begin / _end (additive) */
+#define SDR_ABI_VERSION 5   /* 5: + sdr_bank_tick_mirrored_begin / _end (additive); 4: + sdr_build_id, sdr_epl_plan_create_dev, sdr_bank_tick_mirrored, sdr_iq_upload_begin, sdr_block_schedule, sdr_bank_step_begin / _end (additive) */
 
 typedef struct sdr_engine sdr_engine;
 
@@ -403,10 +403,24 @@ typedef struct sdr_tick_mirror {
  * ring's write index AFTER this tick's slab (CircularBuffer.idxWrite). */
 int sdr_bank_tick_mirrored(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
                            int64_t write_index, sdr_tick_mirror* m);
+/* The same tick in two halves, so that ONE host thread drives the banks of several devices the way the reference's
+ * manager drives its channel processes -- start every one, then wait for each (channelManager.py:164-171: eventRun.set()
+ * for all, then eventDone.wait() for all).  _begin decides who is ready and queues their epoch on the engine's stream
+ * (nothing is waited for; the bank's own page-locked block takes the results, so other calls on the engine may come in
+ * between, but none that touches THIS bank: they return SDR_ERR_STATE); _end waits, absorbs the results into the mirrors
+ * and writes the tick's rows.  sdr_bank_tick_mirrored == _begin + _end.  Same `m` in both halves. */
+int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
+                                 int64_t write_index, sdr_tick_mirror* m);
+int sdr_bank_tick_mirrored_end(sdr_engine* e, sdr_bank* b, sdr_tick_mirror* m);
 /* sdr_iq_upload without the wait: the samples are copied out of `iq` before the call returns (the caller may reuse
  * its buffer), their transfer into the ring is queued on the engine's stream and ordered before everything queued
  * there afterwards (slabs above 1 MiB are uploaded synchronously).  sdr_engine_sync completes it for readers on
- * other streams.  Lets addNewRFData start the transfer while the caller is still on its way to run(). */
+ * other streams.  Lets addNewRFData start the transfer while the caller is still on its way to run().  Any number of
+ * slabs may be outstanding: the engine stages them in two page-locked halves and waits, before it overwrites a half, for
+ * the transfer that read it (an event per half) -- a caller that queues a third slab while the first has not reached the
+ * ring blocks in this call until it has; nothing is lost or reordered.  A tick in which no channel was ready
+ * (sdr_bank_tick_mirrored with n_ran == 0 and n_samples == 0) launches nothing and waits for nothing: the slab is then
+ * still in flight when the call returns. */
 int sdr_iq_upload_begin(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset);
 
 /* Host-only helper of a receiver that tracks ahead (no device work): `records[n_ch][n_cols]` hold `done[r]` epochs per channel

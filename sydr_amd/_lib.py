@@ -169,6 +169,8 @@ _PROTOTYPES = {
     "sdr_bank_step_end": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "sdr_bank_tick": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, _VP, C.c_int, _VP, _VP, _VP]),
     "sdr_bank_tick_mirrored": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.POINTER(TickMirror)]),
+    "sdr_bank_tick_mirrored_begin": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int64, C.c_int64, C.POINTER(TickMirror)]),
+    "sdr_bank_tick_mirrored_end": (C.c_int, [_VP, _VP, C.POINTER(TickMirror)]),
     "sdr_iq_upload_begin": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64]),
     "sdr_block_schedule": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, C.c_int64, _VP, _VP, C.c_int] + [_VP] * 15),
     "sdr_stream_create": (C.c_int, [_VP, C.POINTER(C.c_int)]),
@@ -176,7 +178,7 @@ _PROTOTYPES = {
     "sdr_epl_plan_run_range_on": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64, C.c_int]),
     "sdr_epl_plan_variant": (C.c_int, [_VP]),
 }
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 

@@ -9,8 +9,11 @@ advances by one epoch on the device (`sdr_bank_tick`).  Channels still acquiring
 one `sdr_pcps` call.  `runBlock(n)` advances by up to n epochs per channel in one launch (loops closed
 on the device for the whole block).
 
-Multi-GPU (north_star: channels shard across the GPUs of a node, IQ replicated, no collective): give each
-process / device its own manager with `channels=shard_channels(total, rank, world)`.
+Multi-GPU (north_star: channels shard across the GPUs of a node, IQ replicated, no collective):
+`ChannelManager(rfSignal, devices=[0, 1, ..., 7])` is ONE manager over the GPUs of a node in one process (multidevice.py:
+a manager like this one per device behind the same surface, every device's tick begun before any is waited for); a
+job of one process per GPU (bench.py under torch.distributed) gives each rank its own manager and
+`shard_channels(total, rank, world)` of the channels.
 """
 from __future__ import annotations
 
@@ -40,8 +43,18 @@ class ChannelManager:
     STEADY_TICK = True            # all active channels tracking on the device: the tick is one sdr_bank_tick_mirrored call
     PREFETCH = True               # read-ahead: the next block is queued on the device while the current one is handed out
 
-    def __init__(self, rfSignal, engine: Engine | None = None, device_id: int = 0, keepCorrelationMap: bool = True,
-                 ring_ms: int = 100):
+    def __new__(cls, rfSignal=None, *args, devices=None, engines=None, **kwargs):
+        # ChannelManager(rfSignal, devices=[0, 1, ..., 7]) -- ONE manager, as the reference's receiver builds it
+        # (receiver.py:86), over the GPUs of a node: multidevice.py
+        if cls is ChannelManager and (engines is not None or (devices is not None and len(devices) != 1)):
+            from .multidevice import MultiDeviceChannelManager
+            return MultiDeviceChannelManager(rfSignal, *args, devices=devices, engines=engines, **kwargs)
+        return super().__new__(cls)
+
+    def __init__(self, rfSignal, engine: Engine | None = None, device_id: int | None = None, keepCorrelationMap: bool = True,
+                 ring_ms: int = 100, devices=None, engines=None):
+        if devices is not None:
+            device_id = int(devices[0])
         self.rfSignal = rfSignal
         self.channels = {}
         self.nbChannels = 0
@@ -80,6 +93,30 @@ class ChannelManager:
                     ch._ensure_code()
         for _ in range(nbChannels):
             cid = self.nbChannels
+            ch = ChannelObject(cid, self.sharedBuffer, self.resultQueue, self.rfSignal, configuration)
+            ch.codeSlot = cid
+            self.channels[cid] = ch
+            self.nbChannels += 1
+
+    def _addChannelsAt(self, cids, ChannelObject, configuration):
+        """addChannel for a manager that is one DEVICE of a multi-device manager (multidevice.py): the channels get the
+        numbers the whole receiver knows them by; rows of this device's bank and code table that belong to channels of other
+        devices stay empty."""
+        cids = [int(c) for c in cids]
+        if not cids:
+            return
+        need = max(cids) + 1
+        if need > self._slots:
+            self._flush_pending()
+            self._slots = max(32, need)
+            self.engine.code_slots(self._slots)
+            for ch in self.channels.values():
+                if ch.channelState is not ChannelState.IDLE:
+                    ch._stagedPrn = None
+                    ch._ensure_code()
+        for cid in cids:
+            if cid in self.channels:
+                raise ValueError(f"channel {cid} exists already")
             ch = ChannelObject(cid, self.sharedBuffer, self.resultQueue, self.rfSignal, configuration)
             ch.codeSlot = cid
             self.channels[cid] = ch
@@ -342,6 +379,29 @@ class ChannelManager:
     # ------------------------------------------------------------------ the tick
     def run(self):
         """Flat sequence of result packets for this tick (channelManager.py:149-188)."""
+        return self._run_end(self._run_begin())
+
+    def _run_begin(self):
+        """First half of run(): when the tick is the steady one (every active channel tracking on the device), the ready
+        channels' epoch is QUEUED on this manager's device and a token returned; anything else returns None and the whole
+        tick happens in `_run_end`.  A manager of several devices begins every device's tick before it ends any
+        (multidevice.py) -- the reference starts every channel process, then waits for each (channelManager.py:164-171)."""
+        version = getattr(self.sharedBuffer, "stateVersion", None)
+        lists = self._lists
+        if lists is None or lists[0] != (version, self.nbChannels) or not (lists[6] and self.STEADY_TICK):
+            return None
+        bank, ra = self.bank, self._readahead
+        if bank is None or (ra is not None and (ra.bank is not bank or not ra.empty)):
+            return None
+        bank.tick_ready_begin(None, 0)
+        return (TickPackets(), bank, lists[4], lists[5], lists[7])
+
+    def _run_end(self, token):
+        if token is not None:
+            return self._tick_steady_end(*token)
+        return self._run_general()
+
+    def _run_general(self):
         out = TickPackets()
         # who is active / acquiring only changes when a channel changes state: device-tracked channels bump the ring's
         # stateVersion when they do, so a tracking receiver does not walk its channel objects every millisecond
@@ -445,12 +505,22 @@ class ChannelManager:
         """The tick of a receiver whose active channels are all tracking on the device: ONE library call
         (sdr_bank_tick_mirrored, behind the slab addNewRFData queued) decides who is ready, runs their epoch, brings
         the bank's mirror up to date and leaves what the packets report; the packets themselves are made when read."""
-        ran, rec, upd, self._unread_max = bank.tick_ready(None, 0)
-        self._pending = False                                # (the call ended with a synchronisation of the stream)
+        bank.tick_ready_begin(None, 0)
+        return self._tick_steady_end(out, bank, cids_active, states_active, upd_templates)
+
+    def _tick_steady_end(self, out, bank, cids_active, states_active, upd_templates):
+        ran, rec, upd, self._unread_max = bank.tick_ready_end()
+        if len(ran):
+            self._pending = False                            # (an epoch ran: the call ended with a synchronisation of the stream)
+        # (no channel ready: nothing was launched and nothing waited for -- the slab stays "queued, not waited for", and
+        # whoever looks at the ring next flushes it; the library guards its own staging halves with events either way)
+        decoded = ()
         if len(ran):
             out.add_lazy(TrackingRows(ran, bank.kinds, rec))
             if bank.decoded:                                  # subframes completed by this tick's bits (kaplan:71-73)
-                out.add_ready(pkt for _, _, pkt in bank.take_decoded())
+                decoded = [pkt for _, _, pkt in bank.take_decoded()]
+                out.add_ready(decoded)
+        self._steady_rows = (ran, rec, upd, decoded)         # (what a manager of several devices merges into one packet list)
         if len(upd) != len(cids_active):                     # (cannot happen while the lists stand; never guess)
             raise RuntimeError("channel bank and channel manager disagree about the tracking channels")
         out.add_lazy(UpdateRows(cids_active, states_active, upd, bank.tow.copy(), bank.tow_decoded.copy(), None, None,

@@ -30,7 +30,7 @@ class GpuCorrelatorSeams:
         if isinstance(self.rfBuffer, DeviceRing):
             return self.rfBuffer.engine
         from ..runtime import get_engine
-        return get_engine(0)
+        return get_engine()
 
     def _ensure_code(self):
         eng = self._engine()

@@ -315,6 +315,8 @@ void sdr_engine_destroy(sdr_engine* e) {
     for (DevBuf* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (e->slab_pinned) (void)hipHostFree(e->slab_pinned);
+    for (int h = 0; h < 2; ++h)
+        if (e->slab_done[h]) (void)hipEventDestroy(e->slab_done[h]);
     if (e->iq) (void)hipFree(e->iq);
     if (e->iq_flip) (void)hipFree(e->iq_flip);
     if (e->iq_flip_done) (void)hipEventDestroy(e->iq_flip_done);
@@ -488,11 +490,20 @@ int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_
             return sdr_fail(SDR_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", 2 * want, hipGetErrorString(err));
         }
         e->slab_bytes = want;
+        e->slab_busy[0] = e->slab_busy[1] = false;   // (the synchronisation above completed whatever read the old halves)
     }
-    // two halves: the DMA of the previous tick's slab has completed by the time its half is reused (every tick ends
-    // with a synchronisation of this stream, and a bare upload is followed by one before the next)
+    // Two halves, used alternately, each guarded by an event recorded behind the transfer that reads it: a tick normally
+    // ends with a synchronisation of this stream, but a tick in which no channel is ready does not, and a C caller may
+    // queue any number of slabs -- a half is written again only when the transfer out of it has completed (the wait is
+    // free in the common case: the event completed with the tick before last).
     e->slab_flip ^= 1;
-    char* stage = (char*)e->slab_pinned + (e->slab_flip ? e->slab_bytes : 0);
+    const int half = e->slab_flip;
+    if (e->slab_busy[half]) {
+        SDR_HIP(hipEventSynchronize(e->slab_done[half]));
+        e->slab_busy[half] = false;
+    }
+    if (!e->slab_done[half]) SDR_HIP(hipEventCreateWithFlags(&e->slab_done[half], hipEventDisableTiming));
+    char* stage = (char*)e->slab_pinned + (half ? e->slab_bytes : 0);
     memcpy(stage, iq, bytes);
     // A KERNEL pulls the slab out of the page-locked buffer (16 bytes per lane over PCIe) instead of a copy command: the
     // tick's launch follows it on the same queue with nothing but the queue's own ordering in between, where a DMA
@@ -510,8 +521,13 @@ int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_
             hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)stage, (uint4*)e->iq, n16,
                                off_b / 16, cap_b / 16);
             SDR_HIP(hipGetLastError());
+            SDR_HIP(hipEventRecord(e->slab_done[half], e->stream));
+            e->slab_busy[half] = true;
             return SDR_OK;
         }
     }
-    return iq_copy(e, stage, n_samples, ring_offset, true, false);
+    if (int rc = iq_copy(e, stage, n_samples, ring_offset, true, false)) return rc;
+    SDR_HIP(hipEventRecord(e->slab_done[half], e->stream));
+    e->slab_busy[half] = true;
+    return SDR_OK;
 }

@@ -99,6 +99,8 @@ struct sdr_engine {
     void* slab_pinned = nullptr;  // page-locked staging of the slab a receiver tick brings (sdr_bank_tick)
     size_t slab_bytes = 0;        // bytes of ONE of its two halves
     int slab_flip = 0;
+    hipEvent_t slab_done[2] = {nullptr, nullptr};   // recorded behind the transfer that reads a half: a half is reused only
+    bool slab_busy[2] = {false, false};             // after its event has completed (any number of slabs may be outstanding)
     int64_t pcps_tw_n = 0;
     // chirp-z (Bluestein) plan for code lengths the mixed-radix planner cannot factor: [chirp N][B_fwd M][B_inv M][tw M]
     DevBuf pcps_blu, pcps_blu_x, pcps_blu_a, pcps_blu_b;

@@ -1103,6 +1103,13 @@ struct sdr_bank {
     // scratch of sdr_bank_tick_mirrored (kept between ticks: no allocation in the steady state)
     std::vector<int32_t> tick_list, tick_done;
     std::vector<sdr_track_state> tick_states;
+    // a tick between its two halves (sdr_bank_tick_mirrored_begin / _end): one queued launch per tap group
+    BankPending* tick_pending[2] = {nullptr, nullptr};
+    StreamCtx tick_ctx[2];                // their scratch and page-locked blocks, the bank's own: other calls on the engine
+                                          // between the two halves (an upload, a search) cannot move them
+    bool tick_open = false, tick_two = false, tick_slab_queued = false;
+    int tick_groups = 0, tick_group_n[2] = {0, 0}, tick_rc = 0;
+    int64_t tick_write_index = 0;
 };
 
 extern "C" {
@@ -1230,9 +1237,11 @@ void sdr_bank_destroy(sdr_engine* e, sdr_bank* b) {
     }
     if (b->d_states) (void)hipFree(b->d_states);
     if (b->d_cfgs) (void)hipFree(b->d_cfgs);
-    for (DevBuf* d : {&b->async_ctx.traj, &b->async_ctx.bits, &b->async_ctx.xchg})
-        if (d->ptr) (void)hipFree(d->ptr);
-    if (b->async_ctx.pinned) (void)hipHostFree(b->async_ctx.pinned);
+    for (StreamCtx* c : {&b->async_ctx, &b->tick_ctx[0], &b->tick_ctx[1]}) {
+        for (DevBuf* d : {&c->traj, &c->bits, &c->xchg})
+            if (d->ptr) (void)hipFree(d->ptr);
+        if (c->pinned) (void)hipHostFree(c->pinned);
+    }
     sdr_bank_free_pending(b);
     delete b;
 }
@@ -1241,6 +1250,7 @@ int sdr_bank_put(sdr_engine* e, sdr_bank* b, int ch, const sdr_track_state* st, 
     if (int rc = sdr_set_device(e)) return rc;
     if (!b || !st || !cfg) return sdr_fail(SDR_ERR_INVALID, "NULL bank, state or configuration");
     if (ch < 0 || ch >= b->max_channels) return sdr_fail(SDR_ERR_RANGE, "channel %d outside the bank's %d", ch, b->max_channels);
+    if (b->tick_open) return sdr_fail(SDR_ERR_STATE, "a tick of this bank is in flight: sdr_bank_tick_mirrored_end first");
     if (!e->codes) return sdr_fail(SDR_ERR_STATE, "code slots not allocated");
     if (int rc = check_cfg(cfg, ch)) return rc;
     if (int rc = check_state(e, st, ch)) return rc;
@@ -1297,6 +1307,10 @@ struct BankPending {
 static void sdr_bank_free_pending(sdr_bank* b) {
     delete b->pending;
     b->pending = nullptr;
+    for (int g = 0; g < 2; ++g) {
+        delete b->tick_pending[g];
+        b->tick_pending[g] = nullptr;
+    }
 }
 
 // What is left of a step once everything is queued: wait, check, hand the results out of the page-locked block.
@@ -1440,6 +1454,7 @@ int sdr_bank_step(sdr_engine* e, sdr_bank* b, const int32_t* channels, int n_ch,
                   int8_t* nav_bits, int max_bits, int32_t* n_bits, int stream_id) {
     if (int rc = sdr_set_device(e)) return rc;
     if (!b) return sdr_fail(SDR_ERR_INVALID, "bank is NULL");
+    if (b->tick_open) return sdr_fail(SDR_ERR_STATE, "a tick of this bank is in flight: sdr_bank_tick_mirrored_end first");
     StreamCtx* ctx = sdr_stream_ctx(e, stream_id);
     if (!ctx) return sdr_fail(SDR_ERR_INVALID, "stream id %d does not exist", stream_id);
     return bank_run(e, b, ctx, channels, n_ch, n_epochs, records, states_out, epochs_done, nav_bits, max_bits, n_bits);
@@ -1451,6 +1466,7 @@ int sdr_bank_step(sdr_engine* e, sdr_bank* b, const int32_t* channels, int n_ch,
 int sdr_bank_step_begin(sdr_engine* e, sdr_bank* b, const int32_t* channels, int n_ch, int n_epochs) {
     if (int rc = sdr_set_device(e)) return rc;
     if (!b) return sdr_fail(SDR_ERR_INVALID, "bank is NULL");
+    if (b->tick_open) return sdr_fail(SDR_ERR_STATE, "a tick of this bank is in flight: sdr_bank_tick_mirrored_end first");
     if (!b->pending) b->pending = new BankPending();
     if (b->pending->active) return sdr_fail(SDR_ERR_STATE, "a step of this bank is already in flight: sdr_bank_step_end first");
     b->async_ctx.stream = e->ctx0.stream;
@@ -1469,6 +1485,7 @@ int sdr_bank_tick(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples,
                   int32_t* epochs_done) {
     if (int rc = sdr_set_device(e)) return rc;
     if (!b) return sdr_fail(SDR_ERR_INVALID, "bank is NULL");
+    if (b->tick_open) return sdr_fail(SDR_ERR_STATE, "a tick of this bank is in flight: sdr_bank_tick_mirrored_end first");
     if (n_samples > 0)
         if (int rc = sdr_iq_upload_async(e, iq, n_samples, ring_offset)) return rc;
     if (n_ch == 0) {
@@ -1481,10 +1498,14 @@ int sdr_bank_tick(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples,
 
 // The tick with its bookkeeping here instead of in the caller's language: which channels are ready (channel.py:137-146
 // -- the ring holds their next epoch completely), their epoch, and the caller's mirrors brought up to date in place.
-int sdr_bank_tick_mirrored(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
-                           int64_t write_index, sdr_tick_mirror* m) {
+// In two halves so that ONE host thread can drive several devices (channelManager.py:149-188 starts every channel
+// before it waits for any): _begin decides who is ready and queues their epoch -- nothing is waited for -- and _end waits,
+// absorbs the results into the mirrors and writes the tick's update rows.  sdr_bank_tick_mirrored is the two in a row.
+int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
+                                 int64_t write_index, sdr_tick_mirror* m) {
     if (int rc = sdr_set_device(e)) return rc;
     if (!b) return sdr_fail(SDR_ERR_INVALID, "bank is NULL");
+    if (b->tick_open) return sdr_fail(SDR_ERR_STATE, "a tick of this bank is already in flight: sdr_bank_tick_mirrored_end first");
     if (!m || !m->states || !m->last || !m->tracking || !m->lost || !m->ran || !m->records || !m->updates)
         return sdr_fail(SDR_ERR_INVALID, "tick mirror: a required array is NULL");
     if (m->max_channels != b->max_channels)
@@ -1512,12 +1533,18 @@ int sdr_bank_tick_mirrored(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n
         if (taps_seen[0] == 0 || taps_seen[0] == nt) taps_seen[0] = nt;
         else taps_seen[1] = nt;
     }
-    if (list.empty()) {
-        if (n_samples > 0) SDR_HIP(hipStreamSynchronize(e->ctx0.stream));
-    } else {
-        const int n = (int)list.size();
+    b->tick_write_index = write_index;
+    b->tick_slab_queued = n_samples > 0;
+    b->tick_rc = SDR_OK;
+    b->tick_groups = 0;
+    b->tick_two = taps_seen[1] != 0;
+    if (!list.empty()) {
+        int n = (int)list.size();
         b->tick_states.resize((size_t)n);
         b->tick_done.resize((size_t)n);
+        if (!b->tick_pending[0]) b->tick_pending[0] = new BankPending();
+        if (b->tick_two && !b->tick_pending[1]) b->tick_pending[1] = new BankPending();
+        b->tick_ctx[0].stream = b->tick_ctx[1].stream = e->ctx0.stream;      // (the engine's stream, the bank's scratch)
         int at = 0;
         for (int g = 0; g < 2 && taps_seen[g]; ++g) {
             // (stable partition: the group's channels to the front of the remaining range, ascending)
@@ -1527,12 +1554,54 @@ int sdr_bank_tick_mirrored(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n
                                                   [&](int32_t ch) { return b->n_taps[ch] == taps_seen[g]; }) -
                             (list.begin() + at));
             }
-            if (int rc = bank_run(e, b, &e->ctx0, list.data() + at, n_g, 1, m->records + at, b->tick_states.data() + at,
-                                  b->tick_done.data() + at, nullptr, 0, nullptr))
-                return rc;
+            if (int rc = bank_run(e, b, &b->tick_ctx[g], list.data() + at, n_g, 1, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                                  b->tick_pending[g])) {
+                // a group queued before this one WILL advance its channels on the device: its results are absorbed by _end
+                // (the caller's mirrors must keep matching the bank), which then returns the error
+                if (at == 0) return rc;
+                b->tick_rc = rc;
+                list.resize((size_t)at);
+                break;
+            }
+            b->tick_group_n[g] = n_g;
+            b->tick_groups = g + 1;
             at += n_g;
         }
-        if (taps_seen[1]) {   // back to ascending channel order, records and states with them
+    }
+    b->tick_open = true;
+    return SDR_OK;
+}
+
+int sdr_bank_tick_mirrored_end(sdr_engine* e, sdr_bank* b, sdr_tick_mirror* m) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!b) return sdr_fail(SDR_ERR_INVALID, "bank is NULL");
+    if (!b->tick_open) return sdr_fail(SDR_ERR_STATE, "no tick of this bank is in flight");
+    if (!m || !m->states || !m->last || !m->tracking || !m->lost || !m->ran || !m->records || !m->updates || m->max_channels != b->max_channels)
+        return sdr_fail(SDR_ERR_INVALID, "tick mirror: not the one the tick was begun with");
+    b->tick_open = false;
+    const int64_t cap = e->iq_capacity, write_index = b->tick_write_index;
+    auto unread_of = [&](int ch) {
+        int64_t cur = m->states[ch].current_sample % cap;
+        if (cur < 0) cur += cap;
+        return cur <= write_index ? write_index - cur : cap - cur + write_index;
+    };
+    std::vector<int32_t>& list = b->tick_list;
+    int run_rc = b->tick_rc;
+    if (list.empty()) {
+        if (b->tick_slab_queued) SDR_HIP(hipStreamSynchronize(e->ctx0.stream));
+    } else {
+        int n = (int)list.size();
+        int at = 0;
+        for (int g = 0; g < b->tick_groups; ++g) {
+            const int n_g = b->tick_group_n[g];
+            if (int rc = bank_collect(*b->tick_pending[g], m->records + at, b->tick_states.data() + at, b->tick_done.data() + at, nullptr,
+                                      nullptr)) {
+                if (b->tick_pending[1]) b->tick_pending[1]->active = false;
+                return rc;      // (a cluster that never published: the device's state is unknown, nothing to absorb)
+            }
+            at += n_g;
+        }
+        if (b->tick_two) {   // back to ascending channel order, records and states with them
             std::vector<int> order((size_t)n);
             for (int i = 0; i < n; ++i) order[(size_t)i] = i;
             std::sort(order.begin(), order.end(), [&](int x, int y) { return list[(size_t)x] < list[(size_t)y]; });
@@ -1578,7 +1647,13 @@ int sdr_bank_tick_mirrored(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n
     }
     m->n_updates = nu;
     m->max_unread = max_unread;
-    return SDR_OK;
+    return run_rc;
+}
+
+int sdr_bank_tick_mirrored(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
+                           int64_t write_index, sdr_tick_mirror* m) {
+    if (int rc = sdr_bank_tick_mirrored_begin(e, b, iq, n_samples, ring_offset, write_index, m)) return rc;
+    return sdr_bank_tick_mirrored_end(e, b, m);
 }
 
 int sdr_iq_upload_begin(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset) {

@@ -18,7 +18,7 @@ def PCPS(rfData, interFrequency, samplingFrequency, codeFFT, dopplerRange, doppl
     codeFFT = np.asarray(codeFFT, dtype=np.complex128).reshape(1, -1)
     if codeFFT.shape[1] != samplesPerCode:
         raise ValueError("codeFFT length must equal samplesPerCode")
-    eng = get_engine(0)
+    eng = get_engine()
     cap = (need + 7) // 8 * 8
     if eng.iq_fmt != FMT_CF64 or eng.iq_capacity < cap:
         eng.iq_alloc(cap, FMT_CF64)
@@ -33,7 +33,7 @@ def TwoCorrelationPeakComparison(correlationMap, samplesPerCode, samplesPerCodeC
     cmap = np.atleast_2d(np.asarray(correlationMap, dtype=np.float64))
     if cmap.shape[1] != samplesPerCode:
         raise ValueError("correlationMap row length must equal samplesPerCode")
-    return get_engine(0).two_peak_compare(cmap, int(samplesPerCodeChip))
+    return get_engine().two_peak_compare(cmap, int(samplesPerCodeChip))
 
 
 def SerialSearch(rfdata, code, dopplerRange, dopplerStep, samplingFrequency, samplesPerCode):
@@ -42,7 +42,7 @@ def SerialSearch(rfdata, code, dopplerRange, dopplerStep, samplingFrequency, sam
     if rf.size < samplesPerCode:
         raise ValueError(f"SerialSearch needs {samplesPerCode} samples, got {rf.size}")
     chips = np.asarray(code)
-    eng = get_engine(0)
+    eng = get_engine()
     if getattr(eng, "n_slots", 0) < 4:
         eng.code_slots(4, 4092)
     eng.set_code(3, chips.astype(np.int8))
@@ -57,4 +57,4 @@ def SerialSearch(rfdata, code, dopplerRange, dopplerStep, samplingFrequency, sam
 
 def TwoCorrelationPeakComparison_SS(correlationMap):
     """([bin, chip], ratio) of acquisition.py:159-193 (3x3 exclusion block, Python slice semantics), on the GPU."""
-    return get_engine(0).two_peak_compare_ss(np.atleast_2d(np.asarray(correlationMap, dtype=np.float64)))
+    return get_engine().two_peak_compare_ss(np.atleast_2d(np.asarray(correlationMap, dtype=np.float64)))

@@ -25,7 +25,7 @@ def EPL(rfData, code, samplingFrequency, carrierFrequency, remainingCarrier, rem
     rf = np.squeeze(np.asarray(rfData, dtype=np.complex128))
     n = rf.size
     chips = np.asarray(code)[1:-1]
-    eng = get_engine(0)
+    eng = get_engine()
     if getattr(eng, "n_slots", 0) < 4:
         eng.code_slots(4, 4092)
     eng.set_code(2, chips.astype(np.int8))

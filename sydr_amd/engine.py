@@ -121,7 +121,8 @@ class Bank:
     def step_end(self):
         """-> (records[n][n_epochs], states[n], epochs_done[n]) of the step `step_begin` queued."""
         if getattr(self, "_in_flight", None) is None:
-            check(self._lib.sdr_bank_step_end(self._e._h, self._h, None, None, None))      # (the library says what is wrong)
+            # (never ask the library: a step begun through another wrapper would be collected into nothing and discarded)
+            raise RuntimeError("step_end(): no step of this bank was begun through this object (step_begin first)")
         n, n_epochs = self._in_flight
         self._in_flight = None
         rec = np.empty((n, n_epochs), dtype=TRACK_EPOCH_DTYPE)
@@ -179,6 +180,26 @@ class Bank:
             raw = self._e._ring_samples(raw)
             status = self._lib.sdr_bank_tick_mirrored(self._e._h, self._h, ptr(raw), raw.size // 2, ring_offset, write_index,
                                                       self._mirror_ref)
+        if status:
+            check(status)
+        return self._mirror
+
+    def tick_mirrored_begin(self, raw, ring_offset: int, write_index: int):
+        """First half of `tick_mirrored` (sdr_bank_tick_mirrored_begin): who is ready is decided and their epoch queued on
+        the engine's stream; nothing is waited for.  A manager of several devices begins every device's tick, then ends
+        each."""
+        if raw is None:
+            status = self._lib.sdr_bank_tick_mirrored_begin(*self._tick_no_slab, ring_offset, write_index, self._mirror_ref)
+        else:
+            raw = self._e._ring_samples(raw)
+            status = self._lib.sdr_bank_tick_mirrored_begin(self._e._h, self._h, ptr(raw), raw.size // 2, ring_offset, write_index,
+                                                            self._mirror_ref)
+        if status:
+            check(status)
+
+    def tick_mirrored_end(self):
+        """Second half: wait, mirrors and per-tick rows updated in place.  -> the bound sdr_tick_mirror."""
+        status = self._lib.sdr_bank_tick_mirrored_end(self._e._h, self._h, self._mirror_ref)
         if status:
             check(status)
         return self._mirror

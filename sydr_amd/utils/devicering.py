@@ -21,7 +21,7 @@ class CircularBuffer:
             raise ValueError("device ring size must be a multiple of 8 samples")
         if engine is None:
             from ..runtime import get_engine
-            engine = get_engine(0)
+            engine = get_engine()
         self.engine = engine
         self.maxSize = int(size)
         self.dtype = dtype

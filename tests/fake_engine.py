@@ -273,6 +273,17 @@ def _step_end(self):
     return out
 
 
+def _tick_mirrored_begin(self, raw, ring_offset, write_index):
+    self._tick_args = (raw, ring_offset, write_index)         # (nothing runs beside the host here)
+
+
+def _tick_mirrored_end(self):
+    args, self._tick_args = self._tick_args, None
+    return _tick_mirrored(self, *args)
+
+
+OracleBank.tick_mirrored_begin = _tick_mirrored_begin
+OracleBank.tick_mirrored_end = _tick_mirrored_end
 OracleBank.step_begin = _step_begin
 OracleBank.step_end = _step_end
 OracleBank.bind_mirror = _bind_mirror

@@ -558,7 +558,7 @@ def test_step_in_two_halves_equals_the_step(engine):
     tick_a = a.tick(None, 0, np.array([3], dtype=np.int32))
     a.close()
     b = fresh()
-    with pytest.raises(SdrError, match="no step"):
+    with pytest.raises(RuntimeError, match="no step"):
         b.step_end()
     b.step_begin([0, 2], 30)
     with pytest.raises(SdrError, match="already in flight"):
@@ -611,3 +611,81 @@ def test_mirrored_tick_parks_a_runaway_channel_alone(engine):
         assert bank.records[0].tobytes() == want[k].tobytes() == bank.records[1].tobytes()
     assert states["carrier_hz"][1] == 2e9 and last["n_samples"][1] == 0       # (its state as it was put; no record ever)
     bank.close()
+
+
+@pytest.mark.parametrize("n_ch, forced_cluster", [(64, 1), (32, 0)])
+def test_one_manager_over_two_devices_equals_the_single_device_manager(engine, n_ch, forced_cluster):
+    """ChannelManager(rfSignal, engines=[a, b]) -- ONE manager over two devices in one process (two engines on this
+    box's one card) -- against the single-device manager of the same channels on the same stream, 300 ticks at 10 MHz
+    from acquisition on: every packet of every tick equal BIT FOR BIT and in the same order, channel attributes too.
+    64 channels: a channel's partial sums are added in the order its cluster size gives, and a launch of 64 channels
+    picks clusters of 4 where one of 32 picks 8, so the cluster size is pinned (1) on all three engines; 32 channels
+    (16 + 16 against 32) take clusters of 8 either way and need no pinning.  Every device's tick is begun before any
+    is ended."""
+    import configparser
+    import os
+    from conftest import REPO
+    from sydr_amd.channel.l1ca_kaplan import ChannelL1CA_Kaplan
+    from sydr_amd.channel.manager import ChannelManager
+    from sydr_amd.channel.multidevice import MultiDeviceChannelManager
+    from sydr_amd.signal.iqsource import RFSignal
+    from sydr_amd.utils.enumerations import ChannelMessage, ChannelState
+    fs, n_ms = 10e6, 300
+    spms = int(fs * 1e-3)
+    rng = np.random.default_rng(8080 + n_ch)
+    sats = [dict(prn=1 + c, doppler=float(250.0 * rng.integers(-15, 16) + rng.uniform(-40, 40)),
+                 code_phase=float(rng.uniform(0, 1023)), phase=float(rng.uniform(0, 1)), amp=3.0) for c in range(n_ch)]
+    total = n_ms * spms
+    engine.iq_alloc(total, FMT_CI8)
+    engine.code_slots(n_ch)
+    engine.iq_synth(sats, fs, 10.0, 8081, 0, total)
+    raw = engine.iq_download(total, 0)
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(REPO, "examples", "channel_GPS_L1CA_kaplan.ini"))
+    half = n_ch // 2
+
+    def receiver(engines):
+        rf = RFSignal(dict(filepath="none", sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0, data_size=8))
+        for e in engines:
+            e.track_cluster(forced_cluster)
+        if len(engines) == 1:
+            mgr = ChannelManager(rf, engine=engines[0], keepCorrelationMap=False)
+            order = list(range(n_ch))
+        else:
+            mgr = ChannelManager(rf, engines=engines, keepCorrelationMap=False)
+            assert isinstance(mgr, MultiDeviceChannelManager)
+            # devices fill round-robin (request k lands on device k % 2, channel k // 2 + half * (k % 2)): asking for the
+            # satellites in that order gives every satellite the channel number the single manager gives it
+            order = [k // 2 + half * (k % 2) for k in range(n_ch)]
+        mgr.addChannel(ChannelL1CA_Kaplan, cfg, n_ch)
+        for c in order:
+            ch = mgr.requestTracking(sats[c]["prn"])
+            assert ch.channelID == c
+        ticks = []
+        try:
+            for k in range(n_ms):
+                mgr.addNewRFData(raw[2 * k * spms:2 * (k + 1) * spms])
+                ticks.append([dict(q) for q in mgr.run()])
+            attrs = [(c, ch.channelState, ch.carrierFrequency, ch.codeFrequency, ch.currentSample, ch.codeSinceTOW, int(ch.trackFlags),
+                      len(ch.navBits)) for c, ch in sorted(mgr.channels.items())]
+            if len(engines) > 1:
+                assert [mgr.deviceOf(c) for c in range(n_ch)] == [0] * half + [1] * half
+                assert [sum(ch.channelState is ChannelState.TRACKING for ch in p.channels.values()) for p in mgr.parts] == [half, half]
+        finally:
+            mgr.close()
+            for e in engines:
+                e.track_cluster(0)
+        return ticks, attrs
+
+    one, attrs_1 = receiver([engine])
+    a, b = Engine(0), Engine(0)
+    try:
+        two, attrs_2 = receiver([a, b])
+    finally:
+        a.close()
+        b.close()
+    assert sum(p["type"] is ChannelMessage.TRACKING_UPDATE for t in two for p in t) > n_ch * 250
+    for k, (x, y) in enumerate(zip(one, two)):
+        assert x == y, k
+    assert attrs_1 == attrs_2
+    assert all(st is ChannelState.TRACKING for _, st, *_ in attrs_2)

@@ -37,3 +37,33 @@ def test_rank_rehearsal_reports_one_self_verified_job(world):
     assert sorted({c[0] for c in m["channels_recomputed_on_rank0"]}) == list(range(1, world))
     assert len(m["per_rank_ms_per_step"]) == world and min(m["per_rank_Msamples_per_s"]) > 0
     assert m["distinct_devices"] == 1 and len({d["pid"] for d in m["devices"]}) == world     # (a rehearsal: one card, `world` processes)
+
+
+def test_gpus_2_without_a_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` started as the driver starts N = 1 (no torchrun): the process becomes the launcher, two
+    fresh ranks run the job and rank 0's line reports two GPUs -- never an `n_gpus: 1` line for a `--gpus 2` command."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SYDR_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--stream-seconds", "2.5"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["multi_gpu"]["ranks_seen"] == 2 and r["multi_gpu"]["bitwise_identical"] is True
+    assert r["config"]["channels_total"] == 64
+
+
+def test_more_ranks_than_devices_is_an_error_outside_rehearsal():
+    """Two ranks on a one-GPU box without SYDR_BENCH_REHEARSE: every rank refuses (no two ranks on one device, no CPU
+    path) and the launcher's exit code is non-zero; nothing is printed as a result line."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                              "SYDR_BENCH_REHEARSE")}
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--stream-seconds", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert "needs 2 MI355X" in out.stderr

@@ -190,11 +190,11 @@ def test_pending_slab_is_owned_and_survives_a_failed_tick():
     def failing(*a, **k):
         raise boom
     bank = mgr.bank
-    real = (mgr._acquire, bank.tick, bank.tick_ready)
-    mgr._acquire = bank.tick = bank.tick_ready = failing       # (whichever this tick needs)
+    real = (mgr._acquire, bank.tick, bank.tick_ready_begin)
+    mgr._acquire = bank.tick = bank.tick_ready_begin = failing       # (whichever this tick needs)
     with pytest.raises(RuntimeError):
         mgr.run()
-    mgr._acquire, bank.tick, bank.tick_ready = real
+    mgr._acquire, bank.tick, bank.tick_ready_begin = real
     assert np.array_equal(eng.iq_download(spms, spms), second)
     # a second slab without a run() in between waits for the first one's transfer (the staging buffer is re-used)
     synced = []
@@ -696,3 +696,78 @@ def test_read_ahead_switched_off_while_a_block_is_queued_ahead(tmp_path):
     assert mgr2._ahead is not None
     mgr2.close()                                               # (collects the queued block before the bank goes)
     assert mgr2._ahead is None
+
+
+def test_one_manager_over_several_devices_equals_the_single_device_manager():
+    """ChannelManager(rfSignal, engines=[...]) -- ONE manager over several devices in one process (multidevice.py; the
+    reference builds one manager, receiver.py:86) -- against the single-device manager on the same stream: the same
+    channel numbers, the same packets in the same order tick for tick (acquisition, Kaplan lock states, a decoder's
+    subframe events), the channels dealt out in shard_channels order and filled round-robin, every device given every slab,
+    and every device's tick BEGUN before any is ended."""
+    from test_decoding import RecordingDecoder
+    from sydr_amd.channel.multidevice import MultiDeviceChannelManager
+    g, fs, raw = trajectory_iq("g6b_kaplan_strong.npz")
+    cfg = channel_config(KAPLAN_INI)
+    for k, v in zip(g["track_override_keys"], g["track_override_vals"]):
+        cfg["TRACKING"][str(k)] = repr(float(v))
+    spms = int(fs * 1e-3)
+    order = []
+
+    def receiver(n_dev, n_ms=330):
+        engines = [OracleEngine() for _ in range(n_dev)]
+        mgr = ChannelManager(rf_signal(fs), engines=engines) if n_dev > 1 else ChannelManager(rf_signal(fs), engine=engines[0])
+        assert isinstance(mgr, MultiDeviceChannelManager) == (n_dev > 1)
+        mgr.addChannel(ChannelL1CA_Kaplan, cfg, 5)           # 5 channels over 3 devices: [0, 1] [2, 3] [4]
+        mgr.addChannel(ChannelL1CA_Kaplan, cfg, 1)           # a later pool of one: channel 5 on device 0
+        chans = [mgr.requestTracking(7)]
+        chans[0].setDecoding(RecordingDecoder(every=2))
+        ticks = []
+        for k in range(n_ms):
+            if k == 40:
+                chans.append(mgr.requestTracking(7))         # a late joiner (same satellite: the stream carries one)
+            if k == 45:
+                chans.append(mgr.requestTracking(7))
+            mgr.addNewRFData(raw[2 * k * spms:2 * (k + 1) * spms])
+            ticks.append([dict(x) for x in mgr.run()])
+        for t in ticks:
+            for x in t:
+                x.pop("correlation_map", None)
+        ends = [(ch.channelID, ch.carrierFrequency, ch.codeFrequency, ch.currentSample, ch.codeSinceTOW, int(ch.trackFlags),
+                 list(ch.navBits)) for ch in chans]
+        return mgr, ticks, ends, engines
+
+    one, ticks_1, ends_1, _ = receiver(1)
+    many, ticks_n, ends_n, engines = receiver(3)
+    assert [many.deviceOf(c) for c in range(6)] == [0, 0, 1, 1, 2, 0]
+    # round-robin fill: the first satellite on device 0 (channel 0), the second on device 1 (channel 2), the third on 2 (4)
+    assert [e[0] for e in ends_n] == [0, 2, 4] and [e[0] for e in ends_1] == [0, 1, 2]
+    # same packets tick for tick once the channel numbers are mapped (a single manager fills 0, 1, 2)
+    remap = {0: 0, 1: 2, 2: 4}
+    for k, (a, b) in enumerate(zip(ticks_1, ticks_n)):
+        a = sorted(({**x, "cid": remap[x["cid"]]} for x in a), key=lambda x: (x["type"].value, x["cid"]))
+        assert a == sorted(b, key=lambda x: (x["type"].value, x["cid"])), k
+        kinds = [x["type"] for x in b]                        # merged order: by kind, by channel within a kind
+        rank = {ChannelMessage.ACQUISITION_UPDATE: 0, ChannelMessage.TRACKING_UPDATE: 1, ChannelMessage.DECODING_UPDATE: 2,
+                ChannelMessage.CHANNEL_UPDATE: 3}
+        assert [(rank[x["type"]], x["cid"]) for x in b] == sorted((rank[x["type"]], x["cid"]) for x in b), k
+    assert [e[1:] for e in ends_1] == [e[1:] for e in ends_n]
+    assert sum(x["type"] is ChannelMessage.DECODING_UPDATE for t in ticks_n for x in t) >= 2
+    assert sum(x["type"] is ChannelMessage.TRACKING_UPDATE for t in ticks_n for x in t) > 800
+    # every device holds the whole stream at the same ring positions
+    for eng in engines[1:]:
+        assert np.array_equal(eng.iq_download(8 * spms, 0), engines[0].iq_download(8 * spms, 0))
+    assert many.parts[1].sharedBuffer.idxWrite == many.parts[0].sharedBuffer.idxWrite == one.sharedBuffer.idxWrite
+
+    # begin on every device before end on any (channelManager.py:164-171: eventRun.set() for all, then eventDone.wait())
+    for d, part in enumerate(many.parts):
+        dev = part.bank.device
+        dev.tick_mirrored_begin = (lambda *a, _f=dev.tick_mirrored_begin, _d=d: (order.append(("begin", _d)), _f(*a))[1])
+        dev.tick_mirrored_end = (lambda *a, _f=dev.tick_mirrored_end, _d=d: (order.append(("end", _d)), _f(*a))[1])
+    k = 330
+    many.addNewRFData(raw[2 * k * spms:2 * (k + 1) * spms])
+    many.run()
+    assert order == [("begin", 0), ("begin", 1), ("begin", 2), ("end", 0), ("end", 1), ("end", 2)]
+    many.close()
+    one.close()
+    with pytest.raises(ValueError):
+        ChannelManager(rf_signal(fs), devices=[])
