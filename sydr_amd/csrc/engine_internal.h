@@ -92,6 +92,8 @@ struct sdr_engine {
     // workspaces
     DevBuf ws_items, ws_out, ws_spacing, ws_setups, ws_stats;
     DevBuf pcps_fwd, pcps_a, pcps_b, pcps_code, pcps_tw, pcps_map, pcps_csum, pcps_part, pcps_res;
+    DevBuf pcps_code2;            // N = 50 000, fused search: [prn][parity][N] -- the spectra and their image with the odd half's twiddle (pcps_fused.h)
+    bool pcps_code2_ok = false;   // ... made from what pcps_code holds now
     DevBuf track_state, track_cfg;
     int n_cus = 0;              // compute units of the device (sizes the closed-loop clusters)
     int track_force_parts = 0;  // diagnostics / tests: 0 = choose, else 1, 2, 4 or 8 workgroups per channel
@@ -177,11 +179,12 @@ const void* sdr_epl_km_kernel(int km);   // three taps, the block length alone c
 
 // pcps_fused.hip: every (PRN, bin) inverse transform of a map-free search at N = 25 000 in one launch; leaves
 // SDR_PCPS_FUSED_RECORDS (value, index) records per transform in `partials` ([transform][record], 16 bytes each).
+// N = 50 000 (terms = 2): a unit is one parity of a transform -- twice the records -- and C is the [prn][parity][N] image.
 #define SDR_PCPS_FUSED_RECORDS 8
 int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int nbins, int N, void* partials);
 // records per PRN that sweep leaves (PRN-major: [prn][records]); a search that is not a whole number of rounds of its 256
 // workgroups has its last transforms cut into five units of SDR_PCPS_FUSED_RECORDS records each
-int sdr_pcps_fused_records_per_prn(int n_prn, int nbins);
+int sdr_pcps_fused_records_per_prn(int n_prn, int nbins, int terms);
 // pcps_fused10k.h: a search at N = 10 000 that wants indices and ratio only (coh = 1, any number of non-coherent blocks): one
 // workgroup per (PRN, bin) keeps the transform in its LDS and the non-coherent sum in registers; F_all = [noncoh][nbins][N]
 // forward spectra, records = n_prn * nbins * SDR_PCPS_FUSED10K_RECORD_BYTES bytes of scratch; the results go to out_*.

@@ -294,6 +294,22 @@ __global__ __launch_bounds__(kThreads) void twiddle_kernel(double2* tw, int N) {
     tw[m] = make_double2(c, -s);
 }
 
+// The two operand images of a PRN's code spectrum for the fused search at N = 2 M = 50 000 (pcps_fused.h): parity 0 is the
+// spectrum itself, parity 1 carries the twiddle of the odd half of the radix-2 decimation-in-frequency step,
+//     C1[k] = C[k] w^-k,  C1[k + M] = -C[k + M] w^-k,  w = exp(-2 pi i / N)   (tw[k] = w^k: multiplied conjugated).
+__global__ __launch_bounds__(kThreads) void code_parity_kernel(const double2* __restrict__ C, const double2* __restrict__ tw, int N,
+                                                               double2* __restrict__ out) {
+    const int k = blockIdx.x * kThreads + threadIdx.x, prn = blockIdx.y;
+    if (k >= N) return;
+    const int M = N / 2;
+    const double2 c = C[(size_t)prn * N + k];
+    const double2 w = tw[k < M ? k : k - M];
+    double2 o = make_double2(__builtin_fma(c.y, w.y, c.x * w.x), __builtin_fma(-c.x, w.y, c.y * w.x));    // c * conj(w)
+    if (k >= M) o = make_double2(-o.x, -o.y);
+    out[((size_t)prn * 2) * N + k] = c;
+    out[((size_t)prn * 2 + 1) * N + k] = o;
+}
+
 __global__ __launch_bounds__(kThreads) void upsample_batch_kernel(const int8_t* __restrict__ codes,
                                                                   const int32_t* __restrict__ code_len,
                                                                   int code_stride, const int32_t* __restrict__ slots,
@@ -947,11 +963,17 @@ void run_four_step(sdr_engine* e, const FourStep& f, PassArgs a, int batch, doub
 // per-wave records one map-free inverse sweep leaves per transform
 inline int records_per_transform(const FourStep& f) { return ((f.N1 + kRowTile - 1) / kRowTile) * (kThreads / 64); }
 // ... and of the main sweep, which may run the register-resident kernels
-inline bool fused_applies(const sdr_engine* e, const FourStep& f) { return fast25k_applies(e, f) && e->pcps_fused; }
+// operand terms per point of the one-workgroup-per-transform sweep: 1 at N = 25 000, 2 at N = 50 000 (a radix-2 step in
+// front of two 25 000-point transforms, pcps_fused.h), 0 = the sweep does not serve this length
+inline int fused_terms(const sdr_engine* e, const FourStep& f) {
+    if (!e->pcps_fused || !f.ok || e->pcps_no_fast) return 0;
+    if (f.N1 == fast25k::N1 && f.N2 == fast25k::N2) return 1;
+    return f.N1 * f.N2 == 2 * fast25k::N ? 2 : 0;
+}
 // The fused sweep takes a map-free search whole when it fills at least one round of its 256 persistent workgroups (a
 // smaller search is quicker through the two-kernel path: ~8 us + 0.19 us per transform against ~35 us per round).
 inline bool fused_takes(const sdr_engine* e, const FourStep& f, int n_prn, int nbins) {
-    return fused_applies(e, f) && n_prn * nbins >= 256;
+    return fused_terms(e, f) * n_prn * nbins >= 256;
 }
 inline int records_main_sweep(const sdr_engine* e, const FourStep& f) {
     if (fast25k_applies(e, f)) return fast25k::kRecordsPerTransform;
@@ -1114,6 +1136,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
     }
     const bool spectra_cached = !have_spectra && key == e->pcps_spec_key && !e->pcps_no_spec_cache;
     if (have_spectra) e->pcps_spec_key.clear();
+    if (!spectra_cached) e->pcps_code2_ok = false;
     if (!have_spectra && !spectra_cached) {
         e->pcps_spec_key.clear();   // (valid again only once the new spectra are queued without error, below)
         int8_t* up = (int8_t*)B;  // scratch: n_prn*N bytes fits easily in a work buffer
@@ -1173,6 +1196,15 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
 
             if (map_free && fused_takes(e, plan_four_step(N), n_prn, nbins)) {
                 // every (PRN, bin) transform of the search in ONE launch of persistent workgroups: no intermediate, no sweeps
+                if (fused_terms(e, plan_four_step(N)) == 2) {
+                    if (!e->pcps_code2_ok) {       // (made with the spectra, kept as long as they are)
+                        ProfScope ps(e, "pcps_code_fft");
+                        hipLaunchKernelGGL(code_parity_kernel, dim3((N + kThreads - 1) / kThreads, n_prn), dim3(kThreads), 0, e->stream, C,
+                                           tw, N, (double2*)e->pcps_code2.ptr);
+                        e->pcps_code2_ok = true;
+                    }
+                    C = (double2*)e->pcps_code2.ptr;
+                }
                 if (int rcf = sdr_pcps_fused_sweep(e, F, C, tw, n_prn, nbins, N, e->pcps_part.ptr)) return rcf;
                 continue;
             }
@@ -1252,7 +1284,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
         // the map was never written: maximum from the per-wave records, then the winning row of every PRN alone
         // (1/nbins of one inverse sweep) for the second peak
         const FourStep four = plan_four_step(N);
-        const int per_prn = fused_takes(e, four, n_prn, nbins) ? sdr_pcps_fused_records_per_prn(n_prn, nbins)
+        const int per_prn = fused_takes(e, four, n_prn, nbins) ? sdr_pcps_fused_records_per_prn(n_prn, nbins, fused_terms(e, four))
                                                                : nbins * records_main_sweep(e, four);
         Best* tops = parts + (size_t)n_prn * per_prn;
         Best* seconds = tops + n_prn;      // [n_prn][records of the second sweep]
@@ -1260,7 +1292,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
         if (fused_takes(e, four, n_prn, nbins) && !e->pcps_slow_second) {
             // first peaks + second sweep in one launch of n_prn x 5 workgroups (pcps_fused.h ifft_second_kernel)
             if (int rc2 = sdr_pcps_fused_second(e, F, C, tw, n_prn, N, spc, parts, per_prn, tops, dev_bin, dev_code, seconds)) return rc2;
-            per_second = 5 * SDR_PCPS_FUSED_RECORDS;
+            per_second = 5 * fused_terms(e, four) * SDR_PCPS_FUSED_RECORDS;
         } else {
             {
                 ProfScope ps(e, "pcps_peak");
@@ -1416,8 +1448,13 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_a, work);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_b, work);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_code, tbytes * n_prn);
-    // (the fused sweep leaves at most 5 x SDR_PCPS_FUSED_RECORDS records per transform)
-    const size_t n_records = map_free ? (size_t)n_prn * (nbins + 1) * std::max(std::max(records_per_transform(four), records_main_sweep(e, four)), 5 * SDR_PCPS_FUSED_RECORDS) + n_prn : 0;
+    if (!rc && map_free && fused_terms(e, four) == 2 && fused_takes(e, four, n_prn, nbins)) {
+        void* before = e->pcps_code2.ptr;
+        rc = sdr_devbuf_reserve(e, &e->pcps_code2, 2 * tbytes * n_prn);
+        if (e->pcps_code2.ptr != before) e->pcps_code2_ok = false;
+    }
+    // (the fused sweep leaves at most 5 x SDR_PCPS_FUSED_RECORDS records per transform, twice that at N = 50 000)
+    const size_t n_records = map_free ? (size_t)n_prn * (nbins + 1) * std::max(std::max(records_per_transform(four), records_main_sweep(e, four)), 10 * SDR_PCPS_FUSED_RECORDS) + n_prn : 0;
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_map, (size_t)n_prn * ((map_free || fused10k) ? 1 : nbins) * N * sizeof(double));
     if (!rc && coh > 1) rc = sdr_devbuf_reserve(e, &e->pcps_csum, (size_t)n_prn * nbins * tbytes);
     if (!rc) rc = sdr_devbuf_reserve(e, &e->pcps_part, std::max(std::max((size_t)n_prn * kPeakParts, n_records) * sizeof(Best),

@@ -25,6 +25,18 @@
 // The workgroups are persistent: workgroup (XCD x, slot s) walks its XCD's share of a host-made work list in steps of
 // 32, and the list is ordered in blocks of 4 bins x 8 PRNs so that the operands of the transforms an XCD has in flight
 // (12 arrays of 400 KB) mostly sit in its L2.
+//
+// N = 50 000 (50 MHz, BASELINE configs[3]/[4]; TERMS = 2): 800 KB of state do not fit a compute unit, two transforms of
+// 25 000 do.  One radix-2 decimation-in-frequency step in FRONT of the kernel above -- with P = spectrum x conj(fft(code)),
+// M = 25 000, w = exp(-2 pi i / 50 000):
+//     x[2m]     = IFFT_M( P[k] + P[k + M] )[m]                x[2m + 1] = IFFT_M( (P[k] - P[k + M]) w^-k )[m]
+// and the twiddle of the odd half is folded into a second image of the PRN's code spectrum, made with the spectrum and
+// cached with it (pcps.hip code_parity_kernel: C1[k] = C[k] w^-k, C1[k + M] = -C[k + M] w^-k), so that BOTH halves are
+//     IFFT_M( F[k] Cp[k] + F[k + M] Cp[k + M] ),   p = parity of the output sample,
+// the same unit with two operand terms per point instead of one: four loads per point where the 25 000-point search has
+// two, everything behind the operand stage unchanged.  A unit is (PRN, bin, parity); the work list sees 2 nbins "virtual
+// bins" (parity-major: a block of 4 virtual bins x 8 PRNs still shares 4 + 8 operand arrays); records carry the index in
+// the 50 000-sample row, 2m + p.
 #pragma once
 
 // Build-time switches of the A/B variants (tools/build_variant.sh <tag> pcps_fused -DFUSED_...=0|1); measured on one
@@ -138,6 +150,7 @@ struct Args {
     unsigned long long* theta;
     unsigned long long* theta_next;
     int n_prn;
+    int nbins;                 // TERMS = 2: real Doppler bins (a unit's virtual bin is parity * nbins + bin)
 };
 
 // Diagnostic build (-DSDR_FUSED_STAMPS, tools/pcps_fused_phases.py): wave 0 of every workgroup adds up the shader cycles
@@ -160,15 +173,20 @@ __device__ unsigned long long g_fused_stamps[256][8];
 // SECOND: the unit belongs to the second sweep -- the winning Doppler row of a PRN again, the maximum over the columns
 // TwoCorrelationPeakComparison allows: [0, a1) U [b0, b1) (acquisition.py:98-111); flat index = the code phase;
 // no bound from the first sweep (the second peak lies below it).
-template <bool WHOLE, bool SECOND = false>
+// TERMS = 2: the unit is one parity of a 50 000-point transform (header comment): `bin` = the real bin, `par` the parity.
+template <bool WHOLE, bool SECOND = false, int TERMS = 1>
 __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int tid, const int prn, const int bin, const int mode,
-                                         const int rec_slot, const int a1 FUSED_DFLT(0), const int b0 FUSED_DFLT(0), const int b1 FUSED_DFLT(0)
+                                         const int rec_slot, const int a1 FUSED_DFLT(0), const int b0 FUSED_DFLT(0), const int b1 FUSED_DFLT(0),
+                                         const int par FUSED_DFLT(0)
 #ifdef SDR_FUSED_STAMPS
                                          , unsigned long long& stamp_
 #endif
 ) {
+    constexpr int NF = TERMS * N;                       // samples of the row the unit's outputs belong to
     double2* const tab = lds4 + 2 * kBuf;
+    // (TERMS = 2: the engine's table is exp(-2 pi i m / 50 000); the 25 000-point transform's own twiddles are its even entries)
     const double2* __restrict__ tw = a.tw;
+    auto twi = [&](int m) -> double2 { return tw[TERMS * m]; };
     // Thread roles, re-derived per transform from an opaque copy of the thread number: left loop-invariant the compiler
     // keeps every address of the loop body in registers across the whole loop -- and spills them.
     int t_ = tid;
@@ -187,7 +205,7 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     const int si = live2 ? t2 / 10 : 0, sk = live2 ? t2 - 10 * si : 0;
     const int kf0 = 5 * (si / 5) + 25 * (si % 5) + N1 * (sk + 10 * h);
 
-    if (tid < 97) tab[tid] = tw[(N / 125) * tid];
+    if (tid < 97) tab[tid] = twi((N / 125) * tid);
     __syncthreads();   // the table; and every reader of the previous transform's last rounds is done with the buffers
     FUSED_STAMP(0);
 
@@ -196,8 +214,8 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     // stage while the NEXT group's ten loads are in flight; while item 1 is transformed, ten of item 0's fifteen
     // parked points wait in the LDS slots item 1 will fill at its end (a thread's own slots: no barrier).
     double2 park[2][15];
-    const Operand xs_u = make_operand(a.spec + (size_t)bin * N);
-    const Operand cs_u = make_operand(a.code_spec + (size_t)prn * N);
+    const Operand xs_u = make_operand(a.spec + (size_t)bin * NF);
+    const Operand cs_u = make_operand(a.code_spec + ((size_t)prn * TERMS + par) * NF);
     const unsigned toff = (unsigned)cb * 16u;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -218,32 +236,81 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
                     eP[kBuf + 5 * N2 * g] = park[0][5 + g];
                 }
             }
+            if constexpr (TERMS == 1) {
 #pragma unroll
-            for (int m1 = 0; m1 < 5; ++m1) {
-                double2 xb[5], cb_[5];
-                if (m1 < 4) {
+                for (int m1 = 0; m1 < 5; ++m1) {
+                    double2 xb[5], cb_[5];
+                    if (m1 < 4) {
 #pragma unroll
-                    for (int m2 = 0; m2 < 5; ++m2) {
-                        xb[m2] = ldb(xs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
-                        cb_[m2] = ldb(cs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
+                        for (int m2 = 0; m2 < 5; ++m2) {
+                            xb[m2] = ldb(xs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
+                            cb_[m2] = ldb(cs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double2 t[5];
+#pragma unroll
+                    for (int m2 = 0; m2 < 5; ++m2) t[m2] = cmulf(xa[m2], ca[m2]);
+                    ibf5(t);
+                    v[m1] = t[0];
+#pragma unroll
+                    for (int kA = 1; kA < 5; ++kA)
+                        v[m1 + 5 * kA] = m1 ? cmul_conj(t[kA], make_double2(kW25X[m1 * kA], kW25Y[m1 * kA])) : t[kA];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m1 < 4) {
+#pragma unroll
+                        for (int m2 = 0; m2 < 5; ++m2) {
+                            xa[m2] = xb[m2];
+                            ca[m2] = cb_[m2];
+                        }
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                double2 t[5];
+            } else {
+                // two operand terms per point: P = F[k] C[k] + F[k + M] C[k + M].  Ten half-steps, two register sets that
+                // take turns (no copies): while one term of a group of five points is multiplied, the ten loads of the next
+                // half-step are in flight.  The products are PINNED where they are written (an empty volatile asm that
+                // "modifies" them): left free, the arithmetic of all ten half-steps sinks below the last load -- the
+                // scheduling barriers order memory operations, not pure arithmetic -- and 100 loads x 4 registers are
+                // alive at once (the 25 000-point kernel lives with exactly that: its 50 loads fit).
+                constexpr unsigned kHalf = (unsigned)N * 16u;      // k + M
+                auto pin = [](double2& d) { asm volatile("" : "+v"(d.x), "+v"(d.y)); };
 #pragma unroll
-                for (int m2 = 0; m2 < 5; ++m2) t[m2] = cmulf(xa[m2], ca[m2]);
-                ibf5(t);
-                v[m1] = t[0];
-#pragma unroll
-                for (int kA = 1; kA < 5; ++kA)
-                    v[m1 + 5 * kA] = m1 ? cmul_conj(t[kA], make_double2(kW25X[m1 * kA], kW25Y[m1 * kA])) : t[kA];
-                __builtin_amdgcn_sched_barrier(0);
-                if (m1 < 4) {
+                for (int m1 = 0; m1 < 5; ++m1) {
+                    double2 xb[5], cb_[5];
 #pragma unroll
                     for (int m2 = 0; m2 < 5; ++m2) {
-                        xa[m2] = xb[m2];
-                        ca[m2] = cb_[m2];
+                        xb[m2] = ldb(xs_u, toff, kHalf + 1600 * j + kRowBytes * 5 * (m1 + 5 * m2));
+                        cb_[m2] = ldb(cs_u, toff, kHalf + 1600 * j + kRowBytes * 5 * (m1 + 5 * m2));
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double2 t[5];
+#pragma unroll
+                    for (int m2 = 0; m2 < 5; ++m2) {
+                        t[m2] = cmulf(xa[m2], ca[m2]);
+                        pin(t[m2]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m1 < 4) {
+#pragma unroll
+                        for (int m2 = 0; m2 < 5; ++m2) {
+                            xa[m2] = ldb(xs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
+                            ca[m2] = ldb(cs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m2 = 0; m2 < 5; ++m2) {
+                        t[m2].x = __builtin_fma(-xb[m2].y, cb_[m2].y, __builtin_fma(xb[m2].x, cb_[m2].x, t[m2].x));
+                        t[m2].y = __builtin_fma(xb[m2].y, cb_[m2].x, __builtin_fma(xb[m2].x, cb_[m2].y, t[m2].y));
+                    }
+                    ibf5(t);
+                    v[m1] = t[0];
+#pragma unroll
+                    for (int kA = 1; kA < 5; ++kA)
+                        v[m1 + 5 * kA] = m1 ? cmul_conj(t[kA], make_double2(kW25X[m1 * kA], kW25Y[m1 * kA])) : t[kA];
+#pragma unroll
+                    for (int kA = 0; kA < 5; ++kA) pin(v[m1 + 5 * kA]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // second stage of the 25-point transform and the twiddle between the column's two levels
@@ -302,11 +369,11 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     // the row's four-step twiddle w_N^(k1 (e + 20 m)) = base * step^m: two scattered table reads per round, requested
     // a phase ahead
 #if FUSED_TW_AHEAD
-    double2 tw_base = tw[k1b * re], tw_step = tw[20 * k1b];
+    double2 tw_base = twi(k1b * re), tw_step = twi(20 * k1b);
 #endif
 #if FUSED_MERGE_Y
     if (live) y_in_place(lds4);
-    if (tid < 172) tab[tid] = tw[(N / 200) * tid];   // (every w125 read lies before the last barrier)
+    if (tid < 172) tab[tid] = twi((N / 200) * tid);   // (every w125 read lies before the last barrier)
     __syncthreads();
     FUSED_STAMP(4);
 #endif
@@ -316,7 +383,7 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     // (squared, unscaled, a little low: the bound the lanes' squared magnitudes are screened against)
     double floor_sq = 0.0;
     if constexpr (!SECOND) {
-        const double th = __longlong_as_double((long long)__hip_atomic_load(&a.theta[prn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) * (double)N;
+        const double th = __longlong_as_double((long long)__hip_atomic_load(&a.theta[prn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) * (double)NF;
         floor_sq = th * th * (1.0 - 0x1p-40);
     }
     // (unrolled: as a run-time loop -- FUSED_UNROLL_ROUNDS 1: buffer offsets and the parked registers' cases decided per round,
@@ -330,11 +397,11 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
         double2* const X = lds4 + ((WHOLE && (rho & 1)) ? kBuf : 0);
         double2* const Xo = lds4 + ((rho & 1) ? 0 : kBuf);
 #if !FUSED_TW_AHEAD
-        const double2 tw_base = tw[(rho + k1b) * re], tw_step = tw[20 * (rho + k1b)];
+        const double2 tw_base = twi((rho + k1b) * re), tw_step = twi(20 * (rho + k1b));
 #endif
 #if !FUSED_MERGE_Y
         if (live) y_in_place(X);
-        if ((rho == 0 || !WHOLE) && tid < 172) tab[tid] = tw[(N / 200) * tid];   // (every w125 read lies before the last barrier)
+        if ((rho == 0 || !WHOLE) && tid < 172) tab[tid] = twi((N / 200) * tid);   // (every w125 read lies before the last barrier)
         __syncthreads();
         FUSED_STAMP(4);
 #endif
@@ -381,8 +448,8 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
         }
 #if FUSED_TW_AHEAD
         if (rho < 4) {
-            tw_base = tw[(rho + 1 + k1b) * re];
-            tw_step = tw[20 * (rho + 1 + k1b)];
+            tw_base = twi((rho + 1 + k1b) * re);
+            tw_step = twi(20 * (rho + 1 + k1b));
         }
 #endif
         __syncthreads();   // every read of the row is done: the exchange goes in place
@@ -433,7 +500,7 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
             for (int g = 0; g < 10; ++g) {
                 sqv[g] = __builtin_fma(u[g].x, u[g].x, u[g].y * u[g].y);
                 if constexpr (SECOND) {        // (a column the peak comparison excludes never becomes a candidate: -2 loses against -1)
-                    const int k = k_first + 20 * N1 * (g / 2 + 5 * (g % 2));
+                    const int k = TERMS * (k_first + 20 * N1 * (g / 2 + 5 * (g % 2))) + par;     // (sample of the whole row)
                     sqv[g] = (k < a1 || (k >= b0 && k < b1)) ? sqv[g] : -2.0;
                 }
             }
@@ -480,7 +547,7 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
                         const int k = k_first + 20 * N1 * p;
                         const double2 x = copy[g];
                         double sq = __builtin_fma(x.x, x.x, x.y * x.y);
-                        if (SECOND && !(k < a1 || (k >= b0 && k < b1))) sq = -2.0;
+                        if (SECOND && !(TERMS * k + par < a1 || (TERMS * k + par >= b0 && TERMS * k + par < b1))) sq = -2.0;
                         bool take = sq > best_sq;
                         if (sq >= 0.0 && fabs(sq - best_sq) <= best_sq * 0x1p-48) {
                             const double m_new = hypot(x.x * a.scale, x.y * a.scale), m_old = hypot(best_x * a.scale, best_y * a.scale);
@@ -502,7 +569,7 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     int best_i = 0x7fffffff;
     double best_v = -1.0;
     if (live2 && best_k >= 0) {
-        best_i = (SECOND ? 0 : bin * N) + best_k;
+        best_i = (SECOND ? 0 : bin * NF) + TERMS * best_k + par;
         best_v = 0.0 + hypot(best_x * a.scale, best_y * a.scale);   // (0.0 + |.|: the map's own rounding)
     }
     wave_best(best_v, best_i);
@@ -514,13 +581,14 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     }
 }
 
+template <int TERMS>
 __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
     extern __shared__ double2 lds4[];
 #ifdef SDR_FUSED_STAMPS
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
-#define FUSED_STAMP_ARG , 0, 0, 0, stamp_
+#define FUSED_STAMP_ARG , 0, 0, 0, par, stamp_
 #else
-#define FUSED_STAMP_ARG
+#define FUSED_STAMP_ARG , 0, 0, 0, par
 #endif
     const int tid = threadIdx.x;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -529,11 +597,13 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
     const int w_end = a.xcd_first[xcd + 1];
     for (int w = a.xcd_first[xcd] + slot; w < w_end; w += kSlotsPerXcd) {
         // (wave-uniform: scalar base addresses in the unit)
-        const int prn = __builtin_amdgcn_readfirstlane(a.work[w].prn), bin = __builtin_amdgcn_readfirstlane(a.work[w].bin);
+        const int prn = __builtin_amdgcn_readfirstlane(a.work[w].prn);
+        int bin = __builtin_amdgcn_readfirstlane(a.work[w].bin), par = 0;
+        if (TERMS == 2 && bin >= a.nbins) bin -= a.nbins, par = 1;            // (virtual bin = parity * nbins + bin)
         const int mode = __builtin_amdgcn_readfirstlane(a.work[w].round);     // -1: the whole transform; else that round only
         const int rec_slot = __builtin_amdgcn_readfirstlane(a.work[w].record);
-        if (mode < 0) one_unit<true>(a, lds4, tid, prn, bin, mode, rec_slot FUSED_STAMP_ARG);
-        else one_unit<false>(a, lds4, tid, prn, bin, mode, rec_slot FUSED_STAMP_ARG);
+        if (mode < 0) one_unit<true, false, TERMS>(a, lds4, tid, prn, bin, mode, rec_slot FUSED_STAMP_ARG);
+        else one_unit<false, false, TERMS>(a, lds4, tid, prn, bin, mode, rec_slot FUSED_STAMP_ARG);
     }
 }
 
@@ -552,12 +622,15 @@ struct SecondArgs {
     long long* out_code;
 };
 
+template <int TERMS>
 __global__ __launch_bounds__(kThreads) void ifft_second_kernel(const SecondArgs s) {
     extern __shared__ double2 lds4[];
+    constexpr int NF = TERMS * N;
     const int tid = threadIdx.x;
-    // (the five workgroups of a PRN read the same two 400 KB arrays: block numbers equal modulo 8 share an XCD's L2)
-    const int prn8 = (int)(gridDim.x / 5);
-    const int rho = blockIdx.x / prn8, prn = blockIdx.x - rho * prn8;
+    // (the 5 TERMS workgroups of a PRN read the same two arrays: block numbers equal modulo 8 share an XCD's L2)
+    const int prn8 = (int)(gridDim.x / (5 * TERMS));
+    const int unit = blockIdx.x / prn8, prn = blockIdx.x - unit * prn8;      // unit = round + 5 parity
+    const int par = unit / 5, rho = unit - 5 * par;
     if (prn >= s.n_prn) return;
     // first peak: larger value, smaller flat index on ties (np.argmax's first occurrence)
     Best* const sh = reinterpret_cast<Best*>(lds4);
@@ -582,9 +655,9 @@ __global__ __launch_bounds__(kThreads) void ifft_second_kernel(const SecondArgs 
     for (int w = 1; w < kWaves; ++w)
         if (sh[w].v > top.v || (sh[w].v == top.v && sh[w].i < top.i)) top = sh[w];
     if (top.v < 0.0) top.i = 0;          // (no record at all: never an index a row is read with)
-    const int bin = __builtin_amdgcn_readfirstlane((int)(top.i / N));
-    const int code = __builtin_amdgcn_readfirstlane((int)(top.i - (long long)bin * N));
-    if (rho == 0 && tid == 0) {
+    const int bin = __builtin_amdgcn_readfirstlane((int)(top.i / NF));
+    const int code = __builtin_amdgcn_readfirstlane((int)(top.i - (long long)bin * NF));
+    if (unit == 0 && tid == 0) {
         s.tops[prn] = top;
         s.out_bin[prn] = bin;
         s.out_code[prn] = code;
@@ -594,21 +667,21 @@ __global__ __launch_bounds__(kThreads) void ifft_second_kernel(const SecondArgs 
         const int e0 = code - s.spc, e1 = code + s.spc;
         if (e0 < 1) {
             b0 = e1;
-            b1 = N - 1;
-        } else if (e1 >= N) {
+            b1 = NF - 1;
+        } else if (e1 >= NF) {
             a1 = e0;
         } else {
             a1 = e0;
             b0 = e1;
-            b1 = N - 1;
+            b1 = NF - 1;
         }
     }
     __syncthreads();                     // (the record scratch is the first buffer)
 #ifdef SDR_FUSED_STAMPS
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
-    one_unit<false, true>(s.a, lds4, tid, prn, bin, rho, prn * 5 + rho, a1, b0, b1, stamp_);
+    one_unit<false, true, TERMS>(s.a, lds4, tid, prn, bin, rho, prn * (5 * TERMS) + unit, a1, b0, b1, par, stamp_);
 #else
-    one_unit<false, true>(s.a, lds4, tid, prn, bin, rho, prn * 5 + rho, a1, b0, b1);
+    one_unit<false, true, TERMS>(s.a, lds4, tid, prn, bin, rho, prn * (5 * TERMS) + unit, a1, b0, b1, par);
 #endif
 }
 

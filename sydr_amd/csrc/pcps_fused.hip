@@ -26,24 +26,30 @@ static int fused_plan(int n_prn, int nbins, int* bins_whole) {
     return bw + 5 * (nbins - bw);
 }
 
-int sdr_pcps_fused_records_per_prn(int n_prn, int nbins) {
+// (terms: 1 at N = 25 000; 2 at N = 50 000, where a unit is one parity of a (PRN, bin) transform and the plan sees
+// 2 nbins virtual bins)
+int sdr_pcps_fused_records_per_prn(int n_prn, int nbins, int terms) {
     int bw;
-    return fused_plan(n_prn, nbins, &bw) * SDR_PCPS_FUSED_RECORDS;
+    return fused_plan(n_prn, terms * nbins, &bw) * SDR_PCPS_FUSED_RECORDS;
 }
 
+// C: [n_prn][N] code spectra at N = 25 000; [n_prn][2][N] at N = 50 000 -- the spectrum and its image with the odd half's
+// twiddle folded in (pcps.hip code_parity_kernel).
 int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int nbins, int N, void* partials) {
-    if (N != fused25k::N) return sdr_fail(SDR_ERR_UNSUPPORTED, "fused PCPS sweep: N = %d", N);
-    if (e->pcps_work_prn != n_prn || e->pcps_work_bins != nbins) {
+    if (N != fused25k::N && N != 2 * fused25k::N) return sdr_fail(SDR_ERR_UNSUPPORTED, "fused PCPS sweep: N = %d", N);
+    const int terms = N / fused25k::N;
+    const int vbins = terms * nbins;
+    if (e->pcps_work_prn != n_prn || e->pcps_work_bins != vbins) {
         std::vector<fused25k::WorkItem> order;
         int bins_whole;
-        fused_plan(n_prn, nbins, &bins_whole);
-        fused25k::make_work_list(n_prn, nbins, bins_whole, order, e->pcps_work_first);
+        fused_plan(n_prn, vbins, &bins_whole);
+        fused25k::make_work_list(n_prn, vbins, bins_whole, order, e->pcps_work_first);
         if (int rc = sdr_devbuf_reserve(e, &e->pcps_work, order.size() * sizeof(fused25k::WorkItem))) return rc;
         // (pageable source, tiny: the copy is complete when the stream has been waited for)
         SDR_HIP(hipMemcpyAsync(e->pcps_work.ptr, order.data(), order.size() * sizeof(fused25k::WorkItem), hipMemcpyHostToDevice, e->stream));
         SDR_HIP(hipStreamSynchronize(e->stream));
         e->pcps_work_prn = n_prn;
-        e->pcps_work_bins = nbins;
+        e->pcps_work_bins = vbins;
     }
     fused25k::Args a = {};
     a.spec = (const double2*)F;
@@ -63,19 +69,20 @@ int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void
     a.theta = (unsigned long long*)e->pcps_theta.ptr + (size_t)e->pcps_theta_flip * n_prn;
     a.theta_next = (unsigned long long*)e->pcps_theta.ptr + (size_t)(e->pcps_theta_flip ^ 1) * n_prn;
     a.n_prn = n_prn;
+    a.nbins = nbins;
     e->pcps_theta_flip ^= 1;
-    (void)hipFuncSetAttribute((const void*)fused25k::ifft_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)fused25k::kLdsBytes);
+    auto* kernel = terms == 2 ? fused25k::ifft_max_kernel<2> : fused25k::ifft_max_kernel<1>;
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused25k::kLdsBytes);
     ProfScope ps(e, "pcps_inv_fft");
-    hipLaunchKernelGGL(fused25k::ifft_max_kernel, dim3(8 * fused25k::kSlotsPerXcd), dim3(fused25k::kThreads),
-                       fused25k::kLdsBytes, e->stream, a);
+    hipLaunchKernelGGL(kernel, dim3(8 * fused25k::kSlotsPerXcd), dim3(fused25k::kThreads), fused25k::kLdsBytes, e->stream, a);
     SDR_HIP(hipGetLastError());
     return SDR_OK;
 }
 
 int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int N, int spc, const void* recs,
                           int per_prn, void* tops, void* dev_bin, void* dev_code, void* seconds) {
-    if (N != fused25k::N) return sdr_fail(SDR_ERR_UNSUPPORTED, "fused PCPS sweep: N = %d", N);
+    if (N != fused25k::N && N != 2 * fused25k::N) return sdr_fail(SDR_ERR_UNSUPPORTED, "fused PCPS sweep: N = %d", N);
+    const int terms = N / fused25k::N;
     fused25k::SecondArgs s = {};
     s.a.spec = (const double2*)F;
     s.a.code_spec = (const double2*)C;
@@ -89,10 +96,11 @@ int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* C, const voi
     s.tops = (Best*)tops;
     s.out_bin = (long long*)dev_bin;
     s.out_code = (long long*)dev_code;
-    (void)hipFuncSetAttribute((const void*)fused25k::ifft_second_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)fused25k::kLdsBytes);
+    auto* kernel = terms == 2 ? fused25k::ifft_second_kernel<2> : fused25k::ifft_second_kernel<1>;
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused25k::kLdsBytes);
     ProfScope ps(e, "pcps_inv_fft");
-    hipLaunchKernelGGL(fused25k::ifft_second_kernel, dim3(5 * ((n_prn + 7) / 8 * 8)), dim3(fused25k::kThreads), fused25k::kLdsBytes, e->stream, s);
+    // (n_prn x 5 rounds x `terms` parities: one round of one parity of the PRN's winning row per workgroup)
+    hipLaunchKernelGGL(kernel, dim3(5 * terms * ((n_prn + 7) / 8 * 8)), dim3(fused25k::kThreads), fused25k::kLdsBytes, e->stream, s);
     SDR_HIP(hipGetLastError());
     return SDR_OK;
 }

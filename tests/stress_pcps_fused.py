@@ -1,6 +1,7 @@
 """Randomised stress of the map-free searches that keep a whole inverse transform inside one workgroup: N = 25 000
 (pcps_fused.h: persistent workgroups, whole rounds + a tail of single-round units, the second sweep on five workgroups per
-PRN) and N = 10 000 (pcps_fused10k.h: transform in LDS, non-coherent sum in registers).  Every round draws PRN count,
+PRN), N = 50 000 (the same kernel behind a radix-2 decimation-in-frequency step: a unit is one parity of a transform, two
+operand terms per point) and N = 10 000 (pcps_fused10k.h: transform in LDS, non-coherent sum in registers).  Every round draws PRN count,
 Doppler grid, IF, start offset, noise level, non-coherent blocks (10 MHz) and which satellites are present; the result must
 equal the path with the fused kernels switched off (`pcps_fused` = 0) -- indices bit for bit, ratio to 1e-12 -- and, for
 three PRNs of every `oracle_every`-th round, the oracle's map (indices exactly, ratio to 1e-9).
@@ -18,13 +19,13 @@ def run(rounds, seed, oracle_every=8, eng=None):
     searched, checked, worst_ratio, worst_vs_general = 0, 0, 0.0, 0.0
     t0 = time.time()
     for r in range(rounds):
-        fs = 25e6 if r % 2 == 0 else 10e6
+        fs = (25e6, 10e6, 50e6)[r % 3]
         n = orc.samples_per_code(fs)
-        noncoh = 1 if fs == 25e6 else int(rng.choice([1, 2, 3, 10]))
+        noncoh = 1 if fs != 10e6 else int(rng.choice([1, 2, 3, 10]))
         drange = float(rng.choice([5000.0, 4000.0, 2500.0, 1000.0]))
         dstep = float(rng.choice([250.0, 500.0, 300.0, 125.0, 100.0]))
         nbins = len(np.arange(-drange, drange + 1, dstep))
-        need = 256 if fs == 25e6 else 32                     # transforms from which the fused kernels take a search
+        need = {25e6: 256, 50e6: 128, 10e6: 32}[fs]         # transforms from which the fused kernels take a search
         lo = max(1, -(-need // nbins))
         if lo > 32:
             continue

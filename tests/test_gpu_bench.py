@@ -57,8 +57,8 @@ def test_gpus_2_without_a_launcher_spawns_its_own_ranks():
 def test_more_ranks_than_devices_is_an_error_outside_rehearsal():
     """Two ranks on a one-GPU box without SYDR_BENCH_REHEARSE: every rank refuses (no two ranks on one device, no CPU
     path) and the launcher's exit code is non-zero; nothing is printed as a result line."""
-    import torch
-    if torch.cuda.device_count() >= 2:
+    from sydr_amd._lib import device_count      # (never `import torch` in the test process: it brings its own HIP runtime,
+    if device_count() >= 2:                     # and tests that open libamdhip64.so themselves would then talk to that one)
         pytest.skip("this box has two devices")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
                                                               "SYDR_BENCH_REHEARSE")}

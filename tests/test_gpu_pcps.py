@@ -279,8 +279,24 @@ def test_fused_sweep_vs_two_kernel_sweeps_and_oracle(engine, n_prn, drange, dste
     round left over -- whole transforms throughout).  Peaks equal to the two-kernel sweeps' bit for bit, ratios to
     rounding, and both equal to the oracle's for the PRNs checked; a constant stream (every value of a row ties) must
     give the first index."""
-    fs = 25e6
-    rng = np.random.default_rng(9000 + n_prn + int(dstep))
+    _fused_sweep_case(engine, 25e6, n_prn, drange, dstep)
+
+
+@pytest.mark.parametrize("n_prn,drange,dstep", [(32, 5000.0, 250.0), (8, 5000.0, 250.0), (16, 1750.0, 500.0), (3, 5000.0, 100.0),
+                                                  (2, 5000.0, 50.0)])
+def test_fused_sweep_at_50_mhz_vs_two_kernel_sweeps_and_oracle(engine, n_prn, drange, dstep):
+    """N = 50 000 (BASELINE configs 4-5's rate): 800 KB of state per transform do not fit a compute unit, so a radix-2
+    decimation-in-frequency step in front splits every (PRN, bin) transform into its even and its odd output samples --
+    two 25 000-point transforms with two operand terms per point (pcps_fused.h, TERMS = 2; the odd half's twiddle lives in
+    a second image of the code spectrum).  Units = PRNs x bins x 2: ten rounds of 256 and a tail (32 x 41), two rounds and
+    a tail (8 x 41), exactly one round (16 x 8), odd PRN counts.  Same checks as at 25 MHz: indices equal to the
+    two-kernel sweeps' bit for bit (records carry 2m + parity), ratios to rounding, both equal to the oracle's; a
+    constant stream gives the first index."""
+    _fused_sweep_case(engine, 50e6, n_prn, drange, dstep)
+
+
+def _fused_sweep_case(engine, fs, n_prn, drange, dstep):
+    rng = np.random.default_rng(9000 + n_prn + int(dstep) + int(fs / 1e6))
     n = orc.samples_per_code(fs)
     prns = [int(p) for p in rng.choice(np.arange(1, 33), n_prn, replace=False)]
     sats = [dict(prn=p, doppler=float(rng.uniform(-3500, 3500)), code_phase=float(rng.uniform(0, 1023)),
@@ -293,7 +309,7 @@ def test_fused_sweep_vs_two_kernel_sweeps_and_oracle(engine, n_prn, drange, dste
         engine.load_gps_code(s, p)
     engine.iq_synth(sats, fs, 12.0, 4242, 0, cap)
     nbins = len(np.arange(-drange, drange + 1, dstep))
-    assert n_prn * nbins >= 256
+    assert n_prn * nbins * (2 if fs == 50e6 else 1) >= 256
     res = {}
     for fused in (1, 0):
         engine.set_option("pcps_fused", fused)
