@@ -309,7 +309,7 @@ void sdr_engine_destroy(sdr_engine* e) {
     }
     for (auto ev : e->prof_pool) (void)hipEventDestroy(ev);
     DevBuf* bufs[] = {&e->ws_items,  &e->ws_out,   &e->ws_spacing, &e->ws_setups, &e->ws_stats, &e->pcps_fwd,   &e->pcps_a,
-                      &e->pcps_b,    &e->pcps_code, &e->pcps_code2, &e->pcps_tw,   &e->pcps_map,   &e->pcps_csum,
+                      &e->pcps_b,    &e->pcps_code, &e->pcps_code2, &e->pcps_tickets, &e->pcps_tw,   &e->pcps_map,   &e->pcps_csum,
                       &e->pcps_part, &e->pcps_res,  &e->track_state, &e->track_cfg,
                       &e->pcps_blu,  &e->pcps_blu_x, &e->pcps_blu_a, &e->pcps_blu_b, &e->pcps_work, &e->pcps_theta};
     for (DevBuf* b : bufs)

@@ -94,6 +94,8 @@ struct sdr_engine {
     DevBuf pcps_fwd, pcps_a, pcps_b, pcps_code, pcps_tw, pcps_map, pcps_csum, pcps_part, pcps_res;
     DevBuf pcps_code2;            // N = 50 000, fused search: [prn][parity][N] -- the spectra and their image with the odd half's twiddle (pcps_fused.h)
     bool pcps_code2_ok = false;   // ... made from what pcps_code holds now
+    DevBuf pcps_tickets;          // one word per PRN: the second sweep's last workgroup of a PRN divides the two peaks (pcps_fused.h)
+    int pcps_tickets_n = 0;
     DevBuf track_state, track_cfg;
     int n_cus = 0;              // compute units of the device (sizes the closed-loop clusters)
     int track_force_parts = 0;  // diagnostics / tests: 0 = choose, else 1, 2, 4 or 8 workgroups per channel
@@ -193,5 +195,7 @@ int sdr_pcps_fused10k_search(sdr_engine* e, const void* F_all, const void* C, co
                              void* records, void* out_bin, void* out_code, void* out_ratio);
 // The second sweep of such a search in one launch: the first peaks from `recs` ([n_prn][per_prn] records) into tops / dev_bin /
 // dev_code, and 5 x SDR_PCPS_FUSED_RECORDS records per PRN of its winning row's allowed columns into `seconds`.
+// ... and TwoCorrelationPeakComparison's results (bin, code phase, ratio of the two peaks) into res_*.
 int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int N, int spc, const void* recs,
-                          int per_prn, void* tops, void* dev_bin, void* dev_code, void* seconds);
+                          int per_prn, void* tops, void* dev_bin, void* dev_code, void* seconds, void* res_bin, void* res_code,
+                          void* res_ratio);

@@ -1291,8 +1291,9 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
         int per_second = records_per_transform(four);
         if (fused_takes(e, four, n_prn, nbins) && !e->pcps_slow_second) {
             // first peaks + second sweep in one launch of n_prn x 5 workgroups (pcps_fused.h ifft_second_kernel)
-            if (int rc2 = sdr_pcps_fused_second(e, F, C, tw, n_prn, N, spc, parts, per_prn, tops, dev_bin, dev_code, seconds)) return rc2;
-            per_second = 5 * fused_terms(e, four) * SDR_PCPS_FUSED_RECORDS;
+            // ... which also divides the two peaks (its last workgroup per PRN): the whole K6 in one launch
+            return sdr_pcps_fused_second(e, F, C, tw, n_prn, N, spc, parts, per_prn, tops, dev_bin, dev_code, seconds, res_bin, res_code,
+                                         res_ratio);
         } else {
             {
                 ProfScope ps(e, "pcps_peak");

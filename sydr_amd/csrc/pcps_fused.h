@@ -160,7 +160,7 @@ __device__ unsigned long long g_fused_stamps[256][8];
 #define FUSED_STAMP(slot)                                                  \
     do {                                                                   \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
-        if (tid == 0) g_fused_stamps[blockIdx.x][slot] += now_ - stamp_;   \
+        if (tid == 0) g_fused_stamps[blockIdx.x & 255][slot] += now_ - stamp_;   /* (the second sweep at N = 50 000 has 320 workgroups) */   \
         stamp_ = now_;                                                     \
     } while (0)
 #define FUSED_DFLT(x)                 /* (the stamp reference follows these parameters: no defaults in this build) */
@@ -169,7 +169,9 @@ __device__ unsigned long long g_fused_stamps[256][8];
 #define FUSED_DFLT(x) = x
 #endif
 
-// One unit of work (a whole transform, or round `mode` of one) by the 512 threads of the workgroup.
+// One unit of work (a whole transform, or one or two of its five rounds) by the 512 threads of the workgroup.
+// !WHOLE: `mode` = r0 | r1 << 4, the unit's rounds (r1 = 15: one round only); round r0 lives in the first LDS buffer, r1 in
+// the second -- nothing is parked in registers.
 // SECOND: the unit belongs to the second sweep -- the winning Doppler row of a PRN again, the maximum over the columns
 // TwoCorrelationPeakComparison allows: [0, a1) U [b0, b1) (acquisition.py:98-111); flat index = the code phase;
 // no bound from the first sweep (the second peak lies below it).
@@ -183,6 +185,7 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
 #endif
 ) {
     constexpr int NF = TERMS * N;                       // samples of the row the unit's outputs belong to
+    const int r0 = mode & 15, r1 = mode >> 4;           // (!WHOLE)
     double2* const tab = lds4 + 2 * kBuf;
     // (TERMS = 2: the engine's table is exp(-2 pi i m / 50 000); the 25 000-point transform's own twiddles are its even entries)
     const double2* __restrict__ tw = a.tw;
@@ -316,7 +319,7 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
             // second stage of the 25-point transform and the twiddle between the column's two levels
 #pragma unroll
             for (int kA = 0; kA < 5; ++kA) {
-                if (WHOLE || mode == kA) {          // (a single round: its five outputs alone, straight into the first buffer)
+                if (WHOLE || r0 == kA || r1 == kA) {          // (a unit of one or two rounds: their outputs alone, straight into the buffers)
                     double2 t[5] = {v[5 * kA], v[5 * kA + 1], v[5 * kA + 2], v[5 * kA + 3], v[5 * kA + 4]};
                     ibf5(t);
 #pragma unroll
@@ -326,7 +329,7 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
                     }
                     if (!WHOLE) {
 #pragma unroll
-                        for (int kB = 0; kB < 5; ++kB) eP[5 * N2 * kB] = v[5 * kA + kB];
+                        for (int kB = 0; kB < 5; ++kB) eP[(kA == r1 ? kBuf : 0) + 5 * N2 * kB] = v[5 * kA + kB];
                     }
                 }
             }
@@ -393,8 +396,8 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
 #endif
 #pragma unroll FUSED_UNROLL_ROUNDS
     for (int rho = 0; rho < 5; ++rho) {
-        if (!WHOLE && mode != rho) continue;
-        double2* const X = lds4 + ((WHOLE && (rho & 1)) ? kBuf : 0);
+        if (!WHOLE && rho != r0 && rho != r1) continue;
+        double2* const X = lds4 + ((WHOLE ? (rho & 1) : rho == r1) ? kBuf : 0);
         double2* const Xo = lds4 + ((rho & 1) ? 0 : kBuf);
 #if !FUSED_TW_AHEAD
         const double2 tw_base = twi((rho + k1b) * re), tw_step = twi(20 * (rho + k1b));
@@ -511,7 +514,7 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
             const bool candidate = round_max >= fmax(floor_sq, best_sq * (1.0 - 0x1p-40));
             if (__any(candidate)) {
 #ifdef SDR_FUSED_STAMPS
-                if (tid == 0) g_fused_stamps[blockIdx.x][6] += 1000000;    // (diagnostic: rounds of wave 0 that keep books)
+                if (tid == 0) g_fused_stamps[blockIdx.x & 255][6] += 1000000;    // (diagnostic: rounds of wave 0 that keep books)
 #endif
                 // Ordering by the squared magnitude.  A candidate within 2^-48 of the lane's best has to be compared through
                 // the scaled hypot -- the reference's np.abs -- with an exact tie keeping the smaller index (pcps_fast.h): the
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
         const int prn = __builtin_amdgcn_readfirstlane(a.work[w].prn);
         int bin = __builtin_amdgcn_readfirstlane(a.work[w].bin), par = 0;
         if (TERMS == 2 && bin >= a.nbins) bin -= a.nbins, par = 1;            // (virtual bin = parity * nbins + bin)
-        const int mode = __builtin_amdgcn_readfirstlane(a.work[w].round);     // -1: the whole transform; else that round only
+        const int mode = __builtin_amdgcn_readfirstlane(a.work[w].round);     // -1: the whole transform; else its rounds r0 | r1 << 4
         const int rec_slot = __builtin_amdgcn_readfirstlane(a.work[w].record);
         if (mode < 0) one_unit<true, false, TERMS>(a, lds4, tid, prn, bin, mode, rec_slot FUSED_STAMP_ARG);
         else one_unit<false, false, TERMS>(a, lds4, tid, prn, bin, mode, rec_slot FUSED_STAMP_ARG);
@@ -620,6 +623,12 @@ struct SecondArgs {
     Best* tops;                // [n_prn] out
     long long* out_bin;        // [n_prn] out
     long long* out_code;
+    // the ratio of the two peaks by whichever of the PRN's workgroups finishes LAST (a ticket per PRN; that workgroup
+    // sets it back to zero): no launch of its own for 32 divisions
+    unsigned* tickets;         // [n_prn], zero between launches
+    long long* res_bin;        // [n_prn] the caller's results (page-locked memory or the device copies themselves)
+    long long* res_code;
+    double* res_ratio;
 };
 
 template <int TERMS>
@@ -627,10 +636,15 @@ __global__ __launch_bounds__(kThreads) void ifft_second_kernel(const SecondArgs 
     extern __shared__ double2 lds4[];
     constexpr int NF = TERMS * N;
     const int tid = threadIdx.x;
-    // (the 5 TERMS workgroups of a PRN read the same two arrays: block numbers equal modulo 8 share an XCD's L2)
-    const int prn8 = (int)(gridDim.x / (5 * TERMS));
-    const int unit = blockIdx.x / prn8, prn = blockIdx.x - unit * prn8;      // unit = round + 5 parity
-    const int par = unit / 5, rho = unit - 5 * par;
+    // (the workgroups of a PRN read the same arrays: block numbers equal modulo 8 share an XCD's L2)
+    // TERMS = 1: five workgroups per PRN, one round each.  TERMS = 2: three per parity -- rounds {0, 1}, {2, 3}, {4} -- six per
+    // PRN: 192 workgroups for 32 PRNs, ONE wave of workgroups on the 256 compute units where ten per PRN were a wave and a quarter
+    constexpr int kUnits = TERMS == 2 ? 6 : 5;
+    const int prn8 = (int)(gridDim.x / kUnits);
+    const int unit = blockIdx.x / prn8, prn = blockIdx.x - unit * prn8;
+    const int par = TERMS == 2 ? unit / 3 : 0;
+    const int piece = TERMS == 2 ? unit - 3 * par : unit;
+    const int rounds = TERMS == 2 ? (piece == 2 ? (4 | 15 << 4) : (2 * piece | (2 * piece + 1) << 4)) : (piece | 15 << 4);
     if (prn >= s.n_prn) return;
     // first peak: larger value, smaller flat index on ties (np.argmax's first occurrence)
     Best* const sh = reinterpret_cast<Best*>(lds4);
@@ -679,10 +693,46 @@ __global__ __launch_bounds__(kThreads) void ifft_second_kernel(const SecondArgs 
     __syncthreads();                     // (the record scratch is the first buffer)
 #ifdef SDR_FUSED_STAMPS
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
-    one_unit<false, true, TERMS>(s.a, lds4, tid, prn, bin, rho, prn * (5 * TERMS) + unit, a1, b0, b1, par, stamp_);
+    one_unit<false, true, TERMS>(s.a, lds4, tid, prn, bin, rounds, prn * kUnits + unit, a1, b0, b1, par, stamp_);
 #else
-    one_unit<false, true, TERMS>(s.a, lds4, tid, prn, bin, rho, prn * (5 * TERMS) + unit, a1, b0, b1, par);
+    one_unit<false, true, TERMS>(s.a, lds4, tid, prn, bin, rounds, prn * kUnits + unit, a1, b0, b1, par);
 #endif
+    // ---- TwoCorrelationPeakComparison's ratio (acquisition.py:113) by the PRN's last workgroup.  Every workgroup makes its
+    // records visible device-wide (release), takes a ticket; the one that drew the last ticket reads all of the PRN's records
+    // (loads that go to memory, not to this XCD's L2) and divides.  No workgroup waits for another: nothing can hang.
+    // (ONE release per workgroup, no acquire: an acquire invalidates the XCD's L2 under the workgroups still streaming their
+    // operands from it -- with a fence per thread and an acq_rel ticket the call measured 0.250 ms against 0.228 at N = 25 000)
+    __syncthreads();
+    unsigned* const sh_ticket = reinterpret_cast<unsigned*>(lds4);
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        *sh_ticket = __hip_atomic_fetch_add(&s.tickets[prn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (*sh_ticket != (unsigned)(kUnits - 1) || tid >= 64) return;
+    constexpr int kRec = kUnits * kRecordsPerTransform;
+    double v = -1.0;
+    long long i = 0x7fffffffffffffffLL;
+    for (int k = tid; k < kRec; k += 64) {
+        const Best* const rec = s.a.partials + (size_t)prn * kRec + k;
+        const double rv = __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(&rec->v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const long long ri = __hip_atomic_load(&rec->i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (rv > v || (rv == v && ri < i)) v = rv, i = ri;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_down(v, off, 64);
+        const long long oi = __shfl_down(i, off, 64);
+        if (ov > v || (ov == v && oi < i)) v = ov, i = oi;
+    }
+    if (tid == 0) {
+        s.res_ratio[prn] = v >= 0.0 ? top.v / v : __builtin_nan("");
+        if (s.res_bin != s.out_bin) {
+            s.res_bin[prn] = bin;
+            s.res_code[prn] = code;
+        }
+        __hip_atomic_store(&s.tickets[prn], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Processing order and record slots of a search over bins [0, nbins) x n_prn PRNs.  The first `bins_whole` bins are done
@@ -690,8 +740,10 @@ __global__ __launch_bounds__(kThreads) void ifft_second_kernel(const SecondArgs 
 // operands an XCD has in flight mostly sit in its L2), dealt to the XCDs in contiguous eighths; the transforms of the
 // remaining bins are cut into their five rounds, dealt out behind the whole ones (a workgroup's last, short unit).
 // Record slots are PRN-major: PRN p owns slots [p * per_prn, (p + 1) * per_prn), per_prn = bins_whole + 5 (nbins - bins_whole).
-inline int make_work_list(int n_prn, int nbins, int bins_whole, std::vector<WorkItem>& order, int first[9]) {
-    const int per_prn = bins_whole + 5 * (nbins - bins_whole);
+inline int make_work_list(int n_prn, int nbins, int bins_whole, std::vector<WorkItem>& order, int first[9], int pieces = 5) {
+    // pieces: 5 = one unit per round; 3 = rounds {0, 1}, {2, 3}, {4} (N = 50 000: the operand stage of a unit costs what four
+    // rounds do, and 64 left-over transforms x 3 fit ONE wave of workgroups where x 5 need a wave and a quarter)
+    const int per_prn = bins_whole + pieces * (nbins - bins_whole);
     std::vector<WorkItem> whole, parts;
     for (int b0 = 0; b0 < bins_whole; b0 += 4)
         for (int p0 = 0; p0 < n_prn; p0 += 8)
@@ -699,15 +751,26 @@ inline int make_work_list(int n_prn, int nbins, int bins_whole, std::vector<Work
                 for (int p = p0; p < p0 + 8 && p < n_prn; ++p) whole.push_back({p, b, -1, p * per_prn + b});
     for (int b = bins_whole; b < nbins; ++b)
         for (int p = 0; p < n_prn; ++p)
-            for (int rho = 0; rho < 5; ++rho) parts.push_back({p, b, rho, p * per_prn + bins_whole + 5 * (b - bins_whole) + rho});
-    // XCD x: its eighth of the whole transforms, then its eighth of the single rounds (its workgroups walk the list in
-    // steps of 32: whole transforms first, the short units last)
+            for (int u = 0; u < pieces; ++u) {
+                const int rounds = pieces == 5 ? (u | 15 << 4) : (u == 2 ? (4 | 15 << 4) : (2 * u | (2 * u + 1) << 4));
+                parts.push_back({p, b, rounds, p * per_prn + bins_whole + pieces * (b - bins_whole) + u});
+            }
+    // XCD x: its eighth of the short units, then its eighth of the whole transforms (its workgroups walk the list in steps
+    // of 32)
     order.clear();
     const int nw = (int)whole.size(), np = (int)parts.size();
     first[0] = 0;
+    // The short units go FIRST (round 5): three workgroups in four start with one and run the rest of the launch ~3/4 of a
+    // unit out of step with the others -- the operand stages of an XCD's 32 workgroups no longer all fall into the same
+    // moments -- and no workgroup is left holding a short unit while the others have finished.  Measured, one box, ms of
+    // kernels per 32-PRN call: N = 50 000 0.532 -> 0.511, N = 25 000 0.235 -> 0.228 (gpurun_out/r05_partsfirst.txt).
+    constexpr bool parts_first = true;
     for (int x = 0; x < 8; ++x) {
+        if (parts_first)
+            for (int i = (int)(((long long)np * x) / 8); i < (int)(((long long)np * (x + 1)) / 8); ++i) order.push_back(parts[i]);
         for (int i = (int)(((long long)nw * x) / 8); i < (int)(((long long)nw * (x + 1)) / 8); ++i) order.push_back(whole[i]);
-        for (int i = (int)(((long long)np * x) / 8); i < (int)(((long long)np * (x + 1)) / 8); ++i) order.push_back(parts[i]);
+        if (!parts_first)
+            for (int i = (int)(((long long)np * x) / 8); i < (int)(((long long)np * (x + 1)) / 8); ++i) order.push_back(parts[i]);
         first[x + 1] = (int)order.size();
     }
     return per_prn;

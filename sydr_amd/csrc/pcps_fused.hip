@@ -16,21 +16,23 @@ static_assert(sizeof(fused10k::UnitRecord) == SDR_PCPS_FUSED10K_RECORD_BYTES, "u
 
 // How the fused sweep cuts a search of n_prn x nbins transforms: whole transforms for the bins that fill whole rounds of
 // its 256 workgroups, single rounds for the rest (returns the records per PRN the sweep leaves).
-static int fused_plan(int n_prn, int nbins, int* bins_whole) {
+static int fused_plan(int n_prn, int nbins, int* bins_whole, int pieces) {
     const int rounds = (n_prn * nbins) / 256;
     int bw = rounds > 0 ? (256 * rounds) / n_prn : 0;
     if (bw > nbins) bw = nbins;
     // (more than a round's worth left over -- few PRNs, many bins -- : cutting buys nothing, whole transforms throughout)
     if (n_prn * (nbins - bw) > 256) bw = nbins;
     *bins_whole = bw;
-    return bw + 5 * (nbins - bw);
+    return bw + pieces * (nbins - bw);
 }
+// units a left-over transform is cut into: its five rounds at N = 25 000; rounds {0, 1}, {2, 3}, {4} at N = 50 000
+static int fused_pieces(int terms) { return terms == 2 ? 3 : 5; }
 
 // (terms: 1 at N = 25 000; 2 at N = 50 000, where a unit is one parity of a (PRN, bin) transform and the plan sees
 // 2 nbins virtual bins)
 int sdr_pcps_fused_records_per_prn(int n_prn, int nbins, int terms) {
     int bw;
-    return fused_plan(n_prn, terms * nbins, &bw) * SDR_PCPS_FUSED_RECORDS;
+    return fused_plan(n_prn, terms * nbins, &bw, fused_pieces(terms)) * SDR_PCPS_FUSED_RECORDS;
 }
 
 // C: [n_prn][N] code spectra at N = 25 000; [n_prn][2][N] at N = 50 000 -- the spectrum and its image with the odd half's
@@ -42,8 +44,8 @@ int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void
     if (e->pcps_work_prn != n_prn || e->pcps_work_bins != vbins) {
         std::vector<fused25k::WorkItem> order;
         int bins_whole;
-        fused_plan(n_prn, vbins, &bins_whole);
-        fused25k::make_work_list(n_prn, vbins, bins_whole, order, e->pcps_work_first);
+        fused_plan(n_prn, vbins, &bins_whole, fused_pieces(terms));
+        fused25k::make_work_list(n_prn, vbins, bins_whole, order, e->pcps_work_first, fused_pieces(terms));
         if (int rc = sdr_devbuf_reserve(e, &e->pcps_work, order.size() * sizeof(fused25k::WorkItem))) return rc;
         // (pageable source, tiny: the copy is complete when the stream has been waited for)
         SDR_HIP(hipMemcpyAsync(e->pcps_work.ptr, order.data(), order.size() * sizeof(fused25k::WorkItem), hipMemcpyHostToDevice, e->stream));
@@ -80,7 +82,8 @@ int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void
 }
 
 int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int N, int spc, const void* recs,
-                          int per_prn, void* tops, void* dev_bin, void* dev_code, void* seconds) {
+                          int per_prn, void* tops, void* dev_bin, void* dev_code, void* seconds, void* res_bin, void* res_code,
+                          void* res_ratio) {
     if (N != fused25k::N && N != 2 * fused25k::N) return sdr_fail(SDR_ERR_UNSUPPORTED, "fused PCPS sweep: N = %d", N);
     const int terms = N / fused25k::N;
     fused25k::SecondArgs s = {};
@@ -96,11 +99,21 @@ int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* C, const voi
     s.tops = (Best*)tops;
     s.out_bin = (long long*)dev_bin;
     s.out_code = (long long*)dev_code;
+    // one ticket per PRN, zero between launches (the workgroup that draws a PRN's last ticket sets it back)
+    if (e->pcps_tickets_n < n_prn) {
+        if (int rc = sdr_devbuf_reserve(e, &e->pcps_tickets, (size_t)n_prn * sizeof(unsigned))) return rc;
+        SDR_HIP(hipMemsetAsync(e->pcps_tickets.ptr, 0, (size_t)n_prn * sizeof(unsigned), e->stream));
+        e->pcps_tickets_n = n_prn;
+    }
+    s.tickets = (unsigned*)e->pcps_tickets.ptr;
+    s.res_bin = (long long*)res_bin;
+    s.res_code = (long long*)res_code;
+    s.res_ratio = (double*)res_ratio;
     auto* kernel = terms == 2 ? fused25k::ifft_second_kernel<2> : fused25k::ifft_second_kernel<1>;
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused25k::kLdsBytes);
     ProfScope ps(e, "pcps_inv_fft");
-    // (n_prn x 5 rounds x `terms` parities: one round of one parity of the PRN's winning row per workgroup)
-    hipLaunchKernelGGL(kernel, dim3(5 * terms * ((n_prn + 7) / 8 * 8)), dim3(fused25k::kThreads), fused25k::kLdsBytes, e->stream, s);
+    // (five workgroups per PRN, a round each, at N = 25 000; six -- two parities x rounds {0, 1}, {2, 3}, {4} -- at N = 50 000)
+    hipLaunchKernelGGL(kernel, dim3((terms == 2 ? 6 : 5) * ((n_prn + 7) / 8 * 8)), dim3(fused25k::kThreads), fused25k::kLdsBytes, e->stream, s);
     SDR_HIP(hipGetLastError());
     return SDR_OK;
 }

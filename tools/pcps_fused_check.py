@@ -1,7 +1,7 @@
 """The one-workgroup-per-transform inverse sweep of the map-free search (`pcps_fused`, sydr_amd/csrc/pcps_fused.h) against the
 two-kernel register-resident path, same process, same box: identical peaks / ratios to rounding on a stream with real
 satellites and on noise, then wall time and in-stream kernel time (one HIP-event pair per call) of both, alternating.
-    python tools/pcps_fused_check.py [reps]"""
+    python tools/pcps_fused_check.py [reps] [fs_mhz: 25 | 50]"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,8 @@ from sydr_amd.engine import Engine, FMT_CI8
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 e = Engine(0)
-fs, n = 25e6, 25000
+fs = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 25e6
+n = int(fs / 1000)
 e.iq_alloc(4 * n, FMT_CI8)
 e.code_slots(32)
 for s in range(32):

@@ -1,6 +1,6 @@
 """Where a transform's time goes inside the one-workgroup-per-transform PCPS kernel: shader cycles between phase boundaries,
 summed by wave 0 of every workgroup (diagnostic build:  tools/build_variant.sh stamps pcps_fused -DSDR_FUSED_STAMPS, then
-SYDR_AMD_LIB=tools/scratch/var/lib_stamps.so python tools/pcps_fused_phases.py)."""
+SYDR_AMD_LIB=tools/scratch/var/lib_stamps.so python tools/pcps_fused_phases.py [fs_mhz: 25 | 50])."""
 import ctypes, json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,9 @@ import sydr_amd
 from sydr_amd.engine import Engine, FMT_CI8
 e = Engine(0)
 lib = sydr_amd.load()
-fs, n = 25e6, 25000
+fs = float(sys.argv[1]) * 1e6 if len(sys.argv) > 1 else 25e6
+n = int(fs / 1000)
+whole = 5 if n == 25000 else 10          # whole transforms (units) per workgroup and call at 32 PRNs x 41 bins
 e.iq_alloc(n, FMT_CI8)
 e.iq_upload(np.random.default_rng(0).integers(-60, 60, 2 * n).astype(np.int8), 0)
 e.code_slots(32)
@@ -28,7 +30,8 @@ names = ["top barrier (tail of previous, table)", "column item 0", "column item 
          "round: row stage 1 + barrier", "round: exchange write + barrier", "round: row stage 2 + max"]
 per_call = buf.astype(np.float64) / reps
 tot = per_call.sum(axis=1)
-five = per_call[tot < np.median(tot) * 1.1]      # workgroups with five transforms
-print(json.dumps({"workgroups_with_5": int(len(five)), "cycles_per_transform": {nm: float(five[:, i].mean() / 5) for i, nm in enumerate(names)},
-                  "total_cycles_per_transform": float(five.sum(axis=1).mean() / 5),
+five = per_call[tot < np.median(tot) * 1.1]      # workgroups with the usual number of units
+print(json.dumps({"workgroups_counted": int(len(five)), "units_per_workgroup_assumed": whole,
+                  "cycles_per_transform": {nm: float(five[:, i].mean() / whole) for i, nm in enumerate(names)},
+                  "total_cycles_per_transform": float(five.sum(axis=1).mean() / whole),
                   "max_workgroup_cycles_per_call": float(tot.max()), "median_workgroup_cycles_per_call": float(np.median(tot))}, indent=1))

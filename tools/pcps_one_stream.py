@@ -1,13 +1,14 @@
 """One-stream acquisitions at BASELINE config 2 (32 PRNs, 25 MHz, 41 bins, map-free) for `rocprofv3 --kernel-trace --stats`:
 every sdr_pcps call of this process runs on ONE HIP stream (`pcps_one_stream`), so the per-kernel totals of the profile
 divided by the number of calls ARE the kernel time of one call -- the figure bench.py reports as `kernel_ms_32_prn` from
-its own HIP events, printed here for the same process."""
+its own HIP events, printed here for the same process.  python tools/pcps_one_stream.py [fs_mhz: 25 | 50]"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sydr_amd.engine import Engine, FMT_CI8
 e = Engine(0)
-fs, n = 25e6, 25000
+fs = float(sys.argv[1]) * 1e6 if len(sys.argv) > 1 else 25e6
+n = int(fs / 1000)
 e.iq_alloc(n, FMT_CI8)
 e.iq_upload(np.random.default_rng(0).integers(-60, 60, 2 * n).astype(np.int8), 0)
 e.code_slots(32)

@@ -2,7 +2,7 @@
 # Everything a round's profiles/ entry needs, on the GPU box:  tools/profile_round.sh <tag>
 #   1. tools/profile_bench.sh <tag>      rocprofv3 kernel statistics of the default bench command + separate PMC passes
 #   2. the same bench command WITHOUT the profiler (what the driver's own run measures)
-#   3. one-stream acquisitions under --kernel-trace --stats (tools/pcps_one_stream.py)
+#   3. one-stream acquisitions under --kernel-trace --stats (tools/pcps_one_stream.py), at 25 and at 50 MHz
 # then, back in the build container:  python tools/summarize_pmc.py gpurun_out/prof_<tag> <tag>
 set -u
 TAG=${1:-r00}
@@ -14,4 +14,8 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pcps_one_stream" -- python3 "$ROOT/tools/pcps_one_stream.py" > "$OUT/pcps_one_stream.log" 2>&1
 find "$OUT/pcps_one_stream" -name "*kernel_trace.csv" -size +8M -delete
 tail -1 "$OUT/pcps_one_stream.log"
+# ... and the same at N = 50 000 (configs 4-5's rate: the multignss leg's acquisition)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pcps_one_stream_50" -- python3 "$ROOT/tools/pcps_one_stream.py" 50 > "$OUT/pcps_one_stream_50.log" 2>&1
+find "$OUT/pcps_one_stream_50" -name "*kernel_trace.csv" -size +8M -delete
+tail -1 "$OUT/pcps_one_stream_50.log"
 tail -c 400 "$OUT/bench_plain_run.json"

@@ -42,7 +42,7 @@ def short(name):
     m = re.match(r"((?:fast25k::|fused25k::|fused10k::|fastn::)?[A-Za-z0-9_]+)(<[^>]*>)?", name)
     base, targs = m.group(1), m.group(2) or ""
     if base in ("epl_kernel", "epl2_kernel", "track_kernel", "fft4_rows_kernel", "fft4_cols_kernel", "fft_pass_kernel", "fastn::cols_kernel",
-                "fastn::rows_kernel"):
+                "fastn::rows_kernel", "fused25k::ifft_max_kernel", "fused25k::ifft_second_kernel"):   # (<1>: N = 25 000, <2>: N = 50 000)
         return base + targs.replace(", ", ",")
     return base[:48]
 
@@ -122,8 +122,9 @@ if multi:
                 info[f"multignss_{key}_insts_per_wave"] = big(m[counter]) / big(m["SQ_WAVES"])
 # The acquisition figure: the kernels of ONE sdr_pcps call of the headline search (N = 25 000: the calls that contain a
 # fast25k:: kernel -- the bench also runs searches at other rates, which share the small kernels).  Dispatches are walked
-# in order per counter pass; a call ends with its one ratio_kernel dispatch.
-def pcps_calls(counter, marker=("fast25k", "fused25k")):
+# in order per counter pass; a call ends with its one ratio_kernel dispatch -- or, where the one-workgroup-per-transform
+# kernels ran, with the second sweep, whose last workgroup per PRN divides the two peaks (round 5).
+def pcps_calls(counter, marker=("fast25k", "fused25k::ifft_max_kernel<1>")):
     per_kernel, calls = collections.defaultdict(float), 0
     for path in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
         rows_ = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
@@ -134,7 +135,7 @@ def pcps_calls(counter, marker=("fast25k", "fused25k")):
             if not any(k.startswith(p) for p in PCPS):
                 continue
             cur.append((k, float(r["Counter_Value"])))
-            if k in ("ratio_kernel", "peak_finish_kernel", "fused10k::peaks_kernel"):   # (the call's last kernel: map-free / with a map / 10 MHz fused)
+            if k in ("ratio_kernel", "peak_finish_kernel", "fused10k::peaks_kernel") or k.startswith("fused25k::ifft_second_kernel"):   # (the call's last kernel: map-free / with a map / 10 MHz fused / fused second sweep)
                 if any(name.startswith(marker) for name, _ in cur):
                     calls += 1
                     for name, v in cur:
@@ -154,7 +155,7 @@ if calls and calls_w:
 # ... and of the searches at the other rates bench.py runs (their register-resident kernels carry N1 = N / 200 as a template
 # argument: 50 -> the reference's shipped 10 MHz, 250 -> 50 MHz)
 for marker, key, what in ((("fastn::cols_kernel<50,", "fused10k::search_kernel"), "pcps_10mhz", "ref_config leg: 32 PRNs x 34 bins x 10 blocks x 10000 samples, indices + ratio (no map)"),
-                          (("fastn::cols_kernel<250,",), "pcps_50mhz", "multignss leg: 32 PRNs x 41 bins x 50000 samples, no map")):
+                          (("fastn::cols_kernel<250,", "fused25k::ifft_max_kernel<2>"), "pcps_50mhz", "multignss leg: 32 PRNs x 41 bins x 50000 samples, no map")):
     f_k, c_f = pcps_calls("FETCH_SIZE", marker)
     w_k, c_w = pcps_calls("WRITE_SIZE", marker)
     if c_f and c_w:
@@ -177,7 +178,8 @@ print(json.dumps(info, indent=1))
 import shutil
 prof = os.path.join(repo, "profiles")
 for pattern, name in (("stats/*/*kernel_stats.csv", f"{tag}_bench_kernel_stats.csv"),
-                      ("pcps_one_stream/*/*kernel_stats.csv", f"{tag}_pcps_one_stream_kernel_stats.csv")):
+                      ("pcps_one_stream/*/*kernel_stats.csv", f"{tag}_pcps_one_stream_kernel_stats.csv"),
+                      ("pcps_one_stream_50/*/*kernel_stats.csv", f"{tag}_pcps50_one_stream_kernel_stats.csv")):
     hits = glob.glob(os.path.join(src, pattern))
     if hits:
         shutil.copyfile(hits[0], os.path.join(prof, name))
@@ -185,9 +187,13 @@ for fname, name in (("bench.json", f"{tag}_bench.json"), ("bench_plain_run.json"
     path = os.path.join(src, fname)
     if os.path.exists(path) and os.path.getsize(path):
         shutil.copyfile(path, os.path.join(prof, name))
-log = os.path.join(src, "pcps_one_stream.log")
-stats = os.path.join(prof, f"{tag}_pcps_one_stream_kernel_stats.csv")
-if os.path.exists(log) and os.path.exists(stats):
+for log_name, stats_name, out_name, bench_key in (
+        ("pcps_one_stream.log", f"{tag}_pcps_one_stream_kernel_stats.csv", f"{tag}_pcps_one_stream.json", ("acquisition",)),
+        ("pcps_one_stream_50.log", f"{tag}_pcps50_one_stream_kernel_stats.csv", f"{tag}_pcps50_one_stream.json", ("multignss", "acquisition"))):
+    log = os.path.join(src, log_name)
+    stats = os.path.join(prof, stats_name)
+    if not (os.path.exists(log) and os.path.exists(stats)):
+        continue
     line = [l for l in open(log) if l.startswith("{")][-1]
     rec = json.loads(line)
     total_ns = sum(float(r["TotalDurationNs"]) for r in csv.DictReader(open(stats))
@@ -198,9 +204,12 @@ if os.path.exists(log) and os.path.exists(stats):
     # reports comes from an untraced process: held against that one too)
     plain = os.path.join(src, "bench_plain_run.json")
     try:
-        rec["bench_kernel_ms_32_prn_untraced"] = json.load(open(plain))["acquisition"]["kernel_ms_32_prn"]
+        leg = json.load(open(plain))
+        for k in bench_key:
+            leg = leg[k]
+        rec["bench_kernel_ms_32_prn_untraced"] = leg["kernel_ms_32_prn"]
         rec["agreement_with_untraced_bench"] = rec["rocprof_kernel_ms_per_call"] / rec["bench_kernel_ms_32_prn_untraced"]
     except Exception:
         pass
-    json.dump(rec, open(os.path.join(prof, f"{tag}_pcps_one_stream.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(prof, out_name), "w"), indent=1)
     print(json.dumps(rec))
