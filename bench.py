@@ -495,6 +495,87 @@ def ref_config_leg(eng, cpu_seconds=4.0):
             "closed_loop": closed_loop_leg(eng, items, min(n_epochs, 2000), fs=fs)}
 
 
+def host_fed_leg(eng, items, n_epochs, total, one_launch_out, batch_stream, chunk_s=1.0, pageable_seconds=12.0):
+    """The headline stream fed FROM THE HOST, as a file reader hands it over (rfsignal.py:58-132 reads the recording chunk by
+    chunk): the 60 s of ci8 sit in page-locked host memory, go into the (zeroed) ring a second at a time as asynchronous copies
+    on the engine's stream (sdr_iq_upload_queue) while the batch stream correlates the second before (the plan's item ranges;
+    the straight-line kernels' sign-flipped image of each chunk is made behind its copy and is what the batch stream waits
+    for) -- double-buffered by the two streams, one plan for the whole list made inside the timed region.  Outputs must be
+    bit-identical to the one-launch pass over the device-born stream.  Then the same from a pageable np.memmap of a file
+    (what RFSignal hands out), over the first `pageable_seconds` of the stream.  The bound is the host link, not the kernel."""
+    import tempfile
+    from sydr_amd.engine import FMT_CI8
+    chunk = int(chunk_s * FS) // 8 * 8
+    host = eng.host_alloc(2 * total, np.int8)
+    try:
+        for a in range(0, total, 8 * chunk):                    # (the device-born stream becomes "the recording")
+            b = min(total, a + 8 * chunk)
+            host[2 * a:2 * b] = eng.iq_download(b - a, a)
+        # item ranges per chunk: an epoch goes with the first chunk that completes it for every channel
+        ends = (items["start_sample"] + items["n_samples"])[:n_epochs * N_CH].reshape(n_epochs, N_CH).max(axis=1)
+        bounds = [min(total, (k + 1) * chunk) for k in range((total + chunk - 1) // chunk)]
+        upto = np.searchsorted(ends, bounds, side="right") * N_CH   # items complete once chunk k is in
+
+        def one_pass(source, n_chunks, zero_first):
+            if zero_first:
+                eng.iq_alloc(total, FMT_CI8)                      # a ring of zeros: what is correlated below came over the link
+            eng.sync()
+            t0 = time.perf_counter()
+            plan = eng.epl_plan(items, SPACING, FS)
+            done = 0
+            for k in range(n_chunks):
+                a, b = k * chunk, bounds[k]
+                eng.iq_upload_queue(source[2 * a:2 * b], a)
+                if upto[k] > done:
+                    plan.run(done, int(upto[k]) - done, stream=batch_stream)
+                    done = int(upto[k])
+            eng.stream_sync(batch_stream)
+            eng.sync()
+            dt = time.perf_counter() - t0
+            return plan, done, dt
+
+        plan, done, first_dt = one_pass(host, len(bounds), True)
+        got = plan.fetch()[:done]
+        same = bool(done == n_epochs * N_CH and got.tobytes() == np.ascontiguousarray(one_launch_out[:done]).tobytes())
+        plan.close()
+        times = []
+        for _ in range(3):
+            plan, done, dt = one_pass(host, len(bounds), False)
+            plan.close()
+            times.append(dt)
+        dt = min(times)
+        out = {"x_realtime": total / FS / dt, "pcie_GBps": 2.0 * total / dt / 1e9, "chunk_s": chunk / FS, "ms_per_pass": dt * 1e3,
+               "first_pass_ms": first_dt * 1e3, "passes_ms": [t * 1e3 for t in times], "stream_seconds": total / FS,
+               "bitwise_identical_to_one_launch": same, "bound": "pcie (host link): the kernel alone runs the stream ~4x faster",
+               "memory": "page-locked (sdr_host_alloc)", "includes": "plan creation (one plan, whole list), every copy, the flipped "
+               "ring image per chunk, every launch; one chunk's copy runs beside the chunk before's correlation (two HIP streams)"}
+        if not same:
+            raise SystemExit("host-fed pass differs from the one-launch pass")
+        # ... and from a pageable np.memmap of a file
+        n_page = min(total, int(pageable_seconds * FS) // chunk * chunk)
+        if n_page >= 2 * chunk:
+            tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+            with tempfile.TemporaryDirectory(dir=tmpdir) as tmp:
+                path = os.path.join(tmp, "recording.ci8")
+                host[:2 * n_page].tofile(path)
+                rec = np.asarray(np.memmap(path, dtype=np.int8, mode="r"))
+                k_page = n_page // chunk
+                one_pass(rec, k_page, True)[0].close()
+                plan, done_p, dt_p = one_pass(rec, k_page, False)
+                got_p = plan.fetch()[:done_p]
+                same_p = bool(got_p.tobytes() == np.ascontiguousarray(one_launch_out[:done_p]).tobytes())
+                plan.close()
+                del rec
+            out["pageable"] = {"x_realtime": n_page / FS / dt_p, "pcie_GBps": 2.0 * n_page / dt_p / 1e9, "stream_seconds": n_page / FS,
+                               "ms_per_pass": dt_p * 1e3, "bitwise_identical_to_one_launch": same_p,
+                               "memory": "np.memmap of a file (pageable; the runtime stages it), plan of the whole 60 s list"}
+            if not same_p:
+                raise SystemExit("host-fed pass (pageable) differs from the one-launch pass")
+        return out
+    finally:
+        eng.host_free(host)
+
+
 def per_tick_leg(eng, read_ahead=0):
     """ChannelManager.addNewRFData(1 ms) + run() from Python, 32 channels (tools/per_tick_rate.py); read_ahead: the same
     calls with ChannelManager.enableReadAhead (blocks of epochs computed ahead and handed out tick by tick)."""
@@ -886,6 +967,7 @@ def main():
     ap.add_argument("--no-multignss", action="store_true")
     ap.add_argument("--no-ref-config", action="store_true")
     ap.add_argument("--no-rates", action="store_true", help="skip the E/P/L leg over the other sampling rates")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the leg that streams the recording from host memory")
     ap.add_argument("--cpu-mp-seconds", type=float, default=10.0, help="budget of the all-cores CPU baseline (0: skip)")
     ap.add_argument("--watchdog-seconds", type=float, default=300.0,
                     help="if the legs AFTER the timed headline measurement have not finished by then, print the line with what "
@@ -1171,7 +1253,14 @@ def main():
         result["closed_loop"] = closed_loop_leg(eng, items, min(n_epochs, args.closed_loop_epochs))
         result["closed_loop_dense"] = closed_loop_leg(eng, items, min(n_epochs, args.closed_loop_epochs, 1000), n_ch=768)
         leg_done()
-    plan.close()
+    if rank == 0 and world == 1 and not args.no_host_fed:
+        one_launch_out = plan.fetch()[:n_run].copy()
+        plan.close()
+        result["host_fed"] = host_fed_leg(eng, items, n_epochs, total, one_launch_out, batch_stream)
+        del one_launch_out
+        leg_done()
+    else:
+        plan.close()
     if rank == 0 and world == 1 and not args.no_rates:
         result["rates"] = rates_leg(eng)
         leg_done()

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SDR_ABI_VERSION 5   /* 5: + sdr_bank_tick_mirrored_begin / _end (additive); 4: + sdr_build_id, sdr_epl_plan_create_dev, sdr_bank_tick_mirrored, sdr_iq_upload_begin, sdr_block_schedule, sdr_bank_step_begin / _end (additive) */
+#define SDR_ABI_VERSION 5   /* 5: + sdr_bank_tick_mirrored_begin / _end, sdr_iq_upload_queue, sdr_host_alloc / _free (additive); 4: + sdr_build_id, sdr_epl_plan_create_dev, sdr_bank_tick_mirrored, sdr_iq_upload_begin, sdr_block_schedule, sdr_bank_step_begin / _end (additive) */
 
 typedef struct sdr_engine sdr_engine;
 
@@ -422,6 +422,18 @@ int sdr_bank_tick_mirrored_end(sdr_engine* e, sdr_bank* b, sdr_tick_mirror* m);
  * (sdr_bank_tick_mirrored with n_ran == 0 and n_samples == 0) launches nothing and waits for nothing: the slab is then
  * still in flight when the call returns. */
 int sdr_iq_upload_begin(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset);
+/* A chunk of a recording (any size) queued for the ring WITHOUT being copied first: one asynchronous copy command on the
+ * engine's stream, ordered like everything else queued there; the caller keeps `iq` valid and unchanged until
+ * sdr_engine_sync (or a later synchronous call on the engine) returns.  From page-locked memory (sdr_host_alloc) the call
+ * returns at once and the transfer runs beside whatever other streams compute -- how a file reader feeds the ring a second
+ * of samples at a time while the previous second is correlated (rfsignal.py:58-132 reads the file chunk by chunk; bench.py
+ * `host_fed`); from pageable memory the runtime stages the chunk through its own buffers and the call returns when the last
+ * piece has been handed over.  n_samples up to the ring's capacity, wrapping at its end. */
+int sdr_iq_upload_queue(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset);
+/* Page-locked host memory for recordings that are fed with sdr_iq_upload_queue (hipHostMalloc / hipHostFree on the engine's
+ * device).  The block is the caller's until sdr_host_free; the engine keeps no pointer to it. */
+int sdr_host_alloc(sdr_engine* e, size_t bytes, void** out);
+int sdr_host_free(sdr_engine* e, void* block);
 
 /* Host-only helper of a receiver that tracks ahead (no device work): `records[n_ch][n_cols]` hold `done[r]` epochs per channel
  * computed in one sdr_bank_step while the host still feeds its per-millisecond loop (receiver.py:120-131); this works out

@@ -469,6 +469,31 @@ int sdr_iq_download(sdr_engine* e, void* iq, int64_t n_samples, int64_t ring_off
     return iq_copy(e, iq, n_samples, ring_offset, false);
 }
 
+int sdr_iq_upload_queue(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset) {
+    if (!e) return sdr_fail(SDR_ERR_INVALID, "null engine");
+    return iq_copy(e, const_cast<void*>(iq), n_samples, ring_offset, true, false);
+}
+
+int sdr_host_alloc(sdr_engine* e, size_t bytes, void** out) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!out || bytes == 0) return sdr_fail(SDR_ERR_INVALID, "sdr_host_alloc: NULL result pointer or zero bytes");
+    *out = nullptr;
+    hipError_t err = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (err != hipSuccess) {
+        *out = nullptr;
+        return sdr_fail(SDR_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+    }
+    return SDR_OK;
+}
+
+int sdr_host_free(sdr_engine* e, void* block) {
+    if (int rc = sdr_set_device(e)) return rc;
+    if (!block) return SDR_OK;
+    SDR_HIP(hipStreamSynchronize(e->stream));     // (a queued upload may still read it)
+    SDR_HIP(hipHostFree(block));
+    return SDR_OK;
+}
+
 }  // extern "C"
 
 // Asynchronous upload of a caller-owned (pageable) slab: small slabs -- a receiver tick brings 1 ms, 50 KB at 25 MHz --

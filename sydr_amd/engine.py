@@ -224,10 +224,14 @@ class Engine:
         self.device_id = device_id
         self.iq_fmt = None
         self.iq_capacity = 0
+        self._host_blocks = {}        # page-locked blocks handed out by host_alloc: address -> block
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
         if self._h:
+            for block in list(getattr(self, "_host_blocks", {}).values()):
+                self._lib.sdr_host_free(self._h, block)
+            self._host_blocks = {}
             self._lib.sdr_engine_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -292,6 +296,34 @@ class Engine:
         status = self._lib.sdr_iq_upload_begin(self._h, raw.ctypes.data, raw.size >> 1, ring_offset)
         if status:
             check(status)
+
+    def iq_upload_queue(self, raw: np.ndarray, ring_offset: int = 0):
+        """A chunk of a recording queued for the ring without a copy of its own (sdr_iq_upload_queue): `raw` -- contiguous,
+        the ring's element type -- must stay alive and unchanged until `sync()`.  From `host_alloc` memory the call returns at
+        once and the transfer overlaps what other streams compute."""
+        if not (isinstance(raw, np.ndarray) and raw.ndim == 1 and raw.flags.c_contiguous and raw.dtype == _lib.fmt_dtype(self.iq_fmt)
+                and not raw.size & 1):
+            raise ValueError("iq_upload_queue takes a contiguous 1-D array of interleaved I,Q in the ring's element type")
+        status = self._lib.sdr_iq_upload_queue(self._h, raw.ctypes.data, raw.size >> 1, int(ring_offset))
+        if status:
+            check(status)
+
+    def host_alloc(self, n_elements: int, dtype=np.int8) -> np.ndarray:
+        """Page-locked host memory as a NumPy array (sdr_host_alloc); `host_free(array)` gives it back -- the array must not
+        be used afterwards."""
+        dtype = np.dtype(dtype)
+        block = C.c_void_p()
+        check(self._lib.sdr_host_alloc(self._h, int(n_elements) * dtype.itemsize, C.byref(block)))
+        buf = (C.c_char * (int(n_elements) * dtype.itemsize)).from_address(block.value)
+        arr = np.frombuffer(buf, dtype=dtype)
+        self._host_blocks[arr.ctypes.data] = block
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        block = self._host_blocks.pop(arr.ctypes.data, None)
+        if block is None:
+            raise ValueError("not a block of host_alloc (or freed already)")
+        check(self._lib.sdr_host_free(self._h, block))
 
     def iq_download(self, n_samples: int, ring_offset: int = 0) -> np.ndarray:
         out = np.empty(2 * int(n_samples), dtype=_lib.fmt_dtype(self.iq_fmt))
