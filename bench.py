@@ -576,12 +576,13 @@ def host_fed_leg(eng, items, n_epochs, total, one_launch_out, batch_stream, chun
         eng.host_free(host)
 
 
-def per_tick_leg(eng, read_ahead=0):
+def per_tick_leg(eng, read_ahead=0, tick_server=False):
     """ChannelManager.addNewRFData(1 ms) + run() from Python, 32 channels (tools/per_tick_rate.py); read_ahead: the same
-    calls with ChannelManager.enableReadAhead (blocks of epochs computed ahead and handed out tick by tick)."""
+    calls with ChannelManager.enableReadAhead (blocks of epochs computed ahead and handed out tick by tick); tick_server: the
+    same calls answered by the resident kernel (sdr_set_option "tick_server": no launch, no stream synchronisation per tick)."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import per_tick_rate
-    return per_tick_rate.measure(600 if read_ahead else 300, N_CH, engine=eng, read_ahead=read_ahead)
+    return per_tick_rate.measure(600 if read_ahead or tick_server else 300, N_CH, engine=eng, read_ahead=read_ahead, tick_server=tick_server)
 
 
 def closed_loop_leg(eng, items, n_epochs, n_ch=N_CH, fs=None):
@@ -1266,6 +1267,7 @@ def main():
         leg_done()
     if rank == 0 and world == 1 and not args.no_per_tick:
         result["per_tick"] = per_tick_leg(eng)
+        result["per_tick_server"] = per_tick_leg(eng, tick_server=True)
         result["per_tick_readahead"] = per_tick_leg(eng, read_ahead=50)
         leg_done()
     if rank == 0 and world == 1 and not args.no_ref_config:

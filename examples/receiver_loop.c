@@ -4,7 +4,8 @@
  *     sdr_bank_tick_mirrored  -- who is ready (channel.py:137-146), one epoch for them on the device, the caller's mirrors of
  *                                the channel bank and the rows the packets report (channelManager.py:149-188) updated in place
  * 32 channels @ 25 MHz: acquisition of the first millisecond, then `ticks` milliseconds tracked tick by tick with the host as
- * IQ source; prints where the channels ended and the time per tick.
+ * IQ source; prints where the channels ended and the time per tick.  A second argument `server` switches the resident
+ * tick server on (sdr_set_option "tick_server"): the same two calls per tick, answered by a kernel that is already there.
  * Build:  gcc -std=c99 -O2 -Iinclude examples/receiver_loop.c -Lsydr_amd -lsydr_amd -lm -Wl,-rpath,'$ORIGIN/../sydr_amd' -o examples/receiver_loop
  */
 #define _POSIX_C_SOURCE 199309L
@@ -36,6 +37,7 @@ enum { N_CH = 32 };
 int main(int argc, char** argv) {
     const double fs = 25e6, code_rate = 1.023e6;
     const int ticks = argc > 1 ? atoi(argv[1]) : 400;
+    const int server = argc > 2 && !strcmp(argv[2], "server");
     const int spms = (int)(fs * 1e-3);                   /* samples per millisecond */
     const int64_t ring = 100 * (int64_t)spms;            /* the reference's 100 ms ring (channelManager.py:57) */
     const int64_t total = (int64_t)(ticks + 2) * spms;
@@ -103,6 +105,7 @@ int main(int argc, char** argv) {
     m.states = states, m.last = last, m.epochs_since_tow = since_tow, m.tracking = tracking, m.lost = lost, m.host_flags = host_flags;
     m.ran = ran, m.records = records, m.updates = updates;
 
+    if (server) CK(sdr_set_option(e, "tick_server", 1));
     long epochs = 0, bits = 0;
     double t_ticks = 0.0;
     for (int k = 1; k <= ticks; ++k) {
@@ -129,6 +132,12 @@ int main(int argc, char** argv) {
     }
     printf("%d ticks, %ld epochs, %ld navigation bits, %d of %d channels on their Doppler (or its 500 Hz alias)\n", ticks, epochs, bits, locked, N_CH);
     if (ticks > 100) printf("%.1f us per tick = %.1f x real time\n", t_ticks / (ticks - 100), 1000.0 / (t_ticks / (ticks - 100)));
+    if (server) {
+        int64_t st[4];
+        CK(sdr_tick_server_stats(e, st));
+        printf("tick server: %lld requests answered, %lld server(s) started%s\n", (long long)st[1], (long long)st[2], st[3] ? ", gave up" : "");
+        if (st[3] || st[1] < ticks - 2) return 4;
+    }
     sdr_bank_destroy(e, bank);
     sdr_engine_destroy(e);
     free(stream);

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SDR_ABI_VERSION 5   /* 5: + sdr_bank_tick_mirrored_begin / _end, sdr_iq_upload_queue, sdr_host_alloc / _free (additive); 4: + sdr_build_id, sdr_epl_plan_create_dev, sdr_bank_tick_mirrored, sdr_iq_upload_begin, sdr_block_schedule, sdr_bank_step_begin / _end (additive) */
+#define SDR_ABI_VERSION 5   /* 5: + sdr_bank_tick_mirrored_begin / _end, sdr_iq_upload_queue, sdr_host_alloc / _free, option "tick_server" + sdr_tick_server_stats (additive); 4: + sdr_build_id, sdr_epl_plan_create_dev, sdr_bank_tick_mirrored, sdr_iq_upload_begin, sdr_block_schedule, sdr_bank_step_begin / _end (additive) */
 
 typedef struct sdr_engine sdr_engine;
 
@@ -412,6 +412,25 @@ int sdr_bank_tick_mirrored(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n
 int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
                                  int64_t write_index, sdr_tick_mirror* m);
 int sdr_bank_tick_mirrored_end(sdr_engine* e, sdr_bank* b, sdr_tick_mirror* m);
+/* sdr_set_option(e, "tick_server", 1): the steady tick (sdr_bank_tick_mirrored*, the slab handed over by
+ * sdr_iq_upload_begin) is answered by a RESIDENT kernel instead of launches and a stream synchronisation -- what the
+ * reference's manager gets from channel processes that wait on an Event between ticks (channel.py:121-160).  The cluster form
+ * of the tracking kernel stays on the device with one more workgroup, the doorman, which polls a request word in page-locked
+ * memory, pulls the slab into the ring, releases the trackers and gathers their answers; who is ready is decided on the
+ * device by the arithmetic of channel.py:137-146 and must agree with the caller's mirror (SDR_ERR_STATE otherwise).  Same
+ * clusters and order of additions as the plain tick: same bits.  Served: banks whose tracking channels run one tap count
+ * and number at most a quarter of the compute units (64); anything else takes the plain path.  Any other call on the engine
+ * (a search, a put, an upload by another route, sdr_engine_destroy) tells the server to leave first and waits for it; the
+ * next steady tick starts a new one.  Nothing on the device waits without a bound: the server leaves by itself after 0.2 s
+ * without a request; the host waits at most 0.25 s for an answer, then reports SDR_ERR_HIP and goes back to plain ticks.
+ * out4: {a server is resident now, requests answered, servers started, the engine went back to plain ticks for good}. */
+int sdr_tick_server_stats(sdr_engine* e, int64_t* out4);
+/* Where the answered requests' time went ON THE DEVICE, microseconds summed over them (the doorman's wall-clock stamps):
+ * {slab pulled into the ring, trackers released, every channel answered, answers gathered into page-locked memory}. */
+int sdr_tick_server_phases(sdr_engine* e, double* out4);
+/* ... and channel 0's own tick (lane 0 of its first part): {release seen, samples visible, correlated, sums exchanged, loops
+ * updated, answer written}. */
+int sdr_tick_server_tracker_phases(sdr_engine* e, double* out6);
 /* sdr_iq_upload without the wait: the samples are copied out of `iq` before the call returns (the caller may reuse
  * its buffer), their transfer into the ring is queued on the engine's stream and ordered before everything queued
  * there afterwards (slabs above 1 MiB are uploaded synchronously).  sdr_engine_sync completes it for readers on

@@ -173,6 +173,9 @@ _PROTOTYPES = {
     "sdr_bank_tick_mirrored_end": (C.c_int, [_VP, _VP, C.POINTER(TickMirror)]),
     "sdr_iq_upload_begin": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64]),
     "sdr_iq_upload_queue": (C.c_int, [_VP, _VP, C.c_int64, C.c_int64]),
+    "sdr_tick_server_stats": (C.c_int, [_VP, C.POINTER(C.c_int64)]),
+    "sdr_tick_server_phases": (C.c_int, [_VP, C.POINTER(C.c_double)]),
+    "sdr_tick_server_tracker_phases": (C.c_int, [_VP, C.POINTER(C.c_double)]),
     "sdr_host_alloc": (C.c_int, [_VP, C.c_size_t, C.POINTER(_VP)]),
     "sdr_host_free": (C.c_int, [_VP, _VP]),
     "sdr_block_schedule": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, C.c_int64, _VP, _VP, C.c_int] + [_VP] * 15),

@@ -25,9 +25,18 @@ int sdr_fail(int status, const char* fmt, ...) {
     return status;
 }
 
-int sdr_set_device(sdr_engine* e) {
+int sdr_set_device_keep(sdr_engine* e) {
     if (!e) return sdr_fail(SDR_ERR_INVALID, "engine is NULL");
     SDR_HIP(hipSetDevice(e->device));
+    return SDR_OK;
+}
+
+// Every entry point comes through here: whatever it is about to do -- another launch, an allocation, a channel's state
+// written from the host -- a resident tick server (track.hip) must not be in its way, nor keep its copy of what changes.
+int sdr_set_device(sdr_engine* e) {
+    if (int rc = sdr_set_device_keep(e)) return rc;
+    if (e->srv_running)
+        if (int rc = sdr_tick_server_stop(e)) return rc;
     return SDR_OK;
 }
 
@@ -197,6 +206,10 @@ int sdr_set_option(sdr_engine* e, const char* name, int value) {
     else if (!strcmp(name, "pcps_no_spectra_cache")) e->pcps_no_spec_cache = value != 0;
     else if (!strcmp(name, "ingest_by_copy_command")) e->ingest_by_copy = value != 0;
     else if (!strcmp(name, "track_one_launch_tick")) e->track_one_launch_tick = value != 0;
+    else if (!strcmp(name, "tick_server")) {
+        if (e->srv_running) (void)sdr_tick_server_stop(e);
+        e->tick_server_opt = value != 0;
+    }
     else if (!strcmp(name, "pcps_prn_chunk")) e->pcps_prn_chunk = value;
     else if (!strcmp(name, "epl_no_chip_variant")) e->epl_no_chip = value != 0;
     else if (!strcmp(name, "epl_no_split_variant")) e->epl_no_split = value != 0;
@@ -296,6 +309,7 @@ static void free_ctx(StreamCtx* c) {
 void sdr_engine_destroy(sdr_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    sdr_tick_server_free(e);            // (a resident tick server leaves first: the synchronisation below would wait for it)
     (void)hipDeviceSynchronize();
     free_ctx(&e->ctx0);
     for (StreamCtx* c : e->streams) {
@@ -496,13 +510,32 @@ int sdr_host_free(sdr_engine* e, void* block) {
 
 }  // extern "C"
 
+int sdr_iq_flush_server_slab(sdr_engine* e) {
+    if (!e->srv_slab_pending) return SDR_OK;
+    e->srv_slab_pending = false;
+    const size_t sb = sdr_fmt_bytes(e->iq_fmt);
+    const size_t bytes = (size_t)e->srv_slab_n * sb, off_b = (size_t)e->srv_slab_off * sb, cap_b = (size_t)e->iq_capacity * sb;
+    const int half = e->srv_slab_half;
+    const char* stage = (const char*)e->slab_pinned + (half ? e->slab_bytes : 0);
+    const size_t n16 = bytes / 16;
+    const unsigned blocks = (unsigned)((n16 + 255) / 256 < 64 ? (n16 + 255) / 256 : 64);
+    hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)stage, (uint4*)e->iq, n16, off_b / 16, cap_b / 16);
+    SDR_HIP(hipGetLastError());
+    if (!e->slab_done[half]) SDR_HIP(hipEventCreateWithFlags(&e->slab_done[half], hipEventDisableTiming));
+    SDR_HIP(hipEventRecord(e->slab_done[half], e->stream));
+    e->slab_busy[half] = true;
+    return SDR_OK;
+}
+
 // Asynchronous upload of a caller-owned (pageable) slab: small slabs -- a receiver tick brings 1 ms, 50 KB at 25 MHz --
 // go through a page-locked staging buffer of the engine (one memcpy here, then a DMA the stream does not wait for the
 // host on); the caller's pointer is not kept past return either way.
 int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset) {
     const size_t bytes = n_samples > 0 ? (size_t)n_samples * sdr_fmt_bytes(e->iq_fmt) : 0;
     if (!iq || bytes == 0 || bytes > (1u << 20)) return iq_copy(e, const_cast<void*>(iq), n_samples, ring_offset, true, false);
-    if (int rc = sdr_set_device(e)) return rc;
+    if (int rc = sdr_set_device_keep(e)) return rc;           // (a resident tick server stays: it may be the one to pull this slab)
+    if (e->srv_slab_pending)                                   // (a slab still waiting for a request: into the ring the ordinary way first)
+        if (int rc = sdr_iq_flush_server_slab(e)) return rc;
     if (bytes > e->slab_bytes) {
         SDR_HIP(hipStreamSynchronize(e->stream));   // (an earlier slab's DMA may still read the old buffer)
         if (e->slab_pinned) SDR_HIP(hipHostFree(e->slab_pinned));
@@ -541,6 +574,15 @@ int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_
         const size_t off_b = (size_t)off * sb, cap_b = (size_t)cap * sb;
         if (off_b % 16 == 0 && bytes % 16 == 0 && cap_b % 16 == 0) {
             sdr_iq_mark_written(e, off, n_samples);
+            if (e->srv_running) {
+                // the resident tick server's doorman pulls it out of the staging half with the next request (track.hip): no
+                // launch here.  The half is busy until that request has been answered (or the slab flushed the ordinary way).
+                e->srv_slab_pending = true;
+                e->srv_slab_half = half;
+                e->srv_slab_off = off;
+                e->srv_slab_n = n_samples;
+                return SDR_OK;
+            }
             const size_t n16 = bytes / 16;
             const unsigned blocks = (unsigned)((n16 + 255) / 256 < 64 ? (n16 + 255) / 256 : 64);
             hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)stage, (uint4*)e->iq, n16,

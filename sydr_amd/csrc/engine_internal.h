@@ -121,6 +121,15 @@ struct sdr_engine {
     hipEvent_t pcps_ev[2] = {nullptr, nullptr};
     bool pcps_no_fast = false;       // diagnostics: keep the general four-step kernels where the N = 125 x 200 ones would run
     bool track_one_launch_tick = false;  // "track_one_launch_tick": a one-epoch step as one workgroup per channel in one launch
+    // "tick_server": the steady receiver tick served by a resident kernel (track.hip).  srv_running: one is resident NOW --
+    // every call on the engine but the tick's own stops it first (sdr_set_device); a slab handed over by sdr_iq_upload_begin
+    // while it runs waits in its staging half for the next request (srv_slab_*).
+    bool tick_server_opt = false;
+    bool srv_running = false;
+    struct TickServerState* srv = nullptr;
+    bool srv_slab_pending = false;
+    int srv_slab_half = 0;
+    int64_t srv_slab_off = 0, srv_slab_n = 0;
     bool ingest_by_copy = false;     // "ingest_by_copy_command": queued slabs go into the ring by hipMemcpyAsync, not by the ingest kernel
     bool pcps_no_spec_cache = false; // "pcps_no_spectra_cache": conj(fft(code)) recomputed by every search, as the reference does (kaplan:184-185)
     bool pcps_force_passes = false;  // diagnostics: use the one-kernel-per-radix-pass transform instead of the four-step one
@@ -145,6 +154,14 @@ int sdr_pinned_reserve(sdr_engine* e, StreamCtx* ctx, size_t bytes);
 StreamCtx* sdr_stream_ctx(sdr_engine* e, int stream_id);   // nullptr when the id does not exist
 // Queue the ring write of sdr_iq_upload on the engine's stream without waiting for it.
 int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset);
+// hipSetDevice WITHOUT stopping a resident tick server (the tick's own entry points); sdr_set_device stops it.
+int sdr_set_device_keep(sdr_engine* e);
+// track.hip: tell the resident tick server to leave and wait for it (bounded); a slab it had not pulled yet goes into the ring
+// the ordinary way.  No-op when none runs.
+int sdr_tick_server_stop(sdr_engine* e);
+void sdr_tick_server_free(sdr_engine* e);
+// engine.hip: the slab waiting in a staging half (srv_slab_*) into the ring by the ingest kernel, on the engine's stream
+int sdr_iq_flush_server_slab(sdr_engine* e);
 // Ring samples [offset, offset + n) (modulo capacity) are being written on e->stream: the flipped image is stale there.
 void sdr_iq_mark_written(sdr_engine* e, int64_t ring_offset, int64_t n_samples);
 // The flipped image of a ci8 ring, up to date with everything queued on e->stream, usable from `stream`.

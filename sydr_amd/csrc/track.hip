@@ -21,6 +21,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #ifdef SDR_TRACE_TRACK
@@ -46,6 +48,226 @@ namespace {
 using namespace sdr;
 
 constexpr int kMaxParts = 8;
+
+// ------------------------------------------------------------------------------------------------ the tick server
+// The receiver's per-millisecond loop (receiver.py:120-131: addNewRFData(1 ms); run()) pays a kernel launch and a stream
+// synchronisation per tick: ~13 of a tick's ~29 us in the library (tools/ubench_pingpong.hip: a round trip host -> resident
+// workgroup -> host through page-locked words takes 1.8 us, an empty launch + synchronisation 12.5).  With
+// sdr_set_option("tick_server", 1) the cluster form of the kernel stays RESIDENT between ticks: one more workgroup, the
+// doorman, polls a request word in page-locked memory; a request carries the ring's write index and the slab addNewRFData
+// staged; the doorman pulls the slab into the ring, releases the trackers (a device word they poll), every channel whose next
+// epoch is complete runs it exactly as a block launch would (same cluster, same order of additions: the bits of a plain
+// tick), the doorman gathers records and states into page-locked memory and raises the done word the host spins on.
+// Nothing waits without a bound: the doorman gives up after `idle_ticks` without a request (the host starts a new server
+// with the next tick), a tracker after twice that without a release, the doorman after `busy_ticks` without the channels'
+// answers (fault), the exchange as ever after kSpinLimit polls; the host waits a bounded time for the done word and falls
+// back to plain launches.  Every other call on the engine stops the server first (sdr_set_device).
+constexpr unsigned kServerStop = 0xFFFFFFFFu;
+struct TickServerHost {            // page-locked: the words the host and the doorman share
+    unsigned req_seq;              // host: request number, 1, 2, 3, ...; kServerStop = leave
+    unsigned done_seq;             // doorman: the last request answered
+    unsigned alive;                // doorman: 1 while the server runs
+    unsigned fault;                // doorman: why it gave up (1 idle, 2 a channel never answered, 3 exchange fault)
+    long long write_index;         // request: the ring's write index after the slab
+    unsigned long long slab_src16; // request: the slab's first 16-byte granule inside the staging block; slab_n16 = 0: no slab
+    unsigned long long slab_n16, slab_first16;   // granules, first ring granule
+    // doorman: wall-clock stamps (100 MHz) of the last request -- seen, slab in the ring, trackers released, all channels
+    // answered, answers in page-locked memory (sdr_tick_server_stats' second half: where a served tick's time goes)
+    unsigned long long stamps[6];
+    unsigned long long tracker[12]; // ... and channel 0's own: release seen, samples visible, correlated, exchanged, updated, answered
+};
+struct TickServerDev {             // device memory: the words the doorman and the trackers share
+    unsigned go_seq;               // doorman: the request the trackers may work on (kServerStop: leave)
+    unsigned done_count;           // trackers: channels that have answered, all requests together
+    unsigned pull_count;           // the doorman's helpers: shares of slabs pulled, all requests together
+    long long write_index;
+    int fault;                     // a cluster exchange timed out
+    unsigned long long t[12];      // channel 0, part 0, lane 0: wall-clock stamps of its last tick (sdr_tick_server_phases); [8..11]: trace build
+};
+struct TickServer {
+    TickServerHost* host;          // nullptr: not a server launch
+    TickServerDev* dev;
+    const uint4* staging;          // page-locked slab staging of the engine
+    uint4* ring16;
+    unsigned long long ring_n16;
+    int* ran;                      // device [n_ch]: 1 the channel ran its epoch, 0 not ready, -1 stopped (NCO left the replica / the ring)
+    sdr_track_state* st_out;       // device [n_ch]
+    sdr_track_epoch* rec_out;      // device [n_ch]
+    int* h_ran;                    // page-locked copies the doorman fills
+    sdr_track_state* h_st;
+    sdr_track_epoch* h_rec;
+    unsigned long long idle_ticks, busy_ticks;   // of wall_clock64() (100 MHz)
+};
+
+// The doorman: one workgroup of 256 threads, a launch of its own beside the trackers' (the cluster of 32 channels x 8
+// parts fills the cooperative launch's 256 workgroups; the doorman needs a few registers and no LDS to speak of, and shares a
+// compute unit with one of them).
+// (eight waves, two per SIMD, few registers: it has to fit beside a tracker workgroup that holds 256 registers per lane on
+// every SIMD of its compute unit -- sixteen waves did not.  A 50 KB slab is seven 16-byte loads per lane, four in flight.)
+constexpr int kDoorThreads = 512;
+// One workgroup reads the host's memory at a few GB/s (a 50 KB slab took it 19 us): kDoorGroups workgroups pull an equal share
+// each.  All of them watch the request word; the first is the doorman proper, the others tell it through a device counter
+// when their share is in the ring, and leave when it does (or by their own, longer, clock).
+constexpr int kDoorGroups = 8;
+__device__ __attribute__((unused)) void tick_server_doorman(const TickServer& s, const int n_ch, const int tid, unsigned* sh_words,
+                                                            unsigned long long* sh_q, const int group) {
+    unsigned served = 0, requests = 0;
+    unsigned long long t_last = wall_clock64();
+    unsigned why = 0;
+    const bool helper = group != 0;
+    if (tid == 0 && !helper) __hip_atomic_store(&s.host->alive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (;;) {
+        if (tid == 0) {
+            // (one look per turn of the loop, a short sleep between turns: eight workgroups reading the host's word back to back
+            // slowed the trackers' own traffic -- the channels' answers took 14.9 instead of 12.0 us)
+            unsigned seq = __hip_atomic_load(&s.host->req_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (seq == served && wall_clock64() - t_last > (helper ? 2 * s.idle_ticks : s.idle_ticks)) seq = kServerStop, sh_words[1] = 1;
+            if (helper && seq == served && __hip_atomic_load(&s.dev->go_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kServerStop)
+                seq = kServerStop;                       // (the doorman has left)
+            if (seq != served && seq != kServerStop) {   // a request: its words (written before its number) for everybody
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                sh_q[0] = (unsigned long long)*(volatile long long*)&s.host->write_index;
+                sh_q[1] = *(volatile unsigned long long*)&s.host->slab_n16;
+                sh_q[2] = *(volatile unsigned long long*)&s.host->slab_src16;
+                sh_q[3] = *(volatile unsigned long long*)&s.host->slab_first16;
+            }
+            sh_words[0] = seq;
+        }
+        __syncthreads();
+        const unsigned seq = sh_words[0];
+        __syncthreads();
+        if (seq == served) {
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        if (seq == kServerStop) {
+            why = sh_words[1];
+            break;
+        }
+        unsigned long long stamp[6];
+        stamp[0] = wall_clock64();
+        const long long wi = (long long)sh_q[0];
+        const unsigned long long n16 = sh_q[1], src16 = sh_q[2], first16 = sh_q[3];
+        // this workgroup's share of the slab: granules [lo, hi)
+        const unsigned long long lo = n16 * (unsigned long long)group / kDoorGroups, hi = n16 * (unsigned long long)(group + 1) / kDoorGroups;
+        for (unsigned long long i0 = lo + tid; i0 < hi; i0 += 4 * kDoorThreads) {     // four loads per lane in flight, then their stores
+            uint4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + (unsigned long long)k * kDoorThreads < hi) v[k] = s.staging[src16 + i0 + (unsigned long long)k * kDoorThreads];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long i = i0 + (unsigned long long)k * kDoorThreads;
+                if (i < hi) {
+                    unsigned long long d = first16 + i;
+                    if (d >= s.ring_n16) d -= s.ring_n16;
+                    s.ring16[d] = v[k];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every wave: its stores have left (the barrier orders them ...)
+        __syncthreads();                                          // ... before lane 0's device-wide release below)
+        ++requests;
+        if (helper) {
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_fetch_add(&s.dev->pull_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            served = seq;
+            t_last = wall_clock64();
+            continue;
+        }
+        if (tid == 0) {
+            s.dev->write_index = wi;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // the helpers' shares (bounded: a helper that never shows up is a fault like a channel that never answers)
+            unsigned ok_pull = 1;
+            {
+                const unsigned want = requests * (unsigned)(kDoorGroups - 1);
+                const unsigned long long t0 = wall_clock64();
+                while (n16 && __hip_atomic_load(&s.dev->pull_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+                    if (wall_clock64() - t0 > s.busy_ticks) {
+                        ok_pull = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            sh_words[3] = ok_pull;
+            stamp[1] = wall_clock64();
+            if (ok_pull) __hip_atomic_store(&s.dev->go_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stamp[2] = wall_clock64();
+            const unsigned target = requests * (unsigned)n_ch;
+            const unsigned long long t0 = wall_clock64();
+            unsigned ok = 1;
+#ifdef SDR_SRV_TRACE
+            unsigned long long seen[4] = {0, 0, 0, 0};      // first sight of 1, n/2, n - 1, n answers
+#endif
+            for (;;) {
+                const unsigned c = __hip_atomic_load(&s.dev->done_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SDR_SRV_TRACE
+                const unsigned have = c - (target - (unsigned)n_ch);
+                const unsigned long long now = wall_clock64();
+                if (have >= 1 && !seen[0]) seen[0] = now;
+                if (have >= (unsigned)n_ch / 2 && !seen[1]) seen[1] = now;
+                if (have >= (unsigned)n_ch - 1 && !seen[2]) seen[2] = now;
+                if (have >= (unsigned)n_ch && !seen[3]) seen[3] = now;
+#endif
+                if (c == target) break;
+                if (wall_clock64() - t0 > s.busy_ticks) {
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+#ifdef SDR_SRV_TRACE
+            for (int k = 0; k < 4; ++k) s.dev->t[8 + k] = seen[k] - t0;
+#endif
+            sh_words[2] = ok && sh_words[3];
+            stamp[3] = wall_clock64();
+        }
+        __syncthreads();
+        if (!sh_words[2]) {
+            why = 2;
+            break;
+        }
+        if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the channels' answers, written on other XCDs (one
+        __syncthreads();                                                     // invalidation serves the compute unit)
+        {   // answers -> page-locked memory, 8 bytes per lane
+            const int w_st = n_ch * (int)(sizeof(sdr_track_state) / 8), w_rec = n_ch * (int)(sizeof(sdr_track_epoch) / 8);
+            for (int i = tid; i < n_ch; i += kDoorThreads) s.h_ran[i] = s.ran[i];
+            for (int i = tid; i < w_st; i += kDoorThreads) reinterpret_cast<unsigned long long*>(s.h_st)[i] = reinterpret_cast<const unsigned long long*>(s.st_out)[i];
+            for (int i = tid; i < w_rec; i += kDoorThreads) reinterpret_cast<unsigned long long*>(s.h_rec)[i] = reinterpret_cast<const unsigned long long*>(s.rec_out)[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (tid == 0) {
+            stamp[4] = wall_clock64();
+            for (int k = 0; k < 5; ++k) s.host->stamps[k] = stamp[k];
+            for (int k = 0; k < 12; ++k) s.host->tracker[k] = s.dev->t[k];
+            if (__hip_atomic_load(&s.dev->fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                __hip_atomic_store(&s.host->fault, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&s.host->done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        served = seq;
+        t_last = wall_clock64();
+    }
+    if (tid == 0 && !helper) {
+        __hip_atomic_store(&s.dev->go_seq, kServerStop, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (why) __hip_atomic_store(&s.host->fault, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&s.host->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+#ifndef SDR_TRACK_DENSE_TU
+__global__ __launch_bounds__(kDoorThreads) void tick_doorman_kernel(const TickServer srv, int n_ch) {
+    __shared__ unsigned words[4];
+    __shared__ unsigned long long q[4];
+    if (threadIdx.x < 4) words[threadIdx.x] = 0, q[threadIdx.x] = 0;
+    __syncthreads();
+    tick_server_doorman(srv, n_ch, (int)threadIdx.x, words, q, (int)blockIdx.x);
+}
+#endif
 // Exchange line of one part and parity: 4*NT tagged half-values padded to whole 128-byte lines (16 words for E/P/L,
 // 32 for five taps).
 constexpr int xchg_words(int nt) { return 4 * nt <= 16 ? 16 : 32; }
@@ -101,7 +323,10 @@ struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind 
     // (same operands => same bits): atan(qP'/iP') of the previous epoch, the Kaplan natural frequencies for the
     // bandwidths they were computed from, the Borre filter ratios
     double at_prev, w0f, w0p, w0f_bw, w0p_bw, pll_r1, pll_r2, dll_r1, dll_r2;
-    double pad_sh_;            // (keeps the struct a multiple of 16 bytes)
+    unsigned gate;             // (tick server) the release the workgroup's lane 0 saw at the top of the tick
+    unsigned pad_sh_;          // (keeps the struct a multiple of 16 bytes)
+    long long gate_wi;         // ... and the request's write index
+    long long pad_sh2_;
     sdr_track_state st;        // the loop state; each update role owns a disjoint set of its fields
     sdr_loop_cfg cfg;
 };
@@ -507,7 +732,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                                                         const uint32_t* __restrict__ luts,
                                                         int lut_words, int lut_stride, int use_prefix,
                                                         int n_ch, int parts, unsigned long long* xchg,
-                                                        int* __restrict__ fault, int phase, unsigned tag_base) {
+                                                        int* __restrict__ fault, int phase, unsigned tag_base, const TickServer srv) {
     constexpr int kTaps = NT;
     constexpr int kXchgWords = xchg_words(NT);
     constexpr bool kCluster = THREADS == 256 && WAVES == 1;
@@ -518,6 +743,9 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + (use_prefix ? THREADS * kPrefixSlots : 0));
 
     const int tid = threadIdx.x;
+    // (uniform) a tick-server launch of the cluster form: resident, every tick behind the doorman's release
+    const bool server = kCluster && srv.host != nullptr;
+    const int n_wg = (int)gridDim.x;
     // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8): the parts of one channel are
     // blockIdx-es with the same residue, so a cluster shares one XCD's L2 for its exchange lines.
     int ch, part;
@@ -526,11 +754,11 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     if (collect_only) {
         ch = blockIdx.x;
         part = 0;
-    } else if (parts == 1 || gridDim.x % (8 * parts) != 0) {
+    } else if (parts == 1 || n_wg % (8 * parts) != 0) {
         ch = blockIdx.x / parts;
         part = blockIdx.x % parts;
     } else {
-        const int per_xcd = gridDim.x / 8;               // workgroups per XCD = channels per XCD * parts
+        const int per_xcd = n_wg / 8;                    // workgroups per XCD = channels per XCD * parts
         const int xcd = blockIdx.x % 8, q = blockIdx.x / 8;
         ch = xcd * (per_xcd / parts) + q / parts;
         part = q % parts;
@@ -637,6 +865,16 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         const int64_t p0 = s_init.current_sample % capacity;
         ring_pos = ((int64_t)__builtin_amdgcn_readfirstlane((int)(p0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
     }
+    // the channel's state as the roles' LDS copy and their last announcement give it (lane 0 of the recording part)
+    auto compose_state = [&]() {
+        st.current_sample = sh->ep.start_sample;
+        st.n_samples = sh->ep.n;
+        st.carrier_hz = sh->ep.carrier_hz;
+        st.rem_carrier = sh->ep.rem_carrier;
+        st.rem_code = sh->ep.rem_code;
+        st.code_step = sh->ep.code_step;
+    };
+    unsigned server_tick = 0;                              // (server) requests this workgroup has seen
     for (int epoch = 0; epoch < n_epochs; ++epoch) {
         TRACK_MARK(5);
         __syncthreads();
@@ -644,6 +882,52 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
 #ifdef SDR_TRACE_TRACK
         const unsigned long long wave_mark_ = wall_clock64();
 #endif
+        if constexpr (kCluster) {
+            if (server) {
+                // ---- the gate: wait for the doorman's release of the next request (bounded), see the samples it brought
+                if (tid == 0) {
+                    const unsigned want = server_tick + 1;
+                    const unsigned long long t0 = wall_clock64();
+                    unsigned g;
+                    for (;;) {
+                        g = __hip_atomic_load(&srv.dev->go_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (g == want || g == kServerStop) break;
+                        if (wall_clock64() - t0 > 2 * srv.idle_ticks) {
+                            g = kServerStop;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    sh->gate = g;
+                    // (the request's write index now, past the L2: its round trip runs beside the invalidation below)
+                    sh->gate_wi = __hip_atomic_load(&srv.dev->write_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ch == 0 && part == 0) srv.dev->t[0] = wall_clock64();
+                }
+                __syncthreads();
+                if (sh->gate == kServerStop) break;
+                ++server_tick;
+                // (the slab was written through another XCD's L2: one invalidation serves the compute unit; the barrier hands it on)
+                if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __syncthreads();
+                if (tid == 0 && ch == 0 && part == 0) srv.dev->t[1] = wall_clock64();
+                const bool dead = (sh->fault | sh->stop_code | sh->stop_carrier) != 0;
+                bool ready = false;
+                if (!dead) {
+                    const int64_t wi = sh->gate_wi;
+                    const int64_t unread = ring_pos <= wi ? wi - ring_pos : capacity - ring_pos + wi;   // circularbuffer.py:139-148
+                    ready = unread >= (int64_t)sh->ep.n;
+                }
+                if (!ready) {       // (uniform over the channel's parts: same state, same write index)
+                    if (tid == 0 && writer) {
+                        srv.ran[ch] = dead ? -1 : 0;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        __hip_atomic_fetch_add(&srv.dev->done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    --epoch;        // (this channel's next epoch is still the same one)
+                    continue;
+                }
+            }
+        }
         if (sh->fault | sh->stop_code | sh->stop_carrier) break;
         const EpochParams ep = uniform_params(sh->ep);
         const double dphi = uniform(sh->dphi);
@@ -654,6 +938,8 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         u.cur_lock_state = __builtin_amdgcn_readfirstlane(sh->lock_state);
         u.epoch = epoch;
         u.rec = (writer && keep_traj) ? traj + ((size_t)ch * n_epochs + epoch) : nullptr;
+        if constexpr (kCluster)
+            if (server) u.rec = writer ? srv.rec_out + ch : nullptr;
 
         double accr[kTaps], acci[kTaps];
 #pragma unroll
@@ -722,6 +1008,8 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         if ((tid & 63) == 0 && ch == 0) g_track_phase[8 + part * (THREADS / 64) + (tid >> 6)] += wall_clock64() - wave_mark_;
 #endif
         TRACK_MARK(2);
+        if constexpr (kCluster)
+            if (server && tid == 0 && ch == 0 && part == 0) srv.dev->t[2] = wall_clock64();
         // (cluster form: the totals go to wave 3, which publishes them while the three measuring roles already wait for
         // the peers' -- their chains are the epoch's critical path, the carrier-phase role's is short)
         double total;
@@ -761,7 +1049,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             // Request the next epoch's samples now -- after this epoch's last use of `cur`, before the wait for the
             // peers, so that nothing waits on them: they arrive while this wave sleeps (the counter a wave waits on
             // retires loads in order, and these are ~0.4 us older than the first poll).
-            have_next = single && epoch + 1 < n_epochs;
+            have_next = single && epoch + 1 < n_epochs && !server;   // (server: the next epoch's samples are not in the ring yet)
             if (have_next) {
                 const SingleGeometry next = single_geometry(ring_pos_next, ep.n, capacity);
                 single_load<FMT>(ring, single_load_pos(next, lane_global, capacity), nxt);
@@ -835,11 +1123,30 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             for (int k2 = 0; k2 < 2 * kTaps; ++k2) corr[k2] = uniform(sh->corr[k2]);
         }
         ring_pos = ring_pos_next;
+        if constexpr (kCluster)
+            if (server && tid == 0 && ch == 0 && part == 0) srv.dev->t[3] = wall_clock64();
         if (role_ok && role < 4) loop_update<kTaps>(sh, u, corr, role, rlane, lk);
 #ifdef SDR_TRACE_TRACK
         if (rlane == 0 && role < 4 && ch == 0 && part == 0) g_track_phase[48 + role] += wall_clock64() - role_mark_;
 #endif
         TRACK_MARK(4);
+        if constexpr (kCluster) {
+            if (server) {       // ---- the channel's answer: the state after this epoch, then the count the doorman waits for
+                if (tid == 0 && ch == 0 && part == 0) srv.dev->t[4] = wall_clock64();
+                if (role == 2 && rlane == 0) lock_regs_store(lk, sh);
+                __syncthreads();
+                if (tid == 0 && writer) {
+                    compose_state();
+                    states[sidx] = st;
+                    srv.st_out[ch] = st;
+                    srv.ran[ch] = 1;
+                    if (ch == 0) srv.dev->t[5] = wall_clock64();
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    const unsigned before = __hip_atomic_fetch_add(&srv.dev->done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ch == 0) srv.dev->t[6] = wall_clock64() + (before & 0);      // (stamped after the add has returned: the next tick reports it)
+                }
+            }
+        }
         // the next iteration's first barrier orders the roles' LDS writes against everyone's reads
     }
 #ifdef SDR_TRACE_TRACK
@@ -856,12 +1163,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     if (tid == 0 && writer) {
         const int epochs_done = sh->epochs_done;
         // the NCO values of the next epoch are the ones the roles published last
-        st.current_sample = sh->ep.start_sample;
-        st.n_samples = sh->ep.n;
-        st.carrier_hz = sh->ep.carrier_hz;
-        st.rem_carrier = sh->ep.rem_carrier;
-        st.rem_code = sh->ep.rem_code;
-        st.code_step = sh->ep.code_step;
+        compose_state();
         // stopped early (the NCO left the staged replica / the ring, or a peer part never showed up): the state is
         // the one after the last completed epoch; the records of the epochs that did not run are marked empty
         if (epochs_done < n_epochs && keep_traj)
@@ -917,6 +1219,7 @@ struct TrackRun {
     sdr_track_state* d_states_copy = nullptr;  // [n_ch] end states by position in the list (nullable)
     int* fault_word = nullptr;            // where the launch's fault flag lives (already zero); nullptr: behind the exchange lines
     int force_parts = 0;                  // 0: choose
+    const TickServer* server = nullptr;   // a tick-server launch: cluster form + the doorman, resident until told to leave
 };
 
 // Enqueue one closed-loop launch on ctx's stream.  *d_fault_out points at the launch's fault word.
@@ -963,8 +1266,10 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
         if (*too_big) return hipSuccess;
         if (parts > 1 && !phase)  // tags of a previous launch must not validate this one's polls
             if (hipError_t me = hipMemsetAsync(ctx->xchg.ptr, 0, xchg_bytes + 16, ctx->stream)) return me;
+        TickServer srv_arg = {};
+        if (r.server) srv_arg = *r.server;
         void* args[] = {&d_iq, &cap, &d_st, &d_st_copy, &d_map, &d_cfgs, &cfg_stride, &n_ep, &d_traj, &keep, &d_bits, &mb,
-                        &d_nbits, &d_done, &d_luts, &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault, &phase, &tag_base};
+                        &d_nbits, &d_done, &d_luts, &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault, &phase, &tag_base, &srv_arg};
         if (dense) return sdr_track_dense_launch(e->iq_fmt, nt, r.n_ch, shmem, ctx->stream, args);
         hipError_t err = hipSuccess;
         auto launch = [&](auto kernel) {
@@ -1005,6 +1310,7 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
     // depend on how they are batched into steps (a block of 49 + a step of 2 == a block of 51, bit for bit).
     const int forced = r.force_parts ? r.force_parts : e->track_force_parts;
     int parts = 1;
+    if (r.server && (forced < 2 || r.n_epochs < 2)) return sdr_fail(SDR_ERR_INVALID, "tick server: cluster size not given");
     if (forced) {
         parts = forced;
     } else if (r.n_epochs > 1) {
@@ -1108,6 +1414,8 @@ struct sdr_bank {
     StreamCtx tick_ctx[2];                // their scratch and page-locked blocks, the bank's own: other calls on the engine
                                           // between the two halves (an upload, a search) cannot move them
     bool tick_open = false, tick_two = false, tick_slab_queued = false;
+    bool tick_served = false;             // ... answered by the resident tick server instead
+    std::vector<int32_t> tick_candidates; // every tracking channel of the bank (what a tick server serves)
     int tick_groups = 0, tick_group_n[2] = {0, 0}, tick_rc = 0;
     int64_t tick_write_index = 0;
 };
@@ -1233,6 +1541,7 @@ void sdr_bank_destroy(sdr_engine* e, sdr_bank* b) {
     if (!b) return;
     if (e) {
         (void)hipSetDevice(e->device);
+        (void)sdr_tick_server_stop(e);      // (a resident tick server serves this bank: it leaves before the bank goes)
         (void)hipDeviceSynchronize();
     }
     if (b->d_states) (void)hipFree(b->d_states);
@@ -1480,6 +1789,168 @@ int sdr_bank_step_end(sdr_engine* e, sdr_bank* b, sdr_track_epoch* records, sdr_
     return bank_collect(*b->pending, records, states_out, epochs_done, nullptr, nullptr);
 }
 
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------- the tick server, host side
+struct TickServerState {
+    sdr_bank* bank = nullptr;
+    std::vector<int32_t> channels;          // the channels it serves (every tracking channel of the bank when it started), ascending
+    int parts = 0, n_taps = 0;
+    StreamCtx ctx;                          // the trackers' own stream and exchange lines
+    hipStream_t door_stream = nullptr;      // the doorman's
+    TickServerHost* host = nullptr;         // page-locked: control words, then [ran][states][records]
+    size_t host_bytes = 0;
+    int* h_ran = nullptr;
+    sdr_track_state* h_st = nullptr;
+    sdr_track_epoch* h_rec = nullptr;
+    DevBuf dev;                             // TickServerDev, then [ran][states][records][channel map]
+    unsigned seq = 0;                       // requests posted to the running server
+    bool disabled = false;                  // a launch was refused, or a server died at work: plain ticks from then on
+    int64_t served_total = 0, starts = 0;   // requests answered / servers started, over the engine's life
+    double phase_us[4] = {0, 0, 0, 0};      // summed over the answered requests: slab pull, release, channels' answers, gather
+    double tracker_us[6] = {0, 0, 0, 0, 0, 0};
+    double seen_us[4] = {0, 0, 0, 0};       // (trace build) release -> the doorman sees 1, n/2, n - 1, n answers
+    double fence_add_us = 0;                // channel 0: its release + count, as the NEXT tick's stamps tell (t[6] of the tick before)
+    unsigned long long prev_t5 = 0;   // channel 0: release -> seen, -> samples visible, -> correlated, -> exchanged, -> updated, -> answered
+    int64_t code_generation = -1;
+    void* ring = nullptr;
+    void* staging = nullptr;
+};
+
+static bool server_wait(volatile unsigned* word, unsigned want, double seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0;; ++spins) {
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return true;
+        if ((spins & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+    }
+}
+
+int sdr_tick_server_stop(sdr_engine* e) {
+    if (!e || !e->srv_running) return SDR_OK;
+    TickServerState* s = e->srv;
+    e->srv_running = false;
+    __atomic_store_n(&s->host->req_seq, kServerStop, __ATOMIC_RELEASE);
+    // (the doorman looks at the word every few microseconds; the trackers follow its release word.  Should the words never be
+    // seen -- they always are -- every workgroup still leaves by its own clock: the stream synchronisation below ends either way)
+    (void)server_wait(&s->host->alive, 0u, 1.0);
+    SDR_HIP(hipStreamSynchronize(s->door_stream));
+    SDR_HIP(hipStreamSynchronize(s->ctx.stream));
+    s->seq = 0;
+    // a slab the server had not pulled yet: into the ring the ordinary way
+    if (e->srv_slab_pending) return sdr_iq_flush_server_slab(e);
+    return SDR_OK;
+}
+
+void sdr_tick_server_free(sdr_engine* e) {
+    if (!e || !e->srv) return;
+    (void)sdr_tick_server_stop(e);
+    TickServerState* s = e->srv;
+    for (DevBuf* d : {&s->ctx.traj, &s->ctx.bits, &s->ctx.xchg, &s->dev})
+        if (d->ptr) (void)hipFree(d->ptr);
+    if (s->ctx.pinned) (void)hipHostFree(s->ctx.pinned);
+    if (s->host) (void)hipHostFree(s->host);
+    if (s->ctx.stream) (void)hipStreamDestroy(s->ctx.stream);
+    if (s->door_stream) (void)hipStreamDestroy(s->door_stream);
+    delete s;
+    e->srv = nullptr;
+}
+
+// Start a server for `channels` (ascending, one tap count, n <= 64 so that the cluster form applies).  On return the
+// kernel is queued on the server's own stream; it raises `alive` when it runs.
+static int tick_server_start(sdr_engine* e, sdr_bank* b, const int32_t* channels, int n, int nt) {
+    if (!e->srv) e->srv = new TickServerState();
+    TickServerState* s = e->srv;
+    if (!s->ctx.stream) SDR_HIP(hipStreamCreateWithFlags(&s->ctx.stream, hipStreamNonBlocking));
+    if (!s->door_stream) SDR_HIP(hipStreamCreateWithFlags(&s->door_stream, hipStreamNonBlocking));
+    int parts = 1;
+    while (parts < kMaxParts && (long)n * parts * 2 <= (long)e->n_cus) parts *= 2;     // (the cluster a tick of these channels takes)
+    if (parts < 2) return sdr_fail(SDR_ERR_UNSUPPORTED, "tick server: %d channels leave no cluster", n);
+    const size_t res_bytes = (size_t)n * (sizeof(int) + sizeof(sdr_track_state) + sizeof(sdr_track_epoch));
+    const size_t host_bytes = ((sizeof(TickServerHost) + 63) & ~(size_t)63) + res_bytes + 64;
+    if (host_bytes > s->host_bytes) {
+        if (s->host) SDR_HIP(hipHostFree(s->host));
+        s->host = nullptr;
+        s->host_bytes = 0;
+        hipError_t err = hipHostMalloc((void**)&s->host, host_bytes, hipHostMallocDefault);
+        if (err != hipSuccess) {
+            s->host = nullptr;
+            return sdr_fail(SDR_ERR_NOMEM, "hipHostMalloc(%zu) for the tick server failed: %s", host_bytes, hipGetErrorString(err));
+        }
+        s->host_bytes = host_bytes;
+    }
+    memset(s->host, 0, host_bytes);
+    char* hp = (char*)s->host + ((sizeof(TickServerHost) + 63) & ~(size_t)63);
+    s->h_st = (sdr_track_state*)hp;                                   // (8-byte fields first: the doorman copies 8 bytes per lane)
+    s->h_rec = (sdr_track_epoch*)(hp + (size_t)n * sizeof(sdr_track_state));
+    s->h_ran = (int*)(hp + (size_t)n * (sizeof(sdr_track_state) + sizeof(sdr_track_epoch)));
+    const size_t dev_head = (sizeof(TickServerDev) + 63) & ~(size_t)63;
+    const size_t dev_bytes = dev_head + res_bytes + (size_t)n * sizeof(int32_t) + 64;
+    if (int rc = sdr_devbuf_reserve_on(e, s->ctx.stream, &s->dev, dev_bytes)) return rc;
+    SDR_HIP(hipMemsetAsync(s->dev.ptr, 0, dev_bytes, s->ctx.stream));
+    char* dp = (char*)s->dev.ptr + dev_head;
+    TickServer a = {};
+    a.host = s->host;
+    a.dev = (TickServerDev*)s->dev.ptr;
+    a.staging = (const uint4*)e->slab_pinned;
+    a.ring16 = (uint4*)e->iq;
+    a.ring_n16 = (unsigned long long)((size_t)e->iq_capacity * sdr_fmt_bytes(e->iq_fmt) / 16);
+    a.st_out = (sdr_track_state*)dp;
+    a.rec_out = (sdr_track_epoch*)(dp + (size_t)n * sizeof(sdr_track_state));
+    a.ran = (int*)(dp + (size_t)n * (sizeof(sdr_track_state) + sizeof(sdr_track_epoch)));
+    int32_t* d_map = (int32_t*)(dp + res_bytes);
+    a.h_ran = s->h_ran, a.h_st = s->h_st, a.h_rec = s->h_rec;
+    a.idle_ticks = 20000000ull;      // 0.2 s of the 100 MHz wall clock without a request: leave (the next tick starts a new server)
+    a.busy_ticks = 5000000ull;       // 50 ms for the channels' answers to one request: something is wrong, leave
+    SDR_HIP(hipMemcpyAsync(d_map, channels, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s->ctx.stream));
+    if (int rc = sdr_devbuf_reserve_on(e, s->ctx.stream, &s->ctx.traj, sizeof(sdr_track_epoch))) return rc;
+    TrackRun r;
+    r.d_states = b->d_states;
+    r.d_cfgs = b->d_cfgs;
+    r.cfg_stride = 1;
+    r.d_map = d_map;
+    r.n_ch = n, r.n_epochs = 0x7fffffff, r.n_taps = nt;
+    r.keep = 0;
+    r.d_traj = (sdr_track_epoch*)s->ctx.traj.ptr;
+    r.fault_word = &a.dev->fault;
+    r.force_parts = parts;
+    r.server = &a;
+    int used = 0;
+    int* d_fault = nullptr;
+    // the trackers first (a cooperative launch: it goes through or is refused as a whole), then the doorman; trackers without
+    // a doorman leave by their own clock
+    SDR_HIP(hipStreamSynchronize(s->ctx.stream));      // (the control block is zero, the channel list in place)
+    if (int rc = launch_track(e, &s->ctx, r, &used, &d_fault)) {
+        (void)hipGetLastError();                       // (a refused launch must not surface at somebody else's check)
+        return rc;
+    }
+    hipLaunchKernelGGL(tick_doorman_kernel, dim3(kDoorGroups), dim3(kDoorThreads), 0, s->door_stream, a, n);
+    const hipError_t door_err = hipGetLastError();
+    // the doorman has to be RESIDENT beside the trackers (they fill the device): it says so itself
+    if (door_err != hipSuccess || !server_wait(&s->host->alive, 1u, 0.05)) {
+        // no doorman: tell it (should it still arrive) and the trackers (they poll the device word) to leave, wait for them
+        __atomic_store_n(&s->host->req_seq, kServerStop, __ATOMIC_RELEASE);
+        (void)hipMemsetAsync(&a.dev->go_seq, 0xFF, sizeof(unsigned), e->ctx0.stream);
+        (void)hipStreamSynchronize(e->ctx0.stream);
+        (void)hipStreamSynchronize(s->ctx.stream);
+        (void)hipStreamSynchronize(s->door_stream);
+        return sdr_fail(SDR_ERR_HIP, "tick server: the doorman did not become resident beside the trackers (%s)",
+                        door_err != hipSuccess ? hipGetErrorString(door_err) : "no room on a compute unit");
+    }
+    s->bank = b;
+    s->channels.assign(channels, channels + n);
+    s->parts = parts, s->n_taps = nt;
+    s->seq = 0;
+    s->code_generation = e->code_generation;
+    s->ring = e->iq;
+    s->staging = e->slab_pinned;
+    s->starts += 1;
+    e->srv_running = true;
+    return SDR_OK;
+}
+
+extern "C" {
+
 int sdr_bank_tick(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
                   const int32_t* channels, int n_ch, sdr_track_epoch* records, sdr_track_state* states_out,
                   int32_t* epochs_done) {
@@ -1503,7 +1974,7 @@ int sdr_bank_tick(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples,
 // absorbs the results into the mirrors and writes the tick's update rows.  sdr_bank_tick_mirrored is the two in a row.
 int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
                                  int64_t write_index, sdr_tick_mirror* m) {
-    if (int rc = sdr_set_device(e)) return rc;
+    if (int rc = sdr_set_device_keep(e)) return rc;        // (a resident tick server stays: this may be its next request)
     if (!b) return sdr_fail(SDR_ERR_INVALID, "bank is NULL");
     if (b->tick_open) return sdr_fail(SDR_ERR_STATE, "a tick of this bank is already in flight: sdr_bank_tick_mirrored_end first");
     if (!m || !m->states || !m->last || !m->tracking || !m->lost || !m->ran || !m->records || !m->updates)
@@ -1538,6 +2009,60 @@ int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int
     b->tick_rc = SDR_OK;
     b->tick_groups = 0;
     b->tick_two = taps_seen[1] != 0;
+    b->tick_served = false;
+    // ---- the resident tick server ("tick_server"): the request goes to the kernel that is already there
+    if (e->tick_server_opt && !(e->srv && e->srv->disabled) && !b->tick_two && !e->track_force_parts && !e->track_one_launch_tick &&
+        !e->prof && !(b->pending && b->pending->active)) {
+        // the server serves EVERY tracking channel of the bank (who is ready is decided there, as it is above)
+        std::vector<int32_t>& cand = b->tick_candidates;
+        cand.clear();
+        int nt = 0;
+        bool one_tap_count = true;
+        for (int ch = 0; ch < b->max_channels; ++ch) {
+            if (!m->tracking[ch] || m->lost[ch] || !b->n_taps[ch]) continue;
+            cand.push_back(ch);
+            if (nt && b->n_taps[ch] != nt) one_tap_count = false;
+            nt = b->n_taps[ch];
+        }
+        TickServerState* s = e->srv;
+        const bool same = e->srv_running && s->bank == b && s->channels == cand && s->code_generation == e->code_generation &&
+                          s->ring == e->iq && s->staging == e->slab_pinned;
+        bool use = one_tap_count && !cand.empty() && (long)cand.size() * 4 <= (long)e->n_cus;
+        if (use && !same) {
+            if (e->srv_running)
+                if (int rc = sdr_tick_server_stop(e)) return rc;
+            // (what is queued on the engine's stream -- an ingest, the states a put uploaded -- is done before the server reads it)
+            SDR_HIP(hipStreamSynchronize(e->ctx0.stream));
+            if (int rc = tick_server_start(e, b, cand.data(), (int)cand.size(), nt)) {
+                (void)rc;                       // refused (no room for the cooperative launch, ...): plain ticks from now on
+                if (e->srv) e->srv->disabled = true;
+                use = false;
+            }
+        }
+        if (!use && e->srv_running)
+            if (int rc = sdr_tick_server_stop(e)) return rc;
+        if (use) {
+            s = e->srv;
+            TickServerHost* h = s->host;
+            const size_t sb = sdr_fmt_bytes(e->iq_fmt);
+            h->write_index = write_index;
+            if (e->srv_slab_pending) {
+                h->slab_src16 = (unsigned long long)((e->srv_slab_half ? e->slab_bytes : 0) / 16);
+                h->slab_n16 = (unsigned long long)((size_t)e->srv_slab_n * sb / 16);
+                h->slab_first16 = (unsigned long long)((size_t)e->srv_slab_off * sb / 16);
+            } else {
+                h->slab_n16 = 0;
+            }
+            __atomic_store_n(&h->req_seq, ++s->seq, __ATOMIC_RELEASE);
+            b->tick_served = true;
+            b->tick_open = true;
+            return SDR_OK;
+        }
+    } else if (e->srv_running) {
+        if (int rc = sdr_tick_server_stop(e)) return rc;
+    }
+    if (e->srv_slab_pending)            // (no server after all: the slab it would have pulled goes the ordinary way)
+        if (int rc = sdr_iq_flush_server_slab(e)) return rc;
     if (!list.empty()) {
         int n = (int)list.size();
         b->tick_states.resize((size_t)n);
@@ -1573,7 +2098,7 @@ int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int
 }
 
 int sdr_bank_tick_mirrored_end(sdr_engine* e, sdr_bank* b, sdr_tick_mirror* m) {
-    if (int rc = sdr_set_device(e)) return rc;
+    if (int rc = sdr_set_device_keep(e)) return rc;
     if (!b) return sdr_fail(SDR_ERR_INVALID, "bank is NULL");
     if (!b->tick_open) return sdr_fail(SDR_ERR_STATE, "no tick of this bank is in flight");
     if (!m || !m->states || !m->last || !m->tracking || !m->lost || !m->ran || !m->records || !m->updates || m->max_channels != b->max_channels)
@@ -1587,9 +2112,70 @@ int sdr_bank_tick_mirrored_end(sdr_engine* e, sdr_bank* b, sdr_tick_mirror* m) {
     };
     std::vector<int32_t>& list = b->tick_list;
     int run_rc = b->tick_rc;
-    if (list.empty()) {
+    if (b->tick_served) {
+        // ---- the answer of the resident server: wait for its done word (bounded), take the listed channels' rows
+        TickServerState* s = e->srv;
+        TickServerHost* h = s->host;
+        if (!server_wait(&h->done_seq, s->seq, 0.25)) {
+            const unsigned alive = __atomic_load_n(&h->alive, __ATOMIC_ACQUIRE), why = __atomic_load_n(&h->fault, __ATOMIC_ACQUIRE);
+            (void)sdr_tick_server_stop(e);
+            s->disabled = true;
+            return sdr_fail(SDR_ERR_HIP, "the resident tick server did not answer request %u (alive %u, fault %u): stopped; plain "
+                                         "ticks from now on -- the bank's channels may have advanced, read them back (sdr_bank_get)",
+                            s->seq, alive, why);
+        }
+        s->served_total += 1;
+        for (int k = 0; k < 4; ++k) s->phase_us[k] += (double)(h->stamps[k + 1] - h->stamps[k]) * 0.01;
+        if (h->tracker[5] > h->stamps[2]) {     // (channel 0 ran in this tick)
+            s->tracker_us[0] += (double)((long long)(h->tracker[0] - h->stamps[2])) * 0.01;
+            for (int k = 1; k < 6; ++k) s->tracker_us[k] += (double)((long long)(h->tracker[k] - h->tracker[k - 1])) * 0.01;
+#ifdef SDR_SRV_TRACE
+            for (int k = 0; k < 4; ++k) s->seen_us[k] += (double)h->tracker[8 + k] * 0.01;
+#endif
+            if (h->tracker[6] > h->tracker[5]) s->fence_add_us += (double)(h->tracker[6] - h->tracker[5]) * 0.01, s->prev_t5 += 1;
+        }
+        if (e->srv_slab_pending) {              // (the doorman has pulled it: its staging half is free again)
+            e->srv_slab_pending = false;
+            e->slab_busy[e->srv_slab_half] = false;
+        }
+        if (__atomic_load_n(&h->fault, __ATOMIC_ACQUIRE)) {
+            (void)sdr_tick_server_stop(e);
+            s->disabled = true;
+            return sdr_fail(SDR_ERR_HIP, "closed-loop tracking: a workgroup of a %d-part cluster never published its sums (tick server)", s->parts);
+        }
+        const int n = (int)list.size();
+        b->tick_states.resize((size_t)n);
+        b->tick_done.resize((size_t)n);
+        size_t k = 0;
+        int i = 0;
+        for (size_t c = 0; c < s->channels.size(); ++c) {
+            const int ch = s->channels[c];
+            const bool listed = i < n && list[(size_t)i] == ch;
+            const int ran = s->h_ran[c];
+            if (listed != (ran != 0)) {
+                (void)sdr_tick_server_stop(e);
+                s->disabled = true;
+                return sdr_fail(SDR_ERR_STATE, "tick server: channel %d %s on the device but the mirror says otherwise -- the mirror and "
+                                               "the bank disagree", ch, ran ? "ran" : "did not run");
+            }
+            if (!listed) continue;
+            b->tick_states[(size_t)i] = s->h_st[c];
+            b->tick_done[(size_t)i] = ran == 1 ? 1 : 0;
+            m->records[i] = s->h_rec[c];
+            if (ran != 1) b->tick_states[(size_t)i] = m->states[ch];        // (stopped before its epoch: the state it had)
+            ++i, ++k;
+        }
+        if (i != n) {
+            (void)sdr_tick_server_stop(e);
+            s->disabled = true;
+            return sdr_fail(SDR_ERR_STATE, "tick server: a listed channel is not among the channels it serves");
+        }
+        b->tick_two = false;
+        b->tick_groups = 0;
+    } else if (list.empty()) {
         if (b->tick_slab_queued) SDR_HIP(hipStreamSynchronize(e->ctx0.stream));
-    } else {
+    }
+    if (!list.empty()) {
         int n = (int)list.size();
         int at = 0;
         for (int g = 0; g < b->tick_groups; ++g) {
@@ -1654,6 +2240,40 @@ int sdr_bank_tick_mirrored(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n
                            int64_t write_index, sdr_tick_mirror* m) {
     if (int rc = sdr_bank_tick_mirrored_begin(e, b, iq, n_samples, ring_offset, write_index, m)) return rc;
     return sdr_bank_tick_mirrored_end(e, b, m);
+}
+
+int sdr_tick_server_stats(sdr_engine* e, int64_t* out4) {
+    if (!e || !out4) return sdr_fail(SDR_ERR_INVALID, "null engine or output");
+    out4[0] = e->srv_running ? 1 : 0;
+    out4[1] = e->srv ? e->srv->served_total : 0;
+    out4[2] = e->srv ? e->srv->starts : 0;
+    out4[3] = e->srv && e->srv->disabled ? 1 : 0;
+    return SDR_OK;
+}
+
+// Where the served requests' time went on the device, in microseconds summed over them (the doorman's wall-clock stamps):
+// {slab pulled into the ring, trackers released, every channel answered, answers gathered into page-locked memory}.
+int sdr_tick_server_phases(sdr_engine* e, double* out4) {
+    if (!e || !out4) return sdr_fail(SDR_ERR_INVALID, "null engine or output");
+    for (int k = 0; k < 4; ++k) out4[k] = e->srv ? e->srv->phase_us[k] : 0.0;
+    return SDR_OK;
+}
+
+// ... and channel 0's own tick (lane 0 of its first part), the same way: {release seen, samples visible (L2 invalidated),
+// correlated, sums exchanged, loops updated, answer written}.
+int sdr_tick_server_tracker_phases(sdr_engine* e, double* out6) {
+    if (!e || !out6) return sdr_fail(SDR_ERR_INVALID, "null engine or output");
+    for (int k = 0; k < 6; ++k) out6[k] = e->srv ? e->srv->tracker_us[k] : 0.0;
+#ifdef SDR_SRV_TRACE
+    if (e->srv && e->srv->served_total)
+        fprintf(stderr, "tick server: the doorman sees 1 / half / all but one / all answers %.2f / %.2f / %.2f / %.2f us after the release\n",
+                e->srv->seen_us[0] / e->srv->served_total, e->srv->seen_us[1] / e->srv->served_total, e->srv->seen_us[2] / e->srv->served_total,
+                e->srv->seen_us[3] / e->srv->served_total);
+#endif
+#ifdef SDR_SRV_TRACE
+    if (e->srv) fprintf(stderr, "tick server: channel 0 release fence + count: %.2f us (mean of %llu)\n", e->srv->fence_add_us / (double)(e->srv->prev_t5 ? e->srv->prev_t5 : 1), e->srv->prev_t5);
+#endif
+    return SDR_OK;
 }
 
 int sdr_iq_upload_begin(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset) {

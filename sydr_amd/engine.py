@@ -447,6 +447,23 @@ class Engine:
         """Workgroups cooperating on one channel in `track_closed_loop` (0 = fill the GPU; 1, 2, 4, 8)."""
         check(self._lib.sdr_track_cluster(self._h, int(parts)))
 
+    def tick_server_stats(self) -> dict:
+        """The resident tick server of this engine (set_option("tick_server", 1)): is one resident now, requests answered,
+        servers started, and whether the engine went back to plain ticks for good (a launch refused, a server that died)."""
+        out = (C.c_int64 * 4)()
+        check(self._lib.sdr_tick_server_stats(self._h, out))
+        ph = (C.c_double * 4)()
+        check(self._lib.sdr_tick_server_phases(self._h, ph))
+        return {"running": bool(out[0]), "served": int(out[1]), "starts": int(out[2]), "disabled": bool(out[3]),
+                "device_us_total": {"slab": ph[0], "release": ph[1], "channels": ph[2], "gather": ph[3]},
+                "channel0_us_total": dict(zip(("release_seen", "samples_visible", "correlated", "exchanged", "updated", "answered"),
+                                              self._tracker_phases()))}
+
+    def _tracker_phases(self):
+        t = (C.c_double * 6)()
+        check(self._lib.sdr_tick_server_tracker_phases(self._h, t))
+        return list(t)
+
     def stream_create(self) -> int:
         """A further HIP stream of this engine (north_star: one stream per channel batch); 0 is the default one."""
         sid = C.c_int(0)

@@ -2,8 +2,10 @@
 (the headline geometry), a few seconds of stream, read-ahead blocks of random lengths re-drawn now and then (the next
 block queued on the device while the current one is handed out), late joiners -- every packet of every tick equal to the
 plain loop's, bit for bit (both run an epoch on the cluster of 8 workgroups).  --general: the plain loop's library-side tick
-against the manager's general tick instead.  --steady: every channel
-requested at the start (no late joiners: a block is queued ahead all the time).  Usage: python tests/stress_readahead.py [ms] [seed] [--general] [--steady]"""
+against the manager's general tick instead.  --tick-server: the plain loop answered by the resident tick server
+(sdr_set_option "tick_server": late joiners stop and restart it) against the plain loop on launches.  --steady: every channel
+requested at the start (no late joiners: a block is queued ahead all the time).
+Usage: python tests/stress_readahead.py [ms] [seed] [--general | --tick-server] [--steady]"""
 import configparser, os, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +17,7 @@ from sydr_amd.signal.iqsource import RFSignal
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(n_ms=2000, seed=1, fs=25e6, n_ch=32, general=False, steady=False):
+def run(n_ms=2000, seed=1, fs=25e6, n_ch=32, general=False, steady=False, tick_server=False):
     rng = np.random.default_rng(seed)
     eng = Engine(0)
     spms = int(fs * 1e-3)
@@ -32,8 +34,9 @@ def run(n_ms=2000, seed=1, fs=25e6, n_ch=32, general=False, steady=False):
     late = [] if steady else sorted(int(t) for t in rng.integers(150, n_ms // 2, 6))   # ticks at which one more satellite is requested
     redraw = {int(t): int(b) for t, b in zip(rng.integers(100, n_ms - 100, 8), rng.choice([7, 16, 25, 40, 50], 8))}
 
-    def receiver(read_ahead, steady=True):
+    def receiver(read_ahead, steady=True, server=False):
         rf = RFSignal(dict(filepath=tmp.name, sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0, data_size=8))
+        eng.set_option("tick_server", 1 if server else 0)
         mgr = ChannelManager(rf, engine=eng, keepCorrelationMap=False)
         mgr.STEADY_TICK = steady
         mgr.addChannel(ChannelL1CA_Kaplan, cfg, n_ch)
@@ -53,11 +56,18 @@ def run(n_ms=2000, seed=1, fs=25e6, n_ch=32, general=False, steady=False):
             ticks.append([dict(p) for p in mgr.run()])
             queued += mgr._ahead is not None
         dt = time.perf_counter() - t0
+        if server:
+            st = eng.tick_server_stats()
+            assert not st["disabled"], st
+            queued = st["served"]
         mgr.close()
+        eng.set_option("tick_server", 0)
         return ticks, dt, queued
 
     plain, t_plain, _ = receiver(0)
-    if general:      # the library-side tick (sdr_bank_tick_mirrored) against the manager's general tick instead
+    if tick_server:  # the same ticks answered by the resident server
+        ahead, t_ahead, queued = receiver(0, server=True)
+    elif general:      # the library-side tick (sdr_bank_tick_mirrored) against the manager's general tick instead
         ahead, t_ahead, queued = receiver(0, steady=False)
     else:
         ahead, t_ahead, queued = receiver(50)
@@ -79,7 +89,11 @@ if __name__ == "__main__":
     n_ms = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     general = "--general" in sys.argv
-    n_pk, t_plain, t_ahead, queued = run(n_ms, seed, general=general, steady="--steady" in sys.argv)
+    n_pk, t_plain, t_ahead, queued = run(n_ms, seed, general=general, steady="--steady" in sys.argv, tick_server="--tick-server" in sys.argv)
+    if "--tick-server" in sys.argv:
+        print(f"{n_ms} ticks x 32 channels: {n_pk} packets equal bit for bit between the plain loop on launches ({t_plain:.2f} s incl. "
+              f"materialising) and the plain loop answered by the resident tick server ({t_ahead:.2f} s; {queued} requests answered)")
+        sys.exit(0)
     if general:
         print(f"{n_ms} ticks x 32 channels: {n_pk} packets equal bit for bit between the library-side tick ({t_plain:.2f} s) and the "
               f"manager's general tick ({t_ahead:.2f} s)")

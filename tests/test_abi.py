@@ -122,6 +122,13 @@ def test_c_receiver_loop_ticks_through_the_mirrored_call(tmp_path):
     ticks, epochs, bits, locked = (int(g) for g in m.groups())
     assert ticks == 300 and locked == 32 and epochs >= 32 * 297 and bits >= 20, out
     assert re.search(r"us per tick", out), out
+    # the same loop answered by the resident tick server (sdr_set_option "tick_server"): the same channels in the same
+    # states (what it prints about them is equal line for line), every tick a request the server answered
+    served = subprocess.check_output([str(_build_c_example(tmp_path, "receiver_loop")), "300", "server"], text=True, timeout=120)
+    strip = lambda text: [l for l in text.splitlines() if "us per tick" not in l and not l.startswith("tick server:")]
+    assert strip(served) == strip(out), served
+    m = re.search(r"tick server: (\d+) requests answered, (\d+) server\(s\) started$", served, re.M)
+    assert m and int(m.group(1)) == 300 and int(m.group(2)) == 1, served
 
 
 @pytest.mark.gpu

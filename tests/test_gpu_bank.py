@@ -689,3 +689,85 @@ def test_one_manager_over_two_devices_equals_the_single_device_manager(engine, n
         assert x == y, k
     assert attrs_1 == attrs_2
     assert all(st is ChannelState.TRACKING for _, st, *_ in attrs_2)
+
+
+def test_resident_tick_server_equals_plain_ticks(engine):
+    """sdr_set_option("tick_server", 1): the steady receiver tick is answered by a RESIDENT kernel (the cluster form of the
+    tracking kernel + a doorman workgroup that polls a request word in page-locked memory, pulls the slab, releases the
+    trackers and gathers their answers) instead of two launches and a synchronisation.  12 channels at 10 MHz from
+    acquisition on, against the same receiver on plain ticks: every packet of every tick equal BIT FOR BIT (same cluster,
+    same order of additions), channel attributes too; the server is started when the channels have all reached tracking,
+    survives ticks in which a channel is not ready, is stopped by any other call on the engine (here: an acquisition-sized
+    download) and started again by the next tick; an engine closed with a server resident returns at once."""
+    import configparser
+    import os
+    import time
+    from conftest import REPO
+    from sydr_amd.channel.l1ca_kaplan import ChannelL1CA_Kaplan
+    from sydr_amd.channel.manager import ChannelManager
+    from sydr_amd.signal.iqsource import RFSignal
+    from sydr_amd.utils.enumerations import ChannelMessage
+    fs, n_ms = 10e6, 400
+    spms = int(fs * 1e-3)
+    rng = np.random.default_rng(7070)
+    sats = [dict(prn=1 + c, doppler=float(250.0 * rng.integers(-15, 16) + rng.uniform(-40, 40)),
+                 code_phase=float(rng.uniform(0, 1023)), phase=float(rng.uniform(0, 1)), amp=5.0) for c in range(12)]
+    total = n_ms * spms
+    engine.iq_alloc(total, FMT_CI8)
+    engine.code_slots(32)
+    engine.iq_synth(sats, fs, 10.0, 7071, 0, total)
+    raw = engine.iq_download(total, 0)
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(REPO, "examples", "channel_GPS_L1CA_kaplan.ini"))
+
+    def receiver(eng, server):
+        rf = RFSignal(dict(filepath="none", sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0, data_size=8))
+        eng.set_option("tick_server", 1 if server else 0)
+        mgr = ChannelManager(rf, engine=eng, keepCorrelationMap=False)
+        mgr.addChannel(ChannelL1CA_Kaplan, cfg, 12)
+        for s in sats:
+            mgr.requestTracking(s["prn"])
+        ticks = []
+        try:
+            for k in range(n_ms):
+                if k == 250:
+                    eng.iq_download(64, 0)                   # any other call on the engine: the server leaves, the next tick starts one
+                mgr.addNewRFData(raw[2 * k * spms:2 * (k + 1) * spms])
+                ticks.append([dict(q) for q in mgr.run()])
+            attrs = [(ch.carrierFrequency, ch.codeFrequency, ch.currentSample, ch.codeSinceTOW, int(ch.trackFlags), len(ch.navBits))
+                     for ch in mgr.channels.values()]
+            stats = eng.tick_server_stats()
+        finally:
+            mgr.close()
+            eng.set_option("tick_server", 0)
+        return ticks, attrs, stats
+
+    plain, attrs_p, stats_p = receiver(engine, False)
+    before = engine.tick_server_stats()
+    served, attrs_s, stats_s = receiver(engine, True)
+    assert stats_p["served"] == before["served"] and not stats_p["running"]
+    # the server answered the steady ticks (all but acquisition and the ticks around it), was resident at the end, was
+    # started twice (the download at tick 250 sent the first one away) and never gave up
+    assert stats_s["served"] - before["served"] > 330 and stats_s["running"] and stats_s["starts"] - before["starts"] == 2 and not stats_s["disabled"]
+    assert sum(p["type"] is ChannelMessage.TRACKING_UPDATE for t in served for p in t) > 12 * 330
+    for k, (a, b) in enumerate(zip(plain, served)):
+        assert a == b, k
+    assert attrs_p == attrs_s
+    # ticks with nothing ready: the server answers "nobody ran"; a channel whose epoch is not complete waits a tick
+    # (both happen above: 10 MHz epochs are 10 000 +- a sample long against slabs of exactly 10 000)
+    # an engine that goes away with a server resident: the server is told to leave, the destroy returns at once
+    e2 = Engine(0)
+    try:
+        e2.set_option("tick_server", 1)
+        rf = RFSignal(dict(filepath="none", sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0, data_size=8))
+        mgr = ChannelManager(rf, engine=e2, keepCorrelationMap=False)
+        mgr.addChannel(ChannelL1CA_Kaplan, cfg, 4)
+        for s in sats[:4]:
+            mgr.requestTracking(s["prn"])
+        for k in range(60):
+            mgr.addNewRFData(raw[2 * k * spms:2 * (k + 1) * spms])
+            mgr.run()
+        t0 = time.perf_counter()
+    finally:
+        e2.close()
+    assert time.perf_counter() - t0 < 1.0

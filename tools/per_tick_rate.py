@@ -20,11 +20,14 @@ FS = bench.FS
 WARMUP_MS = 100     # ticks not counted: acquisition, the first launches of each kernel (code objects load on first use), the first block
 
 
-def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0):
+def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0, tick_server=False):
     """read_ahead > 0: the same loop with ChannelManager.enableReadAhead(read_ahead) and the stream served from a file
     through this package's RFSignal (what lets the manager look ahead); the calls per tick are the reference's.
-    The first WARMUP_MS ticks are fed and run but not counted (their time is reported as warmup_ms_total)."""
+    The first WARMUP_MS ticks are fed and run but not counted (their time is reported as warmup_ms_total).
+    tick_server: the steady ticks answered by the resident kernel (sdr_set_option "tick_server")."""
     eng = engine or Engine(0)
+    eng.set_option("tick_server", 1 if tick_server else 0)
+    served0 = eng.tick_server_stats()["served"]
     # synthesise the stream on the device, then bring it to the host: the host is the IQ source in this mode
     total = int(n_ms * 1e-3 * FS) // 8 * 8
     eng.iq_alloc(total, FMT_CI8)
@@ -73,7 +76,9 @@ def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0):
         pstats.Stats(pr).sort_stats("tottime").print_stats(22)
     tracking_now = sum(ch.channelState is ChannelState.TRACKING for ch in mgr.channels.values())
     lost = sum(getattr(ch, "lostLock", False) for ch in mgr.channels.values())
+    srv = eng.tick_server_stats()
     mgr.close()
+    eng.set_option("tick_server", 0)
     # read-ahead: a tick in ~50 pays for the block, so the MEAN per tick is the honest figure there (the median is the
     # price of a tick that only hands packets out); the plain loop keeps its median (every tick is alike)
     avg = (lambda v: float(np.mean(v))) if read_ahead else (lambda v: float(np.median(v)))
@@ -83,7 +88,13 @@ def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0):
                x_realtime=1e-3 / avg(lazy) if lazy else None,
                ms_per_tick_all_packets_read=avg(eager) * 1e3 if eager else None,
                x_realtime_all_packets_read=1e-3 / avg(eager) if eager else None,
+               mean_ms_per_tick=float(np.mean(lazy)) * 1e3 if lazy else None, p99_ms_per_tick=float(np.percentile(lazy, 99)) * 1e3 if lazy else None,
+               max_ms_per_tick=float(np.max(lazy)) * 1e3 if lazy else None,
                other_ticks_ms_total=other * 1e3, warmup_ms_excluded=WARMUP_MS, warmup_ms_total=warm * 1e3)
+    if tick_server:
+        res.update(tick_server=True, requests_answered=srv["served"] - served0, servers_started=srv["starts"], gave_up=srv["disabled"],
+                   device_us_per_request={k: v / max(1, srv["served"]) for k, v in srv["device_us_total"].items()},
+                   channel0_us_per_request={k: v / max(1, srv["served"]) for k, v in srv["channel0_us_total"].items()})
     if tmp is not None:
         tmp.close()
     return res
@@ -92,4 +103,4 @@ def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0):
 if __name__ == "__main__":
     n_ms = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 600
     ra = int(sys.argv[sys.argv.index("--read-ahead") + 1]) if "--read-ahead" in sys.argv else 0
-    print(json.dumps(measure(n_ms, profile="--profile" in sys.argv, read_ahead=ra)))
+    print(json.dumps(measure(n_ms, profile="--profile" in sys.argv, read_ahead=ra, tick_server="--tick-server" in sys.argv)))
