@@ -305,6 +305,21 @@ __device__ __forceinline__ double np_sign(double x) { return x > 0.0 ? 1.0 : (x 
 // FLL atan (:156-176), BorreLoopFilter (:180-186) -- are evaluated inside the kernel's loop update, their
 // divisions / square roots / arctangents spread over lanes (see there).
 
+// The lock role's share of the loop state, held in registers of its lane 0 for the whole run (19 LDS reads and as many
+// writes per epoch otherwise -- and this role is the longest of the four: tools/track_phases.py).  Written back to
+// the LDS copy of the state once, after the last epoch.
+struct LockRegs {
+    double fll_lock, pll_lock, cn0, ratio_acc, ipp, qpp, fll_bw, pll_bw, nav_sum;
+    int accum, lock_state, time_in_state, spacing_sel, flags, code_counter, nav_count, bits_emitted, bits_run;
+};
+// The run's constants the update roles divide and scale with.  The forms with registers to spare keep them in registers
+// (UpdateCtx); the dense form (three workgroups per compute unit, 168 registers) reads them from LDS when a role needs them.
+struct UpdateConsts {
+    double fs, chips, dt;
+    double by_fs_b, by_fs_y, by_dt_b, by_dt_y, by_2pi_b, by_2pi_y;
+    int epochs_per_bit, ok_bits;       // ok_bits: InvDen::ok of by_fs | by_dt << 1 | by_2pi << 2
+};
+
 struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind it is copied with 16-byte stores)
     EpochParams ep;
     double spacing[SDR_MAX_TAPS];
@@ -329,7 +344,14 @@ struct alignas(16) EpochShared {  // (size a multiple of 16: the replica behind 
     long long pad_sh2_;
     sdr_track_state st;        // the loop state; each update role owns a disjoint set of its fields
     sdr_loop_cfg cfg;
+    // the dense form: what the other forms carry in registers across the whole epoch -- the lock role's state and the run's
+    // constants.  At 168 registers per lane the compiler spilled them to scratch memory and the roles fetched them back one
+    // dependent load at a time, on the epoch's critical path (76 scratch loads behind the reduction barrier, round 5).
+    LockRegs lk;
+    UpdateConsts uc;
+    long long pad_dense_;
 };
+static_assert(sizeof(EpochShared) % 16 == 0, "the replica behind it is copied with 16-byte stores");
 
 // a / b for a denominator that does not change during the run (fs, 2*pi, the epoch duration), given y = RN(1/b):
 // two Newton corrections of the quotient with exact FMA residuals.  The second one rounds correctly (Markstein's
@@ -359,13 +381,6 @@ __device__ __forceinline__ double div_by(double a, const InvDen& d) {
     return __builtin_fma(r1, d.y, q1);
 }
 
-// The lock role's share of the loop state, held in registers of its lane 0 for the whole run (19 LDS reads and as many
-// writes per epoch otherwise -- and this role is the longest of the four: tools/track_phases.py).  Written back to
-// the LDS copy of the state once, after the last epoch.
-struct LockRegs {
-    double fll_lock, pll_lock, cn0, ratio_acc, ipp, qpp, fll_bw, pll_bw, nav_sum;
-    int accum, lock_state, time_in_state, spacing_sel, flags, code_counter, nav_count, bits_emitted, bits_run;
-};
 __device__ __forceinline__ LockRegs lock_regs_from(const sdr_track_state& s) {
     LockRegs r;
     r.fll_lock = s.fll_lock, r.pll_lock = s.pll_lock, r.cn0 = s.cn0, r.ratio_acc = s.cn0_ratio_acc;
@@ -417,16 +432,31 @@ __device__ __forceinline__ bool code_out_of_range(const EpochShared* sh, int64_t
 // Each wave evaluates its divisions / roots / arctangents side by side, one per lane (same IEEE operations on
 // the same operands as the reference's statements: bit-identical), then lane 0 runs the rest of its chain and
 // publishes its share of the next epoch's parameters.  corr[2*NT]: this epoch's correlator totals.
-template <int NT>
+template <int NT, bool DENSE = false>
 __device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u, const double* corr, int role, int rlane,
-                                            LockRegs& lk) {
+                                            LockRegs& lk_regs) {
     constexpr int kTaps = NT;
     constexpr int kPrompt = NT / 2;                       // centre tap; its neighbours are early and late
     sdr_track_state& st = sh->st;
     const sdr_loop_cfg& cfg = sh->cfg;
     const EpochParams& ep = u.ep;
-    const double fs = u.fs, kChips = u.chips, kDt = u.dt;
-    const int kMsPerBit = u.epochs_per_bit;
+    double fs = u.fs, kChips = u.chips, kDt = u.dt;
+    int kMsPerBit = u.epochs_per_bit;
+    InvDen by_fs = u.by_fs, by_dt = u.by_dt, by_2pi = u.by_2pi;
+    LockRegs lk_local;
+    if constexpr (DENSE) {
+        // (through a pointer the compiler cannot see through: read HERE, every epoch -- hoisted out of the epoch loop they
+        // would be registers again, and spilled again)
+        const UpdateConsts* c = &sh->uc;
+        asm volatile("" : "+v"(c));
+        fs = c->fs, kChips = c->chips, kDt = c->dt, kMsPerBit = c->epochs_per_bit;
+        const int okb = c->ok_bits;
+        by_fs = InvDen{c->by_fs_b, c->by_fs_y, (okb & 1) != 0};
+        by_dt = InvDen{c->by_dt_b, c->by_dt_y, (okb & 2) != 0};
+        by_2pi = InvDen{c->by_2pi_b, c->by_2pi_y, (okb & 4) != 0};
+        if (role == 2 && rlane == 0) lk_local = sh->lk;
+    }
+    LockRegs& lk = DENSE ? lk_local : lk_regs;
     const double ie = corr[2 * kPrompt - 2], qe = corr[2 * kPrompt - 1], ip = corr[2 * kPrompt], qp = corr[2 * kPrompt + 1],
                  il = corr[2 * kPrompt + 2], ql = corr[2 * kPrompt + 3];
     const int n = ep.n;
@@ -442,8 +472,8 @@ __device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u,
         if (fll_err != fll_err) fll_err = 0.0;
         if (fll_err >= kGpsHalfPi) fll_err = fll_err - kGpsPi;
         else if (fll_err <= -kGpsHalfPi) fll_err = fll_err + kGpsPi;
-        const double costas = div_by(at_now, u.by_2pi);                          // atan/2pi (pll_costas)
-        const double fll_full = div_by(div_by(fll_err, u.by_dt), u.by_2pi);     // (err/dt)/2pi (fll_atan)
+        const double costas = div_by(at_now, by_2pi);                          // atan/2pi (pll_costas)
+        const double fll_full = div_by(div_by(fll_err, by_dt), by_2pi);       // (err/dt)/2pi (fll_atan)
         double w0f = sh->w0f, w0p = sh->w0p;
         if (kaplan && (sh->w0f_bw != u.cur_fll_bw || sh->w0p_bw != u.cur_pll_bw)) {   // (the lock state changed the bandwidths)
             w0f = u.cur_fll_bw / kW0Bw1;
@@ -489,7 +519,7 @@ __device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u,
             sh->c_code_counter = c_code_counter + 1;
             sh->ep.carrier_hz = carrier_hz;
             sh->stop_carrier = carrier_bad(carrier_hz) ? 1 : 0;
-            sh->dphi = div_by((carrier_hz * 2.0) * M_PI, u.by_fs);  // carrier_step(): tracking.py:102 uses np.pi
+            sh->dphi = div_by((carrier_hz * 2.0) * M_PI, by_fs);  // carrier_step(): tracking.py:102 uses np.pi
             if (rec) {
                 rec->carrier_hz_in = ep.carrier_hz;
                 rec->rem_carrier_in = ep.rem_carrier;
@@ -514,7 +544,7 @@ __device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u,
             st.code_hz = k_code_hz;
             double rem_code = ep.rem_code;
             rem_code += (double)n * ep.code_step - kChips;
-            const double code_step = div_by(k_code_hz, u.by_fs);
+            const double code_step = div_by(k_code_hz, by_fs);
             const int64_t next_start = ep.start_sample + n;
             const int next_n = (int)ceil((kChips - rem_code) / code_step);
             sh->stop_code = code_out_of_range(sh, u.capacity, u.lut_words, next_start, next_n, rem_code, code_step) ? 1 : 0;
@@ -658,6 +688,7 @@ __device__ __forceinline__ void loop_update(EpochShared* sh, const UpdateCtx& u,
             lk.accum = l_accum, lk.lock_state = l_lock_state, lk.time_in_state = l_time_in_state;
             lk.spacing_sel = l_spacing_sel, lk.flags = l_flags, lk.code_counter = l_code_counter;
             lk.nav_count = l_nav_count, lk.bits_emitted = l_bits_emitted, lk.bits_run = l_bits_run;
+            if constexpr (DENSE) sh->lk = lk;
             if (rec) {
                 rec->cn0 = kaplan ? l_cn0 : 0.0;
                 rec->pll_lock = kaplan ? l_pll_lock : 0.0;
@@ -794,9 +825,23 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     u.by_fs = inv_den(fs);
     u.by_dt = inv_den(u.dt);
     u.by_2pi = inv_den(kGpsTwoPi);
-    // (vector registers: the scalar file is full of per-epoch constants, and spilled SGPRs come back as v_readlane)
-    asm volatile("" : "+v"(u.fs), "+v"(u.chips), "+v"(u.dt));
-    asm volatile("" : "+v"(u.by_fs.b), "+v"(u.by_fs.y), "+v"(u.by_dt.b), "+v"(u.by_dt.y), "+v"(u.by_2pi.b), "+v"(u.by_2pi.y));
+    // the one-workgroup forms (three 256-thread workgroups per compute unit at 168 registers per lane; 512 threads, two waves
+    // per SIMD): no registers to spare for what only the roles read
+    constexpr bool kDense = !kCluster;
+    if constexpr (kDense) {
+        if (tid == 0) {
+            UpdateConsts c;
+            c.fs = u.fs, c.chips = u.chips, c.dt = u.dt, c.epochs_per_bit = u.epochs_per_bit;
+            c.by_fs_b = u.by_fs.b, c.by_fs_y = u.by_fs.y, c.by_dt_b = u.by_dt.b, c.by_dt_y = u.by_dt.y;
+            c.by_2pi_b = u.by_2pi.b, c.by_2pi_y = u.by_2pi.y;
+            c.ok_bits = (u.by_fs.ok ? 1 : 0) | (u.by_dt.ok ? 2 : 0) | (u.by_2pi.ok ? 4 : 0);
+            sh->uc = c;
+        }
+    } else {
+        // (vector registers: the scalar file is full of per-epoch constants, and spilled SGPRs come back as v_readlane)
+        asm volatile("" : "+v"(u.fs), "+v"(u.chips), "+v"(u.dt));
+        asm volatile("" : "+v"(u.by_fs.b), "+v"(u.by_fs.y), "+v"(u.by_dt.b), "+v"(u.by_dt.y), "+v"(u.by_2pi.b), "+v"(u.by_2pi.y));
+    }
     u.capacity = capacity;
     u.lut_words = lut_words;
     u.n_epochs = n_epochs;
@@ -858,6 +903,8 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     Raw8<FMT> cur[2], nxt[2];
     bool have_next = false;
     LockRegs lk = lock_regs_from(s_init);                  // (meaningful in lane 0 of the lock role's wave only)
+    if constexpr (kDense)
+        if (tid == 0) sh->lk = lk;                         // (the dense form keeps it in LDS: see EpochShared)
     // ring position of the current epoch's first sample: start % capacity once, then += n (minus the capacity when it
     // passes it) -- the 64-bit modulo is not paid three times per epoch
     int64_t ring_pos;
@@ -1125,7 +1172,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         ring_pos = ring_pos_next;
         if constexpr (kCluster)
             if (server && tid == 0 && ch == 0 && part == 0) srv.dev->t[3] = wall_clock64();
-        if (role_ok && role < 4) loop_update<kTaps>(sh, u, corr, role, rlane, lk);
+        if (role_ok && role < 4) loop_update<kTaps, kDense>(sh, u, corr, role, rlane, lk);
 #ifdef SDR_TRACE_TRACK
         if (rlane == 0 && role < 4 && ch == 0 && part == 0) g_track_phase[48 + role] += wall_clock64() - role_mark_;
 #endif
@@ -1158,7 +1205,10 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     // End state: the roles kept the LDS copy of the state current (the lock role hands its registers back now); one lane
     // of the recording part writes it out.
     if (publish_only) return;   // (only reached when the channel was stopped before its epoch: phase 2 reports that)
-    if (role == 2 && rlane == 0) lock_regs_store(lk, sh);
+    if (role == 2 && rlane == 0) {
+        if constexpr (kDense) lk = sh->lk;
+        lock_regs_store(lk, sh);
+    }
     __syncthreads();
     if (tid == 0 && writer) {
         const int epochs_done = sh->epochs_done;
