@@ -766,11 +766,22 @@ inline int make_work_list(int n_prn, int nbins, int bins_whole, std::vector<Work
     // kernels per 32-PRN call: N = 50 000 0.532 -> 0.511, N = 25 000 0.235 -> 0.228 (gpurun_out/r05_partsfirst.txt).
     constexpr bool parts_first = true;
     for (int x = 0; x < 8; ++x) {
-        if (parts_first)
-            for (int i = (int)(((long long)np * x) / 8); i < (int)(((long long)np * (x + 1)) / 8); ++i) order.push_back(parts[i]);
-        for (int i = (int)(((long long)nw * x) / 8); i < (int)(((long long)nw * (x + 1)) / 8); ++i) order.push_back(whole[i]);
-        if (!parts_first)
-            for (int i = (int)(((long long)np * x) / 8); i < (int)(((long long)np * (x + 1)) / 8); ++i) order.push_back(parts[i]);
+        const int p_lo = (int)(((long long)np * x) / 8), p_hi = (int)(((long long)np * (x + 1)) / 8);
+        const int w_lo = (int)(((long long)nw * x) / 8), w_hi = (int)(((long long)nw * (x + 1)) / 8);
+        if (parts_first) {
+            for (int i = p_lo; i < p_hi; ++i) order.push_back(parts[i]);
+            // the XCD's 32 workgroups walk the list 32 items at a time, and the whole transforms come in blocks of 32 that share
+            // their operand arrays: the step the short units leave incomplete is filled with the LAST whole transforms, so that
+            // every later step is one block again (with the blocks straddling two steps the launch fetched 1.34 instead of
+            // 0.87 GB through the fabric at N = 50 000)
+            int pad = (kSlotsPerXcd - (p_hi - p_lo) % kSlotsPerXcd) % kSlotsPerXcd;
+            if (pad > w_hi - w_lo) pad = w_hi - w_lo;
+            for (int i = w_hi - pad; i < w_hi; ++i) order.push_back(whole[i]);
+            for (int i = w_lo; i < w_hi - pad; ++i) order.push_back(whole[i]);
+        } else {
+            for (int i = w_lo; i < w_hi; ++i) order.push_back(whole[i]);
+            for (int i = p_lo; i < p_hi; ++i) order.push_back(parts[i]);
+        }
         first[x + 1] = (int)order.size();
     }
     return per_prn;
