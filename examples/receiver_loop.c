@@ -136,7 +136,7 @@ int main(int argc, char** argv) {
         int64_t st[4];
         CK(sdr_tick_server_stats(e, st));
         printf("tick server: %lld requests answered, %lld server(s) started%s\n", (long long)st[1], (long long)st[2], st[3] ? ", gave up" : "");
-        if (st[3] || st[1] < ticks - 2) return 4;
+        if (st[3] || st[1] < ticks - 10) return 4;        /* (a server starts once eight steady ticks have passed) */
     }
     sdr_bank_destroy(e, bank);
     sdr_engine_destroy(e);

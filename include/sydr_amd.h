@@ -419,7 +419,8 @@ int sdr_bank_tick_mirrored_end(sdr_engine* e, sdr_bank* b, sdr_tick_mirror* m);
  * memory, pulls the slab into the ring, releases the trackers and gathers their answers; who is ready is decided on the
  * device by the arithmetic of channel.py:137-146 and must agree with the caller's mirror (SDR_ERR_STATE otherwise).  Same
  * clusters and order of additions as the plain tick: same bits.  Served: banks whose tracking channels run one tap count
- * and number at most a quarter of the compute units (64); anything else takes the plain path.  Any other call on the engine
+ * and number at most a quarter of the compute units (64), after eight such ticks in a row with no other call on the engine
+ * in between (a server takes ~25 ms to start); anything else takes the plain path.  Any other call on the engine
  * (a search, a put, an upload by another route, sdr_engine_destroy) tells the server to leave first and waits for it; the
  * next steady tick starts a new one.  Nothing on the device waits without a bound: the server leaves by itself after 0.2 s
  * without a request; the host waits at most 0.25 s for an answer, then reports SDR_ERR_HIP and goes back to plain ticks.

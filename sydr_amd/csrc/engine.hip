@@ -35,6 +35,7 @@ int sdr_set_device_keep(sdr_engine* e) {
 // written from the host -- a resident tick server (track.hip) must not be in its way, nor keep its copy of what changes.
 int sdr_set_device(sdr_engine* e) {
     if (int rc = sdr_set_device_keep(e)) return rc;
+    e->srv_steady_ticks = 0;
     if (e->srv_running)
         if (int rc = sdr_tick_server_stop(e)) return rc;
     return SDR_OK;

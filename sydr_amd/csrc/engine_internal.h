@@ -126,6 +126,7 @@ struct sdr_engine {
     // while it runs waits in its staging half for the next request (srv_slab_*).
     bool tick_server_opt = false;
     bool srv_running = false;
+    int srv_steady_ticks = 0;     // steady ticks in a row with no other call on the engine in between (a server starts at 8)
     struct TickServerState* srv = nullptr;
     bool srv_slab_pending = false;
     int srv_slab_half = 0;

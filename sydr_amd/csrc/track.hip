@@ -1877,6 +1877,7 @@ static bool server_wait(volatile unsigned* word, unsigned want, double seconds) 
 }
 
 int sdr_tick_server_stop(sdr_engine* e) {
+    if (e) e->srv_steady_ticks = 0;
     if (!e || !e->srv_running) return SDR_OK;
     TickServerState* s = e->srv;
     e->srv_running = false;
@@ -2078,6 +2079,10 @@ int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int
         const bool same = e->srv_running && s->bank == b && s->channels == cand && s->code_generation == e->code_generation &&
                           s->ring == e->iq && s->staging == e->slab_pinned;
         bool use = one_tap_count && !cand.empty() && (long)cand.size() * 4 <= (long)e->n_cus;
+        // A server costs ~25 ms to start (a cooperative launch, the doormen becoming resident): it is started for a receiver
+        // that HAS settled into steady ticks -- eight in a row with nothing else on the engine in between -- not for the
+        // ticks between two other calls (a manager that replays read-ahead blocks uploads and steps in between).
+        if (use && !same && ++e->srv_steady_ticks < 8) use = false;
         if (use && !same) {
             if (e->srv_running)
                 if (int rc = sdr_tick_server_stop(e)) return rc;
@@ -2110,6 +2115,8 @@ int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int
         }
     } else if (e->srv_running) {
         if (int rc = sdr_tick_server_stop(e)) return rc;
+    } else {
+        e->srv_steady_ticks = 0;
     }
     if (e->srv_slab_pending)            // (no server after all: the slab it would have pulled goes the ordinary way)
         if (int rc = sdr_iq_flush_server_slab(e)) return rc;
