@@ -207,6 +207,7 @@ int sdr_set_option(sdr_engine* e, const char* name, int value) {
     else if (!strcmp(name, "pcps_no_spectra_cache")) e->pcps_no_spec_cache = value != 0;
     else if (!strcmp(name, "ingest_by_copy_command")) e->ingest_by_copy = value != 0;
     else if (!strcmp(name, "track_one_launch_tick")) e->track_one_launch_tick = value != 0;
+    else if (!strcmp(name, "pcps_no_shared_spectra")) e->pcps_no_shared_spectra = value != 0;
     else if (!strcmp(name, "tick_server")) {
         if (e->srv_running) (void)sdr_tick_server_stop(e);
         e->tick_server_opt = value != 0;
@@ -324,7 +325,7 @@ void sdr_engine_destroy(sdr_engine* e) {
     }
     for (auto ev : e->prof_pool) (void)hipEventDestroy(ev);
     DevBuf* bufs[] = {&e->ws_items,  &e->ws_out,   &e->ws_spacing, &e->ws_setups, &e->ws_stats, &e->pcps_fwd,   &e->pcps_a,
-                      &e->pcps_b,    &e->pcps_code, &e->pcps_code2, &e->pcps_tickets, &e->pcps_tw,   &e->pcps_map,   &e->pcps_csum,
+                      &e->pcps_b,    &e->pcps_code, &e->pcps_code2, &e->pcps_tickets, &e->pcps_spec_off, &e->pcps_tw,   &e->pcps_map,   &e->pcps_csum,
                       &e->pcps_part, &e->pcps_res,  &e->track_state, &e->track_cfg,
                       &e->pcps_blu,  &e->pcps_blu_x, &e->pcps_blu_a, &e->pcps_blu_b, &e->pcps_work, &e->pcps_theta};
     for (DevBuf* b : bufs)

@@ -94,6 +94,11 @@ struct sdr_engine {
     DevBuf pcps_fwd, pcps_a, pcps_b, pcps_code, pcps_tw, pcps_map, pcps_csum, pcps_part, pcps_res;
     DevBuf pcps_code2;            // N = 50 000, fused search: [prn][parity][N] -- the spectra and their image with the odd half's twiddle (pcps_fused.h)
     bool pcps_code2_ok = false;   // ... made from what pcps_code holds now
+    bool pcps_shared = false;     // the search in flight read shared spectra (its second sweep reads them the same way)
+    const long long* pcps_shared_off = nullptr;
+    DevBuf pcps_spec_off;         // shared spectra: every bin's element offset into the padded class spectra (pcps.hip)
+    std::vector<int64_t> pcps_spec_off_key;
+    bool pcps_no_shared_spectra = false;   // "pcps_no_shared_spectra": one forward transform per bin, as before round 5
     DevBuf pcps_tickets;          // one word per PRN: the second sweep's last workgroup of a PRN divides the two peaks (pcps_fused.h)
     int pcps_tickets_n = 0;
     DevBuf track_state, track_cfg;
@@ -201,7 +206,9 @@ const void* sdr_epl_km_kernel(int km);   // three taps, the block length alone c
 // SDR_PCPS_FUSED_RECORDS (value, index) records per transform in `partials` ([transform][record], 16 bytes each).
 // N = 50 000 (terms = 2): a unit is one parity of a transform -- twice the records -- and C is the [prn][parity][N] image.
 #define SDR_PCPS_FUSED_RECORDS 8
-int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int nbins, int N, void* partials);
+// spec_off (nullable): element offset of every bin's spectrum inside F (shared spectra: pcps.hip); else bin b is at b * N.
+int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* spec_off, const void* C, const void* tw, int n_prn, int nbins, int N,
+                         void* partials);
 // records per PRN that sweep leaves (PRN-major: [prn][records]); a search that is not a whole number of rounds of its 256
 // workgroups has its last transforms cut into five units of SDR_PCPS_FUSED_RECORDS records each
 int sdr_pcps_fused_records_per_prn(int n_prn, int nbins, int terms);
@@ -214,6 +221,6 @@ int sdr_pcps_fused10k_search(sdr_engine* e, const void* F_all, const void* C, co
 // The second sweep of such a search in one launch: the first peaks from `recs` ([n_prn][per_prn] records) into tops / dev_bin /
 // dev_code, and 5 x SDR_PCPS_FUSED_RECORDS records per PRN of its winning row's allowed columns into `seconds`.
 // ... and TwoCorrelationPeakComparison's results (bin, code phase, ratio of the two peaks) into res_*.
-int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int N, int spc, const void* recs,
+int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* spec_off, const void* C, const void* tw, int n_prn, int N, int spc, const void* recs,
                           int per_prn, void* tops, void* dev_bin, void* dev_code, void* seconds, void* res_bin, void* res_code,
                           void* res_ratio);

@@ -68,6 +68,9 @@ struct PassArgs {
     int bin0;
     // LOAD_IQ_MIX over several blocks at once: bins per block (0: the batch is one block's bins)
     int iq_blocks;
+    // STORE_PLAIN with a halo (shared spectra): row t of the output is halo + N elements long, element k goes to halo + k and
+    // the row's last `halo` elements are written in front of it as well -- out[t][i] = X_t[(i - halo) mod N]
+    int halo;
 };
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
@@ -220,7 +223,13 @@ template <int STORE>
 __device__ __forceinline__ void store_elem(const PassArgs& a, int batch, int idx, double2 v) {
     const size_t o = (size_t)batch * a.N + idx;
     if (STORE == STORE_PLAIN) {
-        a.out[o] = v;
+        if (a.halo) {
+            const size_t row = (size_t)batch * (size_t)(a.halo + a.N);
+            a.out[row + a.halo + idx] = v;
+            if (idx >= a.N - a.halo) a.out[row + (idx - (a.N - a.halo))] = v;
+        } else {
+            a.out[o] = v;
+        }
     } else if (STORE == STORE_CONJ) {
         a.out[o] = make_double2(v.x, -v.y);
     } else if (STORE == STORE_MAG_ACC) {
@@ -958,6 +967,14 @@ void run_four_step(sdr_engine* e, const FourStep& f, PassArgs a, int batch, doub
             return;
         }
     }
+    if constexpr (!INV && LOAD0 == LOAD_IQ_MIX && STORE_LAST == STORE_PLAIN) {
+        // a handful of forward transforms (shared spectra: four for a 250 Hz grid) are a chain of latencies, not work: narrower
+        // column tiles put twice as many workgroups on its first half
+        if (batch <= 8) {           // (measured: 0.2179 -> 0.2159 ms per 32-PRN call at 25 MHz, 0.4863 -> 0.4833 at 50 MHz)
+            run_four_step_t<INV, LOAD0, STORE_LAST, FMT, 4, 4>(e, f, a, batch, Z, final_out);
+            return;
+        }
+    }
     run_four_step_t<INV, LOAD0, STORE_LAST, FMT, SDR_PCPS_COL_TILE, kRowTile>(e, f, a, batch, Z, final_out);
 }
 // per-wave records one map-free inverse sweep leaves per transform
@@ -1192,7 +1209,45 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
             f.if_hz = if_hz;
             f.bin_start = bin_start;
             f.bin_delta = bin_delta;
-            run_fft<false, LOAD_IQ_MIX, STORE_PLAIN, FMT>(e, radices, f, nbins, A, B, F, "pcps_fwd_fft", blu);
+            // ---- shared spectra.  x mixed with exp(-2 pi i (f - q / T) t) is x mixed with f, times exp(+2 pi i q n / N): its
+            // spectrum is the other's, circularly shifted by q elements.  Bins P apart whose distance P * step is a whole
+            // number q of transform bins (1 / T = fs / N: 250 Hz steps over 1 ms -> P = 4, q = 1; 300 Hz -> P = 10, q = 3)
+            // therefore share ONE forward transform: the search transforms its first P bins and reads bin c + P j as the
+            // spectrum of bin c shifted by j q (acquisition.py:42-59 transforms every bin; the values agree to rounding,
+            // ~1e-15 relative, like any two orders of the same additions).  4 forward transforms instead of 41, and the
+            // inverse sweep's operands on the spectra side are 4 arrays that never leave the L2s.
+            int share_P = 0, share_q = 0;
+            if (map_free && fused_takes(e, plan_four_step(N), n_prn, nbins) && !e->pcps_no_shared_spectra && bin_delta > 0.0) {
+                for (int P = 1; P <= 64 && 2 * P <= nbins; ++P) {
+                    const double v = (double)P * bin_delta * (double)N / fs, r = std::nearbyint(v);
+                    if (r >= 1.0 && std::fabs(v - r) <= 1e-9 * r && r * (double)((nbins - 1) / P) <= 4096.0) {
+                        share_P = P, share_q = (int)r;
+                        break;
+                    }
+                }
+            }
+            const long long* spec_off = nullptr;
+            if (share_P) {
+                const int H = share_q * ((nbins - 1) / share_P);
+                std::vector<int64_t> key = {(int64_t)N, (int64_t)nbins, (int64_t)share_P, (int64_t)share_q};
+                if (key != e->pcps_spec_off_key) {
+                    std::vector<long long> off((size_t)nbins);
+                    for (int b = 0; b < nbins; ++b) off[(size_t)b] = (long long)(b % share_P) * (H + N) + H - (long long)(b / share_P) * share_q;
+                    e->pcps_spec_off_key.clear();
+                    if (int rco = sdr_devbuf_reserve(e, &e->pcps_spec_off, off.size() * sizeof(long long))) return rco;
+                    SDR_HIP(hipMemcpyAsync(e->pcps_spec_off.ptr, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice, e->stream));
+                    SDR_HIP(hipStreamSynchronize(e->stream));      // (pageable source: complete before `off` goes)
+                    e->pcps_spec_off_key = key;
+                }
+                spec_off = (const long long*)e->pcps_spec_off.ptr;
+                // (the class spectra with their halos, written so by the transform's last pass: F holds share_P rows of H + N)
+                f.halo = H;
+                run_fft<false, LOAD_IQ_MIX, STORE_PLAIN, FMT>(e, radices, f, share_P, A, B, F, "pcps_fwd_fft", blu);
+            } else {
+                run_fft<false, LOAD_IQ_MIX, STORE_PLAIN, FMT>(e, radices, f, nbins, A, B, F, "pcps_fwd_fft", blu);
+            }
+            e->pcps_shared = share_P != 0;
+            e->pcps_shared_off = spec_off;
 
             if (map_free && fused_takes(e, plan_four_step(N), n_prn, nbins)) {
                 // every (PRN, bin) transform of the search in ONE launch of persistent workgroups: no intermediate, no sweeps
@@ -1205,7 +1260,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
                     }
                     C = (double2*)e->pcps_code2.ptr;
                 }
-                if (int rcf = sdr_pcps_fused_sweep(e, F, C, tw, n_prn, nbins, N, e->pcps_part.ptr)) return rcf;
+                if (int rcf = sdr_pcps_fused_sweep(e, F, spec_off, C, tw, n_prn, nbins, N, e->pcps_part.ptr)) return rcf;
                 continue;
             }
             // Register-resident kernels, several sweeps, nobody timing the stages: the sweeps alternate between two
@@ -1292,8 +1347,10 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
         if (fused_takes(e, four, n_prn, nbins) && !e->pcps_slow_second) {
             // first peaks + second sweep in one launch of n_prn x 5 workgroups (pcps_fused.h ifft_second_kernel)
             // ... which also divides the two peaks (its last workgroup per PRN): the whole K6 in one launch
-            return sdr_pcps_fused_second(e, F, C, tw, n_prn, N, spc, parts, per_prn, tops, dev_bin, dev_code, seconds, res_bin, res_code,
-                                         res_ratio);
+            // (C: at N = 50 000 the parity images the first sweep used; the spectra: shared ones when that sweep read them so)
+            const bool two = fused_terms(e, four) == 2;
+            return sdr_pcps_fused_second(e, F, e->pcps_shared_off, two ? (double2*)e->pcps_code2.ptr : C, tw, n_prn, N, spc,
+                                         parts, per_prn, tops, dev_bin, dev_code, seconds, res_bin, res_code, res_ratio);
         } else {
             {
                 ProfScope ps(e, "pcps_peak");

@@ -137,6 +137,10 @@ struct WorkItem {
 
 struct Args {
     const double2* spec;       // [nbins][N] forward spectra of the Doppler-mixed block
+    // Doppler bins whose frequencies differ by a whole number of transform bins (250 Hz steps over 1 ms: every fourth) have
+    // the SAME spectrum, circularly shifted (pcps.hip: shared spectra): when given, bin b's spectrum starts spec_off[b]
+    // elements into `spec` -- a row of its class with the shift taken out of a halo in front of it.
+    const long long* spec_off;
     const double2* code_spec;  // [n_prn][N]
     const double2* tw;         // exp(-2 pi i m / N)
     const WorkItem* work;      // in processing order
@@ -217,7 +221,7 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     // stage while the NEXT group's ten loads are in flight; while item 1 is transformed, ten of item 0's fifteen
     // parked points wait in the LDS slots item 1 will fill at its end (a thread's own slots: no barrier).
     double2 park[2][15];
-    const Operand xs_u = make_operand(a.spec + (size_t)bin * NF);
+    const Operand xs_u = make_operand(a.spec + (a.spec_off ? (size_t)a.spec_off[bin] : (size_t)bin * NF));
     const Operand cs_u = make_operand(a.code_spec + ((size_t)prn * TERMS + par) * NF);
     const unsigned toff = (unsigned)cb * 16u;
 #pragma unroll

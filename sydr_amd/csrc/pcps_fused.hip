@@ -37,7 +37,8 @@ int sdr_pcps_fused_records_per_prn(int n_prn, int nbins, int terms) {
 
 // C: [n_prn][N] code spectra at N = 25 000; [n_prn][2][N] at N = 50 000 -- the spectrum and its image with the odd half's
 // twiddle folded in (pcps.hip code_parity_kernel).
-int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int nbins, int N, void* partials) {
+int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* spec_off, const void* C, const void* tw, int n_prn, int nbins, int N,
+                         void* partials) {
     if (N != fused25k::N && N != 2 * fused25k::N) return sdr_fail(SDR_ERR_UNSUPPORTED, "fused PCPS sweep: N = %d", N);
     const int terms = N / fused25k::N;
     const int vbins = terms * nbins;
@@ -55,6 +56,7 @@ int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void
     }
     fused25k::Args a = {};
     a.spec = (const double2*)F;
+    a.spec_off = (const long long*)spec_off;
     a.code_spec = (const double2*)C;
     a.tw = (const double2*)tw;
     a.work = (const fused25k::WorkItem*)e->pcps_work.ptr;
@@ -81,13 +83,14 @@ int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* C, const void
     return SDR_OK;
 }
 
-int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* C, const void* tw, int n_prn, int N, int spc, const void* recs,
+int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* spec_off, const void* C, const void* tw, int n_prn, int N, int spc, const void* recs,
                           int per_prn, void* tops, void* dev_bin, void* dev_code, void* seconds, void* res_bin, void* res_code,
                           void* res_ratio) {
     if (N != fused25k::N && N != 2 * fused25k::N) return sdr_fail(SDR_ERR_UNSUPPORTED, "fused PCPS sweep: N = %d", N);
     const int terms = N / fused25k::N;
     fused25k::SecondArgs s = {};
     s.a.spec = (const double2*)F;
+    s.a.spec_off = (const long long*)spec_off;
     s.a.code_spec = (const double2*)C;
     s.a.tw = (const double2*)tw;
     s.a.scale = 1.0 / (double)N;
