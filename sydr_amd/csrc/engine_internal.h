@@ -216,8 +216,9 @@ int sdr_pcps_fused_records_per_prn(int n_prn, int nbins, int terms);
 // workgroup per (PRN, bin) keeps the transform in its LDS and the non-coherent sum in registers; F_all = [noncoh][nbins][N]
 // forward spectra, records = n_prn * nbins * SDR_PCPS_FUSED10K_RECORD_BYTES bytes of scratch; the results go to out_*.
 #define SDR_PCPS_FUSED10K_RECORD_BYTES 32
-int sdr_pcps_fused10k_search(sdr_engine* e, const void* F_all, const void* C, const void* tw, int n_prn, int nbins, int noncoh, int N, int spc,
-                             void* records, void* out_bin, void* out_code, void* out_ratio);
+// (spec_off / blk_stride: shared spectra, as above; nullptr / nbins * N: one spectrum per bin)
+int sdr_pcps_fused10k_search(sdr_engine* e, const void* F_all, const void* spec_off, long long blk_stride, const void* C, const void* tw, int n_prn,
+                             int nbins, int noncoh, int N, int spc, void* records, void* out_bin, void* out_code, void* out_ratio);
 // The second sweep of such a search in one launch: the first peaks from `recs` ([n_prn][per_prn] records) into tops / dev_bin /
 // dev_code, and 5 x SDR_PCPS_FUSED_RECORDS records per PRN of its winning row's allowed columns into `seconds`.
 // ... and TwoCorrelationPeakComparison's results (bin, code phase, ratio of the two peaks) into res_*.

@@ -1125,6 +1125,45 @@ void run_fft(sdr_engine* e, const std::vector<int>& radices, PassArgs a, int bat
     }
 }
 
+// ---- shared spectra (round 5).  x mixed with exp(-2 pi i (f - q / T) t) is x mixed with f, times exp(+2 pi i q n / N): its
+// spectrum is the other's, circularly shifted by q elements.  Bins P apart whose distance P * step is a whole number q of
+// transform bins (1 / T = fs / N: 250 Hz steps over 1 ms -> P = 4, q = 1; 300 Hz -> P = 10, q = 3) therefore share ONE
+// forward transform: a search transforms its first P bins and reads bin c + P j as the spectrum of bin c shifted by j q
+// (acquisition.py:42-59 transforms every bin; the values agree to rounding, ~1e-15 relative, like any two orders of the same
+// additions).  4 forward transforms instead of 41 for the headline grid, and the spectra side of the inverse sweep's operands
+// is 4 arrays.  The class spectra are written with the row's last H elements in front of it (PassArgs::halo), so that a
+// shift is a contiguous read H - j q elements into the row.
+struct SharedSpectra {
+    int P = 0, q = 0, H = 0;            // P == 0: every bin has its own transform
+    const long long* off = nullptr;     // device: element offset of every bin's spectrum inside ITS BLOCK of P rows of H + N
+};
+inline int plan_shared_spectra(sdr_engine* e, int nbins, int N, double fs, double bin_delta, SharedSpectra* out) {
+    *out = SharedSpectra{};
+    if (e->pcps_no_shared_spectra || !(bin_delta > 0.0)) return SDR_OK;
+    for (int P = 1; P <= 64 && 2 * P <= nbins; ++P) {
+        const double v = (double)P * bin_delta * (double)N / fs, r = std::nearbyint(v);
+        if (r >= 1.0 && std::fabs(v - r) <= 1e-9 * r && r * (double)((nbins - 1) / P) <= 4096.0) {
+            out->P = P, out->q = (int)r;
+            break;
+        }
+    }
+    if (!out->P) return SDR_OK;
+    out->H = out->q * ((nbins - 1) / out->P);
+    std::vector<int64_t> key = {(int64_t)N, (int64_t)nbins, (int64_t)out->P, (int64_t)out->q};
+    if (key != e->pcps_spec_off_key) {
+        std::vector<long long> off((size_t)nbins);
+        for (int b = 0; b < nbins; ++b)
+            off[(size_t)b] = (long long)(b % out->P) * (out->H + N) + out->H - (long long)(b / out->P) * out->q;
+        e->pcps_spec_off_key.clear();
+        if (int rc = sdr_devbuf_reserve(e, &e->pcps_spec_off, off.size() * sizeof(long long))) return rc;
+        SDR_HIP(hipMemcpyAsync(e->pcps_spec_off.ptr, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice, e->stream));
+        SDR_HIP(hipStreamSynchronize(e->stream));      // (pageable source: complete before `off` goes)
+        e->pcps_spec_off_key = key;
+    }
+    out->off = (const long long*)e->pcps_spec_off.ptr;
+    return SDR_OK;
+}
+
 template <int FMT>
 int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int n_prn, int64_t start, double fs, double if_hz,
              double bin_start, double bin_delta, int nbins, int N, int spc, int coh, int noncoh,
@@ -1176,6 +1215,7 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
         // N = 10 000, indices and ratio only, one coherent millisecond per block: the forward transforms of every block
         // first, then ONE launch that keeps each (PRN, bin)'s transform in LDS and its non-coherent sum in registers and
         // finds both peaks (pcps_fused10k.h) -- no map, no intermediate, no second sweep
+        SharedSpectra sh10;
         {
             PassArgs f = {};
             f.tw = tw;
@@ -1188,12 +1228,16 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
             f.if_hz = if_hz;
             f.bin_start = bin_start;
             f.bin_delta = bin_delta;
-            f.iq_blocks = nbins;             // all blocks in one batch: [block][bin]
-            run_fft<false, LOAD_IQ_MIX, STORE_PLAIN, FMT>(e, radices, f, nbins * noncoh, A, B, F, "pcps_fwd_fft", blu);
+            // (shared spectra: the shipped 300 Hz grid has ten classes -- 10 transforms per block instead of 34)
+            if (int rcs = plan_shared_spectra(e, nbins, N, fs, bin_delta, &sh10)) return rcs;
+            const int per_block = sh10.P ? sh10.P : nbins;
+            f.iq_blocks = per_block;         // all blocks in one batch: [block][bin]
+            f.halo = sh10.H;
+            run_fft<false, LOAD_IQ_MIX, STORE_PLAIN, FMT>(e, radices, f, per_block * noncoh, A, B, F, "pcps_fwd_fft", blu);
         }
         long long* out_bin = e->pcps_res_direct ? (long long*)e->pcps_res_direct : (long long*)e->pcps_res.ptr;
-        return sdr_pcps_fused10k_search(e, F, C, tw, n_prn, nbins, noncoh, N, spc, e->pcps_part.ptr, out_bin, out_bin + n_prn,
-                                        (double*)(out_bin + 2 * n_prn));
+        return sdr_pcps_fused10k_search(e, F, sh10.off, sh10.P ? (long long)sh10.P * (sh10.H + N) : (long long)nbins * N, C, tw, n_prn, nbins,
+                                        noncoh, N, spc, e->pcps_part.ptr, out_bin, out_bin + n_prn, (double*)(out_bin + 2 * n_prn));
     }
     for (int inc = 0; inc < noncoh; ++inc) {
         for (int ic = 0; ic < coh; ++ic) {
@@ -1209,39 +1253,14 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
             f.if_hz = if_hz;
             f.bin_start = bin_start;
             f.bin_delta = bin_delta;
-            // ---- shared spectra.  x mixed with exp(-2 pi i (f - q / T) t) is x mixed with f, times exp(+2 pi i q n / N): its
-            // spectrum is the other's, circularly shifted by q elements.  Bins P apart whose distance P * step is a whole
-            // number q of transform bins (1 / T = fs / N: 250 Hz steps over 1 ms -> P = 4, q = 1; 300 Hz -> P = 10, q = 3)
-            // therefore share ONE forward transform: the search transforms its first P bins and reads bin c + P j as the
-            // spectrum of bin c shifted by j q (acquisition.py:42-59 transforms every bin; the values agree to rounding,
-            // ~1e-15 relative, like any two orders of the same additions).  4 forward transforms instead of 41, and the
-            // inverse sweep's operands on the spectra side are 4 arrays that never leave the L2s.
-            int share_P = 0, share_q = 0;
-            if (map_free && fused_takes(e, plan_four_step(N), n_prn, nbins) && !e->pcps_no_shared_spectra && bin_delta > 0.0) {
-                for (int P = 1; P <= 64 && 2 * P <= nbins; ++P) {
-                    const double v = (double)P * bin_delta * (double)N / fs, r = std::nearbyint(v);
-                    if (r >= 1.0 && std::fabs(v - r) <= 1e-9 * r && r * (double)((nbins - 1) / P) <= 4096.0) {
-                        share_P = P, share_q = (int)r;
-                        break;
-                    }
-                }
-            }
-            const long long* spec_off = nullptr;
+            SharedSpectra sh;
+            if (map_free && fused_takes(e, plan_four_step(N), n_prn, nbins))
+                if (int rcs = plan_shared_spectra(e, nbins, N, fs, bin_delta, &sh)) return rcs;
+            const int share_P = sh.P;
+            const long long* spec_off = sh.off;
             if (share_P) {
-                const int H = share_q * ((nbins - 1) / share_P);
-                std::vector<int64_t> key = {(int64_t)N, (int64_t)nbins, (int64_t)share_P, (int64_t)share_q};
-                if (key != e->pcps_spec_off_key) {
-                    std::vector<long long> off((size_t)nbins);
-                    for (int b = 0; b < nbins; ++b) off[(size_t)b] = (long long)(b % share_P) * (H + N) + H - (long long)(b / share_P) * share_q;
-                    e->pcps_spec_off_key.clear();
-                    if (int rco = sdr_devbuf_reserve(e, &e->pcps_spec_off, off.size() * sizeof(long long))) return rco;
-                    SDR_HIP(hipMemcpyAsync(e->pcps_spec_off.ptr, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice, e->stream));
-                    SDR_HIP(hipStreamSynchronize(e->stream));      // (pageable source: complete before `off` goes)
-                    e->pcps_spec_off_key = key;
-                }
-                spec_off = (const long long*)e->pcps_spec_off.ptr;
                 // (the class spectra with their halos, written so by the transform's last pass: F holds share_P rows of H + N)
-                f.halo = H;
+                f.halo = sh.H;
                 run_fft<false, LOAD_IQ_MIX, STORE_PLAIN, FMT>(e, radices, f, share_P, A, B, F, "pcps_fwd_fft", blu);
             } else {
                 run_fft<false, LOAD_IQ_MIX, STORE_PLAIN, FMT>(e, radices, f, nbins, A, B, F, "pcps_fwd_fft", blu);

@@ -121,11 +121,13 @@ int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* spec_off, co
     return SDR_OK;
 }
 
-int sdr_pcps_fused10k_search(sdr_engine* e, const void* F_all, const void* C, const void* tw, int n_prn, int nbins, int noncoh, int N, int spc,
-                             void* records, void* out_bin, void* out_code, void* out_ratio) {
+int sdr_pcps_fused10k_search(sdr_engine* e, const void* F_all, const void* spec_off, long long blk_stride, const void* C, const void* tw, int n_prn,
+                             int nbins, int noncoh, int N, int spc, void* records, void* out_bin, void* out_code, void* out_ratio) {
     if (N != fused10k::N) return sdr_fail(SDR_ERR_UNSUPPORTED, "fused 10 MHz PCPS search: N = %d", N);
     fused10k::Args a = {};
     a.spec = (const double2*)F_all;
+    a.spec_off = (const long long*)spec_off;
+    a.blk_stride = blk_stride;
     a.code_spec = (const double2*)C;
     a.tw = (const double2*)tw;
     a.n_prn = n_prn, a.nbins = nbins, a.noncoh = noncoh, a.spc = spc;

@@ -48,6 +48,10 @@ struct UnitRecord {        // what a (PRN, bin) unit leaves: its row's first max
 
 struct Args {
     const double2* spec;       // [noncoh][nbins][N] forward spectra of the Doppler-mixed blocks
+    // shared spectra (pcps.hip): a block is blk_stride elements long, bin b's spectrum starts spec_off[b] elements into it
+    // (spec_off == nullptr: b * N, blk_stride = nbins * N)
+    const long long* spec_off;
+    long long blk_stride;
     const double2* code_spec;  // [n_prn][N]
     const double2* tw;         // exp(-2 pi i m / N)
     int n_prn, nbins, noncoh, spc;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(kThreads) void search_kernel(const Args a) {
             for (int g = 0; g < 10; ++g) acc[j][g] = 0.0;
 
         for (int blk = 0; blk < a.noncoh; ++blk) {
-            const double2* __restrict__ xs = a.spec + ((size_t)blk * a.nbins + bin) * N + cb;
+            const double2* __restrict__ xs = a.spec + (size_t)blk * (size_t)a.blk_stride + (a.spec_off ? (size_t)a.spec_off[bin] : (size_t)bin * N) + cb;
             __syncthreads();   // the tables (first block); the previous block's / unit's readers are done with the buffers
             // ---- column stage (the block's spectrum is read as it is needed: its item-0 values requested a block ahead --
             // 40 more registers across the rounds -- made the kernel spill 199 of them: 1.04 instead of 0.75 ms per search, with the code spectrum kept in registers)
