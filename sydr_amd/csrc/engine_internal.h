@@ -142,7 +142,7 @@ struct sdr_engine {
     bool pcps_slow_second = false;   // "pcps_general_second_sweep": peak kernel + general four-step pair where the fused second sweep would run
     bool pcps_fused = true;          // map-free search at N = 125 x 200 of a round of 256 transforms or more: one workgroup per (PRN, bin) transform (pcps_fused.h); "pcps_fused" = 0: the two-kernel sweeps
     DevBuf pcps_work;                // its work list (transform numbers in processing order)
-    int pcps_work_prn = 0, pcps_work_bins = 0;   // ... and the grid it was made for
+    int pcps_work_prn = 0, pcps_work_bins = 0, pcps_work_block = 0;   // ... and the grid / block shape it was made for
     int pcps_work_first[9] = {0};
     DevBuf pcps_theta;               // its two per-PRN bound arrays (pcps_fused.h Args::theta), the PRN count they are for, the one in use
     int pcps_theta_prn = 0, pcps_theta_flip = 0;

@@ -744,15 +744,20 @@ __global__ __launch_bounds__(kThreads) void ifft_second_kernel(const SecondArgs 
 // operands an XCD has in flight mostly sit in its L2), dealt to the XCDs in contiguous eighths; the transforms of the
 // remaining bins are cut into their five rounds, dealt out behind the whole ones (a workgroup's last, short unit).
 // Record slots are PRN-major: PRN p owns slots [p * per_prn, (p + 1) * per_prn), per_prn = bins_whole + 5 (nbins - bins_whole).
-inline int make_work_list(int n_prn, int nbins, int bins_whole, std::vector<WorkItem>& order, int first[9], int pieces = 5) {
+inline int make_work_list(int n_prn, int nbins, int bins_whole, std::vector<WorkItem>& order, int first[9], int pieces = 5,
+                          int block_bins = 4) {
+    // block_bins: bins of a block of 32 whole transforms (x 32 / block_bins PRNs).  4 x 8 shares 4 spectra + 8 code spectra;
+    // with SHARED spectra (pcps.hip: a handful of class arrays serve every bin, and stay in the L2s) 16 x 2 shares the classes
+    // + 2 code spectra, 32 x 1 the classes + 1: half the operand arrays an XCD has in flight, or fewer.
+    const int block_prns = kSlotsPerXcd / block_bins;
     // pieces: 5 = one unit per round; 3 = rounds {0, 1}, {2, 3}, {4} (N = 50 000: the operand stage of a unit costs what four
     // rounds do, and 64 left-over transforms x 3 fit ONE wave of workgroups where x 5 need a wave and a quarter)
     const int per_prn = bins_whole + pieces * (nbins - bins_whole);
     std::vector<WorkItem> whole, parts;
-    for (int b0 = 0; b0 < bins_whole; b0 += 4)
-        for (int p0 = 0; p0 < n_prn; p0 += 8)
-            for (int b = b0; b < b0 + 4 && b < bins_whole; ++b)
-                for (int p = p0; p < p0 + 8 && p < n_prn; ++p) whole.push_back({p, b, -1, p * per_prn + b});
+    for (int b0 = 0; b0 < bins_whole; b0 += block_bins)
+        for (int p0 = 0; p0 < n_prn; p0 += block_prns)
+            for (int b = b0; b < b0 + block_bins && b < bins_whole; ++b)
+                for (int p = p0; p < p0 + block_prns && p < n_prn; ++p) whole.push_back({p, b, -1, p * per_prn + b});
     for (int b = bins_whole; b < nbins; ++b)
         for (int p = 0; p < n_prn; ++p)
             for (int u = 0; u < pieces; ++u) {

@@ -42,17 +42,21 @@ int sdr_pcps_fused_sweep(sdr_engine* e, const void* F, const void* spec_off, con
     if (N != fused25k::N && N != 2 * fused25k::N) return sdr_fail(SDR_ERR_UNSUPPORTED, "fused PCPS sweep: N = %d", N);
     const int terms = N / fused25k::N;
     const int vbins = terms * nbins;
-    if (e->pcps_work_prn != n_prn || e->pcps_work_bins != vbins) {
+    // (shared spectra: see make_work_list.  Measured, ms of kernels per 32-PRN x 41-bin call with blocks of 4 / 8 / 16 / 32 bins:
+    // N = 25 000 0.2165 / 0.2116 / 0.2118 / 0.2144, N = 50 000 0.4834 / 0.4790 / 0.4705 / 0.4665 -- gpurun_out/r05_block_bins.txt)
+    const int block_bins = spec_off ? (terms == 2 ? 32 : 16) : 4;
+    if (e->pcps_work_prn != n_prn || e->pcps_work_bins != vbins || e->pcps_work_block != block_bins) {
         std::vector<fused25k::WorkItem> order;
         int bins_whole;
         fused_plan(n_prn, vbins, &bins_whole, fused_pieces(terms));
-        fused25k::make_work_list(n_prn, vbins, bins_whole, order, e->pcps_work_first, fused_pieces(terms));
+        fused25k::make_work_list(n_prn, vbins, bins_whole, order, e->pcps_work_first, fused_pieces(terms), block_bins);
         if (int rc = sdr_devbuf_reserve(e, &e->pcps_work, order.size() * sizeof(fused25k::WorkItem))) return rc;
         // (pageable source, tiny: the copy is complete when the stream has been waited for)
         SDR_HIP(hipMemcpyAsync(e->pcps_work.ptr, order.data(), order.size() * sizeof(fused25k::WorkItem), hipMemcpyHostToDevice, e->stream));
         SDR_HIP(hipStreamSynchronize(e->stream));
         e->pcps_work_prn = n_prn;
         e->pcps_work_bins = vbins;
+        e->pcps_work_block = block_bins;
     }
     fused25k::Args a = {};
     a.spec = (const double2*)F;
