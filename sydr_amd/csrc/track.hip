@@ -2099,6 +2099,13 @@ int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int
         if (use) {
             s = e->srv;
             TickServerHost* h = s->host;
+            // a slab that went into the ring the ordinary way while the server was resident (a second sdr_iq_upload_begin before
+            // this tick: sdr_iq_flush_server_slab) is an ingest kernel on the engine's stream: it has to be IN the ring before
+            // the trackers are released on it
+            if (e->slab_busy[0] || e->slab_busy[1]) {
+                SDR_HIP(hipStreamSynchronize(e->ctx0.stream));
+                e->slab_busy[0] = e->slab_busy[1] = false;
+            }
             const size_t sb = sdr_fmt_bytes(e->iq_fmt);
             h->write_index = write_index;
             if (e->srv_slab_pending) {
