@@ -228,13 +228,15 @@ __device__ __forceinline__ bool correlate_epoch_chipn(const void* __restrict__ r
                 }
             }
             b.S = S;
-            unsigned later = 0;
+            // (every boundary at P_g or one later: d_g = 0 / 1 is bit g; anything else, in any of them, shows in their union)
+            unsigned later = 0, any_d = 0;
             static_for<0, NB>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
                 const unsigned d = (unsigned)(at[g] - Shape::pos(g));
-                bad = bad || d > 1u;
-                later |= (d & 1u) << g;
+                any_d |= d;
+                later |= d << g;
             });
+            bad = bad || any_d > 1u;
             b.later = later;
             const char* src = ring_base + (int64_t)S * 2;                  // the block's dwords from a 2-byte aligned address
             static_for<0, kRaw / 4>([&](auto ic) {
