@@ -577,8 +577,8 @@ int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_
         if (off_b % 16 == 0 && bytes % 16 == 0 && cap_b % 16 == 0) {
             sdr_iq_mark_written(e, off, n_samples);
             if (e->srv_running) {
-                // the resident tick server's doorman pulls it out of the staging half with the next request (track.hip): no
-                // launch here.  The half is busy until that request has been answered (or the slab flushed the ordinary way).
+                // the resident tick server's doormen pull it out of the staging half (track.hip): no launch here.  The half is
+                // busy until the request that needs it has been answered (or the slab flushed the ordinary way).
                 e->srv_slab_pending = true;
                 e->srv_slab_half = half;
                 e->srv_slab_off = off;

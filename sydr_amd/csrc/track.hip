@@ -53,33 +53,44 @@ constexpr int kMaxParts = 8;
 // The receiver's per-millisecond loop (receiver.py:120-131: addNewRFData(1 ms); run()) pays a kernel launch and a stream
 // synchronisation per tick: ~13 of a tick's ~29 us in the library (tools/ubench_pingpong.hip: a round trip host -> resident
 // workgroup -> host through page-locked words takes 1.8 us, an empty launch + synchronisation 12.5).  With
-// sdr_set_option("tick_server", 1) the cluster form of the kernel stays RESIDENT between ticks: one more workgroup, the
-// doorman, polls a request word in page-locked memory; a request carries the ring's write index and the slab addNewRFData
-// staged; the doorman pulls the slab into the ring, releases the trackers (a device word they poll), every channel whose next
-// epoch is complete runs it exactly as a block launch would (same cluster, same order of additions: the bits of a plain
-// tick), the doorman gathers records and states into page-locked memory and raises the done word the host spins on.
-// Nothing waits without a bound: the doorman gives up after `idle_ticks` without a request (the host starts a new server
+// sdr_set_option("tick_server", 1) the cluster form of the kernel stays RESIDENT between ticks, and eight more workgroups, the
+// doormen, watch two words in page-locked memory.  A SLAB (sdr_iq_upload_begin) is announced at once: every doorman pulls
+// an eighth of it out of the staging block into the ring and says so in device memory -- while the host is still on its way to
+// the tick.  A REQUEST (sdr_bank_tick_mirrored) carries the ring's write index and the slab it needs; the first doorman waits
+// for the eight shares and releases the channels, each through a word of its own; every channel whose next epoch is complete
+// runs it exactly as a block launch would (same cluster, same order of additions: the bits of a plain tick) and ANSWERS THE
+// HOST ITSELF: one wave writes state and record into page-locked memory and, behind a system-wide release, the request's
+// number into the channel's done word; the host spins on those words.  The doorman only counts the answers (its clock bounds
+// them) and stamps the request.
+// Nothing waits without a bound: the doormen give up after `idle_ticks` without a request (the host starts a new server
 // with the next tick), a tracker after twice that without a release, the doorman after `busy_ticks` without the channels'
-// answers (fault), the exchange as ever after kSpinLimit polls; the host waits a bounded time for the done word and falls
+// answers (fault), the exchange as ever after kSpinLimit polls; the host waits a bounded time for the done words and falls
 // back to plain launches.  Every other call on the engine stops the server first (sdr_set_device).
 constexpr unsigned kServerStop = 0xFFFFFFFFu;
-struct TickServerHost {            // page-locked: the words the host and the doorman share
-    unsigned req_seq;              // host: request number, 1, 2, 3, ...; kServerStop = leave
-    unsigned done_seq;             // doorman: the last request answered
+constexpr int kGoStride = 32;      // unsigned words between two channels' release words: a 128-byte line each
+// The request line: 64 bytes, 64-byte aligned, read by the doormen in ONE access (eight lanes x 8 bytes).  The host writes
+// words 1-5, then word 7, then word 0 (both hold the same numbers); a reader takes the line when words 0 and 7 agree -- each
+// 32-byte half of the access is then at least as new as its number, should the access ever be split.
+enum { kReqSeqs = 0, kReqWriteIndex = 1, kReqSlabSrc16 = 2, kReqSlabN16 = 3, kReqSlabFirst16 = 4, kReqNeedPull = 5, kReqSeqsCopy = 7 };
+struct TickServerHost {            // page-locked: the words the host and the doormen share
+    // [0] / [7]: request number (low half: 1, 2, 3, ...; kServerStop = leave) and slab number (high half: 1, 2, 3, ...: "pull
+    // this slab into the ring"); [1] the ring's write index after the slab; [2] the slab's first 16-byte granule inside the
+    // staging block, [3] its granules, [4] its first ring granule; [5] the slab the request needs in the ring before the channels
+    // are released (0: none)
+    unsigned long long line[8];
+    unsigned done_seq;             // doorman: the last request it has seen answered by every channel (stamps below are that request's)
     unsigned alive;                // doorman: 1 while the server runs
     unsigned fault;                // doorman: why it gave up (1 idle, 2 a channel never answered, 3 exchange fault)
-    long long write_index;         // request: the ring's write index after the slab
-    unsigned long long slab_src16; // request: the slab's first 16-byte granule inside the staging block; slab_n16 = 0: no slab
-    unsigned long long slab_n16, slab_first16;   // granules, first ring granule
-    // doorman: wall-clock stamps (100 MHz) of the last request -- seen, slab in the ring, trackers released, all channels
-    // answered, answers in page-locked memory (sdr_tick_server_stats' second half: where a served tick's time goes)
+    unsigned pad_;
+    // doorman: wall-clock stamps (100 MHz) of the last request -- seen, slab in the ring, channels released, all channels
+    // answered, stamps written (sdr_tick_server_phases: where a served tick's time goes on the device)
     unsigned long long stamps[6];
     unsigned long long tracker[12]; // ... and channel 0's own: release seen, samples visible, correlated, exchanged, updated, answered
 };
-struct TickServerDev {             // device memory: the words the doorman and the trackers share
-    unsigned go_seq;               // doorman: the request the trackers may work on (kServerStop: leave)
-    unsigned done_count;           // trackers: channels that have answered, all requests together
-    unsigned pull_count;           // the doorman's helpers: shares of slabs pulled, all requests together
+struct TickServerDev {             // device memory: the words the doormen and the trackers share
+    unsigned done_count;           // trackers: channels that have answered, all requests together (the doorman's watch on them)
+    unsigned stop;                 // doorman: it has left (the helpers follow)
+    unsigned pulled[8];            // doormen: the last slab whose share each has put into the ring
     long long write_index;
     int fault;                     // a cluster exchange timed out
     unsigned long long t[12];      // channel 0, part 0, lane 0: wall-clock stamps of its last tick (sdr_tick_server_phases); [8..11]: trace build
@@ -87,115 +98,142 @@ struct TickServerDev {             // device memory: the words the doorman and t
 struct TickServer {
     TickServerHost* host;          // nullptr: not a server launch
     TickServerDev* dev;
+    unsigned* go;                  // device [n_ch * kGoStride]: channel c's release word (the request its cluster may work on; kServerStop: leave)
     const uint4* staging;          // page-locked slab staging of the engine
     uint4* ring16;
     unsigned long long ring_n16;
-    int* ran;                      // device [n_ch]: 1 the channel ran its epoch, 0 not ready, -1 stopped (NCO left the replica / the ring)
-    sdr_track_state* st_out;       // device [n_ch]
-    sdr_track_epoch* rec_out;      // device [n_ch]
-    int* h_ran;                    // page-locked copies the doorman fills
+    sdr_track_epoch* rec_out;      // device [n_ch]: where the roles write the epoch's record
+    // page-locked, written by the channels themselves: the answer (state, record, 1 ran / 0 not ready / -1 stopped), then -- behind a
+    // system-wide release -- the number of the request it answers
+    int* h_ran;
     sdr_track_state* h_st;
     sdr_track_epoch* h_rec;
+    unsigned* h_done;
     unsigned long long idle_ticks, busy_ticks;   // of wall_clock64() (100 MHz)
 };
 
-// The doorman: one workgroup of 256 threads, a launch of its own beside the trackers' (the cluster of 32 channels x 8
-// parts fills the cooperative launch's 256 workgroups; the doorman needs a few registers and no LDS to speak of, and shares a
-// compute unit with one of them).
+// The doormen: kDoorGroups workgroups, a launch of their own beside the trackers' (the cluster of 32 channels x 8 parts fills
+// the cooperative launch's 256 workgroups; a doorman needs a few registers and no LDS to speak of, and shares a compute unit
+// with one of them).
 // (eight waves, two per SIMD, few registers: it has to fit beside a tracker workgroup that holds 256 registers per lane on
 // every SIMD of its compute unit -- sixteen waves did not.  A 50 KB slab is seven 16-byte loads per lane, four in flight.)
 constexpr int kDoorThreads = 512;
 // One workgroup reads the host's memory at a few GB/s (a 50 KB slab took it 19 us): kDoorGroups workgroups pull an equal share
-// each.  All of them watch the request word; the first is the doorman proper, the others tell it through a device counter
-// when their share is in the ring, and leave when it does (or by their own, longer, clock).
+// each.  All of them watch the host's words; the first is the doorman proper (requests are its business alone), the others
+// leave when it does (or by their own, longer, clock).
 constexpr int kDoorGroups = 8;
+static_assert(kDoorGroups == 8, "TickServerDev::pulled has eight words");
+__device__ __forceinline__ unsigned long long lane_u64(unsigned long long x, int lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __attribute__((unused)) void tick_server_doorman(const TickServer& s, const int n_ch, const int tid, unsigned* sh_words,
                                                             unsigned long long* sh_q, const int group) {
-    unsigned served = 0, requests = 0;
+    unsigned served = 0, pulled = 0, requests = 0;
     unsigned long long t_last = wall_clock64();
     unsigned why = 0;
     const bool helper = group != 0;
     if (tid == 0 && !helper) __hip_atomic_store(&s.host->alive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (;;) {
-        if (tid == 0) {
-            // (one look per turn of the loop, a short sleep between turns: eight workgroups reading the host's word back to back
-            // slowed the trackers' own traffic -- the channels' answers took 14.9 instead of 12.0 us)
-            unsigned seq = __hip_atomic_load(&s.host->req_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (seq == served && wall_clock64() - t_last > (helper ? 2 * s.idle_ticks : s.idle_ticks)) seq = kServerStop, sh_words[1] = 1;
-            if (helper && seq == served && __hip_atomic_load(&s.dev->go_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kServerStop)
-                seq = kServerStop;                       // (the doorman has left)
-            if (seq != served && seq != kServerStop) {   // a request: its words (written before its number) for everybody
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-                sh_q[0] = (unsigned long long)*(volatile long long*)&s.host->write_index;
-                sh_q[1] = *(volatile unsigned long long*)&s.host->slab_n16;
-                sh_q[2] = *(volatile unsigned long long*)&s.host->slab_src16;
-                sh_q[3] = *(volatile unsigned long long*)&s.host->slab_first16;
+        if (tid < 64) {
+            // (one look per turn of the loop, a short sleep between turns: eight workgroups reading the host's line back to back
+            // slowed the trackers' own traffic -- the channels' answers took 14.9 instead of 12.0 us.  The whole request comes
+            // with the look: eight lanes, 8 bytes each, one access over the link -- no second round trip for its words)
+            unsigned long long w = 0;
+            if (tid < 8) w = __hip_atomic_load(&s.host->line[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long w0 = lane_u64(w, kReqSeqs), w7 = lane_u64(w, kReqSeqsCopy);
+            const unsigned long long q_wi = lane_u64(w, kReqWriteIndex), q_src = lane_u64(w, kReqSlabSrc16), q_n = lane_u64(w, kReqSlabN16),
+                                     q_first = lane_u64(w, kReqSlabFirst16), q_need = lane_u64(w, kReqNeedPull);
+            if (tid == 0) {
+                const bool whole = w0 == w7;
+                const unsigned seq = whole ? (unsigned)w0 : served, pseq = whole ? (unsigned)(w0 >> 32) : pulled;
+                unsigned act = 0;                            // 1: a slab to pull, 2: a request (doorman proper), 4: leave
+                if ((unsigned)w0 == kServerStop || (unsigned)w7 == kServerStop) {
+                    act = 4;
+                } else {
+                    if (pseq != pulled) act |= 1;
+                    if (!helper && seq != served) act |= 2;
+                }
+                if (!act && wall_clock64() - t_last > (helper ? 2 * s.idle_ticks : s.idle_ticks)) act = 4, sh_words[1] = 1;
+                if (helper && !act && __hip_atomic_load(&s.dev->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) act = 4;   // (the doorman has left)
+                if (act & 3) sh_q[0] = q_wi, sh_q[1] = q_n, sh_q[2] = q_src, sh_q[3] = q_first, sh_words[6] = (unsigned)q_need;
+                sh_words[0] = act, sh_words[4] = seq, sh_words[5] = pseq;
             }
-            sh_words[0] = seq;
         }
         __syncthreads();
-        const unsigned seq = sh_words[0];
+        const unsigned act = sh_words[0], seq = sh_words[4], pseq = sh_words[5], need_pull = sh_words[6];
+        const long long wi = (long long)sh_q[0];
+        const unsigned long long n16 = sh_q[1], src16 = sh_q[2], first16 = sh_q[3];
         __syncthreads();
-        if (seq == served) {
+        if (!act) {
             __builtin_amdgcn_s_sleep(4);
             continue;
         }
-        if (seq == kServerStop) {
+        if (act & 4) {
             why = sh_words[1];
             break;
         }
         unsigned long long stamp[6];
         stamp[0] = wall_clock64();
-        const long long wi = (long long)sh_q[0];
-        const unsigned long long n16 = sh_q[1], src16 = sh_q[2], first16 = sh_q[3];
-        // this workgroup's share of the slab: granules [lo, hi)
-        const unsigned long long lo = n16 * (unsigned long long)group / kDoorGroups, hi = n16 * (unsigned long long)(group + 1) / kDoorGroups;
-        for (unsigned long long i0 = lo + tid; i0 < hi; i0 += 4 * kDoorThreads) {     // four loads per lane in flight, then their stores
-            uint4 v[4];
+        if (act & 1) {
+            // (the staging block is the host's memory, written since this compute unit last read it: nothing of it may come out
+            // of a cache -- one invalidation by the first wave, the barrier hands it on)
+            if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            __syncthreads();
+            // this workgroup's share of the slab: granules [lo, hi)
+            const unsigned long long lo = n16 * (unsigned long long)group / kDoorGroups, hi = n16 * (unsigned long long)(group + 1) / kDoorGroups;
+            for (unsigned long long i0 = lo + tid; i0 < hi; i0 += 4 * kDoorThreads) {     // four loads per lane in flight, then their stores
+                uint4 v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (i0 + (unsigned long long)k * kDoorThreads < hi) v[k] = s.staging[src16 + i0 + (unsigned long long)k * kDoorThreads];
+                for (int k = 0; k < 4; ++k)
+                    if (i0 + (unsigned long long)k * kDoorThreads < hi) v[k] = s.staging[src16 + i0 + (unsigned long long)k * kDoorThreads];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned long long i = i0 + (unsigned long long)k * kDoorThreads;
-                if (i < hi) {
-                    unsigned long long d = first16 + i;
-                    if (d >= s.ring_n16) d -= s.ring_n16;
-                    s.ring16[d] = v[k];
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long i = i0 + (unsigned long long)k * kDoorThreads;
+                    if (i < hi) {
+                        unsigned long long d = first16 + i;
+                        if (d >= s.ring_n16) d -= s.ring_n16;
+                        s.ring16[d] = v[k];
+                    }
                 }
             }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every wave: its stores have left (the barrier orders them ...)
-        __syncthreads();                                          // ... before lane 0's device-wide release below)
-        ++requests;
-        if (helper) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every wave: its stores have left (the barrier orders them ...)
+            __syncthreads();                                          // ... before lane 0's device-wide release below)
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __hip_atomic_fetch_add(&s.dev->pull_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&s.dev->pulled[group], pseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            served = seq;
+            pulled = pseq;
             t_last = wall_clock64();
-            continue;
         }
+        if (!(act & 2)) continue;
+        // ---- a request (the doorman proper)
+        ++requests;
         if (tid == 0) {
             s.dev->write_index = wi;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            // the helpers' shares (bounded: a helper that never shows up is a fault like a channel that never answers)
+            // the eight shares of the slab it needs (bounded: a helper that never shows up is a fault like a channel that never answers)
             unsigned ok_pull = 1;
-            {
-                const unsigned want = requests * (unsigned)(kDoorGroups - 1);
+            if (need_pull) {
                 const unsigned long long t0 = wall_clock64();
-                while (n16 && __hip_atomic_load(&s.dev->pull_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-                    if (wall_clock64() - t0 > s.busy_ticks) {
-                        ok_pull = 0;
-                        break;
+                for (int g = 0; g < kDoorGroups && ok_pull; ++g) {
+                    while ((int)(__hip_atomic_load(&s.dev->pulled[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need_pull) < 0) {
+                        if (wall_clock64() - t0 > s.busy_ticks) {
+                            ok_pull = 0;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
                     }
-                    __builtin_amdgcn_s_sleep(1);
                 }
             }
             sh_words[3] = ok_pull;
             stamp[1] = wall_clock64();
-            if (ok_pull) __hip_atomic_store(&s.dev->go_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        // the release: every channel's word (n_ch <= 64: one store of the first wave)
+        if (sh_words[3] && tid < n_ch) __hip_atomic_store(&s.go[(size_t)tid * kGoStride], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
             stamp[2] = wall_clock64();
             const unsigned target = requests * (unsigned)n_ch;
             const unsigned long long t0 = wall_clock64();
@@ -225,45 +263,42 @@ __device__ __attribute__((unused)) void tick_server_doorman(const TickServer& s,
 #endif
             sh_words[2] = ok && sh_words[3];
             stamp[3] = wall_clock64();
+            if (sh_words[2]) {
+                // (the channels have answered the host themselves; what is left is the request's bookkeeping)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                stamp[4] = wall_clock64();
+                for (int k = 0; k < 5; ++k) s.host->stamps[k] = stamp[k];
+                for (int k = 0; k < 12; ++k) s.host->tracker[k] = s.dev->t[k];
+                if (__hip_atomic_load(&s.dev->fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    __hip_atomic_store(&s.host->fault, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                __hip_atomic_store(&s.host->done_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         __syncthreads();
         if (!sh_words[2]) {
             why = 2;
             break;
         }
-        if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the channels' answers, written on other XCDs (one
-        __syncthreads();                                                     // invalidation serves the compute unit)
-        {   // answers -> page-locked memory, 8 bytes per lane
-            const int w_st = n_ch * (int)(sizeof(sdr_track_state) / 8), w_rec = n_ch * (int)(sizeof(sdr_track_epoch) / 8);
-            for (int i = tid; i < n_ch; i += kDoorThreads) s.h_ran[i] = s.ran[i];
-            for (int i = tid; i < w_st; i += kDoorThreads) reinterpret_cast<unsigned long long*>(s.h_st)[i] = reinterpret_cast<const unsigned long long*>(s.st_out)[i];
-            for (int i = tid; i < w_rec; i += kDoorThreads) reinterpret_cast<unsigned long long*>(s.h_rec)[i] = reinterpret_cast<const unsigned long long*>(s.rec_out)[i];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        if (tid == 0) {
-            stamp[4] = wall_clock64();
-            for (int k = 0; k < 5; ++k) s.host->stamps[k] = stamp[k];
-            for (int k = 0; k < 12; ++k) s.host->tracker[k] = s.dev->t[k];
-            if (__hip_atomic_load(&s.dev->fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                __hip_atomic_store(&s.host->fault, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&s.host->done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
         served = seq;
         t_last = wall_clock64();
     }
-    if (tid == 0 && !helper) {
-        __hip_atomic_store(&s.dev->go_seq, kServerStop, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        if (why) __hip_atomic_store(&s.host->fault, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&s.host->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!helper) {
+        // the channels (their release words) and the helpers (the stop word) follow; then the host is told
+        if (tid < n_ch) __hip_atomic_store(&s.go[(size_t)tid * kGoStride], kServerStop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(&s.dev->stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (why) __hip_atomic_store(&s.host->fault, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&s.host->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 #ifndef SDR_TRACK_DENSE_TU
 __global__ __launch_bounds__(kDoorThreads) void tick_doorman_kernel(const TickServer srv, int n_ch) {
-    __shared__ unsigned words[4];
+    __shared__ unsigned words[8];
     __shared__ unsigned long long q[4];
-    if (threadIdx.x < 4) words[threadIdx.x] = 0, q[threadIdx.x] = 0;
+    if (threadIdx.x < 8) words[threadIdx.x] = 0;
+    if (threadIdx.x < 4) q[threadIdx.x] = 0;
     __syncthreads();
     tick_server_doorman(srv, n_ch, (int)threadIdx.x, words, q, (int)blockIdx.x);
 }
@@ -936,14 +971,31 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                     const unsigned want = server_tick + 1;
                     const unsigned long long t0 = wall_clock64();
                     unsigned g;
+                    // (four looks in flight, a quarter of a round trip apart: a look that left just before the release landed
+                    // is followed by one that sees it a quarter of a round trip later, not a whole one)
+                    unsigned* const go = &srv.go[(size_t)ch * kGoStride];
+                    auto look = [&]() { return __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+                    auto hit = [&](unsigned v) { return v == want || v == kServerStop; };
+                    unsigned l0 = look();
+                    __builtin_amdgcn_s_sleep(3);
+                    unsigned l1 = look();
+                    __builtin_amdgcn_s_sleep(3);
+                    unsigned l2 = look();
+                    __builtin_amdgcn_s_sleep(3);
+                    unsigned l3 = look();
                     for (;;) {
-                        g = __hip_atomic_load(&srv.dev->go_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (g == want || g == kServerStop) break;
+                        if (hit(l0)) { g = l0; break; }
+                        l0 = look();
+                        if (hit(l1)) { g = l1; break; }
+                        l1 = look();
+                        if (hit(l2)) { g = l2; break; }
+                        l2 = look();
+                        if (hit(l3)) { g = l3; break; }
+                        l3 = look();
                         if (wall_clock64() - t0 > 2 * srv.idle_ticks) {
                             g = kServerStop;
                             break;
                         }
-                        __builtin_amdgcn_s_sleep(2);
                     }
                     sh->gate = g;
                     // (the request's write index now, past the L2: its round trip runs beside the invalidation below)
@@ -966,8 +1018,9 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                 }
                 if (!ready) {       // (uniform over the channel's parts: same state, same write index)
                     if (tid == 0 && writer) {
-                        srv.ran[ch] = dead ? -1 : 0;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        srv.h_ran[ch] = dead ? -1 : 0;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                        __hip_atomic_store(&srv.h_done[ch], server_tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_fetch_add(&srv.dev->done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     --epoch;        // (this channel's next epoch is still the same one)
@@ -1178,19 +1231,33 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
 #endif
         TRACK_MARK(4);
         if constexpr (kCluster) {
-            if (server) {       // ---- the channel's answer: the state after this epoch, then the count the doorman waits for
+            if (server) {       // ---- the channel's answer, straight to the host: state and record, then the request's number
                 if (tid == 0 && ch == 0 && part == 0) srv.dev->t[4] = wall_clock64();
                 if (role == 2 && rlane == 0) lock_regs_store(lk, sh);
                 __syncthreads();
-                if (tid == 0 && writer) {
-                    compose_state();
-                    states[sidx] = st;
-                    srv.st_out[ch] = st;
-                    srv.ran[ch] = 1;
-                    if (ch == 0) srv.dev->t[5] = wall_clock64();
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    const unsigned before = __hip_atomic_fetch_add(&srv.dev->done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (ch == 0) srv.dev->t[6] = wall_clock64() + (before & 0);      // (stamped after the add has returned: the next tick reports it)
+                if (writer && tid < 64) {
+                    if (tid == 0) compose_state();                          // (the NCO values the roles announced, into the LDS copy)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (LDS serves a wave's operations in order)
+                    __builtin_amdgcn_wave_barrier();
+                    // one wave, 8 bytes per lane: the state out of LDS, the record the roles wrote (this workgroup's own stores:
+                    // the barrier above orders them), the flag -- page-locked memory, one store instruction
+                    constexpr int kStateWords = (int)(sizeof(sdr_track_state) / 8), kRecWords = (int)(sizeof(sdr_track_epoch) / 8);
+                    static_assert(sizeof(sdr_track_state) % 8 == 0 && sizeof(sdr_track_epoch) % 8 == 0 && kStateWords + kRecWords < 64,
+                                  "the answer is one 8-byte store per lane of one wave");
+                    if (tid < kStateWords)
+                        reinterpret_cast<unsigned long long*>(srv.h_st + ch)[tid] = reinterpret_cast<const unsigned long long*>(&sh->st)[tid];
+                    else if (tid < kStateWords + kRecWords)
+                        reinterpret_cast<unsigned long long*>(srv.h_rec + ch)[tid - kStateWords] =
+                            reinterpret_cast<const unsigned long long*>(srv.rec_out + ch)[tid - kStateWords];
+                    else if (tid == 63)
+                        srv.h_ran[ch] = sh->fault ? -2 : 1;                 // (-2: a part of the cluster never published its sums)
+                    if (tid == 0 && ch == 0) srv.dev->t[5] = wall_clock64();
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // (the wave's stores have reached the host's memory ...)
+                    if (tid == 0) {
+                        __hip_atomic_store(&srv.h_done[ch], server_tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // ... before this one
+                        const unsigned before = __hip_atomic_fetch_add(&srv.dev->done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (ch == 0) srv.dev->t[6] = wall_clock64() + (before & 0);      // (stamped after the add has returned: the next tick reports it)
+                    }
                 }
             }
         }
@@ -1854,8 +1921,11 @@ struct TickServerState {
     int* h_ran = nullptr;
     sdr_track_state* h_st = nullptr;
     sdr_track_epoch* h_rec = nullptr;
-    DevBuf dev;                             // TickServerDev, then [ran][states][records][channel map]
+    unsigned* h_done = nullptr;             // per served channel: the last request it has answered
+    DevBuf dev;                             // TickServerDev, then [release words][records][channel map]
     unsigned seq = 0;                       // requests posted to the running server
+    unsigned pull_seq = 0;                  // slabs announced to it
+    unsigned stamps_seq = 0;                // the last request whose stamps went into the sums below
     bool disabled = false;                  // a launch was refused, or a server died at work: plain ticks from then on
     int64_t served_total = 0, starts = 0;   // requests answered / servers started, over the engine's life
     double phase_us[4] = {0, 0, 0, 0};      // summed over the answered requests: slab pull, release, channels' answers, gather
@@ -1876,18 +1946,71 @@ static bool server_wait(volatile unsigned* word, unsigned want, double seconds) 
     }
 }
 
+// Every served channel's done word at `want` (bounded; gives up at once when the doorman has left).
+#ifdef SDR_SRV_HOSTTRACE
+static double g_ht[8]; static long g_htn;
+static inline double ht_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define HT(k, t0) do { const double t1_ = ht_now(); g_ht[k] += t1_ - (t0); (t0) = t1_; } while (0)
+#else
+#define HT(k, t0) ((void)0)
+#endif
+static bool server_wait_all(volatile unsigned* words, int n, unsigned want, volatile unsigned* alive, double seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int k = 0;
+    for (long spins = 0;; ++spins) {
+        while (k < n && __atomic_load_n(&words[k], __ATOMIC_ACQUIRE) == want) ++k;
+        if (k == n) return true;
+        if ((spins & 1023) == 1023) {
+            if (!__atomic_load_n(alive, __ATOMIC_ACQUIRE)) return false;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+        }
+    }
+}
+
+// The doorman's stamps of the last request it has closed, into the sums sdr_tick_server_phases reports (once per request;
+// the doorman closes a request a microsecond or two after the host has its answers: read when the next one is posted).
+static void server_absorb_stamps(TickServerState* s) {
+    TickServerHost* h = s->host;
+    const unsigned closed = __atomic_load_n(&h->done_seq, __ATOMIC_ACQUIRE);
+    if (closed == s->stamps_seq || closed != s->seq) return;
+    s->stamps_seq = closed;
+    for (int k = 0; k < 4; ++k) s->phase_us[k] += (double)(h->stamps[k + 1] - h->stamps[k]) * 0.01;
+    if (h->tracker[5] > h->stamps[2]) {     // (channel 0 ran in this tick)
+        s->tracker_us[0] += (double)((long long)(h->tracker[0] - h->stamps[2])) * 0.01;
+        for (int k = 1; k < 6; ++k) s->tracker_us[k] += (double)((long long)(h->tracker[k] - h->tracker[k - 1])) * 0.01;
+#ifdef SDR_SRV_TRACE
+        for (int k = 0; k < 4; ++k) s->seen_us[k] += (double)h->tracker[8 + k] * 0.01;
+#endif
+        if (h->tracker[6] > h->tracker[5]) s->fence_add_us += (double)(h->tracker[6] - h->tracker[5]) * 0.01, s->prev_t5 += 1;
+    }
+}
+
+// The request line (see TickServerHost): words 1-5, then the numbers' copy, then the numbers.
+static void server_post(TickServerState* s, const unsigned long long* words5) {
+    TickServerHost* h = s->host;
+    for (int k = 0; k < 5; ++k) h->line[1 + k] = words5[k];
+    const unsigned long long seqs = (unsigned long long)s->seq | ((unsigned long long)s->pull_seq << 32);
+    __atomic_store_n(&h->line[kReqSeqsCopy], seqs, __ATOMIC_RELEASE);
+    __atomic_store_n(&h->line[kReqSeqs], seqs, __ATOMIC_RELEASE);
+}
+static void server_post_stop(TickServerState* s) {
+    __atomic_store_n(&s->host->line[kReqSeqsCopy], (unsigned long long)kServerStop, __ATOMIC_RELEASE);
+    __atomic_store_n(&s->host->line[kReqSeqs], (unsigned long long)kServerStop, __ATOMIC_RELEASE);
+}
+
 int sdr_tick_server_stop(sdr_engine* e) {
     if (e) e->srv_steady_ticks = 0;
     if (!e || !e->srv_running) return SDR_OK;
     TickServerState* s = e->srv;
     e->srv_running = false;
-    __atomic_store_n(&s->host->req_seq, kServerStop, __ATOMIC_RELEASE);
+    server_post_stop(s);
     // (the doorman looks at the word every few microseconds; the trackers follow its release word.  Should the words never be
     // seen -- they always are -- every workgroup still leaves by its own clock: the stream synchronisation below ends either way)
     (void)server_wait(&s->host->alive, 0u, 1.0);
     SDR_HIP(hipStreamSynchronize(s->door_stream));
     SDR_HIP(hipStreamSynchronize(s->ctx.stream));
-    s->seq = 0;
+    server_absorb_stamps(s);
+    s->seq = s->pull_seq = s->stamps_seq = 0;
     // a slab the server had not pulled yet: into the ring the ordinary way
     if (e->srv_slab_pending) return sdr_iq_flush_server_slab(e);
     return SDR_OK;
@@ -1917,7 +2040,7 @@ static int tick_server_start(sdr_engine* e, sdr_bank* b, const int32_t* channels
     int parts = 1;
     while (parts < kMaxParts && (long)n * parts * 2 <= (long)e->n_cus) parts *= 2;     // (the cluster a tick of these channels takes)
     if (parts < 2) return sdr_fail(SDR_ERR_UNSUPPORTED, "tick server: %d channels leave no cluster", n);
-    const size_t res_bytes = (size_t)n * (sizeof(int) + sizeof(sdr_track_state) + sizeof(sdr_track_epoch));
+    const size_t res_bytes = (size_t)n * (sizeof(int) + sizeof(unsigned) + sizeof(sdr_track_state) + sizeof(sdr_track_epoch));
     const size_t host_bytes = ((sizeof(TickServerHost) + 63) & ~(size_t)63) + res_bytes + 64;
     if (host_bytes > s->host_bytes) {
         if (s->host) SDR_HIP(hipHostFree(s->host));
@@ -1932,25 +2055,26 @@ static int tick_server_start(sdr_engine* e, sdr_bank* b, const int32_t* channels
     }
     memset(s->host, 0, host_bytes);
     char* hp = (char*)s->host + ((sizeof(TickServerHost) + 63) & ~(size_t)63);
-    s->h_st = (sdr_track_state*)hp;                                   // (8-byte fields first: the doorman copies 8 bytes per lane)
+    s->h_st = (sdr_track_state*)hp;                                   // (8-byte fields first: the channels write 8 bytes per lane)
     s->h_rec = (sdr_track_epoch*)(hp + (size_t)n * sizeof(sdr_track_state));
     s->h_ran = (int*)(hp + (size_t)n * (sizeof(sdr_track_state) + sizeof(sdr_track_epoch)));
-    const size_t dev_head = (sizeof(TickServerDev) + 63) & ~(size_t)63;
-    const size_t dev_bytes = dev_head + res_bytes + (size_t)n * sizeof(int32_t) + 64;
+    s->h_done = (unsigned*)(s->h_ran + n);
+    const size_t dev_head = (sizeof(TickServerDev) + 127) & ~(size_t)127;
+    const size_t go_bytes = (size_t)n * kGoStride * sizeof(unsigned);
+    const size_t dev_bytes = dev_head + go_bytes + (size_t)n * (sizeof(sdr_track_epoch) + sizeof(int32_t)) + 64;
     if (int rc = sdr_devbuf_reserve_on(e, s->ctx.stream, &s->dev, dev_bytes)) return rc;
     SDR_HIP(hipMemsetAsync(s->dev.ptr, 0, dev_bytes, s->ctx.stream));
     char* dp = (char*)s->dev.ptr + dev_head;
     TickServer a = {};
     a.host = s->host;
     a.dev = (TickServerDev*)s->dev.ptr;
+    a.go = (unsigned*)dp;
     a.staging = (const uint4*)e->slab_pinned;
     a.ring16 = (uint4*)e->iq;
     a.ring_n16 = (unsigned long long)((size_t)e->iq_capacity * sdr_fmt_bytes(e->iq_fmt) / 16);
-    a.st_out = (sdr_track_state*)dp;
-    a.rec_out = (sdr_track_epoch*)(dp + (size_t)n * sizeof(sdr_track_state));
-    a.ran = (int*)(dp + (size_t)n * (sizeof(sdr_track_state) + sizeof(sdr_track_epoch)));
-    int32_t* d_map = (int32_t*)(dp + res_bytes);
-    a.h_ran = s->h_ran, a.h_st = s->h_st, a.h_rec = s->h_rec;
+    a.rec_out = (sdr_track_epoch*)(dp + go_bytes);
+    int32_t* d_map = (int32_t*)(dp + go_bytes + (size_t)n * sizeof(sdr_track_epoch));
+    a.h_ran = s->h_ran, a.h_st = s->h_st, a.h_rec = s->h_rec, a.h_done = s->h_done;
     a.idle_ticks = 20000000ull;      // 0.2 s of the 100 MHz wall clock without a request: leave (the next tick starts a new server)
     a.busy_ticks = 5000000ull;       // 50 ms for the channels' answers to one request: something is wrong, leave
     SDR_HIP(hipMemcpyAsync(d_map, channels, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s->ctx.stream));
@@ -1980,8 +2104,8 @@ static int tick_server_start(sdr_engine* e, sdr_bank* b, const int32_t* channels
     // the doorman has to be RESIDENT beside the trackers (they fill the device): it says so itself
     if (door_err != hipSuccess || !server_wait(&s->host->alive, 1u, 0.05)) {
         // no doorman: tell it (should it still arrive) and the trackers (they poll the device word) to leave, wait for them
-        __atomic_store_n(&s->host->req_seq, kServerStop, __ATOMIC_RELEASE);
-        (void)hipMemsetAsync(&a.dev->go_seq, 0xFF, sizeof(unsigned), e->ctx0.stream);
+        server_post_stop(s);
+        (void)hipMemsetAsync(a.go, 0xFF, go_bytes, e->ctx0.stream);
         (void)hipStreamSynchronize(e->ctx0.stream);
         (void)hipStreamSynchronize(s->ctx.stream);
         (void)hipStreamSynchronize(s->door_stream);
@@ -1991,7 +2115,7 @@ static int tick_server_start(sdr_engine* e, sdr_bank* b, const int32_t* channels
     s->bank = b;
     s->channels.assign(channels, channels + n);
     s->parts = parts, s->n_taps = nt;
-    s->seq = 0;
+    s->seq = s->pull_seq = s->stamps_seq = 0;
     s->code_generation = e->code_generation;
     s->ring = e->iq;
     s->staging = e->slab_pinned;
@@ -2025,6 +2149,9 @@ int sdr_bank_tick(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples,
 // absorbs the results into the mirrors and writes the tick's update rows.  sdr_bank_tick_mirrored is the two in a row.
 int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int64_t n_samples, int64_t ring_offset,
                                  int64_t write_index, sdr_tick_mirror* m) {
+#ifdef SDR_SRV_HOSTTRACE
+    double ht0 = ht_now();
+#endif
     if (int rc = sdr_set_device_keep(e)) return rc;        // (a resident tick server stays: this may be its next request)
     if (!b) return sdr_fail(SDR_ERR_INVALID, "bank is NULL");
     if (b->tick_open) return sdr_fail(SDR_ERR_STATE, "a tick of this bank is already in flight: sdr_bank_tick_mirrored_end first");
@@ -2098,7 +2225,6 @@ int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int
             if (int rc = sdr_tick_server_stop(e)) return rc;
         if (use) {
             s = e->srv;
-            TickServerHost* h = s->host;
             // a slab that went into the ring the ordinary way while the server was resident (a second sdr_iq_upload_begin before
             // this tick: sdr_iq_flush_server_slab) is an ingest kernel on the engine's stream: it has to be IN the ring before
             // the trackers are released on it
@@ -2106,16 +2232,23 @@ int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int
                 SDR_HIP(hipStreamSynchronize(e->ctx0.stream));
                 e->slab_busy[0] = e->slab_busy[1] = false;
             }
-            const size_t sb = sdr_fmt_bytes(e->iq_fmt);
-            h->write_index = write_index;
+            HT(0, ht0);                       // begin: checks, ready list
+            server_absorb_stamps(s);          // (the request before this one: the doorman has closed it long since)
+            HT(1, ht0);                       // absorb
+            // The slab this tick brought (staged by sdr_iq_upload_begin while the server was resident) is announced WITH the
+            // request, not when it was staged: pulled earlier, its 800 cache lines are taken out of the host core's cache while
+            // the caller is still at work between the two calls -- measured from Python: 43.1 us per tick against 36.4.
+            unsigned long long words[5] = {(unsigned long long)write_index, 0, 0, 0, 0};
             if (e->srv_slab_pending) {
-                h->slab_src16 = (unsigned long long)((e->srv_slab_half ? e->slab_bytes : 0) / 16);
-                h->slab_n16 = (unsigned long long)((size_t)e->srv_slab_n * sb / 16);
-                h->slab_first16 = (unsigned long long)((size_t)e->srv_slab_off * sb / 16);
-            } else {
-                h->slab_n16 = 0;
+                const size_t sb = sdr_fmt_bytes(e->iq_fmt);
+                words[1] = (unsigned long long)((e->srv_slab_half ? e->slab_bytes : 0) / 16);
+                words[2] = (unsigned long long)((size_t)e->srv_slab_n * sb / 16);
+                words[3] = (unsigned long long)((size_t)e->srv_slab_off * sb / 16);
+                words[4] = ++s->pull_seq;
             }
-            __atomic_store_n(&h->req_seq, ++s->seq, __ATOMIC_RELEASE);
+            ++s->seq;
+            server_post(s, words);
+            HT(2, ht0);                       // post
             b->tick_served = true;
             b->tick_open = true;
             return SDR_OK;
@@ -2180,7 +2313,12 @@ int sdr_bank_tick_mirrored_end(sdr_engine* e, sdr_bank* b, sdr_tick_mirror* m) {
         // ---- the answer of the resident server: wait for its done word (bounded), take the listed channels' rows
         TickServerState* s = e->srv;
         TickServerHost* h = s->host;
-        if (!server_wait(&h->done_seq, s->seq, 0.25)) {
+#ifdef SDR_SRV_HOSTTRACE
+        double ht0 = ht_now();
+#endif
+        const bool answered = server_wait_all(s->h_done, (int)s->channels.size(), s->seq, &h->alive, 0.25);
+        HT(3, ht0);                           // wait
+        if (!answered) {
             const unsigned alive = __atomic_load_n(&h->alive, __ATOMIC_ACQUIRE), why = __atomic_load_n(&h->fault, __ATOMIC_ACQUIRE);
             (void)sdr_tick_server_stop(e);
             s->disabled = true;
@@ -2189,20 +2327,13 @@ int sdr_bank_tick_mirrored_end(sdr_engine* e, sdr_bank* b, sdr_tick_mirror* m) {
                             s->seq, alive, why);
         }
         s->served_total += 1;
-        for (int k = 0; k < 4; ++k) s->phase_us[k] += (double)(h->stamps[k + 1] - h->stamps[k]) * 0.01;
-        if (h->tracker[5] > h->stamps[2]) {     // (channel 0 ran in this tick)
-            s->tracker_us[0] += (double)((long long)(h->tracker[0] - h->stamps[2])) * 0.01;
-            for (int k = 1; k < 6; ++k) s->tracker_us[k] += (double)((long long)(h->tracker[k] - h->tracker[k - 1])) * 0.01;
-#ifdef SDR_SRV_TRACE
-            for (int k = 0; k < 4; ++k) s->seen_us[k] += (double)h->tracker[8 + k] * 0.01;
-#endif
-            if (h->tracker[6] > h->tracker[5]) s->fence_add_us += (double)(h->tracker[6] - h->tracker[5]) * 0.01, s->prev_t5 += 1;
-        }
         if (e->srv_slab_pending) {              // (the doorman has pulled it: its staging half is free again)
             e->srv_slab_pending = false;
             e->slab_busy[e->srv_slab_half] = false;
         }
-        if (__atomic_load_n(&h->fault, __ATOMIC_ACQUIRE)) {
+        bool xchg_fault = __atomic_load_n(&h->fault, __ATOMIC_ACQUIRE) != 0;
+        for (size_t c = 0; c < s->channels.size(); ++c) xchg_fault = xchg_fault || s->h_ran[c] == -2;
+        if (xchg_fault) {
             (void)sdr_tick_server_stop(e);
             s->disabled = true;
             return sdr_fail(SDR_ERR_HIP, "closed-loop tracking: a workgroup of a %d-part cluster never published its sums (tick server)", s->parts);
@@ -2236,6 +2367,14 @@ int sdr_bank_tick_mirrored_end(sdr_engine* e, sdr_bank* b, sdr_tick_mirror* m) {
         }
         b->tick_two = false;
         b->tick_groups = 0;
+        HT(4, ht0);                           // answers copied
+#ifdef SDR_SRV_HOSTTRACE
+        if (++g_htn % 500 == 0) {
+            fprintf(stderr, "host trace (us per tick): begin %.2f absorb %.2f post %.2f wait %.2f copy %.2f\n", g_ht[0] / 500, g_ht[1] / 500,
+                    g_ht[2] / 500, g_ht[3] / 500, g_ht[4] / 500);
+            for (double& v : g_ht) v = 0;
+        }
+#endif
     } else if (list.empty()) {
         if (b->tick_slab_queued) SDR_HIP(hipStreamSynchronize(e->ctx0.stream));
     }
@@ -2316,9 +2455,11 @@ int sdr_tick_server_stats(sdr_engine* e, int64_t* out4) {
 }
 
 // Where the served requests' time went on the device, in microseconds summed over them (the doorman's wall-clock stamps):
-// {slab pulled into the ring, trackers released, every channel answered, answers gathered into page-locked memory}.
+// {the slab's shares in the ring (pulled since it was staged: what is left of that when the request arrives), channels released,
+// every channel has answered (the host has the answers by then: the channels write them themselves), the request closed}.
 int sdr_tick_server_phases(sdr_engine* e, double* out4) {
     if (!e || !out4) return sdr_fail(SDR_ERR_INVALID, "null engine or output");
+    if (e->srv && e->srv_running) server_absorb_stamps(e->srv);
     for (int k = 0; k < 4; ++k) out4[k] = e->srv ? e->srv->phase_us[k] : 0.0;
     return SDR_OK;
 }
@@ -2327,6 +2468,7 @@ int sdr_tick_server_phases(sdr_engine* e, double* out4) {
 // correlated, sums exchanged, loops updated, answer written}.
 int sdr_tick_server_tracker_phases(sdr_engine* e, double* out6) {
     if (!e || !out6) return sdr_fail(SDR_ERR_INVALID, "null engine or output");
+    if (e->srv && e->srv_running) server_absorb_stamps(e->srv);
     for (int k = 0; k < 6; ++k) out6[k] = e->srv ? e->srv->tracker_us[k] : 0.0;
 #ifdef SDR_SRV_TRACE
     if (e->srv && e->srv->served_total)
