@@ -969,6 +969,7 @@ def main():
     ap.add_argument("--no-ref-config", action="store_true")
     ap.add_argument("--no-rates", action="store_true", help="skip the E/P/L leg over the other sampling rates")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the leg that streams the recording from host memory")
+    ap.add_argument("--no-bind", action="store_true", help="leave the host thread where the scheduler puts it (default: the CPUs next to the GPU)")
     ap.add_argument("--cpu-mp-seconds", type=float, default=10.0, help="budget of the all-cores CPU baseline (0: skip)")
     ap.add_argument("--watchdog-seconds", type=float, default=300.0,
                     help="if the legs AFTER the timed headline measurement have not finished by then, print the line with what "
@@ -1023,6 +1024,16 @@ def main():
     from sydr_amd.engine import FMT_CI8, Engine
 
     eng = Engine(local_rank)
+    # this rank's host thread onto the CPUs next to its GPU (what `numactl --cpunodebind` per rank does): the host-side legs --
+    # the per-millisecond loop above all -- are round trips through page-locked memory, and from the other socket of a
+    # two-socket host each crosses the sockets' interconnect as well
+    host_thread_bound = False
+    if not args.no_bind:
+        try:
+            eng.set_option("bind_thread_to_device", 1)
+            host_thread_bound = True
+        except Exception as exc:                            # (no sysfs entry, a cpuset that excludes those CPUs: run unbound)
+            print(f"[bench] host thread not bound to the GPU's CPUs: {exc}", file=sys.stderr)
     total = int(args.stream_seconds * FS) // 8 * 8
     eng.iq_alloc(total, FMT_CI8)
     eng.code_slots(N_CH + VERIFY_PER_RANK)                  # (+ spare slots: rank 0 re-tracks other ranks' channels)
@@ -1118,6 +1129,7 @@ def main():
                    "step": f"one pass over the whole stream ({n_epochs} epochs x {N_CH} channels) = {len(launch_starts)} "
                            f"launch(es) of {min(per_launch, n_run)} channel-epochs",
                    "channels_per_gpu": N_CH, "channels_total": n_total, "fs_hz": FS, "taps": len(SPACING), "iq_format": "ci8",
+                   "host_thread_bound_to_gpu_cpus": host_thread_bound,
                    "mode": f"open-loop batched (true NCO trajectory, {min(per_launch, n_run)} channel-epochs per launch)",
                    "sharding": f"one stream of {n_total} satellites replicated on {world} GPU(s) (same seed), channels "
                                f"sharded {N_CH} per GPU, one HIP stream per channel batch, no collective"},

@@ -6,6 +6,8 @@
  * 32 channels @ 25 MHz: acquisition of the first millisecond, then `ticks` milliseconds tracked tick by tick with the host as
  * IQ source; prints where the channels ended and the time per tick.  A second argument `server` switches the resident
  * tick server on (sdr_set_option "tick_server"): the same two calls per tick, answered by a kernel that is already there.
+ * The thread is kept on the CPUs next to the GPU (sdr_set_option "bind_thread_to_device"; a third argument `nobind` leaves it
+ * where the scheduler puts it: ~6 us per tick more from the other socket of a two-socket host).
  * Build:  gcc -std=c99 -O2 -Iinclude examples/receiver_loop.c -Lsydr_amd -lsydr_amd -lm -Wl,-rpath,'$ORIGIN/../sydr_amd' -o examples/receiver_loop
  */
 #define _POSIX_C_SOURCE 199309L
@@ -43,6 +45,8 @@ int main(int argc, char** argv) {
     const int64_t total = (int64_t)(ticks + 2) * spms;
     sdr_engine* e = NULL;
     CK(sdr_engine_create(0, &e));
+    if (!(argc > 3 && !strcmp(argv[3], "nobind")) && !(argc > 2 && !strcmp(argv[2], "nobind")))
+        (void)sdr_set_option(e, "bind_thread_to_device", 1);       /* (best effort: no sysfs, no binding) */
     CK(sdr_code_slots(e, N_CH, 1023));
     sdr_synth_sat sats[N_CH];
     int32_t slots[N_CH];

@@ -413,21 +413,30 @@ int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int
                                  int64_t write_index, sdr_tick_mirror* m);
 int sdr_bank_tick_mirrored_end(sdr_engine* e, sdr_bank* b, sdr_tick_mirror* m);
 /* sdr_set_option(e, "tick_server", 1): the steady tick (sdr_bank_tick_mirrored*, the slab handed over by
- * sdr_iq_upload_begin) is answered by a RESIDENT kernel instead of launches and a stream synchronisation -- what the
+ * sdr_iq_upload_begin) is answered by RESIDENT kernels instead of launches and a stream synchronisation -- what the
  * reference's manager gets from channel processes that wait on an Event between ticks (channel.py:121-160).  The cluster form
- * of the tracking kernel stays on the device with one more workgroup, the doorman, which polls a request word in page-locked
- * memory, pulls the slab into the ring, releases the trackers and gathers their answers; who is ready is decided on the
- * device by the arithmetic of channel.py:137-146 and must agree with the caller's mirror (SDR_ERR_STATE otherwise).  Same
- * clusters and order of additions as the plain tick: same bits.  Served: banks whose tracking channels run one tap count
- * and number at most a quarter of the compute units (64), after eight such ticks in a row with no other call on the engine
- * in between (a server takes ~25 ms to start); anything else takes the plain path.  Any other call on the engine
- * (a search, a put, an upload by another route, sdr_engine_destroy) tells the server to leave first and waits for it; the
- * next steady tick starts a new one.  Nothing on the device waits without a bound: the server leaves by itself after 0.2 s
- * without a request; the host waits at most 0.25 s for an answer, then reports SDR_ERR_HIP and goes back to plain ticks.
- * out4: {a server is resident now, requests answered, servers started, the engine went back to plain ticks for good}. */
+ * of the tracking kernel stays on the device; eight more workgroups, the doormen, watch a 64-byte request line in page-locked
+ * memory (the whole request in one access over the link), pull an eighth of the slab each into the ring and release the
+ * channels; every channel ANSWERS THE HOST ITSELF -- state, record and the request's number written straight into page-locked
+ * memory by one of its waves -- and the host spins on those words; who is ready is decided on the device by the arithmetic of
+ * channel.py:137-146 and must agree with the caller's mirror (SDR_ERR_STATE otherwise).  Same clusters and order of additions
+ * as the plain tick: same bits.  Served: banks whose tracking channels run one tap count and number at most a quarter of the
+ * compute units (64), after eight such ticks in a row with no other call on the engine in between (a server takes ~25 ms to
+ * start); anything else takes the plain path.  Any other call on the engine (a search, a put, an upload by another route,
+ * sdr_engine_destroy) tells the server to leave first and waits for it; the next steady tick starts a new one.  Nothing on the
+ * device waits without a bound: the server leaves by itself after 0.2 s without a request; the host waits at most 0.25 s for
+ * an answer, then reports SDR_ERR_HIP and goes back to plain ticks.
+ * out4: {a server is resident now, requests answered, servers started, the engine went back to plain ticks for good}.
+ *
+ * sdr_set_option(e, "bind_thread_to_device", 1): the CALLING thread is restricted to the CPUs next to the engine's GPU (the
+ * local_cpulist of its PCI function; never outside the thread's present mask), 0 gives it its old mask back; SDR_ERR_UNSUPPORTED
+ * where sysfs does not say.  A served tick is a handful of round trips through page-locked words: from the other socket of a
+ * two-socket host each crosses the sockets' interconnect too (21 us per tick against 27, examples/receiver_loop.c).  Opt-in: a
+ * library does not move its caller's threads unasked. */
 int sdr_tick_server_stats(sdr_engine* e, int64_t* out4);
-/* Where the answered requests' time went ON THE DEVICE, microseconds summed over them (the doorman's wall-clock stamps):
- * {slab pulled into the ring, trackers released, every channel answered, answers gathered into page-locked memory}. */
+/* Where the answered requests' time went ON THE DEVICE, microseconds summed over them (the first doorman's wall-clock stamps):
+ * {slab pulled into the ring, channels released, every channel has answered -- as the doorman sees it, which keeps quiet
+ * while the channels work: up to a microsecond late --, the request closed}. */
 int sdr_tick_server_phases(sdr_engine* e, double* out4);
 /* ... and channel 0's own tick (lane 0 of its first part): {release seen, samples visible, correlated, sums exchanged, loops
  * updated, answer written}. */

@@ -1,5 +1,8 @@
 // Engine lifetime, error text, IQ ring in HBM, per-kernel hipEvent timing.
 #include "engine_internal.h"
+#include <sched.h>
+#include <cerrno>
+#include <cctype>
 #include "build_id.h"
 
 #include <cstring>
@@ -194,6 +197,54 @@ int sdr_iq_flipped(sdr_engine* e, hipStream_t stream, const void** out) {
 }
 
 
+// The calling thread onto the CPUs next to the engine's GPU (its PCI function's local_cpulist in sysfs).  A receiver tick
+// is a few round trips over the link through page-locked words: from the other socket each of them crosses the sockets'
+// interconnect as well -- measured on a two-socket host, examples/receiver_loop.c with the resident tick server: 21.0-21.6 us per
+// tick from the GPU's own node, 26.3-27.5 from the other.  Page-locked memory the engine allocates afterwards lands on that
+// node too (first touch by this thread).  value = 0 restores the mask the thread had.
+static int bind_thread_to_device(sdr_engine* e, int value) {
+    static thread_local cpu_set_t saved;
+    static thread_local bool have_saved = false;
+    if (!value) {
+        if (have_saved && sched_setaffinity(0, sizeof(saved), &saved) != 0)
+            return sdr_fail(SDR_ERR_UNSUPPORTED, "sched_setaffinity: %s", strerror(errno));
+        have_saved = false;
+        return SDR_OK;
+    }
+    char bdf[64] = {0};
+    SDR_HIP(hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf) - 1, e->device));
+    for (char* c = bdf; *c; ++c) *c = (char)tolower((unsigned char)*c);
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+    FILE* f = fopen(path, "r");
+    if (!f) return sdr_fail(SDR_ERR_UNSUPPORTED, "%s: %s", path, strerror(errno));
+    char list[1024] = {0};
+    const bool got = fgets(list, sizeof(list), f) != nullptr;
+    fclose(f);
+    cpu_set_t now, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof(now), &now) != 0) return sdr_fail(SDR_ERR_UNSUPPORTED, "sched_getaffinity: %s", strerror(errno));
+    int n = 0;
+    for (char* p = list; got && *p && *p != '\n';) {            // "0-63,128-191"
+        char* end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+            if (c >= 0 && CPU_ISSET((int)c, &now)) CPU_SET((int)c, &want), ++n;   // (never outside what the thread was allowed)
+        if (*p == ',') ++p;
+    }
+    if (!n) return sdr_fail(SDR_ERR_UNSUPPORTED, "%s names no CPU this thread may run on ('%s')", path, list);
+    if (!have_saved) saved = now, have_saved = true;
+    if (sched_setaffinity(0, sizeof(want), &want) != 0) return sdr_fail(SDR_ERR_UNSUPPORTED, "sched_setaffinity: %s", strerror(errno));
+    return SDR_OK;
+}
+
 extern "C" {
 
 int sdr_set_option(sdr_engine* e, const char* name, int value) {
@@ -212,6 +263,7 @@ int sdr_set_option(sdr_engine* e, const char* name, int value) {
         if (e->srv_running) (void)sdr_tick_server_stop(e);
         e->tick_server_opt = value != 0;
     }
+    else if (!strcmp(name, "bind_thread_to_device")) return bind_thread_to_device(e, value);
     else if (!strcmp(name, "pcps_prn_chunk")) e->pcps_prn_chunk = value;
     else if (!strcmp(name, "epl_no_chip_variant")) e->epl_no_chip = value != 0;
     else if (!strcmp(name, "epl_no_split_variant")) e->epl_no_split = value != 0;

@@ -94,6 +94,12 @@ struct TickServerDev {             // device memory: the words the doormen and t
     long long write_index;
     int fault;                     // a cluster exchange timed out
     unsigned long long t[12];      // channel 0, part 0, lane 0: wall-clock stamps of its last tick (sdr_tick_server_phases); [8..11]: trace build
+#ifdef SDR_SRV_TRACE
+    unsigned long long seen_at;          // the doorman: when it saw the current request
+    unsigned long long ch_gate[64], ch_done[64], ch_n[64];   // per channel, summed over requests: request seen -> release seen / answered (recording part)
+    unsigned ch_where[64];               // ... and where that part runs (XCC_ID << 16 | HW_ID's CU bits)
+    unsigned door_where[8];              // ... and the doormen
+#endif
 };
 struct TickServer {
     TickServerHost* host;          // nullptr: not a server launch
@@ -131,12 +137,29 @@ __device__ __forceinline__ unsigned long long lane_u64(unsigned long long x, int
 __device__ __attribute__((unused)) void tick_server_doorman(const TickServer& s, const int n_ch, const int tid, unsigned* sh_words,
                                                             unsigned long long* sh_q, const int group) {
     unsigned served = 0, pulled = 0, requests = 0;
+    unsigned quiet = 0;                // long sleeps before the next look at the host's line (see below)
     unsigned long long t_last = wall_clock64();
     unsigned why = 0;
     const bool helper = group != 0;
     if (tid == 0 && !helper) __hip_atomic_store(&s.host->alive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef SDR_SRV_TRACE
+    if (tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        s.dev->door_where[group] = (xcc << 16) | (hw & 0xffff);
+    }
+#endif
     for (;;) {
         if (tid < 64) {
+            // A compute unit returns its waves' loads IN ORDER: while a doorman's look at the host's line is on its way over the
+            // link (~1.5 us), every load of the tracker workgroup it shares the compute unit with waits behind it -- measured
+            // per channel (-DSDR_SRV_TRACE): the channels with a part beside a doorman answered 5-7 us after the others, and the
+            // tick is as long as its last channel.  So the doormen keep QUIET while the channels work: a helper for ~12 us after
+            // its share of a slab (the request it came with takes longer than that), the doorman proper between the release
+            // and the time the first answers are due (its count of the answers is not on the host's path any more).
+            for (unsigned k = 0; k < quiet; ++k) __builtin_amdgcn_s_sleep(127);      // (8128 clocks each)
+            quiet = 0;
             // (one look per turn of the loop, a short sleep between turns: eight workgroups reading the host's line back to back
             // slowed the trackers' own traffic -- the channels' answers took 14.9 instead of 12.0 us.  The whole request comes
             // with the look: eight lanes, 8 bytes each, one access over the link -- no second round trip for its words)
@@ -206,12 +229,16 @@ __device__ __attribute__((unused)) void tick_server_doorman(const TickServer& s,
             }
             pulled = pseq;
             t_last = wall_clock64();
+            if (helper) quiet = 3;
         }
         if (!(act & 2)) continue;
         // ---- a request (the doorman proper)
         ++requests;
         if (tid == 0) {
             s.dev->write_index = wi;
+#ifdef SDR_SRV_TRACE
+            s.dev->seen_at = stamp[0];
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             // the eight shares of the slab it needs (bounded: a helper that never shows up is a fault like a channel that never answers)
             unsigned ok_pull = 1;
@@ -238,6 +265,8 @@ __device__ __attribute__((unused)) void tick_server_doorman(const TickServer& s,
             const unsigned target = requests * (unsigned)n_ch;
             const unsigned long long t0 = wall_clock64();
             unsigned ok = 1;
+            __builtin_amdgcn_s_sleep(127);       // (quiet while the channels work: see the top of the loop)
+            __builtin_amdgcn_s_sleep(127);
 #ifdef SDR_SRV_TRACE
             unsigned long long seen[4] = {0, 0, 0, 0};      // first sight of 1, n/2, n - 1, n answers
 #endif
@@ -256,7 +285,7 @@ __device__ __attribute__((unused)) void tick_server_doorman(const TickServer& s,
                     ok = 0;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(32);
             }
 #ifdef SDR_SRV_TRACE
             for (int k = 0; k < 4; ++k) s.dev->t[8 + k] = seen[k] - t0;
@@ -998,6 +1027,16 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                         }
                     }
                     sh->gate = g;
+#ifdef SDR_SRV_TRACE
+                    if (writer) {
+                        const unsigned long long at = __hip_atomic_load(&srv.dev->seen_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        srv.dev->ch_gate[ch] += wall_clock64() - at;
+                        unsigned hw, xcc;
+                        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                        srv.dev->ch_where[ch] = (xcc << 16) | (hw & 0xffff);
+                    }
+#endif
                     // (the request's write index now, past the L2: its round trip runs beside the invalidation below)
                     sh->gate_wi = __hip_atomic_load(&srv.dev->write_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (ch == 0 && part == 0) srv.dev->t[0] = wall_clock64();
@@ -1018,8 +1057,8 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                 }
                 if (!ready) {       // (uniform over the channel's parts: same state, same write index)
                     if (tid == 0 && writer) {
-                        srv.h_ran[ch] = dead ? -1 : 0;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                        __hip_atomic_store(&srv.h_ran[ch], dead ? -1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (acknowledged: in the host's memory -- see the answer below)
                         __hip_atomic_store(&srv.h_done[ch], server_tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         __hip_atomic_fetch_add(&srv.dev->done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -1244,19 +1283,28 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                     constexpr int kStateWords = (int)(sizeof(sdr_track_state) / 8), kRecWords = (int)(sizeof(sdr_track_epoch) / 8);
                     static_assert(sizeof(sdr_track_state) % 8 == 0 && sizeof(sdr_track_epoch) % 8 == 0 && kStateWords + kRecWords < 64,
                                   "the answer is one 8-byte store per lane of one wave");
+                    // (system-scope stores: past every cache, so that "the wave's stores are acknowledged" below means "they are in
+                    // the host's memory".  A release FENCE here writes the whole XCD's L2 back -- the four channels that answer on
+                    // one XCD queued behind each other for it: the last answer came 3 us after the median one)
                     if (tid < kStateWords)
-                        reinterpret_cast<unsigned long long*>(srv.h_st + ch)[tid] = reinterpret_cast<const unsigned long long*>(&sh->st)[tid];
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(srv.h_st + ch) + tid,
+                                           reinterpret_cast<const unsigned long long*>(&sh->st)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     else if (tid < kStateWords + kRecWords)
-                        reinterpret_cast<unsigned long long*>(srv.h_rec + ch)[tid - kStateWords] =
-                            reinterpret_cast<const unsigned long long*>(srv.rec_out + ch)[tid - kStateWords];
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(srv.h_rec + ch) + (tid - kStateWords),
+                                           reinterpret_cast<const unsigned long long*>(srv.rec_out + ch)[tid - kStateWords], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
                     else if (tid == 63)
-                        srv.h_ran[ch] = sh->fault ? -2 : 1;                 // (-2: a part of the cluster never published its sums)
+                        __hip_atomic_store(&srv.h_ran[ch], sh->fault ? -2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (-2: a part of the cluster never published its sums)
                     if (tid == 0 && ch == 0) srv.dev->t[5] = wall_clock64();
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // (the wave's stores have reached the host's memory ...)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the wave's stores have been acknowledged ...)
                     if (tid == 0) {
                         __hip_atomic_store(&srv.h_done[ch], server_tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // ... before this one
                         const unsigned before = __hip_atomic_fetch_add(&srv.dev->done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (ch == 0) srv.dev->t[6] = wall_clock64() + (before & 0);      // (stamped after the add has returned: the next tick reports it)
+#ifdef SDR_SRV_TRACE
+                        srv.dev->ch_done[ch] += wall_clock64() - __hip_atomic_load(&srv.dev->seen_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        srv.dev->ch_n[ch] += 1;
+#endif
                     }
                 }
             }
@@ -2477,6 +2525,19 @@ int sdr_tick_server_tracker_phases(sdr_engine* e, double* out6) {
                 e->srv->seen_us[3] / e->srv->served_total);
 #endif
 #ifdef SDR_SRV_TRACE
+    if (e->srv && e->srv->dev.ptr) {
+        TickServerDev d;
+        if (hipMemcpy(&d, e->srv->dev.ptr, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "tick server: per channel, us after the request was seen: release seen / answered  [xcc:hw_id of the recording part]\n");
+            fprintf(stderr, "  doormen at");
+            for (int g = 0; g < 8; ++g) fprintf(stderr, " [%u:%04x]", d.door_where[g] >> 16, d.door_where[g] & 0xffff);
+            fprintf(stderr, "\n");
+            for (int c = 0; c < 64; ++c)
+                if (d.ch_n[c])
+                    fprintf(stderr, "  ch %2d: %6.2f %6.2f  [%u:%04x]\n", c, (double)d.ch_gate[c] / d.ch_n[c] * 0.01, (double)d.ch_done[c] / d.ch_n[c] * 0.01,
+                            d.ch_where[c] >> 16, d.ch_where[c] & 0xffff);
+        }
+    }
     if (e->srv) fprintf(stderr, "tick server: channel 0 release fence + count: %.2f us (mean of %llu)\n", e->srv->fence_add_us / (double)(e->srv->prev_t5 ? e->srv->prev_t5 : 1), e->srv->prev_t5);
 #endif
     return SDR_OK;

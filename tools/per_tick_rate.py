@@ -20,12 +20,17 @@ FS = bench.FS
 WARMUP_MS = 100     # ticks not counted: acquisition, the first launches of each kernel (code objects load on first use), the first block
 
 
-def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0, tick_server=False):
+def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0, tick_server=False, bind=True):
     """read_ahead > 0: the same loop with ChannelManager.enableReadAhead(read_ahead) and the stream served from a file
     through this package's RFSignal (what lets the manager look ahead); the calls per tick are the reference's.
     The first WARMUP_MS ticks are fed and run but not counted (their time is reported as warmup_ms_total).
     tick_server: the steady ticks answered by the resident kernel (sdr_set_option "tick_server")."""
     eng = engine or Engine(0)
+    if bind:        # (the thread onto the CPUs next to the GPU: a tick is a few round trips through page-locked words)
+        try:
+            eng.set_option("bind_thread_to_device", 1)
+        except Exception:
+            pass
     eng.set_option("tick_server", 1 if tick_server else 0)
     served0 = eng.tick_server_stats()["served"]
     # synthesise the stream on the device, then bring it to the host: the host is the IQ source in this mode
@@ -103,4 +108,4 @@ def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0, tick_se
 if __name__ == "__main__":
     n_ms = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 600
     ra = int(sys.argv[sys.argv.index("--read-ahead") + 1]) if "--read-ahead" in sys.argv else 0
-    print(json.dumps(measure(n_ms, profile="--profile" in sys.argv, read_ahead=ra, tick_server="--tick-server" in sys.argv)))
+    print(json.dumps(measure(n_ms, profile="--profile" in sys.argv, read_ahead=ra, tick_server="--tick-server" in sys.argv, bind="--no-bind" not in sys.argv)))
