@@ -181,8 +181,11 @@ class ChannelBank:
         """The whole tick in one library call (sdr_bank_tick_mirrored): readiness, one epoch for the ready channels,
         this mirror updated in place.  -> (ran, records, updates, max_unread): OWNED copies of the channels that
         completed an epoch, their records, and one sdr_tick_update row per tracking channel."""
-        self.tick_ready_begin(raw, ring_offset)
-        return self.tick_ready_end()
+        self.flush()
+        dev = self.device
+        if self._bound is None:
+            self._bound = dev.bind_mirror(self.state, self.last, self.code_since_tow, self.tracking, self.lost, self.host_flags)
+        return self.tick_ready_end(dev.tick_mirrored(raw, ring_offset, self.ring.idxWrite))
 
     def tick_ready_begin(self, raw, ring_offset):
         """First half of `tick_ready` (sdr_bank_tick_mirrored_begin): the ready channels' epoch is queued on this bank's
@@ -193,9 +196,10 @@ class ChannelBank:
             self._bound = dev.bind_mirror(self.state, self.last, self.code_since_tow, self.tracking, self.lost, self.host_flags)
         dev.tick_mirrored_begin(raw, ring_offset, self.ring.idxWrite)
 
-    def tick_ready_end(self):
+    def tick_ready_end(self, m=None):
         dev = self.device
-        m = dev.tick_mirrored_end()
+        if m is None:
+            m = dev.tick_mirrored_end()
         n = m.n_ran
         ran, rec = dev.ran[:n].copy(), dev.records[:n].copy()
         upd = dev.updates[:m.n_updates].copy()

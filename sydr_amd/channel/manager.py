@@ -379,9 +379,9 @@ class ChannelManager:
     # ------------------------------------------------------------------ the tick
     def run(self):
         """Flat sequence of result packets for this tick (channelManager.py:149-188)."""
-        return self._run_end(self._run_begin())
+        return self._run_end(self._run_begin(queue=False))
 
-    def _run_begin(self):
+    def _run_begin(self, queue=True):
         """First half of run(): when the tick is the steady one (every active channel tracking on the device), the ready
         channels' epoch is QUEUED on this manager's device and a token returned; anything else returns None and the whole
         tick happens in `_run_end`.  A manager of several devices begins every device's tick before it ends any
@@ -393,8 +393,9 @@ class ChannelManager:
         bank, ra = self.bank, self._readahead
         if bank is None or (ra is not None and (ra.bank is not bank or not ra.empty)):
             return None
-        bank.tick_ready_begin(None, 0)
-        return (TickPackets(), bank, lists[4], lists[5], lists[7])
+        if queue:       # (a manager of one device makes the whole tick ONE library call in _tick_steady_end instead)
+            bank.tick_ready_begin(None, 0)
+        return (TickPackets(), bank, lists[4], lists[5], lists[7], queue)
 
     def _run_end(self, token):
         if token is not None:
@@ -505,11 +506,10 @@ class ChannelManager:
         """The tick of a receiver whose active channels are all tracking on the device: ONE library call
         (sdr_bank_tick_mirrored, behind the slab addNewRFData queued) decides who is ready, runs their epoch, brings
         the bank's mirror up to date and leaves what the packets report; the packets themselves are made when read."""
-        bank.tick_ready_begin(None, 0)
-        return self._tick_steady_end(out, bank, cids_active, states_active, upd_templates)
+        return self._tick_steady_end(out, bank, cids_active, states_active, upd_templates, queued=False)
 
-    def _tick_steady_end(self, out, bank, cids_active, states_active, upd_templates):
-        ran, rec, upd, self._unread_max = bank.tick_ready_end()
+    def _tick_steady_end(self, out, bank, cids_active, states_active, upd_templates, queued=True):
+        ran, rec, upd, self._unread_max = bank.tick_ready_end() if queued else bank.tick_ready(None, 0)
         if len(ran):
             self._pending = False                            # (an epoch ran: the call ended with a synchronisation of the stream)
         # (no channel ready: nothing was launched and nothing waited for -- the slab stays "queued, not waited for", and

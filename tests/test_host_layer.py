@@ -190,11 +190,11 @@ def test_pending_slab_is_owned_and_survives_a_failed_tick():
     def failing(*a, **k):
         raise boom
     bank = mgr.bank
-    real = (mgr._acquire, bank.tick, bank.tick_ready_begin)
-    mgr._acquire = bank.tick = bank.tick_ready_begin = failing       # (whichever this tick needs)
+    real = (mgr._acquire, bank.tick, bank.tick_ready, bank.tick_ready_begin)
+    mgr._acquire = bank.tick = bank.tick_ready = bank.tick_ready_begin = failing       # (whichever this tick needs)
     with pytest.raises(RuntimeError):
         mgr.run()
-    mgr._acquire, bank.tick, bank.tick_ready_begin = real
+    mgr._acquire, bank.tick, bank.tick_ready, bank.tick_ready_begin = real
     assert np.array_equal(eng.iq_download(spms, spms), second)
     # a second slab without a run() in between waits for the first one's transfer (the staging buffer is re-used)
     synced = []
