@@ -2251,6 +2251,13 @@ int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int
             nt = b->n_taps[ch];
         }
         TickServerState* s = e->srv;
+        if (e->srv_running && !__atomic_load_n(&s->host->alive, __ATOMIC_ACQUIRE)) {
+            // the server has left by its own clock (0.2 s without a request: a host that paused) -- or given up: tidy up after
+            // it (its streams, the channels' states it wrote on the way out); this tick and the next few are plain ones
+            const unsigned why = __atomic_load_n(&s->host->fault, __ATOMIC_ACQUIRE);
+            if (int rc = sdr_tick_server_stop(e)) return rc;
+            if (why >= 2) s->disabled = true;
+        }
         const bool same = e->srv_running && s->bank == b && s->channels == cand && s->code_generation == e->code_generation &&
                           s->ring == e->iq && s->staging == e->slab_pinned;
         bool use = one_tap_count && !cand.empty() && (long)cand.size() * 4 <= (long)e->n_cus;
@@ -2368,6 +2375,14 @@ int sdr_bank_tick_mirrored_end(sdr_engine* e, sdr_bank* b, sdr_tick_mirror* m) {
         HT(3, ht0);                           // wait
         if (!answered) {
             const unsigned alive = __atomic_load_n(&h->alive, __ATOMIC_ACQUIRE), why = __atomic_load_n(&h->fault, __ATOMIC_ACQUIRE);
+            if (!alive && why <= 1) {
+                // the doorman left by its idle clock just as this request was posted: it never saw it (a doorman that sees a
+                // request answers it), no channel has moved.  The server is tidied up and the tick done over the plain way.
+                if (int rc = sdr_tick_server_stop(e)) return rc;
+                b->tick_served = false;
+                if (int rc = sdr_bank_tick_mirrored_begin(e, b, nullptr, 0, 0, b->tick_write_index, m)) return rc;
+                return sdr_bank_tick_mirrored_end(e, b, m);
+            }
             (void)sdr_tick_server_stop(e);
             s->disabled = true;
             return sdr_fail(SDR_ERR_HIP, "the resident tick server did not answer request %u (alive %u, fault %u): stopped; plain "

@@ -691,6 +691,29 @@ def test_one_manager_over_two_devices_equals_the_single_device_manager(engine, n
     assert all(st is ChannelState.TRACKING for _, st, *_ in attrs_2)
 
 
+def test_bind_thread_to_device_restricts_the_calling_thread_and_gives_the_mask_back(engine):
+    """sdr_set_option "bind_thread_to_device": the calling thread onto the CPUs sysfs lists for the GPU's PCI function -- a
+    non-empty subset of the mask it had -- and back (a served tick is round trips through page-locked words: from the other
+    socket of a two-socket host each takes the sockets' interconnect as well)."""
+    import os
+    from sydr_amd._lib import SdrError
+    before = os.sched_getaffinity(0)
+    try:
+        engine.set_option("bind_thread_to_device", 1)
+    except SdrError as exc:           # (no sysfs entry for the device, or a cpuset without its CPUs)
+        pytest.skip(f"no binding here: {exc}")
+    try:
+        during = os.sched_getaffinity(0)
+        assert during and during <= before
+        engine.set_option("bind_thread_to_device", 1)          # (again: the mask to go back to is still the first one)
+        assert os.sched_getaffinity(0) == during
+    finally:
+        engine.set_option("bind_thread_to_device", 0)
+    assert os.sched_getaffinity(0) == before
+    with pytest.raises(SdrError):
+        engine.set_option("no_such_option", 1)
+
+
 def test_resident_tick_server_equals_plain_ticks(engine):
     """sdr_set_option("tick_server", 1): the steady receiver tick is answered by a RESIDENT kernel (the cluster form of the
     tracking kernel + a doorman workgroup that polls a request word in page-locked memory, pulls the slab, releases the
@@ -698,7 +721,8 @@ def test_resident_tick_server_equals_plain_ticks(engine):
     acquisition on, against the same receiver on plain ticks: every packet of every tick equal BIT FOR BIT (same cluster,
     same order of additions), channel attributes too; the server is started when the channels have all reached tracking,
     survives ticks in which a channel is not ready, is stopped by any other call on the engine (here: an acquisition-sized
-    download) and started again by the next tick; an engine closed with a server resident returns at once."""
+    download) and started again by the next ticks, leaves by itself when the host pauses for 0.3 s (the ticks after the pause
+    are plain ones, then a server again); an engine closed with a server resident returns at once."""
     import configparser
     import os
     import time
@@ -732,6 +756,9 @@ def test_resident_tick_server_equals_plain_ticks(engine):
             for k in range(n_ms):
                 if k == 250:
                     eng.iq_download(64, 0)                   # any other call on the engine: the server leaves, the next tick starts one
+                if k == 320 and server:
+                    time.sleep(0.3)                          # a host that pauses: the server leaves by its own clock (0.2 s), the
+                                                             # next ticks are plain ones, the ninth starts a server again
                 mgr.addNewRFData(raw[2 * k * spms:2 * (k + 1) * spms])
                 ticks.append([dict(q) for q in mgr.run()])
             attrs = [(ch.carrierFrequency, ch.codeFrequency, ch.currentSample, ch.codeSinceTOW, int(ch.trackFlags), len(ch.navBits))
@@ -747,8 +774,8 @@ def test_resident_tick_server_equals_plain_ticks(engine):
     served, attrs_s, stats_s = receiver(engine, True)
     assert stats_p["served"] == before["served"] and not stats_p["running"]
     # the server answered the steady ticks (all but acquisition and the ticks around it), was resident at the end, was
-    # started twice (the download at tick 250 sent the first one away) and never gave up
-    assert stats_s["served"] - before["served"] > 330 and stats_s["running"] and stats_s["starts"] - before["starts"] == 2 and not stats_s["disabled"]
+    # started three times (the download at tick 250 sent the first one away, the pause at tick 320 the second) and never gave up
+    assert stats_s["served"] - before["served"] > 315 and stats_s["running"] and stats_s["starts"] - before["starts"] == 3 and not stats_s["disabled"]
     assert sum(p["type"] is ChannelMessage.TRACKING_UPDATE for t in served for p in t) > 12 * 330
     for k, (a, b) in enumerate(zip(plain, served)):
         assert a == b, k
