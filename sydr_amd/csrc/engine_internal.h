@@ -47,6 +47,7 @@ struct StreamCtx {
     DevBuf traj, bits, xchg;     // closed-loop launch scratch: epoch records, [list][n_bits][done] + bits, cluster exchange lines
     void* xchg_tagged = nullptr; // the exchange-line buffer the two-launch ticks' tags refer to (zeroed when it changes)
     unsigned tick_seq = 0;       // sequence number in those tags
+    unsigned done_seq = 0;       // what the channels of the last launch with results in page-locked memory raise their done words to
     void* pinned = nullptr;      // page-locked host staging for the small per-step results
     size_t pinned_bytes = 0;
 };

@@ -116,6 +116,11 @@ struct TickServer {
     sdr_track_epoch* h_rec;
     unsigned* h_done;
     unsigned long long idle_ticks, busy_ticks;   // of wall_clock64() (100 MHz)
+    // NOT the server's (host == nullptr): a plain launch whose results go straight into page-locked memory has every channel
+    // raise done_words[its position in the list] = done_seq behind them -- the host reads the results when the words are
+    // there instead of waiting for the stream's signal, which follows the kernel's last store by ~9 us (bank_collect)
+    unsigned* done_words;
+    unsigned done_seq;
 };
 
 // The doormen: kDoorGroups workgroups, a launch of their own beside the trackers' (the cluster of 32 channels x 8 parts fills
@@ -1324,6 +1329,9 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         if constexpr (kDense) lk = sh->lk;
         lock_regs_store(lk, sh);
     }
+    // (done words: what this wave wrote of the results -- records, bits -- has been acknowledged before the barrier lets the
+    // recording lane raise the channel's word)
+    if (srv.done_words) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0 && writer) {
         const int epochs_done = sh->epochs_done;
@@ -1337,6 +1345,10 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         if (states_copy) states_copy[ch] = st;   // (position in the launch's list: what the host reads back)
         if (epochs_done_out) epochs_done_out[ch] = epochs_done;
         if (n_bits) n_bits[ch] = sh->l_bits_run < max_bits ? sh->l_bits_run : max_bits;
+        if (srv.done_words) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");       // (everything above is in the host's memory ...)
+            __hip_atomic_store(&srv.done_words[ch], srv.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before this
+        }
     }
 }
 
@@ -1385,6 +1397,8 @@ struct TrackRun {
     int* fault_word = nullptr;            // where the launch's fault flag lives (already zero); nullptr: behind the exchange lines
     int force_parts = 0;                  // 0: choose
     const TickServer* server = nullptr;   // a tick-server launch: cluster form + the doorman, resident until told to leave
+    unsigned* done_words = nullptr;       // page-locked [n_ch] (zero): every channel raises its word to done_seq behind its results
+    unsigned done_seq = 0;
 };
 
 // Enqueue one closed-loop launch on ctx's stream.  *d_fault_out points at the launch's fault word.
@@ -1433,6 +1447,7 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
             if (hipError_t me = hipMemsetAsync(ctx->xchg.ptr, 0, xchg_bytes + 16, ctx->stream)) return me;
         TickServer srv_arg = {};
         if (r.server) srv_arg = *r.server;
+        else srv_arg.done_words = r.done_words, srv_arg.done_seq = r.done_seq;
         void* args[] = {&d_iq, &cap, &d_st, &d_st_copy, &d_map, &d_cfgs, &cfg_stride, &n_ep, &d_traj, &keep, &d_bits, &mb,
                         &d_nbits, &d_done, &d_luts, &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault, &phase, &tag_base, &srv_arg};
         if (dense) return sdr_track_dense_launch(e->iq_fmt, nt, r.n_ch, shmem, ctx->stream, args);
@@ -1776,6 +1791,8 @@ struct BankPending {
     sdr_track_epoch* p_rec = nullptr;
     int8_t* p_bits = nullptr;
     size_t rec_bytes = 0, st_bytes = 0, bits_bytes = 0;
+    volatile unsigned* done_words = nullptr;   // (results straight into page-locked memory) the channels' done words ...
+    unsigned done_seq = 0;                     // ... and what they show when a channel's results are there
 };
 
 static void sdr_bank_free_pending(sdr_bank* b) {
@@ -1791,7 +1808,41 @@ static void sdr_bank_free_pending(sdr_bank* b) {
 static int bank_collect(BankPending& P, sdr_track_epoch* records, sdr_track_state* states_out, int32_t* epochs_done, int8_t* nav_bits,
                         int32_t* n_bits) {
     P.active = false;
-    SDR_HIP(hipStreamSynchronize(P.ctx->stream));
+#ifdef SDR_TICK_TIMING
+    {   // (how long before the stream's signal are the channels' results in page-locked memory?)
+        static double early_sum; static long early_n;
+        const double t0 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        volatile int32_t* done = P.p_head + 4;
+        long spins = 0;
+        for (int c = 0; c < P.n_ch; ++c) while (!done[c] && ++spins < 2000000) {}
+        const double t1 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        (void)hipStreamSynchronize(P.ctx->stream);
+        const double t2 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        early_sum += t2 - t1;
+        if (++early_n % 128 == 0) {
+            fprintf(stderr, "[tick timing] results seen %.2f us after the wait began, the stream's signal %.2f us after that\n", t1 - t0, early_sum / 128);
+            early_sum = 0;
+        }
+    }
+#endif
+    // The results are in page-locked memory ~9 us before the stream says so (the kernel's end, its release, the signal, the
+    // runtime's wake-up: measured on the receiver tick, 18.6 against 27.8 us after the wait began): every channel raises a word
+    // behind its results, and those are what is waited for.  Bounded: a launch that died never raises them -- the stream is
+    // asked then, and says why.
+    bool seen = false;
+    if (P.done_words) {
+        const auto t0 = std::chrono::steady_clock::now();
+        int c = 0;
+        for (long spins = 0;; ++spins) {
+            while (c < P.n_ch && __atomic_load_n(&P.done_words[c], __ATOMIC_ACQUIRE) == P.done_seq) ++c;
+            if (c == P.n_ch) {
+                seen = true;
+                break;
+            }
+            if ((spins & 4095) == 4095 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.02) break;
+        }
+    }
+    if (!seen) SDR_HIP(hipStreamSynchronize(P.ctx->stream));
     TICK_CLOCK(3);
     if (P.p_head[0])
         return sdr_fail(SDR_ERR_HIP, "closed-loop tracking: a workgroup of a %d-part cluster never published its sums", P.parts);
@@ -1839,8 +1890,8 @@ static int bank_run(sdr_engine* e, sdr_bank* b, StreamCtx* ctx, const int32_t* c
     const size_t st_bytes = (size_t)n_ch * sizeof(sdr_track_state);
     const size_t bits_bytes = nav_bits ? (size_t)n_ch * max_bits : 0;
     const size_t head = ((size_t)3 * n_ch * sizeof(int32_t) + 15) & ~(size_t)15;  // [map][n_bits][epochs_done], then the bits
-    // page-locked block: [fault (4 words)][epochs_done n][n_bits n][channel list n] [states][records][bits]
-    const size_t pin_head = ((size_t)(4 + 3 * n_ch) * sizeof(int32_t) + 15) & ~(size_t)15;
+    // page-locked block: [fault (4 words)][epochs_done n][n_bits n][channel list n][done words n] [states][records][bits]
+    const size_t pin_head = ((size_t)(4 + 4 * n_ch) * sizeof(int32_t) + 15) & ~(size_t)15;
     const size_t pin_bytes = pin_head + st_bytes + rec_bytes + bits_bytes;
     int rc = sdr_pinned_reserve(e, ctx, pin_bytes);
     if (rc) return rc;
@@ -1880,6 +1931,8 @@ static int bank_run(sdr_engine* e, sdr_bank* b, StreamCtx* ctx, const int32_t* c
         r.d_traj = records ? p_rec : (sdr_track_epoch*)ctx->traj.ptr;
         r.d_states_copy = states_out ? p_states : nullptr;
         r.fault_word = p_head;
+        r.done_words = (unsigned*)(p_head + 4 + 3 * n_ch);      // (zeroed with the head above)
+        r.done_seq = ++ctx->done_seq ? ctx->done_seq : ++ctx->done_seq;
         if (nav_bits) memset(p_bits, 0, bits_bytes);
     } else {
         int32_t* d_map = (int32_t*)ctx->bits.ptr;
@@ -1919,6 +1972,7 @@ static int bank_run(sdr_engine* e, sdr_bank* b, StreamCtx* ctx, const int32_t* c
     P.active = true, P.ctx = ctx, P.n_ch = n_ch, P.n_epochs = n_epochs, P.parts = parts;
     P.p_head = p_head, P.p_states = p_states, P.p_rec = p_rec, P.p_bits = p_bits;
     P.rec_bytes = rec_bytes, P.st_bytes = st_bytes, P.bits_bytes = bits_bytes;
+    P.done_words = r.done_words, P.done_seq = r.done_seq;
     if (defer) return SDR_OK;
     return bank_collect(P, records, states_out, epochs_done, nav_bits, n_bits);
 }
