@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SDR_ABI_VERSION 5   /* 5: + sdr_bank_tick_mirrored_begin / _end, sdr_iq_upload_queue, sdr_host_alloc / _free, options "tick_server" + sdr_tick_server_stats, "bind_thread_to_device" (additive); 4: + sdr_build_id, sdr_epl_plan_create_dev, sdr_bank_tick_mirrored, sdr_iq_upload_begin, sdr_block_schedule, sdr_bank_step_begin / _end (additive) */
+#define SDR_ABI_VERSION 5   /* 5: + sdr_bank_tick_mirrored_begin / _end, sdr_iq_upload_queue, sdr_host_alloc / _free, option "tick_server" + sdr_tick_server_stats (additive); 4: + sdr_build_id, sdr_epl_plan_create_dev, sdr_bank_tick_mirrored, sdr_iq_upload_begin, sdr_block_schedule, sdr_bank_step_begin / _end (additive) */
 
 typedef struct sdr_engine sdr_engine;
 
