@@ -41,6 +41,11 @@ int sdr_set_device(sdr_engine* e) {
     e->srv_steady_ticks = 0;
     if (e->srv_running)
         if (int rc = sdr_tick_server_stop(e)) return rc;
+    // (a slab staged for the next tick's launch to pull in -- "ingest_with_tick" -- goes into the ring now: whatever this call
+    // is, it may read the ring or write to it)
+    e->last_tick_took_slab = false;
+    if (e->srv_slab_pending)
+        if (int rc = sdr_iq_flush_server_slab(e)) return rc;
     return SDR_OK;
 }
 
@@ -258,6 +263,8 @@ int sdr_set_option(sdr_engine* e, const char* name, int value) {
     else if (!strcmp(name, "pcps_no_spectra_cache")) e->pcps_no_spec_cache = value != 0;
     else if (!strcmp(name, "ingest_by_copy_command")) e->ingest_by_copy = value != 0;
     else if (!strcmp(name, "track_one_launch_tick")) e->track_one_launch_tick = value != 0;
+    else if (!strcmp(name, "track_two_launch_tick")) e->track_two_launch_tick = value != 0;
+    else if (!strcmp(name, "ingest_with_tick")) e->ingest_with_tick = value != 0;
     else if (!strcmp(name, "pcps_no_shared_spectra")) e->pcps_no_shared_spectra = value != 0;
     else if (!strcmp(name, "tick_server")) {
         if (e->srv_running) (void)sdr_tick_server_stop(e);
@@ -628,7 +635,7 @@ int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_
         const size_t off_b = (size_t)off * sb, cap_b = (size_t)cap * sb;
         if (off_b % 16 == 0 && bytes % 16 == 0 && cap_b % 16 == 0) {
             sdr_iq_mark_written(e, off, n_samples);
-            if (e->srv_running) {
+            if (e->srv_running || (e->ingest_with_tick && e->last_tick_took_slab)) {
                 // the resident tick server's doormen pull it out of the staging half (track.hip): no launch here.  The half is
                 // busy until the request that needs it has been answered (or the slab flushed the ordinary way).
                 e->srv_slab_pending = true;

@@ -47,6 +47,8 @@ struct StreamCtx {
     DevBuf traj, bits, xchg;     // closed-loop launch scratch: epoch records, [list][n_bits][done] + bits, cluster exchange lines
     void* xchg_tagged = nullptr; // the exchange-line buffer the two-launch ticks' tags refer to (zeroed when it changes)
     unsigned tick_seq = 0;       // sequence number in those tags
+    int xchg_tagged_ch = 0;      // ... and the channel count the ticket counters behind the lines were laid out for
+    unsigned ingest_launches = 0;// one-launch ticks that brought their slab along since the counters were zeroed
     unsigned done_seq = 0;       // what the channels of the last launch with results in page-locked memory raise their done words to
     void* pinned = nullptr;      // page-locked host staging for the small per-step results
     size_t pinned_bytes = 0;
@@ -127,6 +129,7 @@ struct sdr_engine {
     hipEvent_t pcps_ev[2] = {nullptr, nullptr};
     bool pcps_no_fast = false;       // diagnostics: keep the general four-step kernels where the N = 125 x 200 ones would run
     bool track_one_launch_tick = false;  // "track_one_launch_tick": a one-epoch step as one workgroup per channel in one launch
+    bool track_two_launch_tick = false;  // "track_two_launch_tick": the cluster's one-epoch step as two launches cut at the exchange (A/B)
     // "tick_server": the steady receiver tick served by a resident kernel (track.hip).  srv_running: one is resident NOW --
     // every call on the engine but the tick's own stops it first (sdr_set_device); a slab handed over by sdr_iq_upload_begin
     // while it runs waits in its staging half for the next request (srv_slab_*).
@@ -134,7 +137,11 @@ struct sdr_engine {
     bool srv_running = false;
     int srv_steady_ticks = 0;     // steady ticks in a row with no other call on the engine in between (a server starts at 8)
     struct TickServerState* srv = nullptr;
-    bool srv_slab_pending = false;
+    bool srv_slab_pending = false;       // ... or, without a server, for the tick's own launch (ingest_with_tick): whoever needs the ring
+                                         // first flushes it the ordinary way (sdr_set_device, the tick itself)
+    bool ingest_with_tick = true;        // "ingest_with_tick": a receiver tick's slab is pulled into the ring by workgroups of the tick's
+                                         // own launch instead of a launch of its own in front of it
+    bool last_tick_took_slab = false;    // the previous tick's launch was of that form: the next slab waits for the next tick's
     int srv_slab_half = 0;
     int64_t srv_slab_off = 0, srv_slab_n = 0;
     bool ingest_by_copy = false;     // "ingest_by_copy_command": queued slabs go into the ring by hipMemcpyAsync, not by the ingest kernel

@@ -121,7 +121,15 @@ struct TickServer {
     // there instead of waiting for the stream's signal, which follows the kernel's last store by ~9 us (bank_collect)
     unsigned* done_words;
     unsigned done_seq;
+    // Likewise a plain launch's (the one-launch receiver tick): its first kTickIngestGroups workgroups pull the tick's slab out
+    // of the staging block (`staging`, granules ingest_src16 .. + ingest_n16) into the ring (`ring16`, from ingest_first16) and
+    // count themselves in at *ingest_count; the trackers stage their tables and parameters meanwhile and read their first
+    // sample when the count has reached ingest_target.  ingest_n16 = 0: no slab with this launch.
+    unsigned long long ingest_src16, ingest_n16, ingest_first16;
+    unsigned* ingest_count;
+    unsigned ingest_target;
 };
+constexpr int kTickIngestGroups = 16;    // (a multiple of 8: the trackers' blockIdx % 8 -- their XCD -- is what it was without them)
 
 // The doormen: kDoorGroups workgroups, a launch of their own beside the trackers' (the cluster of 32 channels x 8 parts fills
 // the cooperative launch's 256 workgroups; a doorman needs a few registers and no LDS to speak of, and shares a compute unit
@@ -845,21 +853,49 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     const int tid = threadIdx.x;
     // (uniform) a tick-server launch of the cluster form: resident, every tick behind the doorman's release
     const bool server = kCluster && srv.host != nullptr;
-    const int n_wg = (int)gridDim.x;
+    int n_wg = (int)gridDim.x;
+    int bid = (int)blockIdx.x;
+    // (uniform) a one-launch receiver tick that brings its slab along: the launch's first workgroups are the ingest
+    const bool with_slab = kCluster && !server && srv.ingest_n16 != 0;
+    if constexpr (kCluster) {
+        if (with_slab) {
+            if (bid < kTickIngestGroups) {
+                for (unsigned long long i = (unsigned long long)bid * THREADS + tid; i < srv.ingest_n16; i += (unsigned long long)kTickIngestGroups * THREADS) {
+                    unsigned long long d = srv.ingest_first16 + i;
+                    if (d >= srv.ring_n16) d -= srv.ring_n16;
+                    srv.ring16[d] = srv.staging[srv.ingest_src16 + i];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every wave: its stores have left (the barrier orders them ...)
+                __syncthreads();                                          // ... before lane 0's device-wide release)
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __hip_atomic_fetch_add(srv.ingest_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
+            bid -= kTickIngestGroups;
+            n_wg -= kTickIngestGroups;
+        }
+    }
     // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8): the parts of one channel are
     // blockIdx-es with the same residue, so a cluster shares one XCD's L2 for its exchange lines.
     int ch, part;
     const bool collect_only = kCluster && phase == 2;      // (uniform) second half of a two-launch tick: no correlation here
     const bool publish_only = kCluster && phase == 1;      // (uniform) first half: ends after publishing its sums
+    // (uniform) the two halves in ONE plain launch: every part publishes its sums and draws a ticket; the part that draws its
+    // channel's last one carries on as phase 2 would (it polls the lines, its own among them, and adds them in part order:
+    // the same bits), the others end.  Nobody waits for a peer that may not be resident: a line that is still on its way is
+    // a store already issued by a workgroup that has run.
+    const bool last_collects = kCluster && phase == 3;
     if (collect_only) {
-        ch = blockIdx.x;
+        ch = bid;
         part = 0;
     } else if (parts == 1 || n_wg % (8 * parts) != 0) {
-        ch = blockIdx.x / parts;
-        part = blockIdx.x % parts;
+        ch = bid / parts;
+        part = bid % parts;
     } else {
         const int per_xcd = n_wg / 8;                    // workgroups per XCD = channels per XCD * parts
-        const int xcd = blockIdx.x % 8, q = blockIdx.x / 8;
+        const int xcd = bid % 8, q = bid / 8;
         ch = xcd * (per_xcd / parts) + q / parts;
         part = q % parts;
     }
@@ -918,8 +954,8 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     u.nav_bits = nav_bits;
     u.max_bits = max_bits;
     sdr_track_state& st = sh->st;
-    const bool writer = part == 0;                         // one part records trajectory, bits and the end state
-    u.writer = writer;
+    bool writer = part == 0;                               // one part records trajectory, bits and the end state (phase 3: the
+    u.writer = writer;                                     // part that drew the channel's last ticket; part 0 of a stopped channel)
 
 #ifdef SDR_TRACE_TRACK
     unsigned long long mark_ = wall_clock64();
@@ -1072,6 +1108,26 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                 }
             }
         }
+        if constexpr (kCluster) {
+            if (with_slab && epoch == 0) {
+                // the slab this launch brought along: in the ring when the ingest workgroups have all counted themselves in (they
+                // were dispatched in front of this one; bounded all the same), visible once this compute unit's caches are told
+                if (tid == 0) {
+                    const unsigned long long t0 = wall_clock64();
+                    while ((int)(__hip_atomic_load(srv.ingest_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - srv.ingest_target) < 0) {
+                        if (wall_clock64() - t0 > 200000ull) {      // 2 ms of the 100 MHz clock
+                            sh->fault = 1;
+                            *fault = 2;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                __syncthreads();
+                if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __syncthreads();
+            }
+        }
         if (sh->fault | sh->stop_code | sh->stop_carrier) break;
         const EpochParams ep = uniform_params(sh->ep);
         const double dphi = uniform(sh->dphi);
@@ -1190,6 +1246,19 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                 }
             }
             if (publish_only) return;   // (the whole workgroup: phase 2 takes it from here, in the next launch)
+            if (last_collects) {
+                // tickets: one counter per channel behind the lines and the fault word, never reset -- every launch of this form
+                // adds `parts` to it, so "the last of this launch" is the ticket that completes a multiple of `parts`
+                if (tid == 192) {
+                    unsigned* tickets = reinterpret_cast<unsigned*>(xchg + (size_t)n_ch * 2 * kMaxParts * kXchgWordsMax) + 4;
+                    sh->gate = __hip_atomic_fetch_add(tickets + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                if ((sh->gate + 1u) % (unsigned)parts != 0u) return;      // (the whole workgroup: a later part collects)
+                writer = true;
+                u.writer = true;
+                u.rec = keep_traj ? traj + ((size_t)ch * n_epochs + epoch) : nullptr;
+            }
             // Request the next epoch's samples now -- after this epoch's last use of `cur`, before the wait for the
             // peers, so that nothing waits on them: they arrive while this wave sleeps (the counter a wave waits on
             // retires loads in order, and these are ~0.4 us older than the first poll).
@@ -1218,7 +1287,9 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                 // down (tools/ubench_sload.hip: a store -> load round trip is 1029 cycles alone, 1664 with every
                 // workgroup polling).  Sleeping ~1000 cycles before the first poll: 5.2 -> 4.8 us per epoch at 32
                 // channels (measured 4 / 8 / 12 / 16 / 20 / 28 x 64 cycles: 5.13, 4.97, 4.94, 4.82, 4.87, 5.04).
-                if (!collect_only) __builtin_amdgcn_s_sleep(kXchgSleep);   // (phase 2: the words were there before this launch began)
+                // (phase 2: the words were there before this launch began; phase 3: every peer had stored its own before it drew
+                // the ticket in front of this workgroup's)
+                if (!collect_only && !last_collects) __builtin_amdgcn_s_sleep(kXchgSleep);
                 for (long spins = 0; spins < kSpinLimit; ++spins) {
                     bool ok = true;
 #pragma unroll
@@ -1325,6 +1396,7 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     // End state: the roles kept the LDS copy of the state current (the lock role hands its registers back now); one lane
     // of the recording part writes it out.
     if (publish_only) return;   // (only reached when the channel was stopped before its epoch: phase 2 reports that)
+    if (last_collects && !writer) return;   // (likewise: a stopped channel's parts draw no tickets, part 0 reports)
     if (role == 2 && rlane == 0) {
         if constexpr (kDense) lk = sh->lk;
         lock_regs_store(lk, sh);
@@ -1406,7 +1478,9 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
     const int lut_words = e->lut_stride;  // the whole staged row (every code period the slots were sized for)
     // exchange lines [n_ch][2 parities][8 parts][32 words] (tags zeroed: epoch tags start at 1), then the fault word
     const size_t xchg_bytes = (size_t)r.n_ch * 2 * kMaxParts * kXchgWordsMax * sizeof(unsigned long long);
-    if (int rc = sdr_devbuf_reserve_on(e, ctx->stream, &ctx->xchg, xchg_bytes + 16)) return rc;
+    // (one-launch ticks: a ticket counter per channel behind the fault word, then the ingest workgroups' counter)
+    const size_t ticket_bytes = ((size_t)r.n_ch + 4) * sizeof(unsigned);
+    if (int rc = sdr_devbuf_reserve_on(e, ctx->stream, &ctx->xchg, xchg_bytes + 16 + ticket_bytes)) return rc;
     unsigned long long* d_xchg = (unsigned long long*)ctx->xchg.ptr;
     int* d_fault = r.fault_word ? r.fault_word : (int*)((char*)ctx->xchg.ptr + xchg_bytes);
     *d_fault_out = d_fault;
@@ -1427,6 +1501,8 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
 
     int phase = 0;
     unsigned tag_base = 0;
+    bool take_slab = false;          // the one-launch tick below pulls the staged slab in itself
+    unsigned ingest_target = 0;
     // One attempt with `parts` workgroups per channel.
     auto attempt = [&](int parts, bool* too_big) -> hipError_t {
         // more channels than CUs: smaller workgroups, two or three of which share a CU, so that one channel's
@@ -1448,6 +1524,18 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
         TickServer srv_arg = {};
         if (r.server) srv_arg = *r.server;
         else srv_arg.done_words = r.done_words, srv_arg.done_seq = r.done_seq;
+        if (take_slab && phase == 3) {
+            const size_t sb = sdr_fmt_bytes(e->iq_fmt);
+            srv_arg.staging = (const uint4*)e->slab_pinned;
+            srv_arg.ring16 = (uint4*)e->iq;
+            srv_arg.ring_n16 = (unsigned long long)((size_t)e->iq_capacity * sb / 16);
+            srv_arg.ingest_src16 = (unsigned long long)((e->srv_slab_half ? e->slab_bytes : 0) / 16);
+            srv_arg.ingest_n16 = (unsigned long long)((size_t)e->srv_slab_n * sb / 16);
+            srv_arg.ingest_first16 = (unsigned long long)((size_t)e->srv_slab_off * sb / 16);
+            srv_arg.ingest_count = reinterpret_cast<unsigned*>((char*)ctx->xchg.ptr + xchg_bytes + 16) + r.n_ch;
+            srv_arg.ingest_target = ingest_target;
+        }
+        const int extra_groups = srv_arg.ingest_n16 ? kTickIngestGroups : 0;
         void* args[] = {&d_iq, &cap, &d_st, &d_st_copy, &d_map, &d_cfgs, &cfg_stride, &n_ep, &d_traj, &keep, &d_bits, &mb,
                         &d_nbits, &d_done, &d_luts, &lw, &ls, &up, &nch, &parts, &d_xchg, &d_fault, &phase, &tag_base, &srv_arg};
         if (dense) return sdr_track_dense_launch(e->iq_fmt, nt, r.n_ch, shmem, ctx->stream, args);
@@ -1456,7 +1544,7 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
             // more than 64 KB of dynamic LDS has to be granted per kernel
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
             if (phase)      // a two-launch tick: nobody waits for a peer inside either kernel
-                err = hipLaunchKernel((const void*)kernel, dim3(phase == 1 ? r.n_ch * parts : r.n_ch), dim3(threads), args, shmem, ctx->stream);
+                err = hipLaunchKernel((const void*)kernel, dim3(phase == 2 ? r.n_ch : r.n_ch * parts + extra_groups), dim3(threads), args, shmem, ctx->stream);
             else if (parts > 1)  // the parts of a cluster wait for each other: all workgroups must be resident
                 err = hipLaunchCooperativeKernel((const void*)kernel, dim3(r.n_ch * parts), dim3(threads), args,
                                                  (unsigned)shmem, ctx->stream);
@@ -1500,14 +1588,25 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
     // A one-epoch step (a receiver tick) on the cluster a block of epochs would get -- the same partition, the same order of
     // additions, the same bits -- as TWO plain launches cut at the exchange (see track_kernel): 17.4 us of one workgroup
     // per channel became ~11 on eight, without the +15-19 us a cooperative launch costs the host.
-    if (!forced && r.n_epochs == 1 && !e->track_one_launch_tick) {
-        int p2 = 1;
+    int p2 = 1;
+    if (!forced && r.n_epochs == 1 && !e->track_one_launch_tick && !r.server)
         while (p2 < kMaxParts && (long)r.n_ch * p2 * 2 <= (long)e->n_cus) p2 *= 2;
+    // A slab staged for "the next tick's launch" (sdr_iq_upload_async: ingest_with_tick): the one-launch tick below takes it
+    // along; any other launch wants it in the ring first, the ordinary way.
+    const bool tick_form = p2 > 1 && !e->track_two_launch_tick && e->ingest_with_tick && ctx->stream == e->stream;
+    if (!r.server) {
+        if (e->srv_slab_pending && !tick_form)
+            if (int rc = sdr_iq_flush_server_slab(e)) return rc;
+        e->last_tick_took_slab = tick_form;
+    }
+    if (!forced && r.n_epochs == 1 && !e->track_one_launch_tick && !r.server) {
         if (p2 > 1) {
             // the lines are not zeroed per tick: this launch's tag (bit 31 set: no epoch tag of a block launch has it) has
             // never been stored in them -- unless the buffer is new or the 31-bit sequence wrapped: zero it then
-            if (ctx->xchg_tagged != ctx->xchg.ptr || ctx->tick_seq >= 0x7ffffff0u) {
-                SDR_HIP(hipMemsetAsync(ctx->xchg.ptr, 0, xchg_bytes + 16, ctx->stream));
+            if (ctx->xchg_tagged != ctx->xchg.ptr || ctx->tick_seq >= 0x7ffffff0u || ctx->xchg_tagged_ch != r.n_ch) {
+                SDR_HIP(hipMemsetAsync(ctx->xchg.ptr, 0, xchg_bytes + 16 + ticket_bytes, ctx->stream));
+                ctx->xchg_tagged_ch = r.n_ch;      // (the tickets sit behind n_ch channels' lines: another count, another place)
+                ctx->ingest_launches = 0;
                 ctx->xchg_tagged = ctx->xchg.ptr;
                 ctx->tick_seq = 0;
             }
@@ -1516,10 +1615,27 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
             bool too_big = false;
             {
                 ProfScope ps(e, "track_kernel", ctx->stream);
-                phase = 1;
-                err = attempt(p2, &too_big);
-                phase = 2;
-                if (err == hipSuccess && !too_big) err = attempt(p2, &too_big);
+                if (e->track_two_launch_tick) {
+                    phase = 1;
+                    err = attempt(p2, &too_big);
+                    phase = 2;
+                    if (err == hipSuccess && !too_big) err = attempt(p2, &too_big);
+                } else {
+                    phase = 3;      // (both halves in one plain launch: the part that draws a channel's last ticket collects)
+                    take_slab = tick_form && e->srv_slab_pending;
+                    if (take_slab) ingest_target = (unsigned)kTickIngestGroups * (ctx->ingest_launches + 1);
+                    err = attempt(p2, &too_big);
+                    if (take_slab && err == hipSuccess && !too_big) {
+                        // (the launch reads the staging half: busy until it has run)
+                        ctx->ingest_launches += 1;
+                        e->srv_slab_pending = false;
+                        const int half = e->srv_slab_half;
+                        if (!e->slab_done[half]) (void)hipEventCreateWithFlags(&e->slab_done[half], hipEventDisableTiming);
+                        (void)hipEventRecord(e->slab_done[half], ctx->stream);
+                        e->slab_busy[half] = true;
+                    }
+                    take_slab = false;
+                }
                 phase = 0;
             }
             if (too_big) return sdr_fail(SDR_ERR_RANGE, "closed-loop tracking: code table does not fit the LDS");
@@ -1842,8 +1958,14 @@ static int bank_collect(BankPending& P, sdr_track_epoch* records, sdr_track_stat
             if ((spins & 4095) == 4095 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.02) break;
         }
     }
-    if (!seen) SDR_HIP(hipStreamSynchronize(P.ctx->stream));
+    if (!seen) {
+        if (P.done_words) P.ctx->xchg_tagged = nullptr;      // (whatever kept the words from coming: the next tick zeroes lines and ticket counters)
+        SDR_HIP(hipStreamSynchronize(P.ctx->stream));
+    }
     TICK_CLOCK(3);
+    if (P.p_head[0]) P.ctx->xchg_tagged = nullptr;     // (a part that never showed up has drawn no ticket: start the counters over)
+    if (P.p_head[0] == 2)
+        return sdr_fail(SDR_ERR_HIP, "closed-loop tracking: the slab the tick's launch was to pull into the ring never arrived");
     if (P.p_head[0])
         return sdr_fail(SDR_ERR_HIP, "closed-loop tracking: a workgroup of a %d-part cluster never published its sums", P.parts);
     if (epochs_done) memcpy(epochs_done, P.p_head + 4, (size_t)P.n_ch * sizeof(int32_t));
@@ -2367,7 +2489,7 @@ int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int
     } else {
         e->srv_steady_ticks = 0;
     }
-    if (e->srv_slab_pending)            // (no server after all: the slab it would have pulled goes the ordinary way)
+    if (list.empty() && e->srv_slab_pending)        // (nobody to take it along: the slab goes into the ring the ordinary way)
         if (int rc = sdr_iq_flush_server_slab(e)) return rc;
     if (!list.empty()) {
         int n = (int)list.size();
