@@ -691,6 +691,67 @@ def test_one_manager_over_two_devices_equals_the_single_device_manager(engine, n
     assert all(st is ChannelState.TRACKING for _, st, *_ in attrs_2)
 
 
+def test_one_launch_tick_equals_the_two_launch_tick_and_the_separate_ingest(engine):
+    """The plain receiver tick is ONE launch: the cluster's two halves in one plain launch (the part that draws its channel's
+    last ticket collects the sums -- in part order, whoever it is) and the tick's slab pulled into the ring by workgroups of the
+    same launch.  Against the tick as two launches behind an ingest launch of its own ("track_two_launch_tick",
+    "ingest_with_tick" = 0): every packet of every tick equal BIT FOR BIT, from acquisition on, with ticks in which a channel
+    is not ready (10 MHz epochs are 10 000 +- a sample long against slabs of exactly 10 000), a call in between that needs the
+    ring (the staged slab goes in the ordinary way then) and two slabs before one tick."""
+    import configparser
+    import os
+    from conftest import REPO
+    from sydr_amd.channel.l1ca_kaplan import ChannelL1CA_Kaplan
+    from sydr_amd.channel.manager import ChannelManager
+    from sydr_amd.signal.iqsource import RFSignal
+    from sydr_amd.utils.enumerations import ChannelMessage
+    fs, n_ms = 10e6, 260
+    spms = int(fs * 1e-3)
+    rng = np.random.default_rng(8181)
+    sats = [dict(prn=1 + c, doppler=float(250.0 * rng.integers(-15, 16) + rng.uniform(-40, 40)),
+                 code_phase=float(rng.uniform(0, 1023)), phase=float(rng.uniform(0, 1)), amp=5.0) for c in range(12)]
+    total = n_ms * spms
+    engine.iq_alloc(total, FMT_CI8)
+    engine.code_slots(32)
+    engine.iq_synth(sats, fs, 10.0, 8182, 0, total)
+    raw = engine.iq_download(total, 0)
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(REPO, "examples", "channel_GPS_L1CA_kaplan.ini"))
+
+    def receiver(two_launch, with_tick):
+        engine.set_option("track_two_launch_tick", 1 if two_launch else 0)
+        engine.set_option("ingest_with_tick", 1 if with_tick else 0)
+        rf = RFSignal(dict(filepath="none", sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0, data_size=8))
+        mgr = ChannelManager(rf, engine=engine, keepCorrelationMap=False)
+        mgr.addChannel(ChannelL1CA_Kaplan, cfg, 12)
+        for s in sats:
+            mgr.requestTracking(s["prn"])
+        ticks, k = [], 0
+        try:
+            while k < n_ms:
+                if k == 150:
+                    engine.iq_download(64, 0)                # a call that reads the ring: a staged slab goes in first
+                mgr.addNewRFData(raw[2 * k * spms:2 * (k + 1) * spms])
+                k += 1
+                if k == 200:                                 # two slabs before one tick
+                    mgr.addNewRFData(raw[2 * k * spms:2 * (k + 1) * spms])
+                    k += 1
+                ticks.append([dict(q) for q in mgr.run()])
+        finally:
+            mgr.close()
+            engine.set_option("track_two_launch_tick", 0)
+            engine.set_option("ingest_with_tick", 1)
+        return ticks
+
+    reference = receiver(True, False)
+    assert sum(p["type"] is ChannelMessage.TRACKING_UPDATE for t in reference for p in t) > 12 * 200
+    for form in ((False, False), (False, True), (True, True)):
+        got = receiver(*form)
+        assert len(got) == len(reference)
+        for k, (a, b) in enumerate(zip(reference, got)):
+            assert a == b, (form, k)
+
+
 def test_bind_thread_to_device_restricts_the_calling_thread_and_gives_the_mask_back(engine):
     """sdr_set_option "bind_thread_to_device": the calling thread onto the CPUs sysfs lists for the GPU's PCI function -- a
     non-empty subset of the mask it had -- and back (a served tick is round trips through page-locked words: from the other
