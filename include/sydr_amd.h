@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SDR_ABI_VERSION 5   /* 5: + sdr_bank_tick_mirrored_begin / _end, sdr_iq_upload_queue, sdr_host_alloc / _free, option "tick_server" + sdr_tick_server_stats (additive); 4: + sdr_build_id, sdr_epl_plan_create_dev, sdr_bank_tick_mirrored, sdr_iq_upload_begin, sdr_block_schedule, sdr_bank_step_begin / _end (additive) */
+#define SDR_ABI_VERSION 5   /* 5: + sdr_bank_tick_mirrored_begin / _end, sdr_iq_upload_queue, sdr_host_alloc / _free, options "tick_server" + sdr_tick_server_stats, "bind_thread_to_device" (additive); 4: + sdr_build_id, sdr_epl_plan_create_dev, sdr_bank_tick_mirrored, sdr_iq_upload_begin, sdr_block_schedule, sdr_bank_step_begin / _end (additive) */
 
 typedef struct sdr_engine sdr_engine;
 
@@ -91,8 +91,12 @@ int sdr_prof_reset(sdr_engine* e);
  * recomputes conj(fft(code)) in every search, as the reference does (channel_l1ca_kaplan.py:184-185), instead of keeping
  * the spectra of the staged codes; "ingest_by_copy_command" = 1 moves the slabs of sdr_iq_upload_begin / sdr_bank_tick
  * into the ring with a copy command instead of the ingest kernel; "track_one_launch_tick" = 1 runs a one-epoch step
- * (sdr_bank_tick*, sdr_bank_step with n_epochs = 1) as one workgroup per channel in one launch instead of two launches
- * on the cluster a block of epochs would use (same time; other order of additions); "epl_no_chip_variant",
+ * (sdr_bank_tick*, sdr_bank_step with n_epochs = 1) as one workgroup per channel instead of on the cluster a block of
+ * epochs would use (other order of additions); "track_two_launch_tick" = 1 runs that cluster's one-epoch step as two
+ * launches cut at the exchange of the parts' sums instead of one (the part that draws its channel's last ticket
+ * collects: same bits); "ingest_with_tick" = 0 gives the slab of sdr_iq_upload_begin a launch of its own again instead of
+ * workgroups of the tick's launch; "pcps_no_shared_spectra" = 1 transforms the Doppler-mixed millisecond once per bin
+ * even where bins a whole number of FFT bins apart could share a spectrum; "epl_no_chip_variant",
  * "epl_no_split_variant", "epl_no_half_chip_view" = 1 keep the E/P/L correlator from its chip-aligned core, from the
  * kernel with the tap switch positions compiled in, from the half-chip view of 32-52 samples per chip.  Integer
  * results do not depend on any of them, floating ones to rounding. */
@@ -449,7 +453,9 @@ int sdr_tick_server_tracker_phases(sdr_engine* e, double* out6);
  * the transfer that read it (an event per half) -- a caller that queues a third slab while the first has not reached the
  * ring blocks in this call until it has; nothing is lost or reordered.  A tick in which no channel was ready
  * (sdr_bank_tick_mirrored with n_ran == 0 and n_samples == 0) launches nothing and waits for nothing: the slab is then
- * still in flight when the call returns. */
+ * still in flight when the call returns.  Between receiver ticks the slab only waits in its staging half: the next
+ * sdr_bank_tick_mirrored's ONE launch begins with workgroups that pull it into the ring while the trackers behind them set
+ * up (or the resident tick server's doormen pull it); every other call on the engine puts it into the ring first, in order. */
 int sdr_iq_upload_begin(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset);
 /* A chunk of a recording (any size) queued for the ring WITHOUT being copied first: one asynchronous copy command on the
  * engine's stream, ordered like everything else queued there; the caller keeps `iq` valid and unchanged until

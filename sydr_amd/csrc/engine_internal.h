@@ -47,7 +47,6 @@ struct StreamCtx {
     DevBuf traj, bits, xchg;     // closed-loop launch scratch: epoch records, [list][n_bits][done] + bits, cluster exchange lines
     void* xchg_tagged = nullptr; // the exchange-line buffer the two-launch ticks' tags refer to (zeroed when it changes)
     unsigned tick_seq = 0;       // sequence number in those tags
-    int xchg_tagged_ch = 0;      // ... and the channel count the ticket counters behind the lines were laid out for
     unsigned ingest_launches = 0;// one-launch ticks that brought their slab along since the counters were zeroed
     unsigned done_seq = 0;       // what the channels of the last launch with results in page-locked memory raise their done words to
     void* pinned = nullptr;      // page-locked host staging for the small per-step results

@@ -129,6 +129,9 @@ struct TickServer {
     unsigned* ingest_count;
     unsigned ingest_target;
 };
+// In front of the exchange lines (one-launch ticks): 64 ticket counters (a cluster of two parts or more means 64 channels at
+// most), then the ingest workgroups' counter.
+constexpr int kXchgHeadBytes = 512;
 constexpr int kTickIngestGroups = 16;    // (a multiple of 8: the trackers' blockIdx % 8 -- their XCD -- is what it was without them)
 
 // The doormen: kDoorGroups workgroups, a launch of their own beside the trackers' (the cluster of 32 channels x 8 parts fills
@@ -1247,10 +1250,11 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             }
             if (publish_only) return;   // (the whole workgroup: phase 2 takes it from here, in the next launch)
             if (last_collects) {
-                // tickets: one counter per channel behind the lines and the fault word, never reset -- every launch of this form
-                // adds `parts` to it, so "the last of this launch" is the ticket that completes a multiple of `parts`
+                // tickets: one counter per position in the launch's list, in front of the lines, never reset -- every launch of this
+                // form adds `parts` to the counters it uses, so "the last of this launch" is the ticket that completes a multiple
+                // of `parts`, whichever channel had the position the tick before
                 if (tid == 192) {
-                    unsigned* tickets = reinterpret_cast<unsigned*>(xchg + (size_t)n_ch * 2 * kMaxParts * kXchgWordsMax) + 4;
+                    unsigned* tickets = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(xchg) - kXchgHeadBytes);
                     sh->gate = __hip_atomic_fetch_add(tickets + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 __syncthreads();
@@ -1477,12 +1481,11 @@ struct TrackRun {
 int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_used, int** d_fault_out) {
     const int lut_words = e->lut_stride;  // the whole staged row (every code period the slots were sized for)
     // exchange lines [n_ch][2 parities][8 parts][32 words] (tags zeroed: epoch tags start at 1), then the fault word
+    // [head: ticket counters, ingest counter (one-launch ticks)][lines][fault word]
     const size_t xchg_bytes = (size_t)r.n_ch * 2 * kMaxParts * kXchgWordsMax * sizeof(unsigned long long);
-    // (one-launch ticks: a ticket counter per channel behind the fault word, then the ingest workgroups' counter)
-    const size_t ticket_bytes = ((size_t)r.n_ch + 4) * sizeof(unsigned);
-    if (int rc = sdr_devbuf_reserve_on(e, ctx->stream, &ctx->xchg, xchg_bytes + 16 + ticket_bytes)) return rc;
-    unsigned long long* d_xchg = (unsigned long long*)ctx->xchg.ptr;
-    int* d_fault = r.fault_word ? r.fault_word : (int*)((char*)ctx->xchg.ptr + xchg_bytes);
+    if (int rc = sdr_devbuf_reserve_on(e, ctx->stream, &ctx->xchg, kXchgHeadBytes + xchg_bytes + 16)) return rc;
+    unsigned long long* d_xchg = (unsigned long long*)((char*)ctx->xchg.ptr + kXchgHeadBytes);
+    int* d_fault = r.fault_word ? r.fault_word : (int*)((char*)d_xchg + xchg_bytes);
     *d_fault_out = d_fault;
     const void* d_iq = e->iq;
     int64_t cap = e->iq_capacity;
@@ -1520,7 +1523,7 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
         *too_big = shmem > 160u * 1024u;
         if (*too_big) return hipSuccess;
         if (parts > 1 && !phase)  // tags of a previous launch must not validate this one's polls
-            if (hipError_t me = hipMemsetAsync(ctx->xchg.ptr, 0, xchg_bytes + 16, ctx->stream)) return me;
+            if (hipError_t me = hipMemsetAsync(d_xchg, 0, xchg_bytes + 16, ctx->stream)) return me;
         TickServer srv_arg = {};
         if (r.server) srv_arg = *r.server;
         else srv_arg.done_words = r.done_words, srv_arg.done_seq = r.done_seq;
@@ -1532,7 +1535,7 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
             srv_arg.ingest_src16 = (unsigned long long)((e->srv_slab_half ? e->slab_bytes : 0) / 16);
             srv_arg.ingest_n16 = (unsigned long long)((size_t)e->srv_slab_n * sb / 16);
             srv_arg.ingest_first16 = (unsigned long long)((size_t)e->srv_slab_off * sb / 16);
-            srv_arg.ingest_count = reinterpret_cast<unsigned*>((char*)ctx->xchg.ptr + xchg_bytes + 16) + r.n_ch;
+            srv_arg.ingest_count = reinterpret_cast<unsigned*>(ctx->xchg.ptr) + 64;
             srv_arg.ingest_target = ingest_target;
         }
         const int extra_groups = srv_arg.ingest_n16 ? kTickIngestGroups : 0;
@@ -1603,9 +1606,8 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
         if (p2 > 1) {
             // the lines are not zeroed per tick: this launch's tag (bit 31 set: no epoch tag of a block launch has it) has
             // never been stored in them -- unless the buffer is new or the 31-bit sequence wrapped: zero it then
-            if (ctx->xchg_tagged != ctx->xchg.ptr || ctx->tick_seq >= 0x7ffffff0u || ctx->xchg_tagged_ch != r.n_ch) {
-                SDR_HIP(hipMemsetAsync(ctx->xchg.ptr, 0, xchg_bytes + 16 + ticket_bytes, ctx->stream));
-                ctx->xchg_tagged_ch = r.n_ch;      // (the tickets sit behind n_ch channels' lines: another count, another place)
+            if (ctx->xchg_tagged != ctx->xchg.ptr || ctx->tick_seq >= 0x7ffffff0u) {
+                SDR_HIP(hipMemsetAsync(ctx->xchg.ptr, 0, kXchgHeadBytes + xchg_bytes + 16, ctx->stream));
                 ctx->ingest_launches = 0;
                 ctx->xchg_tagged = ctx->xchg.ptr;
                 ctx->tick_seq = 0;
