@@ -107,6 +107,10 @@ struct sdr_engine {
     int n_cus = 0;              // compute units of the device (sizes the closed-loop clusters)
     int track_force_parts = 0;  // diagnostics / tests: 0 = choose, else 1, 2, 4 or 8 workgroups per channel
     void* pcps_res_direct = nullptr;  // during sdr_pcps: page-locked block the peak kernels write their results into
+    const void* pcps_slots_pinned = nullptr;   // ... the caller's slot numbers in it (copied to the device when spectra have to be made)
+    unsigned* pcps_done = nullptr;    // ... one word per PRN the fused second sweep raises to pcps_done_seq behind the PRN's results
+    unsigned pcps_done_seq = 0, pcps_done_counter = 0;
+    bool pcps_done_used = false;      // the search ended in a kernel that raises them
     void* slab_pinned = nullptr;  // page-locked staging of the slab a receiver tick brings (sdr_bank_tick)
     size_t slab_bytes = 0;        // bytes of ONE of its two halves
     int slab_flip = 0;

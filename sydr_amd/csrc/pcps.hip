@@ -14,6 +14,7 @@
 // accumulation into the last inverse pass.  fp64 throughout: the peak INDEX must
 // match NumPy's bit for bit, and a 1e-7 relative error could reorder near-ties.
 #include "engine_internal.h"
+#include <chrono>
 #include "sincos_reduced.h"
 #include "pcps_codelets.h"
 
@@ -1196,6 +1197,9 @@ int pcps_run(sdr_engine* e, const int32_t* d_slots, const int32_t* h_slots, int 
     if (!have_spectra && !spectra_cached) {
         e->pcps_spec_key.clear();   // (valid again only once the new spectra are queued without error, below)
         int8_t* up = (int8_t*)B;  // scratch: n_prn*N bytes fits easily in a work buffer
+        // (the slot numbers reach the device only now: a search whose spectra are still there needs no copy command in
+        // front of its first kernel -- 2.7 us of copy and two boundaries on the stream)
+        SDR_HIP(hipMemcpyAsync(const_cast<int32_t*>(d_slots), e->pcps_slots_pinned, (size_t)n_prn * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
         {
             ProfScope ps(e, "pcps_upsample");
             hipLaunchKernelGGL(upsample_batch_kernel, dim3((N + kThreads - 1) / kThreads, n_prn), dim3(kThreads), 0,
@@ -1583,15 +1587,22 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     int32_t* d_slots = (int32_t*)((char*)e->pcps_res.ptr + (size_t)n_prn * 3 * sizeof(double));
     // small transfers go through page-locked staging: one copy each way, no hidden synchronisation
     const size_t res_bytes = (size_t)n_prn * 3 * sizeof(double);
-    if ((rc = sdr_pinned_reserve(e, &e->ctx0, res_bytes + (size_t)n_prn * sizeof(int32_t)))) return rc;
+    // page-locked: [results: bin, code, ratio per PRN][slot numbers][done words]
+    if ((rc = sdr_pinned_reserve(e, &e->ctx0, res_bytes + 2 * (size_t)n_prn * sizeof(int32_t)))) return rc;
     char* pin = (char*)e->ctx0.pinned;
     if (code_spectra) {
         SDR_HIP(hipMemcpyAsync(e->pcps_code.ptr, code_spectra, tbytes * n_prn, hipMemcpyHostToDevice, e->stream));
     } else {
         memcpy(pin + res_bytes, code_slots, (size_t)n_prn * sizeof(int32_t));
-        SDR_HIP(hipMemcpyAsync(d_slots, pin + res_bytes, n_prn * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        e->pcps_slots_pinned = pin + res_bytes;      // (copied to the device by pcps_run when it has to make spectra)
     }
     e->pcps_res_direct = pin;
+    // the searches that end in the fused second sweep raise a word per PRN behind its results (sdr_pcps_fused_second): those
+    // are waited for instead of the stream's signal, which follows the last store by ~9 us (the receiver tick's finding)
+    e->pcps_done = (unsigned*)(pin + res_bytes + (size_t)n_prn * sizeof(int32_t));
+    memset(e->pcps_done, 0, (size_t)n_prn * sizeof(unsigned));
+    e->pcps_done_seq = ++e->pcps_done_counter ? e->pcps_done_counter : ++e->pcps_done_counter;
+    e->pcps_done_used = false;
     const bool hs = code_spectra != nullptr;
 
     // np.arange(-R, R+1, S): element k = start + k*delta with delta = (start+step) - start
@@ -1609,6 +1620,8 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     }
     }
     e->pcps_res_direct = nullptr;
+    unsigned* const done_words = e->pcps_done_used ? e->pcps_done : nullptr;
+    e->pcps_done = nullptr;
     if (rc) {
         // a search that stopped half way: what the code-spectra buffer holds is unknown, and a sweep may still be
         // running on the second stream -- join it before anybody re-uses the work buffers
@@ -1620,7 +1633,20 @@ static int pcps_impl(sdr_engine* e, const int32_t* code_slots, const double* cod
     if (corr_map)
         SDR_HIP(hipMemcpyAsync(corr_map, e->pcps_map.ptr, (size_t)n_prn * nbins * N * sizeof(double),
                                hipMemcpyDeviceToHost, e->stream));
-    SDR_HIP(hipStreamSynchronize(e->stream));
+    bool seen = false;
+    if (done_words && !corr_map) {       // (bounded: a launch that died never raises the words -- the stream is asked then)
+        const auto t0 = std::chrono::steady_clock::now();
+        int c = 0;
+        for (long spins = 0;; ++spins) {
+            while (c < n_prn && __atomic_load_n(&done_words[c], __ATOMIC_ACQUIRE) == e->pcps_done_seq) ++c;
+            if (c == n_prn) {
+                seen = true;
+                break;
+            }
+            if ((spins & 4095) == 4095 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) break;
+        }
+    }
+    if (!seen) SDR_HIP(hipStreamSynchronize(e->stream));
     const long long* hb = (const long long*)pin;
     for (int i = 0; i < n_prn; ++i) {
         peak_bin[i] = hb[i];

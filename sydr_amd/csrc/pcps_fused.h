@@ -633,6 +633,8 @@ struct SecondArgs {
     long long* res_bin;        // [n_prn] the caller's results (page-locked memory or the device copies themselves)
     long long* res_code;
     double* res_ratio;
+    unsigned* done;            // (nullable) [n_prn] page-locked: raised to done_seq behind a PRN's results
+    unsigned done_seq;
 };
 
 template <int TERMS>
@@ -736,6 +738,10 @@ __global__ __launch_bounds__(kThreads) void ifft_second_kernel(const SecondArgs 
             s.res_code[prn] = code;
         }
         __hip_atomic_store(&s.tickets[prn], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s.done) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // (the PRN's results are in the host's memory ...)
+            __hip_atomic_store(&s.done[prn], s.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // ... before this word
+        }
     }
 }
 

@@ -116,6 +116,11 @@ int sdr_pcps_fused_second(sdr_engine* e, const void* F, const void* spec_off, co
     s.res_bin = (long long*)res_bin;
     s.res_code = (long long*)res_code;
     s.res_ratio = (double*)res_ratio;
+    if (e->pcps_done && res_bin == e->pcps_res_direct) {      // (the results go straight to the caller's page-locked block)
+        s.done = e->pcps_done;
+        s.done_seq = e->pcps_done_seq;
+        e->pcps_done_used = true;
+    }
     auto* kernel = terms == 2 ? fused25k::ifft_second_kernel<2> : fused25k::ifft_second_kernel<1>;
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused25k::kLdsBytes);
     ProfScope ps(e, "pcps_inv_fft");
