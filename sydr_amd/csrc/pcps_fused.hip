@@ -149,8 +149,13 @@ int sdr_pcps_fused10k_search(sdr_engine* e, const void* F_all, const void* spec_
     }
     {
         ProfScope ps(e, "pcps_peak");
+        unsigned* done = nullptr;
+        if (e->pcps_done && out_bin == e->pcps_res_direct) {     // (the results go straight to the caller's page-locked block)
+            done = e->pcps_done;
+            e->pcps_done_used = true;
+        }
         hipLaunchKernelGGL(fused10k::peaks_kernel, dim3(n_prn), dim3(64), 0, e->stream, a.records, nbins, (long long*)out_bin,
-                           (long long*)out_code, (double*)out_ratio);
+                           (long long*)out_code, (double*)out_ratio, done, e->pcps_done_seq);
     }
     SDR_HIP(hipGetLastError());
     return SDR_OK;

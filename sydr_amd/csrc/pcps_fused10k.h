@@ -314,8 +314,10 @@ __global__ __launch_bounds__(kThreads) void search_kernel(const Args a) {
 
 // Per PRN: the unit with the largest first maximum (smallest flat index on ties: np.argmax over the row-major map) is the
 // winning row; its own second peak gives the ratio.  The call's last kernel: results may go to page-locked host memory.
+// done (nullable): a page-locked word per PRN, raised to done_seq behind the PRN's results (what sdr_pcps waits for).
 __global__ __launch_bounds__(64) void peaks_kernel(const UnitRecord* __restrict__ records, int nbins, long long* __restrict__ out_bin,
-                                                   long long* __restrict__ out_code, double* __restrict__ out_ratio) {
+                                                   long long* __restrict__ out_code, double* __restrict__ out_ratio,
+                                                   unsigned* __restrict__ done, unsigned done_seq) {
     const int prn = blockIdx.x;
     double v = -1.0, second = -1.0;
     long long i = 0x7fffffffffffffffLL;
@@ -334,6 +336,10 @@ __global__ __launch_bounds__(64) void peaks_kernel(const UnitRecord* __restrict_
         out_bin[prn] = i / N;
         out_code[prn] = i - (i / N) * N;
         out_ratio[prn] = second >= 0.0 ? v / second : nan("");
+        if (done) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __hip_atomic_store(&done[prn], done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
