@@ -6,8 +6,9 @@
  * 32 channels @ 25 MHz: acquisition of the first millisecond, then `ticks` milliseconds tracked tick by tick with the host as
  * IQ source; prints where the channels ended and the time per tick.  A second argument `server` switches the resident
  * tick server on (sdr_set_option "tick_server"): the same two calls per tick, answered by a kernel that is already there.
- * The thread is kept on the CPUs next to the GPU (sdr_set_option "bind_thread_to_device"; a third argument `nobind` leaves it
- * where the scheduler puts it: ~6 us per tick more from the other socket of a two-socket host).
+ * The thread is kept on the CPUs next to the GPU (sdr_set_option "bind_thread_to_device"; `nobind` leaves it where the
+ * scheduler puts it: ~6 us per tick more from the other socket of a two-socket host).  `pinned`: the recording in page-locked
+ * memory (sdr_host_alloc): its slabs are read in place, ~2 us per tick less.
  * Build:  gcc -std=c99 -O2 -Iinclude examples/receiver_loop.c -Lsydr_amd -lsydr_amd -lm -Wl,-rpath,'$ORIGIN/../sydr_amd' -o examples/receiver_loop
  */
 #define _POSIX_C_SOURCE 199309L
@@ -39,14 +40,18 @@ enum { N_CH = 32 };
 int main(int argc, char** argv) {
     const double fs = 25e6, code_rate = 1.023e6;
     const int ticks = argc > 1 ? atoi(argv[1]) : 400;
-    const int server = argc > 2 && !strcmp(argv[2], "server");
+    int server = 0, nobind = 0, pinned = 0;              /* any of `server`, `nobind`, `pinned` after the tick count */
+    for (int k = 2; k < argc; ++k) {
+        server |= !strcmp(argv[k], "server");
+        nobind |= !strcmp(argv[k], "nobind");
+        pinned |= !strcmp(argv[k], "pinned");
+    }
     const int spms = (int)(fs * 1e-3);                   /* samples per millisecond */
     const int64_t ring = 100 * (int64_t)spms;            /* the reference's 100 ms ring (channelManager.py:57) */
     const int64_t total = (int64_t)(ticks + 2) * spms;
     sdr_engine* e = NULL;
     CK(sdr_engine_create(0, &e));
-    if (!(argc > 3 && !strcmp(argv[3], "nobind")) && !(argc > 2 && !strcmp(argv[2], "nobind")))
-        (void)sdr_set_option(e, "bind_thread_to_device", 1);       /* (best effort: no sysfs, no binding) */
+    if (!nobind) (void)sdr_set_option(e, "bind_thread_to_device", 1);       /* (best effort: no sysfs, no binding) */
     CK(sdr_code_slots(e, N_CH, 1023));
     sdr_synth_sat sats[N_CH];
     int32_t slots[N_CH];
@@ -60,7 +65,11 @@ int main(int argc, char** argv) {
     /* the stream: synthesised on the device into a ring large enough for all of it, brought to the host (the IQ source) */
     CK(sdr_iq_alloc(e, total, SDR_FMT_CI8));
     CK(sdr_iq_synth(e, sats, N_CH, fs, 12.0, 20260004ull, 0, total));
-    int8_t* stream = (int8_t*)malloc((size_t)total * 2);
+    /* `pinned`: the samples in page-locked memory of the engine's (as a front end's DMA buffer would be): the slabs are then read
+     * in place by the tick's launch instead of being copied into a staging buffer first */
+    int8_t* stream = NULL;
+    if (pinned) CK(sdr_host_alloc(e, (size_t)total * 2, (void**)&stream));
+    else stream = (int8_t*)malloc((size_t)total * 2);
     CK(sdr_iq_download(e, stream, total, 0));
     CK(sdr_iq_alloc(e, ring, SDR_FMT_CI8));              /* the receiver's ring */
     CK(sdr_code_slots(e, N_CH, 1023));                   /* (the tables go with the ring's engine state: staged again) */
@@ -143,7 +152,8 @@ int main(int argc, char** argv) {
         if (st[3] || st[1] < ticks - 10) return 4;        /* (a server starts once eight steady ticks have passed) */
     }
     sdr_bank_destroy(e, bank);
+    if (pinned) CK(sdr_host_free(e, stream));
+    else free(stream);
     sdr_engine_destroy(e);
-    free(stream);
     return locked == N_CH ? 0 : 3;
 }

@@ -455,7 +455,11 @@ int sdr_tick_server_tracker_phases(sdr_engine* e, double* out6);
  * (sdr_bank_tick_mirrored with n_ran == 0 and n_samples == 0) launches nothing and waits for nothing: the slab is then
  * still in flight when the call returns.  Between receiver ticks the slab only waits in its staging half: the next
  * sdr_bank_tick_mirrored's ONE launch begins with workgroups that pull it into the ring while the trackers behind them set
- * up (or the resident tick server's doormen pull it); every other call on the engine puts it into the ring first, in order. */
+ * up (or the resident tick server's doormen pull it); every other call on the engine puts it into the ring first, in order.
+ * ONE exception to "copied before the call returns": a slab that lies in page-locked memory from sdr_host_alloc, on a 16-byte
+ * boundary and a whole number of 16-byte granules long, is read IN PLACE by whoever pulls it into the ring (no staging copy:
+ * ~2 us of a 50 KB slab) -- the caller leaves it unchanged until the next sdr_bank_tick* of the engine, or sdr_engine_sync,
+ * has returned. */
 int sdr_iq_upload_begin(sdr_engine* e, const void* iq, int64_t n_samples, int64_t ring_offset);
 /* A chunk of a recording (any size) queued for the ring WITHOUT being copied first: one asynchronous copy command on the
  * engine's stream, ordered like everything else queued there; the caller keeps `iq` valid and unchanged until

@@ -1,6 +1,7 @@
 // Engine lifetime, error text, IQ ring in HBM, per-kernel hipEvent timing.
 #include "engine_internal.h"
 #include <sched.h>
+#include <cstdint>
 #include <cerrno>
 #include <cctype>
 #include "build_id.h"
@@ -558,6 +559,7 @@ int sdr_host_alloc(sdr_engine* e, size_t bytes, void** out) {
         *out = nullptr;
         return sdr_fail(SDR_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
     }
+    e->host_blocks.emplace_back((const char*)*out, bytes);
     return SDR_OK;
 }
 
@@ -565,6 +567,11 @@ int sdr_host_free(sdr_engine* e, void* block) {
     if (int rc = sdr_set_device(e)) return rc;
     if (!block) return SDR_OK;
     SDR_HIP(hipStreamSynchronize(e->stream));     // (a queued upload may still read it)
+    for (size_t k = 0; k < e->host_blocks.size(); ++k)
+        if (e->host_blocks[k].first == (const char*)block) {
+            e->host_blocks.erase(e->host_blocks.begin() + (long)k);
+            break;
+        }
     SDR_HIP(hipHostFree(block));
     return SDR_OK;
 }
@@ -577,14 +584,16 @@ int sdr_iq_flush_server_slab(sdr_engine* e) {
     const size_t sb = sdr_fmt_bytes(e->iq_fmt);
     const size_t bytes = (size_t)e->srv_slab_n * sb, off_b = (size_t)e->srv_slab_off * sb, cap_b = (size_t)e->iq_capacity * sb;
     const int half = e->srv_slab_half;
-    const char* stage = (const char*)e->slab_pinned + (half ? e->slab_bytes : 0);
+    const char* stage = (const char*)e->srv_slab_src;
     const size_t n16 = bytes / 16;
     const unsigned blocks = (unsigned)((n16 + 255) / 256 < 64 ? (n16 + 255) / 256 : 64);
     hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)stage, (uint4*)e->iq, n16, off_b / 16, cap_b / 16);
     SDR_HIP(hipGetLastError());
-    if (!e->slab_done[half]) SDR_HIP(hipEventCreateWithFlags(&e->slab_done[half], hipEventDisableTiming));
-    SDR_HIP(hipEventRecord(e->slab_done[half], e->stream));
-    e->slab_busy[half] = true;
+    if (half >= 0) {      // (a staging half: busy until the kernel has read it; the caller's own block is the caller's to keep)
+        if (!e->slab_done[half]) SDR_HIP(hipEventCreateWithFlags(&e->slab_done[half], hipEventDisableTiming));
+        SDR_HIP(hipEventRecord(e->slab_done[half], e->stream));
+        e->slab_busy[half] = true;
+    }
     return SDR_OK;
 }
 
@@ -597,6 +606,34 @@ int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_
     if (int rc = sdr_set_device_keep(e)) return rc;           // (a resident tick server stays: it may be the one to pull this slab)
     if (e->srv_slab_pending)                                   // (a slab still waiting for a request: into the ring the ordinary way first)
         if (int rc = sdr_iq_flush_server_slab(e)) return rc;
+    // A slab that already lies in page-locked memory this engine handed out (sdr_host_alloc), on a 16-byte boundary, is read IN
+    // PLACE by whoever pulls it into the ring -- the ingest workgroups of the next tick's launch, the tick server's doormen, an
+    // ingest kernel queued here -- instead of being copied into a staging half first (2 us of a 50 KB slab): the caller leaves
+    // it unchanged until the next tick of the engine (or sdr_engine_sync) has returned.
+    if (e->iq && ring_offset >= 0 && n_samples <= e->iq_capacity && !e->ingest_by_copy && (uintptr_t)iq % 16 == 0 && bytes % 16 == 0) {
+        bool ours = false;
+        for (const auto& blk : e->host_blocks)
+            ours = ours || ((const char*)iq >= blk.first && (const char*)iq + bytes <= blk.first + blk.second);
+        const size_t sb = sdr_fmt_bytes(e->iq_fmt);
+        const int64_t off = ring_offset % e->iq_capacity;
+        const size_t off_b = (size_t)off * sb, cap_b = (size_t)e->iq_capacity * sb;
+        if (ours && off_b % 16 == 0 && cap_b % 16 == 0) {
+            sdr_iq_mark_written(e, off, n_samples);
+            if (e->srv_running || (e->ingest_with_tick && e->last_tick_took_slab)) {
+                e->srv_slab_pending = true;
+                e->srv_slab_half = -1;
+                e->srv_slab_src = iq;
+                e->srv_slab_off = off;
+                e->srv_slab_n = n_samples;
+                return SDR_OK;
+            }
+            const size_t n16 = bytes / 16;
+            const unsigned blocks = (unsigned)((n16 + 255) / 256 < 64 ? (n16 + 255) / 256 : 64);
+            hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)iq, (uint4*)e->iq, n16, off_b / 16, cap_b / 16);
+            SDR_HIP(hipGetLastError());
+            return SDR_OK;
+        }
+    }
     if (bytes > e->slab_bytes) {
         SDR_HIP(hipStreamSynchronize(e->stream));   // (an earlier slab's DMA may still read the old buffer)
         if (e->slab_pinned) SDR_HIP(hipHostFree(e->slab_pinned));
@@ -640,6 +677,7 @@ int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_
                 // busy until the request that needs it has been answered (or the slab flushed the ordinary way).
                 e->srv_slab_pending = true;
                 e->srv_slab_half = half;
+                e->srv_slab_src = stage;
                 e->srv_slab_off = off;
                 e->srv_slab_n = n_samples;
                 return SDR_OK;

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/sydr_amd.h"
@@ -145,7 +146,9 @@ struct sdr_engine {
     bool ingest_with_tick = true;        // "ingest_with_tick": a receiver tick's slab is pulled into the ring by workgroups of the tick's
                                          // own launch instead of a launch of its own in front of it
     bool last_tick_took_slab = false;    // the previous tick's launch was of that form: the next slab waits for the next tick's
-    int srv_slab_half = 0;
+    int srv_slab_half = 0;               // (-1: the slab lies in the caller's page-locked memory -- sdr_host_alloc -- and is read in place)
+    const void* srv_slab_src = nullptr;  // where it lies: a staging half or the caller's block
+    std::vector<std::pair<const char*, size_t>> host_blocks;   // what sdr_host_alloc has handed out
     int64_t srv_slab_off = 0, srv_slab_n = 0;
     bool ingest_by_copy = false;     // "ingest_by_copy_command": queued slabs go into the ring by hipMemcpyAsync, not by the ingest kernel
     bool pcps_no_spec_cache = false; // "pcps_no_spectra_cache": conj(fft(code)) recomputed by every search, as the reference does (kaplan:184-185)

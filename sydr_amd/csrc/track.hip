@@ -74,8 +74,8 @@ constexpr int kGoStride = 32;      // unsigned words between two channels' relea
 enum { kReqSeqs = 0, kReqWriteIndex = 1, kReqSlabSrc16 = 2, kReqSlabN16 = 3, kReqSlabFirst16 = 4, kReqNeedPull = 5, kReqSeqsCopy = 7 };
 struct TickServerHost {            // page-locked: the words the host and the doormen share
     // [0] / [7]: request number (low half: 1, 2, 3, ...; kServerStop = leave) and slab number (high half: 1, 2, 3, ...: "pull
-    // this slab into the ring"); [1] the ring's write index after the slab; [2] the slab's first 16-byte granule inside the
-    // staging block, [3] its granules, [4] its first ring granule; [5] the slab the request needs in the ring before the channels
+    // this slab into the ring"); [1] the ring's write index after the slab; [2] where the slab lies in page-locked memory
+    // (its address / 16: a staging half of the engine's or the caller's own block), [3] its granules, [4] its first ring granule; [5] the slab the request needs in the ring before the channels
     // are released (0: none)
     unsigned long long line[8];
     unsigned done_seq;             // doorman: the last request it has seen answered by every channel (stamps below are that request's)
@@ -105,7 +105,6 @@ struct TickServer {
     TickServerHost* host;          // nullptr: not a server launch
     TickServerDev* dev;
     unsigned* go;                  // device [n_ch * kGoStride]: channel c's release word (the request its cluster may work on; kServerStop: leave)
-    const uint4* staging;          // page-locked slab staging of the engine
     uint4* ring16;
     unsigned long long ring_n16;
     sdr_track_epoch* rec_out;      // device [n_ch]: where the roles write the epoch's record
@@ -122,7 +121,7 @@ struct TickServer {
     unsigned* done_words;
     unsigned done_seq;
     // Likewise a plain launch's (the one-launch receiver tick): its first kTickIngestGroups workgroups pull the tick's slab out
-    // of the staging block (`staging`, granules ingest_src16 .. + ingest_n16) into the ring (`ring16`, from ingest_first16) and
+    // of page-locked memory (address / 16 = ingest_src16, ingest_n16 granules) into the ring (`ring16`, from ingest_first16) and
     // count themselves in at *ingest_count; the trackers stage their tables and parameters meanwhile and read their first
     // sample when the count has reached ingest_target.  ingest_n16 = 0: no slab with this launch.
     unsigned long long ingest_src16, ingest_n16, ingest_first16;
@@ -222,11 +221,12 @@ __device__ __attribute__((unused)) void tick_server_doorman(const TickServer& s,
             __syncthreads();
             // this workgroup's share of the slab: granules [lo, hi)
             const unsigned long long lo = n16 * (unsigned long long)group / kDoorGroups, hi = n16 * (unsigned long long)(group + 1) / kDoorGroups;
+            const uint4* const src = reinterpret_cast<const uint4*>(static_cast<uintptr_t>(src16) << 4);   // (an address in the host's memory / 16)
             for (unsigned long long i0 = lo + tid; i0 < hi; i0 += 4 * kDoorThreads) {     // four loads per lane in flight, then their stores
                 uint4 v[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (i0 + (unsigned long long)k * kDoorThreads < hi) v[k] = s.staging[src16 + i0 + (unsigned long long)k * kDoorThreads];
+                    if (i0 + (unsigned long long)k * kDoorThreads < hi) v[k] = src[i0 + (unsigned long long)k * kDoorThreads];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const unsigned long long i = i0 + (unsigned long long)k * kDoorThreads;
@@ -863,10 +863,11 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
     if constexpr (kCluster) {
         if (with_slab) {
             if (bid < kTickIngestGroups) {
+                const uint4* const src = reinterpret_cast<const uint4*>(static_cast<uintptr_t>(srv.ingest_src16) << 4);
                 for (unsigned long long i = (unsigned long long)bid * THREADS + tid; i < srv.ingest_n16; i += (unsigned long long)kTickIngestGroups * THREADS) {
                     unsigned long long d = srv.ingest_first16 + i;
                     if (d >= srv.ring_n16) d -= srv.ring_n16;
-                    srv.ring16[d] = srv.staging[srv.ingest_src16 + i];
+                    srv.ring16[d] = src[i];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every wave: its stores have left (the barrier orders them ...)
                 __syncthreads();                                          // ... before lane 0's device-wide release)
@@ -1529,10 +1530,9 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
         else srv_arg.done_words = r.done_words, srv_arg.done_seq = r.done_seq;
         if (take_slab && phase == 3) {
             const size_t sb = sdr_fmt_bytes(e->iq_fmt);
-            srv_arg.staging = (const uint4*)e->slab_pinned;
             srv_arg.ring16 = (uint4*)e->iq;
             srv_arg.ring_n16 = (unsigned long long)((size_t)e->iq_capacity * sb / 16);
-            srv_arg.ingest_src16 = (unsigned long long)((e->srv_slab_half ? e->slab_bytes : 0) / 16);
+            srv_arg.ingest_src16 = (unsigned long long)((uintptr_t)e->srv_slab_src / 16);
             srv_arg.ingest_n16 = (unsigned long long)((size_t)e->srv_slab_n * sb / 16);
             srv_arg.ingest_first16 = (unsigned long long)((size_t)e->srv_slab_off * sb / 16);
             srv_arg.ingest_count = reinterpret_cast<unsigned*>(ctx->xchg.ptr) + 64;
@@ -1632,9 +1632,11 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
                         ctx->ingest_launches += 1;
                         e->srv_slab_pending = false;
                         const int half = e->srv_slab_half;
-                        if (!e->slab_done[half]) (void)hipEventCreateWithFlags(&e->slab_done[half], hipEventDisableTiming);
-                        (void)hipEventRecord(e->slab_done[half], ctx->stream);
-                        e->slab_busy[half] = true;
+                        if (half >= 0) {      // (-1: the caller's own page-locked block, the caller's to keep until the tick returns)
+                            if (!e->slab_done[half]) (void)hipEventCreateWithFlags(&e->slab_done[half], hipEventDisableTiming);
+                            (void)hipEventRecord(e->slab_done[half], ctx->stream);
+                            e->slab_busy[half] = true;
+                        }
                     }
                     take_slab = false;
                 }
@@ -2161,7 +2163,6 @@ struct TickServerState {
     unsigned long long prev_t5 = 0;   // channel 0: release -> seen, -> samples visible, -> correlated, -> exchanged, -> updated, -> answered
     int64_t code_generation = -1;
     void* ring = nullptr;
-    void* staging = nullptr;
 };
 
 static bool server_wait(volatile unsigned* word, unsigned want, double seconds) {
@@ -2295,7 +2296,6 @@ static int tick_server_start(sdr_engine* e, sdr_bank* b, const int32_t* channels
     a.host = s->host;
     a.dev = (TickServerDev*)s->dev.ptr;
     a.go = (unsigned*)dp;
-    a.staging = (const uint4*)e->slab_pinned;
     a.ring16 = (uint4*)e->iq;
     a.ring_n16 = (unsigned long long)((size_t)e->iq_capacity * sdr_fmt_bytes(e->iq_fmt) / 16);
     a.rec_out = (sdr_track_epoch*)(dp + go_bytes);
@@ -2344,7 +2344,6 @@ static int tick_server_start(sdr_engine* e, sdr_bank* b, const int32_t* channels
     s->seq = s->pull_seq = s->stamps_seq = 0;
     s->code_generation = e->code_generation;
     s->ring = e->iq;
-    s->staging = e->slab_pinned;
     s->starts += 1;
     e->srv_running = true;
     return SDR_OK;
@@ -2437,7 +2436,7 @@ int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int
             if (why >= 2) s->disabled = true;
         }
         const bool same = e->srv_running && s->bank == b && s->channels == cand && s->code_generation == e->code_generation &&
-                          s->ring == e->iq && s->staging == e->slab_pinned;
+                          s->ring == e->iq;
         bool use = one_tap_count && !cand.empty() && (long)cand.size() * 4 <= (long)e->n_cus;
         // A server costs ~25 ms to start (a cooperative launch, the doormen becoming resident): it is started for a receiver
         // that HAS settled into steady ticks -- eight in a row with nothing else on the engine in between -- not for the
@@ -2474,7 +2473,7 @@ int sdr_bank_tick_mirrored_begin(sdr_engine* e, sdr_bank* b, const void* iq, int
             unsigned long long words[5] = {(unsigned long long)write_index, 0, 0, 0, 0};
             if (e->srv_slab_pending) {
                 const size_t sb = sdr_fmt_bytes(e->iq_fmt);
-                words[1] = (unsigned long long)((e->srv_slab_half ? e->slab_bytes : 0) / 16);
+                words[1] = (unsigned long long)((uintptr_t)e->srv_slab_src / 16);
                 words[2] = (unsigned long long)((size_t)e->srv_slab_n * sb / 16);
                 words[3] = (unsigned long long)((size_t)e->srv_slab_off * sb / 16);
                 words[4] = ++s->pull_seq;
@@ -2570,7 +2569,7 @@ int sdr_bank_tick_mirrored_end(sdr_engine* e, sdr_bank* b, sdr_tick_mirror* m) {
         s->served_total += 1;
         if (e->srv_slab_pending) {              // (the doorman has pulled it: its staging half is free again)
             e->srv_slab_pending = false;
-            e->slab_busy[e->srv_slab_half] = false;
+            if (e->srv_slab_half >= 0) e->slab_busy[e->srv_slab_half] = false;
         }
         bool xchg_fault = __atomic_load_n(&h->fault, __ATOMIC_ACQUIRE) != 0;
         for (size_t c = 0; c < s->channels.size(); ++c) xchg_fault = xchg_fault || s->h_ran[c] == -2;

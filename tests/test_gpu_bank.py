@@ -752,6 +752,67 @@ def test_one_launch_tick_equals_the_two_launch_tick_and_the_separate_ingest(engi
             assert a == b, (form, k)
 
 
+def test_slabs_in_page_locked_memory_are_read_in_place_with_the_same_bits(engine):
+    """A slab that lies in memory from sdr_host_alloc is read in place by whoever pulls it into the ring (the tick's ingest
+    workgroups, the tick server's doormen, an ingest kernel) instead of being staged first: the same packets, bit for bit, as
+    from pageable memory -- plain ticks and served ones, incl. a slab at an address that is NOT on a 16-byte boundary (staged
+    like any other) and a ring-reading call in between."""
+    import configparser
+    import os
+    from conftest import REPO
+    from sydr_amd.channel.l1ca_kaplan import ChannelL1CA_Kaplan
+    from sydr_amd.channel.manager import ChannelManager
+    from sydr_amd.signal.iqsource import RFSignal
+    fs, n_ms = 10e6, 220
+    spms = int(fs * 1e-3)
+    rng = np.random.default_rng(9191)
+    sats = [dict(prn=1 + c, doppler=float(250.0 * rng.integers(-15, 16) + rng.uniform(-40, 40)),
+                 code_phase=float(rng.uniform(0, 1023)), phase=float(rng.uniform(0, 1)), amp=5.0) for c in range(12)]
+    total = n_ms * spms
+    engine.iq_alloc(total, FMT_CI8)
+    engine.code_slots(32)
+    engine.iq_synth(sats, fs, 10.0, 9192, 0, total)
+    raw = engine.iq_download(total, 0)
+    block = engine.host_alloc(raw.size + 16, raw.dtype)
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(REPO, "examples", "channel_GPS_L1CA_kaplan.ini"))
+
+    def receiver(source, server):
+        engine.set_option("tick_server", 1 if server else 0)
+        rf = RFSignal(dict(filepath="none", sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0, data_size=8))
+        mgr = ChannelManager(rf, engine=engine, keepCorrelationMap=False)
+        mgr.addChannel(ChannelL1CA_Kaplan, cfg, 12)
+        for s in sats:
+            mgr.requestTracking(s["prn"])
+        ticks = []
+        try:
+            for k in range(n_ms):
+                if k == 120:
+                    engine.iq_download(64, 0)
+                mgr.addNewRFData(source[2 * k * spms:2 * (k + 1) * spms])
+                ticks.append([dict(q) for q in mgr.run()])
+        finally:
+            mgr.close()
+            engine.set_option("tick_server", 0)
+        return ticks
+
+    try:
+        reference = receiver(raw, False)
+        block[:raw.size] = raw
+        aligned = block[:raw.size]
+        assert aligned.ctypes.data % 16 == 0
+        for server in (False, True):
+            got = receiver(aligned, server)
+            for k, (a, b) in enumerate(zip(reference, got)):
+                assert a == b, (server, k)
+        block[2:2 + raw.size] = raw                       # the same samples two bytes further on: no 16-byte boundary, staged
+        got = receiver(block[2:2 + raw.size], False)
+        for k, (a, b) in enumerate(zip(reference, got)):
+            assert a == b, k
+    finally:
+        engine.host_free(block)
+
+
 def test_bind_thread_to_device_restricts_the_calling_thread_and_gives_the_mask_back(engine):
     """sdr_set_option "bind_thread_to_device": the calling thread onto the CPUs sysfs lists for the GPU's PCI function -- a
     non-empty subset of the mask it had -- and back (a served tick is round trips through page-locked words: from the other

@@ -20,7 +20,7 @@ FS = bench.FS
 WARMUP_MS = 100     # ticks not counted: acquisition, the first launches of each kernel (code objects load on first use), the first block
 
 
-def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0, tick_server=False, bind=True):
+def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0, tick_server=False, bind=True, pinned_source=False):
     """read_ahead > 0: the same loop with ChannelManager.enableReadAhead(read_ahead) and the stream served from a file
     through this package's RFSignal (what lets the manager look ahead); the calls per tick are the reference's.
     The first WARMUP_MS ticks are fed and run but not counted (their time is reported as warmup_ms_total).
@@ -40,6 +40,11 @@ def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0, tick_se
     sats = bench.satellites(n_ch)
     eng.iq_synth(sats, FS, 12.0, 20260003, 0, total)
     raw = eng.iq_download(total, 0)
+    pinned_block = None
+    if pinned_source:     # the recording in page-locked memory of the engine's (a front end's DMA buffer): slabs are read in place
+        pinned_block = eng.host_alloc(raw.size, raw.dtype)
+        pinned_block[:] = raw
+        raw = pinned_block
     tmp = None
     if read_ahead:
         import tempfile
@@ -84,6 +89,8 @@ def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0, tick_se
     srv = eng.tick_server_stats()
     mgr.close()
     eng.set_option("tick_server", 0)
+    if pinned_block is not None:
+        eng.host_free(pinned_block)
     # read-ahead: a tick in ~50 pays for the block, so the MEAN per tick is the honest figure there (the median is the
     # price of a tick that only hands packets out); the plain loop keeps its median (every tick is alike)
     avg = (lambda v: float(np.mean(v))) if read_ahead else (lambda v: float(np.median(v)))
@@ -108,4 +115,4 @@ def measure(n_ms=600, n_ch=32, profile=False, engine=None, read_ahead=0, tick_se
 if __name__ == "__main__":
     n_ms = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 600
     ra = int(sys.argv[sys.argv.index("--read-ahead") + 1]) if "--read-ahead" in sys.argv else 0
-    print(json.dumps(measure(n_ms, profile="--profile" in sys.argv, read_ahead=ra, tick_server="--tick-server" in sys.argv, bind="--no-bind" not in sys.argv)))
+    print(json.dumps(measure(n_ms, profile="--profile" in sys.argv, read_ahead=ra, tick_server="--tick-server" in sys.argv, bind="--no-bind" not in sys.argv, pinned_source="--pinned-source" in sys.argv)))
