@@ -62,6 +62,7 @@ class ChannelManager:
             from ..runtime import get_engine
             engine = get_engine(device_id)
         self.engine = engine
+        self._engine_queues_slabs = hasattr(engine, "iq_upload_begin")      # (asked once, not every millisecond)
         buffersize = int(self.rfSignal.samplingFrequency * 1e-3 * ring_ms)   # 100 ms, as channelManager.py:57
         fmt = {np.int8: FMT_CI8, np.int16: FMT_CI16}.get(getattr(rfSignal, "fileDataType", None), FMT_CF64)
         self.sharedBuffer = CircularBuffer(buffersize, rfSignal.dtype, engine=engine, fmt=fmt)
@@ -331,7 +332,7 @@ class ChannelManager:
         if ring.full and (self._unread_max is None or self._unread_max + count > ring.maxSize):
             self._guard_unread(count)
         self._unread_max = None
-        if staged.nbytes > self.DEFER_BYTES or not hasattr(self.engine, "iq_upload_begin"):
+        if staged.nbytes > self.DEFER_BYTES or not self._engine_queues_slabs:
             self.engine.iq_upload(staged, offset)
         else:
             # the reference copies at this point (circularbuffer.py:54-82); so does this: the samples are copied out of

@@ -23,6 +23,10 @@ def make_items(code_slot, n_samples, start_sample, carrier_hz, rem_carrier, rem_
     return items
 
 
+_addressof = C.addressof
+_char_from_buffer = C.c_char.from_buffer
+
+
 class EplPlan:
     """Items + outputs resident in HBM; run() only launches kernels (asynchronous)."""
 
@@ -293,7 +297,13 @@ class Engine:
         ordered before everything queued on the engine's stream afterwards; `sync()` completes it."""
         if not (type(raw) is np.ndarray and raw.ndim == 1 and raw.flags.c_contiguous and raw.dtype == _lib.fmt_dtype(self.iq_fmt)):
             raw = self._ring_samples(raw)
-        status = self._lib.sdr_iq_upload_begin(self._h, raw.ctypes.data, raw.size >> 1, ring_offset)
+        # (the array's address through the buffer protocol: `raw.ctypes.data` builds a helper object per call -- a microsecond of
+        # a tick that is made of thirty; a read-only array has no writable buffer to offer and takes the long way)
+        try:
+            address = _addressof(_char_from_buffer(raw))
+        except (TypeError, ValueError):
+            address = raw.ctypes.data
+        status = self._lib.sdr_iq_upload_begin(self._h, address, raw.size >> 1, ring_offset)
         if status:
             check(status)
 
