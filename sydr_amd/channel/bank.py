@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from collections.abc import Sequence
 
+import weakref
+
 import numpy as np
 
 from .._lib import LOOP_CFG_DTYPE, TRACK_EPOCH_DTYPE, TRACK_STATE_DTYPE
@@ -56,6 +58,7 @@ class ChannelBank:
         self._any_dirty = False
         self._kinds = None                                                 # cfg["loop_kind"] as a list (see kinds)
         self._bound = None                                                 # the device's sdr_tick_mirror over these arrays
+        self._held = ([], [])                                              # per output set of the device: weak references (hold())
         self.nav_bits = [[] for _ in range(self.max_channels)]
 
     def grown(self, max_channels: int) -> "ChannelBank":
@@ -185,7 +188,28 @@ class ChannelBank:
         dev = self.device
         if self._bound is None:
             self._bound = dev.bind_mirror(self.state, self.last, self.code_since_tow, self.tracking, self.lost, self.host_flags)
+        self._release_next_set()
         return self.tick_ready_end(dev.tick_mirrored(raw, ring_offset, self.ring.idxWrite))
+
+    # The device writes a tick's `ran` / `records` / `updates` into one of TWO sets of arrays, alternately: what tick_ready_end
+    # hands out are VIEWS of them (three copies of together 8 KB cost 5 of a tick's 35 us from Python), good until the tick
+    # after next.  Whoever builds something longer-lived on such views -- the lazy packet rows -- registers it with hold();
+    # before the device comes round to a set again, what is still alive of it is told to take its own copy (detach()).
+    def hold(self, *row_objects):
+        if getattr(self.device, "double_buffered", False):
+            self._held[self.device.out_set].extend(weakref.ref(o) for o in row_objects)
+
+    def _release_next_set(self):
+        dev = self.device
+        if not getattr(dev, "double_buffered", False):
+            return
+        held = self._held[dev.out_set ^ 1]
+        if held:
+            for ref in held:
+                rows = ref()
+                if rows is not None:
+                    rows.detach()
+            held.clear()
 
     def tick_ready_begin(self, raw, ring_offset):
         """First half of `tick_ready` (sdr_bank_tick_mirrored_begin): the ready channels' epoch is queued on this bank's
@@ -194,6 +218,7 @@ class ChannelBank:
         dev = self.device
         if self._bound is None:
             self._bound = dev.bind_mirror(self.state, self.last, self.code_since_tow, self.tracking, self.lost, self.host_flags)
+        self._release_next_set()
         dev.tick_mirrored_begin(raw, ring_offset, self.ring.idxWrite)
 
     def tick_ready_end(self, m=None):
@@ -201,8 +226,10 @@ class ChannelBank:
         if m is None:
             m = dev.tick_mirrored_end()
         n = m.n_ran
-        ran, rec = dev.ran[:n].copy(), dev.records[:n].copy()
-        upd = dev.updates[:m.n_updates].copy()
+        if getattr(dev, "double_buffered", False):      # (views: see hold())
+            ran, rec, upd = dev.ran[:n], dev.records[:n], dev.updates[:m.n_updates]
+        else:
+            ran, rec, upd = dev.ran[:n].copy(), dev.records[:n].copy(), dev.updates[:m.n_updates].copy()
         if m.n_nav_bits:
             bits, decoders, through_decoder = rec["nav_bit"], self.decoders, False
             for r in np.flatnonzero(bits >= 0).tolist():
@@ -350,8 +377,16 @@ class TrackingRows:
     io/database.py:76-93; Borre has no lock indicators: channel_l1ca_borre.py:430-449 sends NaN / zeros there): the
     tick's epoch records, turned into plain Python values in ONE call the first time any packet is filled (field
     access on NumPy records costs more per packet than the dict itself)."""
-    __slots__ = ("cids", "kinds", "records", "_rows", "_row_of", "_templates")
+    __slots__ = ("cids", "kinds", "records", "_rows", "_row_of", "_templates", "__weakref__")
     _AT = {name: k for k, name in enumerate(TRACK_EPOCH_DTYPE.names)}
+
+    def detach(self):
+        """The arrays this was built on are about to be overwritten (ChannelBank.hold): own copies, unless the rows have been
+        turned into Python values already."""
+        if self._rows is None:
+            self.records = self.records.copy()
+            if isinstance(self.cids, np.ndarray):
+                self.cids = self.cids.copy()
 
     def __init__(self, cids, kinds, records, templates=None):
         """cids: channel per record (array or list); kinds: loop kind per CHANNEL NUMBER (a list indexed by cid) or per
@@ -407,7 +442,13 @@ class UpdateRows:
     """Source of one tick's CHANNEL_UPDATE packets (channel.py:205-228) from values captured at the end of the tick.
     `tow` is what the reference's `Channel.tow` holds: the int 0 until a subframe was decoded, then HOW TOW + 1.24 s
     (kaplan:810-822)."""
-    __slots__ = ("cids", "states", "flags", "tows", "tow_decoded", "unread", "code", "samples_per_ms", "_rows", "_templates")
+    __slots__ = ("cids", "states", "flags", "tows", "tow_decoded", "unread", "code", "samples_per_ms", "_rows", "_templates",
+                 "__weakref__")
+
+    def detach(self):
+        """As TrackingRows.detach: `flags` may be a tick's sdr_tick_update rows (a view of the device's array)."""
+        if self._rows is None and isinstance(self.flags, np.ndarray):
+            self.flags = self.flags.copy()
 
     def __init__(self, cids, states, flags, tows, tow_decoded, unread, code_since_tow, samples_per_ms, templates=None):
         """cids / flags / unread / code_since_tow: one value per packet (or flags = the tick's sdr_tick_update rows and

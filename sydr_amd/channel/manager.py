@@ -517,15 +517,19 @@ class ChannelManager:
         # whoever looks at the ring next flushes it; the library guards its own staging halves with events either way)
         decoded = ()
         if len(ran):
-            out.add_lazy(TrackingRows(ran, bank.kinds, rec))
+            rows = TrackingRows(ran, bank.kinds, rec)
+            bank.hold(rows)                                   # (`ran` / `rec` / `upd` are views of the device's arrays: bank.hold)
+            out.add_lazy(rows)
             if bank.decoded:                                  # subframes completed by this tick's bits (kaplan:71-73)
                 decoded = [pkt for _, _, pkt in bank.take_decoded()]
                 out.add_ready(decoded)
         self._steady_rows = (ran, rec, upd, decoded)         # (what a manager of several devices merges into one packet list)
         if len(upd) != len(cids_active):                     # (cannot happen while the lists stand; never guess)
             raise RuntimeError("channel bank and channel manager disagree about the tracking channels")
-        out.add_lazy(UpdateRows(cids_active, states_active, upd, bank.tow.copy(), bank.tow_decoded.copy(), None, None,
-                                self._samples_per_ms, upd_templates))     # (flags / unread / code count: the rows of `upd`)
+        rows = UpdateRows(cids_active, states_active, upd, bank.tow.copy(), bank.tow_decoded.copy(), None, None,
+                          self._samples_per_ms, upd_templates)            # (flags / unread / code count: the rows of `upd`)
+        bank.hold(rows)
+        out.add_lazy(rows)
         return out
 
     def _acquire(self, acquiring):

@@ -161,23 +161,37 @@ class Bank:
                       (tracking, np.bool_), (lost, np.bool_), (host_flags, np.int64)):
             if a.dtype != dt or a.shape != (n,) or not a.flags.c_contiguous:
                 raise ValueError("tick mirror arrays must be contiguous, one row per bank channel, in the bank's dtypes")
-        self.ran = np.zeros(n, dtype=np.int32)
-        self.records = np.zeros(n, dtype=TRACK_EPOCH_DTYPE)
-        self.updates = np.zeros(n, dtype=_lib.TICK_UPDATE_DTYPE)
         self._mirror_arrays = (states, last, epochs_since_tow, tracking, lost, host_flags)
-        m = self._mirror = _lib.TickMirror()
-        m.max_channels = n
-        m.states, m.last, m.epochs_since_tow = states.ctypes.data, last.ctypes.data, epochs_since_tow.ctypes.data
-        m.tracking, m.lost, m.host_flags = tracking.ctypes.data, lost.ctypes.data, host_flags.ctypes.data
-        m.ran, m.records, m.updates = self.ran.ctypes.data, self.records.ctypes.data, self.updates.ctypes.data
-        self._mirror_ref = C.byref(m)
+        # TWO sets of per-tick outputs, used alternately (`out_set`): what a tick left in `ran` / `records` / `updates` stays
+        # untouched through the NEXT tick, so a caller that hands out views of them (the channel bank's lazy packets) need not
+        # copy 8 KB per millisecond -- only what is still looked at when the set comes round again (ChannelBank.hold)
+        self._sets = []
+        for _ in range(2):
+            ran = np.zeros(n, dtype=np.int32)
+            records = np.zeros(n, dtype=TRACK_EPOCH_DTYPE)
+            updates = np.zeros(n, dtype=_lib.TICK_UPDATE_DTYPE)
+            m = _lib.TickMirror()
+            m.max_channels = n
+            m.states, m.last, m.epochs_since_tow = states.ctypes.data, last.ctypes.data, epochs_since_tow.ctypes.data
+            m.tracking, m.lost, m.host_flags = tracking.ctypes.data, lost.ctypes.data, host_flags.ctypes.data
+            m.ran, m.records, m.updates = ran.ctypes.data, records.ctypes.data, updates.ctypes.data
+            self._sets.append((ran, records, updates, m, C.byref(m)))
+        self.out_set = 0
+        self.ran, self.records, self.updates, self._mirror, self._mirror_ref = self._sets[0]
         self._tick_no_slab = (self._e._h, self._h, None, 0)        # leading arguments of a tick whose slab is queued already
-        return m
+        return self._mirror
+
+    double_buffered = True      # (per-tick outputs alternate between two sets: see bind_mirror)
+
+    def _next_set(self):
+        k = self.out_set = self.out_set ^ 1
+        self.ran, self.records, self.updates, self._mirror, self._mirror_ref = self._sets[k]
 
     def tick_mirrored(self, raw, ring_offset: int, write_index: int):
         """One receiver tick with the readiness test and the mirror updates in the library (sdr_bank_tick_mirrored);
         `raw` None when the slab went in with Engine.iq_upload_begin.  -> the bound sdr_tick_mirror (n_ran, n_updates,
         n_nav_bits, n_lost, max_unread; the rows in `ran` / `records` / `updates`)."""
+        self._next_set()
         if raw is None:
             status = self._lib.sdr_bank_tick_mirrored(*self._tick_no_slab, ring_offset, write_index, self._mirror_ref)
         else:
@@ -192,6 +206,7 @@ class Bank:
         """First half of `tick_mirrored` (sdr_bank_tick_mirrored_begin): who is ready is decided and their epoch queued on
         the engine's stream; nothing is waited for.  A manager of several devices begins every device's tick, then ends
         each."""
+        self._next_set()
         if raw is None:
             status = self._lib.sdr_bank_tick_mirrored_begin(*self._tick_no_slab, ring_offset, write_index, self._mirror_ref)
         else:

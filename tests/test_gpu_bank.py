@@ -454,13 +454,13 @@ def test_mirrored_tick_with_three_and_five_tap_channels(engine):
     since, host_flags = np.zeros(6, dtype=np.int64), np.zeros(6, dtype=np.int64)
     tracking, lost = np.ones(6, dtype=bool), np.zeros(6, dtype=bool)
     tracking[5] = False                                     # (not tracking: never runs, no update row)
-    m = bank.bind_mirror(states, last, since, tracking, lost, host_flags)
+    bank.bind_mirror(states, last, since, tracking, lost, host_flags)
     got = {ch: [] for ch in range(6)}
     for k in range(n_ticks + 3):
         # the write index as a receiver's would stand: far enough ahead for every channel's next epoch -- except in
         # tick 3, when nothing new has arrived and nobody has a complete epoch
         write = (int(states["current_sample"].max()) + int(states["n_samples"].max()) + 8) % n if k != 3 else int(states["current_sample"].max()) % n
-        bank.tick_mirrored(None, 0, write)
+        m = bank.tick_mirrored(None, 0, write)       # (the tick's own mirror: the per-tick outputs alternate between two sets)
         ran = bank.ran[:m.n_ran].tolist()
         if k == 3:
             assert ran == [] and m.n_updates == 5
@@ -495,8 +495,8 @@ def test_mirrored_tick_refuses_what_it_cannot_trust(engine):
         bank.bind_mirror(states[:3], last, since, tracking, lost, host_flags)         # rows != bank channels
     with pytest.raises(ValueError):
         bank.bind_mirror(states, last, since.astype(np.int32), tracking, lost, host_flags)
-    m = bank.bind_mirror(states, last, since, tracking, lost, host_flags)
-    bank.tick_mirrored(None, 0, 0)                            # nothing tracking: nothing runs, no update rows
+    bank.bind_mirror(states, last, since, tracking, lost, host_flags)
+    m = bank.tick_mirrored(None, 0, 0)                        # nothing tracking: nothing runs, no update rows
     assert (m.n_ran, m.n_updates, m.n_lost) == (0, 0, 0)
     with pytest.raises(SdrError, match="write index"):
         bank.tick_mirrored(None, 0, 80000)
@@ -513,7 +513,7 @@ def test_mirrored_tick_refuses_what_it_cannot_trust(engine):
     assert b"rows" in lib.sdr_last_error()
     # a tracking flag on a channel that was never put into the bank: it has no epoch to run, but reports its row
     tracking[2] = True
-    bank.tick_mirrored(None, 0, 100)
+    m = bank.tick_mirrored(None, 0, 100)
     assert (m.n_ran, m.n_updates) == (0, 1) and bank.updates["channel"][0] == 2
     # a slab queued without waiting is in the ring when the tick returns
     slab = np.arange(-100, 100, dtype=np.int8)
@@ -602,10 +602,10 @@ def test_mirrored_tick_parks_a_runaway_channel_alone(engine):
     last = np.zeros(3, dtype=TRACK_EPOCH_DTYPE)
     since, host_flags = np.zeros(3, dtype=np.int64), np.zeros(3, dtype=np.int64)
     tracking, lost = np.ones(3, dtype=bool), np.zeros(3, dtype=bool)
-    m = bank.bind_mirror(states, last, since, tracking, lost, host_flags)
+    bank.bind_mirror(states, last, since, tracking, lost, host_flags)
     for k in range(6):
         write = (int(states["current_sample"][[0, 2]].max()) + int(states["n_samples"].max()) + 8) % n
-        bank.tick_mirrored(None, 0, write)
+        m = bank.tick_mirrored(None, 0, write)
         assert bank.ran[:m.n_ran].tolist() == [0, 2] and m.n_updates == 3 and m.n_lost == (1 if k == 0 else 0)
         assert lost.tolist() == [False, True, False] and since.tolist() == [k + 1, 0, k + 1]
         assert bank.records[0].tobytes() == want[k].tobytes() == bank.records[1].tobytes()
@@ -811,6 +811,59 @@ def test_slabs_in_page_locked_memory_are_read_in_place_with_the_same_bits(engine
             assert a == b, k
     finally:
         engine.host_free(block)
+
+
+def test_packets_read_long_after_their_tick_are_the_ticks_own(engine):
+    """The tick's rows are views of arrays the device writes into alternately (two sets: `Bank.bind_mirror`,
+    `ChannelBank.hold`): a packet list read many ticks later -- when both sets have been rewritten many times -- still holds
+    its own tick's values, as does one read a tick later or at once."""
+    import configparser
+    import os
+    from conftest import REPO
+    from sydr_amd.channel.l1ca_kaplan import ChannelL1CA_Kaplan
+    from sydr_amd.channel.manager import ChannelManager
+    from sydr_amd.signal.iqsource import RFSignal
+    fs, n_ms = 10e6, 160
+    spms = int(fs * 1e-3)
+    rng = np.random.default_rng(4242)
+    sats = [dict(prn=1 + c, doppler=float(250.0 * rng.integers(-15, 16) + rng.uniform(-40, 40)),
+                 code_phase=float(rng.uniform(0, 1023)), phase=float(rng.uniform(0, 1)), amp=5.0) for c in range(12)]
+    total = n_ms * spms
+    engine.iq_alloc(total, FMT_CI8)
+    engine.code_slots(32)
+    engine.iq_synth(sats, fs, 10.0, 4243, 0, total)
+    raw = engine.iq_download(total, 0)
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(REPO, "examples", "channel_GPS_L1CA_kaplan.ini"))
+
+    def receiver(read):
+        rf = RFSignal(dict(filepath="none", sampling_frequency=fs, is_complex="true", intermediate_frequency=0.0, data_size=8))
+        mgr = ChannelManager(rf, engine=engine, keepCorrelationMap=False)
+        mgr.addChannel(ChannelL1CA_Kaplan, cfg, 12)
+        for s in sats:
+            mgr.requestTracking(s["prn"])
+        kept, out = [], []
+        try:
+            for k in range(n_ms):
+                mgr.addNewRFData(raw[2 * k * spms:2 * (k + 1) * spms])
+                pk = mgr.run()
+                if read == "at once":
+                    out.append([dict(q) for q in pk])
+                elif read == "a tick later":
+                    if kept:
+                        out.append([dict(q) for q in kept.pop()])
+                    kept.append(pk)
+                else:
+                    kept.append(pk)
+            out.extend([dict(q) for q in t] for t in kept)
+        finally:
+            mgr.close()
+        return out
+
+    at_once = receiver("at once")
+    assert len(at_once) == n_ms and sum(len(t) for t in at_once) > 12 * 100
+    for mode in ("a tick later", "at the end"):
+        assert receiver(mode) == at_once, mode
 
 
 def test_bind_thread_to_device_restricts_the_calling_thread_and_gives_the_mask_back(engine):
