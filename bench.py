@@ -585,6 +585,41 @@ def per_tick_leg(eng, read_ahead=0, tick_server=False):
     return per_tick_rate.measure(600 if read_ahead or tick_server else 300, N_CH, engine=eng, read_ahead=read_ahead, tick_server=tick_server)
 
 
+def per_tick_c_leg(ticks=800):
+    """The same per-millisecond loop from plain C (examples/receiver_loop.c: sdr_iq_upload_begin + sdr_bank_tick_mirrored per
+    tick, 32 channels @ 25 MHz, the host as IQ source), built with the box's gcc against the header alone and run as child
+    processes of its own engine: plain ticks, and plain ticks with the recording in page-locked memory (slabs read in place).
+    What the C-ABI delivers without the interpreter's share of a tick.  (The resident tick server is NOT timed here: its
+    kernels hold the whole device, and as the child of a process that keeps a HIP context of its own -- this one: torch's --
+    they are time-sliced against that context's idle queues: 37-54 us per tick where the same program started from a shell
+    takes 21-22.  The Python `per_tick_server` leg, in this process, is the server's figure.)"""
+    import re
+    import subprocess
+    import tempfile
+    out = {"ticks": ticks, "source": "examples/receiver_loop.c"}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "receiver_loop")
+        lib_dir = os.path.join(REPO, "sydr_amd")
+        build = subprocess.run(["gcc", "-std=c99", "-O2", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "examples", "receiver_loop.c"),
+                                "-L", lib_dir, "-lsydr_amd", "-lm", "-Wl,-rpath," + lib_dir, "-o", exe], capture_output=True, text=True)
+        if build.returncode:
+            return {"error": "gcc: " + build.stderr[-300:]}
+        for key, extra in (("plain", []), ("plain_pinned_source", ["pinned"])):
+            try:
+                run = subprocess.run([exe, str(ticks)] + extra, capture_output=True, text=True, timeout=120)
+            except subprocess.TimeoutExpired:
+                out[key] = {"error": "timed out"}
+                continue
+            m = re.search(r"([0-9.]+) us per tick = ([0-9.]+) x real time", run.stdout)
+            locked = re.search(r"(\d+) of 32 channels on their Doppler", run.stdout)
+            if not m:
+                out[key] = {"error": (run.stdout + run.stderr)[-300:]}
+                continue
+            out[key] = {"us_per_tick": float(m.group(1)), "x_realtime": float(m.group(2)),
+                        "channels_on_their_doppler": int(locked.group(1)) if locked else None}
+    return out
+
+
 def closed_loop_leg(eng, items, n_epochs, n_ch=N_CH, fs=None):
     """On-device loop closure (persistent workgroups, Kaplan loops): latency-bound, so it is reported beside,
     not instead of, the open-loop correlator throughput.  n_ch = 32: each channel on a cluster of 8 CUs (lowest
@@ -914,6 +949,8 @@ def flat_scalars(result):
                 "per_tick_x_realtime": get("per_tick", "x_realtime"),
                 "per_tick_server_x_realtime": get("per_tick_server", "x_realtime"),
                 "per_tick_readahead_x_realtime": get("per_tick_readahead", "x_realtime"),
+                "per_tick_c_x_realtime": get("per_tick_c", "plain", "x_realtime"),
+                "per_tick_c_pinned_x_realtime": get("per_tick_c", "plain_pinned_source", "x_realtime"),
                 "ref_config_tracking_frac": get("ref_config", "tracking", "roofline", "frac"),
                 "ref_config_acq_frac": get("ref_config", "acquisition", "roofline", "frac"),
                 "multignss_frac": get("multignss", "roofline", "frac"),
@@ -1286,6 +1323,10 @@ def main():
         result["ref_config"] = ref_config_leg(eng)
         leg_done()
     eng.close()
+    if rank == 0 and world == 1 and not args.no_per_tick:
+        # (child processes with an engine of their own: run while this process has none)
+        result["per_tick_c"] = per_tick_c_leg()
+        leg_done()
     if rank == 0 and world == 1 and not args.no_multignss:
         margs = argparse.Namespace(**vars(args))
         # (a fresh engine after seconds of CPU legs: ~40 ms of this kernel before the clocks have settled, tools/epl_ramp.py)
