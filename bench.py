@@ -597,11 +597,20 @@ def per_tick_c_leg(ticks=800):
     import subprocess
     import tempfile
     out = {"ticks": ticks, "source": "examples/receiver_loop.c"}
+    # (an optional leg never costs the line: under a profiler's preloaded library -- gcc is a driver that re-execs, and the
+    # child's kernels would land in the same output directory -- it is skipped; no compiler, or a child that cannot start,
+    # is an "error" entry)
+    if os.environ.get("LD_PRELOAD") or any(k.startswith(("ROCP", "ROCPROFILER")) for k in os.environ):
+        return {"skipped": "under a profiler (LD_PRELOAD / ROCP* set): no child processes"}
     with tempfile.TemporaryDirectory() as tmp:
         exe = os.path.join(tmp, "receiver_loop")
         lib_dir = os.path.join(REPO, "sydr_amd")
-        build = subprocess.run(["gcc", "-std=c99", "-O2", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "examples", "receiver_loop.c"),
-                                "-L", lib_dir, "-lsydr_amd", "-lm", "-Wl,-rpath," + lib_dir, "-o", exe], capture_output=True, text=True)
+        try:
+            build = subprocess.run(["gcc", "-std=c99", "-O2", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "examples", "receiver_loop.c"),
+                                    "-L", lib_dir, "-lsydr_amd", "-lm", "-Wl,-rpath," + lib_dir, "-o", exe], capture_output=True, text=True,
+                                   timeout=120)
+        except (OSError, subprocess.SubprocessError) as exc:
+            return {"error": f"gcc: {exc!r}"[:300]}
         if build.returncode:
             return {"error": "gcc: " + build.stderr[-300:]}
         for key, extra in (("plain", []), ("plain_pinned_source", ["pinned"])):
@@ -609,6 +618,9 @@ def per_tick_c_leg(ticks=800):
                 run = subprocess.run([exe, str(ticks)] + extra, capture_output=True, text=True, timeout=120)
             except subprocess.TimeoutExpired:
                 out[key] = {"error": "timed out"}
+                continue
+            except (OSError, subprocess.SubprocessError) as exc:
+                out[key] = {"error": repr(exc)[:300]}
                 continue
             m = re.search(r"([0-9.]+) us per tick = ([0-9.]+) x real time", run.stdout)
             locked = re.search(r"(\d+) of 32 channels on their Doppler", run.stdout)
@@ -1002,6 +1014,7 @@ def main():
     ap.add_argument("--no-acquisition", action="store_true")
     ap.add_argument("--no-closed-loop", action="store_true")
     ap.add_argument("--no-per-tick", action="store_true")
+    ap.add_argument("--no-per-tick-c", action="store_true", help="skip the leg that builds and runs examples/receiver_loop.c as child processes")
     ap.add_argument("--no-multignss", action="store_true")
     ap.add_argument("--no-ref-config", action="store_true")
     ap.add_argument("--no-rates", action="store_true", help="skip the E/P/L leg over the other sampling rates")
@@ -1287,7 +1300,17 @@ def main():
         if args.cpu_mp_seconds > 0:
             hi_ms = min(n_epochs, 700)
             raw = eng.iq_download(int((items["start_sample"][:hi_ms * N_CH] + items["n_samples"][:hi_ms * N_CH]).max()), 0)
-            mval, procs, mdt, mep = cpu_baseline_all_cores(raw, items, [s["prn"] for s in sats], hi_ms, args.cpu_mp_seconds)
+            # (the pool's workers inherit this thread's CPU mask: the host's whole mask for them, the GPU's CPUs again afterwards)
+            if host_thread_bound:
+                eng.set_option("bind_thread_to_device", 0)
+            try:
+                mval, procs, mdt, mep = cpu_baseline_all_cores(raw, items, [s["prn"] for s in sats], hi_ms, args.cpu_mp_seconds)
+            finally:
+                if host_thread_bound:
+                    try:
+                        eng.set_option("bind_thread_to_device", 1)
+                    except Exception:
+                        host_thread_bound = False
             result["cpu_baseline_mp"] = {"value": mval, "unit": "Msamples/s", "cores": procs, "host_cpus": os.cpu_count(),
                                          "kind": "port",
                                          "sample": (f"{mep} ms x 32 ch of the same stream, one oracle process per channel "
@@ -1323,9 +1346,12 @@ def main():
         result["ref_config"] = ref_config_leg(eng)
         leg_done()
     eng.close()
-    if rank == 0 and world == 1 and not args.no_per_tick:
+    if rank == 0 and world == 1 and not args.no_per_tick and not args.no_per_tick_c:
         # (child processes with an engine of their own: run while this process has none)
-        result["per_tick_c"] = per_tick_c_leg()
+        try:
+            result["per_tick_c"] = per_tick_c_leg()
+        except Exception as exc:                            # (belt and braces: the line is already measured)
+            result["per_tick_c"] = {"error": repr(exc)[:300]}
         leg_done()
     if rank == 0 and world == 1 and not args.no_multignss:
         margs = argparse.Namespace(**vars(args))

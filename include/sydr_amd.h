@@ -32,6 +32,13 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: what this header declares -- and nothing else -- is in its dynamic
+ * symbol table (sydr/c_functions/Makefile:1-12: one .so, only the bound symbols matter); tests/test_abi.py holds
+ * `nm -D --defined-only` against these declarations. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define SDR_ABI_VERSION 5   /* 5: + sdr_bank_tick_mirrored_begin / _end, sdr_iq_upload_queue, sdr_host_alloc / _free, options "tick_server" + sdr_tick_server_stats, "bind_thread_to_device" (additive); 4: + sdr_build_id, sdr_epl_plan_create_dev, sdr_bank_tick_mirrored, sdr_iq_upload_begin, sdr_block_schedule, sdr_bank_step_begin / _end (additive) */
 
 typedef struct sdr_engine sdr_engine;
@@ -509,6 +516,10 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
  * + 65536 when the plan runs on the half-chip view of its replicas (32-52 samples per chip: every chip twice).  The
  * results do not depend on it beyond the tolerance of the free arithmetic. */
 int sdr_epl_plan_variant(const sdr_epl_plan* p);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

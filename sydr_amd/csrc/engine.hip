@@ -207,7 +207,9 @@ int sdr_iq_flipped(sdr_engine* e, hipStream_t stream, const void** out) {
 // is a few round trips over the link through page-locked words: from the other socket each of them crosses the sockets'
 // interconnect as well -- measured on a two-socket host, examples/receiver_loop.c with the resident tick server: 21.0-21.6 us per
 // tick from the GPU's own node, 26.3-27.5 from the other.  Page-locked memory the engine allocates afterwards lands on that
-// node too (first touch by this thread).  value = 0 restores the mask the thread had.
+// node too (first touch by this thread).  value = 0 restores the mask the thread had.  The option is a property of the calling
+// THREAD (one saved mask per thread, whichever engine it was set through); processes the thread starts afterwards inherit
+// the narrowed mask.
 static int bind_thread_to_device(sdr_engine* e, int value) {
     static thread_local cpu_set_t saved;
     static thread_local bool have_saved = false;
@@ -230,6 +232,9 @@ static int bind_thread_to_device(sdr_engine* e, int value) {
     cpu_set_t now, want;
     CPU_ZERO(&want);
     if (sched_getaffinity(0, sizeof(now), &now) != 0) return sdr_fail(SDR_ERR_UNSUPPORTED, "sched_getaffinity: %s", strerror(errno));
+    // (per THREAD, not per engine: a thread that drives several engines and binds to a second GPU is moved from the mask it
+    // had before the first binding, not from the first GPU's CPUs -- those of another socket would leave nothing)
+    if (have_saved) now = saved;
     int n = 0;
     for (char* p = list; got && *p && *p != '\n';) {            // "0-63,128-191"
         char* end = nullptr;
@@ -268,6 +273,9 @@ int sdr_set_option(sdr_engine* e, const char* name, int value) {
     else if (!strcmp(name, "ingest_with_tick")) e->ingest_with_tick = value != 0;
     else if (!strcmp(name, "pcps_no_shared_spectra")) e->pcps_no_shared_spectra = value != 0;
     else if (!strcmp(name, "tick_server")) {
+        // (stopping a server may queue its unpulled slab on this engine's stream: with several engines in one process the
+        // current device may be another engine's)
+        if (int rc = sdr_set_device_keep(e)) return rc;
         if (e->srv_running) (void)sdr_tick_server_stop(e);
         e->tick_server_opt = value != 0;
     }
@@ -593,6 +601,11 @@ int sdr_iq_flush_server_slab(sdr_engine* e) {
         if (!e->slab_done[half]) SDR_HIP(hipEventCreateWithFlags(&e->slab_done[half], hipEventDisableTiming));
         SDR_HIP(hipEventRecord(e->slab_done[half], e->stream));
         e->slab_busy[half] = true;
+    } else {
+        // the caller's own page-locked block, read in place: the header promises it back when the next tick has returned, and
+        // a tick in which no channel is ready ends without a synchronisation of its own -- sdr_bank_tick_mirrored_end waits
+        // for this flag's kernel (tick_end_wait_inplace_slab)
+        e->inplace_slab_in_flight = true;
     }
     return SDR_OK;
 }
@@ -631,6 +644,7 @@ int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_
             const unsigned blocks = (unsigned)((n16 + 255) / 256 < 64 ? (n16 + 255) / 256 : 64);
             hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)iq, (uint4*)e->iq, n16, off_b / 16, cap_b / 16);
             SDR_HIP(hipGetLastError());
+            e->inplace_slab_in_flight = true;      // (sdr_bank_tick_mirrored_end waits for it where nothing else would)
             return SDR_OK;
         }
     }

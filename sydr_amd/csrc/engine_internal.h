@@ -141,6 +141,7 @@ struct sdr_engine {
     bool srv_running = false;
     int srv_steady_ticks = 0;     // steady ticks in a row with no other call on the engine in between (a server starts at 8)
     struct TickServerState* srv = nullptr;
+    bool inplace_slab_in_flight = false; // an ingest kernel on `stream` may still be reading a slab out of the CALLER's page-locked block
     bool srv_slab_pending = false;       // ... or, without a server, for the tick's own launch (ingest_with_tick): whoever needs the ring
                                          // first flushes it the ordinary way (sdr_set_device, the tick itself)
     bool ingest_with_tick = true;        // "ingest_with_tick": a receiver tick's slab is pulled into the ring by workgroups of the tick's

@@ -32,7 +32,7 @@
 #ifdef SDR_TRACE_WG
 // Debug build only (tools/wg_trace.py): per-workgroup start/end clock and hardware id.
 __device__ unsigned long long g_wg_trace[3 * 65536];
-extern "C" int sdr_debug_read_trace(unsigned long long* dst, int n) {
+extern "C" __attribute__((visibility("default"))) int sdr_debug_read_trace(unsigned long long* dst, int n) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wg_trace), (size_t)n * 3 * sizeof(unsigned long long));
 }
 #endif

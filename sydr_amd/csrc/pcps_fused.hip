@@ -162,7 +162,7 @@ int sdr_pcps_fused10k_search(sdr_engine* e, const void* F_all, const void* spec_
 }
 
 #ifdef SDR_FUSED_STAMPS
-extern "C" int sdr_debug_fused_stamps(unsigned long long* out, int reset) {
+extern "C" __attribute__((visibility("default"))) int sdr_debug_fused_stamps(unsigned long long* out, int reset) {
     if (out) SDR_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(fused25k::g_fused_stamps), sizeof(unsigned long long) * 256 * 8));
     if (reset) {
         static unsigned long long zeros[256 * 8];

@@ -28,7 +28,7 @@
 #ifdef SDR_TRACE_TRACK
 // Debug build only (tools/track_phases.py): per-phase clock totals of channel 0's epoch loop.
 __device__ unsigned long long g_track_phase[64];   // [0,8) phases, [8,40) per-wave arrival (8 parts x 4 waves), [48,52) per-role, [62,64) clocks
-extern "C" int sdr_debug_track_phases(unsigned long long* dst) {
+extern "C" __attribute__((visibility("default"))) int sdr_debug_track_phases(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_track_phase), sizeof(g_track_phase));
 }
 #define TRACK_MARK(k)                                                     \
@@ -2616,8 +2616,11 @@ int sdr_bank_tick_mirrored_end(sdr_engine* e, sdr_bank* b, sdr_tick_mirror* m) {
         }
 #endif
     } else if (list.empty()) {
-        if (b->tick_slab_queued) SDR_HIP(hipStreamSynchronize(e->ctx0.stream));
+        // (no channel ready: nothing of this tick waits for the stream -- but a slab queued with the tick, or one read IN PLACE
+        // out of the caller's page-locked block by an ingest kernel, must be in the ring before the caller has its buffer back)
+        if (b->tick_slab_queued || e->inplace_slab_in_flight) SDR_HIP(hipStreamSynchronize(e->ctx0.stream));
     }
+    e->inplace_slab_in_flight = false;   // (ready channels: their kernel ran behind the ingest kernel on the same stream)
     if (!list.empty()) {
         int n = (int)list.size();
         int at = 0;

@@ -30,16 +30,30 @@ os.environ.setdefault("MPLBACKEND", "Agg")
 _gt = types.ModuleType("gps_time")
 
 
-class _GPSTime:  # minimal stand-in so `import gps_time` succeeds; never exercised on this path
+class _GPSTime:
+    """Stand-in so that `from gps_time import GPSTime` (sydr/utils/time.py:4) succeeds.  The reference constructs one at IMPORT
+    time (sydr/space/ephemeris.py:50 evaluates `Time()` in a class body -> GPSTime.from_datetime), so construction must work;
+    but the object is poison: reading ANY attribute of it (week_number, time_of_week, ...) raises, and so does any other
+    attribute of the module -- a fixture that was produced is thereby proven not to contain a value that came from here."""
+
     def __init__(self, *a, **k):
-        self.week_number = 0
-        self.time_of_week = 0.0
+        pass
 
     @classmethod
     def from_datetime(cls, _dt):
         return cls()
 
+    def __getattr__(self, name):
+        raise RuntimeError(f"gps_time stand-in used: GPSTime().{name}")
 
+
+def _gt_getattr(name):
+    if name.startswith("__"):                   # (the import machinery's own probes: __path__, __spec__, ...)
+        raise AttributeError(name)
+    raise RuntimeError(f"gps_time stand-in used: gps_time.{name}")
+
+
+_gt.__getattr__ = _gt_getattr
 _gt.GPSTime = _GPSTime
 sys.modules.setdefault("gps_time", _gt)
 
@@ -58,11 +72,11 @@ META = dict(numpy_version=np.__version__, reference="aproposorg/sydr@/root/refer
 
 
 STAND_INS = np.array(["gps_time: third-party calendar module the reference imports (sydr/utils/time.py:4), absent from this "
-                      "image; replaced by a stub so that the import succeeds -- never called on this path"])
+                      "image; replaced by a stub so that the import succeeds -- reading any attribute of a stub object RAISES (only its import-time construction is allowed), so no value in these fixtures came from it"])
 
 
 def save(name, **arrays):
-    path = os.path.join(HERE, name)
+    path = os.path.join(os.environ.get("SYDR_GOLDEN_OUT", HERE), name)     # (SYDR_GOLDEN_OUT: regenerate beside, to compare)
     arrays.setdefault("stand_ins", STAND_INS)     # what was NOT the reference's own code when this file was produced
     np.savez_compressed(path, numpy_version=np.array(np.__version__), **arrays)
     print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")

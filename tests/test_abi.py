@@ -31,6 +31,16 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.exported_symbols()) == names
 
 
+def test_dynamic_symbol_table_is_the_header():
+    """`nm -D --defined-only`: the header's functions, all of type T, and nothing else (no C++-mangled internals, no kernel
+    handles) -- sydr/c_functions/Makefile:1-12's convention of one .so whose bound symbols are its whole surface."""
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    table = [line.split() for line in out.splitlines() if line.strip()]
+    exported = sorted(t[-1] for t in table)
+    assert exported == declared_symbols(), sorted(set(exported) ^ set(declared_symbols()))
+    assert {t[-2] for t in table} == {"T"}, sorted({t[-2] for t in table})
+
+
 def test_only_gfx950_code_objects():
     out = subprocess.run(["strings", "-a", _lib.LIB_PATH], capture_output=True, text=True).stdout
     targets = set(re.findall(r"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", out))

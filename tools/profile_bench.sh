@@ -11,7 +11,8 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # the driver's command with short CPU legs and WITHOUT the process-per-channel CPU baseline: its 32 spawned workers each start
 # under the profiler's preloaded library, and one run of the round hung in their shutdown (the untraced run of profile_round.sh keeps it)
-ARGS="--steps 20 --warmup 5 --cpu-seconds 2 --cpu-mp-seconds 0"
+# (no C per-tick leg under the profiler: gcc re-execs, and a traced child writes a second stats file; bench.py also skips the leg by itself when LD_PRELOAD / ROCP* is set)
+ARGS="--steps 20 --warmup 5 --cpu-seconds 2 --cpu-mp-seconds 0 --no-per-tick-c"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_stats.log" 2>&1
 PARGS="--steps 2 --warmup 1 --stream-seconds 6 --cpu-seconds 0.2 --cpu-mp-seconds 0 --no-closed-loop --no-per-tick --no-rates"   # (the ref_config and multignss legs run: their kernels get counters too)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" $PARGS > "$OUT/bench_pmc_fetch.log" 2>&1

@@ -180,7 +180,8 @@ prof = os.path.join(repo, "profiles")
 for pattern, name in (("stats/*/*kernel_stats.csv", f"{tag}_bench_kernel_stats.csv"),
                       ("pcps_one_stream/*/*kernel_stats.csv", f"{tag}_pcps_one_stream_kernel_stats.csv"),
                       ("pcps_one_stream_50/*/*kernel_stats.csv", f"{tag}_pcps50_one_stream_kernel_stats.csv")):
-    hits = glob.glob(os.path.join(src, pattern))
+    # (a traced child process writes a stats file of its own into the same directory: the bench's is the largest)
+    hits = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getsize, reverse=True)
     if hits:
         shutil.copyfile(hits[0], os.path.join(prof, name))
 for fname, name in (("bench.json", f"{tag}_bench.json"), ("bench_plain_run.json", f"{tag}_bench_plain_run.json")):
