@@ -398,6 +398,8 @@ void sdr_engine_destroy(sdr_engine* e) {
                       &e->pcps_blu,  &e->pcps_blu_x, &e->pcps_blu_a, &e->pcps_blu_b, &e->pcps_work, &e->pcps_theta};
     for (DevBuf* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
+    for (DevBuf& b : e->plan_pool)
+        if (b.ptr) (void)hipFree(b.ptr);
     if (e->slab_pinned) (void)hipHostFree(e->slab_pinned);
     for (int h = 0; h < 2; ++h)
         if (e->slab_done[h]) (void)hipEventDestroy(e->slab_done[h]);
@@ -490,6 +492,9 @@ int sdr_iq_alloc(sdr_engine* e, int64_t capacity_samples, int fmt) {
         return sdr_fail(SDR_ERR_INVALID, "ring capacity %lld must be a positive multiple of 8 samples",
                         (long long)capacity_samples);
     SDR_HIP(hipStreamSynchronize(e->stream));
+    for (DevBuf& b : e->plan_pool)      // (plans of the old ring are stale: what they left behind makes room for the new one)
+        if (b.ptr) (void)hipFree(b.ptr);
+    e->plan_pool.clear();
     if (e->iq) {
         SDR_HIP(hipFree(e->iq));
         e->iq = nullptr;

@@ -94,6 +94,10 @@ struct sdr_engine {
 
     // workspaces
     DevBuf ws_items, ws_out, ws_spacing, ws_setups, ws_stats;
+    // Device buffers of destroyed E/P/L plans, kept for the next plan (epl.hip plan_take / plan_give): a stream correlated
+    // segment by segment makes and drops a plan per segment, and hipMalloc / hipFree cost more than the segment's setups --
+    // hipFree also waits for the whole device, i.e. for the segment still running on another stream.
+    std::vector<DevBuf> plan_pool;
     DevBuf pcps_fwd, pcps_a, pcps_b, pcps_code, pcps_tw, pcps_map, pcps_csum, pcps_part, pcps_res;
     DevBuf pcps_code2;            // N = 50 000, fused search: [prn][parity][N] -- the spectra and their image with the odd half's twiddle (pcps_fused.h)
     bool pcps_code2_ok = false;   // ... made from what pcps_code holds now

@@ -232,6 +232,7 @@ struct sdr_epl_plan {
     double* d_spacing = nullptr;
     char* d_setups = nullptr;   // straight-line kernels: one ChipSetup<n_taps> / ChipNSetup per item (correlator_chip.h, correlator_chip2.h)
     size_t setup_bytes = 0;     // sizeof(ChipSetup<n_taps>), 0: none
+    size_t bytes_items = 0, bytes_out = 0, bytes_spacing = 0, bytes_setups = 0;   // what the four allocations hold (plan_give)
     int n_items = 0;
     int n_taps = 0;
     int lut_words = 0;
@@ -482,6 +483,41 @@ __global__ __launch_bounds__(256) void double_items_kernel(sdr_epl_item* __restr
     items[i].code_step *= 2.0;
 }
 
+// Device memory for a plan: a buffer a destroyed plan left in the engine's pool if one fits (not more than twice the size:
+// a 60 s plan's 0.9 GB of setups never serve a one-second plan), else a fresh allocation.  plan_give: back into the pool --
+// eight buffers at most, the smallest makes room -- instead of hipFree, which waits for every stream of the device.
+static hipError_t plan_take(sdr_engine* e, void** out, size_t bytes, size_t* got) {
+    int best = -1;
+    for (int i = 0; i < (int)e->plan_pool.size(); ++i) {
+        const size_t b = e->plan_pool[(size_t)i].bytes;
+        if (b >= bytes && b <= 2 * bytes + 4096 && (best < 0 || b < e->plan_pool[(size_t)best].bytes)) best = i;
+    }
+    if (best >= 0) {
+        *out = e->plan_pool[(size_t)best].ptr;
+        *got = e->plan_pool[(size_t)best].bytes;
+        e->plan_pool.erase(e->plan_pool.begin() + best);
+        return hipSuccess;
+    }
+    *got = bytes;
+    return hipMalloc(out, bytes);
+}
+
+static void plan_give(sdr_engine* e, void* ptr, size_t bytes) {
+    if (!ptr) return;
+    if (!e || bytes == 0) {
+        (void)hipFree(ptr);
+        return;
+    }
+    e->plan_pool.push_back(DevBuf{ptr, bytes});
+    if (e->plan_pool.size() > 8) {
+        size_t small = 0;
+        for (size_t i = 1; i < e->plan_pool.size(); ++i)
+            if (e->plan_pool[i].bytes < e->plan_pool[small].bytes) small = i;
+        (void)hipFree(e->plan_pool[small].ptr);
+        e->plan_pool.erase(e->plan_pool.begin() + (long)small);
+    }
+}
+
 extern "C" {
 
 static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_epl_item* d_src, int n_items, const double* spacing,
@@ -565,9 +601,9 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
         p->d_out = (double*)e->ws_out.ptr;
         p->d_spacing = (double*)e->ws_spacing.ptr;
     } else {
-        err = hipMalloc(&p->d_items, (size_t)n_items * sizeof(sdr_epl_item));
-        if (err == hipSuccess) err = hipMalloc(&p->d_out, (size_t)n_items * 2 * n_taps * sizeof(double));
-        if (err == hipSuccess) err = hipMalloc(&p->d_spacing, SDR_MAX_TAPS * sizeof(double));
+        err = plan_take(e, (void**)&p->d_items, (size_t)n_items * sizeof(sdr_epl_item), &p->bytes_items);
+        if (err == hipSuccess) err = plan_take(e, (void**)&p->d_out, (size_t)n_items * 2 * n_taps * sizeof(double), &p->bytes_out);
+        if (err == hipSuccess) err = plan_take(e, (void**)&p->d_spacing, SDR_MAX_TAPS * sizeof(double), &p->bytes_spacing);
     }
     const double t_alloc = now();
     if (err == hipSuccess)
@@ -627,7 +663,7 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
             if (sdr_devbuf_reserve(e, &e->ws_setups, bytes + 64) != SDR_OK) err = hipErrorOutOfMemory;
             else p->d_setups = (char*)e->ws_setups.ptr;
         } else {
-            err = hipMalloc(&p->d_setups, bytes + 64);     // (+ the counter of items a scheme does not cover)
+            err = plan_take(e, (void**)&p->d_setups, bytes + 64, &p->bytes_setups);     // (+ the counter of items a scheme does not cover)
         }
     };
     const unsigned setup_grid = (unsigned)((n_items + 255) / 256);
@@ -746,7 +782,7 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
             if (err == hipSuccess && missed <= n_items / 64) {
                 p->wide = wide = (wide & 255) + kVariantC2 * shape;
             } else if (err == hipSuccess) {                 // too many strays: the boundary variant serves the list
-                if (!use_workspaces && p->d_setups) (void)hipFree(p->d_setups);
+                if (!use_workspaces && p->d_setups) plan_give(e, p->d_setups, p->bytes_setups);
                 p->d_setups = nullptr;
                 p->setup_bytes = 0;
             }
@@ -855,11 +891,11 @@ void sdr_epl_plan_destroy(sdr_engine* e, sdr_epl_plan* p) {
         (void)hipEventSynchronize(se.second);
         (void)hipEventDestroy(se.second);
     }
-    if (!p->borrowed) {
-        if (p->d_items) (void)hipFree(p->d_items);
-        if (p->d_out) (void)hipFree(p->d_out);
-        if (p->d_spacing) (void)hipFree(p->d_spacing);
-        if (p->d_setups) (void)hipFree(p->d_setups);
+    if (!p->borrowed) {     // (every stream the plan ran on has been waited for: the buffers are free to serve the next plan)
+        plan_give(e, p->d_items, p->bytes_items);
+        plan_give(e, p->d_out, p->bytes_out);
+        plan_give(e, p->d_spacing, p->bytes_spacing);
+        plan_give(e, p->d_setups, p->bytes_setups);
     }
     delete p;
 }

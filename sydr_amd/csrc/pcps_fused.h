@@ -41,18 +41,13 @@
 
 // Build-time switches of the A/B variants (tools/build_variant.sh <tag> pcps_fused -DFUSED_...=0|1); measured on one
 // box, 32 PRNs x 41 bins, ms per call: all off 0.266; buffer loads 0.267; merged Y step 0.291; twiddles a round ahead
-// 0.273; reads first 0.267 (gpurun_out/r04_fused_var9.txt) -- the defaults are the fastest
+// 0.273; reads first 0.267 (gpurun_out/r04_fused_var9.txt) -- the defaults are the fastest (the last two switches went
+// with round 6's lane roles)
 #ifndef FUSED_BUFLOAD
 #define FUSED_BUFLOAD 0      // operand loads as buffer loads (scalar descriptor + one per-lane offset) instead of 64-bit addresses
 #endif
 #ifndef FUSED_MERGE_Y
 #define FUSED_MERGE_Y 0      // the next round's Y-in-place step inside this round's second row stage (3 barriers per round, not 4)
-#endif
-#ifndef FUSED_TW_AHEAD
-#define FUSED_TW_AHEAD 0     // the row's two four-step twiddle reads requested a round ahead
-#endif
-#ifndef FUSED_READS_FIRST
-#define FUSED_READS_FIRST 0  // row stage 1: LDS reads in front of the parked round's stores
 #endif
 
 namespace fused25k {
@@ -202,15 +197,51 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     const bool live = t_ < 500;
     const int r = live ? t_ / 100 : 0, c = live ? t_ - 100 * r : 0;
     const int cb = r * N2 + c;                          // its slot in a buffer row group
-    // row stage 1: thread (row i, e) of 25 x 20
-    const int ri = live ? t_ / 20 : 0, re = live ? t_ - 20 * ri : 0;
-    const int k1b = 5 * (ri / 5) + 25 * (ri % 5);       // its row's k1 = rho + k1b
-    // row stage 2: waves 0-3 take the even outputs (h = 0), waves 4-7 the odd ones: thread (row, k'') of 25 x 10
+    // Row stages: WHO reads WHAT is laid out for the LDS banks (round 6; tools/lds_conflicts_fused.py is the bank model, exact
+    // against SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT: with threads numbered row-major -- 20, then 10 per row -- 38 % of
+    // the kernel's LDS cycles were conflict cycles, 12.2 k of 32 k per transform).  A ds_read_b128 is served in four
+    // groups of sixteen lanes, {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32, conflict-free when the sixteen
+    // 16-byte elements differ modulo 16; a ds_write_b128 in eight groups of eight contiguous lanes, modulo 8.
+    // (gq, gi): this lane's read group within the wave and its place in it.
+    const int l5 = t_ & 31;
+    const int gq = 2 * ((t_ >> 5) & 1) + ((l5 >= 4 && l5 < 12) || (l5 >= 16 && l5 < 20) || l5 >= 28 ? 1 : 0);
+    const int gi = l5 < 4 ? l5 : (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : (l5 < 28 ? l5 - 12 : l5 - 16)));
+    // row stage 1: thread (row i, e) of 25 x 20.  Read groups 0-24 of the workgroup: e = 0..15 of ONE row (sixteen
+    // consecutive elements); groups 25-31: e = 16..19 of four rows each.  The two groups of a 32-lane half hold rows
+    // whose exchange swizzles differ in bit 0 (below): their lanes share the write groups.
+    const int g1 = 4 * (t_ >> 6) + gq;
+    int role1, role2;      // (row, e | k'', swizzle) packed, < 0: the lane has no part in that stage -- unpacked where a round
+                           // needs them (kept apart the seven values live through the column stage and spill)
+    {
+        int ri, re;
+        bool live1 = true;
+        if (g1 <= 24) {
+            const int n = g1 >> 1;
+            ri = 4 * (n >> 1) + (n & 1) + 2 * (g1 & 1);
+            re = gi;
+        } else {
+            const int u = g1 - 25, q = gi >> 2;
+            ri = 8 * (u >> 1) + ((u & 1) ? 0 : 2) + (q & 1) + 4 * (q >> 1);
+            re = 16 + (gi & 3);
+            if (g1 == 31) ri = 24, live1 = q == 0;
+        }
+        // The exchange between the row stages goes through the row IN PLACE, element (e, k'') at (10 e + k'') ^ swz(row),
+        // swz(row) = 2 ((row >> 1) & 3) + ((row >> 1) & 1): the low three bits of the place only (200 = 25 x 8: closed).
+        auto swz = [](int row) { return 2 * ((row >> 1) & 3) + ((row >> 1) & 1); };
+        // (with what a round derives from them: k1b -- the row's k1 = rho + k1b -- and the first output index of stage 2)
+        role1 = live1 ? (ri | re << 5 | swz(ri) << 10 | (5 * (ri / 5) + 25 * (ri % 5)) << 13) : -1;
+        // row stage 2: waves 0-3 take the even outputs (h = 0), waves 4-7 the odd ones: thread (row, k'') of 25 x 10.  Read
+        // groups 0-11 of a half: k'' = 0..7 of rows 2g, 2g + 1 (same swizzle, bases 8 elements apart modulo 16); 12-14:
+        // k'' = 8, 9 of eight rows (eight different (row parity, swizzle >> 1)); 15: row 24.
+        const int g2 = 4 * ((t_ >> 6) & 3) + gq;
+        int si, sk;
+        bool live2 = true;
+        if (g2 < 12) si = 2 * g2 + (gi >> 3), sk = gi & 7;
+        else if (g2 < 15) si = 8 * (g2 - 12) + (gi >> 1), sk = 8 + (gi & 1);
+        else si = 24, sk = gi, live2 = gi < 10;
+        role2 = live2 ? (si | sk << 5 | swz(si) << 10 | (5 * (si / 5) + 25 * (si % 5) + N1 * (sk + 10 * (tid >> 8))) << 13) : -1;
+    }
     const int h = tid >> 8;
-    const int t2 = t_ & 255;
-    const bool live2 = t2 < 250;
-    const int si = live2 ? t2 / 10 : 0, sk = live2 ? t2 - 10 * si : 0;
-    const int kf0 = 5 * (si / 5) + 25 * (si % 5) + N1 * (sk + 10 * h);
 
     if (tid < 97) tab[tid] = twi((N / 125) * tid);
     __syncthreads();   // the table; and every reader of the previous transform's last rounds is done with the buffers
@@ -375,12 +406,9 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     };
     // the row's four-step twiddle w_N^(k1 (e + 20 m)) = base * step^m: two scattered table reads per round, requested
     // a phase ahead
-#if FUSED_TW_AHEAD
-    double2 tw_base = twi(k1b * re), tw_step = twi(20 * k1b);
-#endif
 #if FUSED_MERGE_Y
     if (live) y_in_place(lds4);
-    if (tid < 172) tab[tid] = twi((N / 200) * tid);   // (every w125 read lies before the last barrier)
+    if (tid < 180) tab[tid] = twi((N / 200) * ((tid % 20) * (tid / 20 + 1)));   // (every w125 read lies before the last barrier)
     __syncthreads();
     FUSED_STAMP(4);
 #endif
@@ -403,42 +431,39 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
         if (!WHOLE && rho != r0 && rho != r1) continue;
         double2* const X = lds4 + ((WHOLE ? (rho & 1) : rho == r1) ? kBuf : 0);
         double2* const Xo = lds4 + ((rho & 1) ? 0 : kBuf);
-#if !FUSED_TW_AHEAD
+        int r1_ = role1, r2_ = role2;
+        asm volatile("" : "+v"(r1_), "+v"(r2_));            // (this round's own unpacking: nothing of it lives across rounds)
+        // (a lane without a part -- role < 0 -- unpacks to in-range garbage and is masked off wherever it would touch memory)
+        const bool live1 = r1_ >= 0, live2 = r2_ >= 0;
+        const int ri = r1_ & 31, re = (r1_ >> 5) & 31, sw1 = (r1_ >> 10) & 7, k1b = (r1_ >> 13) & 127;
+        const int si = r2_ & 31, sk = (r2_ >> 5) & 15, sw2 = (r2_ >> 10) & 7, kf0 = (r2_ >> 13) & 4095;
         const double2 tw_base = twi((rho + k1b) * re), tw_step = twi(20 * (rho + k1b));
-#endif
 #if !FUSED_MERGE_Y
         if (live) y_in_place(X);
-        if ((rho == 0 || !WHOLE) && tid < 172) tab[tid] = twi((N / 200) * tid);   // (every w125 read lies before the last barrier)
+        // w200^(e k''), k'' = 1..9, stored [k'' - 1][e]: the sixteen lanes of a read group take sixteen consecutive entries
+        // (indexed e * k'' the strides 2, 4, 6, 8 cost 2-, 4-, 2-, 8-way conflicts: 1.6 k cycles per transform)
+        if ((rho == 0 || !WHOLE) && tid < 180) tab[tid] = twi((N / 200) * ((tid % 20) * (tid / 20 + 1)));   // (every w125 read lies before the last barrier)
         __syncthreads();
         FUSED_STAMP(4);
 #endif
         // ---- rows, first stage (reads first; then the parked round rho + 1 moves into the buffer round rho - 1 has
         // left -- its stores drain while the transform computes)
         double2 z[10];
-        if (live) {
-            const double2* __restrict__ rowz = X + ri * N2 + re;
-#if FUSED_READS_FIRST
+        if (WHOLE && live) {
 #pragma unroll
-            for (int m = 0; m < 10; ++m) z[m] = rowz[20 * m];
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            if (WHOLE) {
+            for (int rr = 1; rr <= 3; ++rr) {          // (wave-uniform cases: the register index must be a constant)
+                if (rho == rr) {
 #pragma unroll
-                for (int rr = 1; rr <= 3; ++rr) {          // (wave-uniform cases: the register index must be a constant)
-                    if (rho == rr) {
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
-#pragma unroll
-                            for (int kB = 0; kB < 5; ++kB) Xo[cb + 100 * j + 5 * N2 * kB] = park[j][5 * (rr - 1) + kB];
-                    }
+                        for (int kB = 0; kB < 5; ++kB) Xo[cb + 100 * j + 5 * N2 * kB] = park[j][5 * (rr - 1) + kB];
                 }
             }
-#if FUSED_READS_FIRST
-            __builtin_amdgcn_sched_barrier(0);
-#else
+        }
+        if (live1) {
+            const double2* __restrict__ rowz = X + ri * N2 + re;
 #pragma unroll
             for (int m = 0; m < 10; ++m) z[m] = rowz[20 * m];
-#endif
             double2 t = tw_base;
             z[0] = cmul_conj(z[0], t);
 #pragma unroll
@@ -450,23 +475,23 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
 #pragma unroll
             for (int g = 1; g < 10; ++g) {
                 const int kpp = g / 2 + 5 * (g % 2);
-                z[g] = cmul_conj(z[g], tab[re * kpp]);
+                z[g] = cmul_conj(z[g], tab[20 * (kpp - 1) + re]);
             }
         }
-#if FUSED_TW_AHEAD
-        if (rho < 4) {
-            tw_base = twi((rho + 1 + k1b) * re);
-            tw_step = twi(20 * (rho + 1 + k1b));
-        }
-#endif
         __syncthreads();   // every read of the row is done: the exchange goes in place
         FUSED_STAMP(5);
-        if (live) {
-            double2* const roww = X + ri * N2 + 10 * re;
+        if (live1) {
+            // (byte arithmetic on the 32-bit LDS address by hand: the row starts on a multiple of 128 bytes -- 200 elements
+            // of 16 -- so the swizzle, bits 4..6 of the byte address, is one exclusive or behind one addition per store)
+            typedef __attribute__((address_space(3))) char lds_char;
+            typedef double f64x2 __attribute__((ext_vector_type(2)));
+            typedef __attribute__((address_space(3))) f64x2 lds_f64x2;
+            const unsigned roww = (unsigned)(size_t)((lds_char*)(X + ri * N2)) + 160u * (unsigned)re;
+            const unsigned sw16 = (unsigned)sw1 << 4;
 #pragma unroll
             for (int g = 0; g < 10; ++g) {
                 const int kpp = g / 2 + 5 * (g % 2);
-                roww[kpp] = z[g];
+                *(lds_f64x2*)(size_t)((roww + 16u * kpp) ^ sw16) = f64x2{z[g].x, z[g].y};
             }
         }
         __syncthreads();
@@ -475,14 +500,18 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
         // in place in the other buffer (its stores overlap this stage's arithmetic)
         double2 u[10];
         if (live2) {
-            const double2* __restrict__ row = X + si * N2 + sk;
+            // element (e, k'') of the row sits at (10 e + k'') ^ swizzle: with e = 4 a + q that is ((k'' + 2 q) ^ swizzle) + 40 a + 8 q
+            // -- four per-lane places, the rest a constant
+            const double2* __restrict__ const row = X + si * N2;
+            const double2* __restrict__ const rowq[4] = {row + (sk ^ sw2), row + ((sk + 2) ^ sw2), row + ((sk + 4) ^ sw2), row + ((sk + 6) ^ sw2)};
 #pragma unroll
             for (int t0 = 0; t0 < 10; t0 += 5) {     // (five pairs of reads in flight: registers)
                 double2 lo[5], hi[5];
 #pragma unroll
                 for (int t = 0; t < 5; ++t) {
-                    lo[t] = row[10 * (t0 + t)];
-                    hi[t] = row[10 * (t0 + t + 10)];
+                    const int e_lo = t0 + t, e_hi = t0 + t + 10;
+                    lo[t] = rowq[e_lo & 3][10 * e_lo - 2 * (e_lo & 3)];
+                    hi[t] = rowq[e_hi & 3][10 * e_hi - 2 * (e_hi & 3)];
                 }
 #pragma unroll
                 for (int t = 0; t < 5; ++t) u[t0 + t] = h ? csub(lo[t], hi[t]) : cadd(lo[t], hi[t]);
@@ -575,7 +604,7 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     }
     int best_i = 0x7fffffff;
     double best_v = -1.0;
-    if (live2 && best_k >= 0) {
+    if (role2 >= 0 && best_k >= 0) {
         best_i = (SECOND ? 0 : bin * NF) + TERMS * best_k + par;
         best_v = 0.0 + hypot(best_x * a.scale, best_y * a.scale);   // (0.0 + |.|: the map's own rounding)
     }

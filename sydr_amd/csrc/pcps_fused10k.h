@@ -35,7 +35,7 @@ constexpr int N1 = 50, N2 = 200, N = 10000;
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 constexpr int kBuf = 25 * N2;                 // double2 per round buffer
-constexpr int kTab50 = 40, kTab200 = 176;     // w50^e (e <= 36), w200^e (e <= 171): both resident
+constexpr int kTab50 = 40, kTab200 = 180;     // w50^e (e <= 36); w200^(e k''), k'' = 1..9, e < 20, stored [k'' - 1][e] (pcps_fused.h): both resident
 constexpr size_t kLdsBytes = (size_t)(2 * kBuf + 240) * sizeof(double2);
 static_assert(kLdsBytes == 160 * 1024 && kTab50 + kTab200 <= 240, "the whole LDS of a CU");
 
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kThreads) void search_kernel(const Args a) {
     const double2* __restrict__ tw = a.tw;
     const int tid = threadIdx.x;
     if (tid < 37) tab50[tid] = tw[(N / 50) * tid];
-    if (tid < 172) tab200[tid] = tw[(N / 200) * tid];
+    if (tid < 180) tab200[tid] = tw[(N / 200) * ((tid % 20) * (tid / 20 + 1))];
 
     // units in bin-major order: the 32 workgroups of an XCD work on the PRNs of ONE bin at a time and share its ten
     // spectra through their L2
@@ -100,13 +100,40 @@ __global__ __launch_bounds__(kThreads) void search_kernel(const Args a) {
         const bool live = t_ < 500;
         const int r = live ? t_ / 100 : 0, c = live ? t_ - 100 * r : 0;
         const int cb = r * N2 + c;
-        const int ri = live ? t_ / 20 : 0, re = live ? t_ - 20 * ri : 0;
-        const int k1b = (ri / 5) + 10 * (ri % 5);            // its row's k1 = k1b + 5 rho
+        // the row stages' lanes laid out for the LDS banks, and the exchange swizzled, exactly as in pcps_fused.h (round 6;
+        // tools/lds_conflicts_fused.py): read groups of sixteen lanes take sixteen elements that differ modulo 16, write
+        // groups of eight lanes eight that differ modulo 8
+        const int l5 = t_ & 31;
+        const int gq = 2 * ((t_ >> 5) & 1) + ((l5 >= 4 && l5 < 12) || (l5 >= 16 && l5 < 20) || l5 >= 28 ? 1 : 0);
+        const int gi = l5 < 4 ? l5 : (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : (l5 < 28 ? l5 - 12 : l5 - 16)));
+        auto swz = [](int row) { return 2 * ((row >> 1) & 3) + ((row >> 1) & 1); };
+        const int g1 = 4 * (t_ >> 6) + gq;
         const int h = tid >> 8;
-        const int t2 = t_ & 255;
-        const bool live2 = t2 < 250;
-        const int si = live2 ? t2 / 10 : 0, sk = live2 ? t2 - 10 * si : 0;
-        const int kf0 = (si / 5) + 10 * (si % 5) + N1 * (sk + 10 * h);
+        int role1, role2;      // (row, e | k'', swizzle, k1b | first output) packed, < 0: no part in the stage; unpacked per round
+        {
+            int ri, re;
+            bool live1 = true;
+            if (g1 <= 24) {
+                const int n = g1 >> 1;
+                ri = 4 * (n >> 1) + (n & 1) + 2 * (g1 & 1);
+                re = gi;
+            } else {
+                const int u = g1 - 25, q = gi >> 2;
+                ri = 8 * (u >> 1) + ((u & 1) ? 0 : 2) + (q & 1) + 4 * (q >> 1);
+                re = 16 + (gi & 3);
+                if (g1 == 31) ri = 24, live1 = q == 0;
+            }
+            role1 = live1 ? (ri | re << 5 | swz(ri) << 10 | ((ri / 5) + 10 * (ri % 5)) << 13) : -1;   // (k1b: its row's k1 = k1b + 5 rho)
+            const int g2 = 4 * ((t_ >> 6) & 3) + gq;
+            int si, sk;
+            bool live2 = true;
+            if (g2 < 12) si = 2 * g2 + (gi >> 3), sk = gi & 7;
+            else if (g2 < 15) si = 8 * (g2 - 12) + (gi >> 1), sk = 8 + (gi & 1);
+            else si = 24, sk = gi, live2 = gi < 10;
+            role2 = live2 ? (si | sk << 5 | swz(si) << 10 | ((si / 5) + 10 * (si % 5) + N1 * (sk + 10 * h)) << 13) : -1;
+        }
+        const bool live2 = role2 >= 0;
+        const int kf0 = (role2 >> 13) & 4095;
 
         // (the PRN's code spectrum at this lane's points is re-read with every block: kept in registers for the whole unit --
         // FUSED10K_KEEP_CODE 1, 80 registers beside the 40 of the running sums -- the kernel spilled 33 and a search measured
@@ -172,6 +199,11 @@ __global__ __launch_bounds__(kThreads) void search_kernel(const Args a) {
 #pragma unroll
             for (int rho = 0; rho < 2; ++rho) {
                 double2* const X = lds4 + rho * kBuf;
+                int r1_ = role1, r2_ = role2;
+                asm volatile("" : "+v"(r1_), "+v"(r2_));            // (this round's own unpacking: nothing of it lives across rounds)
+                const bool live1 = r1_ >= 0;
+                const int ri = r1_ & 31, re = (r1_ >> 5) & 31, sw1 = (r1_ >> 10) & 7, k1b = (r1_ >> 13) & 127;
+                const int si = r2_ & 31, sk = (r2_ >> 5) & 15, sw2 = (r2_ >> 10) & 7;
                 const int k1 = k1b + 5 * rho;
                 const double2 tw_base = tw[k1 * re], tw_step = tw[20 * k1];
                 // Y[k' + 10 q], in place
@@ -190,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void search_kernel(const Args a) {
                 __syncthreads();
                 // rows, first stage
                 double2 z[10];
-                if (live) {
+                if (live1) {
                     const double2* __restrict__ rowz = X + ri * N2 + re;
 #pragma unroll
                     for (int m = 0; m < 10; ++m) z[m] = rowz[20 * m];
@@ -205,30 +237,37 @@ __global__ __launch_bounds__(kThreads) void search_kernel(const Args a) {
 #pragma unroll
                     for (int g = 1; g < 10; ++g) {
                         const int kpp = g / 2 + 5 * (g % 2);
-                        z[g] = cmul_conj(z[g], tab200[re * kpp]);
+                        z[g] = cmul_conj(z[g], tab200[20 * (kpp - 1) + re]);
                     }
                 }
                 __syncthreads();
-                if (live) {
-                    double2* const roww = X + ri * N2 + 10 * re;
+                if (live1) {
+                    // element (e, k'') at (10 e + k'') ^ swizzle(row): bits 4..6 of the 32-bit LDS byte address (pcps_fused.h)
+                    typedef __attribute__((address_space(3))) char lds_char;
+                    typedef double f64x2 __attribute__((ext_vector_type(2)));
+                    typedef __attribute__((address_space(3))) f64x2 lds_f64x2;
+                    const unsigned roww = (unsigned)(size_t)((lds_char*)(X + ri * N2)) + 160u * (unsigned)re;
+                    const unsigned sw16 = (unsigned)sw1 << 4;
 #pragma unroll
                     for (int g = 0; g < 10; ++g) {
                         const int kpp = g / 2 + 5 * (g % 2);
-                        roww[kpp] = z[g];
+                        *(lds_f64x2*)(size_t)((roww + 16u * kpp) ^ sw16) = f64x2{z[g].x, z[g].y};
                     }
                 }
                 __syncthreads();
                 // rows, second stage; the block's magnitudes into the running sums
                 if (live2) {
                     double2 u[10];
-                    const double2* __restrict__ row = X + si * N2 + sk;
+                    const double2* __restrict__ const row = X + si * N2;
+                    const double2* __restrict__ const rowq[4] = {row + (sk ^ sw2), row + ((sk + 2) ^ sw2), row + ((sk + 4) ^ sw2), row + ((sk + 6) ^ sw2)};
 #pragma unroll
                     for (int t0 = 0; t0 < 10; t0 += 5) {
                         double2 lo[5], hi[5];
 #pragma unroll
                         for (int t = 0; t < 5; ++t) {
-                            lo[t] = row[10 * (t0 + t)];
-                            hi[t] = row[10 * (t0 + t + 10)];
+                            const int e_lo = t0 + t, e_hi = t0 + t + 10;
+                            lo[t] = rowq[e_lo & 3][10 * e_lo - 2 * (e_lo & 3)];
+                            hi[t] = rowq[e_hi & 3][10 * e_hi - 2 * (e_hi & 3)];
                         }
 #pragma unroll
                         for (int t = 0; t < 5; ++t) u[t0 + t] = h ? csub(lo[t], hi[t]) : cadd(lo[t], hi[t]);

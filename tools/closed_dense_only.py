@@ -14,3 +14,4 @@ items, n_epochs = bench.truth_items(sats, bench.FS, total)
 for n_ch in [int(a) for a in sys.argv[1:]] or [768]:
     r = bench.closed_loop_leg(eng, items, 1000, n_ch=n_ch)
     print(n_ch, r["us_per_epoch"], r["channels_lost"])
+eng.close()
