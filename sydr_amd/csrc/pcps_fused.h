@@ -255,17 +255,32 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     const Operand xs_u = make_operand(a.spec + (a.spec_off ? (size_t)a.spec_off[bin] : (size_t)bin * NF));
     const Operand cs_u = make_operand(a.code_spec + ((size_t)prn * TERMS + par) * NF);
     const unsigned toff = (unsigned)cb * 16u;
+    // FUSED_EARLY_ITEM1 = 1 | 2 (N = 25 000, whole transforms): item 1's first one or two groups of operands are requested BEFORE
+    // item 0's second radix-5 stage (~600 instructions per lane with nothing in flight for this wave, then the ~2 k cycles
+    // until the first load of a fresh stream is back).  Measured, same box, ms per 32 x 41 search: off 0.2055, one group
+    // 0.2038, two 0.2066 -- the other waves cover most of that gap already.
+#ifndef FUSED_EARLY_ITEM1
+#define FUSED_EARLY_ITEM1 1
+#endif
+    constexpr bool kEarly = FUSED_EARLY_ITEM1 && TERMS == 1 && WHOLE;       // (the short units keep nothing parked, but their bodies are not where the time is)
+    constexpr int kEarlyGroups = FUSED_EARLY_ITEM1;         // 1 or 2
+    constexpr int kRowBytes = N2 * 16;                      // one n1 step
+    double2 xe[2][5], ce[2][5];                             // (kEarly) item 1's groups 0 and 1
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         double2* const eP = lds4 + cb + 100 * j;            // E slots of this (r, column): + 5 N2 kB; round 1: + kBuf
         double2 v[25];
         if (live) {
-            constexpr int kRowBytes = N2 * 16;              // one n1 step
             double2 xa[5], ca[5];
 #pragma unroll
             for (int m2 = 0; m2 < 5; ++m2) {
-                xa[m2] = ldb(xs_u, toff, 1600 * j + kRowBytes * 25 * m2);
-                ca[m2] = ldb(cs_u, toff, 1600 * j + kRowBytes * 25 * m2);
+                if (kEarly && j == 1) {
+                    xa[m2] = xe[0][m2];
+                    ca[m2] = ce[0][m2];
+                } else {
+                    xa[m2] = ldb(xs_u, toff, 1600 * j + kRowBytes * 25 * m2);
+                    ca[m2] = ldb(cs_u, toff, 1600 * j + kRowBytes * 25 * m2);
+                }
             }
             if (j == 1 && WHOLE) {
 #pragma unroll
@@ -281,8 +296,13 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
                     if (m1 < 4) {
 #pragma unroll
                         for (int m2 = 0; m2 < 5; ++m2) {
-                            xb[m2] = ldb(xs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
-                            cb_[m2] = ldb(cs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
+                            if (kEarly && kEarlyGroups > 1 && j == 1 && m1 == 0) {
+                                xb[m2] = xe[1][m2];
+                                cb_[m2] = ce[1][m2];
+                            } else {
+                                xb[m2] = ldb(xs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
+                                cb_[m2] = ldb(cs_u, toff, 1600 * j + kRowBytes * 5 * (m1 + 1 + 5 * m2));
+                            }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -350,6 +370,16 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
                     for (int kA = 0; kA < 5; ++kA) pin(v[m1 + 5 * kA]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            if (kEarly && j == 0) {
+#pragma unroll
+                for (int g = 0; g < kEarlyGroups; ++g)
+#pragma unroll
+                    for (int m2 = 0; m2 < 5; ++m2) {
+                        xe[g][m2] = ldb(xs_u, toff, 1600 + kRowBytes * 5 * (g + 5 * m2));
+                        ce[g][m2] = ldb(cs_u, toff, 1600 + kRowBytes * 5 * (g + 5 * m2));
+                    }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // second stage of the 25-point transform and the twiddle between the column's two levels
 #pragma unroll
@@ -631,6 +661,9 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
     if (blockIdx.x == 0)
         for (int p = tid; p < a.n_prn; p += kThreads) a.theta_next[p] = 0ull;
     const int w_end = a.xcd_first[xcd + 1];
+    // (requesting the NEXT unit's list entry a unit ahead -- a scalar load by hand, so that nothing waits in vector registers --
+    // measured 0.2037 against 0.2023 ms per search at 25 MHz and 0.4463 against 0.4493 at 50 MHz, same box: the other waves
+    // cover those latencies already; not kept)
     for (int w = a.xcd_first[xcd] + slot; w < w_end; w += kSlotsPerXcd) {
         // (wave-uniform: scalar base addresses in the unit)
         const int prn = __builtin_amdgcn_readfirstlane(a.work[w].prn);
