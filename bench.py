@@ -499,8 +499,8 @@ def host_fed_leg(eng, items, n_epochs, total, one_launch_out, batch_stream, chun
     """The headline stream fed FROM THE HOST, as a file reader hands it over (rfsignal.py:58-132 reads the recording chunk by
     chunk): the 60 s of ci8 sit in page-locked host memory, go into the (zeroed) ring a second at a time as asynchronous copies
     on the engine's stream (sdr_iq_upload_queue) while the batch stream correlates the second before (the plan's item ranges;
-    the straight-line kernels' sign-flipped image of each chunk is made behind its copy and is what the batch stream waits
-    for) -- double-buffered by the two streams, one plan for the whole list made inside the timed region.  Outputs must be
+    a ci8 chunk is flipped into the ring's sign-flipped form behind its copy, and the batch stream waits for an event recorded
+    behind that) -- double-buffered by the two streams, one plan for the whole list made inside the timed region.  Outputs must be
     bit-identical to the one-launch pass over the device-born stream.  Then the same from a pageable np.memmap of a file
     (what RFSignal hands out), over the first `pageable_seconds` of the stream.  The bound is the host link, not the kernel."""
     import tempfile
@@ -547,8 +547,8 @@ def host_fed_leg(eng, items, n_epochs, total, one_launch_out, batch_stream, chun
         out = {"x_realtime": total / FS / dt, "pcie_GBps": 2.0 * total / dt / 1e9, "chunk_s": chunk / FS, "ms_per_pass": dt * 1e3,
                "first_pass_ms": first_dt * 1e3, "passes_ms": [t * 1e3 for t in times], "stream_seconds": total / FS,
                "bitwise_identical_to_one_launch": same, "bound": "pcie (host link): the kernel alone runs the stream ~4x faster",
-               "memory": "page-locked (sdr_host_alloc)", "includes": "plan creation (one plan, whole list), every copy, the flipped "
-               "ring image per chunk, every launch; one chunk's copy runs beside the chunk before's correlation (two HIP streams)"}
+               "memory": "page-locked (sdr_host_alloc)", "includes": "plan creation (one plan, whole list), every copy, the sign flip of every chunk "
+               "(a ci8 ring holds its bytes sign-flipped), every launch; one chunk's copy runs beside the chunk before's correlation (two HIP streams)"}
         if not same:
             raise SystemExit("host-fed pass differs from the one-launch pass")
         # ... and from a pageable np.memmap of a file
@@ -1008,8 +1008,8 @@ def main():
     ap.add_argument("--steps", type=int, default=120)        # (~2 s of timed region at 16.6 ms per pass: the GPU shows up in smi samples)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--stream-seconds", type=float, default=60.0)
-    ap.add_argument("--launch-seconds", type=float, default=0.0,
-                    help="seconds of stream per E/P/L launch (0 = the whole stream in one launch)")
+    ap.add_argument("--plan-seconds", type=float, default=5.0,
+                    help="seconds of stream per segment: one plan + one launch each, the next segment's plan made while this one runs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-acquisition", action="store_true")
     ap.add_argument("--no-closed-loop", action="store_true")
@@ -1095,34 +1095,54 @@ def main():
         eng.load_gps_code(s, sat["prn"])
     eng.iq_synth(all_sats, FS, 12.0, 20260003, 0, total)
     items, n_epochs = truth_items(sats, FS, total)
-    t_plan = time.perf_counter()
-    plan = eng.epl_plan(items, SPACING, FS)                 # upload of the items, one launch that checks them, one for their per-epoch setups
-    plan_create_first_s = time.perf_counter() - t_plan      # (the process's first: kernel modules, page-locked staging, ...)
     n_run = n_epochs * N_CH                                 # every whole code period of the stream, every channel
-    t_first = time.perf_counter()
-    plan.run(0, n_run)                                      # the first pass also makes the sign-flipped image of the ring
-    eng.sync()
-    first_pass_s = time.perf_counter() - t_first
-    t_plan = time.perf_counter()
-    again = eng.epl_plan(items, SPACING, FS)                # what a plan costs from then on (the next stream segment's)
-    plan_create_s = time.perf_counter() - t_plan
-    again.close()
     pass_samples = int(items["n_samples"][:n_run].sum())
     batch_stream = eng.stream_create()                      # one HIP stream per channel batch (north_star)
 
     # One step = one pass of the correlators over the WHOLE stream (configs[2]: 60 s): every whole code period of every
-    # channel (59 998 epochs x 32 at 60 s).  A step of one second (0.3 ms) would put the driver's whole timed region inside
-    # the ~40 ms the chip takes to settle its clocks under this kernel (tools/epl_ramp.py: 0.37 ms per launch falling to
-    # 0.31 over the first ~100 launches, whatever ran before).  The pass is ONE launch by default (1.9 M single-wave
-    # workgroups): every launch ends with a partial round of workgroups on the 3072 resident slots, and launches of one
-    # second each cost 4 % more per second of stream (tools/epl_launch_size.py); --launch-seconds picks smaller launches.
-    per_launch = n_run if args.launch_seconds <= 0 else max(N_CH, int(args.launch_seconds * 1000) * N_CH)
-    launch_starts = list(range(0, n_run, per_launch))
-    secs_per_launch = per_launch / N_CH / 1000.0
+    # channel (59 998 epochs x 32 at 60 s) -- AS A CALLER GETS IT (round 6).  The stream is cut into
+    # segments of --plan-seconds; the plan of a segment (upload of its items, the launch that checks them, the launch that
+    # works out every epoch's setup: sdr_epl_plan_create) is made on the engine's stream WHILE the segment before is
+    # correlated on the batch stream, and dropped when its launch has finished (its device buffers serve a later segment:
+    # the engine's plan pool).  Nothing is outside the timed region but the samples, which lie in HBM when it starts: plan
+    # creation, launch and plan destruction of every segment of every step are in it -- the very first segment's plan,
+    # which nothing hides, included.  (Until round 5 the steps re-ran ONE resident plan: `plan_reuse` below is that figure.)
+    # A step of one second (0.3 ms) would put the driver's whole timed region inside the ~40 ms the chip takes to settle its
+    # clocks under this kernel (tools/epl_ramp.py); segments shorter than a few seconds make the host's share of a plan
+    # (~0.2 ms of calls and waits) as long as the segment's launch.
+    seg_items = max(N_CH, int(round(args.plan_seconds * 1000)) * N_CH)
+    seg_starts = list(range(0, n_run, seg_items))
+    # the item list in page-locked memory (a caller that hands its NCO trajectory to the device segment by segment keeps it
+    # there: the upload of a segment's items is an asynchronous copy, not one staged through the runtime's buffers)
+    from sydr_amd._lib import EPL_ITEM_DTYPE
+    items_pinned = eng.host_alloc(n_run * EPL_ITEM_DTYPE.itemsize, np.uint8).view(EPL_ITEM_DTYPE)
+    items_pinned[:] = items[:n_run]
 
-    def run_step(k):
-        for j in launch_starts:
-            plan.run(j, min(per_launch, n_run - j), stream=batch_stream)
+    def pipelined_passes(n_passes, keep_last=False):
+        """n_passes passes over the stream, segment by segment, each segment's plan made while the one before runs.
+        keep_last: the last pass's plans are handed back [(first item, plan)] (their outputs are checked), not destroyed."""
+        order = [(q, j) for q in range(n_passes) for j in seg_starts]
+        launched, kept = [], []
+        plan = eng.epl_plan(items_pinned[order[0][1]:min(order[0][1] + seg_items, n_run)], SPACING, FS)
+        for i, (q, j) in enumerate(order):
+            plan.run(stream=batch_stream)                   # asynchronous
+            launched.append((q, j, plan))
+            if i + 1 < len(order):                          # the next segment's plan, while this one is correlated
+                nj = order[i + 1][1]
+                plan = eng.epl_plan(items_pinned[nj:min(nj + seg_items, n_run)], SPACING, FS)
+            while len(launched) > 1:                        # what was launched before this segment has finished: its buffers go back
+                oq, oj, old = launched.pop(0)
+                if keep_last and oq == n_passes - 1:
+                    kept.append((oj, old))
+                else:
+                    old.close()
+        oq, oj, old = launched.pop(0)
+        eng.stream_sync(batch_stream)
+        if keep_last:
+            kept.append((oj, old))
+        else:
+            old.close()
+        return kept
 
     def barrier():
         eng.stream_sync(batch_stream)
@@ -1131,19 +1151,22 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for k in range(args.warmup):
-        run_step(k)
+    # untimed: the process's first plan and first pass (kernel modules, page-locked staging, the plan pool's first buffers)
+    t_first = time.perf_counter()
+    pipelined_passes(1)
+    first_pass_s = time.perf_counter() - t_first
+    if args.warmup > 1:
+        pipelined_passes(args.warmup - 1)
     barrier()
     eng.prof_reset()
     eng.prof_enable(True)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        run_step(k)
+    pipelined_passes(args.steps)
     eng.stream_sync(batch_stream)
     torch.cuda.synchronize()
     elapsed = elapsed_own = time.perf_counter() - t0
     ch_samples = pass_samples * args.steps                   # channel-samples, this rank
-    n_launches = len(launch_starts) * args.steps
+    n_launches = len(seg_starts) * args.steps
     job_ch_samples = float(ch_samples)
     if world > 1:
         dist.barrier()
@@ -1156,9 +1179,37 @@ def main():
     eng.prof_enable(False)
     kern_ms, launches = eng.prof_read("epl_kernel")
     eng.prof_reset()
+
+    # ---- outside the timed region: ONE plan for the whole stream -- what the steps re-ran until round 5, the launch the
+    # counters of profiles/pmc_traffic.json were taken on, and the outputs every check below reads
+    t_plan = time.perf_counter()
+    plan = eng.epl_plan(items, SPACING, FS)
+    plan_create_s = time.perf_counter() - t_plan
+    plan.run(0, n_run, stream=batch_stream)
+    barrier()
+    reuse_steps = max(2, min(args.steps, 10))
+    eng.prof_enable(True)
+    t1 = time.perf_counter()
+    for _ in range(reuse_steps):
+        plan.run(0, n_run, stream=batch_stream)
+    eng.stream_sync(batch_stream)
+    reuse_s = (time.perf_counter() - t1) / reuse_steps
+    eng.prof_enable(False)
+    reuse_kern_ms, reuse_launches = eng.prof_read("epl_kernel")
+    eng.prof_reset()
+    # the pipelined pass delivers the one-launch pass's numbers, bit for bit (the same kernel on the same items: a segment is
+    # a range of the list)
+    got_all = plan.fetch()[:n_run]
+    kept = pipelined_passes(1, keep_last=True)
+    seg_equal = True
+    for j, seg_plan in kept:
+        seg_equal = seg_equal and seg_plan.fetch().tobytes() == got_all[j:min(j + seg_items, n_run)].tobytes()
+        seg_plan.close()
+    if not seg_equal:
+        raise SystemExit("bench: the segment-by-segment pass does not reproduce the one-launch pass bit for bit")
     multi_gpu = None
     if world > 1:
-        multi_gpu = verify_across_ranks(eng, dist, torch, rank, local_rank, world, all_sats, mine, plan.fetch()[:n_run], total,
+        multi_gpu = verify_across_ranks(eng, dist, torch, rank, local_rank, world, all_sats, mine, got_all, total,
                                         elapsed_own / args.steps, ch_samples / args.steps)
 
     stream_samples = ch_samples / N_CH                       # samples of THE stream consumed per rank (same on all)
@@ -1167,6 +1218,7 @@ def main():
     algo_bytes_per_launch = 2.0 * ch_samples / max(1, n_launches)  # 2 B per channel-sample (ci8)
     achieved = algo_bytes_per_launch / avg_kernel_s / 1e9 if launches else 0.0
     flops = (6 + 4 * len(SPACING)) * ch_samples / max(1, n_launches)
+    seg_epochs = min(seg_items, n_run) // N_CH
 
     result = {
         "metric": "IQ Msamples/s through 32-ch E/P/L correlators @25 MHz fs",
@@ -1176,34 +1228,49 @@ def main():
         # (the driver's record keeps ~128 characters of a string: the workload first, the step's definition under its own key)
         "config": {"workload": "GPS L1 C/A tracking, 32 channels/GPU, E/P/L (3 taps), fs=25 MHz, 1 ms integration, "
                                f"{args.stream_seconds:g} s synthetic ci8 IQ stream",
-                   "step": f"one pass over the whole stream ({n_epochs} epochs x {N_CH} channels) = {len(launch_starts)} "
-                           f"launch(es) of {min(per_launch, n_run)} channel-epochs",
+                   "step": f"one pass over the whole stream ({n_epochs} epochs x {N_CH} channels) in {len(seg_starts)} segments of "
+                           f"{seg_epochs} ms: per segment plan creation (items uploaded, checked, per-epoch setups), ONE launch, "
+                           "plan destruction -- all inside the timed region, a segment's plan made while the segment before runs",
                    "channels_per_gpu": N_CH, "channels_total": n_total, "fs_hz": FS, "taps": len(SPACING), "iq_format": "ci8",
-                   "host_thread_bound_to_gpu_cpus": host_thread_bound,
-                   "mode": f"open-loop batched (true NCO trajectory, {min(per_launch, n_run)} channel-epochs per launch)",
+                   "host_thread_bound_to_gpu_cpus": host_thread_bound, "plan_seconds": args.plan_seconds,
+                   "mode": f"open-loop batched (true NCO trajectory, {min(seg_items, n_run)} channel-epochs per launch)",
                    "sharding": f"one stream of {n_total} satellites replicated on {world} GPU(s) (same seed), channels "
                                f"sharded {N_CH} per GPU, one HIP stream per channel batch, no collective"},
         "x_realtime": stream_samples / elapsed / FS,          # seconds of THE stream (all channels tracked) per second
         "channel_Msamples_per_s": job_ch_samples / elapsed / 1e6,
         "multi_gpu": multi_gpu,                               # N > 1: who took part, per-rank rates, cross-rank bitwise check
-        # outside the timed region, once per stream: the host checks every item, uploads the list, and one launch with a
-        # thread per item works out each epoch's setup (tap constants, chip geometry, carrier rotations:
-        # sdr_epl_plan_create); the steps re-run the same plan
-        "plan": {"create_ms": plan_create_s * 1e3, "create_ms_first_in_process": plan_create_first_s * 1e3,
-                 "first_pass_ms_incl_flipped_ring_image": first_pass_s * 1e3, "items": int(len(items))},
+        "segments_equal_one_launch_bitwise": bool(seg_equal),
+        # what the timed region contains per segment, host side: sdr_epl_plan_create (4 pooled buffers, item upload from
+        # page-locked memory, the check launch + its read-back, the setup launch, one stream synchronisation),
+        # sdr_epl_plan_run_range_on, sdr_epl_plan_destroy
+        "plan": {"create_ms_whole_stream": plan_create_s * 1e3, "first_pass_ms_in_process": first_pass_s * 1e3,
+                 "items": int(len(items)), "segments_per_pass": len(seg_starts)},
     }
-    # a stream is correlated once: what ONE use of a plan costs (its creation + one pass), against the steps' re-runs
-    pass_ms = elapsed / args.steps * 1e3
-    result["single_use"] = {"plan_create_ms": plan_create_s * 1e3, "pass_ms": pass_ms,
-                            "x_realtime": args.stream_seconds / ((plan_create_s * 1e3 + pass_ms) * 1e-3),
-                            "first_use_in_process_x_realtime": args.stream_seconds / (plan_create_first_s + first_pass_s)}
+    # the SAME stream through ONE resident plan re-run (what `value` was until round 5: nothing but the launch in the step) --
+    # the secondary figure; and a plan used once, unpipelined (its creation, then its pass)
+    reuse_ch = float(pass_samples)
+    result["plan_reuse"] = {"ms_per_pass": reuse_s * 1e3, "x_realtime": reuse_ch / N_CH / reuse_s / FS,
+                            "Msamples_per_s": reuse_ch / N_CH / reuse_s / 1e6, "passes": reuse_steps,
+                            "avg_launch_ms": reuse_kern_ms / max(1, reuse_launches),
+                            "frac": 2.0 * reuse_ch / (reuse_kern_ms / max(1, reuse_launches) * 1e-3) / 1e9 / HBM_PEAK_GBS if reuse_launches else None,
+                            "what": "ONE plan of the whole stream, created outside the timed passes, re-run in one launch per pass"}
+    result["single_use"] = {"plan_create_ms": plan_create_s * 1e3, "pass_ms": reuse_s * 1e3,
+                            "x_realtime": args.stream_seconds / (plan_create_s + reuse_s),
+                            "what": "one plan of the whole stream made, then run once: creation and pass one after the other"}
     setup_bytes = 480 if len(SPACING) == 3 else 560
-    result["device_bytes"] = {"ring": int(total) * 2, "flipped_ring": int(total) * 2, "items": int(len(items)) * 48,
-                              "setups": int(len(items)) * setup_bytes, "outputs": int(len(items)) * 16 * len(SPACING)}
+    # (the ring is the only copy of the samples: round 5's sign-flipped image beside it -- + 2 B per sample -- is gone, a ci8
+    # ring holds that form itself; setups / items / outputs: of the segments in flight, two at most)
+    result["device_bytes"] = {"ring": int(total) * 2, "items": 2 * min(seg_items, n_run) * 48,
+                              "setups": 2 * min(seg_items, n_run) * setup_bytes, "outputs": 2 * min(seg_items, n_run) * 16 * len(SPACING),
+                              "whole_stream_plan_of_the_checks": int(len(items)) * (48 + setup_bytes + 16 * len(SPACING))}
     result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "epl_kernel",
                           "avg_launch_ms": avg_kernel_s * 1e3, "launches": int(launches),
                           "algorithmic_bytes_per_launch": algo_bytes_per_launch,
+                          # `bound` names the roof SURVEY 8(d) prices the path against (the contract's "hbm" | "mfma"); what the
+                          # counters say holds the kernel is below: the 32 channels share the samples through L2 / MALL
+                          # (traffic ~0.3 x the algorithmic bytes) and the vector pipe's fp64 issue slots are ~0.9 busy
+                          "bound_by_counters": "fp64 issue (VALU): see valu_issue.busy_frac, traffic_frac_of_peak",
                           # the same launch against the OTHER roof (6 + 4*taps flops per channel-sample;
                           # fp64 vector peak 78.6 TFLOP/s): the kernel is VALU-issue-bound, not HBM-bound
                           "fp64_vector": {"achieved_tflops": flops / avg_kernel_s / 1e12 if launches else 0.0,
@@ -1329,11 +1396,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_host_fed:
         one_launch_out = plan.fetch()[:n_run].copy()
         plan.close()
+        eng.host_free(items_pinned.view(np.uint8))
         result["host_fed"] = host_fed_leg(eng, items, n_epochs, total, one_launch_out, batch_stream)
         del one_launch_out
         leg_done()
     else:
         plan.close()
+        eng.host_free(items_pinned.view(np.uint8))
     if rank == 0 and world == 1 and not args.no_rates:
         result["rates"] = rates_leg(eng)
         leg_done()

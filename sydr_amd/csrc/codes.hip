@@ -157,8 +157,13 @@ __global__ __launch_bounds__(256) void synth_kernel(T* __restrict__ ring, int64_
         im += r * sn;
     }
     int64_t slot = n % capacity;
-    ring[2 * slot] = quantise<T>(re);
-    ring[2 * slot + 1] = quantise<T>(im);
+    if constexpr (sizeof(T) == 1) {     // (a ci8 ring holds its bytes with the sign bit flipped: correlator.h kCi8Flip)
+        ring[2 * slot] = (T)(quantise<T>(re) ^ (T)0x80);
+        ring[2 * slot + 1] = (T)(quantise<T>(im) ^ (T)0x80);
+    } else {
+        ring[2 * slot] = quantise<T>(re);
+        ring[2 * slot + 1] = quantise<T>(im);
+    }
 }
 
 extern "C" {

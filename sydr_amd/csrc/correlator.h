@@ -44,6 +44,14 @@ __device__ __forceinline__ double uniform(double x) {
     return __hiloint2double(hi, lo);
 }
 
+// A ci8 ring holds its samples with the sign bit of every byte flipped (u = x + 128 as an unsigned byte: "offset binary") --
+// the form the straight-line correlators build their doubles from with one v_perm_b32 per component (correlator_chip.h
+// biased_sample).  Round 6: that IS the ring, not an image beside it -- the engine flips where samples enter (uploads, the
+// ingest kernels, the synthesiser) and flips back where they leave (sdr_iq_download); every other reader takes the bits back
+// with one exclusive or per dword of two samples, here.
+constexpr uint32_t kCi8Flip = 0x80808080u;
+__device__ __forceinline__ int ci8_native(int w) { return w ^ (int)kCi8Flip; }
+
 // Load 8 consecutive ring samples starting at aligned position `pos` and widen to fp64.
 template <int FMT>
 struct Loader;
@@ -52,7 +60,7 @@ template <>
 struct Loader<SDR_FMT_CI8> {
     static __device__ __forceinline__ void load(const void* ring, int64_t pos, double* xr, double* xi) {
         const int4 v = *reinterpret_cast<const int4*>(static_cast<const char*>(ring) + pos * 2);
-        const int w[4] = {v.x, v.y, v.z, v.w};
+        const int w[4] = {ci8_native(v.x), ci8_native(v.y), ci8_native(v.z), ci8_native(v.w)};
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             xr[2 * d] = (double)(int)(int8_t)(w[d]);
@@ -135,8 +143,8 @@ template <int FMT>
 __device__ __forceinline__ void load_one(const void* ring, int64_t pos, double& xr, double& xi) {
     if (FMT == SDR_FMT_CI8) {
         const char2 v = static_cast<const char2*>(ring)[pos];
-        xr = (double)v.x;
-        xi = (double)v.y;
+        xr = (double)(int8_t)(v.x ^ 0x80);
+        xi = (double)(int8_t)(v.y ^ 0x80);
     } else if (FMT == SDR_FMT_CI16) {
         const short2 v = static_cast<const short2*>(ring)[pos];
         xr = (double)v.x;
@@ -387,7 +395,8 @@ struct Raw8<SDR_FMT_CI8> {
         v = *reinterpret_cast<const int4*>(static_cast<const char*>(ring) + pos * 2);
     }
     __device__ __forceinline__ void get(int j, double& xr, double& xi) const {
-        const int w = (j >> 1) == 0 ? v.x : ((j >> 1) == 1 ? v.y : ((j >> 1) == 2 ? v.z : v.w));
+        // (the ring's bytes are sign-flipped: one exclusive or per dword gives the two's-complement samples back)
+        const int w = ci8_native((j >> 1) == 0 ? v.x : ((j >> 1) == 1 ? v.y : ((j >> 1) == 2 ? v.z : v.w)));
         if (j & 1) {
             xr = (double)(int)(int8_t)(w >> 16);
             xi = (double)(w >> 24);

@@ -79,7 +79,7 @@ __device__ __forceinline__ int wave_min_i32(int x) {
 }
 
 // int8 -> fp64 in ONE instruction, with a known offset.  v_perm_b32 drops a sample byte (sign bit flipped: u = x + 128;
-// the engine keeps an image of a ci8 ring with the bits already flipped, engine_internal.h iq_flip)
+// a ci8 ring holds its bytes that way, correlator.h kCi8Flip)
 // into bits 8..15 of the high word 0x40B0_0000 of a double whose low word is zero: that double is 4096 + u = 4224 + x,
 // exactly.  The straight-line kernels mix THESE into their running sums (against 2 instructions for
 // v_bfe_i32 + v_cvt_f64_i32: the conversion was half of the 8-instruction floor per sample) and take the offset's share
@@ -295,7 +295,9 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
     const int tail_start = __builtin_amdgcn_readfirstlane(G.tail_start);
     // (the caller guarantees base + n + 32 <= capacity)
     // (the straight-line forms build their samples from the sign-flipped image of the ring: see biased_sample())
-    const char* ring_base = static_cast<const char*>(KM != 0 && (KS != 0 || KI != 0) && SDR_BIASED_CVT ? ring_flipped : ring) + base * 2;
+    // (round 6: the ring itself holds the sign-flipped bytes -- `ring_flipped` is the same pointer, kept in the signature)
+    (void)ring_flipped;
+    const char* ring_base = static_cast<const char*>(ring) + base * 2;
 
     // in-block rotations exp(-1j*k*dphi), k = 0..25: one per lane, parked in LDS, read back as broadcasts
     // (KS: the block is summed in two halves of KS + 1 and KM - KS samples that both start at rotation 0, so only
@@ -479,7 +481,7 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
             };
             auto sample = [&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                const int w = (int)b.raw[k >> 1];
+                const int w = ci8_native((int)b.raw[k >> 1]);
                 const double ar = (k & 1) ? (double)(int)(int8_t)(w >> 16) : (double)(int)(int8_t)w;
                 const double ai = (k & 1) ? (double)(w >> 24) : (double)(int)(int8_t)(w >> 8);
                 if (k + kAhead < kChipMax) rr[k + kAhead] = rot[k + kAhead];
@@ -499,12 +501,12 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                 if constexpr (SDR_BIASED_CVT) {
                     asm volatile("" : "+v"(hi_const));             // (v_perm_b32 takes one scalar operand: the selector)
 #pragma unroll
-                    for (int i = 0; i < kChipRawDwords; ++i) flipped[i] = b.raw[i];   // (loaded from the flipped image of the ring)
+                    for (int i = 0; i < kChipRawDwords; ++i) flipped[i] = b.raw[i];   // (the ring holds the flipped bytes)
                 }
                 static_for<0, KM + 1>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     constexpr int j = k < kHalf ? k : k - kHalf;
-                    const int w = (int)b.raw[k >> 1];
+                    const int w = ci8_native((int)b.raw[k >> 1]);
                     double ar, ai;
                     if constexpr (SDR_BIASED_CVT) {
                         ar = biased_sample(zI, flipped[k >> 1], cvt_selector((k & 1) ? 2 : 0), hi_const);
@@ -546,7 +548,7 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                         if (k == klast) break;
                     }
                     if (k < kChipMax) {
-                        const int w = (int)b.raw[k >> 1];
+                        const int w = ci8_native((int)b.raw[k >> 1]);
                         const double ar = (k & 1) ? (double)(int)(int8_t)(w >> 16) : (double)(int)(int8_t)w;
                         const double ai = (k & 1) ? (double)(w >> 24) : (double)(int)(int8_t)(w >> 8);
                         if (k + kAhead < kChipMax) rr[k + kAhead] = rot[k + kAhead];

@@ -139,66 +139,65 @@ __global__ __launch_bounds__(256) void hbm_copy_kernel(const uint4* __restrict__
 }
 
 void sdr_iq_mark_written(sdr_engine* e, int64_t ring_offset, int64_t n_samples) {
-    if (n_samples <= 0 || e->iq_capacity <= 0) return;
-    const int64_t cap = e->iq_capacity;
-    int64_t lo = ring_offset % cap, hi = lo + n_samples;
-    if (hi > cap || n_samples >= cap) lo = 0, hi = cap;           // (a write that wraps: the whole ring, for simplicity)
-    if (e->iq_dirty_hi <= e->iq_dirty_lo) {
-        e->iq_dirty_lo = lo, e->iq_dirty_hi = hi;
-    } else {
-        e->iq_dirty_lo = lo < e->iq_dirty_lo ? lo : e->iq_dirty_lo;
-        e->iq_dirty_hi = hi > e->iq_dirty_hi ? hi : e->iq_dirty_hi;
-    }
+    // (round 5 kept a sign-flipped IMAGE of a ci8 ring and refreshed it from the range marked here -- the refresh's event was
+    // also what ordered readers on other streams behind an upload; the ring itself holds that form now, the ordering stays)
+    (void)ring_offset, (void)n_samples;
+    ++e->iq_write_seq;
 }
 
-__global__ __launch_bounds__(256) void flip_sign_bits_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+int sdr_iq_order_reader(sdr_engine* e, StreamCtx* ctx) {
+    if (!ctx || ctx->stream == e->stream || ctx->iq_waited_seq == e->iq_write_seq) return SDR_OK;
+    if (e->iq_recorded_seq != e->iq_write_seq) {
+        if (!e->iq_written) SDR_HIP(hipEventCreateWithFlags(&e->iq_written, hipEventDisableTiming));
+        SDR_HIP(hipEventRecord(e->iq_written, e->stream));
+        e->iq_recorded_seq = e->iq_write_seq;
+    }
+    SDR_HIP(hipStreamWaitEvent(ctx->stream, e->iq_written, 0));
+    ctx->iq_waited_seq = e->iq_recorded_seq;
+    return SDR_OK;
+}
+
+// A ci8 ring holds its samples with the sign bit of every byte flipped (correlator.h kCi8Flip): bytes [lo, hi) of the ring,
+// just copied in as the host has them, flipped in place -- whole 16-byte granules inside the range, byte by byte at its ends.
+__global__ __launch_bounds__(256) void flip_range_kernel(uint4* __restrict__ ring, size_t lo, size_t hi) {
+    const size_t g0 = lo / 16, g1 = (hi + 15) / 16;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
-        uint4 v = src[i];
-        v.x ^= 0x80808080u, v.y ^= 0x80808080u, v.z ^= 0x80808080u, v.w ^= 0x80808080u;
-        dst[i] = v;
+    for (size_t g = g0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < g1; g += stride) {
+        uint4 v = ring[g];
+        const size_t b = g * 16;
+        if (b >= lo && b + 16 <= hi) {
+            v.x ^= 0x80808080u, v.y ^= 0x80808080u, v.z ^= 0x80808080u, v.w ^= 0x80808080u;
+        } else {
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (int i = 0; i < 16; ++i)
+                if (b + (size_t)i >= lo && b + (size_t)i < hi) w[i >> 2] ^= 0x80u << (8 * (i & 3));
+            v.x = w[0], v.y = w[1], v.z = w[2], v.w = w[3];
+        }
+        ring[g] = v;
     }
 }
 
-// sdr_iq_upload_async: 16-byte granules of a page-locked slab into the ring at granule `first` (modulo the ring).
+// sdr_iq_upload_async: 16-byte granules of a page-locked slab into the ring at granule `first` (modulo the ring); flip:
+// what every dword is xor-ed with on the way (ci8: the sign bits).
 __global__ __launch_bounds__(256) void ingest_kernel(const uint4* __restrict__ src, uint4* __restrict__ ring, size_t n16, size_t first,
-                                                     size_t ring16) {
+                                                     size_t ring16, uint32_t flip) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
         size_t d = first + i;
         if (d >= ring16) d -= ring16;
-        ring[d] = src[i];
+        uint4 v = src[i];
+        v.x ^= flip, v.y ^= flip, v.z ^= flip, v.w ^= flip;
+        ring[d] = v;
     }
 }
 
+static inline uint32_t ring_flip_mask(const sdr_engine* e) { return e->iq_fmt == SDR_FMT_CI8 ? 0x80808080u : 0u; }
+
 int sdr_iq_flipped(sdr_engine* e, hipStream_t stream, const void** out) {
-    if (e->iq_fmt != SDR_FMT_CI8 || !e->iq) return sdr_fail(SDR_ERR_STATE, "the flipped ring image exists for ci8 rings only");
-    const size_t bytes = (size_t)e->iq_capacity * 2 + 256;        // (the same slack as the ring itself)
-    if (!e->iq_flip || e->iq_flip_capacity != e->iq_capacity) {
-        if (e->iq_flip) SDR_HIP(hipFree(e->iq_flip));
-        e->iq_flip = nullptr;
-        if (hipMalloc(&e->iq_flip, bytes) != hipSuccess) {
-            e->iq_flip = nullptr;
-            return sdr_fail(SDR_ERR_NOMEM, "hipMalloc(%zu) for the flipped image of the IQ ring failed", bytes);
-        }
-        e->iq_flip_capacity = e->iq_capacity;
-        e->iq_dirty_lo = 0, e->iq_dirty_hi = e->iq_capacity;
-        if (!e->iq_flip_done) SDR_HIP(hipEventCreateWithFlags(&e->iq_flip_done, hipEventDisableTiming));
-    }
-    if (e->iq_dirty_hi > e->iq_dirty_lo) {
-        // 16-byte granules around the dirty samples (2 bytes each); the whole ring takes its slack along
-        size_t lo = (size_t)e->iq_dirty_lo * 2 / 16, hi = ((size_t)e->iq_dirty_hi * 2 + 15) / 16;
-        if (e->iq_dirty_lo == 0 && e->iq_dirty_hi >= e->iq_capacity) hi = bytes / 16;
-        const size_t n16 = hi - lo;
-        const unsigned blocks = (unsigned)(n16 / 256 / 4 + 1 < 8192 ? n16 / 256 / 4 + 1 : 8192);
-        hipLaunchKernelGGL(flip_sign_bits_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)e->iq + lo,
-                           (uint4*)e->iq_flip + lo, n16);
-        SDR_HIP(hipGetLastError());
-        SDR_HIP(hipEventRecord(e->iq_flip_done, e->stream));
-        e->iq_dirty_lo = e->iq_dirty_hi = 0;
-    }
-    if (stream != e->stream && e->iq_flip_done) SDR_HIP(hipStreamWaitEvent(stream, e->iq_flip_done, 0));
-    *out = e->iq_flip;
+    // (round 6: a ci8 ring IS the sign-flipped form -- flipped where the samples enter; no second image, no refresh pass)
+    (void)stream;
+    if (e->iq_fmt != SDR_FMT_CI8 || !e->iq) return sdr_fail(SDR_ERR_STATE, "the sign-flipped sample form exists for ci8 rings only");
+    *out = e->iq;
     return SDR_OK;
 }
 
@@ -403,9 +402,8 @@ void sdr_engine_destroy(sdr_engine* e) {
     if (e->slab_pinned) (void)hipHostFree(e->slab_pinned);
     for (int h = 0; h < 2; ++h)
         if (e->slab_done[h]) (void)hipEventDestroy(e->slab_done[h]);
+    if (e->iq_written) (void)hipEventDestroy(e->iq_written);
     if (e->iq) (void)hipFree(e->iq);
-    if (e->iq_flip) (void)hipFree(e->iq_flip);
-    if (e->iq_flip_done) (void)hipEventDestroy(e->iq_flip_done);
     if (e->codes) (void)hipFree(e->codes);
     if (e->luts) (void)hipFree(e->luts);
     if (e->luts2) (void)hipFree(e->luts2);
@@ -509,15 +507,9 @@ int sdr_iq_alloc(sdr_engine* e, int64_t capacity_samples, int fmt) {
         return sdr_fail(SDR_ERR_NOMEM, "hipMalloc(%zu) for the IQ ring failed: %s", bytes,
                         hipGetErrorString(err));
     }
-    SDR_HIP(hipMemsetAsync(e->iq, 0, bytes, e->stream));
+    SDR_HIP(hipMemsetAsync(e->iq, fmt == SDR_FMT_CI8 ? 0x80 : 0, bytes, e->stream));     // (zero samples: ci8 bytes are kept sign-flipped)
     e->iq_capacity = capacity_samples;
     e->iq_fmt = fmt;
-    if (e->iq_flip) {               // (the image of another ring: rebuilt when a kernel next asks for it)
-        SDR_HIP(hipFree(e->iq_flip));
-        e->iq_flip = nullptr;
-        e->iq_flip_capacity = 0;
-    }
-    e->iq_dirty_lo = 0, e->iq_dirty_hi = capacity_samples;
     return SDR_OK;
 }
 
@@ -534,18 +526,42 @@ static int iq_copy(sdr_engine* e, void* host, int64_t n, int64_t off, bool uploa
     int64_t first = n < e->iq_capacity - off ? n : e->iq_capacity - off;
     char* dev = (char*)e->iq;
     char* h = (char*)host;
+    const bool ci8 = e->iq_fmt == SDR_FMT_CI8;
+    auto flip = [&](size_t lo, size_t hi) {      // (ci8: the bytes just copied in, into the ring's sign-flipped form)
+        const size_t n16 = (hi + 15) / 16 - lo / 16;
+        const unsigned blocks = (unsigned)(n16 / 256 / 4 + 1 < 8192 ? n16 / 256 / 4 + 1 : 8192);
+        hipLaunchKernelGGL(flip_range_kernel, dim3(blocks), dim3(256), 0, e->stream, (uint4*)e->iq, lo, hi);
+    };
     if (upload) {
         sdr_iq_mark_written(e, off, n);
-        if (first) SDR_HIP(hipMemcpyAsync(dev + off * sb, h, first * sb, hipMemcpyHostToDevice, e->stream));
-        if (n > first)
+        if (first) {
+            SDR_HIP(hipMemcpyAsync(dev + off * sb, h, first * sb, hipMemcpyHostToDevice, e->stream));
+            if (ci8) flip((size_t)off * sb, (size_t)(off + first) * sb);
+        }
+        if (n > first) {
             SDR_HIP(hipMemcpyAsync(dev, h + first * sb, (n - first) * sb, hipMemcpyHostToDevice, e->stream));
+            if (ci8) flip(0, (size_t)(n - first) * sb);
+        }
+        if (ci8 && n > 0) SDR_HIP(hipGetLastError());
     } else {
         if (first) SDR_HIP(hipMemcpyAsync(h, dev + off * sb, first * sb, hipMemcpyDeviceToHost, e->stream));
         if (n > first)
             SDR_HIP(hipMemcpyAsync(h + first * sb, dev, (n - first) * sb, hipMemcpyDeviceToHost, e->stream));
     }
     // The caller owns `host`; do not keep it past return (wait == false: the caller of this file synchronises).
-    if (wait) SDR_HIP(hipStreamSynchronize(e->stream));
+    if (wait || (!upload && ci8)) SDR_HIP(hipStreamSynchronize(e->stream));
+    if (!upload && ci8) {                        // (what leaves the ring leaves it as the host wrote it)
+        unsigned char* b = (unsigned char*)host;
+        const size_t nb = (size_t)n * sb;
+        size_t i = 0;
+        for (; i + 8 <= nb; i += 8) {
+            uint64_t w;
+            memcpy(&w, b + i, 8);
+            w ^= 0x8080808080808080ull;
+            memcpy(b + i, &w, 8);
+        }
+        for (; i < nb; ++i) b[i] ^= 0x80;
+    }
     return SDR_OK;
 }
 
@@ -600,7 +616,7 @@ int sdr_iq_flush_server_slab(sdr_engine* e) {
     const char* stage = (const char*)e->srv_slab_src;
     const size_t n16 = bytes / 16;
     const unsigned blocks = (unsigned)((n16 + 255) / 256 < 64 ? (n16 + 255) / 256 : 64);
-    hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)stage, (uint4*)e->iq, n16, off_b / 16, cap_b / 16);
+    hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)stage, (uint4*)e->iq, n16, off_b / 16, cap_b / 16, ring_flip_mask(e));
     SDR_HIP(hipGetLastError());
     if (half >= 0) {      // (a staging half: busy until the kernel has read it; the caller's own block is the caller's to keep)
         if (!e->slab_done[half]) SDR_HIP(hipEventCreateWithFlags(&e->slab_done[half], hipEventDisableTiming));
@@ -647,7 +663,7 @@ int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_
             }
             const size_t n16 = bytes / 16;
             const unsigned blocks = (unsigned)((n16 + 255) / 256 < 64 ? (n16 + 255) / 256 : 64);
-            hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)iq, (uint4*)e->iq, n16, off_b / 16, cap_b / 16);
+            hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)iq, (uint4*)e->iq, n16, off_b / 16, cap_b / 16, ring_flip_mask(e));
             SDR_HIP(hipGetLastError());
             e->inplace_slab_in_flight = true;      // (sdr_bank_tick_mirrored_end waits for it where nothing else would)
             return SDR_OK;
@@ -704,7 +720,7 @@ int sdr_iq_upload_async(sdr_engine* e, const void* iq, int64_t n_samples, int64_
             const size_t n16 = bytes / 16;
             const unsigned blocks = (unsigned)((n16 + 255) / 256 < 64 ? (n16 + 255) / 256 : 64);
             hipLaunchKernelGGL(ingest_kernel, dim3(blocks), dim3(256), 0, e->stream, (const uint4*)stage, (uint4*)e->iq, n16,
-                               off_b / 16, cap_b / 16);
+                               off_b / 16, cap_b / 16, ring_flip_mask(e));
             SDR_HIP(hipGetLastError());
             SDR_HIP(hipEventRecord(e->slab_done[half], e->stream));
             e->slab_busy[half] = true;

@@ -45,6 +45,7 @@ struct DevBuf {
 // batch) never share a scratch buffer.
 struct StreamCtx {
     hipStream_t stream = nullptr;
+    uint64_t iq_waited_seq = 0;  // the engine's ring writes this stream has been ordered behind (sdr_iq_order_reader)
     DevBuf traj, bits, xchg;     // closed-loop launch scratch: epoch records, [list][n_bits][done] + bits, cluster exchange lines
     void* xchg_tagged = nullptr; // the exchange-line buffer the two-launch ticks' tags refer to (zeroed when it changes)
     unsigned tick_seq = 0;       // sequence number in those tags
@@ -67,10 +68,6 @@ struct sdr_engine {
     // ci8 rings: a second image of the ring with the sign bit of every byte flipped (x + 128 as an unsigned byte) -- what
     // the straight-line E/P/L kernels build their doubles from (correlator_chip.h: one v_perm_b32 per component, no
     // v_xor per dword).  Allocated when such a kernel first runs; brought up to date from the ring's dirty range.
-    void* iq_flip = nullptr;
-    int64_t iq_flip_capacity = 0;
-    int64_t iq_dirty_lo = 0, iq_dirty_hi = 0;   // ring samples [lo, hi) written since the flipped image was refreshed (hi - lo >= capacity: all of it)
-    hipEvent_t iq_flip_done = nullptr;
     int iq_fmt = SDR_FMT_CI8;
 
     // code slots: int8 chips, row stride = code_stride bytes, plus per-slot length
@@ -145,6 +142,11 @@ struct sdr_engine {
     bool srv_running = false;
     int srv_steady_ticks = 0;     // steady ticks in a row with no other call on the engine in between (a server starts at 8)
     struct TickServerState* srv = nullptr;
+    // Writes into the ring are queued on `stream`; a reader launched on ANOTHER stream of the engine (one stream per channel
+    // batch) is ordered behind them by an event: iq_write_seq counts the writes queued (sdr_iq_mark_written), iq_written is
+    // recorded on `stream` behind write number iq_recorded_seq, a stream waits for it once (StreamCtx::iq_waited_seq).
+    uint64_t iq_write_seq = 0, iq_recorded_seq = 0;
+    hipEvent_t iq_written = nullptr;
     bool inplace_slab_in_flight = false; // an ingest kernel on `stream` may still be reading a slab out of the CALLER's page-locked block
     bool srv_slab_pending = false;       // ... or, without a server, for the tick's own launch (ingest_with_tick): whoever needs the ring
                                          // first flushes it the ordinary way (sdr_set_device, the tick itself)
@@ -191,6 +193,8 @@ int sdr_iq_flush_server_slab(sdr_engine* e);
 void sdr_iq_mark_written(sdr_engine* e, int64_t ring_offset, int64_t n_samples);
 // The flipped image of a ci8 ring, up to date with everything queued on e->stream, usable from `stream`.
 int sdr_iq_flipped(sdr_engine* e, hipStream_t stream, const void** out);
+// A launch on ctx's stream that reads the ring: behind every ring write queued on the engine's own stream so far.
+int sdr_iq_order_reader(sdr_engine* e, StreamCtx* ctx);
 
 static inline size_t sdr_fmt_bytes(int fmt) {
     switch (fmt) {

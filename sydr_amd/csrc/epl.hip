@@ -134,7 +134,7 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
     auto launch = [&](auto kernel) {
         if (shmem > 64u * 1024u)  // beyond the default dynamic-LDS grant (long multi-period replicas)
             (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), shmem, stream, e->iq, (const void*)e->iq_flip, e->iq_capacity, d_items, n_items, stride,
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), shmem, stream, e->iq, (const void*)e->iq, e->iq_capacity, d_items, n_items, stride,
                            doubled ? e->luts2 : e->luts, lut_words, doubled ? e->lut2_stride : e->lut_stride, d_spacing, fs, tap0,
                            n_taps_total, d_out, d_setups);
     };
@@ -162,7 +162,7 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
     // the straight-line kernels of the other block lengths (ci8, three taps) live in epl_straight.hip: launched through their address
     auto launch_by_address = [&](const void* kernel) {
         const void* ring = e->iq;
-        const void* flipped = (const void*)e->iq_flip;
+        const void* flipped = (const void*)e->iq;
         int64_t cap = e->iq_capacity;
         int n = n_items, gs = stride, lw = lut_words, ls = doubled ? e->lut2_stride : e->lut_stride, t0 = tap0, nt = n_taps_total;
         const uint32_t* luts = doubled ? e->luts2 : e->luts;
@@ -821,10 +821,8 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
                         (long long)(first + count), p->n_items);
     if (p->doubled)
         if (int rc = ensure_doubled_luts(e, ctx->stream)) return rc;   // (a slot may have been re-staged since the plan was made)
-    if (e->iq_fmt == SDR_FMT_CI8 && (p->wide & (kVariantKSMask | kVariantKI | 3 * kVariantC2))) {
-        const void* flipped = nullptr;                                   // (the straight-line kernels read the flipped ring image)
-        if (int rc = sdr_iq_flipped(e, ctx->stream, &flipped)) return rc;
-    }
+    // (the straight-line kernels build their doubles from sign-flipped bytes: a ci8 ring holds them that way -- correlator.h kCi8Flip)
+    if (int rc = sdr_iq_order_reader(e, ctx)) return rc;      // (behind the uploads queued on the engine's stream so far)
     const sdr_epl_item* items = p->d_items + first;
     double* out = p->d_out + (size_t)first * 2 * p->n_taps;
     const int n = (int)count;
@@ -835,7 +833,7 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
         const size_t shmem = 8 * sizeof(uint32_t) + (size_t)((p->lut_words + 3) & ~3) * sizeof(uint32_t);
         const int shape = (p->wide / kVariantC2) & 3;
         auto launch2 = [&](auto kernel, auto* typed) {
-            hipLaunchKernelGGL(kernel, dim3(n), dim3(kWaveThreads), shmem, st, e->iq, (const void*)e->iq_flip, e->iq_capacity,
+            hipLaunchKernelGGL(kernel, dim3(n), dim3(kWaveThreads), shmem, st, e->iq, (const void*)e->iq, e->iq_capacity,
                                items, n, e->luts, p->lut_words, e->lut_stride, p->d_spacing, p->fs, out, typed);
         };
         if (shape == 1) launch2(epl2_kernel<4, 9, 14, 19>, reinterpret_cast<const sdr::ChipNSetup<4, 9, 14, 19>*>(setups));

@@ -169,8 +169,8 @@ struct Butterfly<8, INV> {
 template <int FMT>
 __device__ __forceinline__ double2 ring_sample(const void* ring, int64_t pos) {
     if (FMT == SDR_FMT_CI8) {
-        const char2 v = static_cast<const char2*>(ring)[pos];
-        return make_double2((double)v.x, (double)v.y);
+        const char2 v = static_cast<const char2*>(ring)[pos];      // (sign-flipped bytes: correlator.h kCi8Flip)
+        return make_double2((double)(int8_t)(v.x ^ 0x80), (double)(int8_t)(v.y ^ 0x80));
     } else if (FMT == SDR_FMT_CI16) {
         const short2 v = static_cast<const short2*>(ring)[pos];
         return make_double2((double)v.x, (double)v.y);

@@ -107,6 +107,7 @@ struct TickServer {
     unsigned* go;                  // device [n_ch * kGoStride]: channel c's release word (the request its cluster may work on; kServerStop: leave)
     uint4* ring16;
     unsigned long long ring_n16;
+    unsigned ring_flip;            // what a slab's dwords are xor-ed with on their way into the ring (ci8: every sign bit, correlator.h kCi8Flip)
     sdr_track_epoch* rec_out;      // device [n_ch]: where the roles write the epoch's record
     // page-locked, written by the channels themselves: the answer (state, record, 1 ran / 0 not ready / -1 stopped), then -- behind a
     // system-wide release -- the number of the request it answers
@@ -233,7 +234,9 @@ __device__ __attribute__((unused)) void tick_server_doorman(const TickServer& s,
                     if (i < hi) {
                         unsigned long long d = first16 + i;
                         if (d >= s.ring_n16) d -= s.ring_n16;
-                        s.ring16[d] = v[k];
+                        uint4 o = v[k];
+                        o.x ^= s.ring_flip, o.y ^= s.ring_flip, o.z ^= s.ring_flip, o.w ^= s.ring_flip;
+                        s.ring16[d] = o;
                     }
                 }
             }
@@ -867,7 +870,9 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
                 for (unsigned long long i = (unsigned long long)bid * THREADS + tid; i < srv.ingest_n16; i += (unsigned long long)kTickIngestGroups * THREADS) {
                     unsigned long long d = srv.ingest_first16 + i;
                     if (d >= srv.ring_n16) d -= srv.ring_n16;
-                    srv.ring16[d] = src[i];
+                    uint4 o = src[i];
+                    o.x ^= srv.ring_flip, o.y ^= srv.ring_flip, o.z ^= srv.ring_flip, o.w ^= srv.ring_flip;
+                    srv.ring16[d] = o;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every wave: its stores have left (the barrier orders them ...)
                 __syncthreads();                                          // ... before lane 0's device-wide release)
@@ -1531,6 +1536,7 @@ int launch_track(sdr_engine* e, StreamCtx* ctx, const TrackRun& r, int* parts_us
         if (take_slab && phase == 3) {
             const size_t sb = sdr_fmt_bytes(e->iq_fmt);
             srv_arg.ring16 = (uint4*)e->iq;
+            srv_arg.ring_flip = e->iq_fmt == SDR_FMT_CI8 ? sdr::kCi8Flip : 0u;
             srv_arg.ring_n16 = (unsigned long long)((size_t)e->iq_capacity * sb / 16);
             srv_arg.ingest_src16 = (unsigned long long)((uintptr_t)e->srv_slab_src / 16);
             srv_arg.ingest_n16 = (unsigned long long)((size_t)e->srv_slab_n * sb / 16);
@@ -2111,6 +2117,7 @@ int sdr_bank_step(sdr_engine* e, sdr_bank* b, const int32_t* channels, int n_ch,
     if (b->tick_open) return sdr_fail(SDR_ERR_STATE, "a tick of this bank is in flight: sdr_bank_tick_mirrored_end first");
     StreamCtx* ctx = sdr_stream_ctx(e, stream_id);
     if (!ctx) return sdr_fail(SDR_ERR_INVALID, "stream id %d does not exist", stream_id);
+    if (int rc = sdr_iq_order_reader(e, ctx)) return rc;      // (behind the uploads queued on the engine's stream so far)
     return bank_run(e, b, ctx, channels, n_ch, n_epochs, records, states_out, epochs_done, nav_bits, max_bits, n_bits);
 }
 
@@ -2297,6 +2304,7 @@ static int tick_server_start(sdr_engine* e, sdr_bank* b, const int32_t* channels
     a.dev = (TickServerDev*)s->dev.ptr;
     a.go = (unsigned*)dp;
     a.ring16 = (uint4*)e->iq;
+    a.ring_flip = e->iq_fmt == SDR_FMT_CI8 ? sdr::kCi8Flip : 0u;
     a.ring_n16 = (unsigned long long)((size_t)e->iq_capacity * sdr_fmt_bytes(e->iq_fmt) / 16);
     a.rec_out = (sdr_track_epoch*)(dp + go_bytes);
     int32_t* d_map = (int32_t*)(dp + go_bytes + (size_t)n * sizeof(sdr_track_epoch));
