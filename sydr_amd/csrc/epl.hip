@@ -253,19 +253,36 @@ struct sdr_epl_plan {
 // repeat in all of its 64 lanes -- with the same functions the run-time-position kernels call per wave.  1.92 M items
 // (60 s x 32 channels) take ~0.1 ms of one launch.
 template <int NT, int KM, int KS, int KI>
-__global__ __launch_bounds__(256) void chip_setup_kernel(const sdr_epl_item* __restrict__ items, int n_items,
-                                                         const double* __restrict__ spacing, double fs, int64_t capacity,
-                                                         sdr::ChipSetup<NT>* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_items) return;
-    const sdr_epl_item it = items[i];
-    double sp[NT];
+__global__ __launch_bounds__(64) void chip_setup_kernel(const sdr_epl_item* __restrict__ items, int n_items,
+                                                        const double* __restrict__ spacing, double fs, int64_t capacity,
+                                                        sdr::ChipSetup<NT>* __restrict__ out) {
+    // One wave per 64 items.  A thread's setup is 480 / 560 bytes: stored where it belongs by the thread itself, a wave's store
+    // instruction touches 64 places that far apart (1.4 ms for the 0.92 GB of a 60 s x 32 channel plan); through LDS the
+    // wave writes its 64 setups -- contiguous in memory -- sixteen bytes per lane, a kilobyte per instruction (round 6).
+    constexpr int kWords = (int)(sizeof(sdr::ChipSetup<NT>) / 16);
+    static_assert(sizeof(sdr::ChipSetup<NT>) % 16 == 0, "setups are copied out in 16-byte granules");
+    __shared__ uint4 stage[64 * kWords];
+    const int i0 = blockIdx.x * 64, i = i0 + threadIdx.x;
+    if (i < n_items) {
+        const sdr_epl_item it = items[i];
+        double sp[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) sp[t] = spacing[t];
-    sdr::ChipSetup<NT> S;
-    sdr::chip_setup<NT, KM, KS, KI>(it.n_samples, it.start_sample, capacity, it.carrier_hz, it.rem_code, it.code_step, sp, fs,
-                                kWaveThreads, S);
-    out[i] = S;
+        for (int t = 0; t < NT; ++t) sp[t] = spacing[t];
+        sdr::ChipSetup<NT> S;
+        sdr::chip_setup<NT, KM, KS, KI>(it.n_samples, it.start_sample, capacity, it.carrier_hz, it.rem_code, it.code_step, sp, fs,
+                                    kWaveThreads, S);
+        // (granule w of every lane side by side: lane-major slots would put 64 lanes 30 granules apart on the same banks)
+        const uint4* const src = reinterpret_cast<const uint4*>(&S);
+#pragma unroll
+        for (int w = 0; w < kWords; ++w) stage[w * 64 + threadIdx.x] = src[w];
+    }
+    __syncthreads();
+    const int n_here = n_items - i0 < 64 ? n_items - i0 : 64;
+    uint4* const dst = reinterpret_cast<uint4*>(out + i0);
+    for (int g = threadIdx.x; g < n_here * kWords; g += 64) {
+        const int item = g / kWords, w = g - item * kWords;
+        dst[g] = stage[w * 64 + item];
+    }
 }
 // ... *missed counts the items the several-chips-per-lane scheme does not cover (their setups say so, and the kernel
 // redoes them per sample).
@@ -289,48 +306,85 @@ __global__ __launch_bounds__(256) void chipn_setup_kernel(const sdr_epl_item* __
 // channel plan took the host 20-30 ms of the 34 ms a plan cost; the launch takes ~0.1 ms).
 __device__ __forceinline__ unsigned long long dbits(double x) { return (unsigned long long)__double_as_longlong(x); }
 
-// Two rule sets at once (the list as it is and its half-chip view): one upload, one launch, one read-back.
+// Two rule sets at once (the list as it is and its half-chip view): one upload, one launch, one read-back.  A thread walks
+// the list with the grid's stride and keeps its own statistics; a wave reduces them and adds them to the list's with ONE set
+// of atomics -- at 1.92 M items a set per 64 items was 420 k atomics on seven addresses, 2.2 ms of a 4.5 ms plan (round 6).
 __global__ __launch_bounds__(256) void validate_items_kernel(const sdr_epl_item* __restrict__ items, int n_items, ItemRules r1,
                                                              ItemRules r2, const int32_t* __restrict__ code_len,
                                                              ItemStats* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool have = i < n_items;
-    sdr_epl_item it = {};
-    if (have) it = items[i];
+    const int stride = (int)(gridDim.x * 256);
+    // (a lane without an item, or with a bad one, carries the neutral element of every reduction: all 64 lanes take part)
+    int ml[2] = {0, 0}, mlo[2] = {0x7fffffff, 0x7fffffff}, mhi[2] = {0, 0}, a12[2] = {1, 1}, fb[2] = {0x7fffffff, 0x7fffffff};
+    unsigned long long mx[2] = {0ull, 0ull}, mn[2] = {~0ull, ~0ull};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_items; i += stride) {
+        const sdr_epl_item it = items[i];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const ItemRules& r = v ? r2 : r1;
+            int maxlen = 0, m_chip = 0;
+            double step = 0.0, lo, hi;
+            bool split = true;
+            const int bad = check_item(it, r, code_len, maxlen, step, m_chip, split, lo, hi);
+            if (bad) {
+                fb[v] = min(fb[v], i);
+            } else {
+                ml[v] = max(ml[v], maxlen);
+                const unsigned long long sb = dbits(step);
+                mx[v] = sb > mx[v] ? sb : mx[v];
+                mn[v] = sb < mn[v] ? sb : mn[v];
+                mlo[v] = min(mlo[v], m_chip);
+                mhi[v] = max(mhi[v], m_chip);
+                a12[v] &= split ? 1 : 0;
+            }
+        }
+    }
+#pragma unroll
     for (int v = 0; v < 2; ++v) {
-        const ItemRules& r = v ? r2 : r1;
-        // (a lane without an item, or with a bad one, carries the neutral element of every reduction: all 64 lanes take part)
-        int maxlen = 0, bad = 0;
-        double step = 0.0, lo, hi;
-        int m_chip = 0;
-        bool split = true;
-        if (have) bad = check_item(it, r, code_len, maxlen, step, m_chip, split, lo, hi);
-        const bool good = have && !bad;
-        int ml = good ? maxlen : 0;
-        unsigned long long mx = good ? dbits(step) : 0ull, mn = good ? dbits(step) : ~0ull;
-        int mlo = good ? m_chip : 0x7fffffff, mhi = good ? m_chip : 0, a12 = (!good || split) ? 1 : 0;
-        int fb = bad ? i : 0x7fffffff;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            ml = max(ml, __shfl_xor(ml, off, 64));
-            const unsigned long long ox = __shfl_xor(mx, off, 64), on = __shfl_xor(mn, off, 64);
-            mx = ox > mx ? ox : mx;
-            mn = on < mn ? on : mn;
-            mlo = min(mlo, __shfl_xor(mlo, off, 64));
-            mhi = max(mhi, __shfl_xor(mhi, off, 64));
-            a12 &= __shfl_xor(a12, off, 64);
-            fb = min(fb, __shfl_xor(fb, off, 64));
+            ml[v] = max(ml[v], __shfl_xor(ml[v], off, 64));
+            const unsigned long long ox = __shfl_xor(mx[v], off, 64), on = __shfl_xor(mn[v], off, 64);
+            mx[v] = ox > mx[v] ? ox : mx[v];
+            mn[v] = on < mn[v] ? on : mn[v];
+            mlo[v] = min(mlo[v], __shfl_xor(mlo[v], off, 64));
+            mhi[v] = max(mhi[v], __shfl_xor(mhi[v], off, 64));
+            a12[v] &= __shfl_xor(a12[v], off, 64);
+            fb[v] = min(fb[v], __shfl_xor(fb[v], off, 64));
+        }
+    }
+    // the block's four waves through LDS, then one set of atomics per block and rule set
+    __shared__ int sh_i[4][2][5];
+    __shared__ unsigned long long sh_u[4][2][2];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            sh_i[wave][v][0] = ml[v], sh_i[wave][v][1] = mlo[v], sh_i[wave][v][2] = mhi[v], sh_i[wave][v][3] = a12[v], sh_i[wave][v][4] = fb[v];
+            sh_u[wave][v][0] = mx[v], sh_u[wave][v][1] = mn[v];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int v = threadIdx.x;
+        int b_ml = 0, b_lo = 0x7fffffff, b_hi = 0, b_a12 = 1, b_fb = 0x7fffffff;
+        unsigned long long b_mx = 0ull, b_mn = ~0ull;
+        for (int w = 0; w < 4; ++w) {
+            b_ml = max(b_ml, sh_i[w][v][0]);
+            b_lo = min(b_lo, sh_i[w][v][1]);
+            b_hi = max(b_hi, sh_i[w][v][2]);
+            b_a12 &= sh_i[w][v][3];
+            b_fb = min(b_fb, sh_i[w][v][4]);
+            b_mx = sh_u[w][v][0] > b_mx ? sh_u[w][v][0] : b_mx;
+            b_mn = sh_u[w][v][1] < b_mn ? sh_u[w][v][1] : b_mn;
         }
         ItemStats* o = out + v;
-        if ((threadIdx.x & 63) == 0) {
-            atomicMax(&o->maxlen, ml);
-            atomicMax(&o->max_step_bits, mx);
-            atomicMin(&o->min_step_bits, mn);
-            atomicMin(&o->m_lo, mlo);
-            atomicMax(&o->m_hi, mhi);
-            if (!a12) atomicAnd(&o->all_split, 0);
-            if (fb != 0x7fffffff) atomicMin(&o->first_bad, fb);
-        }
+        atomicMax(&o->maxlen, b_ml);
+        atomicMax(&o->max_step_bits, b_mx);
+        atomicMin(&o->min_step_bits, b_mn);
+        atomicMin(&o->m_lo, b_lo);
+        atomicMax(&o->m_hi, b_hi);
+        if (!b_a12) atomicAnd(&o->all_split, 0);
+        if (b_fb != 0x7fffffff) atomicMin(&o->first_bad, b_fb);
     }
 }
 
@@ -448,7 +502,8 @@ static int validate_items_dev(sdr_engine* e, const sdr_epl_item* d_items, const 
         host[v] = ItemStats{0x7fffffff, 0, 0, 0ull, ~0ull, 0x7fffffff, 0, (v ? r2 : r1).want_s12 ? 1 : 0};
     }
     SDR_HIP(hipMemcpyAsync(e->ws_stats.ptr, host, 2 * sizeof(ItemStats), hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(validate_items_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, e->stream, d_items, n_items, r1, r2,
+    const unsigned check_blocks = (unsigned)((n_items + 255) / 256) < 2048u ? (unsigned)((n_items + 255) / 256) : 2048u;      // (eight per CU)
+    hipLaunchKernelGGL(validate_items_kernel, dim3(check_blocks), dim3(256), 0, e->stream, d_items, n_items, r1, r2,
                        (const int32_t*)e->code_len, static_cast<ItemStats*>(e->ws_stats.ptr));
     SDR_HIP(hipGetLastError());
     SDR_HIP(hipMemcpyAsync(host, e->ws_stats.ptr, 2 * sizeof(ItemStats), hipMemcpyDeviceToHost, e->stream));
@@ -666,7 +721,8 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
             err = plan_take(e, (void**)&p->d_setups, bytes + 64, &p->bytes_setups);     // (+ the counter of items a scheme does not cover)
         }
     };
-    const unsigned setup_grid = (unsigned)((n_items + 255) / 256);
+    const unsigned setup_grid = (unsigned)((n_items + 255) / 256);       // (the two-chips-per-lane setups: 256 items per block)
+    const unsigned setup_grid64 = (unsigned)((n_items + 63) / 64);        // (the one-chip-per-lane setups: a wave per 64 items)
     if (err == hipSuccess && e->iq_fmt == SDR_FMT_CI8 && (wide & 255) >= kChipMax && (wide & (kVariantKSMask | kVariantKI)) &&
         (n_taps == 3 || n_taps == 5)) {
         reserve_setups(n_taps == 3 ? sizeof(sdr::ChipSetup<3>) : sizeof(sdr::ChipSetup<5>));
@@ -710,7 +766,7 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
                 sdr::ChipSetup<5>* d5 = reinterpret_cast<sdr::ChipSetup<5>*>(p->d_setups);
                 switch (km) {
 #define SDR_SETUP5_CASE(K) \
-    case K: hipLaunchKernelGGL((chip_setup_kernel<5, K, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items, p->d_spacing, fs, e->iq_capacity, d5); break;
+    case K: hipLaunchKernelGGL((chip_setup_kernel<5, K, 0, 1>), dim3(setup_grid64), dim3(64), 0, e->stream, p->d_items, n_items, p->d_spacing, fs, e->iq_capacity, d5); break;
                     SDR_SETUP5_CASE(16) SDR_SETUP5_CASE(17) SDR_SETUP5_CASE(18) SDR_SETUP5_CASE(19) SDR_SETUP5_CASE(20) SDR_SETUP5_CASE(21)
                     SDR_SETUP5_CASE(22) SDR_SETUP5_CASE(23) SDR_SETUP5_CASE(24) SDR_SETUP5_CASE(25)
 #undef SDR_SETUP5_CASE
@@ -720,8 +776,8 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
                 sdr::ChipSetup<3>* d3 = reinterpret_cast<sdr::ChipSetup<3>*>(p->d_setups);
                 switch (km * 2 + (ks ? 1 : 0)) {
 #define SDR_SETUP_CASE(K)                                                                                                              \
-    case 2 * K + 1: hipLaunchKernelGGL((chip_setup_kernel<3, K, K / 2, 0>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items, p->d_spacing, fs, e->iq_capacity, d3); break; \
-    case 2 * K: hipLaunchKernelGGL((chip_setup_kernel<3, K, 0, 1>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items, n_items, p->d_spacing, fs, e->iq_capacity, d3); break;
+    case 2 * K + 1: hipLaunchKernelGGL((chip_setup_kernel<3, K, K / 2, 0>), dim3(setup_grid64), dim3(64), 0, e->stream, p->d_items, n_items, p->d_spacing, fs, e->iq_capacity, d3); break; \
+    case 2 * K: hipLaunchKernelGGL((chip_setup_kernel<3, K, 0, 1>), dim3(setup_grid64), dim3(64), 0, e->stream, p->d_items, n_items, p->d_spacing, fs, e->iq_capacity, d3); break;
                     SDR_SETUP_CASE(15) SDR_SETUP_CASE(16) SDR_SETUP_CASE(17) SDR_SETUP_CASE(18) SDR_SETUP_CASE(19) SDR_SETUP_CASE(20)
                     SDR_SETUP_CASE(21) SDR_SETUP_CASE(22) SDR_SETUP_CASE(23) SDR_SETUP_CASE(24) SDR_SETUP_CASE(25)
 #undef SDR_SETUP_CASE
