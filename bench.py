@@ -309,11 +309,14 @@ def rates_leg(eng, seconds=2.0):
     reaches of the roof by SURVEY 8(d)'s bytes -- one launch per pass over a `seconds` stream, outputs of the first
     epochs checked against the oracle."""
     from oracle import sydr_oracle as orc
-    from sydr_amd.engine import FMT_CI8
+    from sydr_amd.engine import FMT_CI8, FMT_CI16
     out = []
-    for fs in (4e6, 10e6, 12e6, 16.368e6, 18e6, 20e6, 22e6, 25e6, 32e6, 40e6, 50e6):
+    # (..., and 16-bit recordings -- rfsignal.py:36-41 reads int16 as readily as int8 -- at the shipped rate and the headline's:
+    # SURVEY 8(d) charges 4 B per channel-sample there)
+    for fs, fmt in [(f, FMT_CI8) for f in (4e6, 10e6, 12e6, 16.368e6, 18e6, 20e6, 22e6, 25e6, 32e6, 40e6, 50e6)] + [(10e6, FMT_CI16), (25e6, FMT_CI16)]:
+        bytes_per_sample = 2.0 if fmt == FMT_CI8 else 4.0
         total = int(seconds * fs) // 8 * 8
-        eng.iq_alloc(total, FMT_CI8)
+        eng.iq_alloc(total, fmt)
         eng.code_slots(N_CH)
         sats = satellites(N_CH, seed=20260020)
         for k, sat in enumerate(sats):
@@ -361,13 +364,18 @@ def rates_leg(eng, seconds=2.0):
                        "one chip per lane, compile-time block length" if w > 26 else
                        "one chip per lane, run-time positions" if w >= 26 else
                        f"{w}-sample boundary groups" if w else "per sample")
-        out.append({"fs_hz": fs, "samples_per_chip": fs / CODE_RATE, "Msamples_per_s": ch_samples / N_CH / avg_s / 1e6 if launches else 0.0,
-                    "x_realtime": ch_samples / N_CH / avg_s / fs if launches else 0.0, "kernel_variant": kernel_of_variant(variant & 0xFFFF, len(SPACING)),
+        kname = kernel_of_variant(variant & 0xFFFF, len(SPACING))
+        if fmt == FMT_CI16:
+            kname = kname.replace("<0,", "<1,", 1)             # (the template's first argument is the ring format)
+        out.append({"fs_hz": fs, "iq_format": "ci8" if fmt == FMT_CI8 else "ci16", "samples_per_chip": fs / CODE_RATE,
+                    "Msamples_per_s": ch_samples / N_CH / avg_s / 1e6 if launches else 0.0,
+                    "x_realtime": ch_samples / N_CH / avg_s / fs if launches else 0.0, "kernel_variant": kname,
                     "correlator": family, "plan_variant": int(variant),
-                    "roofline_frac": 2.0 * ch_samples / avg_s / 1e9 / HBM_PEAK_GBS if launches else 0.0,
+                    "roofline_frac": bytes_per_sample * ch_samples / avg_s / 1e9 / HBM_PEAK_GBS if launches else 0.0,
                     "max_rel_err_gpu_vs_oracle": err})
-    return {"config": {"workload": f"32 channels, E/P/L +-0.5 chip, ci8, {seconds:g} s stream per rate, one launch per pass (kernel time "
-                                   "from HIP events on the launch stream); roofline_frac = 2 B per channel-sample / 8 TB/s"},
+    return {"config": {"workload": f"32 channels, E/P/L +-0.5 chip, ci8 (and ci16 at 10 / 25 MHz), {seconds:g} s stream per rate, one launch per "
+                                   "pass (kernel time from HIP events on the launch stream); roofline_frac = 2 B (ci16: 4 B) per "
+                                   "channel-sample / 8 TB/s"},
             "rates": out}
 
 
@@ -600,8 +608,8 @@ def per_tick_c_leg(ticks=800):
     # (an optional leg never costs the line: under a profiler's preloaded library -- gcc is a driver that re-execs, and the
     # child's kernels would land in the same output directory -- it is skipped; no compiler, or a child that cannot start,
     # is an "error" entry)
-    if os.environ.get("LD_PRELOAD") or any(k.startswith(("ROCP", "ROCPROFILER")) for k in os.environ):
-        return {"skipped": "under a profiler (LD_PRELOAD / ROCP* set): no child processes"}
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ):
+        return {"skipped": "under rocprofv3 (its library preloaded / ROCP* set): no child processes"}
     with tempfile.TemporaryDirectory() as tmp:
         exe = os.path.join(tmp, "receiver_loop")
         lib_dir = os.path.join(REPO, "sydr_amd")
@@ -971,7 +979,8 @@ def flat_scalars(result):
                 "multignss_acq_ms_per_prn": get("multignss", "acquisition", "value")}
         rates = get("rates", "rates") or []
         for row in rates:
-            flat[f"rate_{row['fs_hz'] / 1e6:g}MHz_frac".replace(".", "p")] = row.get("roofline_frac")
+            tag = "" if row.get("iq_format", "ci8") == "ci8" else "_" + row["iq_format"]
+            flat[f"rate_{row['fs_hz'] / 1e6:g}MHz{tag}_frac".replace(".", "p")] = row.get("roofline_frac")
         r.update({k: v for k, v in flat.items() if v is not None})
     c = result.get("cpu_baseline")
     if isinstance(c, dict):

@@ -1036,6 +1036,18 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         st.code_step = sh->ep.code_step;
     };
     unsigned server_tick = 0;                              // (server) requests this workgroup has seen
+#ifndef SDR_DENSE_STAGGER
+#define SDR_DENSE_STAGGER 0
+#endif
+    if constexpr (!kCluster && THREADS == 256 && SDR_DENSE_STAGGER != 0) {
+        // Three workgroups share a compute unit, and workgroups that start together stay together: all three correlate at
+        // once (the vector pipes shared three ways), then all three close their loops at once (one wave per role, the pipes
+        // nearly idle).  The dispatcher fills the 256 compute units once before it gives any a second workgroup, so the
+        // launch's thirds ARE the slots: the second and third start a third / two thirds of an epoch later and their
+        // role phases fall into the others' correlation.
+        const int slot_on_cu = ((int)blockIdx.x / 256) % 3;
+        for (int k = 0; k < slot_on_cu * SDR_DENSE_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);      // (8128 cycles = 3.4 us each)
+    }
     for (int epoch = 0; epoch < n_epochs; ++epoch) {
         TRACK_MARK(5);
         __syncthreads();

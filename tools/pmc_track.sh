@@ -13,10 +13,10 @@ cd /tmp && export TMPDIR=/tmp
 PROG="$ROOT/tools/closed_dense_only.py"
 CH="768 256 32"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/track_stats" -- python3 "$PROG" $CH > "$OUT/track_stats.log" 2>&1 || echo "(stats pass ended non-zero)"
-timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_track_sq" -- python3 "$PROG" $CH > "$OUT/track_pmc_sq.log" 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --output-format csv -d "$OUT/pmc_track_sq2" -- python3 "$PROG" $CH > "$OUT/track_pmc_sq2.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_track_sq" -- python3 "$PROG" $CH > "$OUT/track_pmc_sq.log" 2>&1 || echo "(pass ended non-zero: the profiler crashes in its own teardown after the files are written)"
+timeout -k 10 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --output-format csv -d "$OUT/pmc_track_sq2" -- python3 "$PROG" $CH > "$OUT/track_pmc_sq2.log" 2>&1 || echo "(pass ended non-zero: the profiler crashes in its own teardown after the files are written)"
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_FLAT SQ_INSTS_FLAT_LDS_ONLY SQ_INSTS_GDS SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_FMA_F64 --output-format csv -d "$OUT/pmc_track_sq3" -- python3 "$PROG" $CH > "$OUT/track_pmc_sq3.log" 2>&1 || true
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_track_fetch" -- python3 "$PROG" $CH > "$OUT/track_pmc_fetch.log" 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_track_write" -- python3 "$PROG" $CH > "$OUT/track_pmc_write.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_track_fetch" -- python3 "$PROG" $CH > "$OUT/track_pmc_fetch.log" 2>&1 || echo "(pass ended non-zero: the profiler crashes in its own teardown after the files are written)"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_track_write" -- python3 "$PROG" $CH > "$OUT/track_pmc_write.log" 2>&1 || echo "(pass ended non-zero: the profiler crashes in its own teardown after the files are written)"
 find "$OUT/track_stats" -name "*kernel_trace.csv" -size +8M -delete
 tail -3 "$OUT/track_stats.log"
