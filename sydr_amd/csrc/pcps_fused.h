@@ -46,6 +46,12 @@
 #ifndef FUSED_BUFLOAD
 #define FUSED_BUFLOAD 0      // operand loads as buffer loads (scalar descriptor + one per-lane offset) instead of 64-bit addresses
 #endif
+#ifndef FUSED_SPLIT_S2Y
+#define FUSED_SPLIT_S2Y 0    // whole transforms: waves 0-3 do BOTH halves of a round's second row stage while waves 4-7 do the next round's Y step
+                             // (measured, same box, ms per 32 x 41 search: 0.2077 against 0.2039 at 25 MHz, 0.4514 against 0.4482 at 50 MHz --
+                             // a SIMD's one arithmetic wave issues a dependent fp64 instruction every ~7 cycles, two share the pipe at 4: the
+                             // stage wants both of a SIMD's waves in it; not kept)
+#endif
 #ifndef FUSED_MERGE_Y
 #define FUSED_MERGE_Y 0      // the next round's Y-in-place step inside this round's second row stage (3 barriers per round, not 4)
 #endif
@@ -434,6 +440,29 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
             for (int q = 0; q < 5; ++q) col[q * N2] = t5[q];
         }
     };
+    // FUSED_SPLIT_S2Y (whole transforms; round 6; OFF: see the switch).  The Y step is LDS traffic with a sliver of arithmetic, the second row stage
+    // arithmetic with a sliver of LDS traffic, and as phases of their own -- every wave in both, a barrier between -- neither
+    // covers the other (2.5 k + 2.1 k cycles per round).  Round rho + 1's Y step needs nothing of round rho but its first
+    // stage's stores into the other buffer: waves 4-7 do it (four butterflies per thread: 250 threads x 4 = the 1000 of a
+    // round) WHILE waves 0-3 do both halves of round rho's second stage one after the other -- every SIMD holds one wave
+    // of each kind.
+    constexpr bool kSplit = FUSED_SPLIT_S2Y && WHOLE && !FUSED_MERGE_Y;
+    auto y_by_upper_waves = [&](double2* X) {
+        const int ty = t_ - 256;
+        if (ty >= 0 && ty < 250) {
+            const int yr = ty / 50, yc = ty - 50 * yr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double2* const col = X + (5 * yr) * N2 + yc + 50 * j;
+                double2 t5[5];
+#pragma unroll
+                for (int rr = 0; rr < 5; ++rr) t5[rr] = col[rr * N2];
+                ibf5(t5);
+#pragma unroll
+                for (int q = 0; q < 5; ++q) col[q * N2] = t5[q];
+            }
+        }
+    };
     // the row's four-step twiddle w_N^(k1 (e + 20 m)) = base * step^m: two scattered table reads per round, requested
     // a phase ahead
 #if FUSED_MERGE_Y
@@ -469,11 +498,14 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
         const int si = r2_ & 31, sk = (r2_ >> 5) & 15, sw2 = (r2_ >> 10) & 7, kf0 = (r2_ >> 13) & 4095;
         const double2 tw_base = twi((rho + k1b) * re), tw_step = twi(20 * (rho + k1b));
 #if !FUSED_MERGE_Y
-        if (live) y_in_place(X);
-        // w200^(e k''), k'' = 1..9, stored [k'' - 1][e]: the sixteen lanes of a read group take sixteen consecutive entries
-        // (indexed e * k'' the strides 2, 4, 6, 8 cost 2-, 4-, 2-, 8-way conflicts: 1.6 k cycles per transform)
-        if ((rho == 0 || !WHOLE) && tid < 180) tab[tid] = twi((N / 200) * ((tid % 20) * (tid / 20 + 1)));   // (every w125 read lies before the last barrier)
-        __syncthreads();
+        // (kSplit: rounds 1-4 had their Y step done by waves 4-7 during the round before's second row stage, barrier included)
+        if (!kSplit || rho == 0) {
+            if (live) y_in_place(X);
+            // w200^(e k''), k'' = 1..9, stored [k'' - 1][e]: the sixteen lanes of a read group take sixteen consecutive entries
+            // (indexed e * k'' the strides 2, 4, 6, 8 cost 2-, 4-, 2-, 8-way conflicts: 1.6 k cycles per transform)
+            if ((rho == 0 || !WHOLE) && tid < 180) tab[tid] = twi((N / 200) * ((tid % 20) * (tid / 20 + 1)));   // (every w125 read lies before the last barrier)
+            __syncthreads();
+        }
         FUSED_STAMP(4);
 #endif
         // ---- rows, first stage (reads first; then the parked round rho + 1 moves into the buffer round rho - 1 has
@@ -529,104 +561,113 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
         // ---- rows, second stage: 20 = 2 x 10, radix-2 decimation in frequency while reading; and the next round's Y
         // in place in the other buffer (its stores overlap this stage's arithmetic)
         double2 u[10];
-        if (live2) {
-            // element (e, k'') of the row sits at (10 e + k'') ^ swizzle: with e = 4 a + q that is ((k'' + 2 q) ^ swizzle) + 40 a + 8 q
-            // -- four per-lane places, the rest a constant
-            const double2* __restrict__ const row = X + si * N2;
-            const double2* __restrict__ const rowq[4] = {row + (sk ^ sw2), row + ((sk + 2) ^ sw2), row + ((sk + 4) ^ sw2), row + ((sk + 6) ^ sw2)};
+        if (kSplit && tid >= 256) {
+            if (rho < 4) y_by_upper_waves(Xo);              // (waves 4-7: the next round's Y step, in the other buffer)
+        } else {
+#pragma unroll 1
+            for (int hh = 0; hh < (kSplit ? 2 : 1); ++hh) {  // (kSplit: both halves by the same lane, one after the other)
+                const int hcur = kSplit ? hh : h;
+            if (live2) {
+                // element (e, k'') of the row sits at (10 e + k'') ^ swizzle: with e = 4 a + q that is ((k'' + 2 q) ^ swizzle) + 40 a + 8 q
+                // -- four per-lane places, the rest a constant
+                const double2* __restrict__ const row = X + si * N2;
+                const double2* __restrict__ const rowq[4] = {row + (sk ^ sw2), row + ((sk + 2) ^ sw2), row + ((sk + 4) ^ sw2), row + ((sk + 6) ^ sw2)};
 #pragma unroll
-            for (int t0 = 0; t0 < 10; t0 += 5) {     // (five pairs of reads in flight: registers)
-                double2 lo[5], hi[5];
+                for (int t0 = 0; t0 < 10; t0 += 5) {     // (five pairs of reads in flight: registers)
+                    double2 lo[5], hi[5];
 #pragma unroll
-                for (int t = 0; t < 5; ++t) {
-                    const int e_lo = t0 + t, e_hi = t0 + t + 10;
-                    lo[t] = rowq[e_lo & 3][10 * e_lo - 2 * (e_lo & 3)];
-                    hi[t] = rowq[e_hi & 3][10 * e_hi - 2 * (e_hi & 3)];
+                    for (int t = 0; t < 5; ++t) {
+                        const int e_lo = t0 + t, e_hi = t0 + t + 10;
+                        lo[t] = rowq[e_lo & 3][10 * e_lo - 2 * (e_lo & 3)];
+                        hi[t] = rowq[e_hi & 3][10 * e_hi - 2 * (e_hi & 3)];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) u[t0 + t] = hcur ? csub(lo[t], hi[t]) : cadd(lo[t], hi[t]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int t = 0; t < 5; ++t) u[t0 + t] = h ? csub(lo[t], hi[t]) : cadd(lo[t], hi[t]);
-                __builtin_amdgcn_sched_barrier(0);
             }
-        }
 #if FUSED_MERGE_Y
-        if (rho < 4 && live) y_in_place(Xo);
+            if (rho < 4 && live) y_in_place(Xo);
 #ifdef FUSED_MERGE_SB
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
 #endif
 #endif
-        if (live2) {
-            if (h) {
+            if (live2) {
+                if (hcur) {
 #pragma unroll
-                for (int t = 1; t < 10; ++t) u[t] = cmul_conj(u[t], make_double2(kW20X[t], kW20Y[t]));
-            }
-            idft10c(u);
-            const int k_first = kf0 + rho;
-            double sqv[10];
-#pragma unroll
-            for (int g = 0; g < 10; ++g) {
-                sqv[g] = __builtin_fma(u[g].x, u[g].x, u[g].y * u[g].y);
-                if constexpr (SECOND) {        // (a column the peak comparison excludes never becomes a candidate: -2 loses against -1)
-                    const int k = TERMS * (k_first + 20 * N1 * (g / 2 + 5 * (g % 2))) + par;     // (sample of the whole row)
-                    sqv[g] = (k < a1 || (k >= b0 && k < b1)) ? sqv[g] : -2.0;
+                    for (int t = 1; t < 10; ++t) u[t] = cmul_conj(u[t], make_double2(kW20X[t], kW20Y[t]));
                 }
-            }
-            const double m01 = fmax(sqv[0], sqv[1]), m23 = fmax(sqv[2], sqv[3]), m45 = fmax(sqv[4], sqv[5]), m67 = fmax(sqv[6], sqv[7]),
-                         m89 = fmax(sqv[8], sqv[9]);
-            const double round_max = fmax(fmax(fmax(m01, m23), fmax(m45, m67)), m89);
-            // (the lane's own best with the same margin: a value within 2^-48 of it must still meet it below)
-            const bool candidate = round_max >= fmax(floor_sq, best_sq * (1.0 - 0x1p-40));
-            if (__any(candidate)) {
-#ifdef SDR_FUSED_STAMPS
-                if (tid == 0) g_fused_stamps[blockIdx.x & 255][6] += 1000000;    // (diagnostic: rounds of wave 0 that keep books)
-#endif
-                // Ordering by the squared magnitude.  A candidate within 2^-48 of the lane's best has to be compared through
-                // the scaled hypot -- the reference's np.abs -- with an exact tie keeping the smaller index (pcps_fast.h): the
-                // round is then redone from the state it started with by ONE run-time loop over a copy of the ten values
-                // (a private array: scratch memory, touched on this path alone).  Inlined per candidate that comparison
-                // made the kernel several times the instruction cache.
-                const double sq0 = best_sq, x0 = best_x, y0 = best_y;
-                const int k0 = best_k;
-                bool tie = false;
+                idft10c(u);
+                const int k_first = kf0 + rho + (kSplit ? N1 * 10 * hh : 0);
+                double sqv[10];
 #pragma unroll
                 for (int g = 0; g < 10; ++g) {
-                    const int p = g / 2 + 5 * (g % 2);
-                    const int k = k_first + 20 * N1 * p;              // code phase = position in the transform
-                    const double sq = sqv[g];
-                    const bool take = sq > best_sq;
-                    tie |= sq >= 0.0 && fabs(sq - best_sq) <= best_sq * 0x1p-48;
-                    best_sq = take ? sq : best_sq;
-                    best_x = take ? u[g].x : best_x;
-                    best_y = take ? u[g].y : best_y;
-                    best_k = take ? k : best_k;
+                    sqv[g] = __builtin_fma(u[g].x, u[g].x, u[g].y * u[g].y);
+                    if constexpr (SECOND) {        // (a column the peak comparison excludes never becomes a candidate: -2 loses against -1)
+                        const int k = TERMS * (k_first + 20 * N1 * (g / 2 + 5 * (g % 2))) + par;     // (sample of the whole row)
+                        sqv[g] = (k < a1 || (k >= b0 && k < b1)) ? sqv[g] : -2.0;
+                    }
                 }
-                if (__builtin_expect(__any(tie), 0)) {
-                    double2 copy[10];
+                const double m01 = fmax(sqv[0], sqv[1]), m23 = fmax(sqv[2], sqv[3]), m45 = fmax(sqv[4], sqv[5]), m67 = fmax(sqv[6], sqv[7]),
+                             m89 = fmax(sqv[8], sqv[9]);
+                const double round_max = fmax(fmax(fmax(m01, m23), fmax(m45, m67)), m89);
+                // (the lane's own best with the same margin: a value within 2^-48 of it must still meet it below)
+                const bool candidate = round_max >= fmax(floor_sq, best_sq * (1.0 - 0x1p-40));
+                if (__any(candidate)) {
+#ifdef SDR_FUSED_STAMPS
+                    if (tid == 0) g_fused_stamps[blockIdx.x & 255][6] += 1000000;    // (diagnostic: rounds of wave 0 that keep books)
+#endif
+                    // Ordering by the squared magnitude.  A candidate within 2^-48 of the lane's best has to be compared through
+                    // the scaled hypot -- the reference's np.abs -- with an exact tie keeping the smaller index (pcps_fast.h): the
+                    // round is then redone from the state it started with by ONE run-time loop over a copy of the ten values
+                    // (a private array: scratch memory, touched on this path alone).  Inlined per candidate that comparison
+                    // made the kernel several times the instruction cache.
+                    const double sq0 = best_sq, x0 = best_x, y0 = best_y;
+                    const int k0 = best_k;
+                    bool tie = false;
 #pragma unroll
-                    for (int g = 0; g < 10; ++g) copy[g] = u[g];
-                    best_sq = sq0;
-                    best_x = x0;
-                    best_y = y0;
-                    best_k = k0;
-#pragma unroll 1
                     for (int g = 0; g < 10; ++g) {
                         const int p = g / 2 + 5 * (g % 2);
-                        const int k = k_first + 20 * N1 * p;
-                        const double2 x = copy[g];
-                        double sq = __builtin_fma(x.x, x.x, x.y * x.y);
-                        if (SECOND && !(TERMS * k + par < a1 || (TERMS * k + par >= b0 && TERMS * k + par < b1))) sq = -2.0;
-                        bool take = sq > best_sq;
-                        if (sq >= 0.0 && fabs(sq - best_sq) <= best_sq * 0x1p-48) {
-                            const double m_new = hypot(x.x * a.scale, x.y * a.scale), m_old = hypot(best_x * a.scale, best_y * a.scale);
-                            take = m_new > m_old || (m_new == m_old && k < best_k);
-                        }
+                        const int k = k_first + 20 * N1 * p;              // code phase = position in the transform
+                        const double sq = sqv[g];
+                        const bool take = sq > best_sq;
+                        tie |= sq >= 0.0 && fabs(sq - best_sq) <= best_sq * 0x1p-48;
                         best_sq = take ? sq : best_sq;
-                        best_x = take ? x.x : best_x;
-                        best_y = take ? x.y : best_y;
+                        best_x = take ? u[g].x : best_x;
+                        best_y = take ? u[g].y : best_y;
                         best_k = take ? k : best_k;
+                    }
+                    if (__builtin_expect(__any(tie), 0)) {
+                        double2 copy[10];
+#pragma unroll
+                        for (int g = 0; g < 10; ++g) copy[g] = u[g];
+                        best_sq = sq0;
+                        best_x = x0;
+                        best_y = y0;
+                        best_k = k0;
+#pragma unroll 1
+                        for (int g = 0; g < 10; ++g) {
+                            const int p = g / 2 + 5 * (g % 2);
+                            const int k = k_first + 20 * N1 * p;
+                            const double2 x = copy[g];
+                            double sq = __builtin_fma(x.x, x.x, x.y * x.y);
+                            if (SECOND && !(TERMS * k + par < a1 || (TERMS * k + par >= b0 && TERMS * k + par < b1))) sq = -2.0;
+                            bool take = sq > best_sq;
+                            if (sq >= 0.0 && fabs(sq - best_sq) <= best_sq * 0x1p-48) {
+                                const double m_new = hypot(x.x * a.scale, x.y * a.scale), m_old = hypot(best_x * a.scale, best_y * a.scale);
+                                take = m_new > m_old || (m_new == m_old && k < best_k);
+                            }
+                            best_sq = take ? sq : best_sq;
+                            best_x = take ? x.x : best_x;
+                            best_y = take ? x.y : best_y;
+                            best_k = take ? k : best_k;
+                        }
                     }
                 }
             }
+            }
         }
+        if (kSplit && rho < 4) __syncthreads();             // (the Y step's stores; and this round's readers are done with X, which round rho + 1 overwrites)
 #if FUSED_MERGE_Y
         if (rho < 4) __syncthreads();   // (the last round's readers meet the next transform's first barrier)
 #endif
