@@ -206,7 +206,7 @@ def kernel_of_variant(variant, n_taps, waves_per_group=1):
     spells it -- the key that ties committed counters (profiles/pmc_traffic.json) to the kernel a run actually used."""
     w = variant & 255
     if (variant >> 13) & 3:                                  # two chips per lane (correlator_chip2.h)
-        return "epl2_kernel<" + {1: "4,9,14,19", 2: "5,11,17,23"}[(variant >> 13) & 3] + ">"
+        return "epl2_kernel<" + {1: "4,9,14,19", 2: "5,11,17,23", 3: "1,3,5,7,9,11,13,15"}[(variant >> 13) & 3] + ">"
     if w == 26 + 16 and not variant & (0xF00 | 4096):        # 15.x / 16.x samples per chip: both block lengths in one kernel
         return f"epl_kernel<0,{n_taps},26,15,{waves_per_group},0,0,16>"
     km = w - 26 if w > 26 else 0

@@ -512,7 +512,7 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
  * KM = 16 .. 25; 15 on the half-chip view) and with it + 256 * floor(KM / 2) when the outer taps' switch position is too
  * (three taps half a chip apart: both switch floor(KM / 2).x samples into the prompt tap's chip) or + 4096 when the taps sit
  * whole (half-)chips apart; 26 + 16 alone: two block lengths compiled in (every epoch 15.x or 16.x samples per chip:
- * 16.368 MHz); + 8192 * k: several chips per lane (8.2 - 12 samples per chip);
+ * 16.368 MHz); + 8192 * k: several chips per lane (k = 1, 2: two chips of 9.5 - 10 / 11.5 - 12 samples; k = 3: four of 3.75 - 4);
  * + 65536 when the plan runs on the half-chip view of its replicas (32-52 samples per chip: every chip twice).  The
  * results do not depend on it beyond the tolerance of the free arithmetic. */
 int sdr_epl_plan_variant(const sdr_epl_plan* p);

@@ -3,6 +3,8 @@
 //      <4, 9, 14, 19>             two chips of 9.5 .. 10 samples: a C/A code at the reference's shipped 10 MHz (config/receiver.ini:18-20)
 //      (<4, 9, 14, 19, 24, 29>, three of them, works and was measured: it spills at three waves per SIMD)
 //      <5, 11, 17, 23>            two chips of 11.5 .. 12 samples: 12 MHz
+//      <1, 3, 5, 7, 9, 11, 13, 15>  FOUR chips of 3.75 .. 4 samples: the reference's 4 MHz (BASELINE configs[0]; round 6) -- eight
+//                                 segments of two samples; the per-sample kernel spends 43 instructions per sample there
 // At these rates one chip is too short for a lane (the per-block work of correlator_chip.h would be paid every ~10
 // samples), and 8 consecutive samples per lane (correlator.h's boundary variant) cost ~30 issue slots per sample.  A lane
 // owns chips q .. q + CH - 1: P_last or P_last + 1 samples in which, for c = 0 .. CH - 1,
@@ -85,7 +87,7 @@ __host__ __device__ inline bool chipn_setup(int n, int64_t start_sample, int64_t
     S.base = -1;
     // (4 .. 64 samples per chip, far around anything the shapes cover: a step outside it -- a denormal passes the list's
     // "positive and finite" -- must not reach the fixed-point conversions below: undefined on the host, `make check-sanitize`)
-    if (!(code_step >= 1.0 / 64.0 && code_step <= 0.25) || n < 1) return false;
+    if (!(code_step >= 1.0 / 64.0 && code_step <= 0.3) || n < 1) return false;
     S.dphi = carrier_step(carrier_hz, fs);
     double inv[3];
     const double nd = (double)n;

@@ -83,7 +83,7 @@ int ensure_doubled_luts(sdr_engine* e, hipStream_t stream) {
 // Several chips per lane (correlator_chip2.h): one wave per item, three taps, ci8 ring; the item's setup comes from the plan.
 // Dynamic LDS: [8 zero words][lut: lut_words uint32].
 template <int... P>
-__global__ __launch_bounds__(kWaveThreads, SDR_EPL2_WAVES) void epl2_kernel(const void* __restrict__ ring, const void* __restrict__ ring_flipped,
+__global__ __launch_bounds__(kWaveThreads, (sizeof...(P) > 4 ? 2 : SDR_EPL2_WAVES)) void epl2_kernel(const void* __restrict__ ring, const void* __restrict__ ring_flipped,
                                                             int64_t capacity, const sdr_epl_item* __restrict__ items, int n_items,
                                                             const uint32_t* __restrict__ luts, int lut_words, int lut_stride,
                                                             const double* __restrict__ spacing, double fs, double* __restrict__ out,
@@ -792,15 +792,20 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
     // the same kernel was measured against the one-chip form: 5 % fewer instructions per sample, 60 % more per epoch, at the
     // register cap: 0.335 instead of 0.316 ms per 32 000 epochs; three chips per lane at 10 MHz -- <4, 9, 14, 19, 24, 29> --
     // spill 27 registers at three waves per SIMD: 0.44 instead of 0.57 of the roof.  Neither is instantiated.)
-    if (err == hipSuccess && e->iq_fmt == SDR_FMT_CI8 && n_taps == 3 && !doubled && !e->epl_no_chip2 && (wide & 255) == 8 &&
+    // ... and chips of 3.75 .. 4 samples (the reference's 4 MHz, BASELINE configs[0]): FOUR chips per lane, where the list
+    // would otherwise go per sample (round 6)
+    if (err == hipSuccess && e->iq_fmt == SDR_FMT_CI8 && n_taps == 3 && !doubled && !e->epl_no_chip2 && ((wide & 255) == 8 || (wide & 255) == 0) &&
         lut_words < kLongLutWords) {          // (long multi-period replicas keep the four-epochs-per-workgroup kernels)
         sdr_epl_item first = {};
         if (items) first = items[0];
         else err = hipMemcpy(&first, p->d_items, sizeof(first), hipMemcpyDeviceToHost);
         const double two_chips = err == hipSuccess ? std::floor(2.0 / first.code_step) : 0.0;   // samples in two chips (any positive step got here)
-        const int shape = two_chips == 19.0 ? 1 : (two_chips == 23.0 ? 2 : 0);
+        const double four_chips = err == hipSuccess ? std::floor(4.0 / first.code_step) : 0.0;
+        const bool half_apart = spacing[0] == -0.5 && spacing[1] == 0.0 && spacing[2] == 0.5;
+        const int shape = (wide & 255) == 8 ? (two_chips == 19.0 ? 1 : (two_chips == 23.0 ? 2 : 0)) : (four_chips == 15.0 && half_apart ? 3 : 0);
         if (shape) {
-            reserve_setups(shape == 1 ? sizeof(sdr::ChipNSetup<4, 9, 14, 19>) : sizeof(sdr::ChipNSetup<5, 11, 17, 23>));
+            reserve_setups(shape == 1 ? sizeof(sdr::ChipNSetup<4, 9, 14, 19>) : shape == 2 ? sizeof(sdr::ChipNSetup<5, 11, 17, 23>)
+                                                                                           : sizeof(sdr::ChipNSetup<1, 3, 5, 7, 9, 11, 13, 15>));
             int* d_missed = p->d_setups ? reinterpret_cast<int*>(p->d_setups + p->setup_bytes * (size_t)n_items) : nullptr;
             int missed = n_items;
             if (err == hipSuccess && !long_list) {
@@ -813,8 +818,11 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
                     const bool ok = shape == 1
                         ? sdr::chipn_setup<4, 9, 14, 19>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step,
                                                          spacing, fs, reinterpret_cast<sdr::ChipNSetup<4, 9, 14, 19>*>(host_setups.data())[i])
-                        : sdr::chipn_setup<5, 11, 17, 23>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step,
-                                                          spacing, fs, reinterpret_cast<sdr::ChipNSetup<5, 11, 17, 23>*>(host_setups.data())[i]);
+                        : shape == 2
+                        ? sdr::chipn_setup<5, 11, 17, 23>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step,
+                                                          spacing, fs, reinterpret_cast<sdr::ChipNSetup<5, 11, 17, 23>*>(host_setups.data())[i])
+                        : sdr::chipn_setup<1, 3, 5, 7, 9, 11, 13, 15>(it.n_samples, it.start_sample, e->iq_capacity, it.carrier_hz, it.rem_code, it.code_step,
+                                                                      spacing, fs, reinterpret_cast<sdr::ChipNSetup<1, 3, 5, 7, 9, 11, 13, 15>*>(host_setups.data())[i]);
                     missed += ok ? 0 : 1;
                 }
                 if (missed <= n_items / 64)      // (host_setups lives until the synchronisation that ends the plan's creation)
@@ -826,10 +834,14 @@ static int plan_create_impl(sdr_engine* e, const sdr_epl_item* items, const sdr_
                     hipLaunchKernelGGL((chipn_setup_kernel<4, 9, 14, 19>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items,
                                        n_items, p->d_spacing, fs, e->iq_capacity,
                                        reinterpret_cast<sdr::ChipNSetup<4, 9, 14, 19>*>(p->d_setups), d_missed);
-                else
+                else if (shape == 2)
                     hipLaunchKernelGGL((chipn_setup_kernel<5, 11, 17, 23>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items,
                                        n_items, p->d_spacing, fs, e->iq_capacity,
                                        reinterpret_cast<sdr::ChipNSetup<5, 11, 17, 23>*>(p->d_setups), d_missed);
+                else
+                    hipLaunchKernelGGL((chipn_setup_kernel<1, 3, 5, 7, 9, 11, 13, 15>), dim3(setup_grid), dim3(256), 0, e->stream, p->d_items,
+                                       n_items, p->d_spacing, fs, e->iq_capacity,
+                                       reinterpret_cast<sdr::ChipNSetup<1, 3, 5, 7, 9, 11, 13, 15>*>(p->d_setups), d_missed);
                 err = hipGetLastError();
               }
               if (err == hipSuccess) err = hipMemcpyAsync(&missed, d_missed, sizeof(int), hipMemcpyDeviceToHost, e->stream);
@@ -893,7 +905,8 @@ int sdr_epl_plan_run_range_on(sdr_engine* e, sdr_epl_plan* p, int64_t first, int
                                items, n, e->luts, p->lut_words, e->lut_stride, p->d_spacing, p->fs, out, typed);
         };
         if (shape == 1) launch2(epl2_kernel<4, 9, 14, 19>, reinterpret_cast<const sdr::ChipNSetup<4, 9, 14, 19>*>(setups));
-        else launch2(epl2_kernel<5, 11, 17, 23>, reinterpret_cast<const sdr::ChipNSetup<5, 11, 17, 23>*>(setups));
+        else if (shape == 2) launch2(epl2_kernel<5, 11, 17, 23>, reinterpret_cast<const sdr::ChipNSetup<5, 11, 17, 23>*>(setups));
+        else launch2(epl2_kernel<1, 3, 5, 7, 9, 11, 13, 15>, reinterpret_cast<const sdr::ChipNSetup<1, 3, 5, 7, 9, 11, 13, 15>*>(setups));
     } else {
         hipStream_t st = ctx->stream;
         ProfScope ps(e, "epl_kernel", st);

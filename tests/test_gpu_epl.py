@@ -561,10 +561,11 @@ def test_randomised_stress_of_the_straight_line_kernels(engine):
     assert checked == 640 and worst < 1e-9
 
 
-@pytest.mark.parametrize("fs,seg", [(10e6, 5), (12e6, 6), (9.8e6, 5)])
+@pytest.mark.parametrize("fs,seg", [(10e6, 5), (12e6, 6), (9.8e6, 5), (4e6, 2), (3.9e6, 2)])
 def test_two_chips_per_lane_variant(engine, fs, seg):
     """Chips of 9.5 .. 10 (11.5 .. 12) samples, taps half a chip apart -- a C/A code at the reference's shipped
-    10 MHz (config/receiver.ini:18-20), or at 12 MHz: a lane owns two whole chips of the prompt tap,
+    10 MHz (config/receiver.ini:18-20), or at 12 MHz: a lane owns two whole chips of the prompt tap (four of 3.75 .. 4 samples
+    at the reference's 4 MHz, BASELINE configs[0]),
     every tap switch at a compile-time position up to + 1 (correlator_chip2.h; the plan holds a host-made setup per item).  Random Doppler on
     code and carrier, odd and even numbers of whole chips, odd starts, short and two-period epochs, zero code phase;
     lists with a stray item the scheme does not cover (redone per sample inside the kernel) -- against the oracle, and
@@ -599,7 +600,8 @@ def test_two_chips_per_lane_variant(engine, fs, seg):
         items = make_items(slot, n, start, f, rem_carrier, rem_code, step)
         plan = engine.epl_plan(items, spacing, fs)
         try:
-            assert (plan.variant >> 13) & 3 == {5: 1, 6: 2}[seg], (group, plan.variant)   # <4,9,14,19> / <5,11,17,23>
+            # <4,9,14,19> / <5,11,17,23> / (4 MHz: four chips per lane) <1,3,5,7,9,11,13,15>
+            assert (plan.variant >> 13) & 3 == {5: 1, 6: 2, 2: 3}[seg], (group, plan.variant)
             plan.run()
             got = plan.fetch()
         finally:
