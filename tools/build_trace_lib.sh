@@ -10,8 +10,8 @@ for f in engine codes epl epl_straight pcps pcps_fused track track_dense schedul
   # as the Makefile builds them: 256 / 168 registers per lane and nothing may spill -- a trace of a spilling kernel is not a
   # trace of the shipped one
   { [ $f = track_dense ] || [ $f = pcps_fused ]; } && EXTRA="-mllvm -disable-machine-licm"
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $EXTRA -DSDR_TRACE_WG -DSDR_TRACE_TRACK -I../../include -c $f.hip -o /tmp/sdr_trace_build/$f.o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fvisibility=hidden $EXTRA -DSDR_TRACE_WG -DSDR_TRACE_TRACK -I../../include -c $f.hip -o /tmp/sdr_trace_build/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 /tmp/sdr_trace_build/*.o -o ../../tools/libsydr_trace.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -Wl,--version-script=exports.map /tmp/sdr_trace_build/*.o -o ../../tools/libsydr_trace.so
 echo built tools/libsydr_trace.so

@@ -19,3 +19,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pcps_one_stream_50
 find "$OUT/pcps_one_stream_50" -name "*kernel_trace.csv" -size +8M -delete
 tail -1 "$OUT/pcps_one_stream_50.log"
 tail -c 400 "$OUT/bench_plain_run.json"
+# ... and the closed-loop kernels' counters (tools/pmc_track.sh: track_kernel dense 768 / 256 channels, cluster 32 x 8)
+bash "$ROOT/tools/pmc_track.sh" "$TAG" > "$OUT/pmc_track.log" 2>&1
+# ... and the fused PCPS kernel's LDS side (bank conflicts / LDS busy: tools/lds_conflicts_fused.py is the model they pin)
+bash "$ROOT/tools/pmc_pcps_lds.sh" "$TAG" 25 > "$OUT/pmc_pcps_lds.log" 2>&1
+cp -r "$ROOT/gpurun_out/pmc_pcps_lds_$TAG" "$OUT/pmc_pcps_lds" 2>/dev/null
