@@ -36,6 +36,9 @@ constexpr int kChipMax = 26;                      // samples a lane's block may 
 constexpr double kChipMinCodeStep = 1.0 / 25.9;   // blocks of at most 26 samples
 constexpr double kChipMaxCodeStep = 1.0 / 15.5;   // (16.368 MHz is 16.0 samples per chip: Doppler must not decide the kernel; 31-32 MHz through the half-chip view)
 constexpr int kChipRawDwords = 13;                // 52 bytes: 26 samples
+// per WAVE, double2 slots of LDS behind the lanes' strips: the in-block rotations exp(-1j*k*dphi), k = 0..25, and (round 6, the
+// forms with run-time positions) what the biased conversion's offset puts into a running sum of k samples, k = 0..26
+constexpr int kChipRotSlots = 2 * kChipMax + 2;
 template <int NT>
 constexpr int chip_strip_slots() { return 2 * NT + 1; }   // double2 slots per lane (odd multiple of 16 B: conflict-free)
 
@@ -241,7 +244,7 @@ struct ChipBlock {
 };
 
 // Returns false when a lane met a configuration the uniform-position scheme does not cover: the caller redoes the
-// epoch with correlate_epoch().  strip: this wave-group's [stride][chip_strip_slots<NT>()] double2; rot: 26 double2
+// epoch with correlate_epoch().  strip: this wave-group's [stride][chip_strip_slots<NT>()] double2; rot: kChipRotSlots double2
 // private to the WAVE.
 //
 // Block boundaries come from a fixed-point line (Q32.32 samples): with T = 1/step samples per chip and
@@ -328,9 +331,27 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
 #pragma unroll
                 for (int i = 0; i < 3; ++i) biasc[i] = R->biasc[i], biass[i] = R->biass[i];
             }
-        } else if (wlane < kChipMax) {
-            sincos_reduced(-(double)wlane * dphi_u, &sn, &cs);
-            rot[wlane] = make_double2(cs, sn);
+        } else {
+            if (wlane < kChipMax) {
+                sincos_reduced(-(double)wlane * dphi_u, &sn, &cs);
+                rot[wlane] = make_double2(cs, sn);
+            }
+            if constexpr (SDR_BIASED_CVT) {
+                // Round 6: the ring holds sign-flipped bytes, so these forms take the one-instruction conversion too (a
+                // sample arrives as 4224 + x: two v_perm_b32 instead of an exclusive or, two bit-field extracts and two
+                // converts per sample).  A running sum P_k then carries 4224 (1 + 1j) sum_{i<k} r_i: btab[k], an inclusive
+                // scan of the lanes' rotations, taken out where a parked sum is read.
+                double br = (cs - sn) * kCvtBias, bi = (cs + sn) * kCvtBias;       // (lanes >= 26 hold zeros)
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) {
+                    const double o_r = __shfl_up(br, off, 64), o_i = __shfl_up(bi, off, 64);
+                    br = wlane >= off ? br + o_r : br;
+                    bi = wlane >= off ? bi + o_i : bi;
+                }
+                double2* const btab = rot + kChipMax;
+                if (wlane < kChipMax) btab[wlane + 1] = make_double2(br, bi);
+                if (wlane == 0) btab[0] = make_double2(0.0, 0.0);
+            }
         }
     }
 
@@ -479,15 +500,31 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                 ++wp;
                 asm volatile("" ::: "memory");
             };
+            uint32_t hi_rt = 0x40B00000u;                 // (run-time-position forms: the biased conversion's high-word constant)
+            // ... and its four byte selectors as scalar registers for the whole block: left as literals each costs the scalar
+            // pipe a move in front of EVERY v_perm_b32 (two per sample: measured, + 41 % scalar instructions in the dense
+            // closed-loop kernel and no gain from 6 % fewer vector ones)
+            uint32_t sel_rt[4] = {cvt_selector(0), cvt_selector(1), cvt_selector(2), cvt_selector(3)};
+            if constexpr (!kStatic && SDR_BIASED_CVT) {
+                asm volatile("" : "+v"(hi_rt));
+                asm volatile("" : "+s"(sel_rt[0]), "+s"(sel_rt[1]), "+s"(sel_rt[2]), "+s"(sel_rt[3]));
+            }
             auto sample = [&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                const int w = ci8_native((int)b.raw[k >> 1]);
-                const double ar = (k & 1) ? (double)(int)(int8_t)(w >> 16) : (double)(int)(int8_t)w;
-                const double ai = (k & 1) ? (double)(w >> 24) : (double)(int)(int8_t)(w >> 8);
+                double ar, ai;
+                if constexpr (SDR_BIASED_CVT) {
+                    ar = biased_sample(zI, b.raw[k >> 1], sel_rt[(k & 1) ? 2 : 0], hi_rt);
+                    ai = biased_sample(zQ, b.raw[k >> 1], sel_rt[(k & 1) ? 3 : 1], hi_rt);
+                } else {
+                    const int w = ci8_native((int)b.raw[k >> 1]);
+                    ar = (k & 1) ? (double)(int)(int8_t)(w >> 16) : (double)(int)(int8_t)w;
+                    ai = (k & 1) ? (double)(w >> 24) : (double)(int)(int8_t)(w >> 8);
+                }
                 if (k + kAhead < kChipMax) rr[k + kAhead] = rot[k + kAhead];
                 const double2 r = rr[k];
                 pr = __builtin_fma(-ai, r.y, __builtin_fma(ar, r.x, pr));
                 pi = __builtin_fma(ai, r.x, __builtin_fma(ar, r.y, pi));
+                if constexpr (SDR_BIASED_CVT) asm volatile("" : "+v"(pr), "+v"(pi), "+v"(zI), "+v"(zQ));   // (see the straight-line loop below)
             };
             double capr[3] = {0.0, 0.0, 0.0}, capi[3] = {0.0, 0.0, 0.0};   // KS: P_KS, second half before its last sample, second half
             if constexpr (kStatic) {
@@ -548,13 +585,20 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                         if (k == klast) break;
                     }
                     if (k < kChipMax) {
-                        const int w = ci8_native((int)b.raw[k >> 1]);
-                        const double ar = (k & 1) ? (double)(int)(int8_t)(w >> 16) : (double)(int)(int8_t)w;
-                        const double ai = (k & 1) ? (double)(w >> 24) : (double)(int)(int8_t)(w >> 8);
+                        double ar, ai;
+                        if constexpr (SDR_BIASED_CVT) {
+                            ar = biased_sample(zI, b.raw[k >> 1], sel_rt[(k & 1) ? 2 : 0], hi_rt);
+                            ai = biased_sample(zQ, b.raw[k >> 1], sel_rt[(k & 1) ? 3 : 1], hi_rt);
+                        } else {
+                            const int w = ci8_native((int)b.raw[k >> 1]);
+                            ar = (k & 1) ? (double)(int)(int8_t)(w >> 16) : (double)(int)(int8_t)w;
+                            ai = (k & 1) ? (double)(w >> 24) : (double)(int)(int8_t)(w >> 8);
+                        }
                         if (k + kAhead < kChipMax) rr[k + kAhead] = rot[k + kAhead];
                         const double2 r = rr[k];
                         pr = __builtin_fma(-ai, r.y, __builtin_fma(ar, r.x, pr));
                         pi = __builtin_fma(ai, r.x, __builtin_fma(ar, r.y, pi));
+                        if constexpr (SDR_BIASED_CVT) asm volatile("" : "+v"(pr), "+v"(pi), "+v"(zI), "+v"(zQ));
                     }
                 }
             }
@@ -574,6 +618,10 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                 ptot.y = __builtin_fma(qi, urc[kHalf], __builtin_fma(qr, urs[kHalf], capi[2]));
             } else {
                 ptot = strip[rank[A] + b.dn];
+                if constexpr (SDR_BIASED_CVT) {             // (P_M or P_(M+1): the offset's share of that many samples out)
+                    const double2 bb = (rot + kChipMax)[M + b.dn];
+                    ptot.x -= bb.x, ptot.y -= bb.y;
+                }
             }
             const int first = round * stride;           // (a lane beyond the last whole chip re-does the last one)
             const uint32_t* lq;                         // replica entry of the block's anchor chip
@@ -604,8 +652,13 @@ __device__ __forceinline__ bool correlate_epoch_chip(const void* __restrict__ ri
                     double2 ps;
                     if constexpr (kStatic)
                         ps = b.ds[NT == 3 ? 0 : t] ? make_double2(capr[2], capi[2]) : make_double2(capr[0], capi[0]);
-                    else
+                    else {
                         ps = strip[rank[t] + b.ds[t]];
+                        if constexpr (SDR_BIASED_CVT) {
+                            const double2 bb = (rot + kChipMax)[m[t] + b.ds[t]];
+                            ps.x -= bb.x, ps.y -= bb.y;
+                        }
+                    }
                     const int jt = kStatic ? (t < A ? -1 : 0) : J[t];      // (KS: checked when the epoch was set up)
                     const double ca = __hiloint2double((int)lq[jt], 0);
                     const double cbn = __hiloint2double((int)lq[jt + 1], 0);

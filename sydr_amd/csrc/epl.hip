@@ -125,7 +125,7 @@ void launch_one(sdr_engine* e, hipStream_t stream, const sdr_epl_item* d_items, 
     // long replicas: four waves (four epochs of one channel) per workgroup around one staged table
     const int wpw = (lut_words >= kLongLutWords && group_stride > 0) ? 4 : 1;
     const int threads = kWaveThreads * wpw;
-    const size_t scratch = wide >= kChipMax ? (size_t)threads * chip_strip_slots<NT>() + wpw * kChipMax
+    const size_t scratch = wide >= kChipMax ? (size_t)threads * chip_strip_slots<NT>() + wpw * kChipRotSlots
                                             : (wide ? (size_t)threads * kPrefixSlots : 0);
     size_t shmem = (size_t)(wpw * 2 * NT) * sizeof(double) + (size_t)((lut_words + 3) & ~3) * sizeof(uint32_t) +
                    scratch * sizeof(double2);

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (
     extern __shared__ double smem[];
     double* red = smem;
     double2* prefix = reinterpret_cast<double2*>(red + WPW * 2 * NT);          // boundary variants: kThreads*9 slots; chip variant: strips + rotations
-    constexpr int kScratchSlots = W == kChipMax ? kThreads * chip_strip_slots<NT>() + WPW * kChipMax : (W ? kThreads * kPrefixSlots : 0);
+    constexpr int kScratchSlots = W == kChipMax ? kThreads * chip_strip_slots<NT>() + WPW * kChipRotSlots : (W ? kThreads * kPrefixSlots : 0);
     uint32_t* lut = reinterpret_cast<uint32_t*>(prefix + kScratchSlots);
 
     const int tid = threadIdx.x;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (
         if constexpr (KM2 != 0) {
             static_assert(KS == 0 && KI == 0 && !kPre, "two block lengths: tap positions at run time, no plan setups");
             const int M = __builtin_amdgcn_readfirstlane((int)(G.Tfx >> 32));
-            double2* const rot = prefix + kThreads * chip_strip_slots<NT>() + wave * kChipMax;
+            double2* const rot = prefix + kThreads * chip_strip_slots<NT>() + wave * kChipRotSlots;
             if (base >= 0 && M == KM)
                 done = correlate_epoch_chip<NT, true, KM, 0, 0>(ring, ring_flipped, capacity, ep, dphi, K, G, base, rot_plan, lut, prefix, rot,
                                                                  tid, lane, kWaveThreads, lane, accr, acci);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kWaveThreads * WPW, (KS != 0 ? SDR_EPL_KS_WAVES : (
         } else {
             done = base >= 0 &&
                    correlate_epoch_chip<NT, true, KM, KS, KI>(ring, ring_flipped, capacity, ep, dphi, K, G, base, rot_plan, lut, prefix,
-                                                              prefix + kThreads * chip_strip_slots<NT>() + wave * kChipMax,
+                                                              prefix + kThreads * chip_strip_slots<NT>() + wave * kChipRotSlots,
                                                               tid, lane, kWaveThreads, lane, accr, acci);
         }
         if (!done) {

@@ -1045,7 +1045,11 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
         // nearly idle).  The dispatcher fills the 256 compute units once before it gives any a second workgroup, so the
         // launch's thirds ARE the slots: the second and third start a third / two thirds of an epoch later and their
         // role phases fall into the others' correlation.
-        const int slot_on_cu = ((int)blockIdx.x / 256) % 3;
+#ifndef SDR_DENSE_STAGGER_MODE
+#define SDR_DENSE_STAGGER_MODE 0
+#endif
+        // (mode 1: the dispatcher packs a compute unit before it moves on -- an XCD's workgroups 3 j, 3 j + 1, 3 j + 2 share one)
+        const int slot_on_cu = SDR_DENSE_STAGGER_MODE == 0 ? ((int)blockIdx.x / 256) % 3 : ((int)blockIdx.x / 8) % 3;
         for (int k = 0; k < slot_on_cu * SDR_DENSE_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);      // (8128 cycles = 3.4 us each)
     }
     for (int epoch = 0; epoch < n_epochs; ++epoch) {
@@ -1206,13 +1210,13 @@ __global__ __launch_bounds__(THREADS, WAVES) void track_kernel(const void* __res
             bool chip_done = false;
 #ifndef SDR_TRACK_NO_CHIP
             if constexpr (FMT == SDR_FMT_CI8 && kTaps == 3 && !kCluster && THREADS == 256) {
-                static_assert(THREADS * chip_strip_slots<3>() + (THREADS / 64) * kChipMax <= THREADS * kPrefixSlots, "strips + rotations fit the prefix area");
+                static_assert(THREADS * chip_strip_slots<3>() + (THREADS / 64) * kChipRotSlots <= THREADS * kPrefixSlots, "strips + rotations fit the prefix area");
                 if (try_chip) {
                     ChipGeom<3> G;
                     chip_geometry<3, 24, 0, 0>(ep.n, K.shift, K.step, K.inv_step, G);
                     if (!__builtin_amdgcn_readfirstlane(G.bad))
                         chip_done = correlate_epoch_chip<3, false, 24, 0, 0>(ring, nullptr, capacity, ep, dphi, K, G, ring_pos, nullptr, lut, prefix,
-                                                                             prefix + THREADS * chip_strip_slots<3>() + (tid >> 6) * kChipMax,
+                                                                             prefix + THREADS * chip_strip_slots<3>() + (tid >> 6) * kChipRotSlots,
                                                                              tid, lane_global, cluster_lanes, edge_lane, accr, acci);
                 }
             }
