@@ -174,6 +174,25 @@ __device__ unsigned long long g_fused_stamps[256][8];
 #define FUSED_DFLT(x) = x
 #endif
 
+// FUSED_PREFETCH_UNIT (N = 25 000, whole transforms; round 6): the first three of item 0's five operand groups of the NEXT
+// unit are requested during THIS unit's last two rounds -- into the registers the parked rounds have left by then -- and
+// consumed by the next unit's column stage: 30 of a unit's 100 operand loads, and the ~2 k cycles until a fresh stream's
+// first load is back, move under the rounds, where the vector-memory path is idle.
+// OFF: built and measured (VERDICT r5 item 1's "operands of transform t + 1 loaded while t is in its row stages").  The
+// values cross the persistent loop's back edge, and the register allocator carries them through scratch memory there
+// (48 / 136 / 383 spilled registers for 1 / 2 / 3 groups, whatever is done to shorten their live ranges): same box, ms per
+// 32 x 41 search, 0.2034 without, 0.215 with one group, 0.220 with two.
+#ifndef FUSED_PREFETCH_UNIT
+#define FUSED_PREFETCH_UNIT 0    // groups requested a unit ahead (0: none; 1..3)
+#endif
+constexpr int kPfGroups = FUSED_PREFETCH_UNIT > 0 ? FUSED_PREFETCH_UNIT : 1;
+struct UnitPrefetch {
+    double2 x[kPfGroups][5], c[kPfGroups][5];    // item 0, groups m1 = 0 .. kPfGroups - 1 (points m1 + 5 m2), spectrum and code spectrum
+    bool have;                   // (uniform) x / c hold THIS unit's operands
+    bool next_whole;             // (uniform) the unit after this one is a whole transform: its groups are requested in round 3
+    int next_prn, next_bin;
+};
+
 // One unit of work (a whole transform, or one or two of its five rounds) by the 512 threads of the workgroup.
 // !WHOLE: `mode` = r0 | r1 << 4, the unit's rounds (r1 = 15: one round only); round r0 lives in the first LDS buffer, r1 in
 // the second -- nothing is parked in registers.
@@ -181,15 +200,18 @@ __device__ unsigned long long g_fused_stamps[256][8];
 // TwoCorrelationPeakComparison allows: [0, a1) U [b0, b1) (acquisition.py:98-111); flat index = the code phase;
 // no bound from the first sweep (the second peak lies below it).
 // TERMS = 2: the unit is one parity of a 50 000-point transform (header comment): `bin` = the real bin, `par` the parity.
-template <bool WHOLE, bool SECOND = false, int TERMS = 1>
+template <bool WHOLE, bool SECOND = false, int TERMS = 1, bool PF = false>
 __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int tid, const int prn, const int bin, const int mode,
                                          const int rec_slot, const int a1 FUSED_DFLT(0), const int b0 FUSED_DFLT(0), const int b1 FUSED_DFLT(0),
-                                         const int par FUSED_DFLT(0)
+                                         const int par FUSED_DFLT(0), UnitPrefetch* const pf_ FUSED_DFLT(nullptr)
 #ifdef SDR_FUSED_STAMPS
                                          , unsigned long long& stamp_
 #endif
 ) {
     constexpr int NF = TERMS * N;                       // samples of the row the unit's outputs belong to
+    constexpr bool kPf = PF && FUSED_PREFETCH_UNIT > 0 && WHOLE && !SECOND && TERMS == 1;
+    UnitPrefetch dummy_pf_;                             // (!kPf: never touched)
+    UnitPrefetch* const pf = kPf ? pf_ : &dummy_pf_;     // (kPf: the kernel's own object -- never null, so that it lives in registers)
     const int r0 = mode & 15, r1 = mode >> 4;           // (!WHOLE)
     double2* const tab = lds4 + 2 * kBuf;
     // (TERMS = 2: the engine's table is exp(-2 pi i m / 50 000); the 25 000-point transform's own twiddles are its even entries)
@@ -261,6 +283,9 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
     const Operand xs_u = make_operand(a.spec + (a.spec_off ? (size_t)a.spec_off[bin] : (size_t)bin * NF));
     const Operand cs_u = make_operand(a.code_spec + ((size_t)prn * TERMS + par) * NF);
     const unsigned toff = (unsigned)cb * 16u;
+    long long next_spec = 0;                                // (kPf) where the NEXT unit's spectrum starts: read now, used in round 3
+    if constexpr (kPf)
+        if (pf->next_whole && a.spec_off) next_spec = a.spec_off[pf->next_bin];
     // FUSED_EARLY_ITEM1 = 1 | 2 (N = 25 000, whole transforms): item 1's first one or two groups of operands are requested BEFORE
     // item 0's second radix-5 stage (~600 instructions per lane with nothing in flight for this wave, then the ~2 k cycles
     // until the first load of a fresh stream is back).  Measured, same box, ms per 32 x 41 search: off 0.2055, one group
@@ -280,7 +305,9 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
             double2 xa[5], ca[5];
 #pragma unroll
             for (int m2 = 0; m2 < 5; ++m2) {
-                if (kEarly && j == 1) {
+                if (kPf && j == 0) {
+                    xa[m2] = ca[m2] = make_double2(0.0, 0.0);       // (unused: item 0 reads the prefetched groups)
+                } else if (kEarly && j == 1) {
                     xa[m2] = xe[0][m2];
                     ca[m2] = ce[0][m2];
                 } else {
@@ -295,7 +322,46 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
                     eP[kBuf + 5 * N2 * g] = park[0][5 + g];
                 }
             }
-            if constexpr (TERMS == 1) {
+            if (kPf && j == 0) {
+                // (FUSED_PREFETCH_UNIT) the first kPfGroups groups were requested by the unit before (or are requested now: the
+                // workgroup's first whole unit); the others a group ahead of their use, as in the plain loop
+                if (!pf->have) {
+#pragma unroll
+                    for (int g = 0; g < kPfGroups; ++g)
+#pragma unroll
+                        for (int m2 = 0; m2 < 5; ++m2) {
+                            pf->x[g][m2] = ldb(xs_u, toff, kRowBytes * 5 * (g + 5 * m2));
+                            pf->c[g][m2] = ldb(cs_u, toff, kRowBytes * 5 * (g + 5 * m2));
+                        }
+                }
+                double2 xn[5], cn[5];                        // the group after the one being multiplied
+#pragma unroll
+                for (int m1 = 0; m1 < 5; ++m1) {
+                    double2 xc[5], cc[5];
+#pragma unroll
+                    for (int m2 = 0; m2 < 5; ++m2) {
+                        xc[m2] = m1 < kPfGroups ? pf->x[m1][m2] : xn[m2];
+                        cc[m2] = m1 < kPfGroups ? pf->c[m1][m2] : cn[m2];
+                    }
+                    if (m1 + 1 < 5 && m1 + 1 >= kPfGroups) {
+#pragma unroll
+                        for (int m2 = 0; m2 < 5; ++m2) {
+                            xn[m2] = ldb(xs_u, toff, kRowBytes * 5 * (m1 + 1 + 5 * m2));
+                            cn[m2] = ldb(cs_u, toff, kRowBytes * 5 * (m1 + 1 + 5 * m2));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double2 t[5];
+#pragma unroll
+                    for (int m2 = 0; m2 < 5; ++m2) t[m2] = cmulf(xc[m2], cc[m2]);
+                    ibf5(t);
+                    v[m1] = t[0];
+#pragma unroll
+                    for (int kA = 1; kA < 5; ++kA)
+                        v[m1 + 5 * kA] = m1 ? cmul_conj(t[kA], make_double2(kW25X[m1 * kA], kW25Y[m1 * kA])) : t[kA];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (TERMS == 1) {
 #pragma unroll
                 for (int m1 = 0; m1 < 5; ++m1) {
                     double2 xb[5], cb_[5];
@@ -558,6 +624,30 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
         }
         __syncthreads();
         FUSED_STAMP(6);
+        if constexpr (kPf) {
+            // (FUSED_PREFETCH_UNIT) every parked round has moved into its buffer: 120 registers are free from here to the
+            // unit's end -- the next whole unit's first three operand groups go into them
+            if (rho == 3 && pf->next_whole) {                  // (uniform: a per-lane condition would keep the old values alive in the lanes it leaves out; the twelve spare lanes read column 0)
+                const Operand nxs = make_operand(a.spec + (a.spec_off ? (size_t)next_spec : (size_t)pf->next_bin * NF));
+                const Operand ncs = make_operand(a.code_spec + (size_t)pf->next_prn * NF);
+#pragma unroll
+                for (int g = 0; g < kPfGroups; ++g)
+#pragma unroll
+                    for (int m2 = 0; m2 < 5; ++m2) {
+                        pf->x[g][m2] = ldb(nxs, toff, kRowBytes * 5 * (g + 5 * m2));
+                        pf->c[g][m2] = ldb(ncs, toff, kRowBytes * 5 * (g + 5 * m2));
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (rho == 3) {
+                // (no next whole unit: the registers are "defined" all the same -- an empty statement -- so that on no path
+                // this unit's consumed operands count as alive from the column stage to the next unit)
+#pragma unroll
+                for (int g = 0; g < kPfGroups; ++g)
+#pragma unroll
+                    for (int m2 = 0; m2 < 5; ++m2)
+                        asm volatile("" : "=v"(pf->x[g][m2].x), "=v"(pf->x[g][m2].y), "=v"(pf->c[g][m2].x), "=v"(pf->c[g][m2].y));
+            }
+        }
         // ---- rows, second stage: 20 = 2 x 10, radix-2 decimation in frequency while reading; and the next round's Y
         // in place in the other buffer (its stores overlap this stage's arithmetic)
         double2 u[10];
@@ -673,6 +763,8 @@ __device__ __forceinline__ void one_unit(const Args& a, double2* lds4, const int
 #endif
         FUSED_STAMP(7);
     }
+    if constexpr (kPf)
+        pf->have = pf->next_whole;                              // (what was requested in round 3 is the next unit's)
     int best_i = 0x7fffffff;
     double best_v = -1.0;
     if (role2 >= 0 && best_k >= 0) {
@@ -693,18 +785,21 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
     extern __shared__ double2 lds4[];
 #ifdef SDR_FUSED_STAMPS
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
-#define FUSED_STAMP_ARG , 0, 0, 0, par, stamp_
+#define FUSED_STAMP_ARG , 0, 0, 0, par, nullptr, stamp_
+#define FUSED_STAMP_ARG_PF , 0, 0, 0, par, &pf, stamp_
 #else
 #define FUSED_STAMP_ARG , 0, 0, 0, par
+#define FUSED_STAMP_ARG_PF , 0, 0, 0, par, &pf
 #endif
     const int tid = threadIdx.x;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     if (blockIdx.x == 0)
         for (int p = tid; p < a.n_prn; p += kThreads) a.theta_next[p] = 0ull;
     const int w_end = a.xcd_first[xcd + 1];
-    // (requesting the NEXT unit's list entry a unit ahead -- a scalar load by hand, so that nothing waits in vector registers --
-    // measured 0.2037 against 0.2023 ms per search at 25 MHz and 0.4463 against 0.4493 at 50 MHz, same box: the other waves
-    // cover those latencies already; not kept)
+    // (requesting the NEXT unit's list entry a unit ahead by itself measured 0.2037 against 0.2023 ms per search at 25 MHz: the
+    // other waves cover those latencies; it is read ahead here because FUSED_PREFETCH_UNIT needs to know the next unit)
+    UnitPrefetch pf;
+    pf.have = false;
     for (int w = a.xcd_first[xcd] + slot; w < w_end; w += kSlotsPerXcd) {
         // (wave-uniform: scalar base addresses in the unit)
         const int prn = __builtin_amdgcn_readfirstlane(a.work[w].prn);
@@ -712,8 +807,26 @@ __global__ __launch_bounds__(kThreads) void ifft_max_kernel(const Args a) {
         if (TERMS == 2 && bin >= a.nbins) bin -= a.nbins, par = 1;            // (virtual bin = parity * nbins + bin)
         const int mode = __builtin_amdgcn_readfirstlane(a.work[w].round);     // -1: the whole transform; else its rounds r0 | r1 << 4
         const int rec_slot = __builtin_amdgcn_readfirstlane(a.work[w].record);
-        if (mode < 0) one_unit<true, false, TERMS>(a, lds4, tid, prn, bin, mode, rec_slot FUSED_STAMP_ARG);
-        else one_unit<false, false, TERMS>(a, lds4, tid, prn, bin, mode, rec_slot FUSED_STAMP_ARG);
+        pf.next_whole = false;
+        pf.next_prn = pf.next_bin = 0;
+        if (FUSED_PREFETCH_UNIT > 0 && TERMS == 1 && w + kSlotsPerXcd < w_end) {
+            pf.next_whole = __builtin_amdgcn_readfirstlane(a.work[w + kSlotsPerXcd].round) < 0;
+            pf.next_prn = __builtin_amdgcn_readfirstlane(a.work[w + kSlotsPerXcd].prn);
+            pf.next_bin = __builtin_amdgcn_readfirstlane(a.work[w + kSlotsPerXcd].bin);
+        }
+        if (mode < 0) {
+            one_unit<true, false, TERMS, true>(a, lds4, tid, prn, bin, mode, rec_slot FUSED_STAMP_ARG_PF);
+        } else {
+            // (nothing requested ahead lives across a short unit: "defined" here by an empty statement, so that the register
+            // allocator does not carry thirty operands through this body)
+#pragma unroll
+            for (int g = 0; g < kPfGroups; ++g)
+#pragma unroll
+                for (int m2 = 0; m2 < 5; ++m2)
+                    asm volatile("" : "=v"(pf.x[g][m2].x), "=v"(pf.x[g][m2].y), "=v"(pf.c[g][m2].x), "=v"(pf.c[g][m2].y));
+            one_unit<false, false, TERMS>(a, lds4, tid, prn, bin, mode, rec_slot FUSED_STAMP_ARG);
+            pf.have = false;
+        }
     }
 }
 
@@ -802,7 +915,7 @@ __global__ __launch_bounds__(kThreads) void ifft_second_kernel(const SecondArgs 
     __syncthreads();                     // (the record scratch is the first buffer)
 #ifdef SDR_FUSED_STAMPS
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
-    one_unit<false, true, TERMS>(s.a, lds4, tid, prn, bin, rounds, prn * kUnits + unit, a1, b0, b1, par, stamp_);
+    one_unit<false, true, TERMS>(s.a, lds4, tid, prn, bin, rounds, prn * kUnits + unit, a1, b0, b1, par, nullptr, stamp_);
 #else
     one_unit<false, true, TERMS>(s.a, lds4, tid, prn, bin, rounds, prn * kUnits + unit, a1, b0, b1, par);
 #endif
