@@ -1,4 +1,5 @@
-"""Where a segment-by-segment E/P/L pass (bench.py's headline since round 6) loses time against one resident plan: range launches of\none plan, resident segment plans, create + run + destroy in turn, creation alone.   python tools/epl_segments.py"""
+"""Where a segment-by-segment E/P/L pass (bench.py's headline since round 6) loses time against one resident plan: range launches of
+one plan, resident segment plans, create + run + destroy in turn, creation alone.   python tools/epl_segments.py"""
 import sys, os, time, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
